@@ -1,0 +1,226 @@
+"""Host-side view of the command packet (include/edge264_cmd.h) as numpy dtypes.
+
+The packet is the drop-in boundary between the edge264 C front end and the
+MI355X back end: one packet per coded frame, carrying what the reference's
+leaf functions read (reference citations in include/edge264_cmd.h).  This
+module only builds / parses bytes; it performs no reconstruction.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+E264_MAGIC = 0x34363245
+E264_VERSION = 1
+MAX_SLOTS = 32
+
+MB_ABSENT, MB_I4x4, MB_I8x8, MB_I16x16, MB_PCM, MB_INTER = range(6)
+MBF_T8x8, MBF_EDGE_LEFT, MBF_EDGE_TOP, MBF_DEBLOCK = 1, 2, 4, 8
+CODED_LUMA_DC = 1 << 24
+CODED_CHROMA_DC = 1 << 25
+
+# zig-zag 4x4 block index -> pixel offset inside the macroblock
+# (reference: src/edge264_internal.h:550-553 x444/y444)
+BX = np.array([0, 4, 0, 4, 8, 12, 8, 12, 0, 4, 0, 4, 8, 12, 8, 12])
+BY = np.array([0, 0, 4, 4, 0, 0, 4, 4, 8, 8, 12, 12, 8, 8, 12, 12])
+
+
+def blk_index(bx: int, by: int) -> int:
+    """4x4 block coordinates (0..3) -> zig-zag index."""
+    return (by >> 1) * 8 + (bx >> 1) * 4 + (by & 1) * 2 + (bx & 1)
+
+
+FRAME_HDR = np.dtype([
+    ("magic", "<u4"), ("version", "<u4"), ("total_bytes", "<u4"),
+    ("width_mbs", "<u2"), ("height_mbs", "<u2"),
+    ("stride_Y", "<u4"), ("stride_C", "<u4"), ("plane_size_Y", "<u4"), ("plane_size_C", "<u4"),
+    ("n_slices", "<u4"), ("slices_off", "<u4"), ("mbs_off", "<u4"), ("payload_off", "<u4"),
+    ("payload_bytes", "<u4"), ("dst_slot", "<i4"), ("ref_slots", "<u4"), ("frame_id", "<i4"),
+    ("n_coded_mbs", "<u4"), ("n_inter_mbs", "<u4"), ("reserved", "<u4", (2,)),
+])
+assert FRAME_HDR.itemsize == 80
+
+SLICE_PARAMS = np.dtype([
+    ("slice_type", "i1"), ("weighted_bipred_idc", "i1"),
+    ("luma_log2_weight_denom", "i1"), ("chroma_log2_weight_denom", "i1"),
+    ("FilterOffsetA", "i1"), ("FilterOffsetB", "i1"),
+    ("disable_deblocking_filter_idc", "i1"), ("cabac", "i1"),
+    ("first_mb", "<u4"), ("reserved", "<u4"),
+    ("weightScale4x4", "u1", (6, 16)), ("weightScale8x8", "u1", (6, 64)),
+    ("explicit_weights", "<i2", (3, 64)), ("explicit_offsets", "i1", (3, 64)),
+    ("implicit_weights", "u1", (32, 32)), ("pad", "u1", (16,)),
+])
+assert SLICE_PARAMS.itemsize == 2112
+
+MB = np.dtype([
+    ("kind", "u1"), ("flags", "u1"), ("qp", "u1", (3,)), ("chroma_mode", "u1"), ("i16_mode", "u1"),
+    ("reserved0", "u1"), ("nz_mask", "<u2"), ("slice", "<u2"), ("coded", "<u4"), ("payload_off", "<u4"),
+    ("modes", "u1", (8,)), ("reserved1", "<u4"),
+])
+assert MB.itemsize == 32
+
+MOTION = np.dtype([("refPic", "i1", (8,)), ("refIdx", "i1", (8,)), ("mvs", "<i2", (64,))])
+assert MOTION.itemsize == 144
+
+
+def align16(x: int) -> int:
+    return (x + 15) & ~15
+
+
+def frame_geometry(width_mbs: int, height_mbs: int):
+    """Strides / plane sizes exactly as the reference lays frames out
+    (src/edge264_headers.c:2032-2046): chroma rows hold Cb then Cr."""
+    stride_Y = width_mbs * 16
+    if stride_Y % 2048 == 0:
+        stride_Y += 16
+    stride_C = width_mbs * 16
+    if stride_C % 4096 == 0:
+        stride_C += 8
+    return dict(stride_Y=stride_Y, stride_C=stride_C,
+                plane_size_Y=stride_Y * height_mbs * 16, plane_size_C=stride_C * height_mbs * 8)
+
+
+def frame_bytes(width_mbs: int, height_mbs: int) -> int:
+    g = frame_geometry(width_mbs, height_mbs)
+    return g["plane_size_Y"] + g["plane_size_C"]
+
+
+class PacketBuilder:
+    """Assembles one frame packet.  Mirrors what the C emitters of
+    edge264_amd/frontend do, so tests can fabricate packets without a bitstream."""
+
+    def __init__(self, width_mbs: int, height_mbs: int, dst_slot: int, frame_id: int = 0):
+        self.w, self.h = width_mbs, height_mbs
+        self.dst_slot, self.frame_id = dst_slot, frame_id
+        self.slices: list[np.ndarray] = []
+        self.mbs = np.zeros(width_mbs * height_mbs, dtype=MB)
+        self.payload = bytearray()
+        self.ref_slots = 0
+
+    def add_slice(self, **kw) -> int:
+        s = np.zeros((), dtype=SLICE_PARAMS)
+        s["weightScale4x4"] = 16
+        s["weightScale8x8"] = 16
+        s["implicit_weights"] = 32 + 64
+        s["slice_type"] = 2
+        for k, v in kw.items():
+            s[k] = v
+        self.slices.append(s)
+        return len(self.slices) - 1
+
+    def set_mb(self, addr: int, *, kind: int, slice_idx: int, qp, flags: int = 0, chroma_mode: int = 0,
+               i16_mode: int = 0, nz_mask: int = 0, modes=None, motion=None, pcm=None,
+               luma_dc=None, chroma_dc=None, luma_blocks=None, chroma_blocks=None) -> None:
+        m = self.mbs[addr]
+        m["kind"], m["flags"], m["qp"], m["slice"] = kind, flags, qp, slice_idx
+        m["chroma_mode"], m["i16_mode"], m["nz_mask"] = chroma_mode, i16_mode, nz_mask
+        if modes is not None:
+            mm = np.zeros(8, np.uint8)
+            if kind == MB_I4x4:
+                for k, v in enumerate(modes):
+                    mm[k >> 1] |= (int(v) & 15) << (4 * (k & 1))
+            else:
+                mm[:4] = modes
+            m["modes"] = mm
+        while len(self.payload) % 8:
+            self.payload.append(0)
+        m["payload_off"] = len(self.payload)
+        coded = 0
+        if kind == MB_INTER:
+            mo = np.zeros((), MOTION)
+            mo["refPic"], mo["refIdx"], mo["mvs"] = motion["refPic"], motion["refIdx"], np.asarray(motion["mvs"]).reshape(64)
+            self.payload += mo.tobytes()
+            for r in np.asarray(motion["refPic"]).reshape(8):
+                if r >= 0:
+                    self.ref_slots |= 1 << int(r)
+        if kind == MB_PCM:
+            assert len(pcm) == 384
+            self.payload += bytes(pcm)
+        if luma_dc is not None:
+            coded |= CODED_LUMA_DC
+            self.payload += np.asarray(luma_dc, "<i2").reshape(16).tobytes()
+        if chroma_dc is not None:
+            coded |= CODED_CHROMA_DC
+            self.payload += np.asarray(chroma_dc, "<i2").reshape(8).tobytes()
+        for k in sorted(luma_blocks or {}):
+            n = 64 if flags & MBF_T8x8 else 16
+            assert not (flags & MBF_T8x8) or k % 4 == 0
+            coded |= 1 << k
+            self.payload += np.asarray(luma_blocks[k], "<i2").reshape(n).tobytes()
+        for k in sorted(chroma_blocks or {}):
+            coded |= 1 << (16 + k)
+            self.payload += np.asarray(chroma_blocks[k], "<i2").reshape(16).tobytes()
+        m["coded"] = coded
+
+    def finish(self) -> bytes:
+        g = frame_geometry(self.w, self.h)
+        hdr = np.zeros((), FRAME_HDR)
+        slices_off = align16(FRAME_HDR.itemsize)
+        mbs_off = align16(slices_off + SLICE_PARAMS.itemsize * len(self.slices))
+        payload_off = align16(mbs_off + MB.itemsize * len(self.mbs))
+        pay = bytes(self.payload) + bytes(-len(self.payload) % 16)
+        total = payload_off + len(pay)
+        hdr["magic"], hdr["version"], hdr["total_bytes"] = E264_MAGIC, E264_VERSION, total
+        hdr["width_mbs"], hdr["height_mbs"] = self.w, self.h
+        for k, v in g.items():
+            hdr[k] = v
+        hdr["n_slices"], hdr["slices_off"], hdr["mbs_off"] = len(self.slices), slices_off, mbs_off
+        hdr["payload_off"], hdr["payload_bytes"] = payload_off, len(pay)
+        hdr["dst_slot"], hdr["ref_slots"], hdr["frame_id"] = self.dst_slot, self.ref_slots, self.frame_id
+        hdr["n_coded_mbs"] = int((self.mbs["kind"] != MB_ABSENT).sum())
+        hdr["n_inter_mbs"] = int((self.mbs["kind"] == MB_INTER).sum())
+        out = bytearray(total)
+        out[:FRAME_HDR.itemsize] = hdr.tobytes()
+        for i, s in enumerate(self.slices):
+            o = slices_off + i * SLICE_PARAMS.itemsize
+            out[o:o + SLICE_PARAMS.itemsize] = s.tobytes()
+        out[mbs_off:mbs_off + self.mbs.nbytes] = self.mbs.tobytes()
+        out[payload_off:] = pay
+        return bytes(out)
+
+
+class Packet:
+    """Read-only parsed view of a packet."""
+
+    def __init__(self, data: bytes):
+        self.data = data
+        self.hdr = np.frombuffer(data, FRAME_HDR, 1)[0]
+        if self.hdr["magic"] != E264_MAGIC or self.hdr["version"] != E264_VERSION:
+            raise ValueError("not an edge264 command packet")
+        if self.hdr["total_bytes"] > len(data):
+            raise ValueError("truncated packet")
+        self.slices = np.frombuffer(data, SLICE_PARAMS, int(self.hdr["n_slices"]), int(self.hdr["slices_off"]))
+        n = int(self.hdr["width_mbs"]) * int(self.hdr["height_mbs"])
+        self.mbs = np.frombuffer(data, MB, n, int(self.hdr["mbs_off"]))
+        self.payload_off = int(self.hdr["payload_off"])
+
+    @property
+    def width_mbs(self) -> int:
+        return int(self.hdr["width_mbs"])
+
+    @property
+    def height_mbs(self) -> int:
+        return int(self.hdr["height_mbs"])
+
+    def frame_bytes(self) -> int:
+        return int(self.hdr["plane_size_Y"]) + int(self.hdr["plane_size_C"])
+
+    def algorithmic_bytes(self) -> int:
+        """F written once + F x prediction directions actually used
+        (averaged over macroblocks) + command bytes consumed."""
+        F = self.frame_bytes()
+        n = len(self.mbs)
+        dirs = 0
+        inter = np.nonzero(self.mbs["kind"] == MB_INTER)[0]
+        for a in inter:
+            mo = np.frombuffer(self.data, MOTION, 1, self.payload_off + int(self.mbs[a]["payload_off"]))[0]
+            rp = mo["refPic"].reshape(2, 4)
+            dirs += ((rp[0] >= 0).sum() + (rp[1] >= 0).sum()) / 4.0
+        return int(F + F * dirs / n + int(self.hdr["total_bytes"]))
+
+
+def split_planes(buf: np.ndarray, width_mbs: int, height_mbs: int):
+    """Frame buffer bytes -> (Y, Cb, Cr) 2-D views in the reference layout."""
+    g = frame_geometry(width_mbs, height_mbs)
+    Y = buf[:g["plane_size_Y"]].reshape(height_mbs * 16, g["stride_Y"])[:, :width_mbs * 16]
+    C = buf[g["plane_size_Y"]:g["plane_size_Y"] + g["plane_size_C"]].reshape(height_mbs * 8, g["stride_C"])
+    return Y, C[:, :width_mbs * 8], C[:, g["stride_C"] // 2:g["stride_C"] // 2 + width_mbs * 8]

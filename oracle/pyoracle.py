@@ -1,0 +1,193 @@
+"""ctypes bindings of the CHECKERS (test infrastructure, never the product):
+
+  Oracle       oracle/libe264_oracle.so        scalar restatement (oracle/e264_oracle.c)
+  RefKernels   oracle/_ref/libe264_refkernels.so  the reference's own static kernels
+  RefDecoder   oracle/_ref/libedge264_ref.so   the unmodified reference decoder (edge264.h API)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MAX_SLOTS = 32
+
+
+def build(quiet: bool = True) -> None:
+    """make -C oracle (compiles the restatement; the reference-derived libraries only
+    where /root/reference exists -- building the checker is not using it)."""
+    subprocess.run(["make", "-C", HERE, "all"], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+def _load(path: str):
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    return C.CDLL(path)
+
+
+def _dpb_array(dpb):
+    arr = (C.c_void_p * MAX_SLOTS)()
+    for i in range(MAX_SLOTS):
+        b = dpb[i] if i < len(dpb) else None
+        arr[i] = b.ctypes.data if b is not None else None
+    return arr
+
+
+class Oracle:
+    def __init__(self):
+        path = os.path.join(HERE, "libe264_oracle.so")
+        if not os.path.exists(path):
+            build()
+        self.lib = _load(path)
+        self.lib.e264_oracle_decode_frame.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_int]
+        self.lib.e264_oracle_decode_frame.restype = C.c_int
+        self.lib.e264_oracle_frame_bs.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
+        self.lib.e264_oracle_frame_bs.restype = C.c_int
+
+    def decode_frame(self, pkt: bytes, dpb: list, passes: int = 3) -> None:
+        """dpb: list of 32 uint8 numpy arrays (or None); the destination slot is written in place."""
+        r = self.lib.e264_oracle_decode_frame(pkt, len(pkt), _dpb_array(dpb), passes)
+        if r:
+            raise RuntimeError(f"oracle rejected packet ({r})")
+
+    def frame_bs(self, pkt: bytes, n_mbs: int) -> np.ndarray:
+        out = np.zeros((n_mbs, 2, 4, 4), np.uint8)
+        r = self.lib.e264_oracle_frame_bs(pkt, len(pkt), out.ctypes.data)
+        if r:
+            raise RuntimeError(f"oracle rejected packet ({r})")
+        return out
+
+
+class RefKernels:
+    """The reference's static kernels replaying a packet (oracle/ref_kernels_harness.c)."""
+
+    def __init__(self):
+        self.lib = _load(os.path.join(HERE, "_ref", "libe264_refkernels.so"))
+        L = self.lib
+        L.ref_new.argtypes = [C.c_int, C.c_int]
+        L.ref_new.restype = C.c_void_p
+        L.ref_free.argtypes = [C.c_void_p]
+        L.ref_replay_packet.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_int]
+        L.ref_replay_packet.restype = C.c_int
+        for n in ("ref_intra4x4", "ref_intra8x8", "ref_intra16x16", "ref_intra_chroma"):
+            getattr(L, n).argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+        L.ref_inter_luma.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.ref_inter_chroma.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p] + [C.c_int] * 4
+        self._h = {}
+
+    def replay(self, pkt: bytes, dpb: list, width_mbs: int, height_mbs: int, passes: int = 3) -> None:
+        key = (width_mbs, height_mbs)
+        if key not in self._h:
+            self._h[key] = self.lib.ref_new(width_mbs, height_mbs)
+        r = self.lib.ref_replay_packet(self._h[key], pkt, len(pkt), _dpb_array(dpb), passes)
+        if r:
+            raise RuntimeError(f"reference harness rejected packet ({r})")
+
+
+class Edge264Frame(C.Structure):
+    # edge264.h:45-62
+    _fields_ = [("samples", C.c_void_p * 3), ("samples_mvc", C.c_void_p * 3), ("mb_errors", C.c_void_p),
+                ("bit_depth_Y", C.c_int8), ("bit_depth_C", C.c_int8),
+                ("width_Y", C.c_int16), ("width_C", C.c_int16), ("height_Y", C.c_int16), ("height_C", C.c_int16),
+                ("stride_Y", C.c_int16), ("stride_C", C.c_int16), ("stride_mb", C.c_int16),
+                ("FrameId", C.c_int32), ("FrameId_mvc", C.c_int32), ("frame_crop_offsets", C.c_int16 * 4),
+                ("return_arg", C.c_void_p)]
+
+
+class Edge264Lib:
+    """Any shared object exporting the edge264.h surface (the unmodified reference, or
+    the reference front end bound to our back end).  Mirrors README.md:126-155 usage."""
+
+    def __init__(self, path: str):
+        self.lib = L = _load(path)
+        L.edge264_alloc.restype = C.c_void_p
+        L.edge264_alloc.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.edge264_free.argtypes = [C.POINTER(C.c_void_p)]
+        L.edge264_flush.argtypes = [C.c_void_p]
+        L.edge264_find_start_code.restype = C.c_void_p
+        L.edge264_find_start_code.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.edge264_decode_NAL.restype = C.c_int
+        L.edge264_decode_NAL.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.edge264_get_frame.restype = C.c_int
+        L.edge264_get_frame.argtypes = [C.c_void_p, C.POINTER(Edge264Frame), C.c_int]
+        L.edge264_return_frame.argtypes = [C.c_void_p, C.c_void_p]
+
+    def decode(self, stream: bytes, max_frames: int = 1 << 30, crop: bool = True):
+        """Decodes an Annex-B byte stream; returns (list of (Y,Cb,Cr) arrays, list of NAL return codes)."""
+        import errno
+        L = self.lib
+        buf = np.frombuffer(stream + b"\0" * 64, np.uint8).copy()
+        base = buf.ctypes.data
+        end = base + len(stream)
+        dec = C.c_void_p(L.edge264_alloc(0, None, None, 0, None, None, None))
+        if not dec:
+            raise MemoryError("edge264_alloc")
+        frames, codes = [], []
+        out = Edge264Frame()
+
+        def drain():
+            while len(frames) < max_frames and L.edge264_get_frame(dec, C.byref(out), 0) == 0:
+                frames.append(self._copy_frame(out))
+        nal = L.edge264_find_start_code(base, end, 0)
+        nal = (nal or end) + 3 if (nal or end) < end else end
+        while True:
+            nxt = L.edge264_find_start_code(nal, end, 0) if nal < end else end
+            res = L.edge264_decode_NAL(dec, nal, nxt, None, None)
+            codes.append(res)
+            if res == errno.ENOBUFS:
+                drain()
+                continue
+            drain()
+            if res == errno.ENODATA or nal >= end:
+                break
+            nal = min(nxt + 3, end)
+        drain()
+        L.edge264_free(C.byref(dec))
+        return frames, codes
+
+    @staticmethod
+    def _copy_frame(f: Edge264Frame):
+        def plane(ptr, w, h, stride):
+            a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), ((h - 1) * stride + w,))
+            return np.lib.stride_tricks.as_strided(a, (h, w), (stride, 1)).copy()
+        return (plane(f.samples[0], f.width_Y, f.height_Y, f.stride_Y),
+                plane(f.samples[1], f.width_C, f.height_C, f.stride_C),
+                plane(f.samples[2], f.width_C, f.height_C, f.stride_C))
+
+
+def ref_decoder() -> Edge264Lib:
+    return Edge264Lib(os.path.join(HERE, "_ref", "libedge264_ref.so"))
+
+
+def _u8p(a: np.ndarray, off: int = 0):
+    return C.c_void_p(a.ctypes.data + off)
+
+
+def oracle_intra(o: Oracle, kind: str, buf: np.ndarray, off: int, stride: int, mode: int) -> None:
+    """kind in {'4x4','8x8','16x16','chroma'}; predicts in place at buf[off] (one plane for chroma)."""
+    fn = {"4x4": o.lib.e264o_intra4x4, "8x8": o.lib.e264o_intra8x8, "16x16": o.lib.e264o_intra16x16,
+          "chroma": o.lib.e264o_intra_chroma}[kind]
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    fn(_u8p(buf, off), stride, mode)
+
+
+def oracle_luma_mc(o: Oracle, ref: np.ndarray, stride: int, w: int, h: int, x: int, y: int, mvx: int, mvy: int,
+                   bw: int, bh: int) -> np.ndarray:
+    o.lib.e264o_luma_mc.argtypes = [C.c_void_p] + [C.c_int] * 9 + [C.c_void_p, C.c_int]
+    dst = np.zeros((bh, bw), np.uint8)
+    o.lib.e264o_luma_mc(_u8p(ref), stride, w, h, x, y, mvx, mvy, bw, bh, _u8p(dst), bw)
+    return dst
+
+
+def oracle_chroma_mc(o: Oracle, ref: np.ndarray, stride: int, w: int, h: int, x: int, y: int, mvx: int, mvy: int,
+                     bw: int, bh: int) -> np.ndarray:
+    o.lib.e264o_chroma_mc.argtypes = [C.c_void_p] + [C.c_int] * 9 + [C.c_void_p, C.c_int]
+    dst = np.zeros((bh, bw), np.uint8)
+    o.lib.e264o_chroma_mc(_u8p(ref), stride, w, h, x, y, mvx, mvy, bw, bh, _u8p(dst), bw)
+    return dst
