@@ -1,0 +1,195 @@
+"""ctypes binding of the C-ABI back end (include/edge264_hip.h, libedge264_hip.so).
+
+This is plumbing around the product, not the product: the reconstruction itself is the
+hand-written gfx950 HIP code in edge264_amd/csrc.  There is NO CPU fallback here: if the
+shared library is missing or no MI355X is present, opening a device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import errno
+import os
+
+import numpy as np
+
+from . import packet as P
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libedge264_hip.so")
+RUN_RECON, RUN_DEBLOCK, RUN_ALL = 1, 2, 3
+
+_lib = None
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Loads libedge264_hip.so (in-tree, built by __graft_entry__.build()).  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BackendError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the HIP back end has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
+    sig = {
+        "e264hip_device_open": (i, [i, C.POINTER(vp)]),
+        "e264hip_device_close": (None, [vp]),
+        "e264hip_device_sync": (i, [vp]),
+        "e264hip_last_error": (C.c_char_p, []),
+        "e264hip_stream_open": (i, [vp, C.POINTER(vp)]),
+        "e264hip_stream_close": (None, [vp]),
+        "e264hip_stream_flush": (i, [vp]),
+        "e264hip_frame_alloc": (i, [vp, i, sz, C.POINTER(vp)]),
+        "e264hip_frame_free": (None, [vp, i]),
+        "e264hip_frame_fill": (i, [vp, i, i]),
+        "e264hip_frame_upload": (i, [vp, i, vp, sz]),
+        "e264hip_frame_submit": (i, [vp, vp, sz]),
+        "e264hip_packet_buffer": (vp, [vp, sz]),
+        "e264hip_frame_wait": (i, [vp, i]),
+        "e264hip_frame_download": (i, [vp, i, vp, sz]),
+        "e264hip_packet_upload": (i, [vp, vp, sz, C.POINTER(vp)]),
+        "e264hip_packet_free": (None, [vp]),
+        "e264hip_submit_batch": (i, [vp, C.POINTER(vp), C.POINTER(vp), i, i]),
+        "e264hip_event_record": (i, [vp, i]),
+        "e264hip_event_elapsed_ms": (i, [vp, i, i, C.POINTER(C.c_float)]),
+        "e264hip_kernel_timing": (i, [vp, i]),
+        "e264hip_kernel_time_ms": (i, [vp, C.POINTER(C.c_double), C.POINTER(i)]),
+        "e264hip_set_option": (i, [vp, C.c_char_p, i]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export the header's symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "e264hip_device_open", "e264hip_device_close", "e264hip_device_sync", "e264hip_last_error",
+    "e264hip_stream_open", "e264hip_stream_close", "e264hip_stream_flush", "e264hip_frame_alloc",
+    "e264hip_frame_free", "e264hip_frame_fill", "e264hip_frame_upload", "e264hip_frame_submit",
+    "e264hip_packet_buffer", "e264hip_frame_wait", "e264hip_frame_download", "e264hip_packet_upload",
+    "e264hip_packet_free", "e264hip_submit_batch", "e264hip_event_record", "e264hip_event_elapsed_ms",
+    "e264hip_kernel_timing", "e264hip_kernel_time_ms", "e264hip_set_option",
+]
+
+
+def _check(L, r: int, what: str) -> None:
+    if r:
+        msg = L.e264hip_last_error()
+        raise BackendError(f"{what}: {errno.errorcode.get(r, r)} ({(msg or b'').decode()})")
+
+
+class Device:
+    """One MI355X: queue + kernels (E264Device)."""
+
+    def __init__(self, ordinal: int = 0):
+        self.L = load_library()
+        h = C.c_void_p()
+        _check(self.L, self.L.e264hip_device_open(ordinal, C.byref(h)), "e264hip_device_open")
+        self.h = h
+        self.ordinal = ordinal
+
+    def close(self):
+        if self.h:
+            self.L.e264hip_device_close(self.h)
+            self.h = None
+
+    def sync(self):
+        _check(self.L, self.L.e264hip_device_sync(self.h), "device_sync")
+
+    def set_option(self, name: str, value: int) -> int:
+        return self.L.e264hip_set_option(self.h, name.encode(), value)
+
+    def upload_packet(self, pkt: bytes) -> "DevicePacket":
+        return DevicePacket(self, pkt)
+
+    def submit_batch(self, streams, packets, mode: int = RUN_ALL) -> None:
+        n = len(streams)
+        sa = (C.c_void_p * n)(*[s.h for s in streams])
+        pa = (C.c_void_p * n)(*[p.h for p in packets])
+        _check(self.L, self.L.e264hip_submit_batch(self.h, sa, pa, n, mode), "submit_batch")
+
+    def make_batch(self, streams, packets):
+        """Pre-marshalled argument arrays for repeated launches (bench inner loop)."""
+        n = len(streams)
+        return ((C.c_void_p * n)(*[s.h for s in streams]), (C.c_void_p * n)(*[p.h for p in packets]), n)
+
+    def submit_prepared(self, batch, mode: int = RUN_ALL) -> None:
+        _check(self.L, self.L.e264hip_submit_batch(self.h, batch[0], batch[1], batch[2], mode), "submit_batch")
+
+    def event_record(self, idx: int) -> None:
+        _check(self.L, self.L.e264hip_event_record(self.h, idx), "event_record")
+
+    def event_elapsed_ms(self, a: int, b: int) -> float:
+        ms = C.c_float()
+        _check(self.L, self.L.e264hip_event_elapsed_ms(self.h, a, b, C.byref(ms)), "event_elapsed")
+        return float(ms.value)
+
+    def kernel_timing(self, enable: bool) -> None:
+        _check(self.L, self.L.e264hip_kernel_timing(self.h, int(enable)), "kernel_timing")
+
+    def kernel_time_ms(self):
+        t, n = C.c_double(), C.c_int()
+        _check(self.L, self.L.e264hip_kernel_time_ms(self.h, C.byref(t), C.byref(n)), "kernel_time")
+        return float(t.value), int(n.value)
+
+
+class DevicePacket:
+    def __init__(self, dev: Device, pkt: bytes):
+        self.dev, self.nbytes = dev, len(pkt)
+        h = C.c_void_p()
+        buf = (C.c_char * len(pkt)).from_buffer_copy(pkt)
+        _check(dev.L, dev.L.e264hip_packet_upload(dev.h, C.cast(buf, C.c_void_p), len(pkt), C.byref(h)), "packet_upload")
+        self.h = h
+
+    def free(self):
+        if self.h:
+            self.dev.L.e264hip_packet_free(self.h)
+            self.h = None
+
+
+class Stream:
+    """Device side of one decoder (E264Stream): DPB slots in HBM."""
+
+    def __init__(self, dev: Device, width_mbs: int, height_mbs: int):
+        self.dev, self.L = dev, dev.L
+        self.w, self.h_mbs = width_mbs, height_mbs
+        self.frame_bytes = P.frame_bytes(width_mbs, height_mbs)
+        h = C.c_void_p()
+        _check(self.L, self.L.e264hip_stream_open(dev.h, C.byref(h)), "stream_open")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.e264hip_stream_close(self.h)
+            self.h = None
+
+    def alloc(self, slot: int, mirror: bool = False) -> None:
+        m = C.c_void_p()
+        _check(self.L, self.L.e264hip_frame_alloc(self.h, slot, self.frame_bytes, C.byref(m) if mirror else None), "frame_alloc")
+
+    def free(self, slot: int) -> None:
+        self.L.e264hip_frame_free(self.h, slot)
+
+    def fill(self, slot: int, value: int) -> None:
+        _check(self.L, self.L.e264hip_frame_fill(self.h, slot, value), "frame_fill")
+
+    def upload(self, slot: int, data: np.ndarray) -> None:
+        data = np.ascontiguousarray(data, np.uint8)
+        _check(self.L, self.L.e264hip_frame_upload(self.h, slot, data.ctypes.data, min(data.nbytes, self.frame_bytes)), "frame_upload")
+
+    def submit(self, pkt: bytes) -> None:
+        buf = (C.c_char * len(pkt)).from_buffer_copy(pkt)
+        _check(self.L, self.L.e264hip_frame_submit(self.h, C.cast(buf, C.c_void_p), len(pkt)), "frame_submit")
+
+    def download(self, slot: int) -> np.ndarray:
+        out = np.empty(self.frame_bytes, np.uint8)
+        _check(self.L, self.L.e264hip_frame_download(self.h, slot, out.ctypes.data, out.nbytes), "frame_download")
+        return out
+
+    def flush(self) -> None:
+        _check(self.L, self.L.e264hip_stream_flush(self.h), "stream_flush")

@@ -1,0 +1,411 @@
+// e264_backend.hip -- C-ABI of the MI355X reconstruction back end (include/edge264_hip.h).
+//
+// Host side of the drop-in boundary: owns the device DPB of every decoder ("stream"), moves
+// command packets to HBM with pinned async copies, launches the frame kernels on one HIP
+// queue per device, and copies finished frames back on demand.  No torch types, no CPU
+// fallback: if there is no gfx950 device every entry point fails with ENODEV.
+#include <hip/hip_runtime.h>
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
+
+#include "../../include/edge264_hip.h"
+#include "e264_kernels.h"
+
+#define API extern "C" __attribute__((visibility("default")))
+
+static thread_local char g_err[256];
+static int fail(int code, const char *what, hipError_t e = hipSuccess)
+{
+	snprintf(g_err, sizeof(g_err), "%s%s%s", what, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
+	return code;
+}
+#define HIPCHK(call, code) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(code, #call, e_); } while (0)
+
+API const char *e264hip_last_error(void) { return g_err; }
+
+struct E264Packet {
+	E264Device *dev;
+	uint8_t *d_bytes;
+	size_t bytes;
+	int dst_slot;
+};
+
+struct E264Device {
+	int ordinal;
+	hipStream_t q;
+	int waves;                 // macroblock rows in flight per frame workgroup
+	std::mutex lock;
+	// job table staging (pinned host + device), grown on demand
+	E264Job *h_jobs, *d_jobs;
+	int jobs_cap;
+	hipEvent_t ev[16];
+	// per-launch kernel timing
+	bool ktiming;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
+	size_t kev_used;
+};
+
+struct E264Stream {
+	E264Device *dev;
+	uint8_t **d_table;                    // device array [E264_MAX_SLOTS] of slot pointers
+	uint8_t *h_table[E264_MAX_SLOTS];     // same, host copy
+	void *mirror[E264_MAX_SLOTS];         // pinned host mirrors
+	size_t slot_bytes[E264_MAX_SLOTS];
+	// packet staging ring (pinned host) + device copies
+	struct Stage { void *h; uint8_t *d; size_t cap; hipEvent_t done; bool busy; } stage[4];
+	int stage_next;
+};
+
+static int set_device(E264Device *dev)
+{
+	HIPCHK(hipSetDevice(dev->ordinal), EIO);
+	return 0;
+}
+
+API int e264hip_device_open(int ordinal, E264Device **out)
+{
+	if (!out) return fail(EINVAL, "null out");
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(ENODEV, "no HIP device");
+	if (ordinal < 0 || ordinal >= n) return fail(ENODEV, "device ordinal out of range");
+	hipDeviceProp_t prop;
+	HIPCHK(hipGetDeviceProperties(&prop, ordinal), EIO);
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+		snprintf(g_err, sizeof(g_err), "device %d is %s, this back end is built for gfx950 only", ordinal, prop.gcnArchName);
+		return ENODEV;
+	}
+	E264Device *d = new (std::nothrow) E264Device();
+	if (!d) return fail(ENOMEM, "device object");
+	d->ordinal = ordinal;
+	d->waves = 8;
+	d->h_jobs = nullptr; d->d_jobs = nullptr; d->jobs_cap = 0;
+	d->ktiming = false; d->kev_used = 0;
+	if (hipSetDevice(ordinal) != hipSuccess || hipStreamCreateWithFlags(&d->q, hipStreamNonBlocking) != hipSuccess) {
+		delete d;
+		return fail(EIO, "hipStreamCreate");
+	}
+	for (int i = 0; i < 16; i++)
+		hipEventCreate(&d->ev[i]);
+	*out = d;
+	return 0;
+}
+
+API void e264hip_device_close(E264Device *dev)
+{
+	if (!dev) return;
+	hipSetDevice(dev->ordinal);
+	hipStreamSynchronize(dev->q);
+	for (int i = 0; i < 16; i++) hipEventDestroy(dev->ev[i]);
+	for (auto &p : dev->kev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+	if (dev->h_jobs) hipHostFree(dev->h_jobs);
+	if (dev->d_jobs) hipFree(dev->d_jobs);
+	hipStreamDestroy(dev->q);
+	delete dev;
+}
+
+API int e264hip_device_sync(E264Device *dev)
+{
+	if (!dev) return fail(EINVAL, "null device");
+	if (set_device(dev)) return EIO;
+	HIPCHK(hipStreamSynchronize(dev->q), EIO);
+	return 0;
+}
+
+API int e264hip_set_option(E264Device *dev, const char *name, int value)
+{
+	if (!dev || !name) return -1;
+	if (!strcmp(name, "waves")) {
+		int prev = dev->waves;
+		if (value == 4 || value == 8 || value == 16) dev->waves = value;
+		return prev;
+	}
+	return -1;
+}
+
+API int e264hip_stream_open(E264Device *dev, E264Stream **out)
+{
+	if (!dev || !out) return fail(EINVAL, "null argument");
+	if (set_device(dev)) return EIO;
+	E264Stream *s = new (std::nothrow) E264Stream();
+	if (!s) return fail(ENOMEM, "stream object");
+	memset(s, 0, sizeof(*s));
+	s->dev = dev;
+	if (hipMalloc(&s->d_table, sizeof(uint8_t *) * E264_MAX_SLOTS) != hipSuccess) { delete s; return fail(ENOMEM, "slot table"); }
+	hipMemsetAsync(s->d_table, 0, sizeof(uint8_t *) * E264_MAX_SLOTS, dev->q);
+	*out = s;
+	return 0;
+}
+
+API int e264hip_stream_flush(E264Stream *s)
+{
+	if (!s) return fail(EINVAL, "null stream");
+	return e264hip_device_sync(s->dev);
+}
+
+API void e264hip_stream_close(E264Stream *s)
+{
+	if (!s) return;
+	e264hip_device_sync(s->dev);
+	for (int i = 0; i < E264_MAX_SLOTS; i++) {
+		if (s->h_table[i]) hipFree(s->h_table[i]);
+		if (s->mirror[i]) hipHostFree(s->mirror[i]);
+	}
+	for (auto &st : s->stage) {
+		if (st.h) hipHostFree(st.h);
+		if (st.d) hipFree(st.d);
+		if (st.done) hipEventDestroy(st.done);
+	}
+	hipFree(s->d_table);
+	delete s;
+}
+
+static int push_table(E264Stream *s)
+{
+	// small synchronous-looking update, ordered on the queue before any kernel that reads it
+	HIPCHK(hipMemcpyAsync(s->d_table, s->h_table, sizeof(uint8_t *) * E264_MAX_SLOTS, hipMemcpyHostToDevice, s->dev->q), EIO);
+	HIPCHK(hipStreamSynchronize(s->dev->q), EIO); // h_table is pageable and may change right after
+	return 0;
+}
+
+API int e264hip_frame_alloc(E264Stream *s, int slot, size_t samples_bytes, void **host_mirror)
+{
+	if (!s || slot < 0 || slot >= E264_MAX_SLOTS || samples_bytes == 0) return fail(EINVAL, "frame_alloc arguments");
+	if (set_device(s->dev)) return EIO;
+	if (s->h_table[slot]) e264hip_frame_free(s, slot);
+	// +64: the MC fast path reads whole dwords up to 3 bytes past a 9-sample span (like the
+	// reference's +16 over-read margin, src/edge264_headers.c:115)
+	if (hipMalloc(&s->h_table[slot], samples_bytes + 64) != hipSuccess) { s->h_table[slot] = nullptr; return fail(ENOMEM, "hipMalloc frame"); }
+	s->slot_bytes[slot] = samples_bytes;
+	if (host_mirror) {
+		if (hipHostMalloc(&s->mirror[slot], samples_bytes, hipHostMallocDefault) != hipSuccess) {
+			hipFree(s->h_table[slot]); s->h_table[slot] = nullptr; s->mirror[slot] = nullptr;
+			return fail(ENOMEM, "hipHostMalloc mirror");
+		}
+		*host_mirror = s->mirror[slot];
+	}
+	return push_table(s);
+}
+
+API void e264hip_frame_free(E264Stream *s, int slot)
+{
+	if (!s || slot < 0 || slot >= E264_MAX_SLOTS || !s->h_table[slot]) return;
+	set_device(s->dev);
+	hipStreamSynchronize(s->dev->q);
+	hipFree(s->h_table[slot]);
+	if (s->mirror[slot]) hipHostFree(s->mirror[slot]);
+	s->h_table[slot] = nullptr; s->mirror[slot] = nullptr; s->slot_bytes[slot] = 0;
+	push_table(s);
+}
+
+API int e264hip_frame_fill(E264Stream *s, int slot, int value)
+{
+	if (!s || slot < 0 || slot >= E264_MAX_SLOTS || !s->h_table[slot]) return fail(EINVAL, "frame_fill slot");
+	if (set_device(s->dev)) return EIO;
+	HIPCHK(hipMemsetAsync(s->h_table[slot], value, s->slot_bytes[slot], s->dev->q), EIO);
+	return 0;
+}
+
+API int e264hip_frame_upload(E264Stream *s, int slot, const void *src, size_t bytes)
+{
+	if (!s || slot < 0 || slot >= E264_MAX_SLOTS || !s->h_table[slot] || bytes > s->slot_bytes[slot]) return fail(EINVAL, "frame_upload");
+	if (set_device(s->dev)) return EIO;
+	HIPCHK(hipMemcpyAsync(s->h_table[slot], src, bytes, hipMemcpyHostToDevice, s->dev->q), EIO);
+	HIPCHK(hipStreamSynchronize(s->dev->q), EIO);
+	return 0;
+}
+
+static int check_packet(const void *packet, size_t bytes, int *dst)
+{
+	const E264FrameHdr *h = (const E264FrameHdr *)packet;
+	if (!packet || bytes < sizeof(*h) || h->magic != E264_MAGIC || h->version != E264_VERSION || h->total_bytes > bytes)
+		return fail(EINVAL, "not a command packet");
+	if (h->dst_slot < 0 || h->dst_slot >= E264_MAX_SLOTS) return fail(EINVAL, "dst_slot");
+	size_t need = (size_t)h->mbs_off + (size_t)h->width_mbs * h->height_mbs * sizeof(E264Mb);
+	if (need > h->payload_off || (size_t)h->payload_off + h->payload_bytes > h->total_bytes) return fail(EINVAL, "packet layout");
+	*dst = h->dst_slot;
+	return 0;
+}
+
+static int ensure_jobs(E264Device *dev, int n)
+{
+	if (n <= dev->jobs_cap) return 0;
+	int cap = n < 64 ? 64 : n * 2;
+	if (dev->h_jobs) { hipStreamSynchronize(dev->q); hipHostFree(dev->h_jobs); hipFree(dev->d_jobs); dev->h_jobs = nullptr; dev->d_jobs = nullptr; dev->jobs_cap = 0; }
+	// 4 rotating job tables so that a launch never overwrites one still being read
+	HIPCHK(hipHostMalloc((void **)&dev->h_jobs, sizeof(E264Job) * cap * 4, hipHostMallocDefault), ENOMEM);
+	HIPCHK(hipMalloc((void **)&dev->d_jobs, sizeof(E264Job) * cap * 4), ENOMEM);
+	dev->jobs_cap = cap;
+	return 0;
+}
+
+static int launch(E264Device *dev, const E264Job *jobs_host, int n, int mode)
+{
+	static thread_local int rot = 0;
+	int r = ensure_jobs(dev, n);
+	if (r) return r;
+	std::lock_guard<std::mutex> g(dev->lock);
+	int slot = rot++ & 3;
+	E264Job *hj = dev->h_jobs + (size_t)slot * dev->jobs_cap;
+	E264Job *dj = dev->d_jobs + (size_t)slot * dev->jobs_cap;
+	memcpy(hj, jobs_host, sizeof(E264Job) * n);
+	HIPCHK(hipMemcpyAsync(dj, hj, sizeof(E264Job) * n, hipMemcpyHostToDevice, dev->q), EIO);
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	if (dev->ktiming) {
+		if (dev->kev_used == dev->kev.size()) {
+			hipEvent_t a, b;
+			hipEventCreate(&a); hipEventCreate(&b);
+			dev->kev.push_back({a, b});
+		}
+		e0 = dev->kev[dev->kev_used].first; e1 = dev->kev[dev->kev_used].second;
+		dev->kev_used++;
+		hipEventRecord(e0, dev->q);
+	}
+	HIPCHK(e264_launch_frames(dj, n, mode, dev->waves, dev->q), EIO);
+	if (e1) hipEventRecord(e1, dev->q);
+	return 0;
+}
+
+API void *e264hip_packet_buffer(E264Stream *s, size_t max_bytes)
+{
+	if (!s || set_device(s->dev)) return nullptr;
+	E264Stream::Stage &st = s->stage[s->stage_next];
+	if (st.busy) { hipEventSynchronize(st.done); st.busy = false; }
+	if (st.cap < max_bytes) {
+		if (st.h) hipHostFree(st.h);
+		if (st.d) hipFree(st.d);
+		st.h = nullptr; st.d = nullptr; st.cap = 0;
+		size_t cap = (max_bytes + 65535) & ~(size_t)65535;
+		if (hipHostMalloc(&st.h, cap, hipHostMallocDefault) != hipSuccess) { fail(ENOMEM, "pinned packet buffer"); return nullptr; }
+		if (hipMalloc((void **)&st.d, cap) != hipSuccess) { hipHostFree(st.h); st.h = nullptr; fail(ENOMEM, "device packet buffer"); return nullptr; }
+		st.cap = cap;
+		if (!st.done) hipEventCreateWithFlags(&st.done, hipEventDisableTiming);
+	}
+	return st.h;
+}
+
+API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
+{
+	if (!s) return fail(EINVAL, "null stream");
+	int dst, r = check_packet(packet, bytes, &dst);
+	if (r) return r;
+	if (!s->h_table[dst]) return fail(EINVAL, "destination slot not allocated");
+	if (set_device(s->dev)) return EIO;
+	E264Stream::Stage *st = &s->stage[s->stage_next];
+	if (packet != st->h) { // caller did not use our pinned buffer: stage it
+		void *h = e264hip_packet_buffer(s, bytes);
+		if (!h) return ENOMEM;
+		st = &s->stage[s->stage_next];
+		memcpy(h, packet, bytes);
+	}
+	s->stage_next = (s->stage_next + 1) & 3;
+	HIPCHK(hipMemcpyAsync(st->d, st->h, bytes, hipMemcpyHostToDevice, s->dev->q), EIO);
+	E264Job job = {st->d, s->d_table};
+	r = launch(s->dev, &job, 1, E264_RUN_ALL);
+	if (r) return r;
+	hipEventRecord(st->done, s->dev->q);
+	st->busy = true;
+	return 0;
+}
+
+API int e264hip_frame_wait(E264Stream *s, int slot)
+{
+	if (!s || slot < 0 || slot >= E264_MAX_SLOTS) return fail(EINVAL, "frame_wait");
+	// one in-order queue per device: everything submitted so far has to retire
+	return e264hip_device_sync(s->dev);
+}
+
+API int e264hip_frame_download(E264Stream *s, int slot, void *dst, size_t bytes)
+{
+	if (!s || slot < 0 || slot >= E264_MAX_SLOTS || !s->h_table[slot]) return fail(EINVAL, "frame_download slot");
+	if (set_device(s->dev)) return EIO;
+	if (!dst) dst = s->mirror[slot];
+	if (!dst) return fail(EINVAL, "no destination");
+	if (bytes == 0 || bytes > s->slot_bytes[slot]) bytes = s->slot_bytes[slot];
+	HIPCHK(hipMemcpyAsync(dst, s->h_table[slot], bytes, hipMemcpyDeviceToHost, s->dev->q), EIO);
+	HIPCHK(hipStreamSynchronize(s->dev->q), EIO);
+	return 0;
+}
+
+API int e264hip_packet_upload(E264Device *dev, const void *packet, size_t bytes, E264Packet **out)
+{
+	if (!dev || !out) return fail(EINVAL, "null argument");
+	int dst, r = check_packet(packet, bytes, &dst);
+	if (r) return r;
+	if (set_device(dev)) return EIO;
+	E264Packet *p = new (std::nothrow) E264Packet();
+	if (!p) return fail(ENOMEM, "packet object");
+	p->dev = dev; p->bytes = bytes; p->dst_slot = dst;
+	if (hipMalloc((void **)&p->d_bytes, bytes) != hipSuccess) { delete p; return fail(ENOMEM, "hipMalloc packet"); }
+	hipError_t e = hipMemcpy(p->d_bytes, packet, bytes, hipMemcpyHostToDevice);
+	if (e != hipSuccess) { hipFree(p->d_bytes); delete p; return fail(EIO, "hipMemcpy packet", e); }
+	*out = p;
+	return 0;
+}
+
+API void e264hip_packet_free(E264Packet *p)
+{
+	if (!p) return;
+	hipSetDevice(p->dev->ordinal);
+	hipStreamSynchronize(p->dev->q);
+	hipFree(p->d_bytes);
+	delete p;
+}
+
+API int e264hip_submit_batch(E264Device *dev, E264Stream *const *streams, E264Packet *const *packets, int n, int mode)
+{
+	if (!dev || !streams || !packets || n <= 0) return fail(EINVAL, "submit_batch arguments");
+	if (set_device(dev)) return EIO;
+	std::vector<E264Job> jobs((size_t)n);
+	for (int i = 0; i < n; i++) {
+		if (!streams[i] || !packets[i] || streams[i]->dev != dev || packets[i]->dev != dev) return fail(EINVAL, "submit_batch entry");
+		if (!streams[i]->h_table[packets[i]->dst_slot]) return fail(EINVAL, "destination slot not allocated");
+		jobs[i].packet = packets[i]->d_bytes;
+		jobs[i].dpb = streams[i]->d_table;
+	}
+	return launch(dev, jobs.data(), n, mode);
+}
+
+API int e264hip_event_record(E264Device *dev, int idx)
+{
+	if (!dev || idx < 0 || idx >= 16) return fail(EINVAL, "event index");
+	if (set_device(dev)) return EIO;
+	HIPCHK(hipEventRecord(dev->ev[idx], dev->q), EIO);
+	return 0;
+}
+
+API int e264hip_event_elapsed_ms(E264Device *dev, int a, int b, float *ms)
+{
+	if (!dev || !ms || a < 0 || a >= 16 || b < 0 || b >= 16) return fail(EINVAL, "event index");
+	if (set_device(dev)) return EIO;
+	HIPCHK(hipEventSynchronize(dev->ev[b]), EIO);
+	HIPCHK(hipEventElapsedTime(ms, dev->ev[a], dev->ev[b]), EIO);
+	return 0;
+}
+
+API int e264hip_kernel_timing(E264Device *dev, int enable)
+{
+	if (!dev) return fail(EINVAL, "null device");
+	e264hip_device_sync(dev);
+	dev->ktiming = enable != 0;
+	dev->kev_used = 0;
+	return 0;
+}
+
+API int e264hip_kernel_time_ms(E264Device *dev, double *total_ms, int *launches)
+{
+	if (!dev || !total_ms) return fail(EINVAL, "null argument");
+	int r = e264hip_device_sync(dev);
+	if (r) return r;
+	double t = 0;
+	for (size_t i = 0; i < dev->kev_used; i++) {
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, dev->kev[i].first, dev->kev[i].second) == hipSuccess) t += ms;
+	}
+	*total_ms = t;
+	if (launches) *launches = (int)dev->kev_used;
+	return 0;
+}

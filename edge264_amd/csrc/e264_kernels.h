@@ -1,0 +1,17 @@
+// e264_kernels.h -- launch interface between the C-ABI back end and the gfx950 kernels.
+#ifndef E264_KERNELS_H
+#define E264_KERNELS_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// One job = one coded frame of one stream: its command packet (already in HBM) and the
+// table of the stream's DPB slots (device pointers, E264_MAX_SLOTS entries, NULL if unallocated).
+struct E264Job {
+	const uint8_t *packet;
+	uint8_t *const *dpb;
+};
+
+// mode: bit0 reconstruction pass, bit1 deblocking pass.  waves: 4, 8 or 16 macroblock rows in flight per frame.
+extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int mode, int waves, hipStream_t stream);
+
+#endif

@@ -1,0 +1,1123 @@
+// e264_kernels.hip -- gfx950 (MI355X) macroblock reconstruction kernels.
+//
+// Consumes the command packet of include/edge264_cmd.h and writes the planar YUV DPB.
+// Device restatement of the reference's sample path (file:line in /root/reference/src):
+//   residual   edge264_residual.c:108-538   (dequant + 4x4 / 8x8 integer IDCT, DC transforms)
+//   intra      edge264_intra.c:291-765      (14 + 32 + 7 + 7 internal modes)
+//   inter      edge264_inter.c:416-1251     (6-tap luma, bilinear chroma, 5 weighting schemes)
+//   deblock    edge264_deblock.c:927-1123   (bS / alpha / beta / tC0) and :284-895 (filters)
+//
+// Execution model (DESIGN.md "kernels"): ONE WORKGROUP PER FRAME, ONE WAVE64 PER MACROBLOCK
+// ROW.  The waves of a workgroup walk their rows left to right; row y may reconstruct an
+// intra macroblock x (or deblock any macroblock x) once row y-1 has finished macroblock
+// x+1 -- the 2-MB-lag wavefront that both intra prediction and H.264 in-loop deblocking
+// require.  Progress counters live in LDS, so the hand-off between rows
+// never leaves the CU: no agent-scope fences, no cross-XCD traffic, no placement
+// assumption.  Chip-level parallelism comes from many independent streams (one frame of
+// each per launch), which is the north-star workload (>=1000 concurrent streams).
+// Integer / byte work throughout; HBM-bound by design, no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/edge264_cmd.h"
+#include "e264_kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int clip3i(int lo, int hi, int v) { return min(max(v, lo), hi); }
+__device__ __forceinline__ int clip255(int v) { return min(max(v, 0), 255); }
+__device__ __forceinline__ int sat16(int v) { return min(max(v, -32768), 32767); }
+__device__ __forceinline__ int w16(int v) { return (int)(int16_t)v; }
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+// All LDS scratch is private to one wave; LDS operations of a wave execute in order, so a
+// compiler-level fence is all that is needed between producer and consumer lanes.
+__device__ __forceinline__ void wave_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+
+__constant__ uint8_t c_BX[16] = {0, 4, 0, 4, 8, 12, 8, 12, 0, 4, 0, 4, 8, 12, 8, 12};
+__constant__ uint8_t c_BY[16] = {0, 0, 4, 4, 0, 0, 4, 4, 8, 8, 12, 12, 8, 8, 12, 12};
+__device__ __forceinline__ int BXf(int k) { return ((k & 1) << 2) | ((k & 4) << 1); }
+__device__ __forceinline__ int BYf(int k) { return ((k & 2) << 1) | ((k & 8)); }
+__device__ __forceinline__ int blk_of(int bx, int by) { return (by >> 1) * 8 + (bx >> 1) * 4 + (by & 1) * 2 + (bx & 1); }
+
+__constant__ uint8_t c_na4[6][3] = {{10, 16, 13}, {11, 18, 14}, {13, 20, 16}, {14, 23, 18}, {16, 25, 20}, {18, 29, 23}};
+__constant__ uint8_t c_na8[6][6] = {{20, 18, 32, 19, 25, 24}, {22, 19, 35, 21, 28, 26}, {26, 23, 42, 24, 33, 31},
+	{28, 25, 45, 26, 35, 33}, {32, 28, 51, 30, 40, 38}, {36, 32, 58, 34, 46, 43}};
+__device__ __forceinline__ int norm4(int m, int pos)
+{ // edge264_residual.c:77-84
+	int i = pos >> 2, j = pos & 3;
+	return c_na4[m][(i & j & 1) ? 1 : ((i | j) & 1) ? 2 : 0];
+}
+__device__ __forceinline__ int norm8(int m, int pos)
+{ // edge264_residual.c:85-98
+	int i = pos >> 3, j = pos & 7, k;
+	if ((i & 3) == 0 && (j & 3) == 0) k = 0;
+	else if (i & j & 1) k = 1;
+	else if ((i & 3) == 2 && (j & 3) == 2) k = 2;
+	else if (((i & 3) == 0 && (j & 1)) || ((i & 1) && (j & 3) == 0)) k = 3;
+	else if (((i & 3) == 0 && (j & 3) == 2) || ((i & 3) == 2 && (j & 3) == 0)) k = 4;
+	else k = 5;
+	return c_na8[m][k];
+}
+
+__constant__ uint8_t c_alpha[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 5, 6, 7, 8, 9, 10, 12, 13, 15, 17, 20, 22, 25, 28,
+	32, 36, 40, 45, 50, 56, 63, 71, 80, 90, 101, 113, 127, 144, 162, 182, 203, 226, 255, 255};
+__constant__ uint8_t c_beta[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 6, 6, 7, 7, 8, 8,
+	9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 14, 14, 15, 15, 16, 16, 17, 17, 18, 18};
+__constant__ uint8_t c_tc0[3][52] = {
+	{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 6, 6, 7, 8, 9, 10, 11, 13},
+	{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 5, 6, 7, 8, 8, 10, 11, 12, 13, 15, 17},
+	{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 23, 25}};
+
+// ---------------------------------------------------------------------------------
+// per-wave LDS scratch
+// ---------------------------------------------------------------------------------
+// luma tile: rows -1..15, columns -8..23 (top-right of an 8x8 block reaches x=23), 32-byte rows
+#define YT_STRIDE 32
+#define YT(y, x) ytile[((y) + 1) * YT_STRIDE + (x) + 8]
+// chroma tiles: rows -1..7, columns -4..11
+#define CT_STRIDE 16
+#define CT(p, y, x) ctile[p][((y) + 1) * CT_STRIDE + (x) + 4]
+// deblock tiles: luma rows -4..15, cols -4..15 (stride 20 bytes, dword aligned); chroma rows -4..7, cols -4..7
+#define DY_STRIDE 20
+#define DYT(y, x) dytile[((y) + 4) * DY_STRIDE + (x) + 4]
+#define DC_STRIDE 12
+#define DCT(p, y, x) dctile[p][((y) + 4) * DC_STRIDE + (x) + 4]
+
+struct __attribute__((aligned(16))) WaveLds {
+	union {
+		struct { // reconstruction pass
+			int16_t res[384];          // residual: luma [y*16+x], Cb at 256 [y*8+x], Cr at 320
+			int32_t tmp[256];          // IDCT intermediate (4x4: 16 blocks x 16 int32; 8x8: int16 view)
+			int32_t dc[24];            // 16 luma DC (zig order), 4 Cb, 4 Cr
+			uint8_t ytile[17 * YT_STRIDE];
+			uint8_t ctile[2][9 * CT_STRIDE];
+			uint8_t ftop[32];          // intra 8x8 filtered top  ft[-1..15] at [i+1]
+			uint8_t fleft[8];          // intra 8x8 filtered left
+		};
+		struct { // deblocking pass
+			uint8_t dytile[20 * DY_STRIDE];
+			uint8_t dctile[2][12 * DC_STRIDE];
+			uint8_t bs[32];            // [dir][edge][seg]
+		};
+	};
+};
+
+struct FrameCtx {
+	const E264FrameHdr *h;
+	const E264SliceParams *slices;
+	const E264Mb *mbs;
+	const uint8_t *payload;
+	uint8_t *const *dpb;
+	uint8_t *cur;
+	int W, H;          // luma samples
+	int wm, hm;        // macroblocks
+	int sY, sC;        // strides
+	uint32_t psY;      // plane_size_Y
+};
+
+__device__ __forceinline__ uint8_t *plane_base(const FrameCtx &f, uint8_t *base, int pl)
+{
+	return pl == 0 ? base : base + f.psY + (pl == 2 ? (f.sC >> 1) : 0);
+}
+
+// ---------------------------------------------------------------------------------
+// residual: fills lds.res for the whole macroblock
+// ---------------------------------------------------------------------------------
+// One 4x4 block per 4 lanes.  pass 1 (lane = block k, row y): dequant + horizontal butterfly
+// (edge264_residual.c:118-134); pass 2 (lane = block k, column x'): vertical butterfly, >>6,
+// saturate to int16 (residual.c:141-158).  dc_only blocks get the add_dc4x4 value (residual.c:174-187).
+__device__ __forceinline__ void idct4x4_blocks(WaveLds &L, int nblk, uint32_t codedmask, bool use_dc, bool dc_valid,
+	const int16_t *coef_base, const uint8_t *wS, int qP, int dc_off, int res_off, int res_stride, int lane)
+{
+	int k = lane >> 2, y = lane & 3;
+	bool active = k < nblk;
+	bool coded = active && (codedmask >> k & 1);
+	if (coded) {
+		// coefficient blocks are packed in increasing k: offset = popcount of lower coded bits
+		const int16_t *c = coef_base + __builtin_popcount(codedmask & ((1u << k) - 1)) * 16;
+		int sh = qP / 6, m = qP - sh * 6;
+		int d[4];
+#pragma unroll
+		for (int x = 0; x < 4; x++) {
+			int pos = x * 4 + y;
+			int LS = wS[pos] * norm4(m, pos);
+			d[x] = (int)(((uint32_t)((int)c[pos] * LS) << sh) + 8u) >> 4;
+		}
+		if (use_dc && y == 0)
+			d[0] = L.dc[dc_off + k];
+		int e0 = d[0] + d[2], e1 = d[0] - d[2], e2 = (d[1] >> 1) - d[3], e3 = (d[3] >> 1) + d[1];
+		int32_t *t = L.tmp + k * 16;
+		int add = (y == 0) ? 32 : 0;
+		t[0 * 4 + y] = e0 + e3 + add;
+		t[1 * 4 + y] = e1 + e2 + add;
+		t[2 * 4 + y] = e1 - e2 + add;
+		t[3 * 4 + y] = e0 - e3 + add;
+	}
+	wave_sync();
+	if (active) {
+		int x = y; // second role of the low lane bits: column x'
+		int16_t *r;
+		if (nblk == 16) // luma: block k in zig order inside the 16x16 tile
+			r = L.res + res_off + BYf(k) * res_stride + BXf(k) + x;
+		else            // chroma: plane k>>2 (64 samples each), 2x2 blocks of an 8x8 tile
+			r = L.res + res_off + (k >> 2) * 64 + ((k >> 1) & 1) * 4 * res_stride + (k & 1) * 4 + x;
+		if (coded) {
+			const int32_t *t = L.tmp + k * 16 + x * 4;
+			int f0 = t[0], f1 = t[1], f2 = t[2], f3 = t[3];
+			int g0 = f0 + f2, g1 = f0 - f2, g2 = (f1 >> 1) - f3, g3 = (f3 >> 1) + f1;
+			r[0 * res_stride] = (int16_t)sat16((g0 + g3) >> 6);
+			r[1 * res_stride] = (int16_t)sat16((g1 + g2) >> 6);
+			r[2 * res_stride] = (int16_t)sat16((g1 - g2) >> 6);
+			r[3 * res_stride] = (int16_t)sat16((g0 - g3) >> 6);
+		} else if (dc_valid) {
+			int16_t v = (int16_t)((L.dc[dc_off + k] + 32) >> 6);
+			r[0 * res_stride] = v; r[1 * res_stride] = v; r[2 * res_stride] = v; r[3 * res_stride] = v;
+		}
+	}
+	wave_sync();
+}
+
+// 8x8: lanes 0..31, (block b, lane index j).  int16 arithmetic with wraparound (residual.c:250-316).
+__device__ __forceinline__ void idct8_1d(int16_t d[8])
+{
+	int16_t d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5], d6 = d[6], d7 = d[7];
+	int16_t e0 = (int16_t)(d0 + d4);
+	int16_t e1 = (int16_t)(d5 - d3 - (int16_t)((d7 >> 1) + d7));
+	int16_t e2 = (int16_t)(d0 - d4);
+	int16_t e3 = (int16_t)(d1 + d7 - (int16_t)((d3 >> 1) + d3));
+	int16_t e4 = (int16_t)((d2 >> 1) - d6);
+	int16_t e5 = (int16_t)(d7 - d1 + (int16_t)((d5 >> 1) + d5));
+	int16_t e6 = (int16_t)((d6 >> 1) + d2);
+	int16_t e7 = (int16_t)(d3 + d5 + (int16_t)((d1 >> 1) + d1));
+	int16_t f0 = (int16_t)(e0 + e6);
+	int16_t f1 = (int16_t)((e7 >> 2) + e1);
+	int16_t f2 = (int16_t)(e2 + e4);
+	int16_t f3 = (int16_t)((e5 >> 2) + e3);
+	int16_t f4 = (int16_t)(e2 - e4);
+	int16_t f5 = (int16_t)((e3 >> 2) - e5);
+	int16_t f6 = (int16_t)(e0 - e6);
+	int16_t f7 = (int16_t)(e7 - (e1 >> 2));
+	d[0] = (int16_t)(f0 + f7); d[1] = (int16_t)(f2 + f5); d[2] = (int16_t)(f4 + f3); d[3] = (int16_t)(f6 + f1);
+	d[4] = (int16_t)(f6 - f1); d[5] = (int16_t)(f4 - f3); d[6] = (int16_t)(f2 - f5); d[7] = (int16_t)(f0 - f7);
+}
+
+__device__ __forceinline__ void idct8x8_blocks(WaveLds &L, uint32_t coded, const int16_t *coef_base, const uint8_t *wS, int qP, int lane)
+{
+	int b = lane >> 3, j = lane & 7;
+	bool on = lane < 32 && (coded >> (b * 4) & 1);
+	int16_t *t16 = (int16_t *)L.tmp;
+	if (on) {
+		int nb = 0;
+		for (int i = 0; i < b; i++) nb += coded >> (i * 4) & 1;
+		const int16_t *c = coef_base + nb * 64;
+		int div = qP / 6, m = qP - div * 6;
+		int16_t d[8];
+#pragma unroll
+		for (int i = 0; i < 8; i++) {
+			int pos = i * 8 + j;
+			int LS = wS[pos] * norm8(m, pos);
+			if (div < 6)
+				d[i] = (int16_t)sat16(((int)c[pos] * LS + (1 << (5 - div))) >> (6 - div));
+			else
+				d[i] = (int16_t)((int)c[pos] * (int)(int16_t)(LS << (div - 6)));
+		}
+		idct8_1d(d);
+		// transposed read in pass 2: element [i][j]; +32 lands on the new vector 0 = all elements with j == 0
+#pragma unroll
+		for (int i = 0; i < 8; i++)
+			t16[b * 64 + i * 8 + j] = (int16_t)(d[i] + (j == 0 ? 32 : 0));
+	}
+	wave_sync();
+	if (on) {
+		int i = j; // this lane now owns vector-lane i = pixel column i
+		int16_t d[8];
+#pragma unroll
+		for (int jj = 0; jj < 8; jj++)
+			d[jj] = t16[b * 64 + i * 8 + jj];
+		idct8_1d(d);
+		int16_t *r = L.res + BYf(b * 4) * 16 + BXf(b * 4) + i;
+#pragma unroll
+		for (int jj = 0; jj < 8; jj++)
+			r[jj * 16] = (int16_t)(d[jj] >> 6);
+	}
+	wave_sync();
+}
+
+__device__ void compute_residual(WaveLds &L, const FrameCtx &f, const E264Mb &m, const E264SliceParams *s, const uint8_t *pl, int lane)
+{
+	// zero the residual tile (384 int16 = 192 dwords)
+	uint32_t *rz = (uint32_t *)L.res;
+	rz[lane] = 0; rz[lane + 64] = 0; rz[lane + 128] = 0;
+	const uint32_t coded = m.coded;
+	const bool inter = m.kind == E264_MB_INTER;
+	const int16_t *ldc = nullptr, *cdc = nullptr;
+	if (coded & E264_CODED_LUMA_DC) { ldc = (const int16_t *)pl; pl += 32; }
+	if (coded & E264_CODED_CHROMA_DC) { cdc = (const int16_t *)pl; pl += 16; }
+	const int16_t *co = (const int16_t *)pl;
+	if (lane < 24) L.dc[lane] = 0;
+	wave_sync();
+	if (!coded) return;
+
+	// DC transforms (residual.c:352-399 and :456-480): one output per lane
+	if (ldc && lane < 16) {
+		int r = lane >> 2, l = lane & 3, acc = 0;
+		// f[r][l] = sum_m sum_i A[r][m] A[l][i] c[4i+m], A = rows {++++, ++--, +--+, +-+-}
+		const int sgn[4] = {0x0, 0xC, 0x6, 0xA}; // bit i set => negative
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+#pragma unroll
+			for (int mm = 0; mm < 4; mm++) {
+				int v = ldc[4 * i + mm];
+				bool neg = ((sgn[r] >> mm) ^ (sgn[l] >> i)) & 1;
+				acc += neg ? -v : v;
+			}
+		int qP = m.qp[0];
+		int LS = (s->weightScale4x4[0][0] * norm4(qP % 6, 0)) << (qP / 6);
+		int k = (r >> 1) * 8 + (l >> 1) * 4 + (r & 1) * 2 + (l & 1);
+		L.dc[k] = (int)((uint32_t)acc * (uint32_t)LS + 32u) >> 6;
+	}
+	if (cdc && lane >= 16 && lane < 24) {
+		int n = lane & 3, pc = (lane >> 2) & 1; // pc: 0 Cb, 1 Cr
+		int c0 = cdc[pc], c4 = cdc[4 + pc], c2 = cdc[2 + pc], c6 = cdc[6 + pc];
+		int v = n == 0 ? c0 + c4 + c2 + c6 : n == 1 ? c0 - c4 + c2 - c6 : n == 2 ? c0 + c4 - c2 - c6 : c0 - c4 - c2 + c6;
+		int qP = m.qp[1 + pc];
+		int LS = (s->weightScale4x4[1 + pc + (inter ? 3 : 0)][0] * norm4(qP % 6, 0)) << (qP / 6);
+		L.dc[16 + pc * 4 + n] = (int)((uint32_t)v * (uint32_t)LS) >> 5;
+	}
+	wave_sync();
+
+	// luma
+	if (m.kind == E264_MB_I16x16) {
+		if (coded & (0xffff | E264_CODED_LUMA_DC))
+			idct4x4_blocks(L, 16, coded & 0xffff, true, ldc != nullptr, co, s->weightScale4x4[0], m.qp[0], 0, 0, 16, lane);
+		co += __builtin_popcount(coded & 0xffff) * 16;
+	} else if (m.flags & E264_MBF_T8x8) {
+		if (coded & 0x1111)
+			idct8x8_blocks(L, coded, co, s->weightScale8x8[inter ? 1 : 0], m.qp[0], lane);
+		co += __builtin_popcount(coded & 0x1111) * 64;
+	} else {
+		if (coded & 0xffff)
+			idct4x4_blocks(L, 16, coded & 0xffff, false, false, co, s->weightScale4x4[inter ? 3 : 0], m.qp[0], 0, 0, 16, lane);
+		co += __builtin_popcount(coded & 0xffff) * 16;
+	}
+	// chroma: 8 blocks, Cb 0..3 then Cr 4..7; different QP / scaling list per plane
+	if (coded & (0xff0000 | E264_CODED_CHROMA_DC)) {
+		int k = lane >> 2;
+		int pc = (k >> 2) & 1;
+		idct4x4_blocks(L, 8, coded >> 16 & 0xff, true, cdc != nullptr, co, s->weightScale4x4[1 + pc + (inter ? 3 : 0)], m.qp[1 + pc], 16, 256, 8, lane);
+	}
+}
+
+// ---------------------------------------------------------------------------------
+// inter prediction
+// ---------------------------------------------------------------------------------
+struct Wod { int w0, w1, o, wd; };
+__device__ __forceinline__ int wpred(int q, int p, const Wod &w)
+{ // maddshrL, edge264_inter.c:17-21: pmaddubsw (int8 weights), adds16, sra, packus
+	int x = sat16(q * (int)(int8_t)w.w0 + p * (int)(int8_t)w.w1);
+	x = sat16(x + (int)(int16_t)w.o);
+	return clip255(x >> w.wd);
+}
+
+// decode_inter weight selection, edge264_inter.c:1137-1197
+__device__ void select_weights(const E264SliceParams *s, int list, int refIdx, int refIdxX, Wod &wY, Wod &wCb, Wod &wCr)
+{
+	Wod nw = {0, 1, 0, 0};
+	wY = wCb = wCr = nw;
+	int idc = s->weighted_bipred_idc;
+	if (idc != 1) {
+		if (list == 1 && refIdxX >= 0) {
+			if (idc == 0) {
+				Wod d = {1, 1, 1, 1};
+				wY = wCb = wCr = d;
+			} else {
+				int w1 = (int)s->implicit_weights[refIdxX][refIdx] - 64;
+				Wod d = {64 - w1, w1, 32, 6};
+				if ((unsigned)(w1 + 63) >= 191u) { d.w0 = 2 - (w1 >> 5); d.w1 = w1 >> 5; d.o = 1; d.wd = 1; }
+				wY = wCb = wCr = d;
+			}
+		}
+	} else if (refIdxX < 0) {
+		int i = refIdx + list * 32;
+		int lwd = s->luma_log2_weight_denom, cwd = s->chroma_log2_weight_denom;
+		if (s->explicit_weights[0][i] < 128) {
+			wY.w1 = s->explicit_weights[0][i];
+			wY.o = w16(((s->explicit_offsets[0][i] * 2 + 1) << lwd) >> 1);
+			wY.wd = lwd;
+		}
+		if (s->explicit_weights[1][i] < 128) {
+			wCb.w1 = s->explicit_weights[1][i];
+			wCr.w1 = s->explicit_weights[2][i];
+			wCb.o = w16(((s->explicit_offsets[1][i] * 2 + 1) << cwd) >> 1);
+			wCr.o = w16(((s->explicit_offsets[2][i] * 2 + 1) << cwd) >> 1);
+			wCb.wd = wCr.wd = cwd;
+		}
+	} else if (list == 1) {
+		int i = refIdx + 32, x = refIdxX;
+		int lwd = s->luma_log2_weight_denom, cwd = s->chroma_log2_weight_denom;
+		int a = s->explicit_weights[0][x], b = s->explicit_weights[0][i];
+		int oo = ((s->explicit_offsets[0][x] + s->explicit_offsets[0][i] + 1) | 1) << lwd;
+		if ((a & b) != 128) { wY.w0 = a; wY.w1 = b; wY.o = w16(oo); wY.wd = lwd + 1; }
+		else { wY.w0 = a >> 1; wY.w1 = b >> 1; wY.o = w16(oo >> 1); wY.wd = lwd; }
+		int a1 = s->explicit_weights[1][x], b1 = s->explicit_weights[1][i];
+		int a2 = s->explicit_weights[2][x], b2 = s->explicit_weights[2][i];
+		int o1 = ((s->explicit_offsets[1][x] + s->explicit_offsets[1][i] + 1) | 1) << cwd;
+		int o2 = ((s->explicit_offsets[2][x] + s->explicit_offsets[2][i] + 1) | 1) << cwd;
+		if ((a1 & b1) != 128) {
+			wCb.w0 = a1; wCb.w1 = b1; wCr.w0 = a2; wCr.w1 = b2;
+			wCb.o = w16(o1); wCr.o = w16(o2); wCb.wd = wCr.wd = cwd + 1;
+		} else {
+			wCb.w0 = a1 >> 1; wCb.w1 = b1 >> 1; wCr.w0 = a2 >> 1; wCr.w1 = b2 >> 1;
+			wCb.o = w16(o1 >> 1); wCr.o = w16(o2 >> 1); wCb.wd = wCr.wd = cwd;
+		}
+	}
+}
+
+// 9 consecutive samples x0..x0+8 of row y (clamped coordinates == the reference's edge
+// emulation, edge264_inter.c:1199-1235).  Fast path: three aligned dwords + byte alignment.
+__device__ __forceinline__ void load_row9(const uint8_t *plane, int stride, int W, int H, int x0, int y, int px[9])
+{
+	y = clip3i(0, H - 1, y);
+	const uint8_t *row = plane + (size_t)y * stride;
+	if (x0 >= 0 && x0 + 8 <= W - 1) {
+		uintptr_t p = (uintptr_t)(row + x0);
+		const uint32_t *q = (const uint32_t *)(p & ~(uintptr_t)3);
+		uint32_t off = (uint32_t)(p & 3);
+		uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+		uint32_t a = __builtin_amdgcn_alignbyte(d1, d0, off);
+		uint32_t b = __builtin_amdgcn_alignbyte(d2, d1, off);
+		uint32_t c = d2 >> (off * 8);
+		px[0] = a & 255; px[1] = a >> 8 & 255; px[2] = a >> 16 & 255; px[3] = a >> 24;
+		px[4] = b & 255; px[5] = b >> 8 & 255; px[6] = b >> 16 & 255; px[7] = b >> 24;
+		px[8] = c & 255;
+	} else {
+#pragma unroll
+		for (int i = 0; i < 9; i++)
+			px[i] = row[clip3i(0, W - 1, x0 + i)];
+	}
+}
+
+__device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
+// sixtapHV + shrrpus16(.,6): int16 wraparound, edge264_inter.c:4-9,14
+__device__ __forceinline__ int centre6(int t0, int t1, int t2, int t3, int t4, int t5)
+{
+	int af = w16(t0 + t5), be = w16(t1 + t4), cd = w16(t2 + t3);
+	int x1 = w16(af - be);
+	int x2 = w16((x1 >> 2) + w16(cd - be));
+	int x3 = w16((x2 >> 2) + cd);
+	return clip255(w16(x3 + 32) >> 6);
+}
+__device__ __forceinline__ int avg2(int a, int b) { return (a + b + 1) >> 1; }
+
+// 4 horizontally adjacent luma samples at (X..X+3, Y) displaced by the quarter-pel (xF,yF):
+// 8.4.2.2.1 organised like decode_inter_luma (edge264_inter.c:416-968).
+__device__ void luma_pred4(const uint8_t *ref, int stride, int W, int H, int X, int Y, int xF, int yF, int out[4])
+{
+	int px[9];
+	if (yF == 0) {
+		load_row9(ref, stride, W, H, X - 2, Y, px);
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			if (xF == 0) { out[i] = px[i + 2]; continue; }
+			int b = clip255((tap6(px[i], px[i + 1], px[i + 2], px[i + 3], px[i + 4], px[i + 5]) + 16) >> 5);
+			out[i] = xF == 2 ? b : avg2(px[i + 2 + (xF == 3)], b);
+		}
+		return;
+	}
+	const int cw[6] = {1, -5, 20, 20, -5, 1};
+	if (xF == 2) {
+		// horizontal first, then vertical on the 16-bit intermediates (inter.c:611-646, 779-802, 929-966)
+		int t[6][4];
+#pragma unroll
+		for (int r = 0; r < 6; r++) {
+			load_row9(ref, stride, W, H, X - 2, Y - 2 + r, px);
+#pragma unroll
+			for (int i = 0; i < 4; i++)
+				t[r][i] = tap6(px[i], px[i + 1], px[i + 2], px[i + 3], px[i + 4], px[i + 5]);
+		}
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			int j = centre6(t[0][i], t[1][i], t[2][i], t[3][i], t[4][i], t[5][i]);
+			if (yF == 2) out[i] = j;
+			else out[i] = avg2(j, clip255(((yF == 3 ? t[3][i] : t[2][i]) + 16) >> 5));
+		}
+		return;
+	}
+	// remaining cases need vertical taps over 6 rows; accumulate column sums
+	int v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+	int g[4] = {0, 0, 0, 0};      // integer samples for d/n
+	int hb[4] = {0, 0, 0, 0};     // horizontal half-pel b/s for e,g,p,r
+	const int grow = 2 + (yF == 3);
+#pragma unroll
+	for (int r = 0; r < 6; r++) {
+		load_row9(ref, stride, W, H, X - 2, Y - 2 + r, px);
+#pragma unroll
+		for (int c = 0; c < 9; c++)
+			v[c] += cw[r] * px[c];
+		if (r == grow) {
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				g[i] = px[i + 2];
+				hb[i] = clip255((tap6(px[i], px[i + 1], px[i + 2], px[i + 3], px[i + 4], px[i + 5]) + 16) >> 5);
+			}
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		if (xF == 0) {
+			int h = clip255((v[i + 2] + 16) >> 5);
+			out[i] = yF == 2 ? h : avg2(g[i], h);
+		} else if (yF & 1) { // e,g,p,r (inter.c:510-557)
+			int h = clip255((v[i + 2 + (xF == 3)] + 16) >> 5);
+			out[i] = avg2(hb[i], h);
+		} else { // xF odd, yF == 2: vertical first then horizontal (inter.c:559-609, 741-777, 887-927)
+			int j = centre6(v[i], v[i + 1], v[i + 2], v[i + 3], v[i + 4], v[i + 5]);
+			int h = clip255((v[i + 2 + (xF == 3)] + 16) >> 5);
+			out[i] = avg2(j, h);
+		}
+	}
+}
+
+__device__ __forceinline__ int ldc_px(const uint8_t *plane, int stride, int W, int H, int x, int y)
+{
+	return plane[(size_t)clip3i(0, H - 1, y) * stride + clip3i(0, W - 1, x)];
+}
+
+// Inter prediction of a whole macroblock in the "pixel layout":
+//   luma   lane = (k = lane>>2 : 4x4 block in zig order, r = lane&3 : row) -> 4 samples
+//   chroma lane = (plane = lane>>5, cy = (lane>>2)&7, cx = (lane&3)*2)    -> 2 samples
+__device__ void inter_pred_mb(const FrameCtx &f, const E264SliceParams *s, const E264Motion *mo, int mbx, int mby, int lane,
+	int outY[4], int outC[2])
+{
+	const int k = lane >> 2, r = lane & 3;
+	const int lx = mbx * 16 + BXf(k), ly = mby * 16 + BYf(k) + r;
+	const int cpl = lane >> 5, cy = (lane >> 2) & 7, cx = (lane & 3) * 2;
+	const int kc = blk_of(cx >> 1, cy >> 1);
+	outY[0] = outY[1] = outY[2] = outY[3] = 0;
+	outC[0] = outC[1] = 0;
+	const int idc = s->weighted_bipred_idc;
+#pragma unroll 1
+	for (int list = 0; list < 2; list++) {
+		// luma
+		int pic = mo->refPic[list * 4 + (k >> 2)];
+		if (pic >= 0) {
+			int mx = mo->mvs[list * 32 + k * 2], my = mo->mvs[list * 32 + k * 2 + 1];
+			int p[4];
+			luma_pred4(f.dpb[pic], f.sY, f.W, f.H, lx + (mx >> 2), ly + (my >> 2), mx & 3, my & 3, p);
+			int refIdxX = mo->refIdx[(list ^ 1) * 4 + (k >> 2)];
+			if (idc == 0 && !(list == 1 && refIdxX >= 0)) {
+#pragma unroll
+				for (int i = 0; i < 4; i++) outY[i] = p[i];
+			} else {
+				Wod wY, wCb, wCr;
+				select_weights(s, list, mo->refIdx[list * 4 + (k >> 2)], refIdxX, wY, wCb, wCr);
+#pragma unroll
+				for (int i = 0; i < 4; i++) outY[i] = wpred(outY[i], p[i], wY);
+			}
+		}
+		// chroma
+		int picc = mo->refPic[list * 4 + (kc >> 2)];
+		if (picc >= 0) {
+			int mx = mo->mvs[list * 32 + kc * 2], my = mo->mvs[list * 32 + kc * 2 + 1];
+			const uint8_t *rp = plane_base(f, f.dpb[picc], 1 + cpl);
+			int X = mbx * 8 + cx + (mx >> 3), Y = mby * 8 + cy + (my >> 3);
+			int xF = mx & 7, yF = my & 7;
+			int A = (8 - xF) * (8 - yF), B = xF * (8 - yF), C = (8 - xF) * yF, D = xF * yF;
+			int Wc = f.W >> 1, Hc = f.H >> 1;
+			int a0 = ldc_px(rp, f.sC, Wc, Hc, X, Y), a1 = ldc_px(rp, f.sC, Wc, Hc, X + 1, Y), a2 = ldc_px(rp, f.sC, Wc, Hc, X + 2, Y);
+			int b0 = ldc_px(rp, f.sC, Wc, Hc, X, Y + 1), b1 = ldc_px(rp, f.sC, Wc, Hc, X + 1, Y + 1), b2 = ldc_px(rp, f.sC, Wc, Hc, X + 2, Y + 1);
+			int p0 = (A * a0 + B * a1 + C * b0 + D * b1 + 32) >> 6;
+			int p1 = (A * a1 + B * a2 + C * b1 + D * b2 + 32) >> 6;
+			int refIdxX = mo->refIdx[(list ^ 1) * 4 + (kc >> 2)];
+			if (idc == 0 && !(list == 1 && refIdxX >= 0)) {
+				outC[0] = p0; outC[1] = p1;
+			} else {
+				Wod wY, wC[2];
+				select_weights(s, list, mo->refIdx[list * 4 + (kc >> 2)], refIdxX, wY, wC[0], wC[1]);
+				outC[0] = wpred(outC[0], p0, wC[cpl]);
+				outC[1] = wpred(outC[1], p1, wC[cpl]);
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------
+// intra prediction (modes: edge264_internal.h:564-634; U(navailable) suffixes A left, B top,
+// C top-right, D top-left)
+// ---------------------------------------------------------------------------------
+#define LP(l, m, r) (((l) + 2 * (m) + (r) + 2) >> 2)
+
+// neighbours of the macroblock from the frame (un-deblocked, pass R) into the tiles.
+// Out-of-frame positions are never dereferenced; the remapped modes never use them.
+__device__ void load_intra_neighbours(WaveLds &L, const FrameCtx &f, int mbx, int mby, int lane)
+{
+	const uint8_t *Y = f.cur + (size_t)(mby * 16) * f.sY + mbx * 16;
+	// luma top row x = -1..23 (lanes 0..24), left column (lanes 32..47)
+	if (lane < 25) {
+		int x = lane - 1;
+		int gx = mbx * 16 + x;
+		uint8_t v = 0;
+		if (mby > 0 && gx >= 0 && gx < f.W)
+			v = Y[x - f.sY];
+		L.YT(-1, x) = v;
+	} else if (lane >= 32 && lane < 48) {
+		int y = lane - 32;
+		L.YT(y, -1) = mbx > 0 ? Y[(size_t)y * f.sY - 1] : 0;
+	}
+	wave_sync();
+	// second round for chroma (keeps the lane mapping simple)
+	if (lane < 18) {
+		int pl = lane / 9, x = lane % 9 - 1;
+		const uint8_t *C = plane_base(f, f.cur, 1 + pl) + (size_t)(mby * 8) * f.sC + mbx * 8;
+		int gx = mbx * 8 + x;
+		uint8_t v = 0;
+		if (mby > 0 && gx >= 0)
+			v = C[x - f.sC];
+		L.CT(pl, -1, x) = v;
+	} else if (lane >= 32 && lane < 48) {
+		int pl = (lane - 32) >> 3, y = lane & 7;
+		const uint8_t *C = plane_base(f, f.cur, 1 + pl) + (size_t)(mby * 8) * f.sC + mbx * 8;
+		L.CT(pl, y, -1) = mbx > 0 ? C[(size_t)y * f.sC - 1] : 0;
+	}
+	wave_sync();
+}
+
+// one 4x4 block, lanes 0..15 = (y = lane>>2, x = lane&3); reads/writes the luma tile
+__device__ __forceinline__ int intra4x4_px(const WaveLds &L, int X0, int Y0, int mode, int x, int y)
+{
+#define T(i) ((int)L.YT(Y0 - 1, X0 + (i)))
+#define Lf(i) ((int)L.YT(Y0 + (i), X0 - 1))
+#define TR(i) ((i) < 4 || has_tr ? T(i) : T(3))
+	const bool has_tr = (mode == 6 || mode == 11);
+	switch (mode) {
+	default:
+	case 0: return T(x);
+	case 1: return Lf(y);
+	case 2: return (T(0) + T(1) + T(2) + T(3) + Lf(0) + Lf(1) + Lf(2) + Lf(3) + 4) >> 3;
+	case 3: return (T(0) + T(1) + T(2) + T(3) + 2) >> 2;
+	case 4: return (Lf(0) + Lf(1) + Lf(2) + Lf(3) + 2) >> 2;
+	case 5: return 128;
+	case 6: case 7:
+		return (x == 3 && y == 3) ? (TR(6) + 3 * TR(7) + 2) >> 2 : LP(TR(x + y), TR(x + y + 1), TR(x + y + 2));
+	case 8:
+		if (x > y) return LP(T(x - y - 2), T(x - y - 1), T(x - y));
+		if (x < y) return LP(y - x - 2 < 0 ? T(-1) : Lf(y - x - 2), Lf(y - x - 1), Lf(y - x));
+		return LP(T(0), T(-1), Lf(0));
+	case 9: {
+		int z = 2 * x - y, i = x - (y >> 1);
+		if (z >= 0 && !(z & 1)) return (T(i - 1) + T(i) + 1) >> 1;
+		if (z >= 0) return LP(T(i - 2), T(i - 1), T(i));
+		if (z == -1) return LP(Lf(0), T(-1), T(0));
+		return LP(Lf(y - 1), Lf(y - 2), y - 3 < 0 ? T(-1) : Lf(y - 3)); }
+	case 10: {
+		int z = 2 * y - x, i = y - (x >> 1);
+#define L_(j) ((j) < 0 ? T(-1) : Lf(j))
+		if (z >= 0 && !(z & 1)) return (L_(i - 1) + L_(i) + 1) >> 1;
+		if (z >= 0) return LP(L_(i - 2), L_(i - 1), L_(i));
+		if (z == -1) return LP(Lf(0), T(-1), T(0));
+		return LP(T(x - 1), T(x - 2), T(x - 3));
+#undef L_
+		}
+	case 11: case 12: {
+		int i = x + (y >> 1);
+		return (y & 1) ? LP(TR(i), TR(i + 1), TR(i + 2)) : (TR(i) + TR(i + 1) + 1) >> 1; }
+	case 13: {
+		int z = x + 2 * y, i = y + (x >> 1);
+		if (z > 5) return Lf(3);
+		if (z == 5) return (Lf(2) + 3 * Lf(3) + 2) >> 2;
+		if (z & 1) return LP(Lf(i), Lf(i + 1), Lf(i + 2));
+		return (Lf(i) + Lf(i + 1) + 1) >> 1; }
+	}
+#undef T
+#undef Lf
+#undef TR
+}
+
+__constant__ int8_t c_i8spec[32] = {0, 0, 0, 0, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 5, 5, 6, 7, 7, 7, 7, 8, 8};
+__constant__ int8_t c_i8unav[32] = {0, 4, 8, 12, 0, 8, 0, 1, 5, 9, 13, 2, 10, 4, 8, 12, 3, 0, 4, 8, 12, 0, 4, 0, 4, 0, 0, 4, 8, 12, 0, 8};
+
+// one 8x8 block: all 64 lanes = (y = lane>>3, x = lane&7).  8.3.2.2.1 filtering into L.ftop/L.fleft first.
+__device__ void intra8x8_block(WaveLds &L, int X0, int Y0, int mode, int lane)
+{
+	const int sm = c_i8spec[mode], un = c_i8unav[mode];
+	const bool useA = !(un & 1) && (sm == 1 || sm == 2 || sm == 4 || sm == 5 || sm == 6 || sm == 8);
+	const bool useB = !(un & 2) && (sm == 0 || sm == 2 || sm == 3 || sm == 4 || sm == 5 || sm == 6 || sm == 7);
+	const bool useC = useB && !(un & 4) && sm != 6;
+	const bool cornerAvail = !(un & 8) && (useA || useB);
+#define T(i) ((int)L.YT(Y0 - 1, X0 + (i)))
+#define TC(i) ((i) < 8 || useC ? T(i) : T(7))
+#define Lf(i) ((int)L.YT(Y0 + (i), X0 - 1))
+	if (lane < 16) { // filtered top ft[0..15]
+		int i = lane, v = 0;
+		if (useB) {
+			if (i == 0) v = cornerAvail ? LP(T(-1), T(0), T(1)) : (3 * T(0) + T(1) + 2) >> 2;
+			else if (i == 15) v = (TC(14) + 3 * TC(15) + 2) >> 2;
+			else v = LP(TC(i - 1), TC(i), TC(i + 1));
+		}
+		L.ftop[i + 1] = (uint8_t)v;
+	} else if (lane < 24) { // filtered left
+		int i = lane - 16, v = 0;
+		if (useA) {
+			if (i == 0) v = cornerAvail ? LP(T(-1), Lf(0), Lf(1)) : (3 * Lf(0) + Lf(1) + 2) >> 2;
+			else if (i == 7) v = (Lf(6) + 3 * Lf(7) + 2) >> 2;
+			else v = LP(Lf(i - 1), Lf(i), Lf(i + 1));
+		}
+		L.fleft[i] = (uint8_t)v;
+	} else if (lane == 24) {
+		int v = 0;
+		if (cornerAvail) {
+			if (!useB) v = (3 * T(-1) + Lf(0) + 2) >> 2;
+			else if (!useA) v = (3 * T(-1) + T(0) + 2) >> 2;
+			else v = LP(T(0), T(-1), Lf(0));
+		}
+		L.ftop[0] = (uint8_t)v;
+	}
+#undef T
+#undef TC
+#undef Lf
+	wave_sync();
+	const int x = lane & 7, y = lane >> 3;
+#define FT(i) ((int)L.ftop[(i) + 1])
+#define FL(i) ((i) < 0 ? (int)L.ftop[0] : (int)L.fleft[i])
+	int v;
+	if (mode == 16) v = 128;
+	else switch (sm) {
+	default:
+	case 0: v = FT(x); break;
+	case 1: v = FL(y); break;
+	case 2: {
+		int st = 0, sl = 0;
+#pragma unroll
+		for (int i = 0; i < 8; i++) { st += FT(i); sl += FL(i); }
+		v = useA && useB ? (st + sl + 8) >> 4 : useB ? (st + 4) >> 3 : useA ? (sl + 4) >> 3 : 128;
+		} break;
+	case 3: v = (x == 7 && y == 7) ? (FT(14) + 3 * FT(15) + 2) >> 2 : LP(FT(x + y), FT(x + y + 1), FT(x + y + 2)); break;
+	case 4:
+		if (x > y) v = LP(FT(x - y - 2), FT(x - y - 1), FT(x - y));
+		else if (x < y) v = LP(FL(y - x - 2), FL(y - x - 1), FL(y - x));
+		else v = LP(FT(0), FT(-1), FL(0));
+		break;
+	case 5: {
+		int z = 2 * x - y, i = x - (y >> 1);
+		if (z >= 0 && !(z & 1)) v = (FT(i - 1) + FT(i) + 1) >> 1;
+		else if (z >= 0) v = LP(FT(i - 2), FT(i - 1), FT(i));
+		else if (z == -1) v = LP(FL(0), FT(-1), FT(0));
+		else v = LP(FL(y - 2 * x - 1), FL(y - 2 * x - 2), FL(y - 2 * x - 3));
+		} break;
+	case 6: {
+		int z = 2 * y - x, i = y - (x >> 1);
+		if (z >= 0 && !(z & 1)) v = (FL(i - 1) + FL(i) + 1) >> 1;
+		else if (z >= 0) v = LP(FL(i - 2), FL(i - 1), FL(i));
+		else if (z == -1) v = LP(FL(0), FT(-1), FT(0));
+		else v = LP(FT(x - 2 * y - 1), FT(x - 2 * y - 2), FT(x - 2 * y - 3));
+		} break;
+	case 7: {
+		int i = x + (y >> 1);
+		v = (y & 1) ? LP(FT(i), FT(i + 1), FT(i + 2)) : (FT(i) + FT(i + 1) + 1) >> 1;
+		} break;
+	case 8: {
+		int z = x + 2 * y, i = y + (x >> 1);
+		if (z > 13) v = FL(7);
+		else if (z == 13) v = (FL(6) + 3 * FL(7) + 2) >> 2;
+		else if (z & 1) v = LP(FL(i), FL(i + 1), FL(i + 2));
+		else v = (FL(i) + FL(i + 1) + 1) >> 1;
+		} break;
+	}
+#undef FT
+#undef FL
+	// add residual (add_idct8x8 tail, residual.c:318-342) and write the tile
+	int rres = L.res[(Y0 + y) * 16 + X0 + x];
+	wave_sync();
+	L.YT(Y0 + y, X0 + x) = (uint8_t)clip255(w16(v + rres));
+	wave_sync();
+}
+
+// Intra 16x16 in the pixel layout: returns 4 predicted samples for (row Yr, cols X..X+3)
+__device__ void intra16x16_pred(const WaveLds &L, int mode, int X, int Yr, int out[4])
+{
+#define T(i) ((int)L.YT(-1, (i)))
+#define Lf(i) ((int)L.YT((i), -1))
+	switch (mode) {
+	default:
+	case 0: for (int i = 0; i < 4; i++) out[i] = T(X + i); return;
+	case 1: for (int i = 0; i < 4; i++) out[i] = Lf(Yr); return;
+	case 2: case 3: case 4: case 5: {
+		int st = 0, sl = 0;
+		if (mode == 2 || mode == 3) for (int i = 0; i < 16; i++) st += T(i);
+		if (mode == 2 || mode == 4) for (int i = 0; i < 16; i++) sl += Lf(i);
+		int v = mode == 2 ? (st + sl + 16) >> 5 : mode == 3 ? (st + 8) >> 4 : mode == 4 ? (sl + 8) >> 4 : 128;
+		for (int i = 0; i < 4; i++) out[i] = v;
+		return; }
+	case 6: {
+		int Hh = 0, V = 0;
+		for (int i = 0; i < 8; i++) {
+			Hh += (i + 1) * (T(8 + i) - (i == 7 ? T(-1) : T(6 - i)));
+			V += (i + 1) * (Lf(8 + i) - (i == 7 ? T(-1) : Lf(6 - i)));
+		}
+		int a = 16 * (Lf(15) + T(15)), b = (5 * Hh + 32) >> 6, c = (5 * V + 32) >> 6;
+		for (int i = 0; i < 4; i++) out[i] = clip255((a + b * (X + i - 7) + c * (Yr - 7) + 16) >> 5);
+		return; }
+	}
+#undef T
+#undef Lf
+}
+
+// Intra chroma for plane p, sample (x,y)
+__device__ int intra_chroma_px(const WaveLds &L, int p, int mode, int x, int y)
+{
+#define T(i) ((int)L.CT(p, -1, (i)))
+#define Lf(i) ((int)L.CT(p, (i), -1))
+	switch (mode) {
+	default:
+	case 0: case 1: case 2: case 3: {
+		if (mode == 3) return 128;
+		int bx = x >> 2, by = y >> 2;
+		int t = 0, l = 0;
+		for (int i = 0; i < 4; i++) { t += T(bx * 4 + i); l += Lf(by * 4 + i); }
+		if (mode == 1) return (t + 2) >> 2;
+		if (mode == 2) return (l + 2) >> 2;
+		if (bx == by) return (t + l + 4) >> 3;
+		return bx ? (t + 2) >> 2 : (l + 2) >> 2; }
+	case 4: return Lf(y);
+	case 5: return T(x);
+	case 6: {
+		int Hh = 0, V = 0;
+		for (int i = 0; i < 4; i++) {
+			Hh += (i + 1) * (T(4 + i) - (i == 3 ? T(-1) : T(2 - i)));
+			V += (i + 1) * (Lf(4 + i) - (i == 3 ? T(-1) : Lf(2 - i)));
+		}
+		int a = 16 * (Lf(7) + T(7)), b = (34 * Hh + 32) >> 6, c = (34 * V + 32) >> 6;
+		return clip255((a + b * (x - 3) + c * (y - 3) + 16) >> 5); }
+	}
+#undef T
+#undef Lf
+}
+
+// ---------------------------------------------------------------------------------
+// reconstruction of one macroblock by one wave
+// ---------------------------------------------------------------------------------
+__device__ void recon_mb(WaveLds &L, const FrameCtx &f, int mbx, int mby, int lane)
+{
+	const E264Mb m = f.mbs[mby * f.wm + mbx];
+	if (m.kind == E264_MB_ABSENT)
+		return;
+	const E264SliceParams *s = f.slices + m.slice;
+	const uint8_t *pl = f.payload + m.payload_off;
+	// pixel layout
+	const int k = lane >> 2, r = lane & 3;
+	const int X = BXf(k), Yr = BYf(k) + r;
+	uint8_t *dY = f.cur + (size_t)(mby * 16 + Yr) * f.sY + mbx * 16 + X;
+	const int cpl = lane >> 5, cy = (lane >> 2) & 7, cx = (lane & 3) * 2;
+	uint8_t *dC = plane_base(f, f.cur, 1 + cpl) + (size_t)(mby * 8 + cy) * f.sC + mbx * 8 + cx;
+
+	if (m.kind == E264_MB_PCM) { // edge264_slice.c:914-935
+		*(uint32_t *)dY = *(const uint32_t *)(pl + Yr * 16 + X);
+		*(uint16_t *)dC = *(const uint16_t *)(pl + 256 + cpl * 64 + cy * 8 + cx);
+		return;
+	}
+	const E264Motion *mo = nullptr;
+	if (m.kind == E264_MB_INTER) { mo = (const E264Motion *)pl; pl += sizeof(E264Motion); }
+	compute_residual(L, f, m, s, pl, lane);
+
+	int pY[4], pC[2];
+	bool tile_luma = false;
+	if (m.kind == E264_MB_INTER) {
+		inter_pred_mb(f, s, mo, mbx, mby, lane, pY, pC);
+	} else {
+		load_intra_neighbours(L, f, mbx, mby, lane);
+		if (m.kind == E264_MB_I16x16) {
+			intra16x16_pred(L, m.i16_mode, X, Yr, pY);
+		} else if (m.kind == E264_MB_I4x4) { // edge264_slice.c:615-635: predict, add residual, next block
+			tile_luma = true;
+			for (int b = 0; b < 16; b++) {
+				int mode = m.modes[b >> 1] >> (4 * (b & 1)) & 15;
+				int X0 = BXf(b), Y0 = BYf(b);
+				int v = 0;
+				if (lane < 16) {
+					int x = lane & 3, y = lane >> 2;
+					v = intra4x4_px(L, X0, Y0, mode, x, y);
+					v = clip255(w16(v + L.res[(Y0 + y) * 16 + X0 + x]));
+				}
+				wave_sync();
+				if (lane < 16)
+					L.YT(Y0 + (lane >> 2), X0 + (lane & 3)) = (uint8_t)v;
+				wave_sync();
+			}
+		} else { // I8x8, edge264_slice.c:645-668
+			tile_luma = true;
+			for (int b = 0; b < 4; b++)
+				intra8x8_block(L, BXf(b * 4), BYf(b * 4), m.modes[b], lane);
+		}
+		pC[0] = intra_chroma_px(L, cpl, m.chroma_mode, cx, cy);
+		pC[1] = intra_chroma_px(L, cpl, m.chroma_mode, cx + 1, cy);
+	}
+	// add residual, clip, store (int16 wrap add then packus: residual.c:160-171)
+	uint32_t outw;
+	if (tile_luma) {
+		outw = *(const uint32_t *)&L.YT(Yr, X);
+	} else {
+		const int16_t *rr = L.res + Yr * 16 + X;
+		outw = (uint32_t)clip255(w16(pY[0] + rr[0])) | (uint32_t)clip255(w16(pY[1] + rr[1])) << 8 |
+			(uint32_t)clip255(w16(pY[2] + rr[2])) << 16 | (uint32_t)clip255(w16(pY[3] + rr[3])) << 24;
+	}
+	*(uint32_t *)dY = outw;
+	const int16_t *rc = L.res + 256 + cpl * 64 + cy * 8 + cx;
+	*(uint16_t *)dC = (uint16_t)(clip255(w16(pC[0] + rc[0])) | clip255(w16(pC[1] + rc[1])) << 8);
+}
+
+// ---------------------------------------------------------------------------------
+// deblocking of one macroblock by one wave
+// ---------------------------------------------------------------------------------
+struct BlkMo { int ref0, ref1, mv0x, mv0y, mv1x, mv1y; };
+__device__ __forceinline__ BlkMo blk_motion(const FrameCtx &f, const E264Mb *m, int k)
+{
+	BlkMo o = {-1, -1, 0, 0, 0, 0};
+	if (m->kind == E264_MB_INTER) {
+		const E264Motion *mo = (const E264Motion *)(f.payload + m->payload_off);
+		o.ref0 = mo->refPic[k >> 2]; o.ref1 = mo->refPic[4 + (k >> 2)];
+		o.mv0x = mo->mvs[k * 2]; o.mv0y = mo->mvs[k * 2 + 1];
+		o.mv1x = mo->mvs[32 + k * 2]; o.mv1y = mo->mvs[32 + k * 2 + 1];
+	}
+	return o;
+}
+__device__ __forceinline__ int far4(int ax, int ay, int bx, int by) { return (abs(ax - bx) >= 4) | (abs(ay - by) >= 4); }
+
+__device__ int mb_bs_lane(const FrameCtx &f, const E264Mb *m, int lane)
+{ // lane -> (dir, edge, segment); edge264_deblock.c:958-1118
+	const int dir = lane >> 4 & 1, e = lane >> 2 & 3, sg = lane & 3;
+	const bool intra = m->kind != E264_MB_INTER;
+	const E264Mb *n = m;
+	if (e == 0) {
+		if (!(m->flags & (dir ? E264_MBF_EDGE_TOP : E264_MBF_EDGE_LEFT)))
+			return 0;
+		n = dir ? m - f.wm : m - 1;
+	} else if ((m->flags & E264_MBF_T8x8) && (e & 1)) {
+		return 0;
+	}
+	if (e == 0 && (intra || n->kind != E264_MB_INTER)) return 4;
+	if (intra) return 3;
+	int kq = dir ? blk_of(sg, e) : blk_of(e, sg);
+	int kp = dir ? blk_of(sg, (e + 3) & 3) : blk_of((e + 3) & 3, sg);
+	if ((n->nz_mask >> kp & 1) | (m->nz_mask >> kq & 1)) return 2;
+	BlkMo p = blk_motion(f, n, kp), q = blk_motion(f, m, kq);
+	int refs_p = (p.ref0 != q.ref0) | (p.ref1 != q.ref1);
+	int refs_c = (p.ref0 != q.ref1) | (p.ref1 != q.ref0);
+	int mvs_p = far4(p.mv0x, p.mv0y, q.mv0x, q.mv0y) | far4(p.mv1x, p.mv1y, q.mv1x, q.mv1y);
+	int mvs_c = far4(p.mv0x, p.mv0y, q.mv1x, q.mv1y) | far4(p.mv1x, p.mv1y, q.mv0x, q.mv0y);
+	return (refs_p | mvs_p) & (refs_c | mvs_c);
+}
+
+__device__ __forceinline__ void filter_luma(uint8_t *q0p, int step, int bS, int alpha, int beta, int tc0)
+{
+	int p0 = q0p[-step], p1 = q0p[-2 * step], p2 = q0p[-3 * step], p3 = q0p[-4 * step];
+	int q0 = q0p[0], q1 = q0p[step], q2 = q0p[2 * step], q3 = q0p[3 * step];
+	if (!(abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta))
+		return;
+	int ap = abs(p2 - p0), aq = abs(q2 - q0);
+	if (bS < 4) {
+		int tc = tc0 + (ap < beta) + (aq < beta);
+		int delta = clip3i(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
+		q0p[-step] = (uint8_t)clip255(p0 + delta);
+		q0p[0] = (uint8_t)clip255(q0 - delta);
+		if (ap < beta) q0p[-2 * step] = (uint8_t)(p1 + clip3i(-tc0, tc0, (p2 + ((p0 + q0 + 1) >> 1) - 2 * p1) >> 1));
+		if (aq < beta) q0p[step] = (uint8_t)(q1 + clip3i(-tc0, tc0, (q2 + ((p0 + q0 + 1) >> 1) - 2 * q1) >> 1));
+	} else {
+		bool small = abs(p0 - q0) < (alpha >> 2) + 2;
+		if (ap < beta && small) {
+			q0p[-step] = (uint8_t)((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+			q0p[-2 * step] = (uint8_t)((p2 + p1 + p0 + q0 + 2) >> 2);
+			q0p[-3 * step] = (uint8_t)((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+		} else q0p[-step] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2);
+		if (aq < beta && small) {
+			q0p[0] = (uint8_t)((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
+			q0p[step] = (uint8_t)((p0 + q0 + q1 + q2 + 2) >> 2);
+			q0p[2 * step] = (uint8_t)((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3);
+		} else q0p[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
+	}
+}
+__device__ __forceinline__ void filter_chroma(uint8_t *q0p, int step, int bS, int alpha, int beta, int tc0)
+{
+	int p0 = q0p[-step], p1 = q0p[-2 * step], q0 = q0p[0], q1 = q0p[step];
+	if (!(abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta))
+		return;
+	if (bS < 4) {
+		int tc = tc0 + 1;
+		int delta = clip3i(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
+		q0p[-step] = (uint8_t)clip255(p0 + delta);
+		q0p[0] = (uint8_t)clip255(q0 - delta);
+	} else {
+		q0p[-step] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2);
+		q0p[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
+	}
+}
+
+__device__ void deblock_mb(WaveLds &L, const FrameCtx &f, int mbx, int mby, int lane)
+{
+	const E264Mb *m = f.mbs + mby * f.wm + mbx;
+	if (!(m->flags & E264_MBF_DEBLOCK) || m->kind == E264_MB_ABSENT)
+		return;
+	const E264SliceParams *s = f.slices + m->slice;
+	const bool hasL = m->flags & E264_MBF_EDGE_LEFT, hasT = m->flags & E264_MBF_EDGE_TOP;
+	// boundary strengths: lanes 0..31
+	if (lane < 32)
+		L.bs[lane] = (uint8_t)mb_bs_lane(f, m, lane);
+	// load tiles: luma rows -4..15 x 5 dwords (cols -4..15): 100 dwords; chroma 2 x 12 rows x 3 dwords = 72
+	uint8_t *Yb = f.cur + (size_t)(mby * 16) * f.sY + mbx * 16;
+	for (int i = lane; i < 100; i += 64) {
+		int row = i / 5 - 4, col = (i % 5) * 4 - 4;
+		bool ok = (row >= 0 || hasT) && (col >= 0 || hasL);
+		uint32_t v = 0;
+		if (ok) v = *(const uint32_t *)(Yb + (ptrdiff_t)row * f.sY + col);
+		*(uint32_t *)&L.DYT(row, col) = v;
+	}
+	for (int i = lane; i < 72; i += 64) {
+		int p = i / 36, j = i % 36;
+		int row = j / 3 - 4, col = (j % 3) * 4 - 4;
+		uint8_t *Cb = plane_base(f, f.cur, 1 + p) + (size_t)(mby * 8) * f.sC + mbx * 8;
+		bool ok = (row >= 0 || hasT) && (col >= 0 || hasL);
+		uint32_t v = 0;
+		if (ok) v = *(const uint32_t *)(Cb + (ptrdiff_t)row * f.sC + col);
+		*(uint32_t *)&L.DCT(p, row, col) = v;
+	}
+	wave_sync();
+	// lane roles for edge filtering: 0..15 luma line, 16..23 Cb line, 24..31 Cr line
+	const int pl = lane < 16 ? 0 : lane < 24 ? 1 : 2;
+	const int li = lane < 16 ? lane : (lane & 7);
+	const int qpc = m->qp[pl];
+#pragma unroll 1
+	for (int dir = 0; dir < 2; dir++) {
+#pragma unroll 1
+		for (int e = 0; e < 4; e++) {
+			if (lane < 32 && !(pl && (e & 1))) {
+				const E264Mb *n = m;
+				bool skip = false;
+				if (e == 0) {
+					if (!(dir ? hasT : hasL)) skip = true;
+					else n = dir ? m - f.wm : m - 1;
+				} else if (!pl && (m->flags & E264_MBF_T8x8) && (e & 1)) skip = true;
+				if (!skip) {
+					int b = L.bs[dir * 16 + e * 4 + (pl ? li >> 1 : li >> 2)];
+					if (b) {
+						int qPav = (qpc + n->qp[pl] + 1) >> 1;
+						int iA = clip3i(0, 51, qPav + s->FilterOffsetA), iB = clip3i(0, 51, qPav + s->FilterOffsetB);
+						int alpha = c_alpha[iA], beta = c_beta[iB];
+						int tc0 = b < 4 ? c_tc0[b - 1][iA] : 0;
+						if (pl == 0) {
+							uint8_t *q0 = dir ? &L.DYT(e * 4, li) : &L.DYT(li, e * 4);
+							filter_luma(q0, dir ? DY_STRIDE : 1, b, alpha, beta, tc0);
+						} else {
+							uint8_t *q0 = dir ? &L.DCT(pl - 1, e * 2, li) : &L.DCT(pl - 1, li, e * 2);
+							filter_chroma(q0, dir ? DC_STRIDE : 1, b, alpha, beta, tc0);
+						}
+					}
+				}
+			}
+			wave_sync();
+		}
+	}
+	// write back what this macroblock may have modified (its own samples, 3 columns / rows of neighbours)
+	for (int i = lane; i < 100; i += 64) {
+		int row = i / 5 - 4, col = (i % 5) * 4 - 4;
+		bool ok = (row >= 0 || hasT) && (col >= 0 || hasL) && !(row < 0 && col < 0);
+		if (ok) *(uint32_t *)(Yb + (ptrdiff_t)row * f.sY + col) = *(const uint32_t *)&L.DYT(row, col);
+	}
+	for (int i = lane; i < 72; i += 64) {
+		int p = i / 36, j = i % 36;
+		int row = j / 3 - 4, col = (j % 3) * 4 - 4;
+		uint8_t *Cb = plane_base(f, f.cur, 1 + p) + (size_t)(mby * 8) * f.sC + mbx * 8;
+		bool ok = (row >= 0 || hasT) && (col >= 0 || hasL) && !(row < 0 && col < 0);
+		if (ok) *(uint32_t *)(Cb + (ptrdiff_t)row * f.sC + col) = *(const uint32_t *)&L.DCT(p, row, col);
+	}
+	wave_sync();
+}
+
+// ---------------------------------------------------------------------------------
+// frame kernel: one workgroup per job, NW waves, wavefront over macroblock rows
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int lds_load_relaxed(const int *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ bool open_frame(FrameCtx &f, const E264Job &job)
+{
+	const uint8_t *pkt = job.packet;
+	const E264FrameHdr *h = (const E264FrameHdr *)pkt;
+	if (h->magic != E264_MAGIC || h->version != E264_VERSION)
+		return false;
+	f.h = h;
+	f.slices = (const E264SliceParams *)(pkt + h->slices_off);
+	f.mbs = (const E264Mb *)(pkt + h->mbs_off);
+	f.payload = pkt + h->payload_off;
+	f.dpb = job.dpb;
+	f.cur = job.dpb[h->dst_slot];
+	f.wm = h->width_mbs; f.hm = h->height_mbs;
+	f.W = f.wm * 16; f.H = f.hm * 16;
+	f.sY = (int)h->stride_Y; f.sC = (int)h->stride_C;
+	f.psY = h->plane_size_Y;
+	return f.cur != nullptr;
+}
+
+#define E264_MAX_ROWS 1056
+} // namespace
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void e264_frame_kernel(const E264Job *jobs, int mode)
+{
+	__shared__ WaveLds lds[NW];
+	__shared__ int progress[2][E264_MAX_ROWS]; // macroblocks finished per row, per pass
+	const int lane = lane_id();
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	FrameCtx f;
+	if (!open_frame(f, jobs[blockIdx.x]))
+		return;
+	for (int i = threadIdx.x; i < 2 * E264_MAX_ROWS; i += NW * 64)
+		(&progress[0][0])[i] = 0;
+	__syncthreads();
+	WaveLds &L = lds[wave];
+#pragma unroll 1
+	for (int pass = 0; pass < 2; pass++) {
+		if (!(mode & (1 << pass)))
+			continue;
+		int *prog = progress[pass];
+#pragma unroll 1
+		for (int y = wave; y < f.hm; y += NW) {
+#pragma unroll 1
+			for (int x = 0; x < f.wm; x++) {
+				bool need = y > 0;
+				if (pass == 0)
+					need = need && f.mbs[y * f.wm + x].kind != E264_MB_INTER; // inter MBs depend on nothing in this frame
+				if (need) {
+					int want = min(x + 2, f.wm);
+					while (lds_load_relaxed(&prog[y - 1]) < want)
+						__builtin_amdgcn_s_sleep(2);
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				}
+				if (pass == 0) recon_mb(L, f, x, y, lane);
+				else deblock_mb(L, f, x, y, lane);
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				if (lane == 0)
+					__hip_atomic_store(&prog[y], x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+		}
+		__syncthreads();
+	}
+}
+
+extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int mode, int waves, hipStream_t stream)
+{
+	if (n_jobs <= 0)
+		return hipSuccess;
+	switch (waves) {
+	case 4: hipLaunchKernelGGL(e264_frame_kernel<4>, dim3(n_jobs), dim3(256), 0, stream, jobs, mode); break;
+	case 16: hipLaunchKernelGGL(e264_frame_kernel<16>, dim3(n_jobs), dim3(1024), 0, stream, jobs, mode); break;
+	default: hipLaunchKernelGGL(e264_frame_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs, mode); break;
+	}
+	return hipGetLastError();
+}

@@ -1,0 +1,100 @@
+/*
+ * edge264_hip.h -- C ABI of the MI355X macroblock-reconstruction back end
+ * (libedge264_hip.so, built from edge264_amd/csrc/ with hipcc for gfx950).
+ *
+ * This is the drop-in boundary of BASELINE.json's north_star: everything that
+ * touches the BITSTREAM (CAVLC/CABAC, mvpred, DPB bookkeeping) stays in the
+ * edge264 C front end; everything that touches SAMPLES is behind these entry
+ * points.  Plain pointers and sizes only -- what a C front end (or cgo / JNI /
+ * ctypes) binds.  Each function names the reference interface it replaces
+ * (/root/reference, file:line).  INTEGRATION.md shows the reference-side glue.
+ *
+ * Threading: a E264Device may be shared by threads; one E264Stream (= one
+ * Edge264Decoder) is driven by one thread at a time, like the reference's
+ * n_threads==0 mode (src/edge264_headers.c:1285-1286).
+ * Errors: 0 or a positive errno value like the reference (src/edge264_internal.h:1259-1263):
+ * ENOMEM (device/pinned allocation), EINVAL (bad packet/slot), EIO (HIP runtime failure),
+ * ENODEV (no gfx950 device).  Nothing aborts.
+ */
+#ifndef EDGE264_HIP_H
+#define EDGE264_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "edge264_cmd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct E264Device E264Device; /* one per GPU: HIP stream, kernels, staging */
+typedef struct E264Stream E264Stream; /* one per decoder: device DPB slots + host mirrors */
+
+/* ---- device ------------------------------------------------------------ */
+/* Selected in edge264_alloc where the reference picks its ISA variant
+ * (src/edge264.c:161-216): open once per GPU, share between decoders. */
+int  e264hip_device_open(int ordinal, E264Device **out);
+void e264hip_device_close(E264Device *dev);
+int  e264hip_device_sync(E264Device *dev);
+const char *e264hip_last_error(void);
+
+/* ---- decoder-side objects ---------------------------------------------- */
+int  e264hip_stream_open(E264Device *dev, E264Stream **out);
+void e264hip_stream_close(E264Stream *s);
+
+/* Frame memory.  Replaces Edge264AllocCb / Edge264FreeCb (edge264.h:42-43; called from
+ * alloc_frame, src/edge264_headers.c:113-133): the samples of DPB slot `slot` live in
+ * HBM; *host_mirror (pinned, samples_bytes) is what Edge264Frame.samples will point
+ * into (src/edge264.c:385-387) once e264hip_frame_download has run. */
+int  e264hip_frame_alloc(E264Stream *s, int slot, size_t samples_bytes, void **host_mirror);
+void e264hip_frame_free(E264Stream *s, int slot);
+/* "non-existing" frames of frame_num gaps (src/edge264_headers.c:1122-1144) and tests */
+int  e264hip_frame_fill(E264Stream *s, int slot, int value);
+int  e264hip_frame_upload(E264Stream *s, int slot, const void *src, size_t bytes);
+
+/* Submit one coded frame.  Replaces the sample-writing half of the per-slice worker
+ * (worker_loop, src/edge264_headers.c:450-603: every decode_intra / decode_inter / add_idct /
+ * deblock_mb call issued by parse_slice_data, src/edge264_slice.c:1651-1849).  `packet` is a
+ * host buffer (ideally from e264hip_packet_buffer, pinned); the call enqueues the H2D copy
+ * and the kernels on the device queue and returns without waiting. */
+int  e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes);
+/* Pinned staging memory for the emitters, recycled when the copy has been consumed. */
+void *e264hip_packet_buffer(E264Stream *s, size_t max_bytes);
+
+/* Readiness test of edge264_get_frame (next_deblock_addr[pic]==INT_MAX, src/edge264.c:373)
+ * becomes "the kernels that write this slot have completed". */
+int  e264hip_frame_wait(E264Stream *s, int slot);
+/* Copy the finished frame to its host mirror (what get_frame hands out). */
+int  e264hip_frame_download(E264Stream *s, int slot, void *dst, size_t bytes);
+/* edge264_flush (src/edge264.c:261-270): drain the queue, keep allocations. */
+int  e264hip_stream_flush(E264Stream *s);
+
+/* ---- batched, device-resident replay (multi-stream front end, benchmarking) ---- */
+/* Uploads a packet once; the handle can then be replayed any number of times with the
+ * command bytes already resident in HBM (bench.py's timed region). */
+typedef struct E264Packet E264Packet;
+int  e264hip_packet_upload(E264Device *dev, const void *packet, size_t bytes, E264Packet **out);
+void e264hip_packet_free(E264Packet *p);
+/* One launch over n (stream, packet) pairs: frame i of every stream.  All streams must be
+ * distinct.  mode: E264_RUN_* bits. */
+#define E264_RUN_RECON   1
+#define E264_RUN_DEBLOCK 2
+#define E264_RUN_ALL     3
+int  e264hip_submit_batch(E264Device *dev, E264Stream *const *streams, E264Packet *const *packets, int n, int mode);
+
+/* Timing on the queue the kernels run on (hipEvents; torch.cuda.Event would only see
+ * torch's own stream).  Slots 0..15. */
+int  e264hip_event_record(E264Device *dev, int idx);
+int  e264hip_event_elapsed_ms(E264Device *dev, int idx_start, int idx_stop, float *ms);
+/* Accumulated time of the dominant kernel measured with events around every launch
+ * (only when enabled; adds a sync-free event pair per launch). */
+int  e264hip_kernel_timing(E264Device *dev, int enable);
+int  e264hip_kernel_time_ms(E264Device *dev, double *total_ms, int *launches);
+
+/* Tunables (waves per frame workgroup etc.); returns the previous value, -1 if unknown. */
+int  e264hip_set_option(E264Device *dev, const char *name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
