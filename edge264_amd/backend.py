@@ -54,6 +54,9 @@ def load_library():
         "e264hip_packet_upload": (i, [vp, vp, sz, C.POINTER(vp)]),
         "e264hip_packet_free": (None, [vp]),
         "e264hip_submit_batch": (i, [vp, C.POINTER(vp), C.POINTER(vp), i, i]),
+        "e264hip_batch_create": (i, [vp, C.POINTER(vp), C.POINTER(vp), i, C.POINTER(vp)]),
+        "e264hip_batch_submit": (i, [vp, i]),
+        "e264hip_batch_free": (None, [vp]),
         "e264hip_event_record": (i, [vp, i]),
         "e264hip_event_elapsed_ms": (i, [vp, i, i, C.POINTER(C.c_float)]),
         "e264hip_kernel_timing": (i, [vp, i]),
@@ -72,7 +75,7 @@ EXPORTED_SYMBOLS = [
     "e264hip_stream_open", "e264hip_stream_close", "e264hip_stream_flush", "e264hip_frame_alloc",
     "e264hip_frame_free", "e264hip_frame_fill", "e264hip_frame_upload", "e264hip_frame_submit",
     "e264hip_packet_buffer", "e264hip_frame_wait", "e264hip_frame_download", "e264hip_packet_upload",
-    "e264hip_packet_free", "e264hip_submit_batch", "e264hip_event_record", "e264hip_event_elapsed_ms",
+    "e264hip_packet_free", "e264hip_submit_batch", "e264hip_batch_create", "e264hip_batch_submit", "e264hip_batch_free", "e264hip_event_record", "e264hip_event_elapsed_ms",
     "e264hip_kernel_timing", "e264hip_kernel_time_ms", "e264hip_set_option",
 ]
 
@@ -114,12 +117,19 @@ class Device:
         _check(self.L, self.L.e264hip_submit_batch(self.h, sa, pa, n, mode), "submit_batch")
 
     def make_batch(self, streams, packets):
-        """Pre-marshalled argument arrays for repeated launches (bench inner loop)."""
+        """Device-resident job table for repeated launches (E264Batch)."""
         n = len(streams)
-        return ((C.c_void_p * n)(*[s.h for s in streams]), (C.c_void_p * n)(*[p.h for p in packets]), n)
+        sa = (C.c_void_p * n)(*[s.h for s in streams])
+        pa = (C.c_void_p * n)(*[p.h for p in packets])
+        b = C.c_void_p()
+        _check(self.L, self.L.e264hip_batch_create(self.h, sa, pa, n, C.byref(b)), "batch_create")
+        return b
 
     def submit_prepared(self, batch, mode: int = RUN_ALL) -> None:
-        _check(self.L, self.L.e264hip_submit_batch(self.h, batch[0], batch[1], batch[2], mode), "submit_batch")
+        _check(self.L, self.L.e264hip_batch_submit(batch, mode), "batch_submit")
+
+    def free_batch(self, batch) -> None:
+        self.L.e264hip_batch_free(batch)
 
     def event_record(self, idx: int) -> None:
         _check(self.L, self.L.e264hip_event_record(self.h, idx), "event_record")

@@ -39,9 +39,6 @@ struct E264Device {
 	hipStream_t q;
 	int waves;                 // macroblock rows in flight per frame workgroup
 	std::mutex lock;
-	// job table staging (pinned host + device), grown on demand
-	E264Job *h_jobs, *d_jobs;
-	int jobs_cap;
 	hipEvent_t ev[16];
 	// per-launch kernel timing
 	bool ktiming;
@@ -56,7 +53,7 @@ struct E264Stream {
 	void *mirror[E264_MAX_SLOTS];         // pinned host mirrors
 	size_t slot_bytes[E264_MAX_SLOTS];
 	// packet staging ring (pinned host) + device copies
-	struct Stage { void *h; uint8_t *d; size_t cap; hipEvent_t done; bool busy; } stage[4];
+	struct Stage { void *h; uint8_t *d; size_t cap; hipEvent_t done; bool busy; E264Job *d_job; } stage[4];
 	int stage_next;
 };
 
@@ -82,7 +79,6 @@ API int e264hip_device_open(int ordinal, E264Device **out)
 	if (!d) return fail(ENOMEM, "device object");
 	d->ordinal = ordinal;
 	d->waves = 8;
-	d->h_jobs = nullptr; d->d_jobs = nullptr; d->jobs_cap = 0;
 	d->ktiming = false; d->kev_used = 0;
 	if (hipSetDevice(ordinal) != hipSuccess || hipStreamCreateWithFlags(&d->q, hipStreamNonBlocking) != hipSuccess) {
 		delete d;
@@ -101,8 +97,6 @@ API void e264hip_device_close(E264Device *dev)
 	hipStreamSynchronize(dev->q);
 	for (int i = 0; i < 16; i++) hipEventDestroy(dev->ev[i]);
 	for (auto &p : dev->kev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-	if (dev->h_jobs) hipHostFree(dev->h_jobs);
-	if (dev->d_jobs) hipFree(dev->d_jobs);
 	hipStreamDestroy(dev->q);
 	delete dev;
 }
@@ -157,6 +151,7 @@ API void e264hip_stream_close(E264Stream *s)
 	for (auto &st : s->stage) {
 		if (st.h) hipHostFree(st.h);
 		if (st.d) hipFree(st.d);
+		if (st.d_job) hipFree(st.d_job);
 		if (st.done) hipEventDestroy(st.done);
 	}
 	hipFree(s->d_table);
@@ -230,29 +225,10 @@ static int check_packet(const void *packet, size_t bytes, int *dst)
 	return 0;
 }
 
-static int ensure_jobs(E264Device *dev, int n)
+// Launches the frame kernel over a job table that already lives in HBM.
+static int launch(E264Device *dev, const E264Job *d_jobs, int n, int mode)
 {
-	if (n <= dev->jobs_cap) return 0;
-	int cap = n < 64 ? 64 : n * 2;
-	if (dev->h_jobs) { hipStreamSynchronize(dev->q); hipHostFree(dev->h_jobs); hipFree(dev->d_jobs); dev->h_jobs = nullptr; dev->d_jobs = nullptr; dev->jobs_cap = 0; }
-	// 4 rotating job tables so that a launch never overwrites one still being read
-	HIPCHK(hipHostMalloc((void **)&dev->h_jobs, sizeof(E264Job) * cap * 4, hipHostMallocDefault), ENOMEM);
-	HIPCHK(hipMalloc((void **)&dev->d_jobs, sizeof(E264Job) * cap * 4), ENOMEM);
-	dev->jobs_cap = cap;
-	return 0;
-}
-
-static int launch(E264Device *dev, const E264Job *jobs_host, int n, int mode)
-{
-	static thread_local int rot = 0;
-	int r = ensure_jobs(dev, n);
-	if (r) return r;
 	std::lock_guard<std::mutex> g(dev->lock);
-	int slot = rot++ & 3;
-	E264Job *hj = dev->h_jobs + (size_t)slot * dev->jobs_cap;
-	E264Job *dj = dev->d_jobs + (size_t)slot * dev->jobs_cap;
-	memcpy(hj, jobs_host, sizeof(E264Job) * n);
-	HIPCHK(hipMemcpyAsync(dj, hj, sizeof(E264Job) * n, hipMemcpyHostToDevice, dev->q), EIO);
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (dev->ktiming) {
 		if (dev->kev_used == dev->kev.size()) {
@@ -264,7 +240,7 @@ static int launch(E264Device *dev, const E264Job *jobs_host, int n, int mode)
 		dev->kev_used++;
 		hipEventRecord(e0, dev->q);
 	}
-	HIPCHK(e264_launch_frames(dj, n, mode, dev->waves, dev->q), EIO);
+	HIPCHK(e264_launch_frames(d_jobs, n, mode, dev->waves, dev->q), EIO);
 	if (e1) hipEventRecord(e1, dev->q);
 	return 0;
 }
@@ -279,10 +255,11 @@ API void *e264hip_packet_buffer(E264Stream *s, size_t max_bytes)
 		if (st.d) hipFree(st.d);
 		st.h = nullptr; st.d = nullptr; st.cap = 0;
 		size_t cap = (max_bytes + 65535) & ~(size_t)65535;
-		if (hipHostMalloc(&st.h, cap, hipHostMallocDefault) != hipSuccess) { fail(ENOMEM, "pinned packet buffer"); return nullptr; }
+		if (hipHostMalloc(&st.h, cap + 64, hipHostMallocDefault) != hipSuccess) { fail(ENOMEM, "pinned packet buffer"); return nullptr; }
 		if (hipMalloc((void **)&st.d, cap) != hipSuccess) { hipHostFree(st.h); st.h = nullptr; fail(ENOMEM, "device packet buffer"); return nullptr; }
 		st.cap = cap;
 		if (!st.done) hipEventCreateWithFlags(&st.done, hipEventDisableTiming);
+		if (!st.d_job && hipMalloc((void **)&st.d_job, sizeof(E264Job)) != hipSuccess) { fail(ENOMEM, "job slot"); return nullptr; }
 	}
 	return st.h;
 }
@@ -303,8 +280,11 @@ API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
 	}
 	s->stage_next = (s->stage_next + 1) & 3;
 	HIPCHK(hipMemcpyAsync(st->d, st->h, bytes, hipMemcpyHostToDevice, s->dev->q), EIO);
-	E264Job job = {st->d, s->d_table};
-	r = launch(s->dev, &job, 1, E264_RUN_ALL);
+	// the job record rides at the tail of the pinned staging buffer's lifetime: tiny H2D on the same queue
+	E264Job *job = (E264Job *)((uint8_t *)st->h + st->cap); // pinned, lives as long as the staging slot
+	job->packet = st->d; job->dpb = s->d_table;
+	HIPCHK(hipMemcpyAsync(st->d_job, job, sizeof(*job), hipMemcpyHostToDevice, s->dev->q), EIO);
+	r = launch(s->dev, st->d_job, 1, E264_RUN_ALL);
 	if (r) return r;
 	hipEventRecord(st->done, s->dev->q);
 	st->busy = true;
@@ -355,18 +335,57 @@ API void e264hip_packet_free(E264Packet *p)
 	delete p;
 }
 
-API int e264hip_submit_batch(E264Device *dev, E264Stream *const *streams, E264Packet *const *packets, int n, int mode)
+struct E264Batch {
+	E264Device *dev;
+	E264Job *d_jobs;
+	int n;
+};
+
+API int e264hip_batch_create(E264Device *dev, E264Stream *const *streams, E264Packet *const *packets, int n, E264Batch **out)
 {
-	if (!dev || !streams || !packets || n <= 0) return fail(EINVAL, "submit_batch arguments");
+	if (!dev || !streams || !packets || !out || n <= 0) return fail(EINVAL, "batch_create arguments");
 	if (set_device(dev)) return EIO;
 	std::vector<E264Job> jobs((size_t)n);
 	for (int i = 0; i < n; i++) {
-		if (!streams[i] || !packets[i] || streams[i]->dev != dev || packets[i]->dev != dev) return fail(EINVAL, "submit_batch entry");
+		if (!streams[i] || !packets[i] || streams[i]->dev != dev || packets[i]->dev != dev) return fail(EINVAL, "batch entry");
 		if (!streams[i]->h_table[packets[i]->dst_slot]) return fail(EINVAL, "destination slot not allocated");
 		jobs[i].packet = packets[i]->d_bytes;
 		jobs[i].dpb = streams[i]->d_table;
 	}
-	return launch(dev, jobs.data(), n, mode);
+	E264Batch *b = new (std::nothrow) E264Batch();
+	if (!b) return fail(ENOMEM, "batch object");
+	b->dev = dev; b->n = n;
+	if (hipMalloc((void **)&b->d_jobs, sizeof(E264Job) * n) != hipSuccess) { delete b; return fail(ENOMEM, "hipMalloc jobs"); }
+	hipError_t e = hipMemcpy(b->d_jobs, jobs.data(), sizeof(E264Job) * n, hipMemcpyHostToDevice);
+	if (e != hipSuccess) { hipFree(b->d_jobs); delete b; return fail(EIO, "hipMemcpy jobs", e); }
+	*out = b;
+	return 0;
+}
+
+API int e264hip_batch_submit(E264Batch *b, int mode)
+{
+	if (!b) return fail(EINVAL, "null batch");
+	if (set_device(b->dev)) return EIO;
+	return launch(b->dev, b->d_jobs, b->n, mode);
+}
+
+API void e264hip_batch_free(E264Batch *b)
+{
+	if (!b) return;
+	hipSetDevice(b->dev->ordinal);
+	hipStreamSynchronize(b->dev->q);
+	hipFree(b->d_jobs);
+	delete b;
+}
+
+API int e264hip_submit_batch(E264Device *dev, E264Stream *const *streams, E264Packet *const *packets, int n, int mode)
+{
+	E264Batch *b = nullptr;
+	int r = e264hip_batch_create(dev, streams, packets, n, &b);
+	if (r) return r;
+	r = e264hip_batch_submit(b, mode);
+	e264hip_batch_free(b); // synchronises the queue: convenience path for tests
+	return r;
 }
 
 API int e264hip_event_record(E264Device *dev, int idx)

@@ -249,7 +249,7 @@ __device__ __forceinline__ void idct8x8_blocks(WaveLds &L, uint32_t coded, const
 	wave_sync();
 }
 
-__device__ void compute_residual(WaveLds &L, const FrameCtx &f, const E264Mb &m, const E264SliceParams *s, const uint8_t *pl, int lane)
+__device__ __forceinline__ void compute_residual(WaveLds &L, const FrameCtx &f, const E264Mb &m, const E264SliceParams *s, const uint8_t *pl, int lane)
 {
 	// zero the residual tile (384 int16 = 192 dwords)
 	uint32_t *rz = (uint32_t *)L.res;
@@ -268,13 +268,12 @@ __device__ void compute_residual(WaveLds &L, const FrameCtx &f, const E264Mb &m,
 	if (ldc && lane < 16) {
 		int r = lane >> 2, l = lane & 3, acc = 0;
 		// f[r][l] = sum_m sum_i A[r][m] A[l][i] c[4i+m], A = rows {++++, ++--, +--+, +-+-}
-		const int sgn[4] = {0x0, 0xC, 0x6, 0xA}; // bit i set => negative
 #pragma unroll
 		for (int i = 0; i < 4; i++)
 #pragma unroll
 			for (int mm = 0; mm < 4; mm++) {
 				int v = ldc[4 * i + mm];
-				bool neg = ((sgn[r] >> mm) ^ (sgn[l] >> i)) & 1;
+				bool neg = (((0xA6C0 >> (4 * r)) >> mm) ^ ((0xA6C0 >> (4 * l)) >> i)) & 1; // rows of A: bit set => negative
 				acc += neg ? -v : v;
 			}
 		int qP = m.qp[0];
@@ -286,7 +285,7 @@ __device__ void compute_residual(WaveLds &L, const FrameCtx &f, const E264Mb &m,
 		int n = lane & 3, pc = (lane >> 2) & 1; // pc: 0 Cb, 1 Cr
 		int c0 = cdc[pc], c4 = cdc[4 + pc], c2 = cdc[2 + pc], c6 = cdc[6 + pc];
 		int v = n == 0 ? c0 + c4 + c2 + c6 : n == 1 ? c0 - c4 + c2 - c6 : n == 2 ? c0 + c4 - c2 - c6 : c0 - c4 - c2 + c6;
-		int qP = m.qp[1 + pc];
+		int qP = pc ? m.qp[2] : m.qp[1];
 		int LS = (s->weightScale4x4[1 + pc + (inter ? 3 : 0)][0] * norm4(qP % 6, 0)) << (qP / 6);
 		L.dc[16 + pc * 4 + n] = (int)((uint32_t)v * (uint32_t)LS) >> 5;
 	}
@@ -310,7 +309,7 @@ __device__ void compute_residual(WaveLds &L, const FrameCtx &f, const E264Mb &m,
 	if (coded & (0xff0000 | E264_CODED_CHROMA_DC)) {
 		int k = lane >> 2;
 		int pc = (k >> 2) & 1;
-		idct4x4_blocks(L, 8, coded >> 16 & 0xff, true, cdc != nullptr, co, s->weightScale4x4[1 + pc + (inter ? 3 : 0)], m.qp[1 + pc], 16, 256, 8, lane);
+		idct4x4_blocks(L, 8, coded >> 16 & 0xff, true, cdc != nullptr, co, s->weightScale4x4[1 + pc + (inter ? 3 : 0)], pc ? m.qp[2] : m.qp[1], 16, 256, 8, lane);
 	}
 }
 
@@ -326,7 +325,7 @@ __device__ __forceinline__ int wpred(int q, int p, const Wod &w)
 }
 
 // decode_inter weight selection, edge264_inter.c:1137-1197
-__device__ void select_weights(const E264SliceParams *s, int list, int refIdx, int refIdxX, Wod &wY, Wod &wCb, Wod &wCr)
+__device__ __forceinline__ void select_weights(const E264SliceParams *s, int list, int refIdx, int refIdxX, Wod &wY, Wod &wCb, Wod &wCr)
 {
 	Wod nw = {0, 1, 0, 0};
 	wY = wCb = wCr = nw;
@@ -417,7 +416,7 @@ __device__ __forceinline__ int avg2(int a, int b) { return (a + b + 1) >> 1; }
 
 // 4 horizontally adjacent luma samples at (X..X+3, Y) displaced by the quarter-pel (xF,yF):
 // 8.4.2.2.1 organised like decode_inter_luma (edge264_inter.c:416-968).
-__device__ void luma_pred4(const uint8_t *ref, int stride, int W, int H, int X, int Y, int xF, int yF, int out[4])
+__device__ __forceinline__ void luma_pred4(const uint8_t *ref, int stride, int W, int H, int X, int Y, int xF, int yF, int out[4])
 {
 	int px[9];
 	if (yF == 0) {
@@ -426,7 +425,7 @@ __device__ void luma_pred4(const uint8_t *ref, int stride, int W, int H, int X, 
 		for (int i = 0; i < 4; i++) {
 			if (xF == 0) { out[i] = px[i + 2]; continue; }
 			int b = clip255((tap6(px[i], px[i + 1], px[i + 2], px[i + 3], px[i + 4], px[i + 5]) + 16) >> 5);
-			out[i] = xF == 2 ? b : avg2(px[i + 2 + (xF == 3)], b);
+			out[i] = xF == 2 ? b : avg2(xF == 3 ? px[i + 3] : px[i + 2], b);
 		}
 		return;
 	}
@@ -453,14 +452,13 @@ __device__ void luma_pred4(const uint8_t *ref, int stride, int W, int H, int X, 
 	int v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 	int g[4] = {0, 0, 0, 0};      // integer samples for d/n
 	int hb[4] = {0, 0, 0, 0};     // horizontal half-pel b/s for e,g,p,r
-	const int grow = 2 + (yF == 3);
 #pragma unroll
 	for (int r = 0; r < 6; r++) {
 		load_row9(ref, stride, W, H, X - 2, Y - 2 + r, px);
 #pragma unroll
 		for (int c = 0; c < 9; c++)
 			v[c] += cw[r] * px[c];
-		if (r == grow) {
+		if ((r == 2 && yF != 3) || (r == 3 && yF == 3)) {
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
 				g[i] = px[i + 2];
@@ -474,11 +472,11 @@ __device__ void luma_pred4(const uint8_t *ref, int stride, int W, int H, int X, 
 			int h = clip255((v[i + 2] + 16) >> 5);
 			out[i] = yF == 2 ? h : avg2(g[i], h);
 		} else if (yF & 1) { // e,g,p,r (inter.c:510-557)
-			int h = clip255((v[i + 2 + (xF == 3)] + 16) >> 5);
+			int h = clip255(((xF == 3 ? v[i + 3] : v[i + 2]) + 16) >> 5);
 			out[i] = avg2(hb[i], h);
 		} else { // xF odd, yF == 2: vertical first then horizontal (inter.c:559-609, 741-777, 887-927)
 			int j = centre6(v[i], v[i + 1], v[i + 2], v[i + 3], v[i + 4], v[i + 5]);
-			int h = clip255((v[i + 2 + (xF == 3)] + 16) >> 5);
+			int h = clip255(((xF == 3 ? v[i + 3] : v[i + 2]) + 16) >> 5);
 			out[i] = avg2(j, h);
 		}
 	}
@@ -492,7 +490,7 @@ __device__ __forceinline__ int ldc_px(const uint8_t *plane, int stride, int W, i
 // Inter prediction of a whole macroblock in the "pixel layout":
 //   luma   lane = (k = lane>>2 : 4x4 block in zig order, r = lane&3 : row) -> 4 samples
 //   chroma lane = (plane = lane>>5, cy = (lane>>2)&7, cx = (lane&3)*2)    -> 2 samples
-__device__ void inter_pred_mb(const FrameCtx &f, const E264SliceParams *s, const E264Motion *mo, int mbx, int mby, int lane,
+__device__ __forceinline__ void inter_pred_mb(const FrameCtx &f, const E264SliceParams *s, const E264Motion *mo, int mbx, int mby, int lane,
 	int outY[4], int outC[2])
 {
 	const int k = lane >> 2, r = lane & 3;
@@ -555,7 +553,7 @@ __device__ void inter_pred_mb(const FrameCtx &f, const E264SliceParams *s, const
 
 // neighbours of the macroblock from the frame (un-deblocked, pass R) into the tiles.
 // Out-of-frame positions are never dereferenced; the remapped modes never use them.
-__device__ void load_intra_neighbours(WaveLds &L, const FrameCtx &f, int mbx, int mby, int lane)
+__device__ __forceinline__ void load_intra_neighbours(WaveLds &L, const FrameCtx &f, int mbx, int mby, int lane)
 {
 	const uint8_t *Y = f.cur + (size_t)(mby * 16) * f.sY + mbx * 16;
 	// luma top row x = -1..23 (lanes 0..24), left column (lanes 32..47)
@@ -643,7 +641,7 @@ __constant__ int8_t c_i8spec[32] = {0, 0, 0, 0, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2,
 __constant__ int8_t c_i8unav[32] = {0, 4, 8, 12, 0, 8, 0, 1, 5, 9, 13, 2, 10, 4, 8, 12, 3, 0, 4, 8, 12, 0, 4, 0, 4, 0, 0, 4, 8, 12, 0, 8};
 
 // one 8x8 block: all 64 lanes = (y = lane>>3, x = lane&7).  8.3.2.2.1 filtering into L.ftop/L.fleft first.
-__device__ void intra8x8_block(WaveLds &L, int X0, int Y0, int mode, int lane)
+__device__ __forceinline__ void intra8x8_block(WaveLds &L, int X0, int Y0, int mode, int lane)
 {
 	const int sm = c_i8spec[mode], un = c_i8unav[mode];
 	const bool useA = !(un & 1) && (sm == 1 || sm == 2 || sm == 4 || sm == 5 || sm == 6 || sm == 8);
@@ -739,7 +737,7 @@ __device__ void intra8x8_block(WaveLds &L, int X0, int Y0, int mode, int lane)
 }
 
 // Intra 16x16 in the pixel layout: returns 4 predicted samples for (row Yr, cols X..X+3)
-__device__ void intra16x16_pred(const WaveLds &L, int mode, int X, int Yr, int out[4])
+__device__ __forceinline__ void intra16x16_pred(const WaveLds &L, int mode, int X, int Yr, int out[4])
 {
 #define T(i) ((int)L.YT(-1, (i)))
 #define Lf(i) ((int)L.YT((i), -1))
@@ -769,7 +767,7 @@ __device__ void intra16x16_pred(const WaveLds &L, int mode, int X, int Yr, int o
 }
 
 // Intra chroma for plane p, sample (x,y)
-__device__ int intra_chroma_px(const WaveLds &L, int p, int mode, int x, int y)
+__device__ __forceinline__ int intra_chroma_px(const WaveLds &L, int p, int mode, int x, int y)
 {
 #define T(i) ((int)L.CT(p, -1, (i)))
 #define Lf(i) ((int)L.CT(p, (i), -1))
@@ -802,7 +800,7 @@ __device__ int intra_chroma_px(const WaveLds &L, int p, int mode, int x, int y)
 // ---------------------------------------------------------------------------------
 // reconstruction of one macroblock by one wave
 // ---------------------------------------------------------------------------------
-__device__ void recon_mb(WaveLds &L, const FrameCtx &f, int mbx, int mby, int lane)
+__device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, int mbx, int mby, int lane)
 {
 	const E264Mb m = f.mbs[mby * f.wm + mbx];
 	if (m.kind == E264_MB_ABSENT)
@@ -823,6 +821,7 @@ __device__ void recon_mb(WaveLds &L, const FrameCtx &f, int mbx, int mby, int la
 	}
 	const E264Motion *mo = nullptr;
 	if (m.kind == E264_MB_INTER) { mo = (const E264Motion *)pl; pl += sizeof(E264Motion); }
+	const uint32_t modes_lo = *(const uint32_t *)&m.modes[0], modes_hi = *(const uint32_t *)&m.modes[4];
 	compute_residual(L, f, m, s, pl, lane);
 
 	int pY[4], pC[2];
@@ -836,7 +835,7 @@ __device__ void recon_mb(WaveLds &L, const FrameCtx &f, int mbx, int mby, int la
 		} else if (m.kind == E264_MB_I4x4) { // edge264_slice.c:615-635: predict, add residual, next block
 			tile_luma = true;
 			for (int b = 0; b < 16; b++) {
-				int mode = m.modes[b >> 1] >> (4 * (b & 1)) & 15;
+				int mode = (int)(((b < 8 ? modes_lo : modes_hi) >> (4 * (b & 7))) & 15);
 				int X0 = BXf(b), Y0 = BYf(b);
 				int v = 0;
 				if (lane < 16) {
@@ -852,7 +851,7 @@ __device__ void recon_mb(WaveLds &L, const FrameCtx &f, int mbx, int mby, int la
 		} else { // I8x8, edge264_slice.c:645-668
 			tile_luma = true;
 			for (int b = 0; b < 4; b++)
-				intra8x8_block(L, BXf(b * 4), BYf(b * 4), m.modes[b], lane);
+				intra8x8_block(L, BXf(b * 4), BYf(b * 4), (int)(modes_lo >> (8 * b) & 255), lane);
 		}
 		pC[0] = intra_chroma_px(L, cpl, m.chroma_mode, cx, cy);
 		pC[1] = intra_chroma_px(L, cpl, m.chroma_mode, cx + 1, cy);
@@ -888,7 +887,7 @@ __device__ __forceinline__ BlkMo blk_motion(const FrameCtx &f, const E264Mb *m, 
 }
 __device__ __forceinline__ int far4(int ax, int ay, int bx, int by) { return (abs(ax - bx) >= 4) | (abs(ay - by) >= 4); }
 
-__device__ int mb_bs_lane(const FrameCtx &f, const E264Mb *m, int lane)
+__device__ __forceinline__ int mb_bs_lane(const FrameCtx &f, const E264Mb *m, int lane)
 { // lane -> (dir, edge, segment); edge264_deblock.c:958-1118
 	const int dir = lane >> 4 & 1, e = lane >> 2 & 3, sg = lane & 3;
 	const bool intra = m->kind != E264_MB_INTER;
@@ -957,7 +956,7 @@ __device__ __forceinline__ void filter_chroma(uint8_t *q0p, int step, int bS, in
 	}
 }
 
-__device__ void deblock_mb(WaveLds &L, const FrameCtx &f, int mbx, int mby, int lane)
+__device__ __forceinline__ void deblock_mb(WaveLds &L, const FrameCtx &f, int mbx, int mby, int lane)
 {
 	const E264Mb *m = f.mbs + mby * f.wm + mbx;
 	if (!(m->flags & E264_MBF_DEBLOCK) || m->kind == E264_MB_ABSENT)

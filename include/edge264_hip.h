@@ -81,6 +81,12 @@ void e264hip_packet_free(E264Packet *p);
 #define E264_RUN_DEBLOCK 2
 #define E264_RUN_ALL     3
 int  e264hip_submit_batch(E264Device *dev, E264Stream *const *streams, E264Packet *const *packets, int n, int mode);
+/* Same, with the job table built once and kept in HBM: the launch itself moves no bytes
+ * over PCIe (a persistent multi-stream front end re-submits frame i of every stream). */
+typedef struct E264Batch E264Batch;
+int  e264hip_batch_create(E264Device *dev, E264Stream *const *streams, E264Packet *const *packets, int n, E264Batch **out);
+int  e264hip_batch_submit(E264Batch *b, int mode);
+void e264hip_batch_free(E264Batch *b);
 
 /* Timing on the queue the kernels run on (hipEvents; torch.cuda.Event would only see
  * torch's own stream).  Slots 0..15. */

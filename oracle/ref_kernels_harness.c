@@ -27,6 +27,8 @@ typedef struct {
 	int W, H;
 } RefHarness;
 
+static int g_force4x4;
+EXPORT void ref_force_4x4_calls(int on) { g_force4x4 = on; }
 EXPORT int ref_sizeof_macroblock(void) { return (int)sizeof(Edge264Macroblock); }
 
 EXPORT RefHarness *ref_new(int width_mbs, int height_mbs)
@@ -170,11 +172,35 @@ EXPORT int ref_replay_packet(RefHarness *h, const uint8_t *pkt, size_t bytes, ui
 				i16x8 clip = ctx->t.samples_clip_v[0];
 
 				if (m->kind == E264_MB_INTER) {
-					/* every 4x4 block separately, list 0 then list 1: equal to any partitioning */
-					for (int list = 0; list < 2; list++)
-						for (int k = 0; k < 16; k++)
-							if (mb->refPic[list * 4 + (k >> 2)] >= 0)
-								decode_inter(ctx, list * 16 + k, 4, 4);
+					/* Largest partitions with uniform motion, list 0 then list 1, as the front end
+					 * would call them (slice.c:1226-1264, 1503-1537; mvpred.c:73-513).  The result does
+					 * not depend on the partitioning, only the call count (CPU baseline fairness). */
+					for (int list = 0; list < 2; list++) {
+						const int32_t *mv = mb->mvs_s + list * 16;
+						const int8_t *rp = mb->refPic + list * 4, *ri = mb->refIdx + list * 4;
+						int uni8[4], all = 1;
+						for (int b = 0; b < 4; b++) {
+							uni8[b] = mv[b * 4] == mv[b * 4 + 1] && mv[b * 4] == mv[b * 4 + 2] && mv[b * 4] == mv[b * 4 + 3];
+							all &= uni8[b] && mv[b * 4] == mv[0] && rp[b] == rp[0] && ri[b] == ri[0]
+								&& mb->refIdx[(list ^ 1) * 4 + b] == mb->refIdx[(list ^ 1) * 4];
+						}
+						if (g_force4x4) all = uni8[0] = uni8[1] = uni8[2] = uni8[3] = 0;
+						if (all) {
+							if (rp[0] >= 0)
+								decode_inter(ctx, list * 16, 16, 16);
+							continue;
+						}
+						for (int b = 0; b < 4; b++) {
+							if (rp[b] < 0)
+								continue;
+							if (uni8[b]) {
+								decode_inter(ctx, list * 16 + b * 4, 8, 8);
+							} else {
+								for (int k = b * 4; k < b * 4 + 4; k++)
+									decode_inter(ctx, list * 16 + k, 4, 4);
+							}
+						}
+					}
 				}
 				if (m->kind == E264_MB_I16x16) {
 					decode_intra16x16(ctx->samples_mb[0], sY, m->i16_mode, clip);

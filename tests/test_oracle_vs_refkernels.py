@@ -57,5 +57,13 @@ def test_oracle_matches_reference_kernels(oracle, refkernels, name, pattern, kw)
 
 def test_odd_geometry(oracle, refkernels):
     """1-MB-wide / 1-MB-high frames: every neighbour unavailable somewhere, all MC clamps."""
-    for (w, h) in ((1, 1), (1, 4), (5, 1), (2, 2)):
-        run_stream(oracle, refkernels, 7, "IPB", dict(t8x8=True, i_kinds=ALL_I, mv_range=100), w, h)
+    # The reference's edge test `(unsigned)yInt_Y - yWide*2 >= height - h + 1 - yWide*5`
+    # (src/edge264_inter.c:1203-1204) goes negative -> huge unsigned when a 16-high (wide) partition meets
+    # a 16-sample-high (wide) frame with a fractional vector, so edge emulation is skipped and the reference
+    # reads outside the frame.  Degenerate geometry only; the harness issues 4x4 calls here, which are exact.
+    refkernels.lib.ref_force_4x4_calls(1)
+    try:
+        for (w, h) in ((1, 1), (1, 4), (5, 1), (2, 2)):
+            run_stream(oracle, refkernels, 7, "IPB", dict(t8x8=True, i_kinds=ALL_I, mv_range=100), w, h)
+    finally:
+        refkernels.lib.ref_force_4x4_calls(0)
