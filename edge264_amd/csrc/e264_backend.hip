@@ -32,6 +32,7 @@ struct E264Packet {
 	uint8_t *d_bytes;
 	size_t bytes;
 	int dst_slot;
+	int n_mbs;
 };
 
 struct E264Device {
@@ -42,7 +43,8 @@ struct E264Device {
 	hipEvent_t ev[16];
 	// per-launch kernel timing
 	bool ktiming;
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
+	struct Marks { hipEvent_t e[4]; };
+	std::vector<Marks> kev;
 	size_t kev_used;
 };
 
@@ -52,6 +54,8 @@ struct E264Stream {
 	uint8_t *h_table[E264_MAX_SLOTS];     // same, host copy
 	void *mirror[E264_MAX_SLOTS];         // pinned host mirrors
 	size_t slot_bytes[E264_MAX_SLOTS];
+	uint8_t *d_dbk;                       // deblocking parameters, E264_DBK_BYTES per macroblock
+	size_t dbk_mbs;
 	// packet staging ring (pinned host) + device copies
 	struct Stage { void *h; uint8_t *d; size_t cap; hipEvent_t done; bool busy; E264Job *d_job; } stage[4];
 	int stage_next;
@@ -96,7 +100,7 @@ API void e264hip_device_close(E264Device *dev)
 	hipSetDevice(dev->ordinal);
 	hipStreamSynchronize(dev->q);
 	for (int i = 0; i < 16; i++) hipEventDestroy(dev->ev[i]);
-	for (auto &p : dev->kev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+	for (auto &p : dev->kev) for (int i = 0; i < 4; i++) hipEventDestroy(p.e[i]);
 	hipStreamDestroy(dev->q);
 	delete dev;
 }
@@ -154,6 +158,7 @@ API void e264hip_stream_close(E264Stream *s)
 		if (st.d_job) hipFree(st.d_job);
 		if (st.done) hipEventDestroy(st.done);
 	}
+	if (s->d_dbk) hipFree(s->d_dbk);
 	hipFree(s->d_table);
 	delete s;
 }
@@ -213,7 +218,7 @@ API int e264hip_frame_upload(E264Stream *s, int slot, const void *src, size_t by
 	return 0;
 }
 
-static int check_packet(const void *packet, size_t bytes, int *dst)
+static int check_packet(const void *packet, size_t bytes, int *dst, int *n_mbs)
 {
 	const E264FrameHdr *h = (const E264FrameHdr *)packet;
 	if (!packet || bytes < sizeof(*h) || h->magic != E264_MAGIC || h->version != E264_VERSION || h->total_bytes > bytes)
@@ -222,26 +227,33 @@ static int check_packet(const void *packet, size_t bytes, int *dst)
 	size_t need = (size_t)h->mbs_off + (size_t)h->width_mbs * h->height_mbs * sizeof(E264Mb);
 	if (need > h->payload_off || (size_t)h->payload_off + h->payload_bytes > h->total_bytes) return fail(EINVAL, "packet layout");
 	*dst = h->dst_slot;
+	*n_mbs = (int)h->width_mbs * h->height_mbs;
 	return 0;
 }
 
-// Launches the frame kernel over a job table that already lives in HBM.
-static int launch(E264Device *dev, const E264Job *d_jobs, int n, int mode)
+static int ensure_dbk(E264Stream *s, int n_mbs)
+{
+	if (s->dbk_mbs >= (size_t)n_mbs) return 0;
+	if (s->d_dbk) { hipStreamSynchronize(s->dev->q); hipFree(s->d_dbk); s->d_dbk = nullptr; s->dbk_mbs = 0; }
+	if (hipMalloc((void **)&s->d_dbk, (size_t)n_mbs * E264_DBK_BYTES) != hipSuccess) return fail(ENOMEM, "hipMalloc deblock parameters");
+	s->dbk_mbs = (size_t)n_mbs;
+	return 0;
+}
+
+// Launches the kernels over a job table that already lives in HBM.
+static int launch(E264Device *dev, const E264Job *d_jobs, int n, int max_mbs, int mode)
 {
 	std::lock_guard<std::mutex> g(dev->lock);
-	hipEvent_t e0 = nullptr, e1 = nullptr;
+	hipEvent_t *marks = nullptr;
 	if (dev->ktiming) {
 		if (dev->kev_used == dev->kev.size()) {
-			hipEvent_t a, b;
-			hipEventCreate(&a); hipEventCreate(&b);
-			dev->kev.push_back({a, b});
+			E264Device::Marks m;
+			for (int i = 0; i < 4; i++) hipEventCreate(&m.e[i]);
+			dev->kev.push_back(m);
 		}
-		e0 = dev->kev[dev->kev_used].first; e1 = dev->kev[dev->kev_used].second;
-		dev->kev_used++;
-		hipEventRecord(e0, dev->q);
+		marks = dev->kev[dev->kev_used++].e;
 	}
-	HIPCHK(e264_launch_frames(d_jobs, n, mode, dev->waves, dev->q), EIO);
-	if (e1) hipEventRecord(e1, dev->q);
+	HIPCHK(e264_launch_frames(d_jobs, n, max_mbs, mode, dev->waves, dev->q, marks), EIO);
 	return 0;
 }
 
@@ -267,10 +279,11 @@ API void *e264hip_packet_buffer(E264Stream *s, size_t max_bytes)
 API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
 {
 	if (!s) return fail(EINVAL, "null stream");
-	int dst, r = check_packet(packet, bytes, &dst);
+	int dst, n_mbs, r = check_packet(packet, bytes, &dst, &n_mbs);
 	if (r) return r;
 	if (!s->h_table[dst]) return fail(EINVAL, "destination slot not allocated");
 	if (set_device(s->dev)) return EIO;
+	if ((r = ensure_dbk(s, n_mbs))) return r;
 	E264Stream::Stage *st = &s->stage[s->stage_next];
 	if (packet != st->h) { // caller did not use our pinned buffer: stage it
 		void *h = e264hip_packet_buffer(s, bytes);
@@ -282,9 +295,9 @@ API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
 	HIPCHK(hipMemcpyAsync(st->d, st->h, bytes, hipMemcpyHostToDevice, s->dev->q), EIO);
 	// the job record rides at the tail of the pinned staging buffer's lifetime: tiny H2D on the same queue
 	E264Job *job = (E264Job *)((uint8_t *)st->h + st->cap); // pinned, lives as long as the staging slot
-	job->packet = st->d; job->dpb = s->d_table;
+	job->packet = st->d; job->dpb = s->d_table; job->dbk = s->d_dbk;
 	HIPCHK(hipMemcpyAsync(st->d_job, job, sizeof(*job), hipMemcpyHostToDevice, s->dev->q), EIO);
-	r = launch(s->dev, st->d_job, 1, E264_RUN_ALL);
+	r = launch(s->dev, st->d_job, 1, n_mbs, E264_RUN_ALL);
 	if (r) return r;
 	hipEventRecord(st->done, s->dev->q);
 	st->busy = true;
@@ -313,12 +326,12 @@ API int e264hip_frame_download(E264Stream *s, int slot, void *dst, size_t bytes)
 API int e264hip_packet_upload(E264Device *dev, const void *packet, size_t bytes, E264Packet **out)
 {
 	if (!dev || !out) return fail(EINVAL, "null argument");
-	int dst, r = check_packet(packet, bytes, &dst);
+	int dst, n_mbs, r = check_packet(packet, bytes, &dst, &n_mbs);
 	if (r) return r;
 	if (set_device(dev)) return EIO;
 	E264Packet *p = new (std::nothrow) E264Packet();
 	if (!p) return fail(ENOMEM, "packet object");
-	p->dev = dev; p->bytes = bytes; p->dst_slot = dst;
+	p->dev = dev; p->bytes = bytes; p->dst_slot = dst; p->n_mbs = n_mbs;
 	if (hipMalloc((void **)&p->d_bytes, bytes) != hipSuccess) { delete p; return fail(ENOMEM, "hipMalloc packet"); }
 	hipError_t e = hipMemcpy(p->d_bytes, packet, bytes, hipMemcpyHostToDevice);
 	if (e != hipSuccess) { hipFree(p->d_bytes); delete p; return fail(EIO, "hipMemcpy packet", e); }
@@ -338,7 +351,7 @@ API void e264hip_packet_free(E264Packet *p)
 struct E264Batch {
 	E264Device *dev;
 	E264Job *d_jobs;
-	int n;
+	int n, max_mbs;
 };
 
 API int e264hip_batch_create(E264Device *dev, E264Stream *const *streams, E264Packet *const *packets, int n, E264Batch **out)
@@ -346,15 +359,20 @@ API int e264hip_batch_create(E264Device *dev, E264Stream *const *streams, E264Pa
 	if (!dev || !streams || !packets || !out || n <= 0) return fail(EINVAL, "batch_create arguments");
 	if (set_device(dev)) return EIO;
 	std::vector<E264Job> jobs((size_t)n);
+	int max_mbs = 0;
 	for (int i = 0; i < n; i++) {
 		if (!streams[i] || !packets[i] || streams[i]->dev != dev || packets[i]->dev != dev) return fail(EINVAL, "batch entry");
 		if (!streams[i]->h_table[packets[i]->dst_slot]) return fail(EINVAL, "destination slot not allocated");
+		int r = ensure_dbk(streams[i], packets[i]->n_mbs);
+		if (r) return r;
 		jobs[i].packet = packets[i]->d_bytes;
 		jobs[i].dpb = streams[i]->d_table;
+		jobs[i].dbk = streams[i]->d_dbk;
+		if (packets[i]->n_mbs > max_mbs) max_mbs = packets[i]->n_mbs;
 	}
 	E264Batch *b = new (std::nothrow) E264Batch();
 	if (!b) return fail(ENOMEM, "batch object");
-	b->dev = dev; b->n = n;
+	b->dev = dev; b->n = n; b->max_mbs = max_mbs;
 	if (hipMalloc((void **)&b->d_jobs, sizeof(E264Job) * n) != hipSuccess) { delete b; return fail(ENOMEM, "hipMalloc jobs"); }
 	hipError_t e = hipMemcpy(b->d_jobs, jobs.data(), sizeof(E264Job) * n, hipMemcpyHostToDevice);
 	if (e != hipSuccess) { hipFree(b->d_jobs); delete b; return fail(EIO, "hipMemcpy jobs", e); }
@@ -366,7 +384,7 @@ API int e264hip_batch_submit(E264Batch *b, int mode)
 {
 	if (!b) return fail(EINVAL, "null batch");
 	if (set_device(b->dev)) return EIO;
-	return launch(b->dev, b->d_jobs, b->n, mode);
+	return launch(b->dev, b->d_jobs, b->n, b->max_mbs, mode);
 }
 
 API void e264hip_batch_free(E264Batch *b)
@@ -414,17 +432,17 @@ API int e264hip_kernel_timing(E264Device *dev, int enable)
 	return 0;
 }
 
-API int e264hip_kernel_time_ms(E264Device *dev, double *total_ms, int *launches)
+API int e264hip_kernel_time_ms(E264Device *dev, double *ms3, int *launches)
 {
-	if (!dev || !total_ms) return fail(EINVAL, "null argument");
+	if (!dev || !ms3) return fail(EINVAL, "null argument");
 	int r = e264hip_device_sync(dev);
 	if (r) return r;
-	double t = 0;
-	for (size_t i = 0; i < dev->kev_used; i++) {
-		float ms = 0;
-		if (hipEventElapsedTime(&ms, dev->kev[i].first, dev->kev[i].second) == hipSuccess) t += ms;
-	}
-	*total_ms = t;
+	ms3[0] = ms3[1] = ms3[2] = 0;
+	for (size_t i = 0; i < dev->kev_used; i++)
+		for (int k = 0; k < 3; k++) {
+			float ms = 0;
+			if (hipEventElapsedTime(&ms, dev->kev[i].e[k], dev->kev[i].e[k + 1]) == hipSuccess) ms3[k] += ms;
+		}
 	if (launches) *launches = (int)dev->kev_used;
 	return 0;
 }

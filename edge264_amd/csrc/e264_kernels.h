@@ -9,9 +9,12 @@
 struct E264Job {
 	const uint8_t *packet;
 	uint8_t *const *dpb;
+	uint8_t *dbk; // per-stream scratch: E264_DBK_BYTES per macroblock (bS, alpha, beta, indexA), NULL = no deblocking
 };
+#define E264_DBK_BYTES 64
 
-// mode: bit0 reconstruction pass, bit1 deblocking pass.  waves: 4, 8 or 16 macroblock rows in flight per frame.
-extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int mode, int waves, hipStream_t stream);
+// mode: bit0 reconstruction, bit1 deblocking.  waves: 4, 8 or 16 macroblock rows in flight per frame.
+// max_mbs: largest macroblock count among the jobs.  marks: NULL or 4 events (kernel boundaries).
+extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int max_mbs, int mode, int waves, hipStream_t stream, hipEvent_t *marks);
 
 #endif

@@ -7,15 +7,18 @@
 //   inter      edge264_inter.c:416-1251     (6-tap luma, bilinear chroma, 5 weighting schemes)
 //   deblock    edge264_deblock.c:927-1123   (bS / alpha / beta / tC0) and :284-895 (filters)
 //
-// Execution model (DESIGN.md "kernels"): ONE WORKGROUP PER FRAME, ONE WAVE64 PER MACROBLOCK
-// ROW.  The waves of a workgroup walk their rows left to right; row y may reconstruct an
-// intra macroblock x (or deblock any macroblock x) once row y-1 has finished macroblock
-// x+1 -- the 2-MB-lag wavefront that both intra prediction and H.264 in-loop deblocking
-// require.  Progress counters live in LDS, so the hand-off between rows
-// never leaves the CU: no agent-scope fences, no cross-XCD traffic, no placement
-// assumption.  Chip-level parallelism comes from many independent streams (one frame of
-// each per launch), which is the north-star workload (>=1000 concurrent streams).
-// Integer / byte work throughout; HBM-bound by design, no MFMA.
+// Execution model (DESIGN.md "kernels"), three launches per batch of frames:
+//   e264_mbpar_kernel    one wave64 per macroblock, every macroblock of every frame in parallel:
+//                        inter prediction + residual (+ PCM), which depend on nothing inside the
+//                        frame, and the deblocking parameters (bS, alpha, beta, indexA) of EVERY MB.
+//   e264_intra_kernel    ONE WORKGROUP PER FRAME, ONE WAVE PER MACROBLOCK ROW: intra MBs only, row y
+//                        may reconstruct macroblock x once row y-1 has finished macroblock x+1.
+//   e264_deblock_kernel  same wavefront, every MB: the 2-MB lag is exactly what H.264 in-loop
+//                        deblocking requires.
+// Progress counters live in LDS, so the hand-off between rows never leaves the CU: no
+// agent-scope fences, no cross-XCD traffic, no placement assumption.  Chip-level parallelism
+// comes from many independent streams (one frame of each per launch), the north-star workload
+// (>=1000 concurrent streams).  Integer / byte work throughout; HBM-bound by design, no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/edge264_cmd.h"
@@ -30,6 +33,9 @@ __device__ __forceinline__ int clip3i(int lo, int hi, int v) { return min(max(v,
 __device__ __forceinline__ int clip255(int v) { return min(max(v, 0), 255); }
 __device__ __forceinline__ int sat16(int v) { return min(max(v, -32768), 32767); }
 __device__ __forceinline__ int w16(int v) { return (int)(int16_t)v; }
+typedef uint8_t __attribute__((address_space(1))) gu8;   // global memory, so that loads/stores are global_* not flat_*
+typedef uint32_t __attribute__((address_space(1))) gu32;
+typedef uint16_t __attribute__((address_space(1))) gu16;
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 // All LDS scratch is private to one wave; LDS operations of a wave execute in order, so a
 // compiler-level fence is all that is needed between producer and consumer lanes.
@@ -89,23 +95,20 @@ __constant__ uint8_t c_tc0[3][52] = {
 #define DC_STRIDE 12
 #define DCT(p, y, x) dctile[p][((y) + 4) * DC_STRIDE + (x) + 4]
 
-struct __attribute__((aligned(16))) WaveLds {
-	union {
-		struct { // reconstruction pass
-			int16_t res[384];          // residual: luma [y*16+x], Cb at 256 [y*8+x], Cr at 320
-			int32_t tmp[256];          // IDCT intermediate (4x4: 16 blocks x 16 int32; 8x8: int16 view)
-			int32_t dc[24];            // 16 luma DC (zig order), 4 Cb, 4 Cr
-			uint8_t ytile[17 * YT_STRIDE];
-			uint8_t ctile[2][9 * CT_STRIDE];
-			uint8_t ftop[32];          // intra 8x8 filtered top  ft[-1..15] at [i+1]
-			uint8_t fleft[8];          // intra 8x8 filtered left
-		};
-		struct { // deblocking pass
-			uint8_t dytile[20 * DY_STRIDE];
-			uint8_t dctile[2][12 * DC_STRIDE];
-			uint8_t bs[32];            // [dir][edge][seg]
-		};
-	};
+struct __attribute__((aligned(16))) WaveLds { // reconstruction scratch of one wave
+	int16_t res[384];          // residual: luma [y*16+x], Cb at 256 [y*8+x], Cr at 320
+	int32_t tmp[256];          // IDCT intermediate (4x4: 16 blocks x 16 int32; 8x8: int16 view)
+	int32_t dc[24];            // 16 luma DC (zig order), 4 Cb, 4 Cr
+	uint8_t ytile[17 * YT_STRIDE];
+	uint8_t ctile[2][9 * CT_STRIDE];
+	uint8_t ftop[32];          // intra 8x8 filtered top  ft[-1..15] at [i+1]
+	uint8_t fleft[8];          // intra 8x8 filtered left
+};
+
+struct __attribute__((aligned(16))) DbkLds { // deblocking scratch of one wave
+	uint8_t dytile[20 * DY_STRIDE];
+	uint8_t dctile[2][12 * DC_STRIDE];
+	uint8_t prm[E264_DBK_BYTES]; // deblocking parameters of the current macroblock
 };
 
 struct FrameCtx {
@@ -119,6 +122,7 @@ struct FrameCtx {
 	int wm, hm;        // macroblocks
 	int sY, sC;        // strides
 	uint32_t psY;      // plane_size_Y
+	uint8_t *dbk;      // per-MB deblocking parameters (E264_DBK_BYTES each), written by the mbpar kernel
 };
 
 __device__ __forceinline__ uint8_t *plane_base(const FrameCtx &f, uint8_t *base, int pl)
@@ -800,10 +804,15 @@ __device__ __forceinline__ int intra_chroma_px(const WaveLds &L, int p, int mode
 // ---------------------------------------------------------------------------------
 // reconstruction of one macroblock by one wave
 // ---------------------------------------------------------------------------------
+// WHICH: 1 = inter and PCM macroblocks only (no dependency inside the frame), 2 = intra only, 3 = all
+template <int WHICH>
 __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, int mbx, int mby, int lane)
 {
 	const E264Mb m = f.mbs[mby * f.wm + mbx];
 	if (m.kind == E264_MB_ABSENT)
+		return;
+	const bool par = m.kind == E264_MB_INTER || m.kind == E264_MB_PCM;
+	if ((WHICH == 1 && !par) || (WHICH == 2 && par))
 		return;
 	const E264SliceParams *s = f.slices + m.slice;
 	const uint8_t *pl = f.payload + m.payload_off;
@@ -826,9 +835,9 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, int mbx,
 
 	int pY[4], pC[2];
 	bool tile_luma = false;
-	if (m.kind == E264_MB_INTER) {
+	if (WHICH != 2 && m.kind == E264_MB_INTER) {
 		inter_pred_mb(f, s, mo, mbx, mby, lane, pY, pC);
-	} else {
+	} else if (WHICH != 1) {
 		load_intra_neighbours(L, f, mbx, mby, lane);
 		if (m.kind == E264_MB_I16x16) {
 			intra16x16_pred(L, m.i16_mode, X, Yr, pY);
@@ -912,107 +921,172 @@ __device__ __forceinline__ int mb_bs_lane(const FrameCtx &f, const E264Mb *m, in
 	return (refs_p | mvs_p) & (refs_c | mvs_c);
 }
 
-__device__ __forceinline__ void filter_luma(uint8_t *q0p, int step, int bS, int alpha, int beta, int tc0)
+// ---------------------------------------------------------------------------------
+// deblocking parameters of one macroblock (mbpar kernel): E264_DBK_BYTES = 64 per MB
+//   [0..31]  bS[dir][edge][segment]
+//   [32..40] alpha[plane*3 + t], t = 0 internal edges, 1 left MB edge, 2 top MB edge
+//   [41..49] beta, [50..58] indexA (tC0 lookup)          edge264_deblock.c:945-955
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void write_dbk_params(const FrameCtx &f, int mbx, int mby, int lane)
 {
-	int p0 = q0p[-step], p1 = q0p[-2 * step], p2 = q0p[-3 * step], p3 = q0p[-4 * step];
-	int q0 = q0p[0], q1 = q0p[step], q2 = q0p[2 * step], q3 = q0p[3 * step];
-	if (!(abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta))
+	const E264Mb *m = f.mbs + mby * f.wm + mbx;
+	uint8_t *out = f.dbk + (size_t)(mby * f.wm + mbx) * E264_DBK_BYTES;
+	if (!(m->flags & E264_MBF_DEBLOCK) || m->kind == E264_MB_ABSENT) {
+		if (lane < 16) ((uint32_t *)out)[lane] = 0;
 		return;
-	int ap = abs(p2 - p0), aq = abs(q2 - q0);
-	if (bS < 4) {
-		int tc = tc0 + (ap < beta) + (aq < beta);
-		int delta = clip3i(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
-		q0p[-step] = (uint8_t)clip255(p0 + delta);
-		q0p[0] = (uint8_t)clip255(q0 - delta);
-		if (ap < beta) q0p[-2 * step] = (uint8_t)(p1 + clip3i(-tc0, tc0, (p2 + ((p0 + q0 + 1) >> 1) - 2 * p1) >> 1));
-		if (aq < beta) q0p[step] = (uint8_t)(q1 + clip3i(-tc0, tc0, (q2 + ((p0 + q0 + 1) >> 1) - 2 * q1) >> 1));
-	} else {
-		bool small = abs(p0 - q0) < (alpha >> 2) + 2;
-		if (ap < beta && small) {
-			q0p[-step] = (uint8_t)((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
-			q0p[-2 * step] = (uint8_t)((p2 + p1 + p0 + q0 + 2) >> 2);
-			q0p[-3 * step] = (uint8_t)((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
-		} else q0p[-step] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2);
-		if (aq < beta && small) {
-			q0p[0] = (uint8_t)((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
-			q0p[step] = (uint8_t)((p0 + q0 + q1 + q2 + 2) >> 2);
-			q0p[2 * step] = (uint8_t)((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3);
-		} else q0p[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
+	}
+	if (lane < 32) {
+		out[lane] = (uint8_t)mb_bs_lane(f, m, lane);
+	} else if (lane < 59) {
+		const E264SliceParams *s = f.slices + m->slice;
+		int idx = lane - 32, what = idx / 9, pt = idx % 9, pl = pt / 3, t = pt % 3;
+		const E264Mb *n = m;
+		if (t == 1 && (m->flags & E264_MBF_EDGE_LEFT)) n = m - 1;
+		if (t == 2 && (m->flags & E264_MBF_EDGE_TOP)) n = m - f.wm;
+		int qPav = (m->qp[pl] + n->qp[pl] + 1) >> 1;
+		int iA = clip3i(0, 51, qPav + s->FilterOffsetA), iB = clip3i(0, 51, qPav + s->FilterOffsetB);
+		out[lane] = (uint8_t)(what == 0 ? c_alpha[iA] : what == 1 ? c_beta[iB] : iA);
 	}
 }
-__device__ __forceinline__ void filter_chroma(uint8_t *q0p, int step, int bS, int alpha, int beta, int tc0)
+
+// ---------------------------------------------------------------------------------
+// edge filters on values: v[0..7] = p3 p2 p1 p0 q0 q1 q2 q3   (edge264_deblock.c:95-129, 213-260)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void luma_filter8(int v[8], int bS, int alpha, int beta, int tc0)
 {
-	int p0 = q0p[-step], p1 = q0p[-2 * step], q0 = q0p[0], q1 = q0p[step];
-	if (!(abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta))
+	int p3 = v[0], p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6], q3 = v[7];
+	if (bS == 0 || !(abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta))
+		return;
+	bool ap = abs(p2 - p0) < beta, aq = abs(q2 - q0) < beta;
+	if (bS < 4) {
+		int tc = tc0 + ap + aq;
+		int delta = clip3i(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
+		v[3] = clip255(p0 + delta);
+		v[4] = clip255(q0 - delta);
+		int avg = (p0 + q0 + 1) >> 1;
+		if (ap) v[2] = p1 + clip3i(-tc0, tc0, (p2 + avg - 2 * p1) >> 1);
+		if (aq) v[5] = q1 + clip3i(-tc0, tc0, (q2 + avg - 2 * q1) >> 1);
+	} else {
+		bool small = abs(p0 - q0) < (alpha >> 2) + 2;
+		if (ap && small) {
+			v[3] = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3;
+			v[2] = (p2 + p1 + p0 + q0 + 2) >> 2;
+			v[1] = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
+		} else v[3] = (2 * p1 + p0 + q1 + 2) >> 2;
+		if (aq && small) {
+			v[4] = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3;
+			v[5] = (p0 + q0 + q1 + q2 + 2) >> 2;
+			v[6] = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
+		} else v[4] = (2 * q1 + q0 + p1 + 2) >> 2;
+	}
+}
+// chroma: only p0/q0 change (deblock.c:130-152, 261-276)
+__device__ __forceinline__ void chroma_filter4(int &p1, int &p0, int &q0, int &q1, int bS, int alpha, int beta, int tc0)
+{
+	if (bS == 0 || !(abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta))
 		return;
 	if (bS < 4) {
 		int tc = tc0 + 1;
 		int delta = clip3i(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
-		q0p[-step] = (uint8_t)clip255(p0 + delta);
-		q0p[0] = (uint8_t)clip255(q0 - delta);
+		p0 = clip255(p0 + delta);
+		q0 = clip255(q0 - delta);
 	} else {
-		q0p[-step] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2);
-		q0p[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
+		int np = (2 * p1 + p0 + q1 + 2) >> 2, nq = (2 * q1 + q0 + p1 + 2) >> 2;
+		p0 = np; q0 = nq;
 	}
 }
 
-__device__ __forceinline__ void deblock_mb(WaveLds &L, const FrameCtx &f, int mbx, int mby, int lane)
+// One macroblock.  The tile keeps rows -4..15 x cols -4..15 of luma (and -4..7 of both chroma
+// planes); the left 4 columns are CARRIED in LDS from the previous macroblock of the row (same
+// wave), the rest comes from global memory with two dword loads per lane.
+__device__ __forceinline__ void deblock_mb(DbkLds &L, const uint8_t *tc0tab, const FrameCtx &f, int mbx, int mby, int lane, bool carry)
 {
 	const E264Mb *m = f.mbs + mby * f.wm + mbx;
-	if (!(m->flags & E264_MBF_DEBLOCK) || m->kind == E264_MB_ABSENT)
-		return;
-	const E264SliceParams *s = f.slices + m->slice;
-	const bool hasL = m->flags & E264_MBF_EDGE_LEFT, hasT = m->flags & E264_MBF_EDGE_TOP;
-	// boundary strengths: lanes 0..31
-	if (lane < 32)
-		L.bs[lane] = (uint8_t)mb_bs_lane(f, m, lane);
-	// load tiles: luma rows -4..15 x 5 dwords (cols -4..15): 100 dwords; chroma 2 x 12 rows x 3 dwords = 72
-	uint8_t *Yb = f.cur + (size_t)(mby * 16) * f.sY + mbx * 16;
-	for (int i = lane; i < 100; i += 64) {
-		int row = i / 5 - 4, col = (i % 5) * 4 - 4;
-		bool ok = (row >= 0 || hasT) && (col >= 0 || hasL);
-		uint32_t v = 0;
-		if (ok) v = *(const uint32_t *)(Yb + (ptrdiff_t)row * f.sY + col);
-		*(uint32_t *)&L.DYT(row, col) = v;
-	}
-	for (int i = lane; i < 72; i += 64) {
-		int p = i / 36, j = i % 36;
-		int row = j / 3 - 4, col = (j % 3) * 4 - 4;
-		uint8_t *Cb = plane_base(f, f.cur, 1 + p) + (size_t)(mby * 8) * f.sC + mbx * 8;
-		bool ok = (row >= 0 || hasT) && (col >= 0 || hasL);
-		uint32_t v = 0;
-		if (ok) v = *(const uint32_t *)(Cb + (ptrdiff_t)row * f.sC + col);
-		*(uint32_t *)&L.DCT(p, row, col) = v;
-	}
+	const uint32_t flags = m->flags;
+	const bool on = (flags & E264_MBF_DEBLOCK) && m->kind != E264_MB_ABSENT;
+	const bool hasL = on && (flags & E264_MBF_EDGE_LEFT), hasT = on && (flags & E264_MBF_EDGE_TOP);
+	gu8 *Yb = (gu8 *)(f.cur + (size_t)(mby * 16) * f.sY + mbx * 16);
+	gu8 *Cb0 = (gu8 *)(plane_base(f, f.cur, 1) + (size_t)(mby * 8) * f.sC + mbx * 8);
+	const int half = f.sC >> 1;
+	// ---- lane roles for memory traffic -----------------------------------------------------
+	// A (all 64 lanes): own luma, row lane>>2, dword lane&3
+	const int ar = lane >> 2, ac = (lane & 3) * 4;
+	// B: lanes 0..15 luma top rows (-4..-1); 16..47 own chroma; 48..63 chroma top rows
+	int bpl = 0, brow = 0, bcol = 0; // for chroma roles: plane, row, col
+	bool b_luma = lane < 16, b_top = lane < 16 || lane >= 48;
+	if (lane < 16) { brow = -4 + (lane >> 2); bcol = (lane & 3) * 4; }
+	else if (lane < 48) { int i = lane - 16; bpl = i >> 4; brow = (i >> 1) & 7; bcol = (i & 1) * 4; }
+	else { int i = lane - 48; bpl = i >> 3; brow = -4 + ((i >> 1) & 3); bcol = (i & 1) * 4; }
+	gu8 *bptr = b_luma ? Yb + (ptrdiff_t)brow * f.sY + bcol : Cb0 + bpl * half + (ptrdiff_t)brow * f.sC + bcol;
+	// C: left columns: lanes 0..15 luma row lane; 16..31 chroma (plane, row)
+	const int cpl = (lane - 16) >> 3 & 1, crow = lane < 16 ? lane : (lane & 7);
+
+	// ---- carry the previous macroblock's right 4 columns to the left of the tile ------------
+	uint32_t cv = 0;
+	if (carry && lane < 32)
+		cv = lane < 16 ? *(const uint32_t *)&L.DYT(crow, 12) : *(const uint32_t *)&L.DCT(cpl, crow, 4);
+	uint32_t va = *(const gu32 *)(Yb + (size_t)ar * f.sY + ac);
+	uint32_t vb = 0;
+	if (!b_top || hasT) vb = *(const gu32 *)bptr;
+	uint32_t vp = 0;
+	if (lane < 16) vp = ((const gu32 *)(f.dbk + (size_t)(mby * f.wm + mbx) * E264_DBK_BYTES))[lane];
 	wave_sync();
-	// lane roles for edge filtering: 0..15 luma line, 16..23 Cb line, 24..31 Cr line
+	if (carry && lane < 32) {
+		if (lane < 16) *(uint32_t *)&L.DYT(crow, -4) = cv;
+		else *(uint32_t *)&L.DCT(cpl, crow, -4) = cv;
+	}
+	*(uint32_t *)&L.DYT(ar, ac) = va;
+	if (b_luma) *(uint32_t *)&L.DYT(brow, bcol) = vb;
+	else *(uint32_t *)&L.DCT(bpl, brow, bcol) = vb;
+	if (lane < 16) ((uint32_t *)L.prm)[lane] = vp;
+	wave_sync();
+	if (!on)
+		return; // tile stays valid for the next macroblock's carry
+	// ---- filtering: lanes 0..15 luma lines, 16..23 Cb lines, 24..31 Cr lines -----------------
 	const int pl = lane < 16 ? 0 : lane < 24 ? 1 : 2;
 	const int li = lane < 16 ? lane : (lane & 7);
-	const int qpc = m->qp[pl];
-#pragma unroll 1
+	const bool t8 = flags & E264_MBF_T8x8;
+#pragma unroll
 	for (int dir = 0; dir < 2; dir++) {
-#pragma unroll 1
+#pragma unroll
 		for (int e = 0; e < 4; e++) {
-			if (lane < 32 && !(pl && (e & 1))) {
-				const E264Mb *n = m;
-				bool skip = false;
-				if (e == 0) {
-					if (!(dir ? hasT : hasL)) skip = true;
-					else n = dir ? m - f.wm : m - 1;
-				} else if (!pl && (m->flags & E264_MBF_T8x8) && (e & 1)) skip = true;
-				if (!skip) {
-					int b = L.bs[dir * 16 + e * 4 + (pl ? li >> 1 : li >> 2)];
-					if (b) {
-						int qPav = (qpc + n->qp[pl] + 1) >> 1;
-						int iA = clip3i(0, 51, qPav + s->FilterOffsetA), iB = clip3i(0, 51, qPav + s->FilterOffsetB);
-						int alpha = c_alpha[iA], beta = c_beta[iB];
-						int tc0 = b < 4 ? c_tc0[b - 1][iA] : 0;
-						if (pl == 0) {
-							uint8_t *q0 = dir ? &L.DYT(e * 4, li) : &L.DYT(li, e * 4);
-							filter_luma(q0, dir ? DY_STRIDE : 1, b, alpha, beta, tc0);
+			bool act = lane < 32 && !(pl && (e & 1));
+			if (e == 0) act = act && (dir ? hasT : hasL);
+			else if (e & 1) act = act && !(t8 && pl == 0);
+			if (act) {
+				int b = L.prm[dir * 16 + e * 4 + (pl ? li >> 1 : li >> 2)];
+				if (b) {
+					int t = e == 0 ? 1 + dir : 0;
+					int alpha = L.prm[32 + pl * 3 + t], beta = L.prm[41 + pl * 3 + t], iA = L.prm[50 + pl * 3 + t];
+					int tc0 = b < 4 ? tc0tab[(b - 1) * 52 + iA] : 0;
+					if (pl == 0) {
+						int v[8];
+						if (dir == 0) {
+							uint32_t P = *(const uint32_t *)&L.DYT(li, e * 4 - 4), Q = *(const uint32_t *)&L.DYT(li, e * 4);
+							v[0] = P & 255; v[1] = P >> 8 & 255; v[2] = P >> 16 & 255; v[3] = P >> 24;
+							v[4] = Q & 255; v[5] = Q >> 8 & 255; v[6] = Q >> 16 & 255; v[7] = Q >> 24;
+							luma_filter8(v, b, alpha, beta, tc0);
+							*(uint32_t *)&L.DYT(li, e * 4 - 4) = (uint32_t)v[0] | (uint32_t)v[1] << 8 | (uint32_t)v[2] << 16 | (uint32_t)v[3] << 24;
+							*(uint32_t *)&L.DYT(li, e * 4) = (uint32_t)v[4] | (uint32_t)v[5] << 8 | (uint32_t)v[6] << 16 | (uint32_t)v[7] << 24;
 						} else {
-							uint8_t *q0 = dir ? &L.DCT(pl - 1, e * 2, li) : &L.DCT(pl - 1, li, e * 2);
-							filter_chroma(q0, dir ? DC_STRIDE : 1, b, alpha, beta, tc0);
+#pragma unroll
+							for (int i = 0; i < 8; i++) v[i] = L.DYT(e * 4 - 4 + i, li);
+							luma_filter8(v, b, alpha, beta, tc0);
+#pragma unroll
+							for (int i = 1; i < 7; i++) L.DYT(e * 4 - 4 + i, li) = (uint8_t)v[i];
+						}
+					} else {
+						int p1, p0, q0, q1;
+						if (dir == 0) {
+							p1 = L.DCT(pl - 1, li, e * 2 - 2); p0 = L.DCT(pl - 1, li, e * 2 - 1);
+							q0 = L.DCT(pl - 1, li, e * 2); q1 = L.DCT(pl - 1, li, e * 2 + 1);
+							chroma_filter4(p1, p0, q0, q1, b, alpha, beta, tc0);
+							L.DCT(pl - 1, li, e * 2 - 1) = (uint8_t)p0; L.DCT(pl - 1, li, e * 2) = (uint8_t)q0;
+						} else {
+							p1 = L.DCT(pl - 1, e * 2 - 2, li); p0 = L.DCT(pl - 1, e * 2 - 1, li);
+							q0 = L.DCT(pl - 1, e * 2, li); q1 = L.DCT(pl - 1, e * 2 + 1, li);
+							chroma_filter4(p1, p0, q0, q1, b, alpha, beta, tc0);
+							L.DCT(pl - 1, e * 2 - 1, li) = (uint8_t)p0; L.DCT(pl - 1, e * 2, li) = (uint8_t)q0;
 						}
 					}
 				}
@@ -1020,24 +1094,18 @@ __device__ __forceinline__ void deblock_mb(WaveLds &L, const FrameCtx &f, int mb
 			wave_sync();
 		}
 	}
-	// write back what this macroblock may have modified (its own samples, 3 columns / rows of neighbours)
-	for (int i = lane; i < 100; i += 64) {
-		int row = i / 5 - 4, col = (i % 5) * 4 - 4;
-		bool ok = (row >= 0 || hasT) && (col >= 0 || hasL) && !(row < 0 && col < 0);
-		if (ok) *(uint32_t *)(Yb + (ptrdiff_t)row * f.sY + col) = *(const uint32_t *)&L.DYT(row, col);
+	// ---- write back: own samples, the top rows and the carried left columns ------------------
+	*(gu32 *)(Yb + (size_t)ar * f.sY + ac) = *(const uint32_t *)&L.DYT(ar, ac);
+	if (!b_top || hasT)
+		*(gu32 *)bptr = b_luma ? *(const uint32_t *)&L.DYT(brow, bcol) : *(const uint32_t *)&L.DCT(bpl, brow, bcol);
+	if (hasL && lane < 32) {
+		if (lane < 16) *(gu32 *)(Yb + (size_t)crow * f.sY - 4) = *(const uint32_t *)&L.DYT(crow, -4);
+		else *(gu32 *)(Cb0 + cpl * half + (size_t)crow * f.sC - 4) = *(const uint32_t *)&L.DCT(cpl, crow, -4);
 	}
-	for (int i = lane; i < 72; i += 64) {
-		int p = i / 36, j = i % 36;
-		int row = j / 3 - 4, col = (j % 3) * 4 - 4;
-		uint8_t *Cb = plane_base(f, f.cur, 1 + p) + (size_t)(mby * 8) * f.sC + mbx * 8;
-		bool ok = (row >= 0 || hasT) && (col >= 0 || hasL) && !(row < 0 && col < 0);
-		if (ok) *(uint32_t *)(Cb + (ptrdiff_t)row * f.sC + col) = *(const uint32_t *)&L.DCT(p, row, col);
-	}
-	wave_sync();
 }
 
 // ---------------------------------------------------------------------------------
-// frame kernel: one workgroup per job, NW waves, wavefront over macroblock rows
+// kernels
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ int lds_load_relaxed(const int *p)
 {
@@ -1060,63 +1128,128 @@ __device__ __forceinline__ bool open_frame(FrameCtx &f, const E264Job &job)
 	f.W = f.wm * 16; f.H = f.hm * 16;
 	f.sY = (int)h->stride_Y; f.sC = (int)h->stride_C;
 	f.psY = h->plane_size_Y;
+	f.dbk = job.dbk;
 	return f.cur != nullptr;
 }
 
 #define E264_MAX_ROWS 1056
 } // namespace
 
+// every macroblock of every frame in parallel: 4 waves per workgroup, one macroblock per wave
+__global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, int mode)
+{
+	__shared__ WaveLds lds[4];
+	const int lane = lane_id();
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	FrameCtx f;
+	if (!open_frame(f, jobs[blockIdx.y]))
+		return;
+	const int addr = (int)blockIdx.x * 4 + wave;
+	if (addr >= f.wm * f.hm)
+		return;
+	const int mby = addr / f.wm, mbx = addr - mby * f.wm;
+	if (mode & 1)
+		recon_mb<1>(lds[wave], f, mbx, mby, lane);
+	if ((mode & 2) && f.dbk)
+		write_dbk_params(f, mbx, mby, lane);
+}
+
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void e264_frame_kernel(const E264Job *jobs, int mode)
+__global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs)
 {
 	__shared__ WaveLds lds[NW];
-	__shared__ int progress[2][E264_MAX_ROWS]; // macroblocks finished per row, per pass
+	__shared__ int progress[E264_MAX_ROWS]; // macroblocks finished per row
 	const int lane = lane_id();
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	FrameCtx f;
 	if (!open_frame(f, jobs[blockIdx.x]))
 		return;
-	for (int i = threadIdx.x; i < 2 * E264_MAX_ROWS; i += NW * 64)
-		(&progress[0][0])[i] = 0;
+	if (f.h->n_coded_mbs == f.h->n_inter_mbs)
+		return; // nothing intra in this frame (PCM is handled by the parallel kernel but counted as coded: rare)
+	for (int i = threadIdx.x; i < f.hm; i += NW * 64)
+		progress[i] = 0;
 	__syncthreads();
 	WaveLds &L = lds[wave];
 #pragma unroll 1
-	for (int pass = 0; pass < 2; pass++) {
-		if (!(mode & (1 << pass)))
-			continue;
-		int *prog = progress[pass];
+	for (int y = wave; y < f.hm; y += NW) {
 #pragma unroll 1
-		for (int y = wave; y < f.hm; y += NW) {
-#pragma unroll 1
-			for (int x = 0; x < f.wm; x++) {
-				bool need = y > 0;
-				if (pass == 0)
-					need = need && f.mbs[y * f.wm + x].kind != E264_MB_INTER; // inter MBs depend on nothing in this frame
-				if (need) {
+		for (int x = 0; x < f.wm; x++) {
+			const int kind = f.mbs[y * f.wm + x].kind;
+			const bool intra = kind == E264_MB_I4x4 || kind == E264_MB_I8x8 || kind == E264_MB_I16x16;
+			if (intra) {
+				if (y > 0) {
 					int want = min(x + 2, f.wm);
-					while (lds_load_relaxed(&prog[y - 1]) < want)
-						__builtin_amdgcn_s_sleep(2);
+					while (lds_load_relaxed(&progress[y - 1]) < want)
+						__builtin_amdgcn_s_sleep(1);
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 				}
-				if (pass == 0) recon_mb(L, f, x, y, lane);
-				else deblock_mb(L, f, x, y, lane);
+				recon_mb<2>(L, f, x, y, lane);
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-				if (lane == 0)
-					__hip_atomic_store(&prog[y], x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
+			if (lane == 0 && (intra || x == f.wm - 1 || (x & 7) == 7))
+				__hip_atomic_store(&progress[y], x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
-		__syncthreads();
 	}
 }
 
-extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int mode, int waves, hipStream_t stream)
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jobs)
+{
+	__shared__ DbkLds lds[NW];
+	__shared__ int progress[E264_MAX_ROWS];
+	__shared__ uint8_t tc0tab[3 * 52];
+	const int lane = lane_id();
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	FrameCtx f;
+	if (!open_frame(f, jobs[blockIdx.x]) || !f.dbk)
+		return;
+	for (int i = threadIdx.x; i < f.hm; i += NW * 64)
+		progress[i] = 0;
+	for (int i = threadIdx.x; i < 3 * 52; i += NW * 64)
+		tc0tab[i] = c_tc0[i / 52][i % 52];
+	__syncthreads();
+	DbkLds &L = lds[wave];
+#pragma unroll 1
+	for (int y = wave; y < f.hm; y += NW) {
+#pragma unroll 1
+		for (int x = 0; x < f.wm; x++) {
+			if (y > 0) {
+				int want = min(x + 2, f.wm);
+				while (lds_load_relaxed(&progress[y - 1]) < want)
+					__builtin_amdgcn_s_sleep(1);
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			}
+			deblock_mb(L, tc0tab, f, x, y, lane, x > 0);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			if (lane == 0)
+				__hip_atomic_store(&progress[y], x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+	}
+}
+
+extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int max_mbs, int mode, int waves, hipStream_t stream, hipEvent_t *marks)
 {
 	if (n_jobs <= 0)
 		return hipSuccess;
-	switch (waves) {
-	case 4: hipLaunchKernelGGL(e264_frame_kernel<4>, dim3(n_jobs), dim3(256), 0, stream, jobs, mode); break;
-	case 16: hipLaunchKernelGGL(e264_frame_kernel<16>, dim3(n_jobs), dim3(1024), 0, stream, jobs, mode); break;
-	default: hipLaunchKernelGGL(e264_frame_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs, mode); break;
+	// marks (optional): 4 events recorded before / between / after the three launches
+	if (marks) hipEventRecord(marks[0], stream);
+	hipLaunchKernelGGL(e264_mbpar_kernel, dim3((max_mbs + 3) / 4, n_jobs), dim3(256), 0, stream, jobs, mode);
+	if (marks) hipEventRecord(marks[1], stream);
+	if (mode & 1) {
+		switch (waves) {
+		case 4: hipLaunchKernelGGL(e264_intra_kernel<4>, dim3(n_jobs), dim3(256), 0, stream, jobs); break;
+		case 16: hipLaunchKernelGGL(e264_intra_kernel<16>, dim3(n_jobs), dim3(1024), 0, stream, jobs); break;
+		default: hipLaunchKernelGGL(e264_intra_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs); break;
+		}
 	}
+	if (marks) hipEventRecord(marks[2], stream);
+	if (mode & 2) {
+		switch (waves) {
+		case 4: hipLaunchKernelGGL(e264_deblock_kernel<4>, dim3(n_jobs), dim3(256), 0, stream, jobs); break;
+		case 16: hipLaunchKernelGGL(e264_deblock_kernel<16>, dim3(n_jobs), dim3(1024), 0, stream, jobs); break;
+		default: hipLaunchKernelGGL(e264_deblock_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs); break;
+		}
+	}
+	if (marks) hipEventRecord(marks[3], stream);
 	return hipGetLastError();
 }
