@@ -36,6 +36,16 @@ __device__ __forceinline__ int w16(int v) { return (int)(int16_t)v; }
 typedef uint8_t __attribute__((address_space(1))) gu8;   // global memory, so that loads/stores are global_* not flat_*
 typedef uint32_t __attribute__((address_space(1))) gu32;
 typedef uint16_t __attribute__((address_space(1))) gu16;
+typedef int16_t __attribute__((address_space(1))) gi16;
+// the command packet is read-only for every kernel: constant address space => uniform reads become
+// scalar loads (s_load) and the values live in SGPRs
+typedef const E264FrameHdr __attribute__((address_space(4))) *chdr_t;
+typedef const E264SliceParams __attribute__((address_space(4))) *cslice_t;
+typedef const E264Mb __attribute__((address_space(4))) *cmb_t;
+typedef const E264Motion __attribute__((address_space(1))) *gmotion_t;
+typedef const uint8_t __attribute__((address_space(4))) *cu8p;
+typedef uint8_t *generic_u8p;
+typedef const generic_u8p __attribute__((address_space(1))) *gdpb_t;
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 // All LDS scratch is private to one wave; LDS operations of a wave execute in order, so a
 // compiler-level fence is all that is needed between producer and consumer lanes.
@@ -105,29 +115,58 @@ struct __attribute__((aligned(16))) WaveLds { // reconstruction scratch of one w
 	uint8_t fleft[8];          // intra 8x8 filtered left
 };
 
-struct __attribute__((aligned(16))) DbkLds { // deblocking scratch of one wave
+#define DBK_RING 8 // macroblocks of bottom rows each row keeps in LDS for the row below
+#define DBK_LAG 3  // the second row of a wave trails the first by this many macroblocks
+struct __attribute__((aligned(16))) DbkTile {
 	uint8_t dytile[20 * DY_STRIDE];
 	uint8_t dctile[2][12 * DC_STRIDE];
 	uint8_t prm[E264_DBK_BYTES]; // deblocking parameters of the current macroblock
 };
+// Hand-off to the macroblock row below: the last 4 luma rows / 2 chroma rows of the most recent
+// DBK_RING macroblocks, final for the row below once this row is 2 macroblocks further.
+struct __attribute__((aligned(16))) DbkRing {
+	uint32_t y[4][DBK_RING * 4];      // [row 12..15][mb slot * 4 + dword]
+	uint32_t c[2][2][DBK_RING * 2];   // [plane][row 6..7][mb slot * 2 + dword]
+};
+struct __attribute__((aligned(16))) DbkLds { // deblocking scratch of one wave = two macroblock rows
+	DbkTile tile[2];     // [half-wave]
+	DbkRing ring[2][2];  // [parity of the row-pair round][half-wave]
+};
 
 struct FrameCtx {
-	const E264FrameHdr *h;
-	const E264SliceParams *slices;
-	const E264Mb *mbs;
-	const uint8_t *payload;
-	uint8_t *const *dpb;
-	uint8_t *cur;
+	chdr_t h;
+	cslice_t slices;
+	cmb_t mbs;
+	const gu8 *payload;
+	gdpb_t dpb;
+	gu8 *cur;
 	int W, H;          // luma samples
 	int wm, hm;        // macroblocks
 	int sY, sC;        // strides
 	uint32_t psY;      // plane_size_Y
-	uint8_t *dbk;      // per-MB deblocking parameters (E264_DBK_BYTES each), written by the mbpar kernel
+	gu8 *dbk;          // per-MB deblocking parameters (E264_DBK_BYTES each), written by the mbpar kernel
 };
 
-__device__ __forceinline__ uint8_t *plane_base(const FrameCtx &f, uint8_t *base, int pl)
+__device__ __forceinline__ gu8 *plane_base(const FrameCtx &f, gu8 *base, int pl)
 {
 	return pl == 0 ? base : base + f.psY + (pl == 2 ? (f.sC >> 1) : 0);
+}
+
+// register copy of one macroblock header (uniform: fetched with scalar loads)
+struct MbInfo {
+	int kind, flags, chroma_mode, i16_mode, slice;
+	uint8_t qp[3];
+	uint32_t coded, payload_off, modes_lo, modes_hi;
+};
+__device__ __forceinline__ MbInfo load_mb(cmb_t p)
+{
+	MbInfo m;
+	m.kind = p->kind; m.flags = p->flags; m.chroma_mode = p->chroma_mode; m.i16_mode = p->i16_mode; m.slice = p->slice;
+	m.qp[0] = p->qp[0]; m.qp[1] = p->qp[1]; m.qp[2] = p->qp[2];
+	m.coded = p->coded; m.payload_off = p->payload_off;
+	m.modes_lo = *(const uint32_t __attribute__((address_space(4))) *)&p->modes[0];
+	m.modes_hi = *(const uint32_t __attribute__((address_space(4))) *)&p->modes[4];
+	return m;
 }
 
 // ---------------------------------------------------------------------------------
@@ -137,14 +176,14 @@ __device__ __forceinline__ uint8_t *plane_base(const FrameCtx &f, uint8_t *base,
 // (edge264_residual.c:118-134); pass 2 (lane = block k, column x'): vertical butterfly, >>6,
 // saturate to int16 (residual.c:141-158).  dc_only blocks get the add_dc4x4 value (residual.c:174-187).
 __device__ __forceinline__ void idct4x4_blocks(WaveLds &L, int nblk, uint32_t codedmask, bool use_dc, bool dc_valid,
-	const int16_t *coef_base, const uint8_t *wS, int qP, int dc_off, int res_off, int res_stride, int lane)
+	const gi16 *coef_base, cu8p wS, int qP, int dc_off, int res_off, int res_stride, int lane)
 {
 	int k = lane >> 2, y = lane & 3;
 	bool active = k < nblk;
 	bool coded = active && (codedmask >> k & 1);
 	if (coded) {
 		// coefficient blocks are packed in increasing k: offset = popcount of lower coded bits
-		const int16_t *c = coef_base + __builtin_popcount(codedmask & ((1u << k) - 1)) * 16;
+		const gi16 *c = coef_base + __builtin_popcount(codedmask & ((1u << k) - 1)) * 16;
 		int sh = qP / 6, m = qP - sh * 6;
 		int d[4];
 #pragma unroll
@@ -211,7 +250,7 @@ __device__ __forceinline__ void idct8_1d(int16_t d[8])
 	d[4] = (int16_t)(f6 - f1); d[5] = (int16_t)(f4 - f3); d[6] = (int16_t)(f2 - f5); d[7] = (int16_t)(f0 - f7);
 }
 
-__device__ __forceinline__ void idct8x8_blocks(WaveLds &L, uint32_t coded, const int16_t *coef_base, const uint8_t *wS, int qP, int lane)
+__device__ __forceinline__ void idct8x8_blocks(WaveLds &L, uint32_t coded, const gi16 *coef_base, cu8p wS, int qP, int lane)
 {
 	int b = lane >> 3, j = lane & 7;
 	bool on = lane < 32 && (coded >> (b * 4) & 1);
@@ -219,7 +258,7 @@ __device__ __forceinline__ void idct8x8_blocks(WaveLds &L, uint32_t coded, const
 	if (on) {
 		int nb = 0;
 		for (int i = 0; i < b; i++) nb += coded >> (i * 4) & 1;
-		const int16_t *c = coef_base + nb * 64;
+		const gi16 *c = coef_base + nb * 64;
 		int div = qP / 6, m = qP - div * 6;
 		int16_t d[8];
 #pragma unroll
@@ -253,17 +292,17 @@ __device__ __forceinline__ void idct8x8_blocks(WaveLds &L, uint32_t coded, const
 	wave_sync();
 }
 
-__device__ __forceinline__ void compute_residual(WaveLds &L, const FrameCtx &f, const E264Mb &m, const E264SliceParams *s, const uint8_t *pl, int lane)
+__device__ __forceinline__ void compute_residual(WaveLds &L, const FrameCtx &f, const MbInfo &m, cslice_t s, const gu8 *pl, int lane)
 {
 	// zero the residual tile (384 int16 = 192 dwords)
 	uint32_t *rz = (uint32_t *)L.res;
 	rz[lane] = 0; rz[lane + 64] = 0; rz[lane + 128] = 0;
 	const uint32_t coded = m.coded;
 	const bool inter = m.kind == E264_MB_INTER;
-	const int16_t *ldc = nullptr, *cdc = nullptr;
-	if (coded & E264_CODED_LUMA_DC) { ldc = (const int16_t *)pl; pl += 32; }
-	if (coded & E264_CODED_CHROMA_DC) { cdc = (const int16_t *)pl; pl += 16; }
-	const int16_t *co = (const int16_t *)pl;
+	const gi16 *ldc = nullptr, *cdc = nullptr;
+	if (coded & E264_CODED_LUMA_DC) { ldc = (const gi16 *)pl; pl += 32; }
+	if (coded & E264_CODED_CHROMA_DC) { cdc = (const gi16 *)pl; pl += 16; }
+	const gi16 *co = (const gi16 *)pl;
 	if (lane < 24) L.dc[lane] = 0;
 	wave_sync();
 	if (!coded) return;
@@ -329,7 +368,7 @@ __device__ __forceinline__ int wpred(int q, int p, const Wod &w)
 }
 
 // decode_inter weight selection, edge264_inter.c:1137-1197
-__device__ __forceinline__ void select_weights(const E264SliceParams *s, int list, int refIdx, int refIdxX, Wod &wY, Wod &wCb, Wod &wCr)
+__device__ __forceinline__ void select_weights(cslice_t s, int list, int refIdx, int refIdxX, Wod &wY, Wod &wCb, Wod &wCr)
 {
 	Wod nw = {0, 1, 0, 0};
 	wY = wCb = wCr = nw;
@@ -384,13 +423,13 @@ __device__ __forceinline__ void select_weights(const E264SliceParams *s, int lis
 
 // 9 consecutive samples x0..x0+8 of row y (clamped coordinates == the reference's edge
 // emulation, edge264_inter.c:1199-1235).  Fast path: three aligned dwords + byte alignment.
-__device__ __forceinline__ void load_row9(const uint8_t *plane, int stride, int W, int H, int x0, int y, int px[9])
+__device__ __forceinline__ void load_row9(const gu8 *plane, int stride, int W, int H, int x0, int y, int px[9])
 {
 	y = clip3i(0, H - 1, y);
-	const uint8_t *row = plane + (size_t)y * stride;
+	const gu8 *row = plane + (size_t)y * stride;
 	if (x0 >= 0 && x0 + 8 <= W - 1) {
 		uintptr_t p = (uintptr_t)(row + x0);
-		const uint32_t *q = (const uint32_t *)(p & ~(uintptr_t)3);
+		const gu32 *q = (const gu32 *)(p & ~(uintptr_t)3);
 		uint32_t off = (uint32_t)(p & 3);
 		uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
 		uint32_t a = __builtin_amdgcn_alignbyte(d1, d0, off);
@@ -420,7 +459,7 @@ __device__ __forceinline__ int avg2(int a, int b) { return (a + b + 1) >> 1; }
 
 // 4 horizontally adjacent luma samples at (X..X+3, Y) displaced by the quarter-pel (xF,yF):
 // 8.4.2.2.1 organised like decode_inter_luma (edge264_inter.c:416-968).
-__device__ __forceinline__ void luma_pred4(const uint8_t *ref, int stride, int W, int H, int X, int Y, int xF, int yF, int out[4])
+__device__ __forceinline__ void luma_pred4(const gu8 *ref, int stride, int W, int H, int X, int Y, int xF, int yF, int out[4])
 {
 	int px[9];
 	if (yF == 0) {
@@ -486,7 +525,7 @@ __device__ __forceinline__ void luma_pred4(const uint8_t *ref, int stride, int W
 	}
 }
 
-__device__ __forceinline__ int ldc_px(const uint8_t *plane, int stride, int W, int H, int x, int y)
+__device__ __forceinline__ int ldc_px(const gu8 *plane, int stride, int W, int H, int x, int y)
 {
 	return plane[(size_t)clip3i(0, H - 1, y) * stride + clip3i(0, W - 1, x)];
 }
@@ -494,7 +533,7 @@ __device__ __forceinline__ int ldc_px(const uint8_t *plane, int stride, int W, i
 // Inter prediction of a whole macroblock in the "pixel layout":
 //   luma   lane = (k = lane>>2 : 4x4 block in zig order, r = lane&3 : row) -> 4 samples
 //   chroma lane = (plane = lane>>5, cy = (lane>>2)&7, cx = (lane&3)*2)    -> 2 samples
-__device__ __forceinline__ void inter_pred_mb(const FrameCtx &f, const E264SliceParams *s, const E264Motion *mo, int mbx, int mby, int lane,
+__device__ __forceinline__ void inter_pred_mb(const FrameCtx &f, cslice_t s, gmotion_t mo, int mbx, int mby, int lane,
 	int outY[4], int outC[2])
 {
 	const int k = lane >> 2, r = lane & 3;
@@ -511,7 +550,7 @@ __device__ __forceinline__ void inter_pred_mb(const FrameCtx &f, const E264Slice
 		if (pic >= 0) {
 			int mx = mo->mvs[list * 32 + k * 2], my = mo->mvs[list * 32 + k * 2 + 1];
 			int p[4];
-			luma_pred4(f.dpb[pic], f.sY, f.W, f.H, lx + (mx >> 2), ly + (my >> 2), mx & 3, my & 3, p);
+			luma_pred4((const gu8 *)f.dpb[pic], f.sY, f.W, f.H, lx + (mx >> 2), ly + (my >> 2), mx & 3, my & 3, p);
 			int refIdxX = mo->refIdx[(list ^ 1) * 4 + (k >> 2)];
 			if (idc == 0 && !(list == 1 && refIdxX >= 0)) {
 #pragma unroll
@@ -527,7 +566,7 @@ __device__ __forceinline__ void inter_pred_mb(const FrameCtx &f, const E264Slice
 		int picc = mo->refPic[list * 4 + (kc >> 2)];
 		if (picc >= 0) {
 			int mx = mo->mvs[list * 32 + kc * 2], my = mo->mvs[list * 32 + kc * 2 + 1];
-			const uint8_t *rp = plane_base(f, f.dpb[picc], 1 + cpl);
+			const gu8 *rp = plane_base(f, (gu8 *)f.dpb[picc], 1 + cpl);
 			int X = mbx * 8 + cx + (mx >> 3), Y = mby * 8 + cy + (my >> 3);
 			int xF = mx & 7, yF = my & 7;
 			int A = (8 - xF) * (8 - yF), B = xF * (8 - yF), C = (8 - xF) * yF, D = xF * yF;
@@ -559,7 +598,7 @@ __device__ __forceinline__ void inter_pred_mb(const FrameCtx &f, const E264Slice
 // Out-of-frame positions are never dereferenced; the remapped modes never use them.
 __device__ __forceinline__ void load_intra_neighbours(WaveLds &L, const FrameCtx &f, int mbx, int mby, int lane)
 {
-	const uint8_t *Y = f.cur + (size_t)(mby * 16) * f.sY + mbx * 16;
+	const gu8 *Y = f.cur + (size_t)(mby * 16) * f.sY + mbx * 16;
 	// luma top row x = -1..23 (lanes 0..24), left column (lanes 32..47)
 	if (lane < 25) {
 		int x = lane - 1;
@@ -576,7 +615,7 @@ __device__ __forceinline__ void load_intra_neighbours(WaveLds &L, const FrameCtx
 	// second round for chroma (keeps the lane mapping simple)
 	if (lane < 18) {
 		int pl = lane / 9, x = lane % 9 - 1;
-		const uint8_t *C = plane_base(f, f.cur, 1 + pl) + (size_t)(mby * 8) * f.sC + mbx * 8;
+		const gu8 *C = plane_base(f, f.cur, 1 + pl) + (size_t)(mby * 8) * f.sC + mbx * 8;
 		int gx = mbx * 8 + x;
 		uint8_t v = 0;
 		if (mby > 0 && gx >= 0)
@@ -584,7 +623,7 @@ __device__ __forceinline__ void load_intra_neighbours(WaveLds &L, const FrameCtx
 		L.CT(pl, -1, x) = v;
 	} else if (lane >= 32 && lane < 48) {
 		int pl = (lane - 32) >> 3, y = lane & 7;
-		const uint8_t *C = plane_base(f, f.cur, 1 + pl) + (size_t)(mby * 8) * f.sC + mbx * 8;
+		const gu8 *C = plane_base(f, f.cur, 1 + pl) + (size_t)(mby * 8) * f.sC + mbx * 8;
 		L.CT(pl, y, -1) = mbx > 0 ? C[(size_t)y * f.sC - 1] : 0;
 	}
 	wave_sync();
@@ -808,29 +847,29 @@ __device__ __forceinline__ int intra_chroma_px(const WaveLds &L, int p, int mode
 template <int WHICH>
 __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, int mbx, int mby, int lane)
 {
-	const E264Mb m = f.mbs[mby * f.wm + mbx];
+	const MbInfo m = load_mb(f.mbs + mby * f.wm + mbx);
 	if (m.kind == E264_MB_ABSENT)
 		return;
 	const bool par = m.kind == E264_MB_INTER || m.kind == E264_MB_PCM;
 	if ((WHICH == 1 && !par) || (WHICH == 2 && par))
 		return;
-	const E264SliceParams *s = f.slices + m.slice;
-	const uint8_t *pl = f.payload + m.payload_off;
+	cslice_t s = f.slices + m.slice;
+	const gu8 *pl = f.payload + m.payload_off;
 	// pixel layout
 	const int k = lane >> 2, r = lane & 3;
 	const int X = BXf(k), Yr = BYf(k) + r;
-	uint8_t *dY = f.cur + (size_t)(mby * 16 + Yr) * f.sY + mbx * 16 + X;
+	gu8 *dY = f.cur + (size_t)(mby * 16 + Yr) * f.sY + mbx * 16 + X;
 	const int cpl = lane >> 5, cy = (lane >> 2) & 7, cx = (lane & 3) * 2;
-	uint8_t *dC = plane_base(f, f.cur, 1 + cpl) + (size_t)(mby * 8 + cy) * f.sC + mbx * 8 + cx;
+	gu8 *dC = plane_base(f, f.cur, 1 + cpl) + (size_t)(mby * 8 + cy) * f.sC + mbx * 8 + cx;
 
 	if (m.kind == E264_MB_PCM) { // edge264_slice.c:914-935
-		*(uint32_t *)dY = *(const uint32_t *)(pl + Yr * 16 + X);
-		*(uint16_t *)dC = *(const uint16_t *)(pl + 256 + cpl * 64 + cy * 8 + cx);
+		*(gu32 *)dY = *(const gu32 *)(pl + Yr * 16 + X);
+		*(gu16 *)dC = *(const gu16 *)(pl + 256 + cpl * 64 + cy * 8 + cx);
 		return;
 	}
-	const E264Motion *mo = nullptr;
-	if (m.kind == E264_MB_INTER) { mo = (const E264Motion *)pl; pl += sizeof(E264Motion); }
-	const uint32_t modes_lo = *(const uint32_t *)&m.modes[0], modes_hi = *(const uint32_t *)&m.modes[4];
+	gmotion_t mo = nullptr;
+	if (m.kind == E264_MB_INTER) { mo = (gmotion_t)pl; pl += sizeof(E264Motion); }
+	const uint32_t modes_lo = m.modes_lo, modes_hi = m.modes_hi;
 	compute_residual(L, f, m, s, pl, lane);
 
 	int pY[4], pC[2];
@@ -874,20 +913,20 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, int mbx,
 		outw = (uint32_t)clip255(w16(pY[0] + rr[0])) | (uint32_t)clip255(w16(pY[1] + rr[1])) << 8 |
 			(uint32_t)clip255(w16(pY[2] + rr[2])) << 16 | (uint32_t)clip255(w16(pY[3] + rr[3])) << 24;
 	}
-	*(uint32_t *)dY = outw;
+	*(gu32 *)dY = outw;
 	const int16_t *rc = L.res + 256 + cpl * 64 + cy * 8 + cx;
-	*(uint16_t *)dC = (uint16_t)(clip255(w16(pC[0] + rc[0])) | clip255(w16(pC[1] + rc[1])) << 8);
+	*(gu16 *)dC = (uint16_t)(clip255(w16(pC[0] + rc[0])) | clip255(w16(pC[1] + rc[1])) << 8);
 }
 
 // ---------------------------------------------------------------------------------
 // deblocking of one macroblock by one wave
 // ---------------------------------------------------------------------------------
 struct BlkMo { int ref0, ref1, mv0x, mv0y, mv1x, mv1y; };
-__device__ __forceinline__ BlkMo blk_motion(const FrameCtx &f, const E264Mb *m, int k)
+__device__ __forceinline__ BlkMo blk_motion(const FrameCtx &f, cmb_t m, int k)
 {
 	BlkMo o = {-1, -1, 0, 0, 0, 0};
 	if (m->kind == E264_MB_INTER) {
-		const E264Motion *mo = (const E264Motion *)(f.payload + m->payload_off);
+		gmotion_t mo = (gmotion_t)(f.payload + m->payload_off);
 		o.ref0 = mo->refPic[k >> 2]; o.ref1 = mo->refPic[4 + (k >> 2)];
 		o.mv0x = mo->mvs[k * 2]; o.mv0y = mo->mvs[k * 2 + 1];
 		o.mv1x = mo->mvs[32 + k * 2]; o.mv1y = mo->mvs[32 + k * 2 + 1];
@@ -896,11 +935,11 @@ __device__ __forceinline__ BlkMo blk_motion(const FrameCtx &f, const E264Mb *m, 
 }
 __device__ __forceinline__ int far4(int ax, int ay, int bx, int by) { return (abs(ax - bx) >= 4) | (abs(ay - by) >= 4); }
 
-__device__ __forceinline__ int mb_bs_lane(const FrameCtx &f, const E264Mb *m, int lane)
+__device__ __forceinline__ int mb_bs_lane(const FrameCtx &f, cmb_t m, int lane)
 { // lane -> (dir, edge, segment); edge264_deblock.c:958-1118
 	const int dir = lane >> 4 & 1, e = lane >> 2 & 3, sg = lane & 3;
 	const bool intra = m->kind != E264_MB_INTER;
-	const E264Mb *n = m;
+	cmb_t n = m;
 	if (e == 0) {
 		if (!(m->flags & (dir ? E264_MBF_EDGE_TOP : E264_MBF_EDGE_LEFT)))
 			return 0;
@@ -929,18 +968,18 @@ __device__ __forceinline__ int mb_bs_lane(const FrameCtx &f, const E264Mb *m, in
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ void write_dbk_params(const FrameCtx &f, int mbx, int mby, int lane)
 {
-	const E264Mb *m = f.mbs + mby * f.wm + mbx;
-	uint8_t *out = f.dbk + (size_t)(mby * f.wm + mbx) * E264_DBK_BYTES;
+	cmb_t m = f.mbs + mby * f.wm + mbx;
+	gu8 *out = f.dbk + (size_t)(mby * f.wm + mbx) * E264_DBK_BYTES;
 	if (!(m->flags & E264_MBF_DEBLOCK) || m->kind == E264_MB_ABSENT) {
-		if (lane < 16) ((uint32_t *)out)[lane] = 0;
+		if (lane < 16) ((gu32 *)out)[lane] = 0;
 		return;
 	}
 	if (lane < 32) {
 		out[lane] = (uint8_t)mb_bs_lane(f, m, lane);
 	} else if (lane < 59) {
-		const E264SliceParams *s = f.slices + m->slice;
+		cslice_t s = f.slices + m->slice;
 		int idx = lane - 32, what = idx / 9, pt = idx % 9, pl = pt / 3, t = pt % 3;
-		const E264Mb *n = m;
+		cmb_t n = m;
 		if (t == 1 && (m->flags & E264_MBF_EDGE_LEFT)) n = m - 1;
 		if (t == 2 && (m->flags & E264_MBF_EDGE_TOP)) n = m - f.wm;
 		int qPav = (m->qp[pl] + n->qp[pl] + 1) >> 1;
@@ -950,157 +989,231 @@ __device__ __forceinline__ void write_dbk_params(const FrameCtx &f, int mbx, int
 }
 
 // ---------------------------------------------------------------------------------
-// edge filters on values: v[0..7] = p3 p2 p1 p0 q0 q1 q2 q3   (edge264_deblock.c:95-129, 213-260)
+// deblocking wavefront (edge264_deblock.c:284-895): ONE HALF-WAVE PER MACROBLOCK ROW.
+// A wave owns two consecutive rows; lanes 0..31 walk the upper row, lanes 32..63 the lower row
+// DBK_LAG macroblocks behind, so that all 64 lanes filter (16 luma + 8 Cb + 8 Cr lines per row).
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void luma_filter8(int v[8], int bS, int alpha, int beta, int tc0)
+// One edge on 8 values p3 p2 p1 p0 | q0 q1 q2 q3 held in registers; chroma lines use the same
+// code with ap/aq/strong forced off and tc = tC0+1 (deblock.c:95-152, 213-276).  Branch-free.
+__device__ __forceinline__ void edge_filter(int &p3, int &p2, int &p1, int &p0, int &q0, int &q1, int &q2, int &q3,
+	int bS, int alpha, int beta, int tc0, bool chroma)
 {
-	int p3 = v[0], p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6], q3 = v[7];
-	if (bS == 0 || !(abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta))
-		return;
-	bool ap = abs(p2 - p0) < beta, aq = abs(q2 - q0) < beta;
-	if (bS < 4) {
-		int tc = tc0 + ap + aq;
-		int delta = clip3i(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
-		v[3] = clip255(p0 + delta);
-		v[4] = clip255(q0 - delta);
-		int avg = (p0 + q0 + 1) >> 1;
-		if (ap) v[2] = p1 + clip3i(-tc0, tc0, (p2 + avg - 2 * p1) >> 1);
-		if (aq) v[5] = q1 + clip3i(-tc0, tc0, (q2 + avg - 2 * q1) >> 1);
-	} else {
-		bool small = abs(p0 - q0) < (alpha >> 2) + 2;
-		if (ap && small) {
-			v[3] = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3;
-			v[2] = (p2 + p1 + p0 + q0 + 2) >> 2;
-			v[1] = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
-		} else v[3] = (2 * p1 + p0 + q1 + 2) >> 2;
-		if (aq && small) {
-			v[4] = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3;
-			v[5] = (p0 + q0 + q1 + q2 + 2) >> 2;
-			v[6] = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
-		} else v[4] = (2 * q1 + q0 + p1 + 2) >> 2;
-	}
+	const int dpq = abs(p0 - q0);
+	const bool go = (bS != 0) & (dpq < alpha) & (abs(p1 - p0) < beta) & (abs(q1 - q0) < beta);
+	const bool ap = !chroma & (abs(p2 - p0) < beta), aq = !chroma & (abs(q2 - q0) < beta);
+	const bool strong = bS == 4;
+	// bS < 4
+	const int tc = tc0 + (chroma ? 1 : (int)ap + (int)aq);
+	const int delta = clip3i(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
+	const int avg = (p0 + q0 + 1) >> 1;
+	const int w_p0 = clip255(p0 + delta), w_q0 = clip255(q0 - delta);
+	const int w_p1 = p1 + clip3i(-tc0, tc0, (p2 + avg - 2 * p1) >> 1);
+	const int w_q1 = q1 + clip3i(-tc0, tc0, (q2 + avg - 2 * q1) >> 1);
+	// bS == 4
+	const bool small = dpq < (alpha >> 2) + 2;
+	const bool sp = ap & small, sq = aq & small;
+	const int s_p0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (2 * p1 + p0 + q1 + 2) >> 2;
+	const int s_p1 = (p2 + p1 + p0 + q0 + 2) >> 2;
+	const int s_p2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
+	const int s_q0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (2 * q1 + q0 + p1 + 2) >> 2;
+	const int s_q1 = (p0 + q0 + q1 + q2 + 2) >> 2;
+	const int s_q2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
+	const bool m_p1 = go & (strong ? sp : ap), m_q1 = go & (strong ? sq : aq);
+	const int n_p0 = strong ? s_p0 : w_p0, n_q0 = strong ? s_q0 : w_q0;
+	p0 = go ? n_p0 : p0;
+	q0 = go ? n_q0 : q0;
+	p1 = m_p1 ? (strong ? s_p1 : w_p1) : p1;
+	q1 = m_q1 ? (strong ? s_q1 : w_q1) : q1;
+	p2 = (go & strong & sp) ? s_p2 : p2;
+	q2 = (go & strong & sq) ? s_q2 : q2;
 }
-// chroma: only p0/q0 change (deblock.c:130-152, 261-276)
-__device__ __forceinline__ void chroma_filter4(int &p1, int &p0, int &q0, int &q1, int bS, int alpha, int beta, int tc0)
+
+// A "line" of 20 samples (positions -4..15) crossing the four luma edges at positions 0,4,8,12 lives
+// in v[0..19].  Chroma lines (positions -4..7, edges at 0 and 4) are parked so that their two edges
+// coincide with luma edges 0 and 2: v[0..5] = pos -4..1, v[10..15] = pos 2..7 (v[6..9] unused).
+__device__ __forceinline__ void filter_line(int v[20], const int bS[4], int a_edge0, int a_in, int b_edge0, int b_in, const int tc0[4], bool chroma)
 {
-	if (bS == 0 || !(abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta))
+	edge_filter(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], bS[0], a_edge0, b_edge0, tc0[0], chroma);
+	edge_filter(v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], bS[1], a_in, b_in, tc0[1], chroma);
+	edge_filter(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], bS[2], a_in, b_in, tc0[2], chroma);
+	edge_filter(v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19], bS[3], a_in, b_in, tc0[3], chroma);
+}
+
+// per-lane state of the macroblock a half-wave is about to filter
+struct DbkRegs { uint32_t va0, va1, vc, vp, vt; bool act, hasL, hasT, on, t8; };
+
+// Loads of macroblock (mbx,mby) that do not depend on the row above.  hl = lane within the half-wave:
+// own luma (2 dwords per lane), own chroma (1), parameters (hl < 16).
+// gtop: the row above belongs to the previous ROUND of row pairs (last wave -> first wave); that one
+// hand-off goes through global memory (a bounded LDS ring there would close a dependency cycle).
+__device__ __forceinline__ void dbk_prefetch(const FrameCtx &f, int mbx, int mby, int hl, bool act, bool gtop, DbkRegs &r)
+{
+	r.act = act;
+	r.on = r.hasL = r.hasT = r.t8 = false;
+	r.va0 = r.va1 = r.vc = r.vp = r.vt = 0;
+	if (!act)
 		return;
-	if (bS < 4) {
-		int tc = tc0 + 1;
-		int delta = clip3i(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
-		p0 = clip255(p0 + delta);
-		q0 = clip255(q0 - delta);
-	} else {
-		int np = (2 * p1 + p0 + q1 + 2) >> 2, nq = (2 * q1 + q0 + p1 + 2) >> 2;
-		p0 = np; q0 = nq;
+	cmb_t m = f.mbs + mby * f.wm + mbx;
+	const uint32_t hdr = *(const uint32_t __attribute__((address_space(4))) *)m; // kind, flags, qp0, qp1
+	const uint32_t kind = hdr & 255, flags = hdr >> 8 & 255;
+	r.on = (flags & E264_MBF_DEBLOCK) && kind != E264_MB_ABSENT;
+	r.hasL = r.on && (flags & E264_MBF_EDGE_LEFT);
+	r.hasT = r.on && (flags & E264_MBF_EDGE_TOP);
+	r.t8 = flags & E264_MBF_T8x8;
+	gu8 *Yb = f.cur + (size_t)(mby * 16) * f.sY + mbx * 16;
+	gu8 *Cb0 = plane_base(f, f.cur, 1) + (size_t)(mby * 8) * f.sC + mbx * 8;
+	r.va0 = *(const gu32 *)(Yb + (size_t)(hl >> 2) * f.sY + (hl & 3) * 4);
+	r.va1 = *(const gu32 *)(Yb + (size_t)(8 + (hl >> 2)) * f.sY + (hl & 3) * 4);
+	r.vc = *(const gu32 *)(Cb0 + (hl >> 4) * (f.sC >> 1) + (size_t)((hl >> 1) & 7) * f.sC + (hl & 1) * 4);
+	if (hl < 16)
+		r.vp = ((const gu32 *)(f.dbk + (size_t)(mby * f.wm + mbx) * E264_DBK_BYTES))[hl];
+	if (gtop && r.hasT) {
+		if (hl < 16) r.vt = *(const gu32 *)(Yb + (ptrdiff_t)(-4 + (hl >> 2)) * f.sY + (hl & 3) * 4);
+		else if (hl < 24) { int i = hl - 16; r.vt = *(const gu32 *)(Cb0 + (i >> 2) * (f.sC >> 1) + (ptrdiff_t)(-2 + ((i >> 1) & 1)) * f.sC + (i & 1) * 4); }
 	}
 }
 
-// One macroblock.  The tile keeps rows -4..15 x cols -4..15 of luma (and -4..7 of both chroma
-// planes); the left 4 columns are CARRIED in LDS from the previous macroblock of the row (same
-// wave), the rest comes from global memory with two dword loads per lane.
-__device__ __forceinline__ void deblock_mb(DbkLds &L, const uint8_t *tc0tab, const FrameCtx &f, int mbx, int mby, int lane, bool carry)
+// top rows from the LDS ring of the row above: hl 0..15 luma rows -4..-1 (4 dwords each),
+// hl 16..23 chroma rows -2..-1 (2 planes x 2 rows x 2 dwords)
+__device__ __forceinline__ void dbk_load_top(const DbkRing &up, int mbx, int hl, DbkRegs &r)
 {
-	const E264Mb *m = f.mbs + mby * f.wm + mbx;
-	const uint32_t flags = m->flags;
-	const bool on = (flags & E264_MBF_DEBLOCK) && m->kind != E264_MB_ABSENT;
-	const bool hasL = on && (flags & E264_MBF_EDGE_LEFT), hasT = on && (flags & E264_MBF_EDGE_TOP);
-	gu8 *Yb = (gu8 *)(f.cur + (size_t)(mby * 16) * f.sY + mbx * 16);
-	gu8 *Cb0 = (gu8 *)(plane_base(f, f.cur, 1) + (size_t)(mby * 8) * f.sC + mbx * 8);
-	const int half = f.sC >> 1;
-	// ---- lane roles for memory traffic -----------------------------------------------------
-	// A (all 64 lanes): own luma, row lane>>2, dword lane&3
-	const int ar = lane >> 2, ac = (lane & 3) * 4;
-	// B: lanes 0..15 luma top rows (-4..-1); 16..47 own chroma; 48..63 chroma top rows
-	int bpl = 0, brow = 0, bcol = 0; // for chroma roles: plane, row, col
-	bool b_luma = lane < 16, b_top = lane < 16 || lane >= 48;
-	if (lane < 16) { brow = -4 + (lane >> 2); bcol = (lane & 3) * 4; }
-	else if (lane < 48) { int i = lane - 16; bpl = i >> 4; brow = (i >> 1) & 7; bcol = (i & 1) * 4; }
-	else { int i = lane - 48; bpl = i >> 3; brow = -4 + ((i >> 1) & 3); bcol = (i & 1) * 4; }
-	gu8 *bptr = b_luma ? Yb + (ptrdiff_t)brow * f.sY + bcol : Cb0 + bpl * half + (ptrdiff_t)brow * f.sC + bcol;
-	// C: left columns: lanes 0..15 luma row lane; 16..31 chroma (plane, row)
-	const int cpl = (lane - 16) >> 3 & 1, crow = lane < 16 ? lane : (lane & 7);
+	if (!r.hasT)
+		return;
+	const int slot = mbx & (DBK_RING - 1);
+	if (hl < 16) r.vt = up.y[hl >> 2][slot * 4 + (hl & 3)];
+	else if (hl < 24) { int i = hl - 16; r.vt = up.c[i >> 2][(i >> 1) & 1][slot * 2 + (i & 1)]; }
+}
 
-	// ---- carry the previous macroblock's right 4 columns to the left of the tile ------------
+// Filter the macroblock whose samples are in r, publish its bottom rows in `ring`, store it.
+__device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, const uint8_t *tc0tab, const FrameCtx &f, int mbx, int mby, int hl,
+	const DbkRegs &r, bool carry, bool last)
+{
+	const int pl = hl < 16 ? 0 : hl < 24 ? 1 : 2; // line roles: 0..15 luma, 16..23 Cb, 24..31 Cr
+	const int li = hl < 16 ? hl : (hl & 7);
+	const bool chroma = pl != 0;
+	const int cpl = chroma ? pl - 1 : 0;
+	// ---- carry the previous macroblock's right 4 columns, then drop the new samples in the tile
 	uint32_t cv = 0;
-	if (carry && lane < 32)
-		cv = lane < 16 ? *(const uint32_t *)&L.DYT(crow, 12) : *(const uint32_t *)&L.DCT(cpl, crow, 4);
-	uint32_t va = *(const gu32 *)(Yb + (size_t)ar * f.sY + ac);
-	uint32_t vb = 0;
-	if (!b_top || hasT) vb = *(const gu32 *)bptr;
-	uint32_t vp = 0;
-	if (lane < 16) vp = ((const gu32 *)(f.dbk + (size_t)(mby * f.wm + mbx) * E264_DBK_BYTES))[lane];
+	if (r.act && carry)
+		cv = hl < 16 ? *(const uint32_t *)&L.DYT(li, 12) : *(const uint32_t *)&L.DCT(cpl, li, 4);
 	wave_sync();
-	if (carry && lane < 32) {
-		if (lane < 16) *(uint32_t *)&L.DYT(crow, -4) = cv;
-		else *(uint32_t *)&L.DCT(cpl, crow, -4) = cv;
-	}
-	*(uint32_t *)&L.DYT(ar, ac) = va;
-	if (b_luma) *(uint32_t *)&L.DYT(brow, bcol) = vb;
-	else *(uint32_t *)&L.DCT(bpl, brow, bcol) = vb;
-	if (lane < 16) ((uint32_t *)L.prm)[lane] = vp;
-	wave_sync();
-	if (!on)
-		return; // tile stays valid for the next macroblock's carry
-	// ---- filtering: lanes 0..15 luma lines, 16..23 Cb lines, 24..31 Cr lines -----------------
-	const int pl = lane < 16 ? 0 : lane < 24 ? 1 : 2;
-	const int li = lane < 16 ? lane : (lane & 7);
-	const bool t8 = flags & E264_MBF_T8x8;
-#pragma unroll
-	for (int dir = 0; dir < 2; dir++) {
-#pragma unroll
-		for (int e = 0; e < 4; e++) {
-			bool act = lane < 32 && !(pl && (e & 1));
-			if (e == 0) act = act && (dir ? hasT : hasL);
-			else if (e & 1) act = act && !(t8 && pl == 0);
-			if (act) {
-				int b = L.prm[dir * 16 + e * 4 + (pl ? li >> 1 : li >> 2)];
-				if (b) {
-					int t = e == 0 ? 1 + dir : 0;
-					int alpha = L.prm[32 + pl * 3 + t], beta = L.prm[41 + pl * 3 + t], iA = L.prm[50 + pl * 3 + t];
-					int tc0 = b < 4 ? tc0tab[(b - 1) * 52 + iA] : 0;
-					if (pl == 0) {
-						int v[8];
-						if (dir == 0) {
-							uint32_t P = *(const uint32_t *)&L.DYT(li, e * 4 - 4), Q = *(const uint32_t *)&L.DYT(li, e * 4);
-							v[0] = P & 255; v[1] = P >> 8 & 255; v[2] = P >> 16 & 255; v[3] = P >> 24;
-							v[4] = Q & 255; v[5] = Q >> 8 & 255; v[6] = Q >> 16 & 255; v[7] = Q >> 24;
-							luma_filter8(v, b, alpha, beta, tc0);
-							*(uint32_t *)&L.DYT(li, e * 4 - 4) = (uint32_t)v[0] | (uint32_t)v[1] << 8 | (uint32_t)v[2] << 16 | (uint32_t)v[3] << 24;
-							*(uint32_t *)&L.DYT(li, e * 4) = (uint32_t)v[4] | (uint32_t)v[5] << 8 | (uint32_t)v[6] << 16 | (uint32_t)v[7] << 24;
-						} else {
-#pragma unroll
-							for (int i = 0; i < 8; i++) v[i] = L.DYT(e * 4 - 4 + i, li);
-							luma_filter8(v, b, alpha, beta, tc0);
-#pragma unroll
-							for (int i = 1; i < 7; i++) L.DYT(e * 4 - 4 + i, li) = (uint8_t)v[i];
-						}
-					} else {
-						int p1, p0, q0, q1;
-						if (dir == 0) {
-							p1 = L.DCT(pl - 1, li, e * 2 - 2); p0 = L.DCT(pl - 1, li, e * 2 - 1);
-							q0 = L.DCT(pl - 1, li, e * 2); q1 = L.DCT(pl - 1, li, e * 2 + 1);
-							chroma_filter4(p1, p0, q0, q1, b, alpha, beta, tc0);
-							L.DCT(pl - 1, li, e * 2 - 1) = (uint8_t)p0; L.DCT(pl - 1, li, e * 2) = (uint8_t)q0;
-						} else {
-							p1 = L.DCT(pl - 1, e * 2 - 2, li); p0 = L.DCT(pl - 1, e * 2 - 1, li);
-							q0 = L.DCT(pl - 1, e * 2, li); q1 = L.DCT(pl - 1, e * 2 + 1, li);
-							chroma_filter4(p1, p0, q0, q1, b, alpha, beta, tc0);
-							L.DCT(pl - 1, e * 2 - 1, li) = (uint8_t)p0; L.DCT(pl - 1, e * 2, li) = (uint8_t)q0;
-						}
-					}
-				}
-			}
-			wave_sync();
+	if (r.act) {
+		if (carry) {
+			if (hl < 16) *(uint32_t *)&L.DYT(li, -4) = cv;
+			else *(uint32_t *)&L.DCT(cpl, li, -4) = cv;
+		}
+		*(uint32_t *)&L.DYT(hl >> 2, (hl & 3) * 4) = r.va0;
+		*(uint32_t *)&L.DYT(8 + (hl >> 2), (hl & 3) * 4) = r.va1;
+		*(uint32_t *)&L.DCT(hl >> 4, (hl >> 1) & 7, (hl & 1) * 4) = r.vc;
+		if (hl < 16) ((uint32_t *)L.prm)[hl] = r.vp;
+		if (r.hasT && hl < 24) {
+			if (hl < 16) *(uint32_t *)&L.DYT(-4 + (hl >> 2), (hl & 3) * 4) = r.vt;
+			else { int i = hl - 16; *(uint32_t *)&L.DCT(i >> 2, -2 + ((i >> 1) & 1), (i & 1) * 4) = r.vt; }
 		}
 	}
+	wave_sync();
+	int v[20];
+	int bV[4], bH[4], tV[4], tH[4];
+	int a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
+	if (r.on) {
+		// ---- per-lane parameters: bS of the 8 edges crossing this line, alpha/beta/indexA -----
+		const int seg = chroma ? li >> 1 : li >> 2;
+#pragma unroll
+		for (int e = 0; e < 4; e++) { bV[e] = L.prm[e * 4 + seg]; bH[e] = L.prm[16 + e * 4 + seg]; }
+		if (!r.hasL) bV[0] = 0;
+		if (!r.hasT) bH[0] = 0;
+		if (chroma || r.t8) { bV[1] = bV[3] = 0; bH[1] = bH[3] = 0; }
+		a0 = L.prm[32 + pl * 3]; a1 = L.prm[32 + pl * 3 + 1]; a2 = L.prm[32 + pl * 3 + 2];
+		b0 = L.prm[41 + pl * 3]; b1 = L.prm[41 + pl * 3 + 1]; b2 = L.prm[41 + pl * 3 + 2];
+		const int i0 = L.prm[50 + pl * 3], i1 = L.prm[50 + pl * 3 + 1], i2 = L.prm[50 + pl * 3 + 2];
+#pragma unroll
+		for (int e = 0; e < 4; e++) {
+			int bv = bV[e], bh = bH[e];
+			// tc0tab has a zero row for bS 0 and 4 (index (bS & 3) when bS < 4 ... see kernel prologue)
+			tV[e] = tc0tab[(bv & 3) * 52 + (e ? i0 : i1)] & (bv < 4 ? 255 : 0);
+			tH[e] = tc0tab[(bh & 3) * 52 + (e ? i0 : i2)] & (bh < 4 ? 255 : 0);
+		}
+		// ---- vertical edges: this lane owns ROW li ----------------------------------------
+		if (!chroma) {
+#pragma unroll
+			for (int d = 0; d < 5; d++) {
+				uint32_t w = *(const uint32_t *)&L.DYT(li, d * 4 - 4);
+				v[d * 4] = w & 255; v[d * 4 + 1] = w >> 8 & 255; v[d * 4 + 2] = w >> 16 & 255; v[d * 4 + 3] = w >> 24;
+			}
+		} else {
+			uint32_t w0 = *(const uint32_t *)&L.DCT(cpl, li, -4), w1 = *(const uint32_t *)&L.DCT(cpl, li, 0), w2 = *(const uint32_t *)&L.DCT(cpl, li, 4);
+			v[0] = w0 & 255; v[1] = w0 >> 8 & 255; v[2] = w0 >> 16 & 255; v[3] = w0 >> 24;
+			v[4] = w1 & 255; v[5] = w1 >> 8 & 255; v[10] = w1 >> 16 & 255; v[11] = w1 >> 24;
+			v[12] = w2 & 255; v[13] = w2 >> 8 & 255; v[14] = w2 >> 16 & 255; v[15] = w2 >> 24;
+			v[6] = v[7] = v[8] = v[9] = v[16] = v[17] = v[18] = v[19] = 0;
+		}
+		filter_line(v, bV, a1, a0, b1, b0, tV, chroma);
+		if (!chroma) {
+#pragma unroll
+			for (int d = 0; d < 5; d++)
+				*(uint32_t *)&L.DYT(li, d * 4 - 4) = (uint32_t)v[d * 4] | (uint32_t)v[d * 4 + 1] << 8 | (uint32_t)v[d * 4 + 2] << 16 | (uint32_t)v[d * 4 + 3] << 24;
+		} else {
+			*(uint32_t *)&L.DCT(cpl, li, -4) = (uint32_t)v[0] | (uint32_t)v[1] << 8 | (uint32_t)v[2] << 16 | (uint32_t)v[3] << 24;
+			*(uint32_t *)&L.DCT(cpl, li, 0) = (uint32_t)v[4] | (uint32_t)v[5] << 8 | (uint32_t)v[10] << 16 | (uint32_t)v[11] << 24;
+			*(uint32_t *)&L.DCT(cpl, li, 4) = (uint32_t)v[12] | (uint32_t)v[13] << 8 | (uint32_t)v[14] << 16 | (uint32_t)v[15] << 24;
+		}
+	}
+	wave_sync();
+	if (r.on) {
+		// ---- horizontal edges: this lane owns COLUMN li -----------------------------------
+		if (!chroma) {
+#pragma unroll
+			for (int i = 0; i < 20; i++) v[i] = L.DYT(i - 4, li);
+		} else {
+#pragma unroll
+			for (int i = 0; i < 6; i++) { v[i] = L.DCT(cpl, i - 4, li); v[10 + i] = L.DCT(cpl, i + 2, li); }
+		}
+		filter_line(v, bH, a2, a0, b2, b0, tH, chroma);
+		if (!chroma) {
+#pragma unroll
+			for (int i = 1; i < 19; i++) L.DYT(i - 4, li) = (uint8_t)v[i];
+		} else {
+			L.DCT(cpl, -1, li) = (uint8_t)v[3]; L.DCT(cpl, 0, li) = (uint8_t)v[4];
+			L.DCT(cpl, 3, li) = (uint8_t)v[11]; L.DCT(cpl, 4, li) = (uint8_t)v[12];
+		}
+	}
+	wave_sync();
+	if (!r.act)
+		return;
+	// ---- publish the bottom rows for the row below: this macroblock's columns 0..11 (chroma 0..3)
+	// and, now that the left edge has been filtered, the previous macroblock's columns 12..15 (4..7)
+	{
+		const int slot = mbx & (DBK_RING - 1), pslot = (mbx - 1) & (DBK_RING - 1);
+		if (hl < 16) {
+			int row = 12 + (hl >> 2), d = hl & 3;
+			if (d == 0) { if (carry) ring.y[hl >> 2][pslot * 4 + 3] = *(const uint32_t *)&L.DYT(row, -4); }
+			else ring.y[hl >> 2][slot * 4 + d - 1] = *(const uint32_t *)&L.DYT(row, (d - 1) * 4);
+		} else if (hl < 24) {
+			int i = hl - 16, pc = i >> 2, rr = (i >> 1) & 1, d = i & 1;
+			if (d == 0) { if (carry) ring.c[pc][rr][pslot * 2 + 1] = *(const uint32_t *)&L.DCT(pc, 6 + rr, -4); }
+			else ring.c[pc][rr][slot * 2] = *(const uint32_t *)&L.DCT(pc, 6 + rr, 0);
+		} else if (last) { // last macroblock of the row: nobody will carry its right columns
+			int i = hl - 24;
+			if (i < 4) ring.y[i][slot * 4 + 3] = *(const uint32_t *)&L.DYT(12 + i, 12);
+			else { int j = i - 4; ring.c[j >> 1][j & 1][slot * 2 + 1] = *(const uint32_t *)&L.DCT(j >> 1, 6 + (j & 1), 4); }
+		}
+	}
+	if (!r.on)
+		return;
 	// ---- write back: own samples, the top rows and the carried left columns ------------------
-	*(gu32 *)(Yb + (size_t)ar * f.sY + ac) = *(const uint32_t *)&L.DYT(ar, ac);
-	if (!b_top || hasT)
-		*(gu32 *)bptr = b_luma ? *(const uint32_t *)&L.DYT(brow, bcol) : *(const uint32_t *)&L.DCT(bpl, brow, bcol);
-	if (hasL && lane < 32) {
-		if (lane < 16) *(gu32 *)(Yb + (size_t)crow * f.sY - 4) = *(const uint32_t *)&L.DYT(crow, -4);
-		else *(gu32 *)(Cb0 + cpl * half + (size_t)crow * f.sC - 4) = *(const uint32_t *)&L.DCT(cpl, crow, -4);
+	gu8 *Yb = f.cur + (size_t)(mby * 16) * f.sY + mbx * 16;
+	gu8 *Cb0 = plane_base(f, f.cur, 1) + (size_t)(mby * 8) * f.sC + mbx * 8;
+	const int half = f.sC >> 1;
+	*(gu32 *)(Yb + (size_t)(hl >> 2) * f.sY + (hl & 3) * 4) = *(const uint32_t *)&L.DYT(hl >> 2, (hl & 3) * 4);
+	*(gu32 *)(Yb + (size_t)(8 + (hl >> 2)) * f.sY + (hl & 3) * 4) = *(const uint32_t *)&L.DYT(8 + (hl >> 2), (hl & 3) * 4);
+	*(gu32 *)(Cb0 + (hl >> 4) * half + (size_t)((hl >> 1) & 7) * f.sC + (hl & 1) * 4) = *(const uint32_t *)&L.DCT(hl >> 4, (hl >> 1) & 7, (hl & 1) * 4);
+	if (r.hasT) {
+		if (hl < 16) *(gu32 *)(Yb + (ptrdiff_t)(-4 + (hl >> 2)) * f.sY + (hl & 3) * 4) = *(const uint32_t *)&L.DYT(-4 + (hl >> 2), (hl & 3) * 4);
+		else if (hl < 24) { int i = hl - 16; *(gu32 *)(Cb0 + (i >> 2) * half + (ptrdiff_t)(-2 + ((i >> 1) & 1)) * f.sC + (i & 1) * 4) = *(const uint32_t *)&L.DCT(i >> 2, -2 + ((i >> 1) & 1), (i & 1) * 4); }
+	}
+	if (r.hasL) {
+		if (hl < 16) *(gu32 *)(Yb + (size_t)hl * f.sY - 4) = *(const uint32_t *)&L.DYT(hl, -4);
+		else { int q = hl - 16; *(gu32 *)(Cb0 + (q >> 3) * half + (size_t)(q & 7) * f.sC - 4) = *(const uint32_t *)&L.DCT(q >> 3, q & 7, -4); }
 	}
 }
 
@@ -1115,20 +1228,20 @@ __device__ __forceinline__ int lds_load_relaxed(const int *p)
 __device__ __forceinline__ bool open_frame(FrameCtx &f, const E264Job &job)
 {
 	const uint8_t *pkt = job.packet;
-	const E264FrameHdr *h = (const E264FrameHdr *)pkt;
+	chdr_t h = (chdr_t)pkt;
 	if (h->magic != E264_MAGIC || h->version != E264_VERSION)
 		return false;
 	f.h = h;
-	f.slices = (const E264SliceParams *)(pkt + h->slices_off);
-	f.mbs = (const E264Mb *)(pkt + h->mbs_off);
-	f.payload = pkt + h->payload_off;
-	f.dpb = job.dpb;
-	f.cur = job.dpb[h->dst_slot];
+	f.slices = (cslice_t)(pkt + h->slices_off);
+	f.mbs = (cmb_t)(pkt + h->mbs_off);
+	f.payload = (const gu8 *)(pkt + h->payload_off);
+	f.dpb = (gdpb_t)job.dpb;
+	f.cur = (gu8 *)job.dpb[h->dst_slot];
 	f.wm = h->width_mbs; f.hm = h->height_mbs;
 	f.W = f.wm * 16; f.H = f.hm * 16;
 	f.sY = (int)h->stride_Y; f.sC = (int)h->stride_C;
 	f.psY = h->plane_size_Y;
-	f.dbk = job.dbk;
+	f.dbk = (gu8 *)job.dbk;
 	return f.cur != nullptr;
 }
 
@@ -1197,32 +1310,66 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 {
 	__shared__ DbkLds lds[NW];
 	__shared__ int progress[E264_MAX_ROWS];
-	__shared__ uint8_t tc0tab[3 * 52];
+	__shared__ uint8_t tc0tab[4 * 52]; // row (bS & 3): row 0 is all zero (bS 0 and 4 have no tC0)
 	const int lane = lane_id();
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int half = lane >> 5, hl = lane & 31;
 	FrameCtx f;
 	if (!open_frame(f, jobs[blockIdx.x]) || !f.dbk)
 		return;
 	for (int i = threadIdx.x; i < f.hm; i += NW * 64)
 		progress[i] = 0;
-	for (int i = threadIdx.x; i < 3 * 52; i += NW * 64)
-		tc0tab[i] = c_tc0[i / 52][i % 52];
+	for (int i = threadIdx.x; i < 4 * 52; i += NW * 64)
+		tc0tab[i] = i < 52 ? 0 : c_tc0[i / 52 - 1][i % 52];
 	__syncthreads();
 	DbkLds &L = lds[wave];
+	const int upw = (wave + NW - 1) % NW; // the wave that owns the row pair above
 #pragma unroll 1
-	for (int y = wave; y < f.hm; y += NW) {
+	for (int pr = wave; 2 * pr < f.hm; pr += NW) { // row pair: rows 2*pr (lanes 0..31) and 2*pr+1 (lanes 32..63)
+		const int yA = 2 * pr, yB = yA + 1;
+		const int my_y = yA + half;
+		const bool row_ok = my_y < f.hm;
+		const int par = (pr / NW) & 1, uppar = ((pr - 1 + NW) / NW + 1) & 1; // ring buffers alternate per round
+		DbkRing &myring = L.ring[par][half];
+		const DbkRing &upring = half ? L.ring[par][0] : lds[upw].ring[(wave == 0) ? par ^ 1 : par][1];
+		(void)uppar;
+		// wave 0 takes its top rows from global memory (written by the last wave one round earlier)
+		const bool gtop_wave = wave == 0 && yA > 0;
+		const bool gtop = gtop_wave && half == 0;
+		DbkRegs cur, nxt;
+		if (gtop_wave) {
+			while (lds_load_relaxed(&progress[yA - 1]) < min(2, f.wm))
+				__builtin_amdgcn_s_sleep(1);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		}
+		dbk_prefetch(f, 0, my_y, hl, row_ok && half == 0, gtop, cur);
 #pragma unroll 1
-		for (int x = 0; x < f.wm; x++) {
-			if (y > 0) {
-				int want = min(x + 2, f.wm);
-				while (lds_load_relaxed(&progress[y - 1]) < want)
+		for (int t = 0; t < f.wm + DBK_LAG; t++) {
+			const int xB = t - DBK_LAG;
+			const int my_x = half ? xB : t;
+			if (yA > 0 && t < f.wm) { // the row above must be 2 macroblocks ahead
+				int want = min(t + (gtop_wave ? 3 : 2), f.wm); // wave 0 also prefetches the next macroblock's top rows
+				while (lds_load_relaxed(&progress[yA - 1]) < want)
 					__builtin_amdgcn_s_sleep(1);
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 			}
-			deblock_mb(L, tc0tab, f, x, y, lane, x > 0);
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			if (lane == 0)
-				__hip_atomic_store(&progress[y], x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (wave != NW - 1 && yB + 1 < f.hm && xB >= DBK_RING - 2) { // ring back-pressure: the slot must have been consumed
+				while (lds_load_relaxed(&progress[yB + 1]) < xB - (DBK_RING - 2))
+					__builtin_amdgcn_s_sleep(1);
+			}
+			if (gtop_wave) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			if (!gtop)
+				dbk_load_top(upring, my_x, hl, cur);
+			const int nx = my_x + 1;
+			dbk_prefetch(f, nx, my_y, hl, row_ok && nx >= 0 && nx < f.wm, gtop, nxt);
+			dbk_process(L.tile[half], myring, tc0tab, f, my_x, my_y, hl, cur, my_x > 0, my_x == f.wm - 1);
+			// LDS operations of a wave execute in order: the ring is written before the counter.  The last
+			// wave hands its lower row to the next round through global memory: its stores must be visible.
+			if (wave == NW - 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			if (hl == 0 && cur.act)
+				__hip_atomic_store(&progress[my_y], my_x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			cur = nxt;
 		}
 	}
 }

@@ -98,10 +98,13 @@ def test_odd_geometry(device, oracle):
         run_stream(device, oracle, 7, "IPB", dict(t8x8=True, i_kinds=ALL_I, mv_range=100), w, h)
 
 
-@pytest.mark.parametrize("waves", [4, 16])
+@pytest.mark.parametrize("waves", [4, 8, 16])
 def test_waves_per_frame(device, oracle, waves):
+    """Frames wider than the LDS hand-off ring and taller than one round of row pairs
+    (2 x waves rows): exercises ring wrap, back-pressure and the cross-round hand-off."""
     prev = device.set_option("waves", waves)
     try:
         run_stream(device, oracle, 3, "IPB", dict(t8x8=True, i_kinds=ALL_I), 5, 21)
+        run_stream(device, oracle, 4, "IPP", dict(), 26, 2 * waves * 2 + 3)
     finally:
         device.set_option("waves", prev)
