@@ -45,6 +45,7 @@ def main() -> int:
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--debug-mode", type=int, default=0, help="profiling ablation bits (results are then wrong on purpose)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -70,6 +71,7 @@ def main() -> int:
 
     dev = backend.Device(local_rank)
     dev.set_option("waves", args.waves)
+    dev.set_option("debug_mode", args.debug_mode)
     streams, dpk = [], []
     for s in range(args.streams):
         st = backend.Stream(dev, W, H)

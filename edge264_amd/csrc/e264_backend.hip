@@ -39,6 +39,7 @@ struct E264Device {
 	int ordinal;
 	hipStream_t q;
 	int waves;                 // macroblock rows in flight per frame workgroup
+	int dbg_mode;
 	std::mutex lock;
 	hipEvent_t ev[16];
 	// per-launch kernel timing
@@ -83,6 +84,7 @@ API int e264hip_device_open(int ordinal, E264Device **out)
 	if (!d) return fail(ENOMEM, "device object");
 	d->ordinal = ordinal;
 	d->waves = 8;
+	d->dbg_mode = 0;
 	d->ktiming = false; d->kev_used = 0;
 	if (hipSetDevice(ordinal) != hipSuccess || hipStreamCreateWithFlags(&d->q, hipStreamNonBlocking) != hipSuccess) {
 		delete d;
@@ -116,6 +118,11 @@ API int e264hip_device_sync(E264Device *dev)
 API int e264hip_set_option(E264Device *dev, const char *name, int value)
 {
 	if (!dev || !name) return -1;
+	if (!strcmp(name, "debug_mode")) { // profiling ablation bits OR-ed into the kernels' mode argument
+		int prev = dev->dbg_mode;
+		dev->dbg_mode = value;
+		return prev;
+	}
 	if (!strcmp(name, "waves")) {
 		int prev = dev->waves;
 		if (value == 4 || value == 8 || value == 16) dev->waves = value;
@@ -224,7 +231,9 @@ static int check_packet(const void *packet, size_t bytes, int *dst, int *n_mbs)
 	if (!packet || bytes < sizeof(*h) || h->magic != E264_MAGIC || h->version != E264_VERSION || h->total_bytes > bytes)
 		return fail(EINVAL, "not a command packet");
 	if (h->dst_slot < 0 || h->dst_slot >= E264_MAX_SLOTS) return fail(EINVAL, "dst_slot");
-	size_t need = (size_t)h->mbs_off + (size_t)h->width_mbs * h->height_mbs * sizeof(E264Mb);
+	size_t n_mb = (size_t)h->width_mbs * h->height_mbs;
+	size_t need = (size_t)h->mbs_off + n_mb * sizeof(E264Mb);
+	if (h->motion_off && (h->motion_off < need || (need = (size_t)h->motion_off + n_mb * sizeof(E264Motion)) > h->total_bytes)) return fail(EINVAL, "motion section");
 	if (need > h->payload_off || (size_t)h->payload_off + h->payload_bytes > h->total_bytes) return fail(EINVAL, "packet layout");
 	*dst = h->dst_slot;
 	*n_mbs = (int)h->width_mbs * h->height_mbs;
@@ -253,7 +262,7 @@ static int launch(E264Device *dev, const E264Job *d_jobs, int n, int max_mbs, in
 		}
 		marks = dev->kev[dev->kev_used++].e;
 	}
-	HIPCHK(e264_launch_frames(d_jobs, n, max_mbs, mode, dev->waves, dev->q, marks), EIO);
+	HIPCHK(e264_launch_frames(d_jobs, n, max_mbs, mode | dev->dbg_mode, dev->waves, dev->q, marks), EIO);
 	return 0;
 }
 

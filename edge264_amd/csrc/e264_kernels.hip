@@ -113,6 +113,7 @@ struct __attribute__((aligned(16))) WaveLds { // reconstruction scratch of one w
 	uint8_t ctile[2][9 * CT_STRIDE];
 	uint8_t ftop[32];          // intra 8x8 filtered top  ft[-1..15] at [i+1]
 	uint8_t fleft[8];          // intra 8x8 filtered left
+	uint32_t win[432];         // reference windows of inter prediction: 1 x 21x24, 4 x 13x16 or 16 x 9x12 bytes
 };
 
 #define DBK_RING 8 // macroblocks of bottom rows each row keeps in LDS for the row below
@@ -137,13 +138,16 @@ struct FrameCtx {
 	chdr_t h;
 	cslice_t slices;
 	cmb_t mbs;
+	gmotion_t motion;  // dense per-MB array, NULL if the frame has no inter macroblock
 	const gu8 *payload;
 	gdpb_t dpb;
+	const generic_u8p *dpb_lds; // the same table staged in LDS (mbpar kernel): no dependent global round trip per reference
 	gu8 *cur;
 	int W, H;          // luma samples
 	int wm, hm;        // macroblocks
 	int sY, sC;        // strides
 	uint32_t psY;      // plane_size_Y
+	int dbg;           // profiling ablations: bit8 no luma MC, bit9 no chroma MC, bit10 no residual, bit11 no bS, bit12 no store
 	gu8 *dbk;          // per-MB deblocking parameters (E264_DBK_BYTES each), written by the mbpar kernel
 };
 
@@ -457,70 +461,79 @@ __device__ __forceinline__ int centre6(int t0, int t1, int t2, int t3, int t4, i
 }
 __device__ __forceinline__ int avg2(int a, int b) { return (a + b + 1) >> 1; }
 
-// 4 horizontally adjacent luma samples at (X..X+3, Y) displaced by the quarter-pel (xF,yF):
-// 8.4.2.2.1 organised like decode_inter_luma (edge264_inter.c:416-968).
-__device__ __forceinline__ void luma_pred4(const gu8 *ref, int stride, int W, int H, int X, int Y, int xF, int yF, int out[4])
+// 4 horizontally adjacent luma samples displaced by the quarter-pel (xF,yF): 8.4.2.2.1 as organised
+// by decode_inter_luma (edge264_inter.c:416-968), but BRANCH-FREE over the 16 fractional positions so
+// that the lanes of a wave (which may hold 16 different vectors) never diverge.  d[r][0..2] hold the 9
+// samples x-2..x+6 of row y-2+r (already byte-aligned).  Every lane forms the horizontal taps of the
+// 6 rows and the vertical taps of the 9 columns, then selects.
+__device__ __forceinline__ void luma_from_rows(const uint32_t d[6][3], int xF, int yF, int out[4])
 {
-	int px[9];
-	if (yF == 0) {
-		load_row9(ref, stride, W, H, X - 2, Y, px);
-#pragma unroll
-		for (int i = 0; i < 4; i++) {
-			if (xF == 0) { out[i] = px[i + 2]; continue; }
-			int b = clip255((tap6(px[i], px[i + 1], px[i + 2], px[i + 3], px[i + 4], px[i + 5]) + 16) >> 5);
-			out[i] = xF == 2 ? b : avg2(xF == 3 ? px[i + 3] : px[i + 2], b);
-		}
-		return;
-	}
+	int Hc[6][4], V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, G[4] = {0, 0, 0, 0};
 	const int cw[6] = {1, -5, 20, 20, -5, 1};
-	if (xF == 2) {
-		// horizontal first, then vertical on the 16-bit intermediates (inter.c:611-646, 779-802, 929-966)
-		int t[6][4];
-#pragma unroll
-		for (int r = 0; r < 6; r++) {
-			load_row9(ref, stride, W, H, X - 2, Y - 2 + r, px);
-#pragma unroll
-			for (int i = 0; i < 4; i++)
-				t[r][i] = tap6(px[i], px[i + 1], px[i + 2], px[i + 3], px[i + 4], px[i + 5]);
-		}
-#pragma unroll
-		for (int i = 0; i < 4; i++) {
-			int j = centre6(t[0][i], t[1][i], t[2][i], t[3][i], t[4][i], t[5][i]);
-			if (yF == 2) out[i] = j;
-			else out[i] = avg2(j, clip255(((yF == 3 ? t[3][i] : t[2][i]) + 16) >> 5));
-		}
-		return;
-	}
-	// remaining cases need vertical taps over 6 rows; accumulate column sums
-	int v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-	int g[4] = {0, 0, 0, 0};      // integer samples for d/n
-	int hb[4] = {0, 0, 0, 0};     // horizontal half-pel b/s for e,g,p,r
+	const int grow = yF == 3 ? 3 : 2;
 #pragma unroll
 	for (int r = 0; r < 6; r++) {
-		load_row9(ref, stride, W, H, X - 2, Y - 2 + r, px);
+		int px[9];
+		px[0] = d[r][0] & 255; px[1] = d[r][0] >> 8 & 255; px[2] = d[r][0] >> 16 & 255; px[3] = d[r][0] >> 24;
+		px[4] = d[r][1] & 255; px[5] = d[r][1] >> 8 & 255; px[6] = d[r][1] >> 16 & 255; px[7] = d[r][1] >> 24;
+		px[8] = d[r][2] & 255;
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+			Hc[r][i] = tap6(px[i], px[i + 1], px[i + 2], px[i + 3], px[i + 4], px[i + 5]);
 #pragma unroll
 		for (int c = 0; c < 9; c++)
-			v[c] += cw[r] * px[c];
-		if ((r == 2 && yF != 3) || (r == 3 && yF == 3)) {
+			V[c] += cw[r] * px[c];
+		if (r == 2 || r == 3) {
 #pragma unroll
-			for (int i = 0; i < 4; i++) {
-				g[i] = px[i + 2];
-				hb[i] = clip255((tap6(px[i], px[i + 1], px[i + 2], px[i + 3], px[i + 4], px[i + 5]) + 16) >> 5);
-			}
+			for (int i = 0; i < 4; i++)
+				G[i] = (r == grow) ? (xF == 3 ? px[i + 3] : px[i + 2]) : G[i];
 		}
 	}
+	const bool xo = xF & 1, yo = yF & 1;
+	const bool uses_j = (xF == 2 && yF != 0) || (yF == 2 && xF != 0);
+	const bool uses_G = (xF == 0 || yF == 0) && (xo || yo || (xF | yF) == 0);
+	const bool uses_b = (yF == 0 && xF != 0) || (xo && yo) || (xF == 2 && yo);
+	const bool uses_h = (xF == 0 && yF != 0) || (xo && yo) || (yF == 2 && xo);
 #pragma unroll
 	for (int i = 0; i < 4; i++) {
-		if (xF == 0) {
-			int h = clip255((v[i + 2] + 16) >> 5);
-			out[i] = yF == 2 ? h : avg2(g[i], h);
-		} else if (yF & 1) { // e,g,p,r (inter.c:510-557)
-			int h = clip255(((xF == 3 ? v[i + 3] : v[i + 2]) + 16) >> 5);
-			out[i] = avg2(hb[i], h);
-		} else { // xF odd, yF == 2: vertical first then horizontal (inter.c:559-609, 741-777, 887-927)
-			int j = centre6(v[i], v[i + 1], v[i + 2], v[i + 3], v[i + 4], v[i + 5]);
-			int h = clip255(((xF == 3 ? v[i + 3] : v[i + 2]) + 16) >> 5);
-			out[i] = avg2(j, h);
+		int hsel = yF == 3 ? Hc[3][i] : Hc[2][i];
+		int vsel = xF == 3 ? V[i + 3] : V[i + 2];
+		int b = clip255((hsel + 16) >> 5), h = clip255((vsel + 16) >> 5);
+		// centre: horizontal-then-vertical when xF == 2 (inter.c:611-646, 779-802, 929-966), vertical-then-horizontal
+		// otherwise (inter.c:559-609, 741-777, 887-927); 16-bit intermediates wrap as in the reference
+		int j = centre6(xF == 2 ? Hc[0][i] : V[i], xF == 2 ? Hc[1][i] : V[i + 1], xF == 2 ? Hc[2][i] : V[i + 2],
+			xF == 2 ? Hc[3][i] : V[i + 3], xF == 2 ? Hc[4][i] : V[i + 4], xF == 2 ? Hc[5][i] : V[i + 5]);
+		int op1 = uses_j ? j : uses_G ? G[i] : uses_b ? b : h;
+		int op2 = uses_h ? h : uses_b ? b : uses_j ? j : G[i];
+		out[i] = avg2(op1, op2);
+	}
+}
+
+// Cooperative fetch of the luma reference windows of one list into LDS.  The partitioning is not
+// in the packet (motion is per 4x4 block), so the wave detects the coarsest uniform granularity:
+// S = 16 (one 21-row window, 6 dwords wide), 8 (four 13-row windows, 4 dwords) or 4 (sixteen 9-row
+// windows, 3 dwords).  Each reference cache line is requested once per window instead of once per
+// lane and tap row.  Out-of-frame samples: clamped row index, edge sample replicated over whole
+// dwords (frame width is a multiple of 16, window columns are dword aligned) == the reference's
+// edge emulation (edge264_inter.c:1199-1235).
+template <int S>
+__device__ __forceinline__ void stage_luma_windows(uint32_t *win, const FrameCtx &f, int lane, int XA, int Y0, int pic)
+{
+	constexpr int ROWS = S + 5, ND = S == 16 ? 6 : S == 8 ? 4 : 3, G = 256 / (S * S), PER = ROWS * ND;
+#pragma unroll
+	for (int it = 0; it < (G * PER + 63) / 64; it++) {
+		const int idx = it * 64 + lane;
+		const int g = idx / PER, rem = idx - g * PER, row = rem / ND, dw = rem - row * ND;
+		const int src = (g * (64 / G)) & 63;
+		const int xa = __shfl(XA, src), y0 = __shfl(Y0, src), pc = __shfl(pic, src);
+		if (idx < G * PER && pc >= 0) {
+			const gu8 *plane = (const gu8 *)f.dpb_lds[pc];
+			const gu8 *rowp = plane + (size_t)clip3i(0, f.H - 1, y0 + row) * f.sY;
+			const int x = xa + dw * 4;
+			uint32_t v;
+			if (x >= 0 && x <= f.W - 4) v = *(const gu32 *)(rowp + x);
+			else v = (uint32_t)rowp[x < 0 ? 0 : f.W - 1] * 0x01010101u;
+			win[idx] = v;
 		}
 	}
 }
@@ -533,7 +546,7 @@ __device__ __forceinline__ int ldc_px(const gu8 *plane, int stride, int W, int H
 // Inter prediction of a whole macroblock in the "pixel layout":
 //   luma   lane = (k = lane>>2 : 4x4 block in zig order, r = lane&3 : row) -> 4 samples
 //   chroma lane = (plane = lane>>5, cy = (lane>>2)&7, cx = (lane&3)*2)    -> 2 samples
-__device__ __forceinline__ void inter_pred_mb(const FrameCtx &f, cslice_t s, gmotion_t mo, int mbx, int mby, int lane,
+__device__ __forceinline__ void inter_pred_mb(WaveLds &L, const FrameCtx &f, cslice_t s, gmotion_t mo, int mbx, int mby, int lane,
 	int outY[4], int outC[2])
 {
 	const int k = lane >> 2, r = lane & 3;
@@ -545,28 +558,56 @@ __device__ __forceinline__ void inter_pred_mb(const FrameCtx &f, cslice_t s, gmo
 	const int idc = s->weighted_bipred_idc;
 #pragma unroll 1
 	for (int list = 0; list < 2; list++) {
-		// luma
-		int pic = mo->refPic[list * 4 + (k >> 2)];
-		if (pic >= 0) {
-			int mx = mo->mvs[list * 32 + k * 2], my = mo->mvs[list * 32 + k * 2 + 1];
-			int p[4];
-			luma_pred4((const gu8 *)f.dpb[pic], f.sY, f.W, f.H, lx + (mx >> 2), ly + (my >> 2), mx & 3, my & 3, p);
-			int refIdxX = mo->refIdx[(list ^ 1) * 4 + (k >> 2)];
-			if (idc == 0 && !(list == 1 && refIdxX >= 0)) {
+		// luma: stage the reference windows in LDS, then every lane reads its 6 rows x 12 bytes from there
+		const int pic = mo->refPic[list * 4 + (k >> 2)];
+		const uint32_t mvp = *(const gu32 *)&mo->mvs[list * 32 + k * 2];
+		const int mx = (int)(int16_t)(mvp & 0xffff), my = (int)mvp >> 16;
+		const uint32_t mv0 = __shfl(mvp, 0), mvq = __shfl(mvp, lane & 48);
+		const int pic0 = __shfl(pic, 0), picq = __shfl(pic, lane & 48);
+		const bool u16 = __all(mvp == mv0 && pic == pic0);
+		const bool u8 = __all(mvp == mvq && pic == picq);
+		if (__any(pic >= 0) && !(f.dbg & 256)) {
+			const int gx = u16 ? 0 : u8 ? ((k >> 2) & 1) * 8 : BXf(k);
+			const int gy = u16 ? 0 : u8 ? (k >> 3) * 8 : BYf(k);
+			const int X0 = mbx * 16 + gx + (mx >> 2) - 2, Y0 = mby * 16 + gy + (my >> 2) - 2;
+			const int XA = X0 & ~3;
+			int nd, per, g;
+			if (u16) { stage_luma_windows<16>(L.win, f, lane, XA, Y0, pic); nd = 6; per = 21 * 6; g = 0; }
+			else if (u8) { stage_luma_windows<8>(L.win, f, lane, XA, Y0, pic); nd = 4; per = 13 * 4; g = k >> 2; }
+			else { stage_luma_windows<4>(L.win, f, lane, XA, Y0, pic); nd = 3; per = 9 * 3; g = k; }
+			wave_sync();
+			if (pic >= 0) {
+				const int o = (X0 & 3) + (BXf(k) - gx);
+				const int base = g * per + (BYf(k) - gy + r) * nd + (o >> 2);
+				const uint32_t sh = (uint32_t)(o & 3);
+				uint32_t d[6][3];
 #pragma unroll
-				for (int i = 0; i < 4; i++) outY[i] = p[i];
-			} else {
-				Wod wY, wCb, wCr;
-				select_weights(s, list, mo->refIdx[list * 4 + (k >> 2)], refIdxX, wY, wCb, wCr);
+				for (int rr = 0; rr < 6; rr++) {
+					uint32_t w0 = L.win[base + rr * nd], w1 = L.win[base + rr * nd + 1], w2 = L.win[base + rr * nd + 2];
+					d[rr][0] = __builtin_amdgcn_alignbyte(w1, w0, sh);
+					d[rr][1] = __builtin_amdgcn_alignbyte(w2, w1, sh);
+					d[rr][2] = w2 >> (sh * 8);
+				}
+				int p[4];
+				luma_from_rows(d, mx & 3, my & 3, p);
+				int refIdxX = mo->refIdx[(list ^ 1) * 4 + (k >> 2)];
+				if (idc == 0 && !(list == 1 && refIdxX >= 0)) {
 #pragma unroll
-				for (int i = 0; i < 4; i++) outY[i] = wpred(outY[i], p[i], wY);
+					for (int i = 0; i < 4; i++) outY[i] = p[i];
+				} else {
+					Wod wY, wCb, wCr;
+					select_weights(s, list, mo->refIdx[list * 4 + (k >> 2)], refIdxX, wY, wCb, wCr);
+#pragma unroll
+					for (int i = 0; i < 4; i++) outY[i] = wpred(outY[i], p[i], wY);
+				}
 			}
+			wave_sync();
 		}
 		// chroma
 		int picc = mo->refPic[list * 4 + (kc >> 2)];
-		if (picc >= 0) {
+		if (picc >= 0 && !(f.dbg & 512)) {
 			int mx = mo->mvs[list * 32 + kc * 2], my = mo->mvs[list * 32 + kc * 2 + 1];
-			const gu8 *rp = plane_base(f, (gu8 *)f.dpb[picc], 1 + cpl);
+			const gu8 *rp = plane_base(f, (gu8 *)f.dpb_lds[picc], 1 + cpl);
 			int X = mbx * 8 + cx + (mx >> 3), Y = mby * 8 + cy + (my >> 3);
 			int xF = mx & 7, yF = my & 7;
 			int A = (8 - xF) * (8 - yF), B = xF * (8 - yF), C = (8 - xF) * yF, D = xF * yF;
@@ -868,14 +909,14 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, int mbx,
 		return;
 	}
 	gmotion_t mo = nullptr;
-	if (m.kind == E264_MB_INTER) { mo = (gmotion_t)pl; pl += sizeof(E264Motion); }
+	if (m.kind == E264_MB_INTER) mo = f.motion + (mby * f.wm + mbx);
 	const uint32_t modes_lo = m.modes_lo, modes_hi = m.modes_hi;
-	compute_residual(L, f, m, s, pl, lane);
+	if (!(f.dbg & 1024)) compute_residual(L, f, m, s, pl, lane);
 
 	int pY[4], pC[2];
 	bool tile_luma = false;
 	if (WHICH != 2 && m.kind == E264_MB_INTER) {
-		inter_pred_mb(f, s, mo, mbx, mby, lane, pY, pC);
+		inter_pred_mb(L, f, s, mo, mbx, mby, lane, pY, pC);
 	} else if (WHICH != 1) {
 		load_intra_neighbours(L, f, mbx, mby, lane);
 		if (m.kind == E264_MB_I16x16) {
@@ -913,6 +954,7 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, int mbx,
 		outw = (uint32_t)clip255(w16(pY[0] + rr[0])) | (uint32_t)clip255(w16(pY[1] + rr[1])) << 8 |
 			(uint32_t)clip255(w16(pY[2] + rr[2])) << 16 | (uint32_t)clip255(w16(pY[3] + rr[3])) << 24;
 	}
+	if (f.dbg & 4096) return;
 	*(gu32 *)dY = outw;
 	const int16_t *rc = L.res + 256 + cpl * 64 + cy * 8 + cx;
 	*(gu16 *)dC = (uint16_t)(clip255(w16(pC[0] + rc[0])) | clip255(w16(pC[1] + rc[1])) << 8);
@@ -926,7 +968,7 @@ __device__ __forceinline__ BlkMo blk_motion(const FrameCtx &f, cmb_t m, int k)
 {
 	BlkMo o = {-1, -1, 0, 0, 0, 0};
 	if (m->kind == E264_MB_INTER) {
-		gmotion_t mo = (gmotion_t)(f.payload + m->payload_off);
+		gmotion_t mo = f.motion + (m - f.mbs);
 		o.ref0 = mo->refPic[k >> 2]; o.ref1 = mo->refPic[4 + (k >> 2)];
 		o.mv0x = mo->mvs[k * 2]; o.mv0y = mo->mvs[k * 2 + 1];
 		o.mv1x = mo->mvs[32 + k * 2]; o.mv1y = mo->mvs[32 + k * 2 + 1];
@@ -1235,6 +1277,9 @@ __device__ __forceinline__ bool open_frame(FrameCtx &f, const E264Job &job)
 	f.slices = (cslice_t)(pkt + h->slices_off);
 	f.mbs = (cmb_t)(pkt + h->mbs_off);
 	f.payload = (const gu8 *)(pkt + h->payload_off);
+	f.motion = h->motion_off ? (gmotion_t)(pkt + h->motion_off) : nullptr;
+	f.dpb_lds = nullptr;
+	f.dbg = 0;
 	f.dpb = (gdpb_t)job.dpb;
 	f.cur = (gu8 *)job.dpb[h->dst_slot];
 	f.wm = h->width_mbs; f.hm = h->height_mbs;
@@ -1249,21 +1294,27 @@ __device__ __forceinline__ bool open_frame(FrameCtx &f, const E264Job &job)
 } // namespace
 
 // every macroblock of every frame in parallel: 4 waves per workgroup, one macroblock per wave
-__global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, int mode)
+__global__ __launch_bounds__(256, 6) void e264_mbpar_kernel(const E264Job *jobs, int mode)
 {
 	__shared__ WaveLds lds[4];
+	__shared__ generic_u8p dpbtab[E264_MAX_SLOTS];
 	const int lane = lane_id();
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	FrameCtx f;
 	if (!open_frame(f, jobs[blockIdx.y]))
 		return;
+	if (threadIdx.x < E264_MAX_SLOTS)
+		dpbtab[threadIdx.x] = f.dpb[threadIdx.x];
+	__syncthreads();
+	f.dpb_lds = dpbtab;
+	f.dbg = mode;
 	const int addr = (int)blockIdx.x * 4 + wave;
 	if (addr >= f.wm * f.hm)
 		return;
 	const int mby = addr / f.wm, mbx = addr - mby * f.wm;
 	if (mode & 1)
 		recon_mb<1>(lds[wave], f, mbx, mby, lane);
-	if ((mode & 2) && f.dbk)
+	if ((mode & 2) && f.dbk && !(mode & 2048))
 		write_dbk_params(f, mbx, mby, lane);
 }
 

@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 E264_MAGIC = 0x34363245
-E264_VERSION = 1
+E264_VERSION = 2
 MAX_SLOTS = 32
 
 MB_ABSENT, MB_I4x4, MB_I8x8, MB_I16x16, MB_PCM, MB_INTER = range(6)
@@ -35,7 +35,7 @@ FRAME_HDR = np.dtype([
     ("stride_Y", "<u4"), ("stride_C", "<u4"), ("plane_size_Y", "<u4"), ("plane_size_C", "<u4"),
     ("n_slices", "<u4"), ("slices_off", "<u4"), ("mbs_off", "<u4"), ("payload_off", "<u4"),
     ("payload_bytes", "<u4"), ("dst_slot", "<i4"), ("ref_slots", "<u4"), ("frame_id", "<i4"),
-    ("n_coded_mbs", "<u4"), ("n_inter_mbs", "<u4"), ("reserved", "<u4", (2,)),
+    ("n_coded_mbs", "<u4"), ("n_inter_mbs", "<u4"), ("motion_off", "<u4"), ("reserved", "<u4", (1,)),
 ])
 assert FRAME_HDR.itemsize == 80
 
@@ -94,6 +94,9 @@ class PacketBuilder:
         self.slices: list[np.ndarray] = []
         self.mbs = np.zeros(width_mbs * height_mbs, dtype=MB)
         self.payload = bytearray()
+        self.motion = np.zeros(width_mbs * height_mbs, dtype=MOTION)
+        self.motion['refPic'] = -1
+        self.motion['refIdx'] = -1
         self.ref_slots = 0
 
     def add_slice(self, **kw) -> int:
@@ -126,9 +129,8 @@ class PacketBuilder:
         m["payload_off"] = len(self.payload)
         coded = 0
         if kind == MB_INTER:
-            mo = np.zeros((), MOTION)
+            mo = self.motion[addr]
             mo["refPic"], mo["refIdx"], mo["mvs"] = motion["refPic"], motion["refIdx"], np.asarray(motion["mvs"]).reshape(64)
-            self.payload += mo.tobytes()
             for r in np.asarray(motion["refPic"]).reshape(8):
                 if r >= 0:
                     self.ref_slots |= 1 << int(r)
@@ -156,7 +158,9 @@ class PacketBuilder:
         hdr = np.zeros((), FRAME_HDR)
         slices_off = align16(FRAME_HDR.itemsize)
         mbs_off = align16(slices_off + SLICE_PARAMS.itemsize * len(self.slices))
-        payload_off = align16(mbs_off + MB.itemsize * len(self.mbs))
+        has_motion = bool((self.mbs["kind"] == MB_INTER).any())
+        motion_off = align16(mbs_off + MB.itemsize * len(self.mbs))
+        payload_off = align16(motion_off + (self.motion.nbytes if has_motion else 0))
         pay = bytes(self.payload) + bytes(-len(self.payload) % 16)
         total = payload_off + len(pay)
         hdr["magic"], hdr["version"], hdr["total_bytes"] = E264_MAGIC, E264_VERSION, total
@@ -168,12 +172,15 @@ class PacketBuilder:
         hdr["dst_slot"], hdr["ref_slots"], hdr["frame_id"] = self.dst_slot, self.ref_slots, self.frame_id
         hdr["n_coded_mbs"] = int((self.mbs["kind"] != MB_ABSENT).sum())
         hdr["n_inter_mbs"] = int((self.mbs["kind"] == MB_INTER).sum())
+        hdr["motion_off"] = motion_off if has_motion else 0
         out = bytearray(total)
         out[:FRAME_HDR.itemsize] = hdr.tobytes()
         for i, s in enumerate(self.slices):
             o = slices_off + i * SLICE_PARAMS.itemsize
             out[o:o + SLICE_PARAMS.itemsize] = s.tobytes()
         out[mbs_off:mbs_off + self.mbs.nbytes] = self.mbs.tobytes()
+        if has_motion:
+            out[motion_off:motion_off + self.motion.nbytes] = self.motion.tobytes()
         out[payload_off:] = pay
         return bytes(out)
 
@@ -192,6 +199,7 @@ class Packet:
         n = int(self.hdr["width_mbs"]) * int(self.hdr["height_mbs"])
         self.mbs = np.frombuffer(data, MB, n, int(self.hdr["mbs_off"]))
         self.payload_off = int(self.hdr["payload_off"])
+        self.motion = (np.frombuffer(data, MOTION, n, int(self.hdr["motion_off"])) if int(self.hdr["motion_off"]) else None)
 
     @property
     def width_mbs(self) -> int:
@@ -212,7 +220,7 @@ class Packet:
         dirs = 0
         inter = np.nonzero(self.mbs["kind"] == MB_INTER)[0]
         for a in inter:
-            mo = np.frombuffer(self.data, MOTION, 1, self.payload_off + int(self.mbs[a]["payload_off"]))[0]
+            mo = self.motion[a]
             rp = mo["refPic"].reshape(2, 4)
             dirs += ((rp[0] >= 0).sum() + (rp[1] >= 0).sum()) / 4.0
         return int(F + F * dirs / n + int(self.hdr["total_bytes"]))

@@ -634,6 +634,7 @@ typedef struct {
 	const E264FrameHdr *h;
 	const E264SliceParams *slices;
 	const E264Mb *mbs;
+	const E264Motion *motion; /* NULL if the frame has no inter macroblock */
 	const uint8_t *payload;
 	uint8_t *const *dpb;
 	uint8_t *cur;
@@ -720,7 +721,7 @@ static void recon_mb(const Frame *f, int mbx, int mby)
 		return;
 	}
 	const E264Motion *mo = NULL;
-	if (m->kind == E264_MB_INTER) { mo = (const E264Motion *)pl; pl += sizeof(E264Motion); }
+	if (m->kind == E264_MB_INTER) mo = f->motion + (m - f->mbs);
 	const int16_t *ldc = NULL, *cdc = NULL;
 	if (m->coded & E264_CODED_LUMA_DC) { ldc = (const int16_t *)pl; pl += 32; }
 	if (m->coded & E264_CODED_CHROMA_DC) { cdc = (const int16_t *)pl; pl += 16; }
@@ -783,7 +784,7 @@ static void blk_motion(const Frame *f, const E264Mb *m, int k, BlkMo *o)
 		o->mv[0][0] = o->mv[0][1] = o->mv[1][0] = o->mv[1][1] = 0;
 		return;
 	}
-	const E264Motion *mo = (const E264Motion *)(f->payload + m->payload_off);
+	const E264Motion *mo = f->motion + (m - f->mbs);
 	for (int l = 0; l < 2; l++) {
 		o->ref[l] = mo->refPic[l * 4 + (k >> 2)];
 		o->mv[l][0] = mo->mvs[l * 32 + k * 2];
@@ -942,6 +943,7 @@ static int open_frame(Frame *f, const uint8_t *pkt, size_t bytes, uint8_t *const
 	f->h = h;
 	f->slices = (const E264SliceParams *)(pkt + h->slices_off);
 	f->mbs = (const E264Mb *)(pkt + h->mbs_off);
+	f->motion = h->motion_off ? (const E264Motion *)(pkt + h->motion_off) : NULL;
 	f->payload = pkt + h->payload_off;
 	f->dpb = dpb;
 	if (h->dst_slot < 0 || h->dst_slot >= E264_MAX_SLOTS || !dpb[h->dst_slot])

@@ -100,6 +100,7 @@ EXPORT int ref_replay_packet(RefHarness *h, const uint8_t *pkt, size_t bytes, ui
 	const E264SliceParams *slices = (const E264SliceParams *)(pkt + fh->slices_off);
 	const E264Mb *mbs = (const E264Mb *)(pkt + fh->mbs_off);
 	const uint8_t *payload = pkt + fh->payload_off;
+	const E264Motion *motion = fh->motion_off ? (const E264Motion *)(pkt + fh->motion_off) : NULL;
 	Edge264Context *ctx = &h->c;
 	uint8_t *cur = dpb[fh->dst_slot];
 	ctx->t.pic_width_in_mbs = h->W;
@@ -136,7 +137,7 @@ EXPORT int ref_replay_packet(RefHarness *h, const uint8_t *pkt, size_t bytes, ui
 			M->refIdx_l = -1;
 			M->refPic_l = -1;
 			if (m->kind == E264_MB_INTER) {
-				const E264Motion *mo = (const E264Motion *)(payload + m->payload_off);
+				const E264Motion *mo = motion + (m - mbs);
 				memcpy(M->refPic, mo->refPic, 8);
 				memcpy(M->refIdx, mo->refIdx, 8);
 				memcpy(M->mvs, mo->mvs, 128);
@@ -163,7 +164,6 @@ EXPORT int ref_replay_packet(RefHarness *h, const uint8_t *pkt, size_t bytes, ui
 					}
 					continue;
 				}
-				if (m->kind == E264_MB_INTER) pl += sizeof(E264Motion);
 				const int16_t *ldc = NULL, *cdc = NULL;
 				if (m->coded & E264_CODED_LUMA_DC) { ldc = (const int16_t *)pl; pl += 32; }
 				if (m->coded & E264_CODED_CHROMA_DC) { cdc = (const int16_t *)pl; pl += 16; }
