@@ -113,7 +113,7 @@ struct __attribute__((aligned(16))) WaveLds { // reconstruction scratch of one w
 	uint8_t ctile[2][9 * CT_STRIDE];
 	uint8_t ftop[32];          // intra 8x8 filtered top  ft[-1..15] at [i+1]
 	uint8_t fleft[8];          // intra 8x8 filtered left
-	uint32_t win[432];         // reference windows of inter prediction: 1 x 21x24, 4 x 13x16 or 16 x 9x12 bytes
+	uint32_t win[432];         // reference windows of inter prediction (one list at a time): 1 x 21x24, 4 x 13x16 or 16 x 9x12 bytes
 };
 
 #define DBK_RING 8 // macroblocks of bottom rows each row keeps in LDS for the row below
@@ -509,15 +509,67 @@ __device__ __forceinline__ void luma_from_rows(const uint32_t d[6][3], int xF, i
 	}
 }
 
-// Cooperative fetch of the luma reference windows of one list into LDS.  The partitioning is not
-// in the packet (motion is per 4x4 block), so the wave detects the coarsest uniform granularity:
-// S = 16 (one 21-row window, 6 dwords wide), 8 (four 13-row windows, 4 dwords) or 4 (sixteen 9-row
-// windows, 3 dwords).  Each reference cache line is requested once per window instead of once per
-// lane and tap row.  Out-of-frame samples: clamped row index, edge sample replicated over whole
-// dwords (frame width is a multiple of 16, window columns are dword aligned) == the reference's
+// ---------------------------------------------------------------------------------
+// Inter prediction, software pipelined over a strip of macroblocks (mbpar kernel):
+//   stage A (2 MBs ahead)  motion of the macroblock:   refPic/refIdx (uniform, scalar) + this lane's vectors
+//   stage B (1 MB ahead)   reference samples into registers (luma windows, chroma taps)
+//   stage C                registers -> LDS windows, 6-tap / bilinear filters, weights, residual, store
+// so that every global-memory round trip is overlapped with the arithmetic of earlier macroblocks.
+// Pixel layout of a wave:
+//   luma   lane = (k = lane>>2 : 4x4 block in zig order, r = lane&3 : row) -> 4 samples
+//   chroma lane = (plane = lane>>5, cy = (lane>>2)&7, cx = (lane&3)*2)    -> 2 samples
+// ---------------------------------------------------------------------------------
+struct McMotion {
+	uint32_t refs[4];        // refPic L0, refPic L1, refIdx L0, refIdx L1 (4 x int8 each, per 8x8 block)
+	uint32_t mvY[2], mvC[2]; // packed (x | y<<16) vectors of this lane's luma block and chroma block, per list
+};
+struct McWindows {          // reference samples of ONE list
+	uint32_t y[7];           // luma window dwords fetched by this lane
+	int c[6];                // chroma samples (x..x+2, y..y+1) of this lane
+};
+__device__ __forceinline__ int ref_byte(uint32_t w, int b8) { return (int)(int8_t)(w >> (8 * b8)); }
+
+__device__ __forceinline__ void mc_load_motion(const FrameCtx &f, int addr, int lane, McMotion &M)
+{
+	const int k = lane >> 2, kc = blk_of((lane & 3), ((lane >> 2) & 7) >> 1);
+	if (!f.motion) { M.refs[0] = M.refs[1] = M.refs[2] = M.refs[3] = 0xffffffffu; M.mvY[0] = M.mvY[1] = M.mvC[0] = M.mvC[1] = 0; return; }
+	gmotion_t mo = f.motion + addr;
+	const uint32_t __attribute__((address_space(4))) *rp = (const uint32_t __attribute__((address_space(4))) *)mo;
+	M.refs[0] = rp[0]; M.refs[1] = rp[1]; M.refs[2] = rp[2]; M.refs[3] = rp[3];
+	M.mvY[0] = *(const gu32 *)&mo->mvs[k * 2]; M.mvY[1] = *(const gu32 *)&mo->mvs[32 + k * 2];
+	M.mvC[0] = *(const gu32 *)&mo->mvs[kc * 2]; M.mvC[1] = *(const gu32 *)&mo->mvs[32 + kc * 2];
+}
+
+// geometry of the luma reference window this lane's block belongs to (list l)
+struct McGeom { int S, g, gx, gy, X0, Y0, pic, mx, my; };
+__device__ __forceinline__ McGeom mc_geom(const McMotion &M, int l, int lane, int mbx, int mby)
+{
+	McGeom G;
+	const int k = lane >> 2;
+	G.pic = ref_byte(M.refs[l], k >> 2);
+	const uint32_t mvp = M.mvY[l];
+	G.mx = (int)(int16_t)(mvp & 0xffff); G.my = (int)mvp >> 16;
+	// coarsest uniform granularity (the packet carries per-4x4 motion, not partitions)
+	const uint32_t mv0 = __shfl(mvp, 0), mvq = __shfl(mvp, lane & 48);
+	const int pic0 = __shfl(G.pic, 0), picq = __shfl(G.pic, lane & 48);
+	const bool u16 = __all(mvp == mv0 && G.pic == pic0);
+	const bool u8 = __all(mvp == mvq && G.pic == picq);
+	G.S = u16 ? 16 : u8 ? 8 : 4;
+	G.g = u16 ? 0 : u8 ? k >> 2 : k;
+	G.gx = u16 ? 0 : u8 ? ((k >> 2) & 1) * 8 : BXf(k);
+	G.gy = u16 ? 0 : u8 ? (k >> 3) * 8 : BYf(k);
+	G.X0 = mbx * 16 + G.gx + (G.mx >> 2) - 2;
+	G.Y0 = mby * 16 + G.gy + (G.my >> 2) - 2;
+	return G;
+}
+
+// Fetch of the luma reference windows of one list: S = 16 (one 21-row window, 6 dwords wide), 8 (four
+// 13-row windows, 4 dwords) or 4 (sixteen 9-row windows, 3 dwords).  Each reference cache line is
+// requested once per window.  Out-of-frame samples: clamped row index, edge sample replicated over
+// whole dwords (frame width is a multiple of 16, window columns are dword aligned) == the reference's
 // edge emulation (edge264_inter.c:1199-1235).
 template <int S>
-__device__ __forceinline__ void stage_luma_windows(uint32_t *win, const FrameCtx &f, int lane, int XA, int Y0, int pic)
+__device__ __forceinline__ void mc_issue_luma(const FrameCtx &f, int lane, int XA, int Y0, int pic, uint32_t w[7])
 {
 	constexpr int ROWS = S + 5, ND = S == 16 ? 6 : S == 8 ? 4 : 3, G = 256 / (S * S), PER = ROWS * ND;
 #pragma unroll
@@ -526,107 +578,149 @@ __device__ __forceinline__ void stage_luma_windows(uint32_t *win, const FrameCtx
 		const int g = idx / PER, rem = idx - g * PER, row = rem / ND, dw = rem - row * ND;
 		const int src = (g * (64 / G)) & 63;
 		const int xa = __shfl(XA, src), y0 = __shfl(Y0, src), pc = __shfl(pic, src);
+		uint32_t v = 0;
 		if (idx < G * PER && pc >= 0) {
-			const gu8 *plane = (const gu8 *)f.dpb_lds[pc];
-			const gu8 *rowp = plane + (size_t)clip3i(0, f.H - 1, y0 + row) * f.sY;
+			const gu8 *rowp = (const gu8 *)f.dpb_lds[pc] + (size_t)clip3i(0, f.H - 1, y0 + row) * f.sY;
 			const int x = xa + dw * 4;
-			uint32_t v;
 			if (x >= 0 && x <= f.W - 4) v = *(const gu32 *)(rowp + x);
 			else v = (uint32_t)rowp[x < 0 ? 0 : f.W - 1] * 0x01010101u;
-			win[idx] = v;
 		}
+		w[it] = v;
 	}
 }
 
-__device__ __forceinline__ int ldc_px(const gu8 *plane, int stride, int W, int H, int x, int y)
+__device__ __forceinline__ void mc_issue(const FrameCtx &f, const McMotion &M, int l, int mbx, int mby, int lane, McWindows &Wn)
 {
-	return plane[(size_t)clip3i(0, H - 1, y) * stride + clip3i(0, W - 1, x)];
+	const int cpl = lane >> 5, cy = (lane >> 2) & 7, cx = (lane & 3) * 2;
+	if (M.refs[l] == 0xffffffffu) // list unused by the whole macroblock (uniform): P macroblocks skip list 1
+		return;
+	McGeom G = mc_geom(M, l, lane, mbx, mby);
+	if (!(f.dbg & 256)) {
+		if (G.S == 16) mc_issue_luma<16>(f, lane, G.X0 & ~3, G.Y0, G.pic, Wn.y);
+		else if (G.S == 8) mc_issue_luma<8>(f, lane, G.X0 & ~3, G.Y0, G.pic, Wn.y);
+		else mc_issue_luma<4>(f, lane, G.X0 & ~3, G.Y0, G.pic, Wn.y);
+	}
+	// chroma: the 3x2 samples around this lane's two outputs (8.4.2.2.2)
+	const int kc = blk_of(cx >> 1, cy >> 1);
+	const int picc = ref_byte(M.refs[l], kc >> 2);
+	if (picc >= 0 && !(f.dbg & 512)) {
+		const int mx = (int)(int16_t)(M.mvC[l] & 0xffff), my = (int)M.mvC[l] >> 16;
+		const gu8 *rp = plane_base(f, (gu8 *)f.dpb_lds[picc], 1 + cpl);
+		const int X = mbx * 8 + cx + (mx >> 3), Y = mby * 8 + cy + (my >> 3);
+		const int Wc = f.W >> 1, Hc = f.H >> 1;
+		const gu8 *r0 = rp + (size_t)clip3i(0, Hc - 1, Y) * f.sC, *r1 = rp + (size_t)clip3i(0, Hc - 1, Y + 1) * f.sC;
+		const int x0 = clip3i(0, Wc - 1, X), x1 = clip3i(0, Wc - 1, X + 1), x2 = clip3i(0, Wc - 1, X + 2);
+		Wn.c[0] = r0[x0]; Wn.c[1] = r0[x1]; Wn.c[2] = r0[x2];
+		Wn.c[3] = r1[x0]; Wn.c[4] = r1[x1]; Wn.c[5] = r1[x2];
+	}
 }
 
-// Inter prediction of a whole macroblock in the "pixel layout":
-//   luma   lane = (k = lane>>2 : 4x4 block in zig order, r = lane&3 : row) -> 4 samples
-//   chroma lane = (plane = lane>>5, cy = (lane>>2)&7, cx = (lane&3)*2)    -> 2 samples
-__device__ __forceinline__ void inter_pred_mb(WaveLds &L, const FrameCtx &f, cslice_t s, gmotion_t mo, int mbx, int mby, int lane,
-	int outY[4], int outC[2])
+// registers -> LDS window (the S of the list is recomputed: cheap and uniform)
+__device__ __forceinline__ void mc_commit(WaveLds &L, const McMotion &M, int l, const McWindows &Wn, int mbx, int mby, int lane)
+{
+	if (M.refs[l] == 0xffffffffu)
+		return;
+	McGeom G = mc_geom(M, l, lane, mbx, mby);
+	const int total = G.S == 16 ? 126 : G.S == 8 ? 208 : 432;
+#pragma unroll
+	for (int it = 0; it < 7; it++)
+		if (it * 64 + lane < total)
+			L.win[it * 64 + lane] = Wn.y[it];
+}
+
+// filters + weights of one list of one macroblock from the LDS window / chroma registers
+__device__ __forceinline__ void mc_compute(WaveLds &L, const FrameCtx &f, cslice_t s, const McMotion &M, int l, const McWindows &Wn,
+	int mbx, int mby, int lane, int outY[4], int outC[2])
 {
 	const int k = lane >> 2, r = lane & 3;
-	const int lx = mbx * 16 + BXf(k), ly = mby * 16 + BYf(k) + r;
 	const int cpl = lane >> 5, cy = (lane >> 2) & 7, cx = (lane & 3) * 2;
 	const int kc = blk_of(cx >> 1, cy >> 1);
-	outY[0] = outY[1] = outY[2] = outY[3] = 0;
-	outC[0] = outC[1] = 0;
 	const int idc = s->weighted_bipred_idc;
-#pragma unroll 1
-	for (int list = 0; list < 2; list++) {
-		// luma: stage the reference windows in LDS, then every lane reads its 6 rows x 12 bytes from there
-		const int pic = mo->refPic[list * 4 + (k >> 2)];
-		const uint32_t mvp = *(const gu32 *)&mo->mvs[list * 32 + k * 2];
-		const int mx = (int)(int16_t)(mvp & 0xffff), my = (int)mvp >> 16;
-		const uint32_t mv0 = __shfl(mvp, 0), mvq = __shfl(mvp, lane & 48);
-		const int pic0 = __shfl(pic, 0), picq = __shfl(pic, lane & 48);
-		const bool u16 = __all(mvp == mv0 && pic == pic0);
-		const bool u8 = __all(mvp == mvq && pic == picq);
-		if (__any(pic >= 0) && !(f.dbg & 256)) {
-			const int gx = u16 ? 0 : u8 ? ((k >> 2) & 1) * 8 : BXf(k);
-			const int gy = u16 ? 0 : u8 ? (k >> 3) * 8 : BYf(k);
-			const int X0 = mbx * 16 + gx + (mx >> 2) - 2, Y0 = mby * 16 + gy + (my >> 2) - 2;
-			const int XA = X0 & ~3;
-			int nd, per, g;
-			if (u16) { stage_luma_windows<16>(L.win, f, lane, XA, Y0, pic); nd = 6; per = 21 * 6; g = 0; }
-			else if (u8) { stage_luma_windows<8>(L.win, f, lane, XA, Y0, pic); nd = 4; per = 13 * 4; g = k >> 2; }
-			else { stage_luma_windows<4>(L.win, f, lane, XA, Y0, pic); nd = 3; per = 9 * 3; g = k; }
-			wave_sync();
-			if (pic >= 0) {
-				const int o = (X0 & 3) + (BXf(k) - gx);
-				const int base = g * per + (BYf(k) - gy + r) * nd + (o >> 2);
-				const uint32_t sh = (uint32_t)(o & 3);
-				uint32_t d[6][3];
+	if (M.refs[l] == 0xffffffffu)
+		return;
+	McGeom G = mc_geom(M, l, lane, mbx, mby);
+	if (G.pic >= 0 && !(f.dbg & 256)) {
+		const int nd = G.S == 16 ? 6 : G.S == 8 ? 4 : 3, per = (G.S + 5) * nd;
+		const int o = (G.X0 & 3) + (BXf(k) - G.gx);
+		const int base = G.g * per + (BYf(k) - G.gy + r) * nd + (o >> 2);
+		const uint32_t sh = (uint32_t)(o & 3);
+		uint32_t d[6][3];
 #pragma unroll
-				for (int rr = 0; rr < 6; rr++) {
-					uint32_t w0 = L.win[base + rr * nd], w1 = L.win[base + rr * nd + 1], w2 = L.win[base + rr * nd + 2];
-					d[rr][0] = __builtin_amdgcn_alignbyte(w1, w0, sh);
-					d[rr][1] = __builtin_amdgcn_alignbyte(w2, w1, sh);
-					d[rr][2] = w2 >> (sh * 8);
-				}
-				int p[4];
-				luma_from_rows(d, mx & 3, my & 3, p);
-				int refIdxX = mo->refIdx[(list ^ 1) * 4 + (k >> 2)];
-				if (idc == 0 && !(list == 1 && refIdxX >= 0)) {
-#pragma unroll
-					for (int i = 0; i < 4; i++) outY[i] = p[i];
-				} else {
-					Wod wY, wCb, wCr;
-					select_weights(s, list, mo->refIdx[list * 4 + (k >> 2)], refIdxX, wY, wCb, wCr);
-#pragma unroll
-					for (int i = 0; i < 4; i++) outY[i] = wpred(outY[i], p[i], wY);
-				}
-			}
-			wave_sync();
+		for (int rr = 0; rr < 6; rr++) {
+			uint32_t w0 = L.win[base + rr * nd], w1 = L.win[base + rr * nd + 1], w2 = L.win[base + rr * nd + 2];
+			d[rr][0] = __builtin_amdgcn_alignbyte(w1, w0, sh);
+			d[rr][1] = __builtin_amdgcn_alignbyte(w2, w1, sh);
+			d[rr][2] = w2 >> (sh * 8);
 		}
-		// chroma
-		int picc = mo->refPic[list * 4 + (kc >> 2)];
-		if (picc >= 0 && !(f.dbg & 512)) {
-			int mx = mo->mvs[list * 32 + kc * 2], my = mo->mvs[list * 32 + kc * 2 + 1];
-			const gu8 *rp = plane_base(f, (gu8 *)f.dpb_lds[picc], 1 + cpl);
-			int X = mbx * 8 + cx + (mx >> 3), Y = mby * 8 + cy + (my >> 3);
-			int xF = mx & 7, yF = my & 7;
-			int A = (8 - xF) * (8 - yF), B = xF * (8 - yF), C = (8 - xF) * yF, D = xF * yF;
-			int Wc = f.W >> 1, Hc = f.H >> 1;
-			int a0 = ldc_px(rp, f.sC, Wc, Hc, X, Y), a1 = ldc_px(rp, f.sC, Wc, Hc, X + 1, Y), a2 = ldc_px(rp, f.sC, Wc, Hc, X + 2, Y);
-			int b0 = ldc_px(rp, f.sC, Wc, Hc, X, Y + 1), b1 = ldc_px(rp, f.sC, Wc, Hc, X + 1, Y + 1), b2 = ldc_px(rp, f.sC, Wc, Hc, X + 2, Y + 1);
-			int p0 = (A * a0 + B * a1 + C * b0 + D * b1 + 32) >> 6;
-			int p1 = (A * a1 + B * a2 + C * b1 + D * b2 + 32) >> 6;
-			int refIdxX = mo->refIdx[(list ^ 1) * 4 + (kc >> 2)];
-			if (idc == 0 && !(list == 1 && refIdxX >= 0)) {
-				outC[0] = p0; outC[1] = p1;
-			} else {
-				Wod wY, wC[2];
-				select_weights(s, list, mo->refIdx[list * 4 + (kc >> 2)], refIdxX, wY, wC[0], wC[1]);
-				outC[0] = wpred(outC[0], p0, wC[cpl]);
-				outC[1] = wpred(outC[1], p1, wC[cpl]);
-			}
+		int p[4];
+		luma_from_rows(d, G.mx & 3, G.my & 3, p);
+		const int refIdxX = ref_byte(M.refs[2 + (l ^ 1)], k >> 2);
+		if (idc == 0 && !(l == 1 && refIdxX >= 0)) {
+#pragma unroll
+			for (int i = 0; i < 4; i++) outY[i] = p[i];
+		} else {
+			Wod wY, wCb, wCr;
+			select_weights(s, l, ref_byte(M.refs[2 + l], k >> 2), refIdxX, wY, wCb, wCr);
+#pragma unroll
+			for (int i = 0; i < 4; i++) outY[i] = wpred(outY[i], p[i], wY);
 		}
 	}
+	const int picc = ref_byte(M.refs[l], kc >> 2);
+	if (picc >= 0 && !(f.dbg & 512)) {
+		const int mx = (int)(int16_t)(M.mvC[l] & 0xffff), my = (int)M.mvC[l] >> 16;
+		const int xF = mx & 7, yF = my & 7;
+		const int A = (8 - xF) * (8 - yF), B = xF * (8 - yF), C = (8 - xF) * yF, D = xF * yF;
+		const int p0 = (A * Wn.c[0] + B * Wn.c[1] + C * Wn.c[3] + D * Wn.c[4] + 32) >> 6;
+		const int p1 = (A * Wn.c[1] + B * Wn.c[2] + C * Wn.c[4] + D * Wn.c[5] + 32) >> 6;
+		const int refIdxX = ref_byte(M.refs[2 + (l ^ 1)], kc >> 2);
+		if (idc == 0 && !(l == 1 && refIdxX >= 0)) {
+			outC[0] = p0; outC[1] = p1;
+		} else {
+			Wod wY, wC[2];
+			select_weights(s, l, ref_byte(M.refs[2 + l], kc >> 2), refIdxX, wY, wC[0], wC[1]);
+			outC[0] = wpred(outC[0], p0, cpl ? wC[1] : wC[0]);
+			outC[1] = wpred(outC[1], p1, cpl ? wC[1] : wC[0]);
+		}
+	}
+}
+
+// stage C of one macroblock of the strip: everything that is not intra prediction
+__device__ __forceinline__ void mbpar_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, const McMotion &M, const McWindows &Wn,
+	int mbx, int mby, int lane)
+{
+	if (m.kind != E264_MB_INTER && m.kind != E264_MB_PCM)
+		return;
+	const gu8 *pl = f.payload + m.payload_off;
+	const int k = lane >> 2, r = lane & 3;
+	const int X = BXf(k), Yr = BYf(k) + r;
+	gu8 *dY = f.cur + (size_t)(mby * 16 + Yr) * f.sY + mbx * 16 + X;
+	const int cpl = lane >> 5, cy = (lane >> 2) & 7, cx = (lane & 3) * 2;
+	gu8 *dC = plane_base(f, f.cur, 1 + cpl) + (size_t)(mby * 8 + cy) * f.sC + mbx * 8 + cx;
+	if (m.kind == E264_MB_PCM) { // edge264_slice.c:914-935
+		*(gu32 *)dY = *(const gu32 *)(pl + Yr * 16 + X);
+		*(gu16 *)dC = *(const gu16 *)(pl + 256 + cpl * 64 + cy * 8 + cx);
+		return;
+	}
+	cslice_t s = f.slices + m.slice;
+	if (!(f.dbg & 1024)) compute_residual(L, f, m, s, pl, lane);
+	int pY[4] = {0, 0, 0, 0}, pC[2] = {0, 0};
+	mc_compute(L, f, s, M, 0, Wn, mbx, mby, lane, pY, pC); // list 0: window already in LDS (prefetched)
+	if (M.refs[1] != 0xffffffffu) { // list 1 (B macroblocks): fetched here, not pipelined
+		McWindows W1;
+		wave_sync();
+		mc_issue(f, M, 1, mbx, mby, lane, W1);
+		mc_commit(L, M, 1, W1, mbx, mby, lane);
+		wave_sync();
+		mc_compute(L, f, s, M, 1, W1, mbx, mby, lane, pY, pC);
+	}
+	// add residual, clip, store (int16 wrap add then packus: residual.c:160-171)
+	const int16_t *rr = L.res + Yr * 16 + X;
+	const uint32_t outw = (uint32_t)clip255(w16(pY[0] + rr[0])) | (uint32_t)clip255(w16(pY[1] + rr[1])) << 8 |
+		(uint32_t)clip255(w16(pY[2] + rr[2])) << 16 | (uint32_t)clip255(w16(pY[3] + rr[3])) << 24;
+	if (f.dbg & 4096) return;
+	*(gu32 *)dY = outw;
+	const int16_t *rc = L.res + 256 + cpl * 64 + cy * 8 + cx;
+	*(gu16 *)dC = (uint16_t)(clip255(w16(pC[0] + rc[0])) | clip255(w16(pC[1] + rc[1])) << 8);
 }
 
 // ---------------------------------------------------------------------------------
@@ -908,16 +1002,12 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, int mbx,
 		*(gu16 *)dC = *(const gu16 *)(pl + 256 + cpl * 64 + cy * 8 + cx);
 		return;
 	}
-	gmotion_t mo = nullptr;
-	if (m.kind == E264_MB_INTER) mo = f.motion + (mby * f.wm + mbx);
 	const uint32_t modes_lo = m.modes_lo, modes_hi = m.modes_hi;
 	if (!(f.dbg & 1024)) compute_residual(L, f, m, s, pl, lane);
 
 	int pY[4], pC[2];
 	bool tile_luma = false;
-	if (WHICH != 2 && m.kind == E264_MB_INTER) {
-		inter_pred_mb(L, f, s, mo, mbx, mby, lane, pY, pC);
-	} else if (WHICH != 1) {
+	if (WHICH != 1 && m.kind != E264_MB_INTER) {
 		load_intra_neighbours(L, f, mbx, mby, lane);
 		if (m.kind == E264_MB_I16x16) {
 			intra16x16_pred(L, m.i16_mode, X, Yr, pY);
@@ -1291,10 +1381,12 @@ __device__ __forceinline__ bool open_frame(FrameCtx &f, const E264Job &job)
 }
 
 #define E264_MAX_ROWS 1056
+#define E264_MBPAR_STRIP 8
 } // namespace
 
-// every macroblock of every frame in parallel: 4 waves per workgroup, one macroblock per wave
-__global__ __launch_bounds__(256, 6) void e264_mbpar_kernel(const E264Job *jobs, int mode)
+// every macroblock of every frame in parallel: 4 waves per workgroup, a strip of E264_MBPAR_STRIP
+// consecutive macroblocks per wave, software pipelined (see "Inter prediction" above)
+__global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, int mode)
 {
 	__shared__ WaveLds lds[4];
 	__shared__ generic_u8p dpbtab[E264_MAX_SLOTS];
@@ -1308,14 +1400,59 @@ __global__ __launch_bounds__(256, 6) void e264_mbpar_kernel(const E264Job *jobs,
 	__syncthreads();
 	f.dpb_lds = dpbtab;
 	f.dbg = mode;
-	const int addr = (int)blockIdx.x * 4 + wave;
-	if (addr >= f.wm * f.hm)
+	const int n_mbs = f.wm * f.hm;
+	const int base = ((int)blockIdx.x * 4 + wave) * E264_MBPAR_STRIP;
+	const int n = min(E264_MBPAR_STRIP, n_mbs - base);
+	if (n <= 0)
 		return;
-	const int mby = addr / f.wm, mbx = addr - mby * f.wm;
-	if (mode & 1)
-		recon_mb<1>(lds[wave], f, mbx, mby, lane);
-	if ((mode & 2) && f.dbk && !(mode & 2048))
+	WaveLds &L = lds[wave];
+	const bool recon = mode & 1;
+	MbInfo h0 = load_mb(f.mbs + base), h1 = h0, h2 = h0;
+	McMotion m0, m1, m2;
+	McWindows w0, w1;
+	mc_load_motion(f, base, lane, m0);
+	m1 = m0; m2 = m0;
+	if (n > 1) { h1 = load_mb(f.mbs + base + 1); mc_load_motion(f, base + 1, lane, m1); }
+	int mby = base / f.wm, mbx = base - mby * f.wm;
+	if (recon && h0.kind == E264_MB_INTER)
+		mc_issue(f, m0, 0, mbx, mby, lane, w0);
+#pragma unroll 1
+	for (int i = 0; i < n; i++) {
+		int nx = mbx + 1, ny = mby;
+		if (nx == f.wm) { nx = 0; ny++; }
+		if (i + 2 < n) { h2 = load_mb(f.mbs + base + i + 2); mc_load_motion(f, base + i + 2, lane, m2); }
+		if (recon && h0.kind == E264_MB_INTER)
+			mc_commit(L, m0, 0, w0, mbx, mby, lane);
+		wave_sync();
+		if (recon && i + 1 < n && h1.kind == E264_MB_INTER)
+			mc_issue(f, m1, 0, nx, ny, lane, w1);
+		if (recon)
+			mbpar_mb(L, f, h0, m0, w0, mbx, mby, lane);
+		wave_sync();
+		h0 = h1; h1 = h2; m0 = m1; m1 = m2; w0 = w1;
+		mbx = nx; mby = ny;
+	}
+}
+
+// deblocking parameters (bS, alpha, beta, indexA) of every macroblock: one wave per macroblock, few
+// registers, all loads independent -> latency hidden by occupancy.  Runs concurrently with nothing
+// it depends on: only the command packet is read.
+__global__ __launch_bounds__(256) void e264_dbkparam_kernel(const E264Job *jobs)
+{
+	const int lane = lane_id();
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	FrameCtx f;
+	if (!open_frame(f, jobs[blockIdx.y]) || !f.dbk)
+		return;
+	const int n_mbs = f.wm * f.hm;
+#pragma unroll 1
+	for (int i = 0; i < 4; i++) {
+		const int addr = ((int)blockIdx.x * 4 + wave) * 4 + i;
+		if (addr >= n_mbs)
+			return;
+		const int mby = addr / f.wm, mbx = addr - mby * f.wm;
 		write_dbk_params(f, mbx, mby, lane);
+	}
 }
 
 template <int NW>
@@ -1431,7 +1568,9 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 		return hipSuccess;
 	// marks (optional): 4 events recorded before / between / after the three launches
 	if (marks) hipEventRecord(marks[0], stream);
-	hipLaunchKernelGGL(e264_mbpar_kernel, dim3((max_mbs + 3) / 4, n_jobs), dim3(256), 0, stream, jobs, mode);
+	if ((mode & 2) && !(mode & 2048))
+		hipLaunchKernelGGL(e264_dbkparam_kernel, dim3((max_mbs + 15) / 16, n_jobs), dim3(256), 0, stream, jobs);
+	hipLaunchKernelGGL(e264_mbpar_kernel, dim3((max_mbs + 4 * E264_MBPAR_STRIP - 1) / (4 * E264_MBPAR_STRIP), n_jobs), dim3(256), 0, stream, jobs, mode);
 	if (marks) hipEventRecord(marks[1], stream);
 	if (mode & 1) {
 		switch (waves) {
