@@ -1,0 +1,361 @@
+/*
+ * edge264_hip_frontend.c -- edge264.h surface in front of the MI355X back end.
+ *
+ * One translation unit = the reference's front end (parsers, mvpred, DPB bookkeeping; compiled
+ * from /root/reference through the include farm of oracle/Makefile, with the four sample-kernel
+ * files replaced by the emitters of this directory) + thin wrappers around its 7 public
+ * functions (edge264.h:64-70).  The wrappers
+ *   - force the synchronous mode (n_threads = 0, src/edge264_headers.c:1285-1286) and own the
+ *     frame memory through the reference's own Edge264AllocCb hook (edge264.h:42-43),
+ *   - number the NAL units so that the emitters can tell slices apart,
+ *   - after every NAL, close the frames whose last macroblock has been parsed
+ *     (next_deblock_addr[pic]==INT_MAX, src/edge264_headers.c:567) and hand their command packet
+ *     to the sink,
+ *   - in get_frame, make the samples the reference points at (src/edge264.c:385-387) valid by
+ *     waiting for the device and copying the frame into the host mirror.
+ * Sinks: 0 = libedge264_hip.so (include/edge264_hip.h, resolved with dlopen so that this file has
+ * no link-time dependency on ROCm), 1 = capture (packets are queued for the caller; used by the
+ * tests to replay them through the CPU oracle, and by tools/ to write capture files).
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <stdio.h>
+
+#define edge264_find_start_code e264ref_find_start_code
+#define edge264_alloc e264ref_alloc
+#define edge264_flush e264ref_flush
+#define edge264_free e264ref_free
+#define edge264_decode_NAL e264ref_decode_NAL
+#define edge264_get_frame e264ref_get_frame
+#define edge264_return_frame e264ref_return_frame
+#include E264_FARM_EDGE264_C
+#undef edge264_find_start_code
+#undef edge264_alloc
+#undef edge264_flush
+#undef edge264_free
+#undef edge264_decode_NAL
+#undef edge264_get_frame
+#undef edge264_return_frame
+
+#include "e264_emit.h"
+#include "edge264_hip.h"
+
+#define PUBLIC __attribute__((visibility("default")))
+
+/* ---- back end binding (dlopen) ------------------------------------------------------------ */
+static struct {
+	void *lib;
+	int (*device_open)(int, E264Device **);
+	int (*stream_open)(E264Device *, E264Stream **);
+	void (*stream_close)(E264Stream *);
+	int (*frame_alloc)(E264Stream *, int, size_t, void **);
+	void (*frame_free)(E264Stream *, int);
+	int (*frame_fill)(E264Stream *, int, int);
+	int (*frame_submit)(E264Stream *, const void *, size_t);
+	void *(*packet_buffer)(E264Stream *, size_t);
+	int (*frame_wait)(E264Stream *, int);
+	int (*frame_download)(E264Stream *, int, void *, size_t);
+	int (*stream_flush)(E264Stream *);
+	E264Device *dev; /* one device object shared by every decoder of the process */
+} hip;
+
+static int g_sink_kind = 0;
+static int g_device_ordinal = 0;
+
+PUBLIC void e264front_set_sink(int kind) { g_sink_kind = kind; }
+PUBLIC void e264front_set_device(int ordinal) { g_device_ordinal = ordinal; }
+
+static int hip_bind(void)
+{
+	if (hip.lib)
+		return hip.dev ? 0 : ENODEV;
+	const char *path = getenv("E264_HIP_LIB");
+	char buf[4096];
+	if (!path) { /* <repo>/oracle/_ref/libedge264_hipfront.so -> <repo>/edge264_amd/libedge264_hip.so */
+		Dl_info info;
+		if (dladdr((void *)hip_bind, &info) && info.dli_fname) {
+			snprintf(buf, sizeof(buf), "%s", info.dli_fname);
+			char *s = strrchr(buf, '/');
+			if (s) {
+				snprintf(s, sizeof(buf) - (size_t)(s - buf), "/../../edge264_amd/libedge264_hip.so");
+				path = buf;
+			}
+		}
+	}
+	hip.lib = dlopen(path ? path : "libedge264_hip.so", RTLD_NOW | RTLD_LOCAL);
+	if (!hip.lib)
+		return ENODEV;
+#define BIND(n) if (!(*(void **)&hip.n = dlsym(hip.lib, "e264hip_" #n))) return ENODEV
+	BIND(device_open); BIND(stream_open); BIND(stream_close); BIND(frame_alloc); BIND(frame_free); BIND(frame_fill);
+	BIND(frame_submit); BIND(packet_buffer); BIND(frame_wait); BIND(frame_download); BIND(stream_flush);
+#undef BIND
+	return hip.device_open(g_device_ordinal, &hip.dev);
+}
+
+/* ---- frame memory: the reference's alloc/free hook (src/edge264_headers.c:113-133) -------- */
+static void e264_alloc_cb(void **samples, unsigned samples_size, void **mbs, unsigned mbs_size, int errno_on_fail, void *arg)
+{
+	E264Emitter *e = arg;
+	int slot = (int)((uint8_t **)samples - e->dec->samples_buffers);
+	*samples = NULL;
+	*mbs = NULL;
+	if (slot < 0 || slot >= E264_MAX_SLOTS)
+		return;
+	void *mirror = NULL;
+	if (e->sink_kind == 0) {
+		if (hip.frame_alloc(e->hip_stream, slot, samples_size, &mirror))
+			return;
+		hip.frame_fill(e->hip_stream, slot, 0); /* "non-existing" frames are never written (headers.c:1122-1144) */
+	} else {
+		mirror = aligned_alloc(64, ((size_t)samples_size + 63) & ~(size_t)63);
+	}
+	void *m = aligned_alloc(64, ((size_t)mbs_size + 63) & ~(size_t)63);
+	if (!mirror || !m) {
+		free(m);
+		return;
+	}
+	e->slot[slot].samples = mirror;
+	e->slot[slot].samples_size = samples_size;
+	e->slot[slot].mbs = m;
+	*samples = mirror;
+	*mbs = m;
+	(void)errno_on_fail;
+}
+
+static void e264_free_cb(void *samples, void *mbs, void *arg)
+{
+	E264Emitter *e = arg;
+	for (int s = 0; s < E264_MAX_SLOTS; s++) {
+		if (samples && e->slot[s].samples == samples) {
+			if (e->cur.valid && e->cur.slot == s)
+				e->cur.valid = 0;
+			e->fb[s].active = 0;
+			if (e->sink_kind == 0) hip.frame_free(e->hip_stream, s);
+			else free(samples);
+			free(e->slot[s].mbs);
+			memset(&e->slot[s], 0, sizeof(e->slot[s]));
+			return;
+		}
+	}
+	free(mbs);
+}
+
+/* ---- closing a frame: assemble the packet, give it to the sink --------------------------- */
+static int e264_finish_frame(E264Emitter *e, int slot)
+{
+	E264FrameBuilder *b = &e->fb[slot];
+	Edge264Decoder *dec = e->dec;
+	if (e->cur.valid && e->cur.slot == slot)
+		e264_flush_mb(e);
+	/* I_PCM macroblocks issue no leaf call: the parser wrote their samples into the host mirror
+	 * (src/edge264_slice.c:914-935); decoded-but-unseen macroblocks are PCM */
+	int flip = dec->frame_flip_bits >> slot & 1;
+	const Edge264Macroblock *mbs = e->slot[slot].mbs;
+	int n_coded = 0;
+	for (int a = 0; a < b->n_mbs; a++) {
+		E264Mb *m = &b->mbs[a];
+		const Edge264Macroblock *M = mbs + a % b->width_mbs + (a / b->width_mbs) * (b->width_mbs + 1);
+		if (m->kind == E264_MB_ABSENT && M->recovery_bits == flip && !M->mbIsInterFlag) {
+			m->kind = E264_MB_PCM;
+			m->qp[0] = M->QP[0]; m->qp[1] = M->QP[1]; m->qp[2] = M->QP[2];
+			m->flags = (uint8_t)((M->filter_edges & 1 ? E264_MBF_EDGE_LEFT : 0) | (M->filter_edges & 2 ? E264_MBF_EDGE_TOP : 0) |
+				(M->filter_edges ? E264_MBF_DEBLOCK : 0));
+			m->nz_mask = 0xffff;
+			m->slice = 0;
+			for (int i = b->n_slices - 1; i >= 0; i--)
+				if (b->slices[i].first_mb <= (uint32_t)a && b->slice_filled[i]) { m->slice = (uint16_t)i; break; }
+			while (b->payload_len & 7)
+				e264_payload_append(b, "\0", 1);
+			m->payload_off = (uint32_t)b->payload_len;
+			int mbx = a % b->width_mbs, mby = a / b->width_mbs;
+			const uint8_t *Y = e->slot[slot].samples + (size_t)(mby * 16) * dec->out.stride_Y + mbx * 16;
+			const uint8_t *C = e->slot[slot].samples + dec->plane_size_Y + (size_t)(mby * 8) * dec->out.stride_C + mbx * 8;
+			for (int y = 0; y < 16; y++) e264_payload_append(b, Y + (size_t)y * dec->out.stride_Y, 16);
+			for (int y = 0; y < 8; y++) e264_payload_append(b, C + (size_t)y * dec->out.stride_C, 8);
+			for (int y = 0; y < 8; y++) e264_payload_append(b, C + (dec->out.stride_C >> 1) + (size_t)y * dec->out.stride_C, 8);
+		}
+		n_coded += m->kind != E264_MB_ABSENT;
+	}
+	if (b->n_slices == 0) { /* cannot happen for a decoded frame; keep the packet well formed */
+		int serial = e->serial;
+		e->serial = -1;
+		e264_slice_index(e, b);
+		e->serial = serial;
+	}
+	/* layout: hdr | slices | mbs | motion (if any inter MB) | payload */
+	uint32_t slices_off = E264_ALIGN16((uint32_t)sizeof(E264FrameHdr));
+	uint32_t mbs_off = E264_ALIGN16(slices_off + (uint32_t)sizeof(E264SliceParams) * (uint32_t)b->n_slices);
+	uint32_t motion_off = E264_ALIGN16(mbs_off + (uint32_t)sizeof(E264Mb) * (uint32_t)b->n_mbs);
+	uint32_t payload_off = E264_ALIGN16(motion_off + (b->n_inter ? (uint32_t)sizeof(E264Motion) * (uint32_t)b->n_mbs : 0));
+	uint32_t payload_bytes = E264_ALIGN16((uint32_t)b->payload_len);
+	size_t total = (size_t)payload_off + payload_bytes;
+	uint8_t *pkt;
+	if (e->sink_kind == 0) pkt = hip.packet_buffer(e->hip_stream, total);
+	else pkt = malloc(total);
+	if (!pkt)
+		return ENOMEM;
+	E264FrameHdr h = {0};
+	h.magic = E264_MAGIC; h.version = E264_VERSION; h.total_bytes = (uint32_t)total;
+	h.width_mbs = (uint16_t)b->width_mbs; h.height_mbs = (uint16_t)b->height_mbs;
+	h.stride_Y = (uint32_t)dec->out.stride_Y; h.stride_C = (uint32_t)dec->out.stride_C;
+	h.plane_size_Y = (uint32_t)dec->plane_size_Y; h.plane_size_C = (uint32_t)dec->plane_size_C;
+	h.n_slices = (uint32_t)b->n_slices; h.slices_off = slices_off; h.mbs_off = mbs_off;
+	h.motion_off = b->n_inter ? motion_off : 0;
+	h.payload_off = payload_off; h.payload_bytes = payload_bytes;
+	h.dst_slot = slot; h.frame_id = b->frame_id;
+	h.n_coded_mbs = (uint32_t)n_coded; h.n_inter_mbs = (uint32_t)b->n_inter;
+	for (int a = 0; a < b->n_mbs; a++)
+		if (b->mbs[a].kind == E264_MB_INTER)
+			for (int i = 0; i < 8; i++)
+				if (b->motion[a].refPic[i] >= 0)
+					h.ref_slots |= 1u << b->motion[a].refPic[i];
+	memset(pkt, 0, payload_off);
+	memcpy(pkt, &h, sizeof(h));
+	memcpy(pkt + slices_off, b->slices, sizeof(E264SliceParams) * (size_t)b->n_slices);
+	memcpy(pkt + mbs_off, b->mbs, sizeof(E264Mb) * (size_t)b->n_mbs);
+	if (b->n_inter)
+		memcpy(pkt + motion_off, b->motion, sizeof(E264Motion) * (size_t)b->n_mbs);
+	memcpy(pkt + payload_off, b->payload, b->payload_len);
+	memset(pkt + payload_off + b->payload_len, 0, payload_bytes - b->payload_len);
+	b->active = 0;
+	if (e->sink_kind == 0)
+		return hip.frame_submit(e->hip_stream, pkt, total);
+	struct E264Captured *c = malloc(sizeof(*c));
+	c->data = pkt; c->bytes = total; c->next = NULL;
+	if (e->cap_tail) e->cap_tail->next = c; else e->cap_head = c;
+	e->cap_tail = c;
+	return 0;
+}
+
+static int e264_close_ready_frames(E264Emitter *e)
+{
+	int ret = 0;
+	for (int s = 0; s < E264_MAX_SLOTS; s++)
+		if (e->fb[s].active && e->dec->next_deblock_addr[s] == INT_MAX) {
+			int r = e264_finish_frame(e, s);
+			if (r) ret = r;
+		}
+	return ret;
+}
+
+/* ---- public API (edge264.h:64-70) ---------------------------------------------------------- */
+PUBLIC const uint8_t *edge264_find_start_code(const uint8_t *buf, const uint8_t *end, int four_byte)
+{
+	return e264ref_find_start_code(buf, end, four_byte);
+}
+
+PUBLIC Edge264Decoder *edge264_alloc(int n_threads, Edge264LogCb log_cb, void *log_arg, int log_mbs,
+	Edge264AllocCb alloc_cb, Edge264FreeCb free_cb, void *alloc_arg)
+{
+	/* frame memory is owned by the back end, parsing is synchronous: caller-provided allocators and
+	 * worker threads do not apply (documented in INTEGRATION.md) */
+	(void)n_threads; (void)alloc_cb; (void)free_cb; (void)alloc_arg; (void)log_mbs;
+	E264Emitter *e = calloc(1, sizeof(*e));
+	if (!e)
+		return NULL;
+	e->sink_kind = g_sink_kind;
+	if (e->sink_kind == 0 && (hip_bind() || hip.stream_open(hip.dev, (E264Stream **)&e->hip_stream))) {
+		free(e);
+		return NULL;
+	}
+	Edge264Decoder *dec = e264ref_alloc(0, log_cb, log_arg, 0, e264_alloc_cb, e264_free_cb, e);
+	if (!dec) {
+		if (e->sink_kind == 0) hip.stream_close(e->hip_stream);
+		free(e);
+		return NULL;
+	}
+	e->dec = dec;
+	return dec;
+}
+
+static E264Emitter *emitter_of(Edge264Decoder *dec) { return dec ? dec->alloc_arg : NULL; }
+
+PUBLIC int edge264_decode_NAL(Edge264Decoder *dec, const uint8_t *buf, const uint8_t *end, Edge264UnrefCb unref_cb, void *unref_arg)
+{
+	E264Emitter *e = emitter_of(dec);
+	if (!e)
+		return EINVAL;
+	e264_tls_emitter = e;
+	e->serial++;
+	int ret = e264ref_decode_NAL(dec, buf, end, unref_cb, unref_arg);
+	int r2 = e264_close_ready_frames(e);
+	e264_tls_emitter = NULL;
+	return ret ? ret : (r2 == ENOMEM ? ENOMEM : 0);
+}
+
+PUBLIC int edge264_get_frame(Edge264Decoder *dec, Edge264Frame *out, int borrow)
+{
+	E264Emitter *e = emitter_of(dec);
+	if (!e)
+		return EINVAL;
+	int ret = e264ref_get_frame(dec, out, borrow);
+	if (ret == 0 && e->sink_kind == 0) {
+		uintptr_t mask = (uintptr_t)out->return_arg;
+		for (int s = 0; s < E264_MAX_SLOTS; s++)
+			if (mask >> s & 1)
+				hip.frame_download(e->hip_stream, s, e->slot[s].samples, e->slot[s].samples_size);
+	}
+	return ret;
+}
+
+PUBLIC void edge264_return_frame(Edge264Decoder *dec, void *return_arg)
+{
+	e264ref_return_frame(dec, return_arg);
+}
+
+PUBLIC void edge264_flush(Edge264Decoder *dec)
+{
+	E264Emitter *e = emitter_of(dec);
+	if (!e)
+		return;
+	e264_tls_emitter = e;
+	e264ref_flush(dec);
+	e264_tls_emitter = NULL;
+	e->cur.valid = 0;
+	for (int s = 0; s < E264_MAX_SLOTS; s++)
+		e->fb[s].active = 0;
+	if (e->sink_kind == 0)
+		hip.stream_flush(e->hip_stream);
+}
+
+PUBLIC void edge264_free(Edge264Decoder **pdec)
+{
+	if (!pdec || !*pdec)
+		return;
+	E264Emitter *e = emitter_of(*pdec);
+	e264_tls_emitter = e;
+	e264ref_free(pdec); /* releases every slot through e264_free_cb */
+	e264_tls_emitter = NULL;
+	if (!e)
+		return;
+	if (e->sink_kind == 0) hip.stream_close(e->hip_stream);
+	for (int s = 0; s < E264_MAX_SLOTS; s++) {
+		free(e->fb[s].mbs); free(e->fb[s].motion); free(e->fb[s].slices); free(e->fb[s].slice_serial);
+		free(e->fb[s].slice_filled); free(e->fb[s].payload);
+	}
+	while (e->cap_head) {
+		struct E264Captured *c = e->cap_head;
+		e->cap_head = c->next;
+		free(c->data);
+		free(c);
+	}
+	free(e);
+}
+
+/* ---- capture sink access (tests, tools) ---------------------------------------------------- */
+/* Pops the oldest captured packet; the caller owns *data (free with e264front_free_packet). */
+PUBLIC int e264front_take_packet(Edge264Decoder *dec, void **data, size_t *bytes)
+{
+	E264Emitter *e = emitter_of(dec);
+	if (!e || !e->cap_head)
+		return ENOMSG;
+	struct E264Captured *c = e->cap_head;
+	e->cap_head = c->next;
+	if (!e->cap_head) e->cap_tail = NULL;
+	*data = c->data;
+	*bytes = c->bytes;
+	free(c);
+	return 0;
+}
+
+PUBLIC void e264front_free_packet(void *data) { free(data); }
