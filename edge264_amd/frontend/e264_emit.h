@@ -45,6 +45,7 @@ typedef struct { /* macroblock being assembled: leaf calls arrive in decoding or
 	int kind, chroma_mode, i16_mode, t8;
 	uint8_t modes[16];
 	uint32_t coded;
+	int serial; /* NAL serial of the slice that staged this macroblock */
 	int16_t luma_dc[16], chroma_dc[8];
 	int16_t luma[16][16];   /* 4x4 blocks, or 4 x 64 coefficients of 8x8 blocks (flat view) */
 	int16_t chroma[8][16];
@@ -236,14 +237,17 @@ static void e264_flush_mb(E264Emitter *e)
 static E264MbStage *e264_touch(E264Emitter *e, int slot, int addr)
 {
 	E264MbStage *c = &e->cur;
-	if (c->valid && c->slot == slot && c->addr == addr)
+	if (c->valid && c->slot == slot && c->addr == addr && c->serial == e->serial)
 		return c;
+	if (c->valid && c->slot == slot && c->addr == addr)
+		c->valid = 0; /* the same macroblock decoded again by a later NAL (a slice that failed and is resent): start over */
 	e264_flush_mb(e);
 	E264FrameBuilder *b = e264_builder(e, slot);
 	memset(c, 0, offsetof(E264MbStage, luma_dc));
 	c->valid = 1;
 	c->slot = slot;
 	c->addr = addr;
+	c->serial = e->serial;
 	c->slice = e264_slice_index(e, b);
 	c->kind = E264_MB_ABSENT;
 	int mbx = addr % b->width_mbs, mby = addr / b->width_mbs;

@@ -141,7 +141,10 @@ class Edge264Lib:
             res = L.edge264_decode_NAL(dec, nal, nxt, None, None)
             codes.append(res)
             if res == errno.ENOBUFS:
+                n0 = len(frames)
                 drain()
+                if len(frames) == n0:  # nothing can be output: the stream is stuck (reference behaviour), give up
+                    break
                 continue
             drain()
             if res == errno.ENODATA or nal >= end:
@@ -191,3 +194,77 @@ def oracle_chroma_mc(o: Oracle, ref: np.ndarray, stride: int, w: int, h: int, x:
     dst = np.zeros((bh, bw), np.uint8)
     o.lib.e264o_chroma_mc(_u8p(ref), stride, w, h, x, y, mvx, mvy, bw, bh, _u8p(dst), bw)
     return dst
+
+
+class HipFront(Edge264Lib):
+    """oracle/_ref/libedge264_hipfront.so: the reference's front end (parsers, DPB, reference lists,
+    compiled from /root/reference) bound to edge264_amd/frontend's packet emitters behind the edge264.h
+    API.  sink 1 = capture (packets handed back, replayed here by the oracle: CPU test of the boundary);
+    sink 0 = libedge264_hip.so (GPU)."""
+
+    def __init__(self, path: str | None = None):
+        super().__init__(path or os.path.join(HERE, "_ref", "libedge264_hipfront.so"))
+        L = self.lib
+        L.e264front_set_sink.argtypes = [C.c_int]
+        L.e264front_take_packet.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.e264front_take_packet.restype = C.c_int
+        L.e264front_free_packet.argtypes = [C.c_void_p]
+
+    def decode_capture(self, stream: bytes, oracle: "Oracle"):
+        """Returns (frames, codes, packets): frames as the HIP sink would return them, with the
+        oracle standing in for the GPU (same slot bookkeeping as edge264_get_frame in the shim)."""
+        import errno
+        from edge264_amd import packet as P
+        L = self.lib
+        L.e264front_set_sink(1)
+        buf = np.frombuffer(stream + b"\0" * 64, np.uint8).copy()
+        base = buf.ctypes.data
+        end = base + len(stream)
+        dec = C.c_void_p(L.edge264_alloc(0, None, None, 0, None, None, None))
+        if not dec:
+            raise MemoryError("edge264_alloc")
+        frames, codes, packets = [], [], []
+        dpb = [None] * 32
+        out = Edge264Frame()
+        geom = {}
+
+        def pump():
+            data, n = C.c_void_p(), C.c_size_t()
+            while L.e264front_take_packet(dec, C.byref(data), C.byref(n)) == 0:
+                pkt = C.string_at(data, n.value)
+                L.e264front_free_packet(data)
+                packets.append(pkt)
+                pk = P.Packet(pkt)
+                h = pk.hdr
+                nb = int(h["plane_size_Y"]) + int(h["plane_size_C"])
+                geom.update(stride_Y=int(h["stride_Y"]), stride_C=int(h["stride_C"]), psY=int(h["plane_size_Y"]))
+                for s in range(32):
+                    if dpb[s] is None and (s == int(h["dst_slot"]) or int(h["ref_slots"]) >> s & 1):
+                        dpb[s] = np.zeros(nb + 64, np.uint8)  # like the HIP sink (frame_fill 0) and a fresh mmap in the reference
+                oracle.decode_frame(pkt, dpb, 3)
+            while L.edge264_get_frame(dec, C.byref(out), 0) == 0:
+                mask = out.return_arg or 0
+                slot = [s for s in range(32) if mask >> s & 1][0]
+                d, sy, sc = dpb[slot], geom["stride_Y"], geom["stride_C"]
+                y = d[:out.height_Y * sy].reshape(out.height_Y, sy)[:, :out.width_Y].copy()
+                c = d[geom["psY"]:geom["psY"] + out.height_C * sc].reshape(out.height_C, sc)
+                frames.append((y, c[:, :out.width_C].copy(), c[:, sc // 2:sc // 2 + out.width_C].copy()))
+
+        nal = L.edge264_find_start_code(base, end, 0)
+        nal = (nal or end) + 3 if (nal or end) < end else end
+        while True:
+            nxt = L.edge264_find_start_code(nal, end, 0) if nal < end else end
+            res = L.edge264_decode_NAL(dec, nal, nxt, None, None)
+            codes.append(res)
+            n0 = len(frames)
+            pump()
+            if res == errno.ENOBUFS:
+                if len(frames) == n0:
+                    break
+                continue
+            if res == errno.ENODATA or nal >= end:
+                break
+            nal = min(nxt + 3, end)
+        pump()
+        L.edge264_free(C.byref(dec))
+        return frames, codes, packets
