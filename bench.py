@@ -11,12 +11,18 @@ Streams are independent, so N GPUs = N x the same per-GPU work (weak scaling), n
 on the data path; torch.distributed (RCCL) is used only for the barrier and the max-over-ranks
 of the elapsed time.
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch
-(frame written once + reference samples read once per prediction direction
-used + command bytes consumed) / average duration of e264_frame_kernel measured with HIP
-events on the back end's own queue.  `cpu_baseline` = the reference's own SIMD kernels
-(oracle/_ref/libe264_refkernels.so, compiled from /root/reference) replaying the same packets
-on one host core for a bounded sample.
+Prints ONE JSON line (rank 0).  One submission of a batch (= one frame of every stream) is three
+kernel launches on the back end's queue: e264_mbpar_kernel (bS/alpha/beta + inter prediction +
+residual, macroblock-parallel), e264_intra_kernel (intra wavefront) and e264_deblock_kernel
+(deblocking wavefront).  `roofline.achieved` = algorithmic bytes of one submission (SURVEY.md
+8(d): frame written once + reference samples read once per prediction direction used + command
+bytes consumed, summed over the streams of the batch) / average duration of the DOMINANT of the
+three kernels, measured live with HIP events recorded on the back end's own queue around each
+launch.  `roofline.traffic` = HBM bytes per launch of that kernel from the PMC passes committed
+under profiles/ (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), when a summary for this exact
+configuration exists, else null.  `cpu_baseline` = the reference's own SIMD kernels
+(oracle/_ref/libe264_refkernels.so, compiled from /root/reference) replaying the same packets on
+one host core for a bounded sample.
 """
 import argparse
 import json
@@ -49,9 +55,8 @@ def main() -> int:
     ap.add_argument("--debug-mode", type=int, default=0, help="profiling ablation bits (results are then wrong on purpose)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
+    from edge264_amd.sharding import rank_info, reduce_elapsed, shard_streams
+    rank, local_rank, world = rank_info()
     import torch
     dist = None
     if world > 1:
@@ -120,11 +125,13 @@ def main() -> int:
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # weak scaling: rank r owns streams shard_streams(streams * world, r, world) (= `streams` of them)
+    my_frames = len(shard_streams(args.streams * world, rank, world)) * len(packets) * args.steps
     if dist is not None:
-        t = torch.tensor([elapsed], device=f"cuda:{local_rank}")
         dist.barrier()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, total_frames = reduce_elapsed(elapsed, my_frames, dist, torch.device("cuda", local_rank))
+    else:
+        total_frames = my_frames
     kernel_ms3, launches = [0.0, 0.0, 0.0], 0
     for dv in devs:
         k3, n = dv.kernel_time_ms()
@@ -134,8 +141,8 @@ def main() -> int:
     kernel_ms = sum(kernel_ms3)
     ev_ms = dev.event_elapsed_ms(0, 1)
 
-    frames_per_step = len(packets) * args.streams * world
-    value = frames_per_step * args.steps / elapsed
+    frames_per_step = total_frames // args.steps
+    value = total_frames / elapsed
 
     # ---- bit-exactness at full size (untimed): stream 0's last frame vs the CPU oracle ----
     bit_exact = None
@@ -190,6 +197,16 @@ def main() -> int:
         # the dominant kernel is priced against ALL of them (a conservative fraction of the roofline)
         avg_launch_s = kernel_ms3[dom] / 1e3 / max(launches, 1)
         achieved = per_launch_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            cfg = tj.get("config", {})
+            if (cfg.get("streams"), cfg.get("gop"), cfg.get("width_mbs"), cfg.get("height_mbs")) == (args.streams, args.gop, W, H):
+                k = tj["kernels"].get(names[dom])
+                if k:
+                    traffic = int(k["hbm_bytes_per_launch"])
         out = {
             "metric": "1080p frames/s/GPU (bit-exact YUV) + achieved HBM GB/s vs 8 TB/s peak",
             "value": round(value, 1), "unit": "frames/s",
@@ -203,7 +220,7 @@ def main() -> int:
                        "streams_per_gpu": args.streams, "queues": nq, "frames_per_step": frames_per_step,
                        "waves_per_frame": args.waves, "parallelism": f"stream-parallel x{world}, no collectives"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": names[dom], "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
                          "kernel_ms_per_launch": {n: round(t / max(launches, 1), 4) for n, t in zip(names, kernel_ms3)},
                          "algorithmic_bytes_per_launch": int(per_launch_bytes)},

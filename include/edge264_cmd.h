@@ -159,6 +159,17 @@ static inline uint32_t e264_mb_payload_bytes(const E264Mb *m)
 	return n;
 }
 
+/* the layout is an ABI shared by C (front end), HIP (back end) and numpy (edge264_amd/packet.py) */
+#ifdef __cplusplus
+#define E264_SIZE_CHECK(c, m) static_assert(c, m)
+#else
+#define E264_SIZE_CHECK(c, m) _Static_assert(c, m)
+#endif
+E264_SIZE_CHECK(sizeof(E264FrameHdr) == 80, "E264FrameHdr");
+E264_SIZE_CHECK(sizeof(E264SliceParams) == 2112, "E264SliceParams");
+E264_SIZE_CHECK(sizeof(E264Mb) == 32, "E264Mb");
+E264_SIZE_CHECK(sizeof(E264Motion) == 144, "E264Motion");
+
 #ifdef __cplusplus
 }
 #endif
