@@ -11,13 +11,13 @@ Streams are independent, so N GPUs = N x the same per-GPU work (weak scaling), n
 on the data path; torch.distributed (RCCL) is used only for the barrier and the max-over-ranks
 of the elapsed time.
 
-Prints ONE JSON line (rank 0).  One submission of a batch (= one frame of every stream) is three
-kernel launches on the back end's queue: e264_mbpar_kernel (bS/alpha/beta + inter prediction +
+Prints ONE JSON line (rank 0).  One submission of a batch (= one frame of every stream) is four
+kernel launches on the back end's queue: e264_dbkparam_kernel (bS/alpha/beta), e264_mbpar_kernel (inter prediction +
 residual, macroblock-parallel), e264_intra_kernel (intra wavefront) and e264_deblock_kernel
 (deblocking wavefront).  `roofline.achieved` = algorithmic bytes of one submission (SURVEY.md
 8(d): frame written once + reference samples read once per prediction direction used + command
 bytes consumed, summed over the streams of the batch) / average duration of the DOMINANT of the
-three kernels, measured live with HIP events recorded on the back end's own queue around each
+four kernels, measured live with HIP events recorded on the back end's own queue around each
 launch.  `roofline.traffic` = HBM bytes per launch of that kernel from the PMC passes committed
 under profiles/ (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), when a summary for this exact
 configuration exists, else null.  `cpu_baseline` = the reference's own SIMD kernels
@@ -132,7 +132,7 @@ def main() -> int:
         elapsed, total_frames = reduce_elapsed(elapsed, my_frames, dist, torch.device("cuda", local_rank))
     else:
         total_frames = my_frames
-    kernel_ms3, launches = [0.0, 0.0, 0.0], 0
+    kernel_ms3, launches = [0.0, 0.0, 0.0, 0.0], 0
     for dv in devs:
         k3, n = dv.kernel_time_ms()
         kernel_ms3 = [a + b for a, b in zip(kernel_ms3, k3)]
@@ -191,9 +191,9 @@ def main() -> int:
 
     if rank == 0:
         per_launch_bytes = float(np.mean(alg_bytes)) * args.streams / nq
-        names = ["e264_mbpar_kernel", "e264_intra_kernel", "e264_deblock_kernel"]
+        names = ["e264_dbkparam_kernel", "e264_mbpar_kernel", "e264_intra_kernel", "e264_deblock_kernel"]
         dom = int(np.argmax(kernel_ms3))
-        # the three kernels of one submission together move the algorithmic bytes of the batch once;
+        # the four kernels of one submission together move the algorithmic bytes of the batch once;
         # the dominant kernel is priced against ALL of them (a conservative fraction of the roofline)
         avg_launch_s = kernel_ms3[dom] / 1e3 / max(launches, 1)
         achieved = per_launch_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0

@@ -143,7 +143,7 @@ class Device:
         _check(self.L, self.L.e264hip_kernel_timing(self.h, int(enable)), "kernel_timing")
 
     def kernel_time_ms(self):
-        t, n = (C.c_double * 3)(), C.c_int()
+        t, n = (C.c_double * 4)(), C.c_int()
         _check(self.L, self.L.e264hip_kernel_time_ms(self.h, t, C.byref(n)), "kernel_time")
         return [float(x) for x in t], int(n.value)
 

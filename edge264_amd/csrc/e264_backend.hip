@@ -44,7 +44,7 @@ struct E264Device {
 	hipEvent_t ev[16];
 	// per-launch kernel timing
 	bool ktiming;
-	struct Marks { hipEvent_t e[4]; };
+	struct Marks { hipEvent_t e[5]; };
 	std::vector<Marks> kev;
 	size_t kev_used;
 };
@@ -257,7 +257,7 @@ static int launch(E264Device *dev, const E264Job *d_jobs, int n, int max_mbs, in
 	if (dev->ktiming) {
 		if (dev->kev_used == dev->kev.size()) {
 			E264Device::Marks m;
-			for (int i = 0; i < 4; i++) hipEventCreate(&m.e[i]);
+			for (int i = 0; i < 5; i++) hipEventCreate(&m.e[i]);
 			dev->kev.push_back(m);
 		}
 		marks = dev->kev[dev->kev_used++].e;
@@ -441,16 +441,16 @@ API int e264hip_kernel_timing(E264Device *dev, int enable)
 	return 0;
 }
 
-API int e264hip_kernel_time_ms(E264Device *dev, double *ms3, int *launches)
+API int e264hip_kernel_time_ms(E264Device *dev, double *ms4, int *launches)
 {
-	if (!dev || !ms3) return fail(EINVAL, "null argument");
+	if (!dev || !ms4) return fail(EINVAL, "null argument");
 	int r = e264hip_device_sync(dev);
 	if (r) return r;
-	ms3[0] = ms3[1] = ms3[2] = 0;
+	ms4[0] = ms4[1] = ms4[2] = ms4[3] = 0;
 	for (size_t i = 0; i < dev->kev_used; i++)
-		for (int k = 0; k < 3; k++) {
+		for (int k = 0; k < 4; k++) {
 			float ms = 0;
-			if (hipEventElapsedTime(&ms, dev->kev[i].e[k], dev->kev[i].e[k + 1]) == hipSuccess) ms3[k] += ms;
+			if (hipEventElapsedTime(&ms, dev->kev[i].e[k], dev->kev[i].e[k + 1]) == hipSuccess) ms4[k] += ms;
 		}
 	if (launches) *launches = (int)dev->kev_used;
 	return 0;

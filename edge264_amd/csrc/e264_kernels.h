@@ -14,7 +14,7 @@ struct E264Job {
 #define E264_DBK_BYTES 64
 
 // mode: bit0 reconstruction, bit1 deblocking.  waves: 4, 8 or 16 macroblock rows in flight per frame.
-// max_mbs: largest macroblock count among the jobs.  marks: NULL or 4 events (kernel boundaries).
+// max_mbs: largest macroblock count among the jobs.  marks: NULL or 5 events (boundaries of the 4 kernels).
 extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int max_mbs, int mode, int waves, hipStream_t stream, hipEvent_t *marks);
 
 #endif

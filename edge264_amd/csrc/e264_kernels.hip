@@ -1384,6 +1384,21 @@ __device__ __forceinline__ bool open_frame(FrameCtx &f, const E264Job &job)
 #define E264_MBPAR_STRIP 8
 } // namespace
 
+// XCD-aware workgroup order.  The dispatcher places linear workgroup b on XCD b % 8, each with a private
+// 4 MiB L2; in launch order the strips that share reference rows (vertical neighbours of one frame,
+// 15 strips = 4 workgroups apart) land on different XCDs and every one of them fetches the shared
+// halo lines from HBM again.  This bijective remap gives each XCD a contiguous range of (frame, strip)
+// pairs, so a frame is walked by ONE XCD and the halo rows are L2 hits.  Pure speed choice.
+static __device__ __forceinline__ void xcd_tile(int &bx, int &by)
+{
+	const unsigned gx = gridDim.x, nwg = gx * gridDim.y;
+	const unsigned lin = blockIdx.y * gx + blockIdx.x;
+	const unsigned q = nwg >> 3, r = nwg & 7, xcd = lin & 7;
+	const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+	by = (int)(v / gx);
+	bx = (int)(v - (unsigned)by * gx);
+}
+
 // every macroblock of every frame in parallel: 4 waves per workgroup, a strip of E264_MBPAR_STRIP
 // consecutive macroblocks per wave, software pipelined (see "Inter prediction" above)
 __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, int mode)
@@ -1393,7 +1408,9 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 	const int lane = lane_id();
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	FrameCtx f;
-	if (!open_frame(f, jobs[blockIdx.y]))
+	int bx, by;
+	xcd_tile(bx, by);
+	if (!open_frame(f, jobs[by]))
 		return;
 	if (threadIdx.x < E264_MAX_SLOTS)
 		dpbtab[threadIdx.x] = f.dpb[threadIdx.x];
@@ -1401,7 +1418,7 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 	f.dpb_lds = dpbtab;
 	f.dbg = mode;
 	const int n_mbs = f.wm * f.hm;
-	const int base = ((int)blockIdx.x * 4 + wave) * E264_MBPAR_STRIP;
+	const int base = (bx * 4 + wave) * E264_MBPAR_STRIP;
 	const int n = min(E264_MBPAR_STRIP, n_mbs - base);
 	if (n <= 0)
 		return;
@@ -1442,12 +1459,14 @@ __global__ __launch_bounds__(256) void e264_dbkparam_kernel(const E264Job *jobs)
 	const int lane = lane_id();
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	FrameCtx f;
-	if (!open_frame(f, jobs[blockIdx.y]) || !f.dbk)
+	int bx, by;
+	xcd_tile(bx, by);
+	if (!open_frame(f, jobs[by]) || !f.dbk)
 		return;
 	const int n_mbs = f.wm * f.hm;
 #pragma unroll 1
 	for (int i = 0; i < 4; i++) {
-		const int addr = ((int)blockIdx.x * 4 + wave) * 4 + i;
+		const int addr = (bx * 4 + wave) * 4 + i;
 		if (addr >= n_mbs)
 			return;
 		const int mby = addr / f.wm, mbx = addr - mby * f.wm;
@@ -1566,12 +1585,13 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 {
 	if (n_jobs <= 0)
 		return hipSuccess;
-	// marks (optional): 4 events recorded before / between / after the three launches
+	// marks (optional): 5 events recorded before / between / after the four launches
 	if (marks) hipEventRecord(marks[0], stream);
 	if ((mode & 2) && !(mode & 2048))
 		hipLaunchKernelGGL(e264_dbkparam_kernel, dim3((max_mbs + 15) / 16, n_jobs), dim3(256), 0, stream, jobs);
-	hipLaunchKernelGGL(e264_mbpar_kernel, dim3((max_mbs + 4 * E264_MBPAR_STRIP - 1) / (4 * E264_MBPAR_STRIP), n_jobs), dim3(256), 0, stream, jobs, mode);
 	if (marks) hipEventRecord(marks[1], stream);
+	hipLaunchKernelGGL(e264_mbpar_kernel, dim3((max_mbs + 4 * E264_MBPAR_STRIP - 1) / (4 * E264_MBPAR_STRIP), n_jobs), dim3(256), 0, stream, jobs, mode);
+	if (marks) hipEventRecord(marks[2], stream);
 	if (mode & 1) {
 		switch (waves) {
 		case 4: hipLaunchKernelGGL(e264_intra_kernel<4>, dim3(n_jobs), dim3(256), 0, stream, jobs); break;
@@ -1579,7 +1599,7 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 		default: hipLaunchKernelGGL(e264_intra_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs); break;
 		}
 	}
-	if (marks) hipEventRecord(marks[2], stream);
+	if (marks) hipEventRecord(marks[3], stream);
 	if (mode & 2) {
 		switch (waves) {
 		case 4: hipLaunchKernelGGL(e264_deblock_kernel<4>, dim3(n_jobs), dim3(256), 0, stream, jobs); break;
@@ -1587,6 +1607,6 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 		default: hipLaunchKernelGGL(e264_deblock_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs); break;
 		}
 	}
-	if (marks) hipEventRecord(marks[3], stream);
+	if (marks) hipEventRecord(marks[4], stream);
 	return hipGetLastError();
 }

@@ -92,11 +92,11 @@ void e264hip_batch_free(E264Batch *b);
  * torch's own stream).  Slots 0..15. */
 int  e264hip_event_record(E264Device *dev, int idx);
 int  e264hip_event_elapsed_ms(E264Device *dev, int idx_start, int idx_stop, float *ms);
-/* Accumulated time of each of the three kernels of a submission (ms3[0] parallel MB kernel,
- * ms3[1] intra wavefront, ms3[2] deblocking wavefront), measured with events recorded on the
- * queue between the launches (only when enabled). */
+/* Accumulated time of each of the four kernels of a submission (ms4[0] deblock-parameter kernel,
+ * ms4[1] parallel MB kernel, ms4[2] intra wavefront, ms4[3] deblocking wavefront), measured with
+ * events recorded on the queue between the launches (only when enabled). */
 int  e264hip_kernel_timing(E264Device *dev, int enable);
-int  e264hip_kernel_time_ms(E264Device *dev, double *ms3, int *launches);
+int  e264hip_kernel_time_ms(E264Device *dev, double *ms4, int *launches);
 
 /* Tunables (waves per frame workgroup etc.); returns the previous value, -1 if unknown. */
 int  e264hip_set_option(E264Device *dev, const char *name, int value);
