@@ -15,7 +15,7 @@ import numpy as np
 from . import packet as P
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libedge264_hip.so")
+LIB_PATH = os.environ.get("E264_HIP_LIB") or os.path.join(HERE, "libedge264_hip.so")  # E264_HIP_LIB: A/B builds (csrc/Makefile `variant`)
 RUN_RECON, RUN_DEBLOCK, RUN_ALL = 1, 2, 3
 
 _lib = None

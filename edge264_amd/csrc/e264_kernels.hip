@@ -33,9 +33,18 @@ __device__ __forceinline__ int clip3i(int lo, int hi, int v) { return min(max(v,
 __device__ __forceinline__ int clip255(int v) { return min(max(v, 0), 255); }
 __device__ __forceinline__ int sat16(int v) { return min(max(v, -32768), 32767); }
 __device__ __forceinline__ int w16(int v) { return (int)(int16_t)v; }
+// build-time experiment switches (tools/ab_variants.sh builds one library per setting)
+#ifndef E264_LUMA_SKIP
+#define E264_LUMA_SKIP 0 // 1: wave-uniform tap skipping also for macroblocks with several vectors (measured slower: +27% SALU)
+#endif
 typedef uint8_t __attribute__((address_space(1))) gu8;   // global memory, so that loads/stores are global_* not flat_*
 typedef uint32_t __attribute__((address_space(1))) gu32;
 typedef uint16_t __attribute__((address_space(1))) gu16;
+typedef uint32_t __attribute__((address_space(1), aligned(1))) gu32u;
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef v4u __attribute__((address_space(1), aligned(4))) gv4u; // dword-aligned is all the strides guarantee (stride_C/2 of a 4096-wide frame)
+typedef v2u __attribute__((address_space(1), aligned(4))) gv2u; // unaligned dword (global memory allows it on gfx9+)
 typedef int16_t __attribute__((address_space(1))) gi16;
 // the command packet is read-only for every kernel: constant address space => uniform reads become
 // scalar loads (s_load) and the values live in SGPRs
@@ -116,6 +125,18 @@ struct __attribute__((aligned(16))) WaveLds { // reconstruction scratch of one w
 	uint32_t win[432];         // reference windows of inter prediction (one list at a time): 1 x 21x24, 4 x 13x16 or 16 x 9x12 bytes
 };
 
+// Output staging of one strip of the macroblock-parallel kernel: the samples of its (up to) 8
+// macroblocks are collected here and written at the end of the strip as 16-byte pieces ordered so
+// that 8 consecutive lanes cover 128 contiguous bytes of a luma row (64 of a chroma row).  Storing
+// each macroblock as it is produced (64 lanes x 4 bytes = sixteen 16-byte row pieces) left every
+// 64-byte segment partially written several times: 3.6x the algorithmic write traffic at the L2
+// memory side (TCC_EA0_WRREQ, profiles/r01_pmc_calibration.txt).
+#define E264_MBPAR_STRIP 8
+struct __attribute__((aligned(16))) StripOut {
+	uint32_t y[E264_MBPAR_STRIP][64];  // [mb][row * 4 + dword]
+	uint32_t c[E264_MBPAR_STRIP][32];  // [mb][plane * 16 + row * 2 + dword]
+};
+
 #define DBK_RING 8 // macroblocks of bottom rows each row keeps in LDS for the row below
 #define DBK_LAG 3  // the second row of a wave trails the first by this many macroblocks
 struct __attribute__((aligned(16))) DbkTile {
@@ -129,9 +150,22 @@ struct __attribute__((aligned(16))) DbkRing {
 	uint32_t y[4][DBK_RING * 4];      // [row 12..15][mb slot * 4 + dword]
 	uint32_t c[2][2][DBK_RING * 2];   // [plane][row 6..7][mb slot * 2 + dword]
 };
+// Samples that have become FINAL, collected per group of 4 macroblocks and written as whole 64-byte row
+// pieces (16 bytes per lane, 4 consecutive lanes per row).  Writing every macroblock as it is filtered (16-byte
+// rows, then its top rows and left columns again one step later) cost 5.7x the frame size in partial
+// 32/64-byte memory-side write requests (TCC_EA0_WRREQ, profiles/r01_pmc_calibration.txt).
+// What is final after macroblock x of a row: the rows above it (-4..-1, filtered by its top edge) over its 16
+// columns, and its rows 0..11 over columns -4..11 (the left neighbour's last 4 columns now have their right
+// edge filtered).  Rows 12..15 belong to the row below, except where that row cannot take them from the
+// LDS ring (last row of the frame; last row of a round, handed to wave 0 through memory).
+struct __attribute__((aligned(16))) DbkStage {
+	uint32_t y[20][16];    // luma rows -4..15 (index row + 4) x 64 columns
+	uint32_t c[2][10][8];  // chroma planes, rows -2..7 (index row + 2) x 32 columns
+};
 struct __attribute__((aligned(16))) DbkLds { // deblocking scratch of one wave = two macroblock rows
 	DbkTile tile[2];     // [half-wave]
 	DbkRing ring[2][2];  // [parity of the row-pair round][half-wave]
+	DbkStage stage[2];   // [half-wave]
 };
 
 struct FrameCtx {
@@ -466,34 +500,58 @@ __device__ __forceinline__ int avg2(int a, int b) { return (a + b + 1) >> 1; }
 // that the lanes of a wave (which may hold 16 different vectors) never diverge.  d[r][0..2] hold the 9
 // samples x-2..x+6 of row y-2+r (already byte-aligned).  Every lane forms the horizontal taps of the
 // 6 rows and the vertical taps of the 9 columns, then selects.
+// UNIFORM: the whole macroblock has one vector (16x16 / skip), so (xF,yF) are wave-uniform and only the taps
+// that position needs are computed; otherwise every lane forms everything and selects.
+template <bool UNIFORM>
 __device__ __forceinline__ void luma_from_rows(const uint32_t d[6][3], int xF, int yF, int out[4])
 {
 	int Hc[6][4], V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, G[4] = {0, 0, 0, 0};
 	const int cw[6] = {1, -5, 20, 20, -5, 1};
 	const int grow = yF == 3 ? 3 : 2;
-#pragma unroll
-	for (int r = 0; r < 6; r++) {
-		int px[9];
-		px[0] = d[r][0] & 255; px[1] = d[r][0] >> 8 & 255; px[2] = d[r][0] >> 16 & 255; px[3] = d[r][0] >> 24;
-		px[4] = d[r][1] & 255; px[5] = d[r][1] >> 8 & 255; px[6] = d[r][1] >> 16 & 255; px[7] = d[r][1] >> 24;
-		px[8] = d[r][2] & 255;
-#pragma unroll
-		for (int i = 0; i < 4; i++)
-			Hc[r][i] = tap6(px[i], px[i + 1], px[i + 2], px[i + 3], px[i + 4], px[i + 5]);
-#pragma unroll
-		for (int c = 0; c < 9; c++)
-			V[c] += cw[r] * px[c];
-		if (r == 2 || r == 3) {
-#pragma unroll
-			for (int i = 0; i < 4; i++)
-				G[i] = (r == grow) ? (xF == 3 ? px[i + 3] : px[i + 2]) : G[i];
-		}
-	}
 	const bool xo = xF & 1, yo = yF & 1;
 	const bool uses_j = (xF == 2 && yF != 0) || (yF == 2 && xF != 0);
 	const bool uses_G = (xF == 0 || yF == 0) && (xo || yo || (xF | yF) == 0);
 	const bool uses_b = (yF == 0 && xF != 0) || (xo && yo) || (xF == 2 && yo);
 	const bool uses_h = (xF == 0 && yF != 0) || (xo && yo) || (yF == 2 && xo);
+	// WAVE-UNIFORM work selection: a macroblock with one vector (the common case) only pays for the
+	// taps its fractional position needs; a wave with mixed vectors pays for the union.
+	bool nJH = true, nJV = true, nHmid = true, nVmid = true;
+	if (UNIFORM || E264_LUMA_SKIP) {
+		nJH = __any(uses_j && xF == 2);      // centre from the horizontal taps of 6 rows
+		nJV = __any(uses_j && xF != 2);      // centre from the vertical taps of 9 columns
+		nHmid = __any(uses_b) || nJH;        // horizontal taps of rows 2,3
+		nVmid = __any(uses_h) || nJV;        // vertical taps of columns 2..6
+	}
+#pragma unroll
+	for (int r = 0; r < 6; r++) {
+		const bool mid = r == 2 || r == 3;
+#pragma unroll
+		for (int i = 0; i < 4; i++) Hc[r][i] = 0;
+		if (mid || nVmid || nJH) {
+			int px[9];
+			px[0] = d[r][0] & 255; px[1] = d[r][0] >> 8 & 255; px[2] = d[r][0] >> 16 & 255; px[3] = d[r][0] >> 24;
+			px[4] = d[r][1] & 255; px[5] = d[r][1] >> 8 & 255; px[6] = d[r][1] >> 16 & 255; px[7] = d[r][1] >> 24;
+			px[8] = d[r][2] & 255;
+			if (mid ? nHmid : nJH) {
+#pragma unroll
+				for (int i = 0; i < 4; i++)
+					Hc[r][i] = tap6(px[i], px[i + 1], px[i + 2], px[i + 3], px[i + 4], px[i + 5]);
+			}
+			if (nVmid) {
+#pragma unroll
+				for (int c = 2; c < 7; c++)
+					V[c] += cw[r] * px[c];
+				if (nJV) {
+					V[0] += cw[r] * px[0]; V[1] += cw[r] * px[1]; V[7] += cw[r] * px[7]; V[8] += cw[r] * px[8];
+				}
+			}
+			if (mid) {
+#pragma unroll
+				for (int i = 0; i < 4; i++)
+					G[i] = (r == grow) ? (xF == 3 ? px[i + 3] : px[i + 2]) : G[i];
+			}
+		}
+	}
 #pragma unroll
 	for (int i = 0; i < 4; i++) {
 		int hsel = yF == 3 ? Hc[3][i] : Hc[2][i];
@@ -501,8 +559,10 @@ __device__ __forceinline__ void luma_from_rows(const uint32_t d[6][3], int xF, i
 		int b = clip255((hsel + 16) >> 5), h = clip255((vsel + 16) >> 5);
 		// centre: horizontal-then-vertical when xF == 2 (inter.c:611-646, 779-802, 929-966), vertical-then-horizontal
 		// otherwise (inter.c:559-609, 741-777, 887-927); 16-bit intermediates wrap as in the reference
-		int j = centre6(xF == 2 ? Hc[0][i] : V[i], xF == 2 ? Hc[1][i] : V[i + 1], xF == 2 ? Hc[2][i] : V[i + 2],
-			xF == 2 ? Hc[3][i] : V[i + 3], xF == 2 ? Hc[4][i] : V[i + 4], xF == 2 ? Hc[5][i] : V[i + 5]);
+		int j = 0;
+		if (nJH || nJV)
+			j = centre6(xF == 2 ? Hc[0][i] : V[i], xF == 2 ? Hc[1][i] : V[i + 1], xF == 2 ? Hc[2][i] : V[i + 2],
+				xF == 2 ? Hc[3][i] : V[i + 3], xF == 2 ? Hc[4][i] : V[i + 4], xF == 2 ? Hc[5][i] : V[i + 5]);
 		int op1 = uses_j ? j : uses_G ? G[i] : uses_b ? b : h;
 		int op2 = uses_h ? h : uses_b ? b : uses_j ? j : G[i];
 		out[i] = avg2(op1, op2);
@@ -522,9 +582,11 @@ __device__ __forceinline__ void luma_from_rows(const uint32_t d[6][3], int xF, i
 struct McMotion {
 	uint32_t refs[4];        // refPic L0, refPic L1, refIdx L0, refIdx L1 (4 x int8 each, per 8x8 block)
 	uint32_t mvY[2], mvC[2]; // packed (x | y<<16) vectors of this lane's luma block and chroma block, per list
+	int S;                   // wave-uniform: window granularity of list 0 (bits 0..7) and list 1 (bits 8..15): 16, 8 or 4
 };
 struct McWindows {          // reference samples of ONE list
-	uint32_t y[7];           // luma window dwords fetched by this lane
+	uint32_t y0, y1, y2, y3; // luma window dwords fetched ahead by this lane (iterations 0..3; 4x4 windows fetch 4..6 late)
+	                         // (scalars, not an array: the array form ended up in scratch memory)
 	int c[6];                // chroma samples (x..x+2, y..y+1) of this lane
 };
 __device__ __forceinline__ int ref_byte(uint32_t w, int b8) { return (int)(int8_t)(w >> (8 * b8)); }
@@ -532,12 +594,27 @@ __device__ __forceinline__ int ref_byte(uint32_t w, int b8) { return (int)(int8_
 __device__ __forceinline__ void mc_load_motion(const FrameCtx &f, int addr, int lane, McMotion &M)
 {
 	const int k = lane >> 2, kc = blk_of((lane & 3), ((lane >> 2) & 7) >> 1);
+	M.S = 16 | 16 << 8;
 	if (!f.motion) { M.refs[0] = M.refs[1] = M.refs[2] = M.refs[3] = 0xffffffffu; M.mvY[0] = M.mvY[1] = M.mvC[0] = M.mvC[1] = 0; return; }
 	gmotion_t mo = f.motion + addr;
 	const uint32_t __attribute__((address_space(4))) *rp = (const uint32_t __attribute__((address_space(4))) *)mo;
 	M.refs[0] = rp[0]; M.refs[1] = rp[1]; M.refs[2] = rp[2]; M.refs[3] = rp[3];
 	M.mvY[0] = *(const gu32 *)&mo->mvs[k * 2]; M.mvY[1] = *(const gu32 *)&mo->mvs[32 + k * 2];
 	M.mvC[0] = *(const gu32 *)&mo->mvs[kc * 2]; M.mvC[1] = *(const gu32 *)&mo->mvs[32 + kc * 2];
+	// coarsest uniform granularity per list (the packet carries per-4x4 motion, not partitions); decided once
+	// here (2 macroblocks ahead of use) instead of in each of issue / commit / compute
+	int S = 0;
+#pragma unroll
+	for (int l = 0; l < 2; l++) {
+		const uint32_t mvp = M.mvY[l];
+		const int pic = ref_byte(M.refs[l], k >> 2);
+		const uint32_t mv0 = __shfl(mvp, 0), mvq = __shfl(mvp, lane & 48);
+		const int pic0 = __shfl(pic, 0), picq = __shfl(pic, lane & 48);
+		const bool u16 = __all(mvp == mv0 && pic == pic0);
+		const bool u8 = __all(mvp == mvq && pic == picq);
+		S |= (u16 ? 16 : u8 ? 8 : 4) << (8 * l);
+	}
+	M.S = __builtin_amdgcn_readfirstlane(S);
 }
 
 // geometry of the luma reference window this lane's block belongs to (list l)
@@ -549,12 +626,8 @@ __device__ __forceinline__ McGeom mc_geom(const McMotion &M, int l, int lane, in
 	G.pic = ref_byte(M.refs[l], k >> 2);
 	const uint32_t mvp = M.mvY[l];
 	G.mx = (int)(int16_t)(mvp & 0xffff); G.my = (int)mvp >> 16;
-	// coarsest uniform granularity (the packet carries per-4x4 motion, not partitions)
-	const uint32_t mv0 = __shfl(mvp, 0), mvq = __shfl(mvp, lane & 48);
-	const int pic0 = __shfl(G.pic, 0), picq = __shfl(G.pic, lane & 48);
-	const bool u16 = __all(mvp == mv0 && G.pic == pic0);
-	const bool u8 = __all(mvp == mvq && G.pic == picq);
-	G.S = u16 ? 16 : u8 ? 8 : 4;
+	G.S = (M.S >> (8 * l)) & 255;
+	const bool u16 = G.S == 16, u8 = G.S == 8;
 	G.g = u16 ? 0 : u8 ? k >> 2 : k;
 	G.gx = u16 ? 0 : u8 ? ((k >> 2) & 1) * 8 : BXf(k);
 	G.gy = u16 ? 0 : u8 ? (k >> 3) * 8 : BYf(k);
@@ -568,12 +641,13 @@ __device__ __forceinline__ McGeom mc_geom(const McMotion &M, int l, int lane, in
 // requested once per window.  Out-of-frame samples: clamped row index, edge sample replicated over
 // whole dwords (frame width is a multiple of 16, window columns are dword aligned) == the reference's
 // edge emulation (edge264_inter.c:1199-1235).
-template <int S>
-__device__ __forceinline__ void mc_issue_luma(const FrameCtx &f, int lane, int XA, int Y0, int pic, uint32_t w[7])
-{
+template <int S, int IT0, int IT1>
+__device__ __forceinline__ void mc_issue_luma(const FrameCtx &f, int lane, int XA, int Y0, int pic, uint32_t *w)
+{ // iterations IT0..IT1-1 of the window fetch; w[it - IT0] receives iteration `it`
 	constexpr int ROWS = S + 5, ND = S == 16 ? 6 : S == 8 ? 4 : 3, G = 256 / (S * S), PER = ROWS * ND;
+	constexpr int NIT = (G * PER + 63) / 64;
 #pragma unroll
-	for (int it = 0; it < (G * PER + 63) / 64; it++) {
+	for (int it = IT0; it < (IT1 < NIT ? IT1 : NIT); it++) {
 		const int idx = it * 64 + lane;
 		const int g = idx / PER, rem = idx - g * PER, row = rem / ND, dw = rem - row * ND;
 		const int src = (g * (64 / G)) & 63;
@@ -585,7 +659,7 @@ __device__ __forceinline__ void mc_issue_luma(const FrameCtx &f, int lane, int X
 			if (x >= 0 && x <= f.W - 4) v = *(const gu32 *)(rowp + x);
 			else v = (uint32_t)rowp[x < 0 ? 0 : f.W - 1] * 0x01010101u;
 		}
-		w[it] = v;
+		w[it - IT0] = v;
 	}
 }
 
@@ -596,9 +670,11 @@ __device__ __forceinline__ void mc_issue(const FrameCtx &f, const McMotion &M, i
 		return;
 	McGeom G = mc_geom(M, l, lane, mbx, mby);
 	if (!(f.dbg & 256)) {
-		if (G.S == 16) mc_issue_luma<16>(f, lane, G.X0 & ~3, G.Y0, G.pic, Wn.y);
-		else if (G.S == 8) mc_issue_luma<8>(f, lane, G.X0 & ~3, G.Y0, G.pic, Wn.y);
-		else mc_issue_luma<4>(f, lane, G.X0 & ~3, G.Y0, G.pic, Wn.y);
+		uint32_t t[4] = {0, 0, 0, 0};
+		if (G.S == 16) mc_issue_luma<16, 0, 4>(f, lane, G.X0 & ~3, G.Y0, G.pic, t);
+		else if (G.S == 8) mc_issue_luma<8, 0, 4>(f, lane, G.X0 & ~3, G.Y0, G.pic, t);
+		else mc_issue_luma<4, 0, 4>(f, lane, G.X0 & ~3, G.Y0, G.pic, t);
+		Wn.y0 = t[0]; Wn.y1 = t[1]; Wn.y2 = t[2]; Wn.y3 = t[3];
 	}
 	// chroma: the 3x2 samples around this lane's two outputs (8.4.2.2.2)
 	const int kc = blk_of(cx >> 1, cy >> 1);
@@ -609,9 +685,15 @@ __device__ __forceinline__ void mc_issue(const FrameCtx &f, const McMotion &M, i
 		const int X = mbx * 8 + cx + (mx >> 3), Y = mby * 8 + cy + (my >> 3);
 		const int Wc = f.W >> 1, Hc = f.H >> 1;
 		const gu8 *r0 = rp + (size_t)clip3i(0, Hc - 1, Y) * f.sC, *r1 = rp + (size_t)clip3i(0, Hc - 1, Y + 1) * f.sC;
-		const int x0 = clip3i(0, Wc - 1, X), x1 = clip3i(0, Wc - 1, X + 1), x2 = clip3i(0, Wc - 1, X + 2);
-		Wn.c[0] = r0[x0]; Wn.c[1] = r0[x1]; Wn.c[2] = r0[x2];
-		Wn.c[3] = r1[x0]; Wn.c[4] = r1[x1]; Wn.c[5] = r1[x2];
+		if (X >= 0 && X + 3 < Wc) { // the three columns as one unaligned dword per row
+			const uint32_t a = *(const gu32u *)(r0 + X), b = *(const gu32u *)(r1 + X);
+			Wn.c[0] = a & 255; Wn.c[1] = a >> 8 & 255; Wn.c[2] = a >> 16 & 255;
+			Wn.c[3] = b & 255; Wn.c[4] = b >> 8 & 255; Wn.c[5] = b >> 16 & 255;
+		} else { // frame border: per-sample clamp == the reference's edge emulation
+			const int x0 = clip3i(0, Wc - 1, X), x1 = clip3i(0, Wc - 1, X + 1), x2 = clip3i(0, Wc - 1, X + 2);
+			Wn.c[0] = r0[x0]; Wn.c[1] = r0[x1]; Wn.c[2] = r0[x2];
+			Wn.c[3] = r1[x0]; Wn.c[4] = r1[x1]; Wn.c[5] = r1[x2];
+		}
 	}
 }
 
@@ -622,10 +704,26 @@ __device__ __forceinline__ void mc_commit(WaveLds &L, const McMotion &M, int l, 
 		return;
 	McGeom G = mc_geom(M, l, lane, mbx, mby);
 	const int total = G.S == 16 ? 126 : G.S == 8 ? 208 : 432;
+	if (lane < total) L.win[lane] = Wn.y0;
+	if (64 + lane < total) L.win[64 + lane] = Wn.y1;
+	if (128 + lane < total) L.win[128 + lane] = Wn.y2;
+	if (192 + lane < total) L.win[192 + lane] = Wn.y3;
+}
+
+// 4x4 windows (432 dwords) do not fit the 4 prefetch registers: dwords 256..431 are fetched here, at
+// commit time, and go straight to LDS (sub-8x8 partitions are rare; they pay one exposed round trip
+// instead of every macroblock paying 3 more live registers per list)
+__device__ __forceinline__ void mc_commit_tail(WaveLds &L, const FrameCtx &f, const McMotion &M, int l, int mbx, int mby, int lane)
+{
+	if (M.refs[l] == 0xffffffffu || ((M.S >> (8 * l)) & 255) != 4 || (f.dbg & 256))
+		return;
+	McGeom G = mc_geom(M, l, lane, mbx, mby);
+	uint32_t t[3];
+	mc_issue_luma<4, 4, 7>(f, lane, G.X0 & ~3, G.Y0, G.pic, t);
 #pragma unroll
-	for (int it = 0; it < 7; it++)
-		if (it * 64 + lane < total)
-			L.win[it * 64 + lane] = Wn.y[it];
+	for (int it = 4; it < 7; it++)
+		if (it * 64 + lane < 432)
+			L.win[it * 64 + lane] = t[it - 4];
 }
 
 // filters + weights of one list of one macroblock from the LDS window / chroma registers
@@ -653,7 +751,8 @@ __device__ __forceinline__ void mc_compute(WaveLds &L, const FrameCtx &f, cslice
 			d[rr][2] = w2 >> (sh * 8);
 		}
 		int p[4];
-		luma_from_rows(d, G.mx & 3, G.my & 3, p);
+		if (G.S == 16) luma_from_rows<true>(d, G.mx & 3, G.my & 3, p);
+		else luma_from_rows<false>(d, G.mx & 3, G.my & 3, p);
 		const int refIdxX = ref_byte(M.refs[2 + (l ^ 1)], k >> 2);
 		if (idc == 0 && !(l == 1 && refIdxX >= 0)) {
 #pragma unroll
@@ -685,21 +784,20 @@ __device__ __forceinline__ void mc_compute(WaveLds &L, const FrameCtx &f, cslice
 }
 
 // stage C of one macroblock of the strip: everything that is not intra prediction
-__device__ __forceinline__ void mbpar_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, const McMotion &M, const McWindows &Wn,
+__device__ __forceinline__ bool mbpar_mb(WaveLds &L, StripOut &O, int slot, const FrameCtx &f, const MbInfo &m, const McMotion &M, const McWindows &Wn,
 	int mbx, int mby, int lane)
-{
+{ // returns true when the macroblock's samples were staged in O.y/O.c[slot]
 	if (m.kind != E264_MB_INTER && m.kind != E264_MB_PCM)
-		return;
+		return false;
 	const gu8 *pl = f.payload + m.payload_off;
 	const int k = lane >> 2, r = lane & 3;
 	const int X = BXf(k), Yr = BYf(k) + r;
-	gu8 *dY = f.cur + (size_t)(mby * 16 + Yr) * f.sY + mbx * 16 + X;
 	const int cpl = lane >> 5, cy = (lane >> 2) & 7, cx = (lane & 3) * 2;
-	gu8 *dC = plane_base(f, f.cur, 1 + cpl) + (size_t)(mby * 8 + cy) * f.sC + mbx * 8 + cx;
+	uint16_t *oc = (uint16_t *)O.c[slot] + cpl * 32 + cy * 4 + (cx >> 1);
 	if (m.kind == E264_MB_PCM) { // edge264_slice.c:914-935
-		*(gu32 *)dY = *(const gu32 *)(pl + Yr * 16 + X);
-		*(gu16 *)dC = *(const gu16 *)(pl + 256 + cpl * 64 + cy * 8 + cx);
-		return;
+		O.y[slot][Yr * 4 + (X >> 2)] = *(const gu32 *)(pl + Yr * 16 + X);
+		*oc = *(const gu16 *)(pl + 256 + cpl * 64 + cy * 8 + cx);
+		return true;
 	}
 	cslice_t s = f.slices + m.slice;
 	if (!(f.dbg & 1024)) compute_residual(L, f, m, s, pl, lane);
@@ -710,6 +808,7 @@ __device__ __forceinline__ void mbpar_mb(WaveLds &L, const FrameCtx &f, const Mb
 		wave_sync();
 		mc_issue(f, M, 1, mbx, mby, lane, W1);
 		mc_commit(L, M, 1, W1, mbx, mby, lane);
+		mc_commit_tail(L, f, M, 1, mbx, mby, lane);
 		wave_sync();
 		mc_compute(L, f, s, M, 1, W1, mbx, mby, lane, pY, pC);
 	}
@@ -717,10 +816,35 @@ __device__ __forceinline__ void mbpar_mb(WaveLds &L, const FrameCtx &f, const Mb
 	const int16_t *rr = L.res + Yr * 16 + X;
 	const uint32_t outw = (uint32_t)clip255(w16(pY[0] + rr[0])) | (uint32_t)clip255(w16(pY[1] + rr[1])) << 8 |
 		(uint32_t)clip255(w16(pY[2] + rr[2])) << 16 | (uint32_t)clip255(w16(pY[3] + rr[3])) << 24;
-	if (f.dbg & 4096) return;
-	*(gu32 *)dY = outw;
+	O.y[slot][Yr * 4 + (X >> 2)] = outw;
 	const int16_t *rc = L.res + 256 + cpl * 64 + cy * 8 + cx;
-	*(gu16 *)dC = (uint16_t)(clip255(w16(pC[0] + rc[0])) | clip255(w16(pC[1] + rc[1])) << 8);
+	*oc = (uint16_t)(clip255(w16(pC[0] + rc[0])) | clip255(w16(pC[1] + rc[1])) << 8);
+	return true;
+}
+
+// end of a strip: staged macroblocks (bit i of `mask`) -> frame, 16 bytes per lane
+__device__ __forceinline__ void strip_flush(const StripOut &O, const FrameCtx &f, int mbx0, int mby0, uint32_t mask, int lane)
+{
+	if (!mask || (f.dbg & 4096))
+		return;
+	const int mb = lane & 7;
+	int x = mbx0 + mb, y = mby0;
+	while (x >= f.wm) { x -= f.wm; y++; }
+	if (!(mask >> mb & 1))
+		return;
+	gu8 *Yb = f.cur + (size_t)(y * 16) * f.sY + x * 16;
+#pragma unroll
+	for (int it = 0; it < 2; it++) {
+		const int row = it * 8 + (lane >> 3);
+		const v4u v = *(const v4u *)&O.y[mb][row * 4];
+		*(gv4u *)(Yb + (size_t)row * f.sY) = v;
+	}
+#pragma unroll
+	for (int it = 0; it < 2; it++) { // it = plane
+		const int row = lane >> 3;
+		const v2u v = *(const v2u *)&O.c[mb][it * 16 + row * 2];
+		*(gv2u *)(plane_base(f, f.cur, 1 + it) + (size_t)(y * 8 + row) * f.sC + x * 8) = v;
+	}
 }
 
 // ---------------------------------------------------------------------------------
@@ -1126,14 +1250,16 @@ __device__ __forceinline__ void write_dbk_params(const FrameCtx &f, int mbx, int
 // DBK_LAG macroblocks behind, so that all 64 lanes filter (16 luma + 8 Cb + 8 Cr lines per row).
 // ---------------------------------------------------------------------------------
 // One edge on 8 values p3 p2 p1 p0 | q0 q1 q2 q3 held in registers; chroma lines use the same
-// code with ap/aq/strong forced off and tc = tC0+1 (deblock.c:95-152, 213-276).  Branch-free.
+// code with ap/aq/strong forced off and tc = tC0+1 (deblock.c:95-152, 213-276).  Branch-free per
+// lane; `strong_somewhere` is WAVE-UNIFORM: the bS==4 arithmetic (deblock.c:213-276) is only emitted
+// for macroblock edges (EDGE0) and only executed when some line of the wave has bS 4.
+template <bool EDGE0>
 __device__ __forceinline__ void edge_filter(int &p3, int &p2, int &p1, int &p0, int &q0, int &q1, int &q2, int &q3,
-	int bS, int alpha, int beta, int tc0, bool chroma)
+	int bS, int alpha, int beta, int tc0, bool chroma, bool strong_somewhere)
 {
 	const int dpq = abs(p0 - q0);
 	const bool go = (bS != 0) & (dpq < alpha) & (abs(p1 - p0) < beta) & (abs(q1 - q0) < beta);
 	const bool ap = !chroma & (abs(p2 - p0) < beta), aq = !chroma & (abs(q2 - q0) < beta);
-	const bool strong = bS == 4;
 	// bS < 4
 	const int tc = tc0 + (chroma ? 1 : (int)ap + (int)aq);
 	const int delta = clip3i(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
@@ -1141,34 +1267,47 @@ __device__ __forceinline__ void edge_filter(int &p3, int &p2, int &p1, int &p0, 
 	const int w_p0 = clip255(p0 + delta), w_q0 = clip255(q0 - delta);
 	const int w_p1 = p1 + clip3i(-tc0, tc0, (p2 + avg - 2 * p1) >> 1);
 	const int w_q1 = q1 + clip3i(-tc0, tc0, (q2 + avg - 2 * q1) >> 1);
-	// bS == 4
-	const bool small = dpq < (alpha >> 2) + 2;
-	const bool sp = ap & small, sq = aq & small;
-	const int s_p0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (2 * p1 + p0 + q1 + 2) >> 2;
-	const int s_p1 = (p2 + p1 + p0 + q0 + 2) >> 2;
-	const int s_p2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
-	const int s_q0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (2 * q1 + q0 + p1 + 2) >> 2;
-	const int s_q1 = (p0 + q0 + q1 + q2 + 2) >> 2;
-	const int s_q2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
-	const bool m_p1 = go & (strong ? sp : ap), m_q1 = go & (strong ? sq : aq);
-	const int n_p0 = strong ? s_p0 : w_p0, n_q0 = strong ? s_q0 : w_q0;
-	p0 = go ? n_p0 : p0;
-	q0 = go ? n_q0 : q0;
-	p1 = m_p1 ? (strong ? s_p1 : w_p1) : p1;
-	q1 = m_q1 ? (strong ? s_q1 : w_q1) : q1;
-	p2 = (go & strong & sp) ? s_p2 : p2;
-	q2 = (go & strong & sq) ? s_q2 : q2;
+	if (EDGE0 && strong_somewhere) {
+		// bS == 4
+		const bool strong = bS == 4;
+		const bool small = dpq < (alpha >> 2) + 2;
+		const bool sp = ap & small, sq = aq & small;
+		const int s_p0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (2 * p1 + p0 + q1 + 2) >> 2;
+		const int s_p1 = (p2 + p1 + p0 + q0 + 2) >> 2;
+		const int s_p2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
+		const int s_q0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (2 * q1 + q0 + p1 + 2) >> 2;
+		const int s_q1 = (p0 + q0 + q1 + q2 + 2) >> 2;
+		const int s_q2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
+		const bool m_p1 = go & (strong ? sp : ap), m_q1 = go & (strong ? sq : aq);
+		const int n_p0 = strong ? s_p0 : w_p0, n_q0 = strong ? s_q0 : w_q0;
+		p0 = go ? n_p0 : p0;
+		q0 = go ? n_q0 : q0;
+		p1 = m_p1 ? (strong ? s_p1 : w_p1) : p1;
+		q1 = m_q1 ? (strong ? s_q1 : w_q1) : q1;
+		p2 = (go & strong & sp) ? s_p2 : p2;
+		q2 = (go & strong & sq) ? s_q2 : q2;
+	} else {
+		p0 = go ? w_p0 : p0;
+		q0 = go ? w_q0 : q0;
+		p1 = (go & ap) ? w_p1 : p1;
+		q1 = (go & aq) ? w_q1 : q1;
+	}
 }
 
 // A "line" of 20 samples (positions -4..15) crossing the four luma edges at positions 0,4,8,12 lives
 // in v[0..19].  Chroma lines (positions -4..7, edges at 0 and 4) are parked so that their two edges
 // coincide with luma edges 0 and 2: v[0..5] = pos -4..1, v[10..15] = pos 2..7 (v[6..9] unused).
+// An edge whose bS is 0 on every line of the wave is skipped (wave-uniform branch).
 __device__ __forceinline__ void filter_line(int v[20], const int bS[4], int a_edge0, int a_in, int b_edge0, int b_in, const int tc0[4], bool chroma)
 {
-	edge_filter(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], bS[0], a_edge0, b_edge0, tc0[0], chroma);
-	edge_filter(v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], bS[1], a_in, b_in, tc0[1], chroma);
-	edge_filter(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], bS[2], a_in, b_in, tc0[2], chroma);
-	edge_filter(v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19], bS[3], a_in, b_in, tc0[3], chroma);
+	if (__any(bS[0] != 0))
+		edge_filter<true>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], bS[0], a_edge0, b_edge0, tc0[0], chroma, __any(bS[0] == 4));
+	if (__any(bS[1] != 0))
+		edge_filter<false>(v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], bS[1], a_in, b_in, tc0[1], chroma, false);
+	if (__any(bS[2] != 0))
+		edge_filter<false>(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], bS[2], a_in, b_in, tc0[2], chroma, false);
+	if (__any(bS[3] != 0))
+		edge_filter<false>(v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19], bS[3], a_in, b_in, tc0[3], chroma, false);
 }
 
 // per-lane state of the macroblock a half-wave is about to filter
@@ -1199,7 +1338,7 @@ __device__ __forceinline__ void dbk_prefetch(const FrameCtx &f, int mbx, int mby
 	r.vc = *(const gu32 *)(Cb0 + (hl >> 4) * (f.sC >> 1) + (size_t)((hl >> 1) & 7) * f.sC + (hl & 1) * 4);
 	if (hl < 16)
 		r.vp = ((const gu32 *)(f.dbk + (size_t)(mby * f.wm + mbx) * E264_DBK_BYTES))[hl];
-	if (gtop && r.hasT) {
+	if (gtop) { // (gtop implies mby > 0) needed even without a top edge to filter: this row writes those rows back
 		if (hl < 16) r.vt = *(const gu32 *)(Yb + (ptrdiff_t)(-4 + (hl >> 2)) * f.sY + (hl & 3) * 4);
 		else if (hl < 24) { int i = hl - 16; r.vt = *(const gu32 *)(Cb0 + (i >> 2) * (f.sC >> 1) + (ptrdiff_t)(-2 + ((i >> 1) & 1)) * f.sC + (i & 1) * 4); }
 	}
@@ -1209,17 +1348,40 @@ __device__ __forceinline__ void dbk_prefetch(const FrameCtx &f, int mbx, int mby
 // hl 16..23 chroma rows -2..-1 (2 planes x 2 rows x 2 dwords)
 __device__ __forceinline__ void dbk_load_top(const DbkRing &up, int mbx, int hl, DbkRegs &r)
 {
-	if (!r.hasT)
+	if (!r.act)
 		return;
 	const int slot = mbx & (DBK_RING - 1);
 	if (hl < 16) r.vt = up.y[hl >> 2][slot * 4 + (hl & 3)];
 	else if (hl < 24) { int i = hl - 16; r.vt = up.c[i >> 2][(i >> 1) & 1][slot * 2 + (i & 1)]; }
 }
 
-// Filter the macroblock whose samples are in r, publish its bottom rows in `ring`, store it.
-__device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, const uint8_t *tc0tab, const FrameCtx &f, int mbx, int mby, int hl,
-	const DbkRegs &r, bool carry, bool last)
+// Group g (macroblocks 4g .. 4g+nmb-1) of row mby: staged samples -> frame.
+__device__ __forceinline__ void dbk_flush(const DbkStage &S, const FrameCtx &f, int g, int nmb, int mby, int hl, bool has_top, int nrow, int ncrow)
 {
+	gu8 *Yb = f.cur + (size_t)(mby * 16) * f.sY + g * 64;
+#pragma unroll
+	for (int it = 0; it < 3; it++) { // 20 rows x 4 pieces of 16 bytes
+		const int idx = it * 32 + hl, row = (idx >> 2) - 4, c = idx & 3;
+		if (idx < 80 && c < nmb && (row < 0 ? has_top : row < nrow))
+			*(gv4u *)(Yb + (ptrdiff_t)row * f.sY + c * 16) = *(const v4u *)&S.y[row + 4][c * 4];
+	}
+#pragma unroll
+	for (int it = 0; it < 2; it++) { // 2 planes x 10 rows x 2 pieces of 16 bytes (= 2 macroblocks each)
+		const int idx = it * 32 + hl, pc = idx >= 20, rem = idx - pc * 20, row = (rem >> 1) - 2, c = rem & 1;
+		if (idx < 40 && (row < 0 ? has_top : row < ncrow)) {
+			gu8 *dst = plane_base(f, f.cur, 1 + pc) + (ptrdiff_t)(mby * 8 + row) * f.sC + g * 32 + c * 16;
+			if (nmb >= 2 * c + 2) *(gv4u *)dst = *(const v4u *)&S.c[pc][row + 2][c * 4];
+			else if (nmb == 2 * c + 1) *(gv2u *)dst = *(const v2u *)&S.c[pc][row + 2][c * 4];
+		}
+	}
+}
+
+// Filter the macroblock whose samples are in r, publish its bottom rows in `ring`, store it.
+// S: staging of final samples; self_bottom: this row also writes its rows 12..15 (nobody below takes them from the ring)
+__device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, DbkStage &S, const uint8_t *tc0tab, const FrameCtx &f, int mbx, int mby, int hl,
+	const DbkRegs &r, bool carry, bool last, bool self_bottom)
+{
+	const bool has_top = mby > 0;
 	const int pl = hl < 16 ? 0 : hl < 24 ? 1 : 2; // line roles: 0..15 luma, 16..23 Cb, 24..31 Cr
 	const int li = hl < 16 ? hl : (hl & 7);
 	const bool chroma = pl != 0;
@@ -1238,7 +1400,7 @@ __device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, const uin
 		*(uint32_t *)&L.DYT(8 + (hl >> 2), (hl & 3) * 4) = r.va1;
 		*(uint32_t *)&L.DCT(hl >> 4, (hl >> 1) & 7, (hl & 1) * 4) = r.vc;
 		if (hl < 16) ((uint32_t *)L.prm)[hl] = r.vp;
-		if (r.hasT && hl < 24) {
+		if (has_top && hl < 24) {
 			if (hl < 16) *(uint32_t *)&L.DYT(-4 + (hl >> 2), (hl & 3) * 4) = r.vt;
 			else { int i = hl - 16; *(uint32_t *)&L.DCT(i >> 2, -2 + ((i >> 1) & 1), (i & 1) * 4) = r.vt; }
 		}
@@ -1330,22 +1492,33 @@ __device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, const uin
 			else { int j = i - 4; ring.c[j >> 1][j & 1][slot * 2 + 1] = *(const uint32_t *)&L.DCT(j >> 1, 6 + (j & 1), 4); }
 		}
 	}
-	if (!r.on)
-		return;
-	// ---- write back: own samples, the top rows and the carried left columns ------------------
-	gu8 *Yb = f.cur + (size_t)(mby * 16) * f.sY + mbx * 16;
-	gu8 *Cb0 = plane_base(f, f.cur, 1) + (size_t)(mby * 8) * f.sC + mbx * 8;
-	const int half = f.sC >> 1;
-	*(gu32 *)(Yb + (size_t)(hl >> 2) * f.sY + (hl & 3) * 4) = *(const uint32_t *)&L.DYT(hl >> 2, (hl & 3) * 4);
-	*(gu32 *)(Yb + (size_t)(8 + (hl >> 2)) * f.sY + (hl & 3) * 4) = *(const uint32_t *)&L.DYT(8 + (hl >> 2), (hl & 3) * 4);
-	*(gu32 *)(Cb0 + (hl >> 4) * half + (size_t)((hl >> 1) & 7) * f.sC + (hl & 1) * 4) = *(const uint32_t *)&L.DCT(hl >> 4, (hl >> 1) & 7, (hl & 1) * 4);
-	if (r.hasT) {
-		if (hl < 16) *(gu32 *)(Yb + (ptrdiff_t)(-4 + (hl >> 2)) * f.sY + (hl & 3) * 4) = *(const uint32_t *)&L.DYT(-4 + (hl >> 2), (hl & 3) * 4);
-		else if (hl < 24) { int i = hl - 16; *(gu32 *)(Cb0 + (i >> 2) * half + (ptrdiff_t)(-2 + ((i >> 1) & 1)) * f.sC + (i & 1) * 4) = *(const uint32_t *)&L.DCT(i >> 2, -2 + ((i >> 1) & 1), (i & 1) * 4); }
+	// ---- stage what has become final; groups of 4 macroblocks leave as whole 64-byte row pieces ----------
+	const int gxm = mbx & 3;
+	const int nrow = self_bottom ? 16 : 12, ncrow = self_bottom ? 8 : 6;
+	if (carry) { // the left neighbour's last 4 columns (tile columns -4..-1), rows 0..nrow-1
+		if (hl < nrow) S.y[hl + 4][gxm ? gxm * 4 - 1 : 15] = *(const uint32_t *)&L.DYT(hl, -4);
+		else if (hl >= 16 && ((hl - 16) & 7) < ncrow) S.c[(hl - 16) >> 3][((hl - 16) & 7) + 2][gxm ? gxm * 2 - 1 : 7] = *(const uint32_t *)&L.DCT((hl - 16) >> 3, (hl - 16) & 7, -4);
+		if (gxm == 0) { // ... which completes the previous group
+			wave_sync();
+			dbk_flush(S, f, (mbx >> 2) - 1, 4, mby, hl, has_top, nrow, ncrow);
+		}
 	}
-	if (r.hasL) {
-		if (hl < 16) *(gu32 *)(Yb + (size_t)hl * f.sY - 4) = *(const uint32_t *)&L.DYT(hl, -4);
-		else { int q = hl - 16; *(gu32 *)(Cb0 + (q >> 3) * half + (size_t)(q & 7) * f.sC - 4) = *(const uint32_t *)&L.DCT(q >> 3, q & 7, -4); }
+	wave_sync();
+#pragma unroll
+	for (int it = 0; it < 3; it++) { // luma rows -4..15 x 4 dwords of this macroblock
+		const int idx = it * 32 + hl, row = (idx >> 2) - 4, dw = idx & 3;
+		if (idx < 80 && (row < 0 ? has_top : (row < nrow && (dw < 3 || last))))
+			S.y[row + 4][gxm * 4 + dw] = *(const uint32_t *)&L.DYT(row, dw * 4);
+	}
+#pragma unroll
+	for (int it = 0; it < 2; it++) { // chroma: 2 planes x rows -2..7 x 2 dwords
+		const int idx = it * 32 + hl, pc = idx >= 20, rem = idx - pc * 20, row = (rem >> 1) - 2, dw = rem & 1;
+		if (idx < 40 && (row < 0 ? has_top : (row < ncrow && (dw < 1 || last))))
+			S.c[pc][row + 2][gxm * 2 + dw] = *(const uint32_t *)&L.DCT(pc, row, dw * 4);
+	}
+	if (last) {
+		wave_sync();
+		dbk_flush(S, f, mbx >> 2, gxm + 1, mby, hl, has_top, nrow, ncrow);
 	}
 }
 
@@ -1381,7 +1554,6 @@ __device__ __forceinline__ bool open_frame(FrameCtx &f, const E264Job &job)
 }
 
 #define E264_MAX_ROWS 1056
-#define E264_MBPAR_STRIP 8
 } // namespace
 
 // XCD-aware workgroup order.  The dispatcher places linear workgroup b on XCD b % 8, each with a private
@@ -1404,6 +1576,7 @@ static __device__ __forceinline__ void xcd_tile(int &bx, int &by)
 __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, int mode)
 {
 	__shared__ WaveLds lds[4];
+	__shared__ StripOut outs[4];
 	__shared__ generic_u8p dpbtab[E264_MAX_SLOTS];
 	const int lane = lane_id();
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1431,6 +1604,9 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 	m1 = m0; m2 = m0;
 	if (n > 1) { h1 = load_mb(f.mbs + base + 1); mc_load_motion(f, base + 1, lane, m1); }
 	int mby = base / f.wm, mbx = base - mby * f.wm;
+	const int mbx0 = mbx, mby0 = mby;
+	StripOut &O = outs[wave];
+	uint32_t staged = 0;
 	if (recon && h0.kind == E264_MB_INTER)
 		mc_issue(f, m0, 0, mbx, mby, lane, w0);
 #pragma unroll 1
@@ -1439,16 +1615,20 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 		if (nx == f.wm) { nx = 0; ny++; }
 		if (i + 2 < n) { h2 = load_mb(f.mbs + base + i + 2); mc_load_motion(f, base + i + 2, lane, m2); }
 		if (recon && h0.kind == E264_MB_INTER)
+		{
 			mc_commit(L, m0, 0, w0, mbx, mby, lane);
+			mc_commit_tail(L, f, m0, 0, mbx, mby, lane);
+		}
 		wave_sync();
 		if (recon && i + 1 < n && h1.kind == E264_MB_INTER)
 			mc_issue(f, m1, 0, nx, ny, lane, w1);
-		if (recon)
-			mbpar_mb(L, f, h0, m0, w0, mbx, mby, lane);
+		if (recon && mbpar_mb(L, O, i, f, h0, m0, w0, mbx, mby, lane))
+			staged |= 1u << i;
 		wave_sync();
 		h0 = h1; h1 = h2; m0 = m1; m1 = m2; w0 = w1;
 		mbx = nx; mby = ny;
 	}
+	strip_flush(O, f, mbx0, mby0, staged, lane);
 }
 
 // deblocking parameters (bS, alpha, beta, indexA) of every macroblock: one wave per macroblock, few
@@ -1543,6 +1723,9 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 		// wave 0 takes its top rows from global memory (written by the last wave one round earlier)
 		const bool gtop_wave = wave == 0 && yA > 0;
 		const bool gtop = gtop_wave && half == 0;
+		// the lower row of the last wave is read by wave 0 of the next round from memory, not from the ring
+		const bool handoff = wave == NW - 1 && half == 1 && my_y + 1 < f.hm;
+		const bool self_bottom = handoff || my_y == f.hm - 1;
 		DbkRegs cur, nxt;
 		if (gtop_wave) {
 			while (lds_load_relaxed(&progress[yA - 1]) < min(2, f.wm))
@@ -1565,17 +1748,19 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 			}
 			if (gtop_wave) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 			else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-			if (!gtop)
+			if (!gtop && my_y > 0)
 				dbk_load_top(upring, my_x, hl, cur);
 			const int nx = my_x + 1;
 			dbk_prefetch(f, nx, my_y, hl, row_ok && nx >= 0 && nx < f.wm, gtop, nxt);
-			dbk_process(L.tile[half], myring, tc0tab, f, my_x, my_y, hl, cur, my_x > 0, my_x == f.wm - 1);
+			dbk_process(L.tile[half], myring, L.stage[half], tc0tab, f, my_x, my_y, hl, cur, my_x > 0, my_x == f.wm - 1, self_bottom);
 			// LDS operations of a wave execute in order: the ring is written before the counter.  The last
 			// wave hands its lower row to the next round through global memory: its stores must be visible.
 			if (wave == NW - 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			// a row handed over through memory counts the macroblocks whose samples have LEFT the staging buffer
+			const int done = handoff ? (my_x == f.wm - 1 ? f.wm : (my_x & ~3)) : my_x + 1;
 			if (hl == 0 && cur.act)
-				__hip_atomic_store(&progress[my_y], my_x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__hip_atomic_store(&progress[my_y], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			cur = nxt;
 		}
 	}

@@ -29,6 +29,13 @@ __global__ void k_read_full(const uint4 *src, size_t n16, unsigned *sink)
 	for (; i < n16; i += (size_t)gridDim.x * blockDim.x) { uint4 v = src[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
 	if (acc == 0x12345678u) *sink = acc;
 }
+__global__ void k_read_dword(const uint32_t *src, size_t n4, unsigned *sink)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned acc = 0;
+	for (; i < n4; i += (size_t)gridDim.x * blockDim.x) acc += src[i];
+	if (acc == 0x12345678u) *sink = acc;
+}
 // grid (H/16 * W/128, NF), block 64: one wave = strip of 8 blocks
 __global__ void k_write_mbrow(uint8_t *dst)
 {
@@ -81,6 +88,7 @@ int main()
 	for (int rep = 0; rep < 2; rep++) {
 		hipLaunchKernelGGL(k_write_full, dim3(8192), dim3(256), 0, 0, (uint4 *)buf, bytes / 16);
 		hipLaunchKernelGGL(k_read_full, dim3(8192), dim3(256), 0, 0, (const uint4 *)buf, bytes / 16, sink);
+		hipLaunchKernelGGL(k_read_dword, dim3(8192), dim3(256), 0, 0, (const uint32_t *)buf, bytes / 4, sink);
 		hipLaunchKernelGGL(k_write_mbrow, g, dim3(64), 0, 0, buf);
 		hipLaunchKernelGGL(k_read_window, g, dim3(64), 0, 0, buf, sink);
 		hipLaunchKernelGGL(k_write_row16, g, dim3(64), 0, 0, buf);

@@ -46,9 +46,18 @@ if args.traffic:
            "note": "HBM bytes per launch = 2 x FETCH_SIZE(KB) x 1024 (gfx950 correction) + WRITE_SIZE(KB) x 1024, averaged over all launches of the GOP",
            "kernels": {}}
     for k, c in kern.items():
-        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        if "TCC_EA0_RDREQ_128B" in c and "TCC_EA0_WRREQ" in c:
+            # raw request counters by size (gfx950 lists them; FETCH_SIZE's gfx94x formula mis-sizes 128-B requests)
+            rd = 32 * c["TCC_EA0_RDREQ_32B"] + 64 * c["TCC_EA0_RDREQ_64B"] + 128 * c["TCC_EA0_RDREQ_128B"]
+            wr = 64 * c["TCC_EA0_WRREQ_64B"] + 32 * (c["TCC_EA0_WRREQ"] - c["TCC_EA0_WRREQ_64B"])
+            out["kernels"][k] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr,
+                                 "rdreq": {n: c[n] for n in c if "RDREQ" in n}, "wrreq": {n: c[n] for n in c if "WRREQ" in n}}
+        elif "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             out["kernels"][k] = {"fetch_kb": c["FETCH_SIZE"], "write_kb": c["WRITE_SIZE"],
                                  "hbm_bytes_per_launch": 2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024}
+    out["note"] = ("HBM bytes per launch from the L2 memory-side request counters, sized individually: reads 32*RDREQ_32B + 64*RDREQ_64B + "
+                   "128*RDREQ_128B, writes 64*WRREQ_64B + 32*(WRREQ - WRREQ_64B); calibrated on tools/calib/pmc_calib.hip "
+                   "(profiles/r01_pmc_calibration.txt); averaged over all launches of the GOP")
     with open(args.traffic, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", args.traffic)
