@@ -8,6 +8,7 @@ several rows (one per XCD / instance); they are SUMMED per dispatch, then averag
 counter tallies 128-B requests at 64 B, /opt/skills/guides/MI355X_MICROARCH.md "HBM") + WRITE_SIZE (KB).
 """
 import argparse
+import re
 import json
 import sqlite3
 from collections import defaultdict
@@ -34,7 +35,8 @@ kern = {}
 for k, cs in acc.items():
     if "rocclr" in k:
         continue
-    short = k.split("(")[0].split("<")[0].replace("void ", "")
+    m = re.search(r"(e264_[a-z0-9]+_kernel|k_[a-z0-9_]+?)(?=P|I|$|\.)", k)  # mangled (_Z17e264_mbpar_kernelPK...) or plain names
+    short = m.group(1) if m else k.split("(")[0].split("<")[0].replace("void ", "")
     print(k[:90])
     for n, per in sorted(cs.items()):
         vals = list(per.values())
