@@ -48,6 +48,7 @@ def main() -> int:
     ap.add_argument("--width-mbs", type=int, default=120)
     ap.add_argument("--height-mbs", type=int, default=68)
     ap.add_argument("--waves", type=int, default=int(os.environ.get("E264_WAVES", 8)))
+    ap.add_argument("--intra-waves", type=int, default=int(os.environ.get("E264_INTRA_WAVES", 16)))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
@@ -79,6 +80,8 @@ def main() -> int:
     devs = [backend.Device(local_rank) for _ in range(nq)]
     for dv in devs:
         dv.set_option("waves", args.waves)
+        if args.intra_waves:
+            dv.set_option("intra_waves", args.intra_waves)
         dv.set_option("debug_mode", args.debug_mode)
     dev = devs[0]
     streams, dpk = [], []

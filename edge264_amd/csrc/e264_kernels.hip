@@ -131,7 +131,9 @@ struct __attribute__((aligned(16))) WaveLds { // reconstruction scratch of one w
 // each macroblock as it is produced (64 lanes x 4 bytes = sixteen 16-byte row pieces) left every
 // 64-byte segment partially written several times: 3.6x the algorithmic write traffic at the L2
 // memory side (TCC_EA0_WRREQ, profiles/r01_pmc_calibration.txt).
-#define E264_MBPAR_STRIP 8
+#ifndef E264_MBPAR_STRIP
+#define E264_MBPAR_STRIP 16 // macroblocks per wave (multiple of 8; measured 8: 4.47 ms, 16: 4.27, 24: 4.28, 32: 4.35 per 256-frame launch)
+#endif
 struct __attribute__((aligned(16))) StripOut {
 	uint32_t y[E264_MBPAR_STRIP][64];  // [mb][row * 4 + dword]
 	uint32_t c[E264_MBPAR_STRIP][32];  // [mb][plane * 16 + row * 2 + dword]
@@ -204,6 +206,23 @@ __device__ __forceinline__ MbInfo load_mb(cmb_t p)
 	m.coded = p->coded; m.payload_off = p->payload_off;
 	m.modes_lo = *(const uint32_t __attribute__((address_space(4))) *)&p->modes[0];
 	m.modes_hi = *(const uint32_t __attribute__((address_space(4))) *)&p->modes[4];
+	return m;
+}
+
+// The same header out of a lane-distributed copy of 8 consecutive E264Mb records (lane = mb * 8 + dword, one
+// vector load per strip): v_readlane instead of scalar-memory loads.  Scalar loads share the LGKM counter with
+// LDS and return out of order, so every LDS wait of the inner loop also waited for the headers "prefetched" for
+// later macroblocks (ablation: 40% of the kernel's time was spent with all filters switched off).
+__device__ __forceinline__ MbInfo mb_from_lanes(uint32_t hv, int i)
+{
+	MbInfo m;
+	const uint32_t d0 = __builtin_amdgcn_readlane(hv, i * 8), d1 = __builtin_amdgcn_readlane(hv, i * 8 + 1);
+	const uint32_t d2 = __builtin_amdgcn_readlane(hv, i * 8 + 2);
+	m.kind = d0 & 255; m.flags = d0 >> 8 & 255; m.qp[0] = d0 >> 16 & 255; m.qp[1] = d0 >> 24;
+	m.qp[2] = d1 & 255; m.chroma_mode = d1 >> 8 & 255; m.i16_mode = d1 >> 16 & 255;
+	m.slice = d2 >> 16;
+	m.coded = __builtin_amdgcn_readlane(hv, i * 8 + 3); m.payload_off = __builtin_amdgcn_readlane(hv, i * 8 + 4);
+	m.modes_lo = __builtin_amdgcn_readlane(hv, i * 8 + 5); m.modes_hi = __builtin_amdgcn_readlane(hv, i * 8 + 6);
 	return m;
 }
 
@@ -597,8 +616,11 @@ __device__ __forceinline__ void mc_load_motion(const FrameCtx &f, int addr, int 
 	M.S = 16 | 16 << 8;
 	if (!f.motion) { M.refs[0] = M.refs[1] = M.refs[2] = M.refs[3] = 0xffffffffu; M.mvY[0] = M.mvY[1] = M.mvC[0] = M.mvC[1] = 0; return; }
 	gmotion_t mo = f.motion + addr;
-	const uint32_t __attribute__((address_space(4))) *rp = (const uint32_t __attribute__((address_space(4))) *)mo;
-	M.refs[0] = rp[0]; M.refs[1] = rp[1]; M.refs[2] = rp[2]; M.refs[3] = rp[3];
+	{ // refPic / refIdx (16 bytes, uniform): one vector load + readlane, not scalar memory (see mb_from_lanes)
+		const uint32_t rv = ((const gu32 *)mo)[lane & 3];
+		M.refs[0] = __builtin_amdgcn_readlane(rv, 0); M.refs[1] = __builtin_amdgcn_readlane(rv, 1);
+		M.refs[2] = __builtin_amdgcn_readlane(rv, 2); M.refs[3] = __builtin_amdgcn_readlane(rv, 3);
+	}
 	M.mvY[0] = *(const gu32 *)&mo->mvs[k * 2]; M.mvY[1] = *(const gu32 *)&mo->mvs[32 + k * 2];
 	M.mvC[0] = *(const gu32 *)&mo->mvs[kc * 2]; M.mvC[1] = *(const gu32 *)&mo->mvs[32 + kc * 2];
 	// coarsest uniform granularity per list (the packet carries per-4x4 motion, not partitions); decided once
@@ -607,11 +629,14 @@ __device__ __forceinline__ void mc_load_motion(const FrameCtx &f, int addr, int 
 #pragma unroll
 	for (int l = 0; l < 2; l++) {
 		const uint32_t mvp = M.mvY[l];
-		const int pic = ref_byte(M.refs[l], k >> 2);
-		const uint32_t mv0 = __shfl(mvp, 0), mvq = __shfl(mvp, lane & 48);
-		const int pic0 = __shfl(pic, 0), picq = __shfl(pic, lane & 48);
-		const bool u16 = __all(mvp == mv0 && pic == pic0);
-		const bool u8 = __all(mvp == mvq && pic == picq);
+		// first lane of each 8x8 quadrant through v_readlane (no LDS round trip as with __shfl)
+		const uint32_t q0 = __builtin_amdgcn_readlane(mvp, 0), q1 = __builtin_amdgcn_readlane(mvp, 16);
+		const uint32_t q2 = __builtin_amdgcn_readlane(mvp, 32), q3 = __builtin_amdgcn_readlane(mvp, 48);
+		const uint32_t mvq = lane < 32 ? (lane < 16 ? q0 : q1) : (lane < 48 ? q2 : q3);
+		// refPic is per 8x8 quadrant already: uniform iff the 4 bytes of refs[l] are equal
+		const bool pic_same = M.refs[l] == (M.refs[l] & 255) * 0x01010101u;
+		const bool u16 = pic_same && __all(mvp == q0);
+		const bool u8 = __all(mvp == mvq);
 		S |= (u16 ? 16 : u8 ? 8 : 4) << (8 * l);
 	}
 	M.S = __builtin_amdgcn_readfirstlane(S);
@@ -651,7 +676,12 @@ __device__ __forceinline__ void mc_issue_luma(const FrameCtx &f, int lane, int X
 		const int idx = it * 64 + lane;
 		const int g = idx / PER, rem = idx - g * PER, row = rem / ND, dw = rem - row * ND;
 		const int src = (g * (64 / G)) & 63;
-		const int xa = __shfl(XA, src), y0 = __shfl(Y0, src), pc = __shfl(pic, src);
+		int xa, y0, pc;
+		if (S == 16) { // one window: its origin is lane 0's (uniform)
+			xa = __builtin_amdgcn_readfirstlane(XA); y0 = __builtin_amdgcn_readfirstlane(Y0); pc = __builtin_amdgcn_readfirstlane(pic);
+		} else {
+			xa = __shfl(XA, src); y0 = __shfl(Y0, src); pc = __shfl(pic, src);
+		}
 		uint32_t v = 0;
 		if (idx < G * PER && pc >= 0) {
 			const gu8 *rowp = (const gu8 *)f.dpb_lds[pc] + (size_t)clip3i(0, f.H - 1, y0 + row) * f.sY;
@@ -827,23 +857,26 @@ __device__ __forceinline__ void strip_flush(const StripOut &O, const FrameCtx &f
 {
 	if (!mask || (f.dbg & 4096))
 		return;
-	const int mb = lane & 7;
-	int x = mbx0 + mb, y = mby0;
-	while (x >= f.wm) { x -= f.wm; y++; }
-	if (!(mask >> mb & 1))
-		return;
-	gu8 *Yb = f.cur + (size_t)(y * 16) * f.sY + x * 16;
 #pragma unroll
-	for (int it = 0; it < 2; it++) {
-		const int row = it * 8 + (lane >> 3);
-		const v4u v = *(const v4u *)&O.y[mb][row * 4];
-		*(gv4u *)(Yb + (size_t)row * f.sY) = v;
-	}
+	for (int g = 0; g < E264_MBPAR_STRIP / 8; g++) {
+		const int mb = g * 8 + (lane & 7);
+		int x = mbx0 + mb, y = mby0;
+		while (x >= f.wm) { x -= f.wm; y++; }
+		if (!(mask >> mb & 1))
+			continue;
+		gu8 *Yb = f.cur + (size_t)(y * 16) * f.sY + x * 16;
 #pragma unroll
-	for (int it = 0; it < 2; it++) { // it = plane
-		const int row = lane >> 3;
-		const v2u v = *(const v2u *)&O.c[mb][it * 16 + row * 2];
-		*(gv2u *)(plane_base(f, f.cur, 1 + it) + (size_t)(y * 8 + row) * f.sC + x * 8) = v;
+		for (int it = 0; it < 2; it++) {
+			const int row = it * 8 + (lane >> 3);
+			const v4u v = *(const v4u *)&O.y[mb][row * 4];
+			*(gv4u *)(Yb + (size_t)row * f.sY) = v;
+		}
+#pragma unroll
+		for (int it = 0; it < 2; it++) { // it = plane
+			const int row = lane >> 3;
+			const v2u v = *(const v2u *)&O.c[mb][it * 16 + row * 2];
+			*(gv2u *)(plane_base(f, f.cur, 1 + it) + (size_t)(y * 8 + row) * f.sC + x * 8) = v;
+		}
 	}
 }
 
@@ -1178,42 +1211,47 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, int mbx,
 // deblocking of one macroblock by one wave
 // ---------------------------------------------------------------------------------
 struct BlkMo { int ref0, ref1, mv0x, mv0y, mv1x, mv1y; };
-__device__ __forceinline__ BlkMo blk_motion(const FrameCtx &f, cmb_t m, int k)
+// motion of 4x4 block k of macroblock m; BRANCH-FREE loads (the motion array is dense, so the record of a
+// non-inter macroblock can be read and then ignored): the loads of several macroblocks can be in flight together
+__device__ __forceinline__ BlkMo blk_motion(const FrameCtx &f, cmb_t m, int kind, int k)
 {
 	BlkMo o = {-1, -1, 0, 0, 0, 0};
-	if (m->kind == E264_MB_INTER) {
+	if (f.motion) { // uniform
 		gmotion_t mo = f.motion + (m - f.mbs);
-		o.ref0 = mo->refPic[k >> 2]; o.ref1 = mo->refPic[4 + (k >> 2)];
-		o.mv0x = mo->mvs[k * 2]; o.mv0y = mo->mvs[k * 2 + 1];
-		o.mv1x = mo->mvs[32 + k * 2]; o.mv1y = mo->mvs[32 + k * 2 + 1];
+		const int r0 = mo->refPic[k >> 2], r1 = mo->refPic[4 + (k >> 2)];
+		const uint32_t v0 = *(const gu32 *)&mo->mvs[k * 2], v1 = *(const gu32 *)&mo->mvs[32 + k * 2];
+		const bool inter = kind == E264_MB_INTER;
+		o.ref0 = inter ? r0 : -1; o.ref1 = inter ? r1 : -1;
+		o.mv0x = inter ? (int)(int16_t)(v0 & 0xffff) : 0; o.mv0y = inter ? (int)v0 >> 16 : 0;
+		o.mv1x = inter ? (int)(int16_t)(v1 & 0xffff) : 0; o.mv1y = inter ? (int)v1 >> 16 : 0;
 	}
 	return o;
 }
 __device__ __forceinline__ int far4(int ax, int ay, int bx, int by) { return (abs(ax - bx) >= 4) | (abs(ay - by) >= 4); }
 
 __device__ __forceinline__ int mb_bs_lane(const FrameCtx &f, cmb_t m, int lane)
-{ // lane -> (dir, edge, segment); edge264_deblock.c:958-1118
+{ // lane -> (dir, edge, segment); edge264_deblock.c:958-1118.  No early exits: every load is unconditional.
 	const int dir = lane >> 4 & 1, e = lane >> 2 & 3, sg = lane & 3;
-	const bool intra = m->kind != E264_MB_INTER;
-	cmb_t n = m;
-	if (e == 0) {
-		if (!(m->flags & (dir ? E264_MBF_EDGE_TOP : E264_MBF_EDGE_LEFT)))
-			return 0;
-		n = dir ? m - f.wm : m - 1;
-	} else if ((m->flags & E264_MBF_T8x8) && (e & 1)) {
-		return 0;
-	}
-	if (e == 0 && (intra || n->kind != E264_MB_INTER)) return 4;
-	if (intra) return 3;
-	int kq = dir ? blk_of(sg, e) : blk_of(e, sg);
-	int kp = dir ? blk_of(sg, (e + 3) & 3) : blk_of((e + 3) & 3, sg);
-	if ((n->nz_mask >> kp & 1) | (m->nz_mask >> kq & 1)) return 2;
-	BlkMo p = blk_motion(f, n, kp), q = blk_motion(f, m, kq);
+	const uint32_t hdr = *(const gu32 *)m; // kind, flags, qp0, qp1
+	const int kind = hdr & 255, flags = hdr >> 8 & 255;
+	const bool intra = kind != E264_MB_INTER;
+	const bool has_edge = e != 0 || (flags & (dir ? E264_MBF_EDGE_TOP : E264_MBF_EDGE_LEFT));
+	cmb_t n = (e == 0 && has_edge) ? (dir ? m - f.wm : m - 1) : m;
+	const int nkind = n->kind;
+	const int kq = dir ? blk_of(sg, e) : blk_of(e, sg);
+	const int kp = dir ? blk_of(sg, (e + 3) & 3) : blk_of((e + 3) & 3, sg);
+	const int coded = (n->nz_mask >> kp & 1) | (m->nz_mask >> kq & 1);
+	BlkMo p = blk_motion(f, n, nkind, kp), q = blk_motion(f, m, kind, kq);
 	int refs_p = (p.ref0 != q.ref0) | (p.ref1 != q.ref1);
 	int refs_c = (p.ref0 != q.ref1) | (p.ref1 != q.ref0);
 	int mvs_p = far4(p.mv0x, p.mv0y, q.mv0x, q.mv0y) | far4(p.mv1x, p.mv1y, q.mv1x, q.mv1y);
 	int mvs_c = far4(p.mv0x, p.mv0y, q.mv1x, q.mv1y) | far4(p.mv1x, p.mv1y, q.mv0x, q.mv0y);
-	return (refs_p | mvs_p) & (refs_c | mvs_c);
+	const int bmo = (refs_p | mvs_p) & (refs_c | mvs_c);
+	const bool skip8 = e != 0 && (flags & E264_MBF_T8x8) && (e & 1);
+	int bs = coded ? 2 : bmo;
+	bs = intra ? 3 : bs;
+	bs = (e == 0 && (intra || nkind != E264_MB_INTER)) ? 4 : bs;
+	return (!has_edge || skip8) ? 0 : bs;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1222,26 +1260,24 @@ __device__ __forceinline__ int mb_bs_lane(const FrameCtx &f, cmb_t m, int lane)
 //   [32..40] alpha[plane*3 + t], t = 0 internal edges, 1 left MB edge, 2 top MB edge
 //   [41..49] beta, [50..58] indexA (tC0 lookup)          edge264_deblock.c:945-955
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void write_dbk_params(const FrameCtx &f, int mbx, int mby, int lane)
+// alpha / beta / indexA bytes (record bytes 32..58) of macroblock m
+__device__ __forceinline__ int dbk_ab_lane(const FrameCtx &f, cmb_t m, int lane)
 {
-	cmb_t m = f.mbs + mby * f.wm + mbx;
-	gu8 *out = f.dbk + (size_t)(mby * f.wm + mbx) * E264_DBK_BYTES;
-	if (!(m->flags & E264_MBF_DEBLOCK) || m->kind == E264_MB_ABSENT) {
-		if (lane < 16) ((gu32 *)out)[lane] = 0;
-		return;
-	}
-	if (lane < 32) {
-		out[lane] = (uint8_t)mb_bs_lane(f, m, lane);
-	} else if (lane < 59) {
-		cslice_t s = f.slices + m->slice;
-		int idx = lane - 32, what = idx / 9, pt = idx % 9, pl = pt / 3, t = pt % 3;
-		cmb_t n = m;
-		if (t == 1 && (m->flags & E264_MBF_EDGE_LEFT)) n = m - 1;
-		if (t == 2 && (m->flags & E264_MBF_EDGE_TOP)) n = m - f.wm;
-		int qPav = (m->qp[pl] + n->qp[pl] + 1) >> 1;
-		int iA = clip3i(0, 51, qPav + s->FilterOffsetA), iB = clip3i(0, 51, qPav + s->FilterOffsetB);
-		out[lane] = (uint8_t)(what == 0 ? c_alpha[iA] : what == 1 ? c_beta[iB] : iA);
-	}
+	const uint32_t hdr = *(const gu32 *)m;
+	const int flags = hdr >> 8 & 255;
+	cslice_t s = f.slices + m->slice;
+	int idx = lane - 32, what = idx / 9, pt = idx % 9, pl = pt / 3, t = pt % 3;
+	cmb_t n = m;
+	if (t == 1 && (flags & E264_MBF_EDGE_LEFT)) n = m - 1;
+	if (t == 2 && (flags & E264_MBF_EDGE_TOP)) n = m - f.wm;
+	int qPav = (m->qp[pl] + n->qp[pl] + 1) >> 1;
+	int iA = clip3i(0, 51, qPav + s->FilterOffsetA), iB = clip3i(0, 51, qPav + s->FilterOffsetB);
+	return what == 0 ? c_alpha[iA] : what == 1 ? c_beta[iB] : iA;
+}
+__device__ __forceinline__ bool mb_deblocked(cmb_t m)
+{
+	const uint32_t hdr = *(const gu32 *)m;
+	return (hdr >> 8 & E264_MBF_DEBLOCK) && (hdr & 255) != E264_MB_ABSENT;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1597,12 +1633,26 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 		return;
 	WaveLds &L = lds[wave];
 	const bool recon = mode & 1;
-	MbInfo h0 = load_mb(f.mbs + base), h1 = h0, h2 = h0;
+	// headers of the strip: 8 records x 8 dwords, one dword per lane
+	const gu32 *mbs_g = (const gu32 *)(f.payload - f.h->payload_off + f.h->mbs_off);
+	uint32_t hvs[E264_MBPAR_STRIP / 8];
+#pragma unroll
+	for (int g = 0; g < E264_MBPAR_STRIP / 8; g++)
+		hvs[g] = g * 8 + (lane >> 3) < n ? mbs_g[(size_t)(base + g * 8) * 8 + lane] : 0;
+	auto hv_sel = [&](int i) { // header dwords of the group of 8 that holds macroblock i of the strip (i uniform)
+		uint32_t v = hvs[0];
+#pragma unroll
+		for (int g = 1; g < E264_MBPAR_STRIP / 8; g++)
+			v = (i >> 3) == g ? hvs[g] : v;
+		return v;
+	};
+#define HV(i) hv_sel(i)
+	MbInfo h0 = mb_from_lanes(HV(0), 0);
 	McMotion m0, m1, m2;
 	McWindows w0, w1;
 	mc_load_motion(f, base, lane, m0);
 	m1 = m0; m2 = m0;
-	if (n > 1) { h1 = load_mb(f.mbs + base + 1); mc_load_motion(f, base + 1, lane, m1); }
+	if (n > 1) mc_load_motion(f, base + 1, lane, m1);
 	int mby = base / f.wm, mbx = base - mby * f.wm;
 	const int mbx0 = mbx, mby0 = mby;
 	StripOut &O = outs[wave];
@@ -1613,19 +1663,21 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 	for (int i = 0; i < n; i++) {
 		int nx = mbx + 1, ny = mby;
 		if (nx == f.wm) { nx = 0; ny++; }
-		if (i + 2 < n) { h2 = load_mb(f.mbs + base + i + 2); mc_load_motion(f, base + i + 2, lane, m2); }
+		if (i + 2 < n) mc_load_motion(f, base + i + 2, lane, m2);
 		if (recon && h0.kind == E264_MB_INTER)
 		{
 			mc_commit(L, m0, 0, w0, mbx, mby, lane);
 			mc_commit_tail(L, f, m0, 0, mbx, mby, lane);
 		}
 		wave_sync();
+		const int i1 = min(i + 1, n - 1);
+		const MbInfo h1 = mb_from_lanes(HV(i1), i1 & 7);
 		if (recon && i + 1 < n && h1.kind == E264_MB_INTER)
 			mc_issue(f, m1, 0, nx, ny, lane, w1);
 		if (recon && mbpar_mb(L, O, i, f, h0, m0, w0, mbx, mby, lane))
 			staged |= 1u << i;
 		wave_sync();
-		h0 = h1; h1 = h2; m0 = m1; m1 = m2; w0 = w1;
+		h0 = h1; m0 = m1; m1 = m2; w0 = w1;
 		mbx = nx; mby = ny;
 	}
 	strip_flush(O, f, mbx0, mby0, staged, lane);
@@ -1644,14 +1696,29 @@ __global__ __launch_bounds__(256) void e264_dbkparam_kernel(const E264Job *jobs)
 	if (!open_frame(f, jobs[by]) || !f.dbk)
 		return;
 	const int n_mbs = f.wm * f.hm;
-#pragma unroll 1
-	for (int i = 0; i < 4; i++) {
-		const int addr = (bx * 4 + wave) * 4 + i;
-		if (addr >= n_mbs)
-			return;
-		const int mby = addr / f.wm, mbx = addr - mby * f.wm;
-		write_dbk_params(f, mbx, mby, lane);
+	// all loads of the four macroblocks first (independent, they overlap), then the four stores; the two lane
+	// roles (bS: lanes 0..31, alpha/beta/indexA: lanes 32..58) each run their four macroblocks in ONE region
+	const int a0 = (bx * 4 + wave) * 4;
+	int v[4] = {0, 0, 0, 0};
+	if (lane < 32) {
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			cmb_t m = f.mbs + min(a0 + i, n_mbs - 1);
+			const int bs = mb_bs_lane(f, m, lane);
+			v[i] = mb_deblocked(m) ? bs : 0;
+		}
+	} else if (lane < 59) {
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			cmb_t m = f.mbs + min(a0 + i, n_mbs - 1);
+			const int ab = dbk_ab_lane(f, m, lane);
+			v[i] = mb_deblocked(m) ? ab : 0;
+		}
 	}
+#pragma unroll
+	for (int i = 0; i < 4; i++)
+		if (a0 + i < n_mbs)
+			f.dbk[(size_t)(a0 + i) * E264_DBK_BYTES + lane] = (uint8_t)v[i];
 }
 
 template <int NW>
@@ -1670,13 +1737,26 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 		progress[i] = 0;
 	__syncthreads();
 	WaveLds &L = lds[wave];
+	const gu8 *mbs_g = f.payload - f.h->payload_off + f.h->mbs_off; // the E264Mb array through a per-lane (global) pointer
 #pragma unroll 1
 	for (int y = wave; y < f.hm; y += NW) {
+		// the row is scanned 64 macroblocks at a time (one vector load + ballot) instead of one scalar load per
+		// macroblock: in P/B frames, where few macroblocks are intra, the scan WAS the kernel's run time
 #pragma unroll 1
-		for (int x = 0; x < f.wm; x++) {
-			const int kind = f.mbs[y * f.wm + x].kind;
-			const bool intra = kind == E264_MB_I4x4 || kind == E264_MB_I8x8 || kind == E264_MB_I16x16;
-			if (intra) {
+		for (int x0 = 0; x0 < f.wm; x0 += 64) {
+			const int xl = x0 + lane;
+			const int kind = xl < f.wm ? mbs_g[(size_t)(y * f.wm + xl) * sizeof(E264Mb)] : E264_MB_ABSENT;
+			unsigned long long todo = __ballot(kind == E264_MB_I4x4 || kind == E264_MB_I8x8 || kind == E264_MB_I16x16);
+			const int xe = min(x0 + 64, f.wm);
+			if (todo == 0 || (int)__builtin_ctzll(todo) > 0) { // macroblocks before the first intra one need nothing from this kernel
+				const int upto = todo ? x0 + (int)__builtin_ctzll(todo) : xe;
+				if (lane == 0)
+					__hip_atomic_store(&progress[y], upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+#pragma unroll 1
+			while (todo) {
+				const int x = x0 + (int)__builtin_ctzll(todo);
+				todo &= todo - 1;
 				if (y > 0) {
 					int want = min(x + 2, f.wm);
 					while (lds_load_relaxed(&progress[y - 1]) < want)
@@ -1685,9 +1765,11 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 				}
 				recon_mb<2>(L, f, x, y, lane);
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				// finished: everything up to the next intra macroblock of the chunk (or the chunk's end)
+				const int upto = todo ? x0 + (int)__builtin_ctzll(todo) : xe;
+				if (lane == 0)
+					__hip_atomic_store(&progress[y], upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
-			if (lane == 0 && (intra || x == f.wm - 1 || (x & 7) == 7))
-				__hip_atomic_store(&progress[y], x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 	}
 }
@@ -1777,8 +1859,10 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 	if (marks) hipEventRecord(marks[1], stream);
 	hipLaunchKernelGGL(e264_mbpar_kernel, dim3((max_mbs + 4 * E264_MBPAR_STRIP - 1) / (4 * E264_MBPAR_STRIP), n_jobs), dim3(256), 0, stream, jobs, mode);
 	if (marks) hipEventRecord(marks[2], stream);
+	const int intra_waves = waves >> 8 ? waves >> 8 : waves & 255;
+	waves &= 255;
 	if (mode & 1) {
-		switch (waves) {
+		switch (intra_waves) {
 		case 4: hipLaunchKernelGGL(e264_intra_kernel<4>, dim3(n_jobs), dim3(256), 0, stream, jobs); break;
 		case 16: hipLaunchKernelGGL(e264_intra_kernel<16>, dim3(n_jobs), dim3(1024), 0, stream, jobs); break;
 		default: hipLaunchKernelGGL(e264_intra_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs); break;

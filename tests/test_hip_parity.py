@@ -108,3 +108,4 @@ def test_waves_per_frame(device, oracle, waves):
         run_stream(device, oracle, 4, "IPP", dict(), 26, 2 * waves * 2 + 3)
     finally:
         device.set_option("waves", prev)
+        device.set_option("intra_waves", 16)  # "waves" sets both kernels; the intra default is 16
