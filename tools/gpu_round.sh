@@ -12,15 +12,15 @@ timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err;
 cat $OUT/bench_default.json
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_kt -- python $REPO/bench.py --no-cpu-baseline --no-verify > $OUT/bench_kt.json 2> $OUT/bench_kt.err; echo "kt rc=$?"
-timeout 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify > $OUT/bench_pmc_fetch.json 2> $OUT/bench_pmc_fetch.err; echo "fetch rc=$?"
-timeout 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify > $OUT/bench_pmc_write.json 2> $OUT/bench_pmc_write.err; echo "write rc=$?"
+timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B -d $OUT/pmc_fetch -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify > $OUT/bench_pmc_fetch.json 2> $OUT/bench_pmc_fetch.err; echo "fetch rc=$?"
+timeout 600 rocprofv3 --pmc TCC_EA0_WRREQ TCC_EA0_WRREQ_64B -d $OUT/pmc_write -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify > $OUT/bench_pmc_write.json 2> $OUT/bench_pmc_write.err; echo "write rc=$?"
 cd $REPO
 KT=$(find $OUT/prof_kt -name '*.db' | head -1)
 FE=$(find $OUT/pmc_fetch -name '*.db' | head -1)
 WR=$(find $OUT/pmc_write -name '*.db' | head -1)
 python tools/rocprof_summary.py $KT > $OUT/kernel_stats.txt 2>&1; cat $OUT/kernel_stats.txt
 find $OUT/prof_kt -name '*stats*.csv' | head; 
-python tools/pmc_summary.py $FE $WR --traffic $OUT/hbm_traffic.json --streams 256 --gop IPPPPPPP > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summary.txt
+python tools/pmc_summary.py $FE $WR --traffic $OUT/hbm_traffic.json --streams 256 --gop IPPPPPPP > $OUT/pmc_summary.txt 2>&1; grep -v 'LEVEL\|_DRAM' $OUT/pmc_summary.txt
 du -sh $OUT
 # keep the merge small: databases are summarised above
 find $OUT -name '*.db' -size +20M -delete
