@@ -514,76 +514,92 @@ __device__ __forceinline__ int centre6(int t0, int t1, int t2, int t3, int t4, i
 }
 __device__ __forceinline__ int avg2(int a, int b) { return (a + b + 1) >> 1; }
 
-// 4 horizontally adjacent luma samples displaced by the quarter-pel (xF,yF): 8.4.2.2.1 as organised
-// by decode_inter_luma (edge264_inter.c:416-968), but BRANCH-FREE over the 16 fractional positions so
-// that the lanes of a wave (which may hold 16 different vectors) never diverge.  d[r][0..2] hold the 9
-// samples x-2..x+6 of row y-2+r (already byte-aligned).  Every lane forms the horizontal taps of the
-// 6 rows and the vertical taps of the 9 columns, then selects.
-// UNIFORM: the whole macroblock has one vector (16x16 / skip), so (xF,yF) are wave-uniform and only the taps
-// that position needs are computed; otherwise every lane forms everything and selects.
-template <bool UNIFORM>
+// 4 horizontally adjacent luma samples displaced by the quarter-pel (xF,yF): 8.4.2.2.1 as organised by
+// decode_inter_luma (edge264_inter.c:416-968).  d[r][0..2] hold the 9 samples x-2..x+6 of row y-2+r (already
+// byte-aligned).  The work is split in blocks guarded by PER-LANE conditions; the compiler turns them into
+// EXEC-masked regions that are skipped when no lane of the wave needs them, so a macroblock with one vector
+// pays only for the taps of its fractional position and a wave with several vectors pays for the union:
+//   G  integer sample                                    (always; 6 ops)
+//   b  horizontal half sample of row 2 or 3              (yF==0 | both odd)
+//   h  vertical half sample of column 2 or 3             (xF==0 | both odd)
+//   jH centre from the horizontal taps of 6 rows (+ b)   (xF==2, yF!=0)   inter.c:611-646, 779-802, 929-966
+//   jV centre from the vertical taps of 9 columns (+ h)  (xF odd, yF==2)  inter.c:559-609, 741-777, 887-927
+// 16-bit intermediates of the centre wrap as in the reference (sixtapHV, inter.c:4-9).
+__device__ __forceinline__ void unpack9(const uint32_t w[3], int px[9])
+{
+	px[0] = w[0] & 255; px[1] = w[0] >> 8 & 255; px[2] = w[0] >> 16 & 255; px[3] = w[0] >> 24;
+	px[4] = w[1] & 255; px[5] = w[1] >> 8 & 255; px[6] = w[1] >> 16 & 255; px[7] = w[1] >> 24;
+	px[8] = w[2] & 255;
+}
 __device__ __forceinline__ void luma_from_rows(const uint32_t d[6][3], int xF, int yF, int out[4])
 {
-	int Hc[6][4], V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, G[4] = {0, 0, 0, 0};
-	const int cw[6] = {1, -5, 20, 20, -5, 1};
-	const int grow = yF == 3 ? 3 : 2;
 	const bool xo = xF & 1, yo = yF & 1;
 	const bool uses_j = (xF == 2 && yF != 0) || (yF == 2 && xF != 0);
 	const bool uses_G = (xF == 0 || yF == 0) && (xo || yo || (xF | yF) == 0);
 	const bool uses_b = (yF == 0 && xF != 0) || (xo && yo) || (xF == 2 && yo);
 	const bool uses_h = (xF == 0 && yF != 0) || (xo && yo) || (yF == 2 && xo);
-	// WAVE-UNIFORM work selection: a macroblock with one vector (the common case) only pays for the
-	// taps its fractional position needs; a wave with mixed vectors pays for the union.
-	bool nJH = true, nJV = true, nHmid = true, nVmid = true;
-	if (UNIFORM || E264_LUMA_SKIP) {
-		nJH = __any(uses_j && xF == 2);      // centre from the horizontal taps of 6 rows
-		nJV = __any(uses_j && xF != 2);      // centre from the vertical taps of 9 columns
-		nHmid = __any(uses_b) || nJH;        // horizontal taps of rows 2,3
-		nVmid = __any(uses_h) || nJV;        // vertical taps of columns 2..6
+	const bool jH = uses_j && xF == 2, jV = uses_j && xF != 2;
+	const bool row3 = yF == 3, col3 = xF == 3;
+	int G[4], b[4] = {0, 0, 0, 0}, h[4] = {0, 0, 0, 0}, j[4] = {0, 0, 0, 0};
+	{ // integer sample: row 2 (3 when yF==3), columns 2..5 (3..6 when xF==3)
+		const uint32_t w0 = row3 ? d[3][0] : d[2][0], w1 = row3 ? d[3][1] : d[2][1];
+		const uint32_t g4 = col3 ? __builtin_amdgcn_alignbyte(w1, w0, 3) : __builtin_amdgcn_alignbyte(w1, w0, 2);
+		G[0] = g4 & 255; G[1] = g4 >> 8 & 255; G[2] = g4 >> 16 & 255; G[3] = g4 >> 24;
 	}
+	if (jH) {
+		int Hc[6][4];
 #pragma unroll
-	for (int r = 0; r < 6; r++) {
-		const bool mid = r == 2 || r == 3;
-#pragma unroll
-		for (int i = 0; i < 4; i++) Hc[r][i] = 0;
-		if (mid || nVmid || nJH) {
+		for (int r = 0; r < 6; r++) {
 			int px[9];
-			px[0] = d[r][0] & 255; px[1] = d[r][0] >> 8 & 255; px[2] = d[r][0] >> 16 & 255; px[3] = d[r][0] >> 24;
-			px[4] = d[r][1] & 255; px[5] = d[r][1] >> 8 & 255; px[6] = d[r][1] >> 16 & 255; px[7] = d[r][1] >> 24;
-			px[8] = d[r][2] & 255;
-			if (mid ? nHmid : nJH) {
+			unpack9(d[r], px);
 #pragma unroll
-				for (int i = 0; i < 4; i++)
-					Hc[r][i] = tap6(px[i], px[i + 1], px[i + 2], px[i + 3], px[i + 4], px[i + 5]);
-			}
-			if (nVmid) {
-#pragma unroll
-				for (int c = 2; c < 7; c++)
-					V[c] += cw[r] * px[c];
-				if (nJV) {
-					V[0] += cw[r] * px[0]; V[1] += cw[r] * px[1]; V[7] += cw[r] * px[7]; V[8] += cw[r] * px[8];
-				}
-			}
-			if (mid) {
-#pragma unroll
-				for (int i = 0; i < 4; i++)
-					G[i] = (r == grow) ? (xF == 3 ? px[i + 3] : px[i + 2]) : G[i];
-			}
+			for (int i = 0; i < 4; i++)
+				Hc[r][i] = tap6(px[i], px[i + 1], px[i + 2], px[i + 3], px[i + 4], px[i + 5]);
 		}
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			j[i] = centre6(Hc[0][i], Hc[1][i], Hc[2][i], Hc[3][i], Hc[4][i], Hc[5][i]);
+			b[i] = clip255(((row3 ? Hc[3][i] : Hc[2][i]) + 16) >> 5);
+		}
+	} else if (uses_b) {
+		const uint32_t w[3] = {row3 ? d[3][0] : d[2][0], row3 ? d[3][1] : d[2][1], row3 ? d[3][2] : d[2][2]};
+		int px[9];
+		unpack9(w, px);
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+			b[i] = clip255((tap6(px[i], px[i + 1], px[i + 2], px[i + 3], px[i + 4], px[i + 5]) + 16) >> 5);
+	}
+	if (jV) {
+		int V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+		const int cw[6] = {1, -5, 20, 20, -5, 1};
+#pragma unroll
+		for (int r = 0; r < 6; r++) {
+			int px[9];
+			unpack9(d[r], px);
+#pragma unroll
+			for (int c = 0; c < 9; c++)
+				V[c] += cw[r] * px[c];
+		}
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			j[i] = centre6(V[i], V[i + 1], V[i + 2], V[i + 3], V[i + 4], V[i + 5]);
+			h[i] = clip255(((col3 ? V[i + 3] : V[i + 2]) + 16) >> 5);
+		}
+	} else if (uses_h) {
+		int c4[6][4];
+#pragma unroll
+		for (int r = 0; r < 6; r++) {
+			const uint32_t g4 = col3 ? __builtin_amdgcn_alignbyte(d[r][1], d[r][0], 3) : __builtin_amdgcn_alignbyte(d[r][1], d[r][0], 2);
+			c4[r][0] = g4 & 255; c4[r][1] = g4 >> 8 & 255; c4[r][2] = g4 >> 16 & 255; c4[r][3] = g4 >> 24;
+		}
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+			h[i] = clip255((tap6(c4[0][i], c4[1][i], c4[2][i], c4[3][i], c4[4][i], c4[5][i]) + 16) >> 5);
 	}
 #pragma unroll
 	for (int i = 0; i < 4; i++) {
-		int hsel = yF == 3 ? Hc[3][i] : Hc[2][i];
-		int vsel = xF == 3 ? V[i + 3] : V[i + 2];
-		int b = clip255((hsel + 16) >> 5), h = clip255((vsel + 16) >> 5);
-		// centre: horizontal-then-vertical when xF == 2 (inter.c:611-646, 779-802, 929-966), vertical-then-horizontal
-		// otherwise (inter.c:559-609, 741-777, 887-927); 16-bit intermediates wrap as in the reference
-		int j = 0;
-		if (nJH || nJV)
-			j = centre6(xF == 2 ? Hc[0][i] : V[i], xF == 2 ? Hc[1][i] : V[i + 1], xF == 2 ? Hc[2][i] : V[i + 2],
-				xF == 2 ? Hc[3][i] : V[i + 3], xF == 2 ? Hc[4][i] : V[i + 4], xF == 2 ? Hc[5][i] : V[i + 5]);
-		int op1 = uses_j ? j : uses_G ? G[i] : uses_b ? b : h;
-		int op2 = uses_h ? h : uses_b ? b : uses_j ? j : G[i];
+		int op1 = uses_j ? j[i] : uses_G ? G[i] : uses_b ? b[i] : h[i];
+		int op2 = uses_h ? h[i] : uses_b ? b[i] : uses_j ? j[i] : G[i];
 		out[i] = avg2(op1, op2);
 	}
 }
@@ -781,8 +797,7 @@ __device__ __forceinline__ void mc_compute(WaveLds &L, const FrameCtx &f, cslice
 			d[rr][2] = w2 >> (sh * 8);
 		}
 		int p[4];
-		if (G.S == 16) luma_from_rows<true>(d, G.mx & 3, G.my & 3, p);
-		else luma_from_rows<false>(d, G.mx & 3, G.my & 3, p);
+		luma_from_rows(d, G.mx & 3, G.my & 3, p);
 		const int refIdxX = ref_byte(M.refs[2 + (l ^ 1)], k >> 2);
 		if (idc == 0 && !(l == 1 && refIdxX >= 0)) {
 #pragma unroll
@@ -1295,6 +1310,8 @@ __device__ __forceinline__ void edge_filter(int &p3, int &p2, int &p1, int &p0, 
 {
 	const int dpq = abs(p0 - q0);
 	const bool go = (bS != 0) & (dpq < alpha) & (abs(p1 - p0) < beta) & (abs(q1 - q0) < beta);
+	if (!go) // filterSamplesFlag (8.7.2.3): per-lane; the region below is skipped when no line of the wave passes
+		return;
 	const bool ap = !chroma & (abs(p2 - p0) < beta), aq = !chroma & (abs(q2 - q0) < beta);
 	// bS < 4
 	const int tc = tc0 + (chroma ? 1 : (int)ap + (int)aq);
@@ -1314,19 +1331,17 @@ __device__ __forceinline__ void edge_filter(int &p3, int &p2, int &p1, int &p0, 
 		const int s_q0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (2 * q1 + q0 + p1 + 2) >> 2;
 		const int s_q1 = (p0 + q0 + q1 + q2 + 2) >> 2;
 		const int s_q2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
-		const bool m_p1 = go & (strong ? sp : ap), m_q1 = go & (strong ? sq : aq);
-		const int n_p0 = strong ? s_p0 : w_p0, n_q0 = strong ? s_q0 : w_q0;
-		p0 = go ? n_p0 : p0;
-		q0 = go ? n_q0 : q0;
-		p1 = m_p1 ? (strong ? s_p1 : w_p1) : p1;
-		q1 = m_q1 ? (strong ? s_q1 : w_q1) : q1;
-		p2 = (go & strong & sp) ? s_p2 : p2;
-		q2 = (go & strong & sq) ? s_q2 : q2;
+		p0 = strong ? s_p0 : w_p0;
+		q0 = strong ? s_q0 : w_q0;
+		p1 = (strong ? sp : ap) ? (strong ? s_p1 : w_p1) : p1;
+		q1 = (strong ? sq : aq) ? (strong ? s_q1 : w_q1) : q1;
+		p2 = (strong & sp) ? s_p2 : p2;
+		q2 = (strong & sq) ? s_q2 : q2;
 	} else {
-		p0 = go ? w_p0 : p0;
-		q0 = go ? w_q0 : q0;
-		p1 = (go & ap) ? w_p1 : p1;
-		q1 = (go & aq) ? w_q1 : q1;
+		p0 = w_p0;
+		q0 = w_q0;
+		p1 = ap ? w_p1 : p1;
+		q1 = aq ? w_q1 : q1;
 	}
 }
 
