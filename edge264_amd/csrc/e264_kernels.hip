@@ -748,8 +748,8 @@ __device__ __forceinline__ void mc_commit(WaveLds &L, const McMotion &M, int l, 
 {
 	if (M.refs[l] == 0xffffffffu)
 		return;
-	McGeom G = mc_geom(M, l, lane, mbx, mby);
-	const int total = G.S == 16 ? 126 : G.S == 8 ? 208 : 432;
+	const int S = (M.S >> (8 * l)) & 255;
+	const int total = S == 16 ? 126 : S == 8 ? 208 : 432;
 	if (lane < total) L.win[lane] = Wn.y0;
 	if (64 + lane < total) L.win[64 + lane] = Wn.y1;
 	if (128 + lane < total) L.win[128 + lane] = Wn.y2;
@@ -845,7 +845,8 @@ __device__ __forceinline__ bool mbpar_mb(WaveLds &L, StripOut &O, int slot, cons
 		return true;
 	}
 	cslice_t s = f.slices + m.slice;
-	if (!(f.dbg & 1024)) compute_residual(L, f, m, s, pl, lane);
+	const bool has_res = m.coded != 0 && !(f.dbg & 1024); // uniform; most inter macroblocks carry no residual
+	if (has_res) compute_residual(L, f, m, s, pl, lane);
 	int pY[4] = {0, 0, 0, 0}, pC[2] = {0, 0};
 	mc_compute(L, f, s, M, 0, Wn, mbx, mby, lane, pY, pC); // list 0: window already in LDS (prefetched)
 	if (M.refs[1] != 0xffffffffu) { // list 1 (B macroblocks): fetched here, not pipelined
@@ -857,13 +858,16 @@ __device__ __forceinline__ bool mbpar_mb(WaveLds &L, StripOut &O, int slot, cons
 		wave_sync();
 		mc_compute(L, f, s, M, 1, W1, mbx, mby, lane, pY, pC);
 	}
-	// add residual, clip, store (int16 wrap add then packus: residual.c:160-171)
-	const int16_t *rr = L.res + Yr * 16 + X;
-	const uint32_t outw = (uint32_t)clip255(w16(pY[0] + rr[0])) | (uint32_t)clip255(w16(pY[1] + rr[1])) << 8 |
-		(uint32_t)clip255(w16(pY[2] + rr[2])) << 16 | (uint32_t)clip255(w16(pY[3] + rr[3])) << 24;
-	O.y[slot][Yr * 4 + (X >> 2)] = outw;
-	const int16_t *rc = L.res + 256 + cpl * 64 + cy * 8 + cx;
-	*oc = (uint16_t)(clip255(w16(pC[0] + rc[0])) | clip255(w16(pC[1] + rc[1])) << 8);
+	if (has_res) { // add residual, clip (int16 wrap add then packus: residual.c:160-171)
+		const int16_t *rr = L.res + Yr * 16 + X;
+		const int16_t *rc = L.res + 256 + cpl * 64 + cy * 8 + cx;
+#pragma unroll
+		for (int i = 0; i < 4; i++) pY[i] = clip255(w16(pY[i] + rr[i]));
+		pC[0] = clip255(w16(pC[0] + rc[0])); pC[1] = clip255(w16(pC[1] + rc[1]));
+	}
+	// the predictions are already within 0..255
+	O.y[slot][Yr * 4 + (X >> 2)] = (uint32_t)pY[0] | (uint32_t)pY[1] << 8 | (uint32_t)pY[2] << 16 | (uint32_t)pY[3] << 24;
+	*oc = (uint16_t)(pC[0] | pC[1] << 8);
 	return true;
 }
 
