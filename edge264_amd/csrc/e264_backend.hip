@@ -84,7 +84,7 @@ API int e264hip_device_open(int ordinal, E264Device **out)
 	E264Device *d = new (std::nothrow) E264Device();
 	if (!d) return fail(ENOMEM, "device object");
 	d->ordinal = ordinal;
-	d->waves = 8;
+	d->waves = 12; // 24 macroblock rows in flight: 1080p = 3 rounds (8 waves: 5 rounds); fits 168 VGPRs with a few spills, still faster
 	d->intra_waves = 16; // 16 rows in flight: 1.6 -> 1.1 ms per 256-frame launch (the intra kernel fits 128 VGPRs)
 	d->dbg_mode = 0;
 	d->ktiming = false; d->kev_used = 0;
@@ -133,6 +133,7 @@ API int e264hip_set_option(E264Device *dev, const char *name, int value)
 	if (!strcmp(name, "waves")) {
 		int prev = dev->waves;
 		if (value == 4 || value == 8 || value == 16) dev->waves = dev->intra_waves = value;
+		else if (value == 9 || value == 10 || value == 12) dev->waves = value; // deblocking kernel only
 		return prev;
 	}
 	return -1;

@@ -1890,6 +1890,9 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 	if (marks) hipEventRecord(marks[3], stream);
 	if (mode & 2) {
 		switch (waves) {
+		case 9: hipLaunchKernelGGL(e264_deblock_kernel<9>, dim3(n_jobs), dim3(576), 0, stream, jobs); break;
+		case 10: hipLaunchKernelGGL(e264_deblock_kernel<10>, dim3(n_jobs), dim3(640), 0, stream, jobs); break;
+		case 12: hipLaunchKernelGGL(e264_deblock_kernel<12>, dim3(n_jobs), dim3(768), 0, stream, jobs); break;
 		case 4: hipLaunchKernelGGL(e264_deblock_kernel<4>, dim3(n_jobs), dim3(256), 0, stream, jobs); break;
 		case 16: hipLaunchKernelGGL(e264_deblock_kernel<16>, dim3(n_jobs), dim3(1024), 0, stream, jobs); break;
 		default: hipLaunchKernelGGL(e264_deblock_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs); break;

@@ -98,7 +98,7 @@ def test_odd_geometry(device, oracle):
         run_stream(device, oracle, 7, "IPB", dict(t8x8=True, i_kinds=ALL_I, mv_range=100), w, h)
 
 
-@pytest.mark.parametrize("waves", [4, 8, 16])
+@pytest.mark.parametrize("waves", [4, 8, 9, 10, 12, 16])
 def test_waves_per_frame(device, oracle, waves):
     """Frames wider than the LDS hand-off ring and taller than one round of row pairs
     (2 x waves rows): exercises ring wrap, back-pressure and the cross-round hand-off."""
