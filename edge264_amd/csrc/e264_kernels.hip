@@ -1628,6 +1628,9 @@ static __device__ __forceinline__ void xcd_tile(int &bx, int &by)
 
 // every macroblock of every frame in parallel: 4 waves per workgroup, a strip of E264_MBPAR_STRIP
 // consecutive macroblocks per wave, software pipelined (see "Inter prediction" above)
+#ifdef E264_MBPAR_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(E264_MBPAR_WAVES_PER_EU, E264_MBPAR_WAVES_PER_EU)))
+#endif
 __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, int mode)
 {
 	__shared__ WaveLds lds[4];
