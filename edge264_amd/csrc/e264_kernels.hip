@@ -1462,26 +1462,21 @@ __device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, DbkStage 
 	}
 	wave_sync();
 	int v[20];
-	int bV[4], bH[4], tV[4], tH[4];
-	int a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
+	const int seg = chroma ? li >> 1 : li >> 2;
 	if (r.on) {
-		// ---- per-lane parameters: bS of the 8 edges crossing this line, alpha/beta/indexA -----
-		const int seg = chroma ? li >> 1 : li >> 2;
+		// ---- per-lane parameters of the VERTICAL edges crossing this line (those of the horizontal edges are
+		// fetched after the vertical pass: fewer live registers) -------------------------------------------
+		int bV[4], tV[4];
 #pragma unroll
-		for (int e = 0; e < 4; e++) { bV[e] = L.prm[e * 4 + seg]; bH[e] = L.prm[16 + e * 4 + seg]; }
+		for (int e = 0; e < 4; e++) bV[e] = L.prm[e * 4 + seg];
 		if (!r.hasL) bV[0] = 0;
-		if (!r.hasT) bH[0] = 0;
-		if (chroma || r.t8) { bV[1] = bV[3] = 0; bH[1] = bH[3] = 0; }
-		a0 = L.prm[32 + pl * 3]; a1 = L.prm[32 + pl * 3 + 1]; a2 = L.prm[32 + pl * 3 + 2];
-		b0 = L.prm[41 + pl * 3]; b1 = L.prm[41 + pl * 3 + 1]; b2 = L.prm[41 + pl * 3 + 2];
-		const int i0 = L.prm[50 + pl * 3], i1 = L.prm[50 + pl * 3 + 1], i2 = L.prm[50 + pl * 3 + 2];
+		if (chroma || r.t8) bV[1] = bV[3] = 0;
+		const int a0 = L.prm[32 + pl * 3], a1 = L.prm[32 + pl * 3 + 1];
+		const int b0 = L.prm[41 + pl * 3], b1 = L.prm[41 + pl * 3 + 1];
+		const int i0 = L.prm[50 + pl * 3], i1 = L.prm[50 + pl * 3 + 1];
 #pragma unroll
-		for (int e = 0; e < 4; e++) {
-			int bv = bV[e], bh = bH[e];
-			// tc0tab has a zero row for bS 0 and 4 (index (bS & 3) when bS < 4 ... see kernel prologue)
-			tV[e] = tc0tab[(bv & 3) * 52 + (e ? i0 : i1)] & (bv < 4 ? 255 : 0);
-			tH[e] = tc0tab[(bh & 3) * 52 + (e ? i0 : i2)] & (bh < 4 ? 255 : 0);
-		}
+		for (int e = 0; e < 4; e++) // tc0tab has a zero row for bS 0 and 4 (index bS & 3; see kernel prologue)
+			tV[e] = tc0tab[(bV[e] & 3) * 52 + (e ? i0 : i1)] & (bV[e] < 4 ? 255 : 0);
 		// ---- vertical edges: this lane owns ROW li ----------------------------------------
 		if (!chroma) {
 #pragma unroll
@@ -1510,6 +1505,17 @@ __device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, DbkStage 
 	wave_sync();
 	if (r.on) {
 		// ---- horizontal edges: this lane owns COLUMN li -----------------------------------
+		int bH[4], tH[4];
+#pragma unroll
+		for (int e = 0; e < 4; e++) bH[e] = L.prm[16 + e * 4 + seg];
+		if (!r.hasT) bH[0] = 0;
+		if (chroma || r.t8) bH[1] = bH[3] = 0;
+		const int a0 = L.prm[32 + pl * 3], a2 = L.prm[32 + pl * 3 + 2];
+		const int b0 = L.prm[41 + pl * 3], b2 = L.prm[41 + pl * 3 + 2];
+		const int i0 = L.prm[50 + pl * 3], i2 = L.prm[50 + pl * 3 + 2];
+#pragma unroll
+		for (int e = 0; e < 4; e++)
+			tH[e] = tc0tab[(bH[e] & 3) * 52 + (e ? i0 : i2)] & (bH[e] < 4 ? 255 : 0);
 		if (!chroma) {
 #pragma unroll
 			for (int i = 0; i < 20; i++) v[i] = L.DYT(i - 4, li);
