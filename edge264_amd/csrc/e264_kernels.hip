@@ -1255,7 +1255,10 @@ __device__ __forceinline__ int mb_bs_lane(const FrameCtx &f, cmb_t m, int lane)
 	const int kind = hdr & 255, flags = hdr >> 8 & 255;
 	const bool intra = kind != E264_MB_INTER;
 	const bool has_edge = e != 0 || (flags & (dir ? E264_MBF_EDGE_TOP : E264_MBF_EDGE_LEFT));
-	cmb_t n = (e == 0 && has_edge) ? (dir ? m - f.wm : m - 1) : m;
+	// the neighbour record is addressed from the lane's role alone (index clamped into the array), NOT from the
+	// flags just loaded: all loads of the macroblock then form a single round trip; has_edge gates the result
+	const int mi = (int)(m - f.mbs);
+	cmb_t n = e == 0 ? f.mbs + max(mi - (dir ? f.wm : 1), 0) : m;
 	const int nkind = n->kind;
 	const int kq = dir ? blk_of(sg, e) : blk_of(e, sg);
 	const int kp = dir ? blk_of(sg, (e + 3) & 3) : blk_of((e + 3) & 3, sg);
@@ -1286,10 +1289,11 @@ __device__ __forceinline__ int dbk_ab_lane(const FrameCtx &f, cmb_t m, int lane)
 	const int flags = hdr >> 8 & 255;
 	cslice_t s = f.slices + m->slice;
 	int idx = lane - 32, what = idx / 9, pt = idx % 9, pl = pt / 3, t = pt % 3;
-	cmb_t n = m;
-	if (t == 1 && (flags & E264_MBF_EDGE_LEFT)) n = m - 1;
-	if (t == 2 && (flags & E264_MBF_EDGE_TOP)) n = m - f.wm;
-	int qPav = (m->qp[pl] + n->qp[pl] + 1) >> 1;
+	const int mi = (int)(m - f.mbs);
+	cmb_t nb = t == 0 ? m : f.mbs + max(mi - (t == 2 ? f.wm : 1), 0); // addressed without waiting for the flags
+	const int qn = nb->qp[pl], qm = m->qp[pl];
+	const bool use_nb = (t == 1 && (flags & E264_MBF_EDGE_LEFT)) || (t == 2 && (flags & E264_MBF_EDGE_TOP));
+	int qPav = (qm + (use_nb ? qn : qm) + 1) >> 1;
 	int iA = clip3i(0, 51, qPav + s->FilterOffsetA), iB = clip3i(0, 51, qPav + s->FilterOffsetB);
 	return what == 0 ? c_alpha[iA] : what == 1 ? c_beta[iB] : iA;
 }
@@ -1724,29 +1728,32 @@ __global__ __launch_bounds__(256) void e264_dbkparam_kernel(const E264Job *jobs)
 	if (!open_frame(f, jobs[by]) || !f.dbk)
 		return;
 	const int n_mbs = f.wm * f.hm;
-	// all loads of the four macroblocks first (independent, they overlap), then the four stores; the two lane
-	// roles (bS: lanes 0..31, alpha/beta/indexA: lanes 32..58) each run their four macroblocks in ONE region
+	// 4 macroblocks per wave, TWO per instruction: lanes 0..31 serve macroblock 2*it, lanes 32..63 macroblock
+	// 2*it+1 -- first the 32 bS bytes of each, then the 27 alpha/beta/indexA bytes.  All loads are issued
+	// before the stores (independent, they overlap).
 	const int a0 = (bx * 4 + wave) * 4;
-	int v[4] = {0, 0, 0, 0};
-	if (lane < 32) {
+	const int hl = lane & 31, hi = lane >> 5;
+	int bs[2], ab[2];
 #pragma unroll
-		for (int i = 0; i < 4; i++) {
-			cmb_t m = f.mbs + min(a0 + i, n_mbs - 1);
-			const int bs = mb_bs_lane(f, m, lane);
-			v[i] = mb_deblocked(m) ? bs : 0;
-		}
-	} else if (lane < 59) {
-#pragma unroll
-		for (int i = 0; i < 4; i++) {
-			cmb_t m = f.mbs + min(a0 + i, n_mbs - 1);
-			const int ab = dbk_ab_lane(f, m, lane);
-			v[i] = mb_deblocked(m) ? ab : 0;
-		}
+	for (int it = 0; it < 2; it++) {
+		cmb_t m = f.mbs + min(a0 + 2 * it + hi, n_mbs - 1);
+		const int v = mb_bs_lane(f, m, hl);
+		bs[it] = mb_deblocked(m) ? v : 0;
 	}
 #pragma unroll
-	for (int i = 0; i < 4; i++)
-		if (a0 + i < n_mbs)
-			f.dbk[(size_t)(a0 + i) * E264_DBK_BYTES + lane] = (uint8_t)v[i];
+	for (int it = 0; it < 2; it++) {
+		cmb_t m = f.mbs + min(a0 + 2 * it + hi, n_mbs - 1);
+		const int v = hl < 27 ? dbk_ab_lane(f, m, 32 + hl) : 0;
+		ab[it] = mb_deblocked(m) ? v : 0;
+	}
+#pragma unroll
+	for (int it = 0; it < 2; it++) {
+		const int addr = a0 + 2 * it + hi;
+		if (addr < n_mbs) {
+			f.dbk[(size_t)addr * E264_DBK_BYTES + hl] = (uint8_t)bs[it];
+			f.dbk[(size_t)addr * E264_DBK_BYTES + 32 + hl] = (uint8_t)ab[it];
+		}
+	}
 }
 
 template <int NW>
