@@ -1671,6 +1671,16 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 #pragma unroll
 	for (int g = 0; g < E264_MBPAR_STRIP / 8; g++)
 		hvs[g] = g * 8 + (lane >> 3) < n ? mbs_g[(size_t)(base + g * 8) * 8 + lane] : 0;
+	{ // nothing for this kernel in the strip (all intra / absent: every strip of an I frame)? leave at once
+		bool mine = false;
+#pragma unroll
+		for (int g = 0; g < E264_MBPAR_STRIP / 8; g++) {
+			const int kind = hvs[g] & 255;
+			mine |= (lane & 7) == 0 && g * 8 + (lane >> 3) < n && (kind == E264_MB_INTER || kind == E264_MB_PCM);
+		}
+		if (!__any(mine))
+			return;
+	}
 	auto hv_sel = [&](int i) { // header dwords of the group of 8 that holds macroblock i of the strip (i uniform)
 		uint32_t v = hvs[0];
 #pragma unroll
