@@ -56,11 +56,16 @@ def main() -> int:
     ap.add_argument("--debug-mode", type=int, default=0, help="profiling ablation bits (results are then wrong on purpose)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): libraries that chat on fd 1 (the RCCL version banner) go to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     from edge264_amd.sharding import rank_info, reduce_elapsed, shard_streams
     rank, local_rank, world = rank_info()
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("E264_FORCE_DIST"):  # E264_FORCE_DIST: exercise the RCCL path on one GPU
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -231,7 +236,7 @@ def main() -> int:
             "bit_exact": bit_exact,
             "gpu_event_ms_per_step": round(ev_ms / args.steps, 3),
         }
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     for st in streams:
         st.close()
     for dv in devs:

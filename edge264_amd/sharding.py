@@ -24,7 +24,7 @@ def shard_streams(n_streams: int, rank: int, world: int) -> range:
 
 def reduce_elapsed(elapsed: float, frames: int, dist=None, device=None) -> tuple[float, int]:
     """max over ranks of the elapsed time, sum over ranks of the frames processed."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return elapsed, frames
     import torch
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
