@@ -98,6 +98,19 @@ def test_odd_geometry(device, oracle):
         run_stream(device, oracle, 7, "IPB", dict(t8x8=True, i_kinds=ALL_I, mv_range=100), w, h)
 
 
+def test_padded_strides(device, oracle):
+    """Frames whose strides carry the reference's anti-aliasing padding (src/edge264_headers.c:2032-2041):
+    2048 luma samples wide -> stride_Y + 16; 4096 wide -> stride_C + 8, i.e. Cr rows only 4-byte aligned
+    (the 16-byte vector stores of the strip / group flushes must cope)."""
+    run_stream(device, oracle, 11, "IPB", dict(i_kinds=ALL_I), 128, 2)
+    run_stream(device, oracle, 12, "IPP", dict(t8x8=True), 256, 2)
+
+
+def test_1080p_ipb(device, oracle):
+    """BASELINE geometry (120 x 68 macroblocks) with B frames, 8x8 transform and weighted prediction."""
+    run_stream(device, oracle, 21, "IPB", dict(t8x8=True, weighted=1, i_kinds=ALL_I), 120, 68, passes_split=False)
+
+
 @pytest.mark.parametrize("waves", [4, 8, 9, 10, 12, 16])
 def test_waves_per_frame(device, oracle, waves):
     """Frames wider than the LDS hand-off ring and taller than one round of row pairs
