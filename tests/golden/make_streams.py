@@ -96,13 +96,14 @@ class Synth:
 
     def __init__(self, g, name, W, H, frames, seed, *, t8x8=False, num_refs=2, weighted_pred=0, weighted_bipred=0,
                  slices=1, deblock=(0,), direct_spatial=1, scaling=False, pcm=0.03, qp=28, cqp=(0, 0), level=3.0,
-                 intra_in_inter=0.12, skip=0.15, coef_density=0.35, big_levels=0.03):
+                 intra_in_inter=0.12, skip=0.15, coef_density=0.35, big_levels=0.03, cbp_zero=0.0):
         self.g, self.name, self.W, self.H = g, name, W, H
         self.frames, self.rng = frames, random.Random(seed)
         self.t8x8, self.num_refs, self.wp, self.wbp = t8x8, num_refs, weighted_pred, weighted_bipred
         self.slices, self.deblock, self.direct_spatial, self.scaling = slices, deblock, direct_spatial, scaling
         self.pcm, self.qp, self.cqp, self.level = pcm, qp, cqp, level
         self.intra_in_inter, self.skip, self.coef_density, self.big_levels = intra_in_inter, skip, coef_density, big_levels
+        self.cbp_zero = cbp_zero
         self.log2_fn, self.log2_poc = 4, 6
 
     # ---- parameter sets (payload bits by gen_avc.py) --------------------------------------------
@@ -186,6 +187,8 @@ class Synth:
 
     def pick_cbp(self):
         r = self.rng
+        if r.random() < self.cbp_zero:
+            return 0
         luma = r.choice([0, 0, 15, 15, r.randint(0, 15), r.randint(0, 15)])
         return luma | r.choice([0, 0, 1, 2, 2]) << 4
 
@@ -213,7 +216,7 @@ class Synth:
         if x < 0.4:
             modes = [2] + ([0] if top else []) + ([1] if left else []) + ([3] if left and top and topleft else [])
             mode = r.choice(modes)
-            cbp = r.choice([0, 15]) | r.choice([0, 1, 2]) << 4
+            cbp = 0 if r.random() < self.cbp_zero else r.choice([0, 15]) | r.choice([0, 1, 2]) << 4
             mb = {"mb_type": base + 1 + mode + 4 * (cbp >> 4) + 12 * (cbp & 15 == 15),
                   "intra_chroma_pred_mode": r.choice(cmodes), "mb_qp_delta": self.qp_delta()}
             mb["coeffLevels"] = self.residual(fc, mx, my, sl, cbp, True)
@@ -480,6 +483,8 @@ STREAMS = [
     ("tall_narrow", 2, 7, "IPBP", 10, dict(num_refs=2, qp=36)),
     ("low_qp_big_levels", 4, 3, "IPP", 11, dict(qp=12, big_levels=0.2, coef_density=0.8)),
     ("high_qp", 4, 3, "IPB", 12, dict(qp=46, cqp=(6, 6))),
+    # BASELINE geometry through the real parser: sparse residual / many skips keep the file small
+    ("hd1080_ippb", 120, 68, "IPPB", 13, dict(num_refs=2, level=4.0, skip=0.45, coef_density=0.12, intra_in_inter=0.03, pcm=0.0005, cbp_zero=0.8)),
 ]
 
 
