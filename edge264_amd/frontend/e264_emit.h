@@ -60,7 +60,7 @@ typedef struct E264Emitter {
 	int serial;         /* incremented by the API wrapper before every NAL: one slice per serial */
 	int cabac_of_serial;
 	/* sink */
-	int sink_kind;      /* 0 HIP back end, 1 capture */
+	int sink_kind;      /* 0 HIP back end, 1 capture, 2 HIP frames + queued packets (external batcher) */
 	void *hip_dev, *hip_stream;
 	/* capture queue */
 	struct E264Captured { uint8_t *data; size_t bytes; struct E264Captured *next; } *cap_head, *cap_tail;

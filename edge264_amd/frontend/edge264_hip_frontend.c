@@ -13,7 +13,8 @@
  *     to the sink,
  *   - in get_frame, make the samples the reference points at (src/edge264.c:385-387) valid by
  *     waiting for the device and copying the frame into the host mirror.
- * Sinks: 0 = libedge264_hip.so (include/edge264_hip.h, resolved with dlopen so that this file has
+ * Sinks: 2 = frames on the device like 0, packets queued like 1 (a driver batches the packets of many decoders);
+ * 0 = libedge264_hip.so (include/edge264_hip.h, resolved with dlopen so that this file has
  * no link-time dependency on ROCm), 1 = capture (packets are queued for the caller; used by the
  * tests to replay them through the CPU oracle, and by tools/ to write capture files).
  */
@@ -41,6 +42,7 @@
 #include "edge264_hip.h"
 
 #define PUBLIC __attribute__((visibility("default")))
+#define ON_DEVICE(e) ((e)->sink_kind != 1) /* sinks 0 and 2 keep the frames in HBM */
 
 /* ---- back end binding (dlopen) ------------------------------------------------------------ */
 static struct {
@@ -102,7 +104,7 @@ static void e264_alloc_cb(void **samples, unsigned samples_size, void **mbs, uns
 	if (slot < 0 || slot >= E264_MAX_SLOTS)
 		return;
 	void *mirror = NULL;
-	if (e->sink_kind == 0) {
+	if (ON_DEVICE(e)) {
 		if (hip.frame_alloc(e->hip_stream, slot, samples_size, &mirror))
 			return;
 		hip.frame_fill(e->hip_stream, slot, 0); /* "non-existing" frames are never written (headers.c:1122-1144) */
@@ -130,7 +132,7 @@ static void e264_free_cb(void *samples, void *mbs, void *arg)
 			if (e->cur.valid && e->cur.slot == s)
 				e->cur.valid = 0;
 			e->fb[s].active = 0;
-			if (e->sink_kind == 0) hip.frame_free(e->hip_stream, s);
+			if (ON_DEVICE(e)) hip.frame_free(e->hip_stream, s);
 			else free(samples);
 			free(e->slot[s].mbs);
 			memset(&e->slot[s], 0, sizeof(e->slot[s]));
@@ -254,13 +256,13 @@ PUBLIC Edge264Decoder *edge264_alloc(int n_threads, Edge264LogCb log_cb, void *l
 	if (!e)
 		return NULL;
 	e->sink_kind = g_sink_kind;
-	if (e->sink_kind == 0 && (hip_bind() || hip.stream_open(hip.dev, (E264Stream **)&e->hip_stream))) {
+	if (ON_DEVICE(e) && (hip_bind() || hip.stream_open(hip.dev, (E264Stream **)&e->hip_stream))) {
 		free(e);
 		return NULL;
 	}
 	Edge264Decoder *dec = e264ref_alloc(0, log_cb, log_arg, 0, e264_alloc_cb, e264_free_cb, e);
 	if (!dec) {
-		if (e->sink_kind == 0) hip.stream_close(e->hip_stream);
+		if (ON_DEVICE(e)) hip.stream_close(e->hip_stream);
 		free(e);
 		return NULL;
 	}
@@ -289,7 +291,7 @@ PUBLIC int edge264_get_frame(Edge264Decoder *dec, Edge264Frame *out, int borrow)
 	if (!e)
 		return EINVAL;
 	int ret = e264ref_get_frame(dec, out, borrow);
-	if (ret == 0 && e->sink_kind == 0) {
+	if (ret == 0 && ON_DEVICE(e)) {
 		uintptr_t mask = (uintptr_t)out->return_arg;
 		for (int s = 0; s < E264_MAX_SLOTS; s++)
 			if (mask >> s & 1)
@@ -314,7 +316,7 @@ PUBLIC void edge264_flush(Edge264Decoder *dec)
 	e->cur.valid = 0;
 	for (int s = 0; s < E264_MAX_SLOTS; s++)
 		e->fb[s].active = 0;
-	if (e->sink_kind == 0)
+	if (ON_DEVICE(e))
 		hip.stream_flush(e->hip_stream);
 }
 
@@ -328,7 +330,7 @@ PUBLIC void edge264_free(Edge264Decoder **pdec)
 	e264_tls_emitter = NULL;
 	if (!e)
 		return;
-	if (e->sink_kind == 0) hip.stream_close(e->hip_stream);
+	if (ON_DEVICE(e)) hip.stream_close(e->hip_stream);
 	for (int s = 0; s < E264_MAX_SLOTS; s++) {
 		free(e->fb[s].mbs); free(e->fb[s].motion); free(e->fb[s].slices); free(e->fb[s].slice_serial);
 		free(e->fb[s].slice_filled); free(e->fb[s].payload);
@@ -359,3 +361,13 @@ PUBLIC int e264front_take_packet(Edge264Decoder *dec, void **data, size_t *bytes
 }
 
 PUBLIC void e264front_free_packet(void *data) { free(data); }
+
+/* sink 2 (external batcher, edge264_amd/driver/e264_multi.cpp): the device stream that holds this decoder's
+ * frames and the process-wide device object, so that the driver can hand the queued packets of MANY decoders
+ * to e264hip_submit_batch in one launch. */
+PUBLIC void *e264front_stream(Edge264Decoder *dec)
+{
+	E264Emitter *e = emitter_of(dec);
+	return e && ON_DEVICE(e) ? e->hip_stream : NULL;
+}
+PUBLIC void *e264front_device(void) { return hip_bind() ? NULL : hip.dev; }

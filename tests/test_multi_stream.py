@@ -1,0 +1,61 @@
+"""Batched multi-stream front end (edge264_amd/driver/e264_multi.cpp) on the MI355X: many decoder instances
+(reference parsers + our emitters, sink 2) advanced round-robin, the finished frames of a round submitted as ONE
+batch; every output frame must equal the unmodified reference decoder's (tests/golden/streams/reference_md5.json)."""
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+STREAMS = os.path.join(HERE, "golden", "streams")
+EXE = os.path.join(ROOT, "edge264_amd", "e264_multi")
+FRONT = os.path.join(ROOT, "oracle", "_ref", "libedge264_hipfront.so")
+HIP = os.path.join(ROOT, "edge264_amd", "libedge264_hip.so")
+
+pytestmark = pytest.mark.gpu
+
+
+def frame_md5s(path, w_mbs, h_mbs):
+    n = w_mbs * 16 * h_mbs * 16 * 3 // 2
+    data = open(path, "rb").read()
+    assert len(data) % n == 0
+    return [hashlib.md5(data[i:i + n]).hexdigest() for i in range(0, len(data), n)]
+
+
+@pytest.mark.parametrize("names,repeat", [
+    (["ipb_spatial", "t8x8_scaling", "slices_deblock_idc", "weighted_explicit", "one_mb", "tall_narrow", "i_4x4_16x16_pcm"], 3),
+    (["hd1080_ippb"], 8),
+])
+def test_multi_stream_driver(tmp_path, names, repeat):
+    for p in (EXE, FRONT, HIP):
+        assert os.path.exists(p), f"{p} missing (built by __graft_entry__.build())"
+    with open(os.path.join(STREAMS, "reference_md5.json")) as f:
+        sums = json.load(f)
+    files = [os.path.join(STREAMS, n + ".264") for n in names]
+    dump = tmp_path / "packets.e264"
+    out = subprocess.run([EXE, "--front", FRONT, "--hip", HIP, "--repeat", str(repeat), "--out", str(tmp_path),
+                          "--dump-packets", str(dump)] + files, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    stats = json.loads(out.stdout.strip().splitlines()[-1])
+    assert stats["streams"] == len(names) * repeat
+    assert stats["frames"] == repeat * sum(len(sums[n]["md5"]) for n in names)
+    assert stats["avg_batch"] > 1.5  # frames of different streams really share launches
+    k = 0
+    for _ in range(repeat):
+        for n in names:
+            got = frame_md5s(tmp_path / f"s{k}.yuv", sums[n]["width_mbs"], sums[n]["height_mbs"])
+            assert got == sums[n]["md5"], f"stream {k} ({n})"
+            k += 1
+    # the packet dump is the capture format: self-describing records
+    from edge264_amd import packet as P
+    data = dump.read_bytes()
+    off, npk = 0, 0
+    while off < len(data):
+        pk = P.Packet(data[off:off + int.from_bytes(data[off + 8:off + 12], "little")])
+        off += int(pk.hdr["total_bytes"])
+        npk += 1
+    assert off == len(data) and npk == stats["packets"]
+    print(stats)
