@@ -34,6 +34,9 @@ __device__ __forceinline__ int clip255(int v) { return min(max(v, 0), 255); }
 __device__ __forceinline__ int sat16(int v) { return min(max(v, -32768), 32767); }
 __device__ __forceinline__ int w16(int v) { return (int)(int16_t)v; }
 // build-time experiment switches (tools/ab_variants.sh builds one library per setting)
+#ifndef E264_LUMA_PACKED
+#define E264_LUMA_PACKED 1 // luma interpolation in packed 16-bit arithmetic (two samples per VALU instruction)
+#endif
 #ifndef E264_LUMA_SKIP
 #define E264_LUMA_SKIP 0 // 1: wave-uniform tap skipping also for macroblocks with several vectors (measured slower: +27% SALU)
 #endif
@@ -525,6 +528,122 @@ __device__ __forceinline__ int avg2(int a, int b) { return (a + b + 1) >> 1; }
 //   jH centre from the horizontal taps of 6 rows (+ b)   (xF==2, yF!=0)   inter.c:611-646, 779-802, 929-966
 //   jV centre from the vertical taps of 9 columns (+ h)  (xF odd, yF==2)  inter.c:559-609, 741-777, 887-927
 // 16-bit intermediates of the centre wrap as in the reference (sixtapHV, inter.c:4-9).
+#if E264_LUMA_PACKED
+// ---- packed 16-bit arithmetic (v_pk_*_i16: two samples per instruction) --------------------------------------
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ uint32_t as_u(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+// pair (byte i, byte i+1) of the 8 bytes {hi, lo}, zero-extended to 16 bits each (v_perm_b32; selector 0x0c = 0x00)
+template <int I>
+__device__ __forceinline__ s16x2 pair_at(uint32_t hi, uint32_t lo)
+{
+	return as_s2(__builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)I | (uint32_t)(I + 1) << 16));
+}
+// the 8 pairs Q_i = (p_i, p_i+1), i = 0..7, of the 9 samples of one row
+__device__ __forceinline__ void pairs9(const uint32_t w[3], s16x2 Q[8])
+{
+	Q[0] = pair_at<0>(w[1], w[0]); Q[1] = pair_at<1>(w[1], w[0]); Q[2] = pair_at<2>(w[1], w[0]); Q[3] = pair_at<3>(w[1], w[0]);
+	Q[4] = pair_at<0>(w[2], w[1]); Q[5] = pair_at<1>(w[2], w[1]); Q[6] = pair_at<2>(w[2], w[1]); Q[7] = pair_at<3>(w[2], w[1]);
+}
+__device__ __forceinline__ s16x2 tap6p(s16x2 a, s16x2 b, s16x2 c, s16x2 d, s16x2 e, s16x2 f)
+{
+	const s16x2 k5 = {5, 5}, k20 = {20, 20};
+	return (a + f) - (b + e) * k5 + (c + d) * k20;
+}
+// sixtapHV + (x + 32) >> 6, clipped: 16-bit lanes wrap exactly like the reference's int16 vectors (inter.c:4-9,14)
+__device__ __forceinline__ s16x2 centre6p(s16x2 t0, s16x2 t1, s16x2 t2, s16x2 t3, s16x2 t4, s16x2 t5)
+{
+	const s16x2 s2 = {2, 2}, s6 = {6, 6}, r32 = {32, 32}, z = {0, 0}, m = {255, 255};
+	const s16x2 af = t0 + t5, be = t1 + t4, cd = t2 + t3;
+	const s16x2 x1 = af - be;
+	const s16x2 x2 = (x1 >> s2) + (cd - be);
+	const s16x2 x3 = (x2 >> s2) + cd;
+	return __builtin_elementwise_min(__builtin_elementwise_max((x3 + r32) >> s6, z), m);
+}
+__device__ __forceinline__ s16x2 half5p(s16x2 v) // clip255((v + 16) >> 5)
+{
+	const s16x2 s5 = {5, 5}, r16 = {16, 16}, z = {0, 0}, m = {255, 255};
+	return __builtin_elementwise_min(__builtin_elementwise_max((v + r16) >> s5, z), m);
+}
+__device__ __forceinline__ void luma_from_rows(const uint32_t d[6][3], int xF, int yF, int out[4])
+{
+	const bool xo = xF & 1, yo = yF & 1;
+	const bool uses_j = (xF == 2 && yF != 0) || (yF == 2 && xF != 0);
+	const bool uses_G = (xF == 0 || yF == 0) && (xo || yo || (xF | yF) == 0);
+	const bool uses_b = (yF == 0 && xF != 0) || (xo && yo) || (xF == 2 && yo);
+	const bool uses_h = (xF == 0 && yF != 0) || (xo && yo) || (yF == 2 && xo);
+	const bool jH = uses_j && xF == 2, jV = uses_j && xF != 2;
+	const bool row3 = yF == 3, col3 = xF == 3;
+	const s16x2 z = {0, 0};
+	s16x2 G[2], b[2] = {z, z}, h[2] = {z, z}, j[2] = {z, z}; // [0] = outputs 0,1   [1] = outputs 2,3
+	{ // integer sample: row 2 (3 when yF==3), columns 2..5 (3..6 when xF==3)
+		const uint32_t w0 = row3 ? d[3][0] : d[2][0], w1 = row3 ? d[3][1] : d[2][1];
+		const uint32_t g4 = col3 ? __builtin_amdgcn_alignbyte(w1, w0, 3) : __builtin_amdgcn_alignbyte(w1, w0, 2);
+		G[0] = pair_at<0>(0, g4); G[1] = pair_at<2>(0, g4);
+	}
+	if (jH) {
+		s16x2 H0[6], H1[6];
+#pragma unroll
+		for (int r = 0; r < 6; r++) {
+			s16x2 Q[8];
+			pairs9(d[r], Q);
+			H0[r] = tap6p(Q[0], Q[1], Q[2], Q[3], Q[4], Q[5]);
+			H1[r] = tap6p(Q[2], Q[3], Q[4], Q[5], Q[6], Q[7]);
+		}
+		j[0] = centre6p(H0[0], H0[1], H0[2], H0[3], H0[4], H0[5]);
+		j[1] = centre6p(H1[0], H1[1], H1[2], H1[3], H1[4], H1[5]);
+		b[0] = half5p(row3 ? H0[3] : H0[2]);
+		b[1] = half5p(row3 ? H1[3] : H1[2]);
+	} else if (uses_b) {
+		const uint32_t w[3] = {row3 ? d[3][0] : d[2][0], row3 ? d[3][1] : d[2][1], row3 ? d[3][2] : d[2][2]};
+		s16x2 Q[8];
+		pairs9(w, Q);
+		b[0] = half5p(tap6p(Q[0], Q[1], Q[2], Q[3], Q[4], Q[5]));
+		b[1] = half5p(tap6p(Q[2], Q[3], Q[4], Q[5], Q[6], Q[7]));
+	}
+	if (jV) {
+		// vertical taps of the column pairs (0,1) (2,3) (4,5) (6,7) and of column 8; the odd pairs come from alignbit
+		s16x2 E[5][6];
+#pragma unroll
+		for (int r = 0; r < 6; r++) {
+			E[0][r] = pair_at<0>(d[r][1], d[r][0]); E[1][r] = pair_at<2>(d[r][1], d[r][0]);
+			E[2][r] = pair_at<0>(d[r][2], d[r][1]); E[3][r] = pair_at<2>(d[r][2], d[r][1]);
+			E[4][r] = as_s2(d[r][2] & 255u);
+		}
+		s16x2 V[5];
+#pragma unroll
+		for (int c = 0; c < 5; c++)
+			V[c] = tap6p(E[c][0], E[c][1], E[c][2], E[c][3], E[c][4], E[c][5]);
+		// V[c] = (V_2c, V_2c+1); odd pairs (V_2c+1, V_2c+2)
+		s16x2 O[4];
+#pragma unroll
+		for (int c = 0; c < 4; c++)
+			O[c] = as_s2(__builtin_amdgcn_alignbit(as_u(V[c + 1]), as_u(V[c]), 16));
+		// outputs (0,1): taps at columns (0,1)(1,2)(2,3)(3,4)(4,5)(5,6); outputs (2,3): (2,3)(3,4)(4,5)(5,6)(6,7)(7,8)
+		j[0] = centre6p(V[0], O[0], V[1], O[1], V[2], O[2]);
+		j[1] = centre6p(V[1], O[1], V[2], O[2], V[3], O[3]);
+		h[0] = half5p(col3 ? O[1] : V[1]);
+		h[1] = half5p(col3 ? O[2] : V[2]);
+	} else if (uses_h) {
+		s16x2 C0[6], C1[6];
+#pragma unroll
+		for (int r = 0; r < 6; r++) {
+			const uint32_t g4 = col3 ? __builtin_amdgcn_alignbyte(d[r][1], d[r][0], 3) : __builtin_amdgcn_alignbyte(d[r][1], d[r][0], 2);
+			C0[r] = pair_at<0>(0, g4); C1[r] = pair_at<2>(0, g4);
+		}
+		h[0] = half5p(tap6p(C0[0], C0[1], C0[2], C0[3], C0[4], C0[5]));
+		h[1] = half5p(tap6p(C1[0], C1[1], C1[2], C1[3], C1[4], C1[5]));
+	}
+	const s16x2 one = {1, 1};
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const s16x2 op1 = uses_j ? j[k] : uses_G ? G[k] : uses_b ? b[k] : h[k];
+		const s16x2 op2 = uses_h ? h[k] : uses_b ? b[k] : uses_j ? j[k] : G[k];
+		const s16x2 r = (op1 + op2 + one) >> one;
+		out[2 * k] = r.x; out[2 * k + 1] = r.y;
+	}
+}
+#else
 __device__ __forceinline__ void unpack9(const uint32_t w[3], int px[9])
 {
 	px[0] = w[0] & 255; px[1] = w[0] >> 8 & 255; px[2] = w[0] >> 16 & 255; px[3] = w[0] >> 24;
@@ -603,6 +722,8 @@ __device__ __forceinline__ void luma_from_rows(const uint32_t d[6][3], int xF, i
 		out[i] = avg2(op1, op2);
 	}
 }
+
+#endif
 
 // ---------------------------------------------------------------------------------
 // Inter prediction, software pipelined over a strip of macroblocks (mbpar kernel):
