@@ -743,25 +743,32 @@ struct McMotion {
 struct McWindows {          // reference samples of ONE list
 	uint32_t y0, y1, y2, y3; // luma window dwords fetched ahead by this lane (iterations 0..3; 4x4 windows fetch 4..6 late)
 	                         // (scalars, not an array: the array form ended up in scratch memory)
-	int c[6];                // chroma samples (x..x+2, y..y+1) of this lane
+	uint32_t ca, cb;         // chroma samples x..x+2 of rows y and y+1 of this lane, one byte each (RAW loads on the fast path:
+	                         // they are only taken apart by chroma_taps() one macroblock later)
 };
 __device__ __forceinline__ int ref_byte(uint32_t w, int b8) { return (int)(int8_t)(w >> (8 * b8)); }
 
-__device__ __forceinline__ void mc_load_motion(const FrameCtx &f, int addr, int lane, McMotion &M)
+// Motion of a macroblock in two steps so that the loads stay in flight for a whole macroblock:
+//   mc_issue_raw   only ISSUES the loads (nothing here may use a loaded value: a use is a wait)
+//   mc_finish      one macroblock later: uniform refs through v_readlane, window granularity S
+struct McRaw { uint32_t rv, y0, y1, c0, c1; };
+__device__ __forceinline__ void mc_issue_raw(const FrameCtx &f, int addr, int lane, McRaw &R)
 {
 	const int k = lane >> 2, kc = blk_of((lane & 3), ((lane >> 2) & 7) >> 1);
-	M.S = 16 | 16 << 8;
-	if (!f.motion) { M.refs[0] = M.refs[1] = M.refs[2] = M.refs[3] = 0xffffffffu; M.mvY[0] = M.mvY[1] = M.mvC[0] = M.mvC[1] = 0; return; }
+	R.rv = 0xffffffffu; R.y0 = R.y1 = R.c0 = R.c1 = 0;
+	if (!f.motion)
+		return;
 	gmotion_t mo = f.motion + addr;
-	{ // refPic / refIdx (16 bytes, uniform): one vector load + readlane, not scalar memory (see mb_from_lanes)
-		const uint32_t rv = ((const gu32 *)mo)[lane & 3];
-		M.refs[0] = __builtin_amdgcn_readlane(rv, 0); M.refs[1] = __builtin_amdgcn_readlane(rv, 1);
-		M.refs[2] = __builtin_amdgcn_readlane(rv, 2); M.refs[3] = __builtin_amdgcn_readlane(rv, 3);
-	}
-	M.mvY[0] = *(const gu32 *)&mo->mvs[k * 2]; M.mvY[1] = *(const gu32 *)&mo->mvs[32 + k * 2];
-	M.mvC[0] = *(const gu32 *)&mo->mvs[kc * 2]; M.mvC[1] = *(const gu32 *)&mo->mvs[32 + kc * 2];
-	// coarsest uniform granularity per list (the packet carries per-4x4 motion, not partitions); decided once
-	// here (2 macroblocks ahead of use) instead of in each of issue / commit / compute
+	R.rv = ((const gu32 *)mo)[lane & 3]; // refPic / refIdx: 16 bytes, uniform; vector load + readlane, not scalar memory (see mb_from_lanes)
+	R.y0 = *(const gu32 *)&mo->mvs[k * 2]; R.y1 = *(const gu32 *)&mo->mvs[32 + k * 2];
+	R.c0 = *(const gu32 *)&mo->mvs[kc * 2]; R.c1 = *(const gu32 *)&mo->mvs[32 + kc * 2];
+}
+__device__ __forceinline__ void mc_finish(const McRaw &R, int lane, McMotion &M)
+{
+	M.refs[0] = __builtin_amdgcn_readlane(R.rv, 0); M.refs[1] = __builtin_amdgcn_readlane(R.rv, 1);
+	M.refs[2] = __builtin_amdgcn_readlane(R.rv, 2); M.refs[3] = __builtin_amdgcn_readlane(R.rv, 3);
+	M.mvY[0] = R.y0; M.mvY[1] = R.y1; M.mvC[0] = R.c0; M.mvC[1] = R.c1;
+	// coarsest uniform granularity per list (the packet carries per-4x4 motion, not partitions)
 	int S = 0;
 #pragma unroll
 	for (int l = 0; l < 2; l++) {
@@ -853,15 +860,19 @@ __device__ __forceinline__ void mc_issue(const FrameCtx &f, const McMotion &M, i
 		const int Wc = f.W >> 1, Hc = f.H >> 1;
 		const gu8 *r0 = rp + (size_t)clip3i(0, Hc - 1, Y) * f.sC, *r1 = rp + (size_t)clip3i(0, Hc - 1, Y + 1) * f.sC;
 		if (X >= 0 && X + 3 < Wc) { // the three columns as one unaligned dword per row
-			const uint32_t a = *(const gu32u *)(r0 + X), b = *(const gu32u *)(r1 + X);
-			Wn.c[0] = a & 255; Wn.c[1] = a >> 8 & 255; Wn.c[2] = a >> 16 & 255;
-			Wn.c[3] = b & 255; Wn.c[4] = b >> 8 & 255; Wn.c[5] = b >> 16 & 255;
-		} else { // frame border: per-sample clamp == the reference's edge emulation
+			Wn.ca = *(const gu32u *)(r0 + X); Wn.cb = *(const gu32u *)(r1 + X);
+		} else { // frame border: per-sample clamp == the reference's edge emulation (rare: may wait for its loads)
 			const int x0 = clip3i(0, Wc - 1, X), x1 = clip3i(0, Wc - 1, X + 1), x2 = clip3i(0, Wc - 1, X + 2);
-			Wn.c[0] = r0[x0]; Wn.c[1] = r0[x1]; Wn.c[2] = r0[x2];
-			Wn.c[3] = r1[x0]; Wn.c[4] = r1[x1]; Wn.c[5] = r1[x2];
+			Wn.ca = (uint32_t)r0[x0] | (uint32_t)r0[x1] << 8 | (uint32_t)r0[x2] << 16;
+			Wn.cb = (uint32_t)r1[x0] | (uint32_t)r1[x1] << 8 | (uint32_t)r1[x2] << 16;
 		}
 	}
+}
+
+__device__ __forceinline__ void chroma_taps(const McWindows &Wn, int cc[6])
+{
+	cc[0] = Wn.ca & 255; cc[1] = Wn.ca >> 8 & 255; cc[2] = Wn.ca >> 16 & 255;
+	cc[3] = Wn.cb & 255; cc[4] = Wn.cb >> 8 & 255; cc[5] = Wn.cb >> 16 & 255;
 }
 
 // registers -> LDS window (the S of the list is recomputed: cheap and uniform)
@@ -894,7 +905,7 @@ __device__ __forceinline__ void mc_commit_tail(WaveLds &L, const FrameCtx &f, co
 }
 
 // filters + weights of one list of one macroblock from the LDS window / chroma registers
-__device__ __forceinline__ void mc_compute(WaveLds &L, const FrameCtx &f, cslice_t s, const McMotion &M, int l, const McWindows &Wn,
+__device__ __forceinline__ void mc_compute(WaveLds &L, const FrameCtx &f, cslice_t s, const McMotion &M, int l, const int cc[6],
 	int mbx, int mby, int lane, int outY[4], int outC[2])
 {
 	const int k = lane >> 2, r = lane & 3;
@@ -935,8 +946,8 @@ __device__ __forceinline__ void mc_compute(WaveLds &L, const FrameCtx &f, cslice
 		const int mx = (int)(int16_t)(M.mvC[l] & 0xffff), my = (int)M.mvC[l] >> 16;
 		const int xF = mx & 7, yF = my & 7;
 		const int A = (8 - xF) * (8 - yF), B = xF * (8 - yF), C = (8 - xF) * yF, D = xF * yF;
-		const int p0 = (A * Wn.c[0] + B * Wn.c[1] + C * Wn.c[3] + D * Wn.c[4] + 32) >> 6;
-		const int p1 = (A * Wn.c[1] + B * Wn.c[2] + C * Wn.c[4] + D * Wn.c[5] + 32) >> 6;
+		const int p0 = (A * cc[0] + B * cc[1] + C * cc[3] + D * cc[4] + 32) >> 6;
+		const int p1 = (A * cc[1] + B * cc[2] + C * cc[4] + D * cc[5] + 32) >> 6;
 		const int refIdxX = ref_byte(M.refs[2 + (l ^ 1)], kc >> 2);
 		if (idc == 0 && !(l == 1 && refIdxX >= 0)) {
 			outC[0] = p0; outC[1] = p1;
@@ -950,7 +961,7 @@ __device__ __forceinline__ void mc_compute(WaveLds &L, const FrameCtx &f, cslice
 }
 
 // stage C of one macroblock of the strip: everything that is not intra prediction
-__device__ __forceinline__ bool mbpar_mb(WaveLds &L, StripOut &O, int slot, const FrameCtx &f, const MbInfo &m, const McMotion &M, const McWindows &Wn,
+__device__ __forceinline__ bool mbpar_mb(WaveLds &L, StripOut &O, int slot, const FrameCtx &f, const MbInfo &m, const McMotion &M, const int cc[6],
 	int mbx, int mby, int lane)
 { // returns true when the macroblock's samples were staged in O.y/O.c[slot]
 	if (m.kind != E264_MB_INTER && m.kind != E264_MB_PCM)
@@ -969,7 +980,7 @@ __device__ __forceinline__ bool mbpar_mb(WaveLds &L, StripOut &O, int slot, cons
 	const bool has_res = m.coded != 0 && !(f.dbg & 1024); // uniform; most inter macroblocks carry no residual
 	if (has_res) compute_residual(L, f, m, s, pl, lane);
 	int pY[4] = {0, 0, 0, 0}, pC[2] = {0, 0};
-	mc_compute(L, f, s, M, 0, Wn, mbx, mby, lane, pY, pC); // list 0: window already in LDS (prefetched)
+	mc_compute(L, f, s, M, 0, cc, mbx, mby, lane, pY, pC); // list 0: window already in LDS (prefetched)
 	if (M.refs[1] != 0xffffffffu) { // list 1 (B macroblocks): fetched here, not pipelined
 		McWindows W1;
 		wave_sync();
@@ -977,7 +988,9 @@ __device__ __forceinline__ bool mbpar_mb(WaveLds &L, StripOut &O, int slot, cons
 		mc_commit(L, M, 1, W1, mbx, mby, lane);
 		mc_commit_tail(L, f, M, 1, mbx, mby, lane);
 		wave_sync();
-		mc_compute(L, f, s, M, 1, W1, mbx, mby, lane, pY, pC);
+		int c1[6];
+		chroma_taps(W1, c1);
+		mc_compute(L, f, s, M, 1, c1, mbx, mby, lane, pY, pC);
 	}
 	if (has_res) { // add residual, clip (int16 wrap add then packus: residual.c:160-171)
 		const int16_t *rr = L.res + Yr * 16 + X;
@@ -1811,36 +1824,46 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 	};
 #define HV(i) hv_sel(i)
 	MbInfo h0 = mb_from_lanes(HV(0), 0);
-	McMotion m0, m1, m2;
-	McWindows w0, w1;
-	mc_load_motion(f, base, lane, m0);
-	m1 = m0; m2 = m0;
-	if (n > 1) mc_load_motion(f, base + 1, lane, m1);
+	// Software pipeline.  ONE register set per stage and no register-to-register hand-over of values that are
+	// still being loaded (a copy is a use, a use is a wait):
+	//   raw : motion loads of macroblock i+2, consumed by mc_finish at the top of the next iteration
+	//   m1  : finished motion of macroblock i+1 (drives the window loads issued in iteration i)
+	//   w   : reference windows / chroma taps of macroblock i+1, loaded during iteration i, committed to LDS
+	//         (luma) and copied out (chroma taps cc) at the top of iteration i+1
+	McRaw raw;
+	McMotion m0, m1;
+	McWindows w;
+	int cc[6] = {0, 0, 0, 0, 0, 0};
+	mc_issue_raw(f, base, lane, raw);
+	mc_finish(raw, lane, m0);
+	m1 = m0;
+	if (n > 1) mc_issue_raw(f, base + 1, lane, raw);
 	int mby = base / f.wm, mbx = base - mby * f.wm;
 	const int mbx0 = mbx, mby0 = mby;
 	StripOut &O = outs[wave];
 	uint32_t staged = 0;
 	if (recon && h0.kind == E264_MB_INTER)
-		mc_issue(f, m0, 0, mbx, mby, lane, w0);
+		mc_issue(f, m0, 0, mbx, mby, lane, w);
 #pragma unroll 1
 	for (int i = 0; i < n; i++) {
 		int nx = mbx + 1, ny = mby;
 		if (nx == f.wm) { nx = 0; ny++; }
-		if (i + 2 < n) mc_load_motion(f, base + i + 2, lane, m2);
-		if (recon && h0.kind == E264_MB_INTER)
-		{
-			mc_commit(L, m0, 0, w0, mbx, mby, lane);
+		if (i + 1 < n) mc_finish(raw, lane, m1);             // motion of macroblock i+1 (loads issued one iteration ago)
+		if (i + 2 < n) mc_issue_raw(f, base + i + 2, lane, raw);
+		if (recon && h0.kind == E264_MB_INTER) {
+			mc_commit(L, m0, 0, w, mbx, mby, lane);
 			mc_commit_tail(L, f, m0, 0, mbx, mby, lane);
+			chroma_taps(w, cc);
 		}
 		wave_sync();
 		const int i1 = min(i + 1, n - 1);
 		const MbInfo h1 = mb_from_lanes(HV(i1), i1 & 7);
 		if (recon && i + 1 < n && h1.kind == E264_MB_INTER)
-			mc_issue(f, m1, 0, nx, ny, lane, w1);
-		if (recon && mbpar_mb(L, O, i, f, h0, m0, w0, mbx, mby, lane))
+			mc_issue(f, m1, 0, nx, ny, lane, w);
+		if (recon && mbpar_mb(L, O, i, f, h0, m0, cc, mbx, mby, lane))
 			staged |= 1u << i;
 		wave_sync();
-		h0 = h1; m0 = m1; m1 = m2; w0 = w1;
+		h0 = h1; m0 = m1;
 		mbx = nx; mby = ny;
 	}
 	strip_flush(O, f, mbx0, mby0, staged, lane);
