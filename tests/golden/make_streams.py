@@ -96,7 +96,7 @@ class Synth:
 
     def __init__(self, g, name, W, H, frames, seed, *, t8x8=False, num_refs=2, weighted_pred=0, weighted_bipred=0,
                  slices=1, deblock=(0,), direct_spatial=1, scaling=False, pcm=0.03, qp=28, cqp=(0, 0), level=3.0,
-                 intra_in_inter=0.12, skip=0.15, coef_density=0.35, big_levels=0.03, cbp_zero=0.0):
+                 intra_in_inter=0.12, skip=0.15, coef_density=0.35, big_levels=0.03, cbp_zero=0.0, cabac=False, tables=None):
         self.g, self.name, self.W, self.H = g, name, W, H
         self.frames, self.rng = frames, random.Random(seed)
         self.t8x8, self.num_refs, self.wp, self.wbp = t8x8, num_refs, weighted_pred, weighted_bipred
@@ -104,6 +104,7 @@ class Synth:
         self.pcm, self.qp, self.cqp, self.level = pcm, qp, cqp, level
         self.intra_in_inter, self.skip, self.coef_density, self.big_levels = intra_in_inter, skip, coef_density, big_levels
         self.cbp_zero = cbp_zero
+        self.cabac, self.tables, self.cabac_fs = cabac, tables, None
         self.log2_fn, self.log2_poc = 4, 6
 
     # ---- parameter sets (payload bits by gen_avc.py) --------------------------------------------
@@ -121,7 +122,7 @@ class Synth:
         return d
 
     def pps(self):
-        d = dict(nal_ref_idc=3, nal_unit_type=8, pic_parameter_set_id=0, entropy_coding_mode_flag=0,
+        d = dict(nal_ref_idc=3, nal_unit_type=8, pic_parameter_set_id=0, entropy_coding_mode_flag=int(self.cabac),
                  bottom_field_pic_order_in_frame_present_flag=0, num_ref_idx_default_active={"l0": 1, "l1": 1},
                  weighted_pred_flag=self.wp, weighted_bipred_idc=self.wbp, pic_init_qp=self.qp,
                  chroma_qp_index_offset=self.cqp[0], deblocking_filter_control_present_flag=1,
@@ -413,12 +414,27 @@ class Synth:
                 bits = u(bits, 2, 0)  # no_output_of_prior_pics_flag, long_term_reference_flag
             else:
                 bits = u(bits, 1, 0)  # adaptive_ref_pic_marking_mode_flag
+        cabac_init_idc = (first + hdr["frame_num"]) % 3  # deterministic: the CAVLC and CABAC variants of a stream draw the same random sequence
+        if self.cabac and st != 2:
+            bits = ue(bits, cabac_init_idc)
         bits = se(bits, hdr["slice_qp_delta"])
         idc = hdr["deblock"]
         bits = ue(bits, idc)
         if idc != 1:
             bits = se(bits, hdr["alpha"])
             bits = se(bits, hdr["beta"])
+        if self.cabac:
+            import cabac_writer as cw
+            bl = [int(c) for c in bin(bits)[3:]]           # drop the sentinel bit
+            bl += [1] * (-len(bl) % 8)                     # cabac_alignment_one_bit
+            cs = cw.CabacSlice(self.tables, self.cabac_fs, st, self.qp + hdr["slice_qp_delta"], cabac_init_idc, sl, self.t8x8)
+            for k, addr in enumerate(range(first, last)):
+                cs.macroblock(addr % self.W, addr // self.W, mbs[k], hdr["nref0"])
+                cs.end_of_slice(addr == last - 1)
+            bl += cs.enc.bits                              # ends with the rbsp_stop_one_bit written by the flush
+            bl += [0] * (-len(bl) % 8)
+            raw = bytes(int("".join(map(str, bl[i:i + 8])), 2) for i in range(0, len(bl), 8))
+            return b"\0\0\0\1" + emulation_prevention(raw)
         buf = io.BytesIO()
         ns = g.SimpleNamespace(macroblocks_cavlc=mbs, num_ref_idx_active={"l0": hdr["nref0"], "l1": hdr["nref1"]})
         bits = g.gen_slice_data_cavlc(bits, buf, ns, st)
@@ -452,6 +468,9 @@ class Synth:
             idr = idx == 0
             is_ref = t != "B"
             fc = FrameCtx(self.W, self.H)
+            if self.cabac:
+                import cabac_writer as cw
+                self.cabac_fs = cw.FrameState(self.W, self.H)
             nref0 = max(1, min(nrefs, self.num_refs)) if t != "I" else 1
             nref1 = nref0
             if t != "I":
@@ -484,6 +503,16 @@ STREAMS = [
     ("low_qp_big_levels", 4, 3, "IPP", 11, dict(qp=12, big_levels=0.2, coef_density=0.8)),
     ("high_qp", 4, 3, "IPB", 12, dict(qp=46, cqp=(6, 6))),
     # BASELINE geometry through the real parser: sparse residual / many skips keep the file small
+    # CABAC (tests/golden/cabac_writer.py; I and P slices, no I_PCM).  Each is also generated as CAVLC from the same
+    # description and the two must decode to identical frames with the unmodified reference (checked in main()).
+    ("cabac_i", 5, 4, "II", 31, dict(cabac=True, pcm=0.0)),
+    ("cabac_ipp", 5, 4, "IPPP", 32, dict(cabac=True, pcm=0.0, num_refs=2)),
+    ("cabac_t8x8_scaling", 5, 4, "IPPP", 43, dict(cabac=True, pcm=0.0, num_refs=3, t8x8=True, scaling=True, cqp=(2, -3))),
+    ("cabac_slices_deblock_idc", 6, 4, "IPPP", 34, dict(cabac=True, pcm=0.0, num_refs=2, slices=3, deblock=(0, 1, 2))),
+    ("cabac_weighted", 4, 3, "IPPP", 35, dict(cabac=True, pcm=0.0, num_refs=2, weighted_pred=1)),
+    ("cabac_big_levels", 4, 3, "IPP", 36, dict(cabac=True, pcm=0.0, qp=12, big_levels=0.2, coef_density=0.8)),
+    ("cabac_hd1080_ipp", 120, 68, "IPP", 37, dict(cabac=True, pcm=0.0, num_refs=2, level=4.0, skip=0.45, coef_density=0.12,
+                                                   intra_in_inter=0.03, cbp_zero=0.8)),
     ("hd1080_ippb", 120, 68, "IPPB", 13, dict(num_refs=2, level=4.0, skip=0.45, coef_density=0.12, intra_in_inter=0.03, pcm=0.0005, cbp_zero=0.8)),
 ]
 
@@ -497,12 +526,22 @@ def main():
     from oracle.pyoracle import ref_decoder  # the UNMODIFIED reference decoder (oracle/_ref/libedge264_ref.so)
     ref = ref_decoder()
     sums = {}
+    tables = None
     for name, W, H, frames, seed, opt in STREAMS:
+        twin = None
+        if opt.get("cabac"):
+            import cabac_writer as cw
+            tables = tables or cw.load_tables()
+            opt = dict(opt, tables=tables)
+            twin = Synth(g, name, W, H, frames, seed, **dict(opt, cabac=False)).build()
         data = Synth(g, name, W, H, frames, seed, **opt).build()
         with open(os.path.join(OUT, name + ".264"), "wb") as f:
             f.write(data)
         out, codes = ref.decode(data)
         assert len(out) == len(frames) and all(c in (0, 105, 61) for c in codes), (name, len(out), codes)
+        if twin is not None:  # the CABAC writer is right iff the reference decodes both entropy codings to the same frames
+            tout, _ = ref.decode(twin)
+            assert len(tout) == len(out) and all((a[p] == b[p]).all() for a, b in zip(tout, out) for p in range(3)), name
         sums[name] = {"width_mbs": W, "height_mbs": H, "frames": frames, "nal_codes": codes,
                       "md5": [hashlib.md5(b"".join(p.tobytes() for p in fr)).hexdigest() for fr in out]}
         print(f"{name}.264: {len(data)} bytes, {W}x{H} MBs, {frames}, {len(out)} frames decoded by the reference")
