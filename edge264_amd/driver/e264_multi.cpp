@@ -20,6 +20,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include <string>
 #include <vector>
 
@@ -79,10 +82,22 @@ static void write_frame(FILE *f, const Edge264Frame &fr)
 		for (int y = 0; y < fr.height_C; y++) fwrite(fr.samples[p] + (size_t)y * fr.stride_C, 1, fr.width_C, f);
 }
 
+static void on_crash(int sig)
+{ // a crash inside the (foreign) parser is otherwise silent: print where
+	void *bt[48];
+	int n = backtrace(bt, 48);
+	fprintf(stderr, "e264_multi: signal %d\n", sig);
+	backtrace_symbols_fd(bt, n, 2);
+	_exit(128 + sig);
+}
+
 int main(int argc, char **argv)
 {
+	signal(SIGSEGV, on_crash);
+	signal(SIGBUS, on_crash);
 	std::string front_path, hip_path, out_dir, dump_path;
 	int device = 0, repeat = 1;
+	bool parse_only = false; // --parse-only: sink 1, no GPU: packets are produced and dropped (front-end speed / debugging)
 	std::vector<std::string> files;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
@@ -91,6 +106,7 @@ int main(int argc, char **argv)
 		else if (a == "--hip") hip_path = next();
 		else if (a == "--device") device = atoi(next().c_str());
 		else if (a == "--repeat") repeat = atoi(next().c_str());
+		else if (a == "--parse-only") parse_only = true;
 		else if (a == "--out") out_dir = next();
 		else if (a == "--dump-packets") dump_path = next();
 		else files.push_back(a);
@@ -101,7 +117,7 @@ int main(int argc, char **argv)
 	}
 	setenv("E264_HIP_LIB", hip_path.c_str(), 1); // the front end binds the same back-end library
 	void *hl = dlopen(hip_path.c_str(), RTLD_NOW | RTLD_GLOBAL);
-	if (!hl) { fprintf(stderr, "e264_multi: %s\n", dlerror()); return 2; } // no back end, no decoding: there is no CPU fallback
+	if (!hl && !parse_only) { fprintf(stderr, "e264_multi: %s\n", dlerror()); return 2; } // no back end, no decoding: there is no CPU fallback
 	void *fl = dlopen(front_path.c_str(), RTLD_NOW | RTLD_LOCAL);
 	if (!fl) { fprintf(stderr, "e264_multi: %s\n", dlerror()); return 2; }
 	Front F; Hip H;
@@ -110,12 +126,14 @@ int main(int argc, char **argv)
 	bind(fl, "e264front_set_sink", F.set_sink); bind(fl, "e264front_set_device", F.set_device);
 	bind(fl, "e264front_take_packet", F.take_packet); bind(fl, "e264front_free_packet", F.free_packet);
 	bind(fl, "e264front_stream", F.stream); bind(fl, "e264front_device", F.device);
+	if (!parse_only) {
 	bind(hl, "e264hip_packet_upload", H.packet_upload); bind(hl, "e264hip_packet_free", H.packet_free);
 	bind(hl, "e264hip_submit_batch", H.submit_batch); bind(hl, "e264hip_device_sync", H.device_sync);
 	bind(hl, "e264hip_last_error", H.last_error);
+	}
 
 	F.set_device(device);
-	F.set_sink(2);
+	F.set_sink(parse_only ? 1 : 2);
 	std::vector<Stream> S;
 	for (int r = 0; r < repeat; r++)
 		for (const std::string &path : files) {
@@ -139,8 +157,8 @@ int main(int argc, char **argv)
 				if (!t.out) { perror(o.c_str()); return 2; }
 			}
 		}
-	void *dev = F.device();
-	if (!dev) { fprintf(stderr, "e264_multi: no device\n"); return 2; }
+	void *dev = parse_only ? nullptr : F.device();
+	if (!dev && !parse_only) { fprintf(stderr, "e264_multi: no device\n"); return 2; }
 	FILE *dump = dump_path.empty() ? nullptr : fopen(dump_path.c_str(), "wb");
 
 	auto drain = [&](Stream &s) {
@@ -173,6 +191,7 @@ int main(int argc, char **argv)
 			if (s.pkt) {
 				void *d = nullptr;
 				if (dump) fwrite(s.pkt, 1, s.pkt_bytes, dump);
+				if (parse_only) { F.free_packet(s.pkt); s.pkt = nullptr; packets++; continue; }
 				if (H.packet_upload(dev, s.pkt, s.pkt_bytes, &d)) { fprintf(stderr, "packet_upload: %s\n", H.last_error()); return 1; }
 				F.free_packet(s.pkt); s.pkt = nullptr;
 				streams.push_back(F.stream(s.dec)); dpk.push_back(d);
@@ -183,6 +202,7 @@ int main(int argc, char **argv)
 			for (void *d : dpk) H.packet_free(d);
 			rounds++; packets += (long)streams.size();
 		}
+		if (parse_only) rounds++;
 		// 3. output
 		for (Stream &s : S) drain(s);
 		if (!any) break;

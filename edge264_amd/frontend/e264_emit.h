@@ -22,7 +22,8 @@
 typedef struct {
 	uint8_t *samples;  /* host mirror handed to the reference as samples_buffers[slot] */
 	size_t samples_size;
-	void *mbs;
+	void *mbs;         /* what the reference sees as mb_buffers[slot] */
+	void *mbs_base;    /* start of the allocation (guard bands on both sides of mbs) */
 } E264Slot;
 
 typedef struct {

@@ -111,11 +111,22 @@ static void e264_alloc_cb(void **samples, unsigned samples_size, void **mbs, uns
 	} else {
 		mirror = aligned_alloc(64, ((size_t)samples_size + 63) & ~(size_t)63);
 	}
-	void *m = aligned_alloc(64, ((size_t)mbs_size + 63) & ~(size_t)63);
+	/* The reference's default allocator returns samples and mbs as ONE block, mbs right after samples
+	 * (src/edge264.c:123-130), and its parsers lean on that: the neighbour records of the first macroblock row
+	 * (mb - pic_width_in_mbs - 2 ...) are read -- then masked by the availability flags -- at addresses BEFORE
+	 * mb_buffers[slot].  With a separate allocation those reads fall off the mapping (seen as sporadic SIGSEGVs
+	 * on 1080p CABAC streams), so mbs sits between zeroed guard bands large enough for one macroblock row. */
+	size_t guard = (size_t)mbs_size < 65536 ? 65536 : (size_t)mbs_size > (1u << 20) ? (1u << 20) : (((size_t)mbs_size + 4095) & ~(size_t)4095);
+	size_t body = ((size_t)mbs_size + 63) & ~(size_t)63;
+	uint8_t *base = aligned_alloc(4096, (2 * guard + body + 4095) & ~(size_t)4095);
+	void *m = base ? base + guard : NULL;
 	if (!mirror || !m) {
-		free(m);
+		free(base);
 		return;
 	}
+	memset(base, 0, guard);
+	memset(base + guard + body, 0, guard);
+	e->slot[slot].mbs_base = base;
 	e->slot[slot].samples = mirror;
 	e->slot[slot].samples_size = samples_size;
 	e->slot[slot].mbs = m;
@@ -134,7 +145,7 @@ static void e264_free_cb(void *samples, void *mbs, void *arg)
 			e->fb[s].active = 0;
 			if (ON_DEVICE(e)) hip.frame_free(e->hip_stream, s);
 			else free(samples);
-			free(e->slot[s].mbs);
+			free(e->slot[s].mbs_base);
 			memset(&e->slot[s], 0, sizeof(e->slot[s]));
 			return;
 		}
