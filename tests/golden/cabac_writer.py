@@ -7,8 +7,7 @@ gen_avc.py's CAVLC writer (mb_type, prediction modes, sub_mb_types, ref_idx, mvd
 transform_size_8x8_flag, mb_qp_delta, coefficient lists in scan order), following ITU-T H.264 9.3:
 binarisations (9.3.2), context selection (9.3.3.1) and the arithmetic encoder (9.3.4.2 / Figure 9-7..9-12).
 
-Scope: I and P slices, frame macroblocks, 4:2:0; every macroblock type make_streams.py produces for those
-slices except I_PCM.  Correctness is established by the unmodified reference decoder: it must decode the CABAC
+Scope: I, P and B slices, frame macroblocks, 4:2:0; every macroblock type make_streams.py produces except I_PCM.  Correctness is established by the unmodified reference decoder: it must decode the CABAC
 stream without error to exactly the frames of the CAVLC stream generated from the same description.
 
 Tables: the context initialisation values (Tables 9-12..9-33) are read at generation time from the reference
@@ -155,7 +154,7 @@ CAT = {0: (85, 105, 166, 227), 1: (89, 120, 181, 237), 2: (93, 134, 195, 247), 3
 
 class MbState:
     __slots__ = ("slice", "skip", "intra", "nxn", "i16", "cbp_l", "cbp_c", "cmode", "t8", "cbf_y", "cbf_dc", "cbf_cdc",
-                 "cbf_cac", "mvd", "refgt0", "inter")
+                 "cbf_cac", "mvd", "refgt0", "inter", "direct")
 
     def __init__(self):
         self.slice = -1
@@ -201,12 +200,17 @@ class CabacSlice:
     def mb_skip_flag(self, mx, my, skip):
         A, B = self.nb(mx, my)
         inc = int(A is not None and not A.skip) + int(B is not None and not B.skip)
-        self.enc.decision(11 + inc, int(skip))
+        self.enc.decision((11 if self.st == 0 else 24) + inc, int(skip))
 
     def mb_type_intra(self, mx, my, t, prefix_p):
         """t: I-slice numbering 0 = I_NxN, 1..24 = I_16x16"""
         e = self.enc
-        if prefix_p:
+        if prefix_p and self.st == 1:   # B slice: prefix 1 1 1 1 0 1 (Table 9-37), suffix with ctxIdxOffset 32
+            A, B = self.nb(mx, my)
+            e.decision(27 + int(A is not None and not A.direct) + int(B is not None and not B.direct), 1)
+            e.decision(30, 1); e.decision(31, 1); e.decision(32, 1); e.decision(32, 0); e.decision(32, 1)
+            off, b0 = 32, 32
+        elif prefix_p:
             e.decision(14, 1)
             off, b0 = 17, 17
         else:
@@ -261,7 +265,49 @@ class CabacSlice:
         else:
             e.decision(21, 0); e.decision(22, 1); e.decision(23, 0)
 
-    def ref_idx(self, mx, my, b8, v, cur):
+    def mb_type_b(self, mx, my, t):
+        """t = 0 (B_Direct_16x16) .. 22 (B_8x8), Table 7-14 / 9-37(b)"""
+        e = self.enc
+        A, B = self.nb(mx, my)
+        ctx0 = 27 + int(A is not None and not A.direct) + int(B is not None and not B.direct)
+        if t == 0:
+            e.decision(ctx0, 0)
+            return
+        e.decision(ctx0, 1)
+        if t <= 2:                       # 1 0 b
+            e.decision(30, 0); e.decision(32, t - 1)
+            return
+        e.decision(30, 1)
+        if 3 <= t <= 10:
+            bits = [(t - 3) >> 2 & 1, (t - 3) >> 1 & 1, (t - 3) & 1]; first = 0
+        elif t == 11:
+            first, bits = 1, [1, 1, 0]      # 1110
+        elif t == 22:
+            first, bits = 1, [1, 1, 1]      # 1111
+        else:                                # 12..21: five bits 1 0000 .. 1 1001
+            v = t - 12
+            first, bits = 1, [v >> 3 & 1, v >> 2 & 1, v >> 1 & 1, v & 1]
+        e.decision(31, first)
+        for b in bits:
+            e.decision(32, b)
+
+    def sub_mb_type_b(self, t):
+        e = self.enc
+        if t == 0:
+            e.decision(36, 0)
+            return
+        e.decision(36, 1)
+        if t <= 2:                       # 1 0 b
+            e.decision(37, 0); e.decision(39, t - 1)
+            return
+        e.decision(37, 1)
+        code = {3: [0, 0, 0], 4: [0, 0, 1], 5: [0, 1, 0], 6: [0, 1, 1], 11: [1, 1, 0], 12: [1, 1, 1],
+                7: [1, 0, 0, 0], 8: [1, 0, 0, 1], 9: [1, 0, 1, 0], 10: [1, 0, 1, 1]}[t]
+        e.decision(38, code[0])
+        for b in code[1:]:
+            e.decision(39, b)
+
+    def ref_idx(self, mx, my, b8, v, cur, lst=0):
         # neighbours of the 8x8 partition's top-left 4x4
         bx, by = (b8 & 1) * 2, (b8 >> 1) * 2
         (da, ia), (db, ib) = self.blk_nb(bx, by)
@@ -273,7 +319,7 @@ class CabacSlice:
                 m = self.fs.get(mx - 1, my, self.sl) if horiz else self.fs.get(mx, my - 1, self.sl)
             if m is None or m.intra or m.skip or not m.inter:
                 return 0
-            return int(m.refgt0[i >> 2])
+            return int(m.refgt0[lst][i >> 2])
         inc = cond(da, ia, True) + 2 * cond(db, ib, False)
         e = self.enc
         if v == 0:
@@ -284,7 +330,7 @@ class CabacSlice:
             e.decision(54 + (4 if k == 1 else 5), 1)
         e.decision(54 + (4 if v == 1 else 5), 0)
 
-    def mvd(self, mx, my, blk, comp, v, cur):
+    def mvd(self, mx, my, blk, comp, v, cur, lst=0):
         (da, ia), (db, ib) = self.blk_nb(BLK_X[blk], BLK_Y[blk])
 
         def amv(d, i, horiz):
@@ -294,7 +340,7 @@ class CabacSlice:
                 m = self.fs.get(mx - 1, my, self.sl) if horiz else self.fs.get(mx, my - 1, self.sl)
             if m is None or m.intra or m.skip or not m.inter:
                 return 0
-            return abs(m.mvd[i][comp])
+            return abs(m.mvd[lst][i][comp])
         s = amv(da, ia, True) + amv(db, ib, False)
         inc = 0 if s < 3 else (1 if s <= 32 else 2)
         off = 40 if comp == 0 else 47
@@ -455,24 +501,26 @@ class CabacSlice:
         return 1
 
     # ---- one macroblock ---------------------------------------------------------------------------
-    def macroblock(self, mx, my, mb, num_ref_l0):
+    def macroblock(self, mx, my, mb, num_ref_l0, num_ref_l1=1):
         """mb: dict as built by make_streams.Synth (an empty dict = skipped macroblock)."""
         e = self.enc
+        num_ref = (num_ref_l0, num_ref_l1)
         cur = self.fs.mb[my * self.fs.W + mx]
         cur.slice = self.sl
         cur.skip, cur.intra, cur.nxn, cur.i16, cur.inter = False, False, False, False, False
         cur.cbp_l, cur.cbp_c, cur.cmode, cur.t8 = 0, 0, 0, False
         cur.cbf_y, cur.cbf_dc, cur.cbf_cdc, cur.cbf_cac = [0] * 16, 0, [0, 0], [[0] * 4, [0] * 4]
-        cur.mvd, cur.refgt0 = [(0, 0)] * 16, [False] * 4
+        cur.mvd, cur.refgt0 = [[(0, 0)] * 16, [(0, 0)] * 16], [[False] * 4, [False] * 4]
+        cur.direct = False
         skipped = "mb_type" not in mb
-        if self.st == 0:
+        if self.st != 2:
             self.mb_skip_flag(mx, my, skipped)
         if skipped:
-            cur.skip = True
+            cur.skip = cur.direct = True
             self.prev_qpd_nz = False
             return
         t = mb["mb_type"]
-        base = 0 if self.st == 2 else 5
+        base = {2: 0, 0: 5, 1: 23}[self.st]
         intra = t >= base
         blocks = list(mb.get("coeffLevels", []))
         if intra:
@@ -494,38 +542,43 @@ class CabacSlice:
                 cbp = (15 if k // 12 else 0) | ((k % 12) // 4) << 4
             cur.cmode = mb["intra_chroma_pred_mode"]
             self.intra_chroma_pred_mode(mx, my, cur.cmode)
+        elif self.st == 1:
+            cur.inter = True
+            self.mb_type_b(mx, my, t)
+            self.b_motion(mx, my, mb, t, cur, num_ref)
+            cbp = mb["coded_block_pattern"]
         else:
             cur.inter = True
             self.mb_type_p(t)
-            mvds = list(mb["mvds"])
+            mvds = list(mb.get("mvds", []))
             if t <= 2:
                 parts = [[(0, range(16))], [(0, range(8)), (2, range(8, 16))],
                          [(0, [0, 1, 2, 3, 8, 9, 10, 11]), (1, [4, 5, 6, 7, 12, 13, 14, 15])]][t]
                 refs = mb.get("ref_idx", {})
-                cur.refgt0 = [False] * 4
+                cur.refgt0[0] = [False] * 4
                 for b8, blks in parts:   # syntax order: ref_idx of every partition, then mvd of every partition
                     r = refs.get(str(b8), 0)
                     if num_ref_l0 > 1:
                         self.ref_idx(mx, my, b8, r, cur)
                     for q in set(i >> 2 for i in blks):
-                        cur.refgt0[q] = r > 0
+                        cur.refgt0[0][q] = r > 0
                 for (b8, blks), (dx, dy) in zip(parts, mvds):
                     first = list(blks)[0]
                     self.mvd(mx, my, first, 0, dx, cur)
                     self.mvd(mx, my, first, 1, dy, cur)
                     for i in blks:
-                        cur.mvd[i] = (dx, dy)
+                        cur.mvd[0][i] = (dx, dy)
             else:
                 subs = mb["sub_mb_types"]
                 for s_ in subs:
                     self.sub_mb_type_p(s_)
                 refs = mb.get("ref_idx", {})
-                cur.refgt0 = [False] * 4
+                cur.refgt0[0] = [False] * 4
                 for b8 in range(4):
                     r = refs.get(str(b8), 0)
                     if num_ref_l0 > 1:  # P_8x8ref0 (mb_type 4) does not exist with CABAC: written as P_8x8 with explicit ref_idx 0
                         self.ref_idx(mx, my, b8, r, cur)
-                    cur.refgt0[b8] = r > 0
+                    cur.refgt0[0][b8] = r > 0
                 it_m = iter(mvds)
                 for b8, s_ in enumerate(subs):
                     shapes = {0: [[0, 1, 2, 3]], 1: [[0, 1], [2, 3]], 2: [[0, 2], [1, 3]], 3: [[0], [1], [2], [3]]}[s_]
@@ -535,7 +588,7 @@ class CabacSlice:
                         self.mvd(mx, my, first, 0, dx, cur)
                         self.mvd(mx, my, first, 1, dy, cur)
                         for q in sub:
-                            cur.mvd[b8 * 4 + q] = (dx, dy)
+                            cur.mvd[0][b8 * 4 + q] = (dx, dy)
             cbp = mb["coded_block_pattern"]
         if not cur.i16:
             self.coded_block_pattern(mx, my, cbp, cur)
@@ -575,6 +628,63 @@ class CabacSlice:
                 for b in range(4):
                     c = next(bi)["c"]
                     cur.cbf_cac[pl][b] = self.residual_block(4, c, self.cbf_ctx_inc(mx, my, 4, (pl, b), cur))
+
+    def b_motion(self, mx, my, mb, t, cur, num_ref):
+        """ref_idx_l0, ref_idx_l1, mvd_l0, mvd_l1 of a B macroblock, in syntax order (7.3.5.1 / 7.3.5.2)."""
+        if t == 0:
+            cur.direct = True
+            return
+        refs = mb.get("ref_idx", {})
+        mvds = iter(mb.get("mvds", []))
+        if t <= 21:
+            if t <= 3:
+                parts = [(0, list(range(16)), t - 1)]
+            else:
+                pm = [(0, 0), (1, 1), (0, 1), (1, 0), (0, 2), (1, 2), (2, 0), (2, 1), (2, 2)][(t - 4) >> 1]
+                if t & 1:   # 8x16
+                    parts = [(0, [0, 1, 2, 3, 8, 9, 10, 11], pm[0]), (1, [4, 5, 6, 7, 12, 13, 14, 15], pm[1])]
+                else:       # 16x8
+                    parts = [(0, list(range(8)), pm[0]), (2, list(range(8, 16)), pm[1])]
+            for lst in range(2):
+                for b8, blks, mode in parts:
+                    if mode in (lst, 2):
+                        r = refs.get(str(b8 + 4 * lst), 0)
+                        if num_ref[lst] > 1:
+                            self.ref_idx(mx, my, b8, r, cur, lst)
+                        for q in set(i >> 2 for i in blks):
+                            cur.refgt0[lst][q] = r > 0
+            for lst in range(2):
+                for b8, blks, mode in parts:
+                    if mode in (lst, 2):
+                        dx, dy = next(mvds)
+                        self.mvd(mx, my, blks[0], 0, dx, cur, lst)
+                        self.mvd(mx, my, blks[0], 1, dy, cur, lst)
+                        for i in blks:
+                            cur.mvd[lst][i] = (dx, dy)
+            return
+        subs = mb["sub_mb_types"]
+        for s_ in subs:
+            self.sub_mb_type_b(s_)
+        spm = {0: -1, 1: 0, 2: 1, 3: 2, 4: 0, 5: 0, 6: 1, 7: 1, 8: 2, 9: 2, 10: 0, 11: 1, 12: 2}
+        shapes = {1: [[0, 1, 2, 3]], 2: [[0, 1, 2, 3]], 3: [[0, 1, 2, 3]], 4: [[0, 1], [2, 3]], 5: [[0, 2], [1, 3]],
+                  6: [[0, 1], [2, 3]], 7: [[0, 2], [1, 3]], 8: [[0, 1], [2, 3]], 9: [[0, 2], [1, 3]],
+                  10: [[0], [1], [2], [3]], 11: [[0], [1], [2], [3]], 12: [[0], [1], [2], [3]]}
+        for lst in range(2):
+            for b8, s_ in enumerate(subs):
+                if spm[s_] in (lst, 2):
+                    r = refs.get(str(b8 + 4 * lst), 0)
+                    if num_ref[lst] > 1:
+                        self.ref_idx(mx, my, b8, r, cur, lst)
+                    cur.refgt0[lst][b8] = r > 0
+        for lst in range(2):
+            for b8, s_ in enumerate(subs):
+                if spm[s_] in (lst, 2):
+                    for sub in shapes[s_]:
+                        dx, dy = next(mvds)
+                        self.mvd(mx, my, b8 * 4 + sub[0], 0, dx, cur, lst)
+                        self.mvd(mx, my, b8 * 4 + sub[0], 1, dy, cur, lst)
+                        for q in sub:
+                            cur.mvd[lst][b8 * 4 + q] = (dx, dy)
 
     def end_of_slice(self, last):
         self.enc.terminate(int(last))

@@ -28,7 +28,8 @@ def frame_md5s(path, w_mbs, h_mbs):
 @pytest.mark.parametrize("names,repeat", [
     (["ipb_spatial", "t8x8_scaling", "slices_deblock_idc", "weighted_explicit", "one_mb", "tall_narrow", "i_4x4_16x16_pcm"], 3),
     (["hd1080_ippb", "cabac_hd1080_ipp"], 4),
-    (["cabac_i", "cabac_ipp", "cabac_t8x8_scaling", "cabac_slices_deblock_idc", "cabac_weighted", "cabac_big_levels"], 2),
+    (["cabac_i", "cabac_ipp", "cabac_t8x8_scaling", "cabac_slices_deblock_idc", "cabac_weighted", "cabac_big_levels",
+      "cabac_ipb_spatial", "cabac_ipb_temporal_implicit", "cabac_weighted_b"], 2),
 ])
 def test_multi_stream_driver(tmp_path, names, repeat):
     for p in (EXE, FRONT, HIP):
