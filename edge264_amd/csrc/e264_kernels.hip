@@ -33,12 +33,9 @@ __device__ __forceinline__ int clip3i(int lo, int hi, int v) { return min(max(v,
 __device__ __forceinline__ int clip255(int v) { return min(max(v, 0), 255); }
 __device__ __forceinline__ int sat16(int v) { return min(max(v, -32768), 32767); }
 __device__ __forceinline__ int w16(int v) { return (int)(int16_t)v; }
-// build-time experiment switches (tools/ab_variants.sh builds one library per setting)
+// build-time experiment switches (`make variant NAME=.. DEFS=-D..` builds one library per setting, tools/gpu_ab.sh compares them)
 #ifndef E264_LUMA_PACKED
 #define E264_LUMA_PACKED 1 // luma interpolation in packed 16-bit arithmetic (two samples per VALU instruction)
-#endif
-#ifndef E264_LUMA_SKIP
-#define E264_LUMA_SKIP 0 // 1: wave-uniform tap skipping also for macroblocks with several vectors (measured slower: +27% SALU)
 #endif
 typedef uint8_t __attribute__((address_space(1))) gu8;   // global memory, so that loads/stores are global_* not flat_*
 typedef uint32_t __attribute__((address_space(1))) gu32;

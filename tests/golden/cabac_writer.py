@@ -7,7 +7,7 @@ gen_avc.py's CAVLC writer (mb_type, prediction modes, sub_mb_types, ref_idx, mvd
 transform_size_8x8_flag, mb_qp_delta, coefficient lists in scan order), following ITU-T H.264 9.3:
 binarisations (9.3.2), context selection (9.3.3.1) and the arithmetic encoder (9.3.4.2 / Figure 9-7..9-12).
 
-Scope: I, P and B slices, frame macroblocks, 4:2:0; every macroblock type make_streams.py produces except I_PCM.  Correctness is established by the unmodified reference decoder: it must decode the CABAC
+Scope: I, P and B slices, frame macroblocks, 4:2:0; every macroblock type make_streams.py produces, I_PCM included.  Correctness is established by the unmodified reference decoder: it must decode the CABAC
 stream without error to exactly the frames of the CAVLC stream generated from the same description.
 
 Tables: the context initialisation values (Tables 9-12..9-33) are read at generation time from the reference
@@ -132,6 +132,14 @@ class Encoder:
         else:
             self._renorm()
 
+    def pcm_samples(self, samples):
+        """after terminate(1): pcm_alignment_zero_bits, the raw samples, then the engine starts afresh (9.3.1.2);
+        the context variables keep their states."""
+        self.bits += [0] * (-len(self.bits) % 8)
+        for v in samples:
+            self.bits += [(v >> k) & 1 for k in range(7, -1, -1)]
+        self.low, self.range, self.outstanding, self.first = 0, 510, 0, True
+
     # ---- binarisation helpers -------------------------------------------------------------------
     def ueg_suffix(self, v, k):
         while v >= (1 << k):
@@ -154,7 +162,7 @@ CAT = {0: (85, 105, 166, 227), 1: (89, 120, 181, 237), 2: (93, 134, 195, 247), 3
 
 class MbState:
     __slots__ = ("slice", "skip", "intra", "nxn", "i16", "cbp_l", "cbp_c", "cmode", "t8", "cbf_y", "cbf_dc", "cbf_cdc",
-                 "cbf_cac", "mvd", "refgt0", "inter", "direct")
+                 "cbf_cac", "mvd", "refgt0", "inter", "direct", "pcm")
 
     def __init__(self):
         self.slice = -1
@@ -221,6 +229,9 @@ class CabacSlice:
             e.decision(b0, 0)
             return
         e.decision(b0, 1)
+        if t == 25:      # I_PCM: the terminate bin is 1 and flushes the arithmetic coder
+            e.terminate(1)
+            return
         e.terminate(0)
         t -= 1
         luma15, chroma, pred = t // 12, (t % 12) // 4, t % 4
@@ -429,6 +440,8 @@ class CabacSlice:
                 return int(cur.intra)
             if m.skip:
                 return 0
+            if m.pcm:
+                return 1
             v = getter(m)
             return 0 if v is None else int(v)
         A, B = self.nb(mx, my)
@@ -511,7 +524,7 @@ class CabacSlice:
         cur.cbp_l, cur.cbp_c, cur.cmode, cur.t8 = 0, 0, 0, False
         cur.cbf_y, cur.cbf_dc, cur.cbf_cdc, cur.cbf_cac = [0] * 16, 0, [0, 0], [[0] * 4, [0] * 4]
         cur.mvd, cur.refgt0 = [[(0, 0)] * 16, [(0, 0)] * 16], [[False] * 4, [False] * 4]
-        cur.direct = False
+        cur.direct = cur.pcm = False
         skipped = "mb_type" not in mb
         if self.st != 2:
             self.mb_skip_flag(mx, my, skipped)
@@ -525,9 +538,16 @@ class CabacSlice:
         blocks = list(mb.get("coeffLevels", []))
         if intra:
             it = t - base
-            assert it < 25, "I_PCM is not supported by the CABAC writer"
             cur.intra = True
             self.mb_type_intra(mx, my, it, self.st != 2)
+            if it == 25:
+                ps = mb["pcm_samples"]
+                e.pcm_samples(list(ps["Y"]) + list(ps["Cb"]) + list(ps["Cr"]))
+                cur.pcm = True
+                cur.cbp_l, cur.cbp_c = 15, 2
+                cur.cbf_y, cur.cbf_dc, cur.cbf_cdc, cur.cbf_cac = [1] * 16, 1, [1, 1], [[1] * 4, [1] * 4]
+                self.prev_qpd_nz = False
+                return
             if it == 0:
                 cur.nxn = True
                 t8 = int(mb.get("transform_size_8x8_flag", 0))

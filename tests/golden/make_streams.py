@@ -503,7 +503,7 @@ STREAMS = [
     ("low_qp_big_levels", 4, 3, "IPP", 11, dict(qp=12, big_levels=0.2, coef_density=0.8)),
     ("high_qp", 4, 3, "IPB", 12, dict(qp=46, cqp=(6, 6))),
     # BASELINE geometry through the real parser: sparse residual / many skips keep the file small
-    # CABAC (tests/golden/cabac_writer.py; I, P and B slices, no I_PCM).  Each is also generated as CAVLC from the same
+    # CABAC (tests/golden/cabac_writer.py; I, P and B slices).  Each is also generated as CAVLC from the same
     # description and the two must decode to identical frames with the unmodified reference (checked in main()).
     ("cabac_i", 5, 4, "II", 31, dict(cabac=True, pcm=0.0)),
     ("cabac_ipp", 5, 4, "IPPP", 32, dict(cabac=True, pcm=0.0, num_refs=2)),
@@ -514,6 +514,7 @@ STREAMS = [
     ("cabac_ipb_spatial", 5, 4, "IPBPB", 38, dict(cabac=True, pcm=0.0, num_refs=2)),
     ("cabac_ipb_temporal_implicit", 5, 4, "IPBPBB", 39, dict(cabac=True, pcm=0.0, num_refs=3, direct_spatial=0, weighted_bipred=2, t8x8=True)),
     ("cabac_weighted_b", 4, 3, "IPPBPB", 40, dict(cabac=True, pcm=0.0, num_refs=2, weighted_pred=1, weighted_bipred=1)),
+    ("cabac_pcm", 5, 4, "IPBP", 41, dict(cabac=True, pcm=0.12, num_refs=2)),
     ("cabac_hd1080_ipp", 120, 68, "IPP", 37, dict(cabac=True, pcm=0.0, num_refs=2, level=4.0, skip=0.45, coef_density=0.12,
                                                    intra_in_inter=0.03, cbp_zero=0.8)),
     ("hd1080_ippb", 120, 68, "IPPB", 13, dict(num_refs=2, level=4.0, skip=0.45, coef_density=0.12, intra_in_inter=0.03, pcm=0.0005, cbp_zero=0.8)),
