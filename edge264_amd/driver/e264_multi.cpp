@@ -4,11 +4,12 @@
 // N decoder instances (edge264.h API, served by the reference's parsers + our emitters in sink mode 2: frames
 // live in HBM, finished command packets are queued) are advanced round-robin, one frame each per round; the
 // packets of a round go to the GPU as ONE batch (e264hip_submit_batch: 4 kernel launches for all streams), then
-// every decoder's output frames are fetched.  Host parsing is single-threaded here on purpose (the reference
-// front end is used with n_threads = 0); more host cores = more processes, one per GPU (bench.py --gpus).
+// every decoder's output frames are fetched.  Host parsing (the reference front end with n_threads = 0) is spread
+// over --threads T host threads, each owning a fixed subset of the decoders; the batch submission is done by the
+// main thread between two barriers.
 //
 //   e264_multi --front <libedge264_hipfront.so> --hip <libedge264_hip.so> [--device N] [--repeat R]
-//              [--out DIR] [--dump-packets FILE] a.264 b.264 ...
+//              [--threads T] [--out DIR] [--dump-packets FILE] [--parse-only] a.264 b.264 ...
 //
 // --out writes s<k>.yuv (cropped Y, Cb, Cr planes of every output frame, as README.md:126-155 of the reference
 // does); --dump-packets appends every command packet (self-describing: E264FrameHdr.total_bytes) = the capture
@@ -23,7 +24,11 @@
 #include <execinfo.h>
 #include <signal.h>
 #include <unistd.h>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 // edge264.h:45-62 (layout restated; the header itself is not part of this repository)
@@ -96,7 +101,7 @@ int main(int argc, char **argv)
 	signal(SIGSEGV, on_crash);
 	signal(SIGBUS, on_crash);
 	std::string front_path, hip_path, out_dir, dump_path;
-	int device = 0, repeat = 1;
+	int device = 0, repeat = 1, n_threads = 1;
 	bool parse_only = false; // --parse-only: sink 1, no GPU: packets are produced and dropped (front-end speed / debugging)
 	std::vector<std::string> files;
 	for (int i = 1; i < argc; i++) {
@@ -107,6 +112,7 @@ int main(int argc, char **argv)
 		else if (a == "--device") device = atoi(next().c_str());
 		else if (a == "--repeat") repeat = atoi(next().c_str());
 		else if (a == "--parse-only") parse_only = true;
+		else if (a == "--threads") n_threads = atoi(next().c_str());
 		else if (a == "--out") out_dir = next();
 		else if (a == "--dump-packets") dump_path = next();
 		else files.push_back(a);
@@ -170,21 +176,43 @@ int main(int argc, char **argv)
 	};
 	long rounds = 0, packets = 0, total_frames = 0;
 	std::vector<void *> streams, dpk;
+	// 1. advance a decoder until its next frame is complete (or its stream ends)
+	auto advance = [&](Stream &s) {
+		while (!s.done && !s.pkt) {
+			const uint8_t *nxt = s.nal < s.end ? F.find_start_code(s.nal, s.end, 0) : s.end;
+			int res = F.decode_NAL(s.dec, s.nal, nxt, nullptr, nullptr);
+			if (res == ENOBUFS) { drain(s); continue; } // every earlier packet of this stream is already on the device
+			if (F.take_packet(s.dec, &s.pkt, &s.pkt_bytes) != 0) s.pkt = nullptr;
+			if (res == ENODATA || s.nal >= s.end) { s.done = true; break; }
+			s.nal = nxt + 3 < s.end ? nxt + 3 : s.end;
+		}
+	};
+	// worker threads: thread k owns decoders k, k+T, k+2T, ...; phases are separated by a counting barrier
+	if (n_threads < 1) n_threads = 1;
+	if ((size_t)n_threads > S.size()) n_threads = (int)S.size();
+	std::mutex mu; std::condition_variable cv;
+	int phase = 0, arrived = 0; bool quit = false;
+	auto barrier = [&](std::unique_lock<std::mutex> &lk) { // all n_threads participants (main is participant 0)
+		int my = phase;
+		if (++arrived == n_threads) { arrived = 0; phase++; cv.notify_all(); }
+		else cv.wait(lk, [&] { return phase != my; });
+	};
+	std::vector<std::thread> pool;
+	for (int k = 1; k < n_threads; k++)
+		pool.emplace_back([&, k] {
+			for (;;) {
+				{ std::unique_lock<std::mutex> lk(mu); barrier(lk); if (quit) return; } // start of a parse phase
+				for (size_t i = (size_t)k; i < S.size(); i += (size_t)n_threads) { drain(S[i]); advance(S[i]); }
+				{ std::unique_lock<std::mutex> lk(mu); barrier(lk); }                    // end of the parse phase
+			}
+		});
 	auto t0 = std::chrono::steady_clock::now();
 	for (;;) {
 		bool any = false;
-		// 1. advance every decoder until its next frame is complete (or its stream ends)
-		for (Stream &s : S) {
-			while (!s.done && !s.pkt) {
-				const uint8_t *nxt = s.nal < s.end ? F.find_start_code(s.nal, s.end, 0) : s.end;
-				int res = F.decode_NAL(s.dec, s.nal, nxt, nullptr, nullptr);
-				if (res == ENOBUFS) { drain(s); continue; } // every earlier packet of this stream is already on the device
-				if (F.take_packet(s.dec, &s.pkt, &s.pkt_bytes) != 0) s.pkt = nullptr;
-				if (res == ENODATA || s.nal >= s.end) { s.done = true; break; }
-				s.nal = nxt + 3 < s.end ? nxt + 3 : s.end;
-			}
-			any |= s.pkt != nullptr;
-		}
+		{ std::unique_lock<std::mutex> lk(mu); barrier(lk); }
+		for (size_t i = 0; i < S.size(); i += (size_t)n_threads) { drain(S[i]); advance(S[i]); }
+		{ std::unique_lock<std::mutex> lk(mu); barrier(lk); }
+		for (Stream &s : S) any |= s.pkt != nullptr;
 		// 2. one batch for the whole round
 		streams.clear(); dpk.clear();
 		for (Stream &s : S)
@@ -202,11 +230,12 @@ int main(int argc, char **argv)
 			for (void *d : dpk) H.packet_free(d);
 			rounds++; packets += (long)streams.size();
 		}
-		if (parse_only) rounds++;
-		// 3. output
-		for (Stream &s : S) drain(s);
+		if (parse_only && any) rounds++;
+		// 3. output happens at the start of the next parse phase (each thread drains its own decoders)
 		if (!any) break;
 	}
+	{ std::unique_lock<std::mutex> lk(mu); quit = true; barrier(lk); }
+	for (std::thread &t : pool) t.join();
 	double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	for (Stream &s : S) {
 		drain(s);
@@ -215,7 +244,7 @@ int main(int argc, char **argv)
 		F.free_dec(&s.dec);
 	}
 	if (dump) fclose(dump);
-	printf("{\"streams\": %zu, \"frames\": %ld, \"packets\": %ld, \"rounds\": %ld, \"avg_batch\": %.2f, \"seconds\": %.4f, \"frames_per_s\": %.1f}\n",
-		S.size(), total_frames, packets, rounds, rounds ? (double)packets / rounds : 0.0, sec, sec > 0 ? total_frames / sec : 0.0);
+	printf("{\"streams\": %zu, \"threads\": %d, \"frames\": %ld, \"packets\": %ld, \"rounds\": %ld, \"avg_batch\": %.2f, \"seconds\": %.4f, \"frames_per_s\": %.1f}\n",
+		S.size(), n_threads, total_frames, packets, rounds, rounds ? (double)packets / rounds : 0.0, sec, sec > 0 ? total_frames / sec : 0.0);
 	return 0;
 }

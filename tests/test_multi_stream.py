@@ -38,7 +38,7 @@ def test_multi_stream_driver(tmp_path, names, repeat):
         sums = json.load(f)
     files = [os.path.join(STREAMS, n + ".264") for n in names]
     dump = tmp_path / "packets.e264"
-    out = subprocess.run([EXE, "--front", FRONT, "--hip", HIP, "--repeat", str(repeat), "--out", str(tmp_path),
+    out = subprocess.run([EXE, "--front", FRONT, "--hip", HIP, "--repeat", str(repeat), "--threads", "3", "--out", str(tmp_path),
                           "--dump-packets", str(dump)] + files, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     stats = json.loads(out.stdout.strip().splitlines()[-1])
