@@ -958,7 +958,7 @@ __device__ __forceinline__ void mc_compute(WaveLds &L, const FrameCtx &f, cslice
 }
 
 // stage C of one macroblock of the strip: everything that is not intra prediction
-__device__ __forceinline__ bool mbpar_mb(WaveLds &L, StripOut &O, int slot, const FrameCtx &f, const MbInfo &m, const McMotion &M, const int cc[6],
+__device__ __forceinline__ bool mbpar_mb(WaveLds &L, StripOut &O, int slot, const FrameCtx &f, const MbInfo &m, const McMotion &M, const int cc[6], const McWindows &W1,
 	int mbx, int mby, int lane)
 { // returns true when the macroblock's samples were staged in O.y/O.c[slot]
 	if (m.kind != E264_MB_INTER && m.kind != E264_MB_PCM)
@@ -978,10 +978,8 @@ __device__ __forceinline__ bool mbpar_mb(WaveLds &L, StripOut &O, int slot, cons
 	if (has_res) compute_residual(L, f, m, s, pl, lane);
 	int pY[4] = {0, 0, 0, 0}, pC[2] = {0, 0};
 	mc_compute(L, f, s, M, 0, cc, mbx, mby, lane, pY, pC); // list 0: window already in LDS (prefetched)
-	if (M.refs[1] != 0xffffffffu) { // list 1 (B macroblocks): fetched here, not pipelined
-		McWindows W1;
+	if (M.refs[1] != 0xffffffffu) { // list 1 (B macroblocks): its windows were prefetched with list 0's; same LDS area, second turn
 		wave_sync();
-		mc_issue(f, M, 1, mbx, mby, lane, W1);
 		mc_commit(L, M, 1, W1, mbx, mby, lane);
 		mc_commit_tail(L, f, M, 1, mbx, mby, lane);
 		wave_sync();
@@ -1829,7 +1827,8 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 	//         (luma) and copied out (chroma taps cc) at the top of iteration i+1
 	McRaw raw;
 	McMotion m0, m1;
-	McWindows w;
+	McWindows w, wb, wbc; // wb: list-1 windows of macroblock i+1 in flight; wbc: those of macroblock i (copied once they arrived)
+	wb.y0 = wb.y1 = wb.y2 = wb.y3 = wb.ca = wb.cb = 0; wbc = wb;
 	int cc[6] = {0, 0, 0, 0, 0, 0};
 	mc_issue_raw(f, base, lane, raw);
 	mc_finish(raw, lane, m0);
@@ -1839,8 +1838,10 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 	const int mbx0 = mbx, mby0 = mby;
 	StripOut &O = outs[wave];
 	uint32_t staged = 0;
-	if (recon && h0.kind == E264_MB_INTER)
+	if (recon && h0.kind == E264_MB_INTER) {
 		mc_issue(f, m0, 0, mbx, mby, lane, w);
+		mc_issue(f, m0, 1, mbx, mby, lane, wb);
+	}
 #pragma unroll 1
 	for (int i = 0; i < n; i++) {
 		int nx = mbx + 1, ny = mby;
@@ -1851,13 +1852,16 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 			mc_commit(L, m0, 0, w, mbx, mby, lane);
 			mc_commit_tail(L, f, m0, 0, mbx, mby, lane);
 			chroma_taps(w, cc);
+			if (m0.refs[1] != 0xffffffffu) wbc = wb; // list 1 in use (uniform): take over the prefetched registers (they have arrived with list 0's)
 		}
 		wave_sync();
 		const int i1 = min(i + 1, n - 1);
 		const MbInfo h1 = mb_from_lanes(HV(i1), i1 & 7);
-		if (recon && i + 1 < n && h1.kind == E264_MB_INTER)
+		if (recon && i + 1 < n && h1.kind == E264_MB_INTER) {
 			mc_issue(f, m1, 0, nx, ny, lane, w);
-		if (recon && mbpar_mb(L, O, i, f, h0, m0, cc, mbx, mby, lane))
+			mc_issue(f, m1, 1, nx, ny, lane, wb);
+		}
+		if (recon && mbpar_mb(L, O, i, f, h0, m0, cc, wbc, mbx, mby, lane))
 			staged |= 1u << i;
 		wave_sync();
 		h0 = h1; m0 = m1;
