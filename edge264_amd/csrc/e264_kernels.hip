@@ -1846,8 +1846,9 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 	for (int i = 0; i < n; i++) {
 		int nx = mbx + 1, ny = mby;
 		if (nx == f.wm) { nx = 0; ny++; }
+		// every load of the previous iteration is consumed first (the compiler's vmcnt bookkeeping collapses to
+		// vmcnt(0) across these branches: a load issued before this point would be waited for at once) ...
 		if (i + 1 < n) mc_finish(raw, lane, m1);             // motion of macroblock i+1 (loads issued one iteration ago)
-		if (i + 2 < n) mc_issue_raw(f, base + i + 2, lane, raw);
 		if (recon && h0.kind == E264_MB_INTER) {
 			mc_commit(L, m0, 0, w, mbx, mby, lane);
 			mc_commit_tail(L, f, m0, 0, mbx, mby, lane);
@@ -1855,6 +1856,8 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 			if (m0.refs[1] != 0xffffffffu) wbc = wb; // list 1 in use (uniform): take over the prefetched registers (they have arrived with list 0's)
 		}
 		wave_sync();
+		// ... then the loads of the next stages go out, with the whole reconstruction of macroblock i to hide them
+		if (i + 2 < n) mc_issue_raw(f, base + i + 2, lane, raw);
 		const int i1 = min(i + 1, n - 1);
 		const MbInfo h1 = mb_from_lanes(HV(i1), i1 & 7);
 		if (recon && i + 1 < n && h1.kind == E264_MB_INTER) {
