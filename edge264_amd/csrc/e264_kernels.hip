@@ -1849,7 +1849,7 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 		// every load of the previous iteration is consumed first (the compiler's vmcnt bookkeeping collapses to
 		// vmcnt(0) across these branches: a load issued before this point would be waited for at once) ...
 		if (i + 1 < n) mc_finish(raw, lane, m1);             // motion of macroblock i+1 (loads issued one iteration ago)
-		if (recon && h0.kind == E264_MB_INTER) {
+		if (recon && h0.kind == E264_MB_INTER && !(mode & 8192)) { // 8192: profiling ablation, windows are loaded but never consumed
 			mc_commit(L, m0, 0, w, mbx, mby, lane);
 			mc_commit_tail(L, f, m0, 0, mbx, mby, lane);
 			chroma_taps(w, cc);
