@@ -54,6 +54,7 @@ def load_library():
         "e264hip_packet_upload": (i, [vp, vp, sz, C.POINTER(vp)]),
         "e264hip_packet_free": (None, [vp]),
         "e264hip_submit_batch": (i, [vp, C.POINTER(vp), C.POINTER(vp), i, i]),
+        "e264hip_submit_batch_host": (i, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), i, i]),
         "e264hip_batch_create": (i, [vp, C.POINTER(vp), C.POINTER(vp), i, C.POINTER(vp)]),
         "e264hip_batch_submit": (i, [vp, i]),
         "e264hip_batch_free": (None, [vp]),
@@ -75,7 +76,7 @@ EXPORTED_SYMBOLS = [
     "e264hip_stream_open", "e264hip_stream_close", "e264hip_stream_flush", "e264hip_frame_alloc",
     "e264hip_frame_free", "e264hip_frame_fill", "e264hip_frame_upload", "e264hip_frame_submit",
     "e264hip_packet_buffer", "e264hip_frame_wait", "e264hip_frame_download", "e264hip_packet_upload",
-    "e264hip_packet_free", "e264hip_submit_batch", "e264hip_batch_create", "e264hip_batch_submit", "e264hip_batch_free", "e264hip_event_record", "e264hip_event_elapsed_ms",
+    "e264hip_packet_free", "e264hip_submit_batch", "e264hip_submit_batch_host", "e264hip_batch_create", "e264hip_batch_submit", "e264hip_batch_free", "e264hip_event_record", "e264hip_event_elapsed_ms",
     "e264hip_kernel_timing", "e264hip_kernel_time_ms", "e264hip_set_option",
 ]
 
@@ -115,6 +116,15 @@ class Device:
         sa = (C.c_void_p * n)(*[s.h for s in streams])
         pa = (C.c_void_p * n)(*[p.h for p in packets])
         _check(self.L, self.L.e264hip_submit_batch(self.h, sa, pa, n, mode), "submit_batch")
+
+    def submit_batch_host(self, streams, packets, mode: int = RUN_ALL) -> None:
+        """packets: bytes objects still in host memory (asynchronous: staged, copied and launched on the queue)."""
+        n = len(streams)
+        sa = (C.c_void_p * n)(*[s.h for s in streams])
+        bufs = [(C.c_char * len(p)).from_buffer_copy(p) for p in packets]
+        pa = (C.c_void_p * n)(*[C.cast(b, C.c_void_p) for b in bufs])
+        za = (C.c_size_t * n)(*[len(p) for p in packets])
+        _check(self.L, self.L.e264hip_submit_batch_host(self.h, sa, pa, za, n, mode), "submit_batch_host")
 
     def make_batch(self, streams, packets):
         """Device-resident job table for repeated launches (E264Batch)."""

@@ -48,6 +48,9 @@ struct E264Device {
 	struct Marks { hipEvent_t e[5]; };
 	std::vector<Marks> kev;
 	size_t kev_used;
+	// job tables of host-packet batches (e264hip_submit_batch_host): a ring of pinned + device buffers
+	struct JobRing { E264Job *h = nullptr, *d = nullptr; int cap = 0; hipEvent_t done = nullptr; bool busy = false; } jring[4];
+	int jring_next = 0;
 };
 
 struct E264Stream {
@@ -421,6 +424,58 @@ API int e264hip_submit_batch(E264Device *dev, E264Stream *const *streams, E264Pa
 	r = e264hip_batch_submit(b, mode);
 	e264hip_batch_free(b); // synchronises the queue: convenience path for tests
 	return r;
+}
+
+// Host packets of MANY streams, one submission, nothing synchronous: every packet is staged through its
+// stream's pinned ring and copied on the device queue, the job table through a device-level ring, then the four
+// kernels are launched.  The caller may reuse / free the host packets on return.
+API int e264hip_submit_batch_host(E264Device *dev, E264Stream *const *streams, const void *const *packets, const size_t *bytes, int n, int mode)
+{
+	if (!dev || !streams || !packets || !bytes || n <= 0) return fail(EINVAL, "submit_batch_host arguments");
+	if (set_device(dev)) return EIO;
+	E264Device::JobRing &jr = dev->jring[dev->jring_next];
+	dev->jring_next = (dev->jring_next + 1) & 3;
+	if (jr.busy) { hipEventSynchronize(jr.done); jr.busy = false; }
+	if (jr.cap < n) {
+		if (jr.h) hipHostFree(jr.h);
+		if (jr.d) hipFree(jr.d);
+		jr.h = nullptr; jr.d = nullptr; jr.cap = 0;
+		int cap = (n + 63) & ~63;
+		if (hipHostMalloc((void **)&jr.h, sizeof(E264Job) * cap, hipHostMallocDefault) != hipSuccess) return fail(ENOMEM, "pinned job table");
+		if (hipMalloc((void **)&jr.d, sizeof(E264Job) * cap) != hipSuccess) { hipHostFree(jr.h); jr.h = nullptr; return fail(ENOMEM, "device job table"); }
+		jr.cap = cap;
+		if (!jr.done) hipEventCreateWithFlags(&jr.done, hipEventDisableTiming);
+	}
+	int max_mbs = 0;
+	for (int i = 0; i < n; i++) {
+		E264Stream *s = streams[i];
+		if (!s || s->dev != dev) return fail(EINVAL, "batch entry");
+		for (int j = 0; j < i; j++)
+			if (streams[j] == s) return fail(EINVAL, "a stream may contribute one frame per batch");
+		int dst, n_mbs, r = check_packet(packets[i], bytes[i], &dst, &n_mbs);
+		if (r) return r;
+		if (!s->h_table[dst]) return fail(EINVAL, "destination slot not allocated");
+		if ((r = ensure_dbk(s, n_mbs))) return r;
+		void *h = e264hip_packet_buffer(s, bytes[i]);
+		if (!h) return ENOMEM;
+		E264Stream::Stage *st = &s->stage[s->stage_next];
+		s->stage_next = (s->stage_next + 1) & 3;
+		memcpy(h, packets[i], bytes[i]);
+		HIPCHK(hipMemcpyAsync(st->d, st->h, bytes[i], hipMemcpyHostToDevice, dev->q), EIO);
+		jr.h[i].packet = st->d; jr.h[i].dpb = s->d_table; jr.h[i].dbk = s->d_dbk;
+		if (n_mbs > max_mbs) max_mbs = n_mbs;
+	}
+	HIPCHK(hipMemcpyAsync(jr.d, jr.h, sizeof(E264Job) * n, hipMemcpyHostToDevice, dev->q), EIO);
+	int r = launch(dev, jr.d, n, max_mbs, mode);
+	if (r) return r;
+	hipEventRecord(jr.done, dev->q);
+	jr.busy = true;
+	for (int i = 0; i < n; i++) { // the staging slots are free again when this submission has retired
+		E264Stream::Stage &st = streams[i]->stage[(streams[i]->stage_next + 3) & 3];
+		hipEventRecord(st.done, dev->q);
+		st.busy = true;
+	}
+	return 0;
 }
 
 API int e264hip_event_record(E264Device *dev, int idx)

@@ -9,7 +9,7 @@
 // main thread between two barriers.
 //
 //   e264_multi --front <libedge264_hipfront.so> --hip <libedge264_hip.so> [--device N] [--repeat R]
-//              [--threads T] [--out DIR] [--dump-packets FILE] [--parse-only] a.264 b.264 ...
+//              [--threads T] [--out DIR] [--dump-packets FILE] [--parse-only] [--no-download] a.264 b.264 ...
 //
 // --out writes s<k>.yuv (cropped Y, Cb, Cr planes of every output frame, as README.md:126-155 of the reference
 // does); --dump-packets appends every command packet (self-describing: E264FrameHdr.total_bytes) = the capture
@@ -51,15 +51,14 @@ struct Front {
 	const uint8_t *(*find_start_code)(const uint8_t *, const uint8_t *, int);
 	void (*set_sink)(int);
 	void (*set_device)(int);
+	void (*set_download)(int);
 	int (*take_packet)(void *, void **, size_t *);
 	void (*free_packet)(void *);
 	void *(*stream)(void *);
 	void *(*device)(void);
 };
 struct Hip {
-	int (*packet_upload)(void *, const void *, size_t, void **);
-	void (*packet_free)(void *);
-	int (*submit_batch)(void *, void **, void **, int, int);
+	int (*submit_batch_host)(void *, void **, const void **, const size_t *, int, int);
 	int (*device_sync)(void *);
 	const char *(*last_error)(void);
 };
@@ -75,6 +74,8 @@ struct Stream {
 	const uint8_t *nal = nullptr, *end = nullptr;
 	void *dec = nullptr;
 	bool done = false;
+	int loops_left = 0;
+	const uint8_t *first_nal = nullptr;
 	long frames = 0;
 	FILE *out = nullptr;
 	void *pkt = nullptr; size_t pkt_bytes = 0;
@@ -101,7 +102,8 @@ int main(int argc, char **argv)
 	signal(SIGSEGV, on_crash);
 	signal(SIGBUS, on_crash);
 	std::string front_path, hip_path, out_dir, dump_path;
-	int device = 0, repeat = 1, n_threads = 1;
+	int device = 0, repeat = 1, n_threads = 1, loops = 1; // --loops K: every stream is played K times back to back (steady state)
+	bool no_download = false; // --no-download: output frames stay in HBM (edge264_get_frame does not copy them back)
 	bool parse_only = false; // --parse-only: sink 1, no GPU: packets are produced and dropped (front-end speed / debugging)
 	std::vector<std::string> files;
 	for (int i = 1; i < argc; i++) {
@@ -112,7 +114,9 @@ int main(int argc, char **argv)
 		else if (a == "--device") device = atoi(next().c_str());
 		else if (a == "--repeat") repeat = atoi(next().c_str());
 		else if (a == "--parse-only") parse_only = true;
+		else if (a == "--no-download") no_download = true;
 		else if (a == "--threads") n_threads = atoi(next().c_str());
+		else if (a == "--loops") loops = atoi(next().c_str());
 		else if (a == "--out") out_dir = next();
 		else if (a == "--dump-packets") dump_path = next();
 		else files.push_back(a);
@@ -129,17 +133,17 @@ int main(int argc, char **argv)
 	Front F; Hip H;
 	bind(fl, "edge264_alloc", F.alloc); bind(fl, "edge264_decode_NAL", F.decode_NAL); bind(fl, "edge264_get_frame", F.get_frame);
 	bind(fl, "edge264_free", F.free_dec); bind(fl, "edge264_find_start_code", F.find_start_code);
-	bind(fl, "e264front_set_sink", F.set_sink); bind(fl, "e264front_set_device", F.set_device);
+	bind(fl, "e264front_set_sink", F.set_sink); bind(fl, "e264front_set_device", F.set_device); bind(fl, "e264front_set_download", F.set_download);
 	bind(fl, "e264front_take_packet", F.take_packet); bind(fl, "e264front_free_packet", F.free_packet);
 	bind(fl, "e264front_stream", F.stream); bind(fl, "e264front_device", F.device);
 	if (!parse_only) {
-	bind(hl, "e264hip_packet_upload", H.packet_upload); bind(hl, "e264hip_packet_free", H.packet_free);
-	bind(hl, "e264hip_submit_batch", H.submit_batch); bind(hl, "e264hip_device_sync", H.device_sync);
+	bind(hl, "e264hip_submit_batch_host", H.submit_batch_host); bind(hl, "e264hip_device_sync", H.device_sync);
 	bind(hl, "e264hip_last_error", H.last_error);
 	}
 
 	F.set_device(device);
 	F.set_sink(parse_only ? 1 : 2);
+	F.set_download(no_download ? 0 : 1);
 	std::vector<Stream> S;
 	for (int r = 0; r < repeat; r++)
 		for (const std::string &path : files) {
@@ -155,6 +159,7 @@ int main(int argc, char **argv)
 			t.end = t.data.data() + n;
 			const uint8_t *p = F.find_start_code(t.data.data(), t.end, 0);
 			t.nal = p < t.end ? p + 3 : t.end;
+			t.first_nal = t.nal; t.loops_left = loops - 1;
 			t.dec = F.alloc(0, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
 			if (!t.dec) { fprintf(stderr, "e264_multi: edge264_alloc failed (no MI355X / back end?)\n"); return 2; }
 			if (!out_dir.empty()) {
@@ -175,7 +180,9 @@ int main(int argc, char **argv)
 		}
 	};
 	long rounds = 0, packets = 0, total_frames = 0;
-	std::vector<void *> streams, dpk;
+	std::vector<void *> streams;
+	std::vector<const void *> hpk;
+	std::vector<size_t> hsz;
 	// 1. advance a decoder until its next frame is complete (or its stream ends)
 	auto advance = [&](Stream &s) {
 		while (!s.done && !s.pkt) {
@@ -185,6 +192,7 @@ int main(int argc, char **argv)
 			if (F.take_packet(s.dec, &s.pkt, &s.pkt_bytes) != 0) s.pkt = nullptr;
 			if (res == ENODATA || s.nal >= s.end) { s.done = true; break; }
 			s.nal = nxt + 3 < s.end ? nxt + 3 : s.end;
+			if (s.nal >= s.end && s.loops_left > 0) { s.loops_left--; s.nal = s.first_nal; } // play it again (starts with SPS/PPS/IDR)
 		}
 	};
 	// worker threads: thread k owns decoders k, k+T, k+2T, ...; phases are separated by a counting barrier
@@ -213,27 +221,26 @@ int main(int argc, char **argv)
 		for (size_t i = 0; i < S.size(); i += (size_t)n_threads) { drain(S[i]); advance(S[i]); }
 		{ std::unique_lock<std::mutex> lk(mu); barrier(lk); }
 		for (Stream &s : S) any |= s.pkt != nullptr;
-		// 2. one batch for the whole round
-		streams.clear(); dpk.clear();
+		// 2. one batch for the whole round: staged + copied + launched asynchronously; the next round's parsing overlaps
+		//    with it, and edge264_get_frame (download) or the final sync is where the host meets the device again
+		streams.clear(); hpk.clear(); hsz.clear();
 		for (Stream &s : S)
 			if (s.pkt) {
-				void *d = nullptr;
 				if (dump) fwrite(s.pkt, 1, s.pkt_bytes, dump);
-				if (parse_only) { F.free_packet(s.pkt); s.pkt = nullptr; packets++; continue; }
-				if (H.packet_upload(dev, s.pkt, s.pkt_bytes, &d)) { fprintf(stderr, "packet_upload: %s\n", H.last_error()); return 1; }
-				F.free_packet(s.pkt); s.pkt = nullptr;
-				streams.push_back(F.stream(s.dec)); dpk.push_back(d);
+				packets++;
+				if (!parse_only) { streams.push_back(F.stream(s.dec)); hpk.push_back(s.pkt); hsz.push_back(s.pkt_bytes); }
 			}
 		if (!streams.empty()) {
-			if (H.submit_batch(dev, streams.data(), dpk.data(), (int)streams.size(), 3)) { fprintf(stderr, "submit_batch: %s\n", H.last_error()); return 1; }
-			H.device_sync(dev);
-			for (void *d : dpk) H.packet_free(d);
-			rounds++; packets += (long)streams.size();
+			if (H.submit_batch_host(dev, streams.data(), hpk.data(), hsz.data(), (int)streams.size(), 3)) { fprintf(stderr, "submit_batch_host: %s\n", H.last_error()); return 1; }
+			rounds++;
 		}
+		for (Stream &s : S)
+			if (s.pkt) { F.free_packet(s.pkt); s.pkt = nullptr; }
 		if (parse_only && any) rounds++;
 		// 3. output happens at the start of the next parse phase (each thread drains its own decoders)
 		if (!any) break;
 	}
+	if (!parse_only) H.device_sync(dev);
 	{ std::unique_lock<std::mutex> lk(mu); quit = true; barrier(lk); }
 	for (std::thread &t : pool) t.join();
 	double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -63,9 +63,11 @@ static struct {
 
 static int g_sink_kind = 0;
 static int g_device_ordinal = 0;
+static int g_download = 1; /* 0: edge264_get_frame leaves the samples in HBM (decode-to-device use, throughput runs) */
 
 PUBLIC void e264front_set_sink(int kind) { g_sink_kind = kind; }
 PUBLIC void e264front_set_device(int ordinal) { g_device_ordinal = ordinal; }
+PUBLIC void e264front_set_download(int on) { g_download = on; }
 
 static int hip_bind(void)
 {
@@ -302,7 +304,7 @@ PUBLIC int edge264_get_frame(Edge264Decoder *dec, Edge264Frame *out, int borrow)
 	if (!e)
 		return EINVAL;
 	int ret = e264ref_get_frame(dec, out, borrow);
-	if (ret == 0 && ON_DEVICE(e)) {
+	if (ret == 0 && ON_DEVICE(e) && g_download) {
 		uintptr_t mask = (uintptr_t)out->return_arg;
 		for (int s = 0; s < E264_MAX_SLOTS; s++)
 			if (mask >> s & 1)

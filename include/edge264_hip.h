@@ -81,6 +81,11 @@ void e264hip_packet_free(E264Packet *p);
 #define E264_RUN_DEBLOCK 2
 #define E264_RUN_ALL     3
 int  e264hip_submit_batch(E264Device *dev, E264Stream *const *streams, E264Packet *const *packets, int n, int mode);
+/* Same for packets that still live in HOST memory (the finished frames of many decoders, src/edge264_headers.c:532-568,
+ * one per stream): staged through each stream's pinned ring, copied and launched on the device queue without any
+ * synchronisation; the host buffers may be reused on return.  This is what a multi-stream front end calls once per
+ * round (edge264_amd/driver/e264_multi.cpp). */
+int  e264hip_submit_batch_host(E264Device *dev, E264Stream *const *streams, const void *const *packets, const size_t *bytes, int n, int mode);
 /* Same, with the job table built once and kept in HBM: the launch itself moves no bytes
  * over PCIe (a persistent multi-stream front end re-submits frame i of every stream). */
 typedef struct E264Batch E264Batch;

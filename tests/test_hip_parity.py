@@ -98,6 +98,35 @@ def test_odd_geometry(device, oracle):
         run_stream(device, oracle, 7, "IPB", dict(t8x8=True, i_kinds=ALL_I, mv_range=100), w, h)
 
 
+def test_submit_batch_host(device, oracle):
+    """e264hip_submit_batch_host: host packets of several streams, staged + copied + launched asynchronously,
+    several rounds in flight before anything is read back."""
+    from edge264_amd import backend
+    w, h, n_streams = 9, 5, 5
+    gens = [synth.StreamSynth(w, h, 50 + k, t8x8=bool(k & 1), i_kinds=ALL_I) for k in range(n_streams)]
+    nb = P.frame_bytes(w, h)
+    dpbs = [[np.full(nb + 16, 128, np.uint8) for _ in range(6)] + [None] * 26 for _ in range(n_streams)]
+    sts = [backend.Stream(device, w, h) for _ in range(n_streams)]
+    try:
+        for st in sts:
+            for i in range(6):
+                st.alloc(i)
+                st.fill(i, 128)
+        last = [0] * n_streams
+        for t in "IPBPB":   # five rounds, no synchronisation in between
+            pkts = [g.next_frame(t) for g in gens]
+            for k, pkt in enumerate(pkts):
+                oracle.decode_frame(pkt, dpbs[k], 3)
+                last[k] = int(P.Packet(pkt).hdr["dst_slot"])
+            device.submit_batch_host(sts, pkts)
+        for k, st in enumerate(sts):
+            for slot in range(6):
+                assert np.array_equal(st.download(slot), dpbs[k][slot][:nb]), f"stream {k} slot {slot}"
+    finally:
+        for st in sts:
+            st.close()
+
+
 def test_padded_strides(device, oracle):
     """Frames whose strides carry the reference's anti-aliasing padding (src/edge264_headers.c:2032-2041):
     2048 luma samples wide -> stride_Y + 16; 4096 wide -> stride_C + 8, i.e. Cr rows only 4-byte aligned

@@ -51,6 +51,11 @@ def test_multi_stream_driver(tmp_path, names, repeat):
             got = frame_md5s(tmp_path / f"s{k}.yuv", sums[n]["width_mbs"], sums[n]["height_mbs"])
             assert got == sums[n]["md5"], f"stream {k} ({n})"
             k += 1
+    # decode-to-device mode: nothing is copied back, same frame count
+    out2 = subprocess.run([EXE, "--front", FRONT, "--hip", HIP, "--repeat", str(repeat), "--threads", "2", "--no-download"] + files,
+                          capture_output=True, text=True, timeout=600)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    assert json.loads(out2.stdout.strip().splitlines()[-1])["frames"] == stats["frames"]
     # the packet dump is the capture format: self-describing records
     from edge264_amd import packet as P
     data = dump.read_bytes()
