@@ -132,15 +132,19 @@ struct __attribute__((aligned(16))) WaveLds { // reconstruction scratch of one w
 // 64-byte segment partially written several times: 3.6x the algorithmic write traffic at the L2
 // memory side (TCC_EA0_WRREQ, profiles/r01_pmc_calibration.txt).
 #ifndef E264_MBPAR_STRIP
-#define E264_MBPAR_STRIP 16 // macroblocks per wave (multiple of 8; measured 8: 4.47 ms, 16: 4.27, 24: 4.28, 32: 4.35 per 256-frame launch)
+#define E264_MBPAR_STRIP 24 // macroblocks per wave (multiple of 8; measured with the final pipeline 16: 3.64 ms, 24: 3.60, 32: 3.64 per 256-frame launch)
 #endif
 struct __attribute__((aligned(16))) StripOut {
 	uint32_t y[E264_MBPAR_STRIP][64];  // [mb][row * 4 + dword]
 	uint32_t c[E264_MBPAR_STRIP][32];  // [mb][plane * 16 + row * 2 + dword]
 };
 
-#define DBK_RING 8 // macroblocks of bottom rows each row keeps in LDS for the row below
-#define DBK_LAG 3  // the second row of a wave trails the first by this many macroblocks
+#ifndef DBK_RING
+#define DBK_RING 8 // macroblocks of bottom rows each row keeps in LDS for the row below (power of two)
+#endif
+#ifndef DBK_LAG
+#define DBK_LAG 2  // the second row of a wave trails the first by this many macroblocks (>= 2; measured 2: 2.03 ms, 3: 2.09, 4: 2.06)
+#endif
 struct __attribute__((aligned(16))) DbkTile {
 	uint8_t dytile[20 * DY_STRIDE];
 	uint8_t dctile[2][12 * DC_STRIDE];
