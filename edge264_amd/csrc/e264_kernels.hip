@@ -1322,18 +1322,28 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, int mbx,
 			intra16x16_pred(L, m.i16_mode, X, Yr, pY);
 		} else if (m.kind == E264_MB_I4x4) { // edge264_slice.c:615-635: predict, add residual, next block
 			tile_luma = true;
-			for (int b = 0; b < 16; b++) {
-				int mode = (int)(((b < 8 ? modes_lo : modes_hi) >> (4 * (b & 7))) & 15);
-				int X0 = BXf(b), Y0 = BYf(b);
+			// The 16 blocks are decoded in 10 steps instead of 16: block (x,y) of the 4x4 grid only needs its left, top,
+			// top-left and (when the standard counts it as available, i.e. when it precedes in zig-zag order) top-right
+			// neighbours, all of which belong to earlier anti-diagonals x + 2y.  Lanes 0..15 take the first block of a
+			// diagonal, lanes 16..31 the second one; the modes are already resolved against availability by the parser.
+			// zig-zag indices per step: (0,-)(1,-)(4,2)(5,3)(6,8)(7,9)(12,10)(13,11)(14,-)(15,-)
+			const uint64_t firsts = 0xfedc765410ull, seconds = 0xffba9832ffull; // one nibble per step
+			const int half = lane >> 4, hl16 = lane & 15;
+			for (int t = 0; t < 10; t++) {
+				const int b = (int)((half ? seconds : firsts) >> (4 * t) & 15);
+				const bool on = lane < 32 && !(half == 1 && (t < 2 || t > 7));
+				const int bb = on ? b : 0;
+				int mode = (int)(((bb < 8 ? modes_lo : modes_hi) >> (4 * (bb & 7))) & 15);
+				int X0 = BXf(bb), Y0 = BYf(bb);
 				int v = 0;
-				if (lane < 16) {
-					int x = lane & 3, y = lane >> 2;
+				if (on) {
+					int x = hl16 & 3, y = hl16 >> 2;
 					v = intra4x4_px(L, X0, Y0, mode, x, y);
 					v = clip255(w16(v + L.res[(Y0 + y) * 16 + X0 + x]));
 				}
 				wave_sync();
-				if (lane < 16)
-					L.YT(Y0 + (lane >> 2), X0 + (lane & 3)) = (uint8_t)v;
+				if (on)
+					L.YT(Y0 + (hl16 >> 2), X0 + (hl16 & 3)) = (uint8_t)v;
 				wave_sync();
 			}
 		} else { // I8x8, edge264_slice.c:645-668
