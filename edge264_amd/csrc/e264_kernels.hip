@@ -230,6 +230,22 @@ __device__ __forceinline__ MbInfo mb_from_lanes(uint32_t hv, int i)
 	return m;
 }
 
+// The same header out of an LDS copy of the record (8 dwords), all lanes reading the same words (intra kernel: the
+// headers of 64 macroblocks of the row are fetched with two vector loads per lane instead of one scalar-memory round
+// trip per macroblock in the middle of the dependency chain)
+__device__ __forceinline__ MbInfo mb_from_lds(const uint32_t *rec)
+{
+	MbInfo m;
+	const uint32_t d0 = __builtin_amdgcn_readfirstlane(rec[0]), d1 = __builtin_amdgcn_readfirstlane(rec[1]);
+	const uint32_t d2 = __builtin_amdgcn_readfirstlane(rec[2]);
+	m.kind = d0 & 255; m.flags = d0 >> 8 & 255; m.qp[0] = d0 >> 16 & 255; m.qp[1] = d0 >> 24;
+	m.qp[2] = d1 & 255; m.chroma_mode = d1 >> 8 & 255; m.i16_mode = d1 >> 16 & 255;
+	m.slice = d2 >> 16;
+	m.coded = __builtin_amdgcn_readfirstlane(rec[3]); m.payload_off = __builtin_amdgcn_readfirstlane(rec[4]);
+	m.modes_lo = __builtin_amdgcn_readfirstlane(rec[5]); m.modes_hi = __builtin_amdgcn_readfirstlane(rec[6]);
+	return m;
+}
+
 // ---------------------------------------------------------------------------------
 // residual: fills lds.res for the whole macroblock
 // ---------------------------------------------------------------------------------
@@ -1289,9 +1305,8 @@ __device__ __forceinline__ int intra_chroma_px(const WaveLds &L, int p, int mode
 // ---------------------------------------------------------------------------------
 // WHICH: 1 = inter and PCM macroblocks only (no dependency inside the frame), 2 = intra only, 3 = all
 template <int WHICH>
-__device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, int mbx, int mby, int lane)
+__device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, int mbx, int mby, int lane)
 {
-	const MbInfo m = load_mb(f.mbs + mby * f.wm + mbx);
 	if (m.kind == E264_MB_ABSENT)
 		return;
 	const bool par = m.kind == E264_MB_INTER || m.kind == E264_MB_PCM;
@@ -1932,6 +1947,7 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs)
 {
 	__shared__ WaveLds lds[NW];
+	__shared__ __attribute__((aligned(16))) uint32_t hdrs[NW][64 * 8]; // E264Mb records of the 64 macroblocks being scanned, per wave
 	__shared__ int progress[E264_MAX_ROWS]; // macroblocks finished per row
 	const int lane = lane_id();
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1952,7 +1968,17 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 #pragma unroll 1
 		for (int x0 = 0; x0 < f.wm; x0 += 64) {
 			const int xl = x0 + lane;
-			const int kind = xl < f.wm ? mbs_g[(size_t)(y * f.wm + xl) * sizeof(E264Mb)] : E264_MB_ABSENT;
+			// whole records of the chunk -> LDS (2 x 16 bytes per lane); `kind` for the ballot comes out of the first dword
+			v4u h0v = {0, 0, 0, 0}, h1v = {0, 0, 0, 0};
+			if (xl < f.wm) {
+				const gv4u *rp = (const gv4u *)(mbs_g + (size_t)(y * f.wm + xl) * sizeof(E264Mb));
+				h0v = rp[0]; h1v = rp[1];
+			}
+			wave_sync(); // the previous chunk's records are no longer read
+			*(v4u *)&hdrs[wave][lane * 8] = h0v;
+			*(v4u *)&hdrs[wave][lane * 8 + 4] = h1v;
+			wave_sync();
+			const int kind = xl < f.wm ? (int)(h0v.x & 255) : E264_MB_ABSENT;
 			unsigned long long todo = __ballot(kind == E264_MB_I4x4 || kind == E264_MB_I8x8 || kind == E264_MB_I16x16);
 			const int xe = min(x0 + 64, f.wm);
 			if (todo == 0 || (int)__builtin_ctzll(todo) > 0) { // macroblocks before the first intra one need nothing from this kernel
@@ -1970,7 +1996,7 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 						__builtin_amdgcn_s_sleep(1);
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 				}
-				recon_mb<2>(L, f, x, y, lane);
+				recon_mb<2>(L, f, mb_from_lds(&hdrs[wave][(x - x0) * 8]), x, y, lane);
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 				// finished: everything up to the next intra macroblock of the chunk (or the chunk's end)
 				const int upto = todo ? x0 + (int)__builtin_ctzll(todo) : xe;
