@@ -1056,36 +1056,43 @@ __device__ __forceinline__ void strip_flush(const StripOut &O, const FrameCtx &f
 
 // neighbours of the macroblock from the frame (un-deblocked, pass R) into the tiles.
 // Out-of-frame positions are never dereferenced; the remapped modes never use them.
-__device__ __forceinline__ void load_intra_neighbours(WaveLds &L, const FrameCtx &f, int mbx, int mby, int lane)
+// In two steps, so that the frame reads are in flight while the residual is computed: issue (loads only, nothing may
+// use the values) and commit (values -> tiles).
+struct IntraNb { uint8_t y, c; };
+__device__ __forceinline__ IntraNb issue_intra_neighbours(const FrameCtx &f, int mbx, int mby, int lane)
 {
+	IntraNb n = {0, 0};
 	const gu8 *Y = f.cur + (size_t)(mby * 16) * f.sY + mbx * 16;
 	// luma top row x = -1..23 (lanes 0..24), left column (lanes 32..47)
 	if (lane < 25) {
 		int x = lane - 1;
 		int gx = mbx * 16 + x;
-		uint8_t v = 0;
 		if (mby > 0 && gx >= 0 && gx < f.W)
-			v = Y[x - f.sY];
-		L.YT(-1, x) = v;
+			n.y = Y[x - f.sY];
 	} else if (lane >= 32 && lane < 48) {
 		int y = lane - 32;
-		L.YT(y, -1) = mbx > 0 ? Y[(size_t)y * f.sY - 1] : 0;
+		if (mbx > 0) n.y = Y[(size_t)y * f.sY - 1];
 	}
-	wave_sync();
-	// second round for chroma (keeps the lane mapping simple)
+	// chroma: top rows of both planes (lanes 0..17), left columns (lanes 32..47)
 	if (lane < 18) {
 		int pl = lane / 9, x = lane % 9 - 1;
 		const gu8 *C = plane_base(f, f.cur, 1 + pl) + (size_t)(mby * 8) * f.sC + mbx * 8;
 		int gx = mbx * 8 + x;
-		uint8_t v = 0;
 		if (mby > 0 && gx >= 0)
-			v = C[x - f.sC];
-		L.CT(pl, -1, x) = v;
+			n.c = C[x - f.sC];
 	} else if (lane >= 32 && lane < 48) {
 		int pl = (lane - 32) >> 3, y = lane & 7;
 		const gu8 *C = plane_base(f, f.cur, 1 + pl) + (size_t)(mby * 8) * f.sC + mbx * 8;
-		L.CT(pl, y, -1) = mbx > 0 ? C[(size_t)y * f.sC - 1] : 0;
+		if (mbx > 0) n.c = C[(size_t)y * f.sC - 1];
 	}
+	return n;
+}
+__device__ __forceinline__ void commit_intra_neighbours(WaveLds &L, const IntraNb &n, int lane)
+{
+	if (lane < 25) L.YT(-1, lane - 1) = n.y;
+	else if (lane >= 32 && lane < 48) L.YT(lane - 32, -1) = n.y;
+	if (lane < 18) L.CT(lane / 9, -1, lane % 9 - 1) = n.c;
+	else if (lane >= 32 && lane < 48) L.CT((lane - 32) >> 3, lane & 7, -1) = n.c;
 	wave_sync();
 }
 
@@ -1327,12 +1334,15 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const Mb
 		return;
 	}
 	const uint32_t modes_lo = m.modes_lo, modes_hi = m.modes_hi;
+	IntraNb nbv = {0, 0};
+	if (WHICH != 1 && m.kind != E264_MB_INTER)
+		nbv = issue_intra_neighbours(f, mbx, mby, lane); // in flight during the residual
 	if (!(f.dbg & 1024)) compute_residual(L, f, m, s, pl, lane);
 
 	int pY[4], pC[2];
 	bool tile_luma = false;
 	if (WHICH != 1 && m.kind != E264_MB_INTER) {
-		load_intra_neighbours(L, f, mbx, mby, lane);
+		commit_intra_neighbours(L, nbv, lane);
 		if (m.kind == E264_MB_I16x16) {
 			intra16x16_pred(L, m.i16_mode, X, Yr, pY);
 		} else if (m.kind == E264_MB_I4x4) { // edge264_slice.c:615-635: predict, add residual, next block
