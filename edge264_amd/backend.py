@@ -54,6 +54,7 @@ def load_library():
         "e264hip_packet_upload": (i, [vp, vp, sz, C.POINTER(vp)]),
         "e264hip_packet_free": (None, [vp]),
         "e264hip_submit_batch": (i, [vp, C.POINTER(vp), C.POINTER(vp), i, i]),
+        "e264hip_packet_check": (i, [vp, sz]),
         "e264hip_submit_batch_host": (i, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), i, i]),
         "e264hip_batch_create": (i, [vp, C.POINTER(vp), C.POINTER(vp), i, C.POINTER(vp)]),
         "e264hip_batch_submit": (i, [vp, i]),
@@ -76,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "e264hip_stream_open", "e264hip_stream_close", "e264hip_stream_flush", "e264hip_frame_alloc",
     "e264hip_frame_free", "e264hip_frame_fill", "e264hip_frame_upload", "e264hip_frame_submit",
     "e264hip_packet_buffer", "e264hip_frame_wait", "e264hip_frame_download", "e264hip_packet_upload",
-    "e264hip_packet_free", "e264hip_submit_batch", "e264hip_submit_batch_host", "e264hip_batch_create", "e264hip_batch_submit", "e264hip_batch_free", "e264hip_event_record", "e264hip_event_elapsed_ms",
+    "e264hip_packet_free", "e264hip_packet_check", "e264hip_submit_batch", "e264hip_submit_batch_host", "e264hip_batch_create", "e264hip_batch_submit", "e264hip_batch_free", "e264hip_event_record", "e264hip_event_elapsed_ms",
     "e264hip_kernel_timing", "e264hip_kernel_time_ms", "e264hip_set_option",
 ]
 
@@ -85,6 +86,18 @@ def _check(L, r: int, what: str) -> None:
     if r:
         msg = L.e264hip_last_error()
         raise BackendError(f"{what}: {errno.errorcode.get(r, r)} ({(msg or b'').decode()})")
+
+
+def packet_check(pkt: bytes) -> int:
+    """Host-only validation (no GPU needed): 0 or an errno value."""
+    L = load_library()
+    buf = (C.c_char * len(pkt)).from_buffer_copy(pkt)
+    return L.e264hip_packet_check(C.cast(buf, C.c_void_p), len(pkt))
+
+
+def last_error() -> str:
+    msg = load_library().e264hip_last_error()
+    return msg.decode() if msg else ""
 
 
 class Device:

@@ -251,6 +251,51 @@ static int check_packet(const void *packet, size_t bytes, int *dst, int *n_mbs)
 	return 0;
 }
 
+// Everything a kernel will dereference through the packet, checked on the host before the packet may reach the
+// device (a wild offset would be a GPU memory fault = process abort, not an error code): section layout, per-macroblock
+// kind / slice index / payload bounds, reference slots.  `slots` (may be null): allocated-slot table of the stream.
+static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *slots)
+{
+	int dst, n_mbs, r = check_packet(packet, bytes, &dst, &n_mbs);
+	if (r) return r;
+	const E264FrameHdr *h = (const E264FrameHdr *)packet;
+	const uint8_t *p = (const uint8_t *)packet;
+	if (h->width_mbs == 0 || h->height_mbs == 0 || h->height_mbs > 1056) return fail(EINVAL, "frame size");
+	if (h->n_slices == 0 || (size_t)h->slices_off + (size_t)h->n_slices * sizeof(E264SliceParams) > h->mbs_off) return fail(EINVAL, "slice section");
+	if ((h->slices_off | h->mbs_off | h->motion_off | h->payload_off) & 7) return fail(EINVAL, "section alignment");
+	if (h->stride_Y < (uint32_t)h->width_mbs * 16 || h->stride_C < (uint32_t)h->width_mbs * 16 || (h->stride_Y & 15) || (h->stride_C & 7))
+		return fail(EINVAL, "strides");
+	if ((uint64_t)h->plane_size_Y < (uint64_t)h->stride_Y * h->height_mbs * 16 || (uint64_t)h->plane_size_C < (uint64_t)h->stride_C * h->height_mbs * 8)
+		return fail(EINVAL, "plane sizes");
+	const E264Mb *mbs = (const E264Mb *)(p + h->mbs_off);
+	const E264Motion *mo = h->motion_off ? (const E264Motion *)(p + h->motion_off) : nullptr;
+	for (int a = 0; a < n_mbs; a++) {
+		const E264Mb &m = mbs[a];
+		if (m.kind > E264_MB_INTER) return fail(EINVAL, "macroblock kind");
+		if (m.kind == E264_MB_ABSENT) continue;
+		if (m.slice >= h->n_slices) return fail(EINVAL, "macroblock slice index");
+		if ((m.payload_off & 7) || (uint64_t)m.payload_off + e264_mb_payload_bytes(&m) > h->payload_bytes) return fail(EINVAL, "macroblock payload");
+		if ((m.flags & E264_MBF_EDGE_LEFT) && a % h->width_mbs == 0) return fail(EINVAL, "left edge flag on the first column");
+		if ((m.flags & E264_MBF_EDGE_TOP) && a < h->width_mbs) return fail(EINVAL, "top edge flag on the first row");
+		if (m.kind == E264_MB_INTER) {
+			if (!mo) return fail(EINVAL, "inter macroblock without motion section");
+			for (int i = 0; i < 8; i++) {
+				int rp = mo[a].refPic[i];
+				if (rp < -1 || rp >= E264_MAX_SLOTS) return fail(EINVAL, "reference slot");
+				if (rp >= 0 && slots && !slots[rp]) return fail(EINVAL, "reference slot not allocated");
+				if (mo[a].refIdx[i] < -1 || mo[a].refIdx[i] > 31) return fail(EINVAL, "reference index");
+			}
+		}
+	}
+	return 0;
+}
+
+// host-only entry point of the same checks (tests, front ends that want to vet a capture file)
+API int e264hip_packet_check(const void *packet, size_t bytes)
+{
+	return check_packet_deep(packet, bytes, nullptr);
+}
+
 static int ensure_dbk(E264Stream *s, int n_mbs)
 {
 	if (s->dbk_mbs >= (size_t)n_mbs) return 0;
@@ -302,6 +347,7 @@ API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
 	int dst, n_mbs, r = check_packet(packet, bytes, &dst, &n_mbs);
 	if (r) return r;
 	if (!s->h_table[dst]) return fail(EINVAL, "destination slot not allocated");
+	if ((r = check_packet_deep(packet, bytes, s->h_table))) return r;
 	if (set_device(s->dev)) return EIO;
 	if ((r = ensure_dbk(s, n_mbs))) return r;
 	E264Stream::Stage *st = &s->stage[s->stage_next];
@@ -348,6 +394,7 @@ API int e264hip_packet_upload(E264Device *dev, const void *packet, size_t bytes,
 	if (!dev || !out) return fail(EINVAL, "null argument");
 	int dst, n_mbs, r = check_packet(packet, bytes, &dst, &n_mbs);
 	if (r) return r;
+	if ((r = check_packet_deep(packet, bytes, nullptr))) return r;
 	if (set_device(dev)) return EIO;
 	E264Packet *p = new (std::nothrow) E264Packet();
 	if (!p) return fail(ENOMEM, "packet object");
@@ -455,6 +502,7 @@ API int e264hip_submit_batch_host(E264Device *dev, E264Stream *const *streams, c
 		int dst, n_mbs, r = check_packet(packets[i], bytes[i], &dst, &n_mbs);
 		if (r) return r;
 		if (!s->h_table[dst]) return fail(EINVAL, "destination slot not allocated");
+		if ((r = check_packet_deep(packets[i], bytes[i], s->h_table))) return r;
 		if ((r = ensure_dbk(s, n_mbs))) return r;
 		void *h = e264hip_packet_buffer(s, bytes[i]);
 		if (!h) return ENOMEM;

@@ -81,6 +81,9 @@ void e264hip_packet_free(E264Packet *p);
 #define E264_RUN_DEBLOCK 2
 #define E264_RUN_ALL     3
 int  e264hip_submit_batch(E264Device *dev, E264Stream *const *streams, E264Packet *const *packets, int n, int mode);
+/* Host-only validation of a command packet (layout, per-macroblock offsets and indices): what every host-packet entry
+ * point below runs before the packet may reach the device.  0 or EINVAL (e264hip_last_error() names the field). */
+int  e264hip_packet_check(const void *packet, size_t bytes);
 /* Same for packets that still live in HOST memory (the finished frames of many decoders, src/edge264_headers.c:532-568,
  * one per stream): staged through each stream's pinned ring, copied and launched on the device queue without any
  * synchronisation; the host buffers may be reused on return.  This is what a multi-stream front end calls once per
