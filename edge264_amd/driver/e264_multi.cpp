@@ -83,9 +83,13 @@ struct Stream {
 
 static void write_frame(FILE *f, const Edge264Frame &fr)
 {
-	for (int y = 0; y < fr.height_Y; y++) fwrite(fr.samples[0] + (size_t)y * fr.stride_Y, 1, fr.width_Y, f);
-	for (int p = 1; p < 3; p++)
-		for (int y = 0; y < fr.height_C; y++) fwrite(fr.samples[p] + (size_t)y * fr.stride_C, 1, fr.width_C, f);
+	for (int v = 0; v < 2; v++) { // MVC: the second view follows the base view (edge264.h:46-47)
+		const uint8_t *const *pl = v ? fr.samples_mvc : fr.samples;
+		if (!pl[0]) continue;
+		for (int y = 0; y < fr.height_Y; y++) fwrite(pl[0] + (size_t)y * fr.stride_Y, 1, fr.width_Y, f);
+		for (int p = 1; p < 3; p++)
+			for (int y = 0; y < fr.height_C; y++) fwrite(pl[p] + (size_t)y * fr.stride_C, 1, fr.width_C, f);
+	}
 }
 
 static void on_crash(int sig)

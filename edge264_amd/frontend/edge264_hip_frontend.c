@@ -384,3 +384,12 @@ PUBLIC void *e264front_stream(Edge264Decoder *dec)
 	return e && ON_DEVICE(e) ? e->hip_stream : NULL;
 }
 PUBLIC void *e264front_device(void) { return hip_bind() ? NULL : hip.dev; }
+
+/* DPB slot a sample pointer of Edge264Frame belongs to (samples[] = base view, samples_mvc[] = second view):
+ * return_arg only carries the union of both slots (edge264.c:389,398). */
+PUBLIC int e264front_slot_of(Edge264Decoder *dec, const void *samples)
+{
+	E264Emitter *e = emitter_of(dec);
+	size_t off;
+	return e && samples ? e264_locate(e, (const uint8_t *)samples, &off) : -1;
+}

@@ -159,9 +159,10 @@ class Edge264Lib:
         def plane(ptr, w, h, stride):
             a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), ((h - 1) * stride + w,))
             return np.lib.stride_tricks.as_strided(a, (h, w), (stride, 1)).copy()
-        return (plane(f.samples[0], f.width_Y, f.height_Y, f.stride_Y),
-                plane(f.samples[1], f.width_C, f.height_C, f.stride_C),
-                plane(f.samples[2], f.width_C, f.height_C, f.stride_C))
+        views = [f.samples] + ([f.samples_mvc] if f.samples_mvc[0] else [])   # MVC: second view appended (edge264.h:46-47)
+        return tuple(pl for v in views for pl in (plane(v[0], f.width_Y, f.height_Y, f.stride_Y),
+                                                  plane(v[1], f.width_C, f.height_C, f.stride_C),
+                                                  plane(v[2], f.width_C, f.height_C, f.stride_C)))
 
 
 def ref_decoder() -> Edge264Lib:
@@ -209,6 +210,8 @@ class HipFront(Edge264Lib):
         L.e264front_take_packet.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.e264front_take_packet.restype = C.c_int
         L.e264front_free_packet.argtypes = [C.c_void_p]
+        L.e264front_slot_of.argtypes = [C.c_void_p, C.c_void_p]
+        L.e264front_slot_of.restype = C.c_int
 
     def decode_capture(self, stream: bytes, oracle: "Oracle"):
         """Returns (frames, codes, packets): frames as the HIP sink would return them, with the
@@ -243,12 +246,15 @@ class HipFront(Edge264Lib):
                         dpb[s] = np.zeros(nb + 64, np.uint8)  # like the HIP sink (frame_fill 0) and a fresh mmap in the reference
                 oracle.decode_frame(pkt, dpb, 3)
             while L.edge264_get_frame(dec, C.byref(out), 0) == 0:
-                mask = out.return_arg or 0
-                slot = [s for s in range(32) if mask >> s & 1][0]
-                d, sy, sc = dpb[slot], geom["stride_Y"], geom["stride_C"]
-                y = d[:out.height_Y * sy].reshape(out.height_Y, sy)[:, :out.width_Y].copy()
-                c = d[geom["psY"]:geom["psY"] + out.height_C * sc].reshape(out.height_C, sc)
-                frames.append((y, c[:, :out.width_C].copy(), c[:, sc // 2:sc // 2 + out.width_C].copy()))
+                planes = []
+                for view in ([out.samples] + ([out.samples_mvc] if out.samples_mvc[0] else [])):   # MVC: second view
+                    slot = L.e264front_slot_of(dec, view[0])
+                    assert slot >= 0 and (out.return_arg or 0) >> slot & 1
+                    d, sy, sc = dpb[slot], geom["stride_Y"], geom["stride_C"]
+                    y = d[:out.height_Y * sy].reshape(out.height_Y, sy)[:, :out.width_Y].copy()
+                    c = d[geom["psY"]:geom["psY"] + out.height_C * sc].reshape(out.height_C, sc)
+                    planes += [y, c[:, :out.width_C].copy(), c[:, sc // 2:sc // 2 + out.width_C].copy()]
+                frames.append(tuple(planes))
 
         nal = L.edge264_find_start_code(base, end, 0)
         nal = (nal or end) + 3 if (nal or end) < end else end

@@ -96,7 +96,7 @@ class Synth:
 
     def __init__(self, g, name, W, H, frames, seed, *, t8x8=False, num_refs=2, weighted_pred=0, weighted_bipred=0,
                  slices=1, deblock=(0,), direct_spatial=1, scaling=False, pcm=0.03, qp=28, cqp=(0, 0), level=3.0,
-                 intra_in_inter=0.12, skip=0.15, coef_density=0.35, big_levels=0.03, cbp_zero=0.0, cabac=False, tables=None):
+                 intra_in_inter=0.12, skip=0.15, coef_density=0.35, big_levels=0.03, cbp_zero=0.0, cabac=False, tables=None, mvc=False):
         self.g, self.name, self.W, self.H = g, name, W, H
         self.frames, self.rng = frames, random.Random(seed)
         self.t8x8, self.num_refs, self.wp, self.wbp = t8x8, num_refs, weighted_pred, weighted_bipred
@@ -106,6 +106,7 @@ class Synth:
         self.cbp_zero = cbp_zero
         self.cabac, self.tables, self.cabac_fs = cabac, tables, None
         self.log2_fn, self.log2_poc = 4, 6
+        self.mvc = mvc   # two views (Annex H): base view + NAL 20 slices predicted from their own view and from the base picture
 
     # ---- parameter sets (payload bits by gen_avc.py) --------------------------------------------
     def sps(self):
@@ -120,6 +121,33 @@ class Synth:
                                        [r.randint(6, 40) for _ in range(16)], [], [],
                                        [r.randint(6, 40) for _ in range(64)], [r.randint(6, 40) for _ in range(64)]]
         return d
+
+    def subset_sps(self):
+        d = self.sps()
+        d.update(nal_unit_type=15, profile_idc=118, view_ids=[0, 1], num_anchor_refs={"l0": 1, "l1": 0},
+                 num_non_anchor_refs={"l0": 1, "l1": 0},
+                 level_values_signalled=[dict(idc=self.level, operation_points=[dict(temporal_id=0, target_views=[1], num_views=2)])])
+        return d
+
+    @staticmethod
+    def mvc_ext(bits, idr, view_id, inter_view):
+        # nal_unit_header_mvc_extension (H.7.3.1.1) after svc_extension_flag = 0
+        bits = u(bits, 1, 0)
+        bits = u(bits, 1, 0 if idr else 1)   # non_idr_flag
+        bits = u(bits, 6, 0)                 # priority_id
+        bits = u(bits, 10, view_id)
+        bits = u(bits, 3, 0)                 # temporal_id
+        bits = u(bits, 1, int(idr))          # anchor_pic_flag
+        bits = u(bits, 1, inter_view)
+        return u(bits, 1, 1)                 # reserved_one_bit
+
+    def prefix_nal(self, is_ref, idr):
+        bits = 1 << 1
+        bits = u(bits, 2, 1 if is_ref else 0)
+        bits = u(bits, 5, 14)
+        bits = self.mvc_ext(bits, idr, 0, 1)
+        # prefix_nal_unit_rbsp() is empty when svc_extension_flag = 0 (7.3.2.12): no trailing bits either
+        return b"\0\0\0\1" + emulation_prevention((bits ^ 1 << 32).to_bytes(4, "big"))
 
     def pps(self):
         d = dict(nal_ref_idc=3, nal_unit_type=8, pic_parameter_set_id=0, entropy_coding_mode_flag=int(self.cabac),
@@ -164,14 +192,21 @@ class Synth:
             c[i] = mag if r.random() < 0.5 else -mag
         return c
 
-    def residual(self, fc, mx, my, sl, cbp, i16):
+    def residual(self, fc, mx, my, sl, cbp, i16, t8=False):
         blocks, r = [], self.rng
         if i16:
             blocks.append({"nC": fc.nC(fc.tcY, 2, 4 * mx, 4 * my, sl), "c": self.coeffs(16)})
-        for b in range(16):
-            bx, by = 4 * mx + BLK_X[b], 4 * my + BLK_Y[b]
-            if cbp >> (b >> 2) & 1:
-                c = self.coeffs(15 if i16 else 16)
+        for b8 in range(4):
+            if not cbp >> b8 & 1:
+                continue
+            cs = [self.coeffs(15 if i16 else 16) for _ in range(4)]
+            if t8 and not any(v for c in cs for v in c):
+                # CABAC has no coded_block_flag for an 8x8 luma block (ctxBlockCat 5, non-4:4:4): a set cbp bit MUST carry a
+                # coefficient.  Done for both entropy codings so that the CAVLC twin describes the same picture.
+                cs[0][0] = 1
+            for b in range(4 * b8, 4 * b8 + 4):
+                bx, by = 4 * mx + BLK_X[b], 4 * my + BLK_Y[b]
+                c = cs[b & 3]
                 blocks.append({"nC": fc.nC(fc.tcY, 2, bx, by, sl), "c": c})
                 fc.tcY[by][bx] = sum(1 for v in c if v)
         if cbp >> 4:
@@ -268,7 +303,7 @@ class Synth:
         mb["coded_block_pattern"] = cbp
         if cbp:
             mb["mb_qp_delta"] = self.qp_delta()
-            mb["coeffLevels"] = self.residual(fc, mx, my, sl, cbp, False)
+            mb["coeffLevels"] = self.residual(fc, mx, my, sl, cbp, False, bool(t8))
         return mb
 
     # ---- inter macroblocks ------------------------------------------------------------------------
@@ -286,7 +321,7 @@ class Synth:
             mb["transform_size_8x8_flag"] = int(self.rng.random() < 0.5)
         if cbp:
             mb["mb_qp_delta"] = self.qp_delta()
-            mb["coeffLevels"] = self.residual(fc, mx, my, sl, cbp, False)
+            mb["coeffLevels"] = self.residual(fc, mx, my, sl, cbp, False, bool(mb.get("transform_size_8x8_flag")))
         return mb
 
     def p_mb(self, fc, mx, my, sl, nref):
@@ -375,10 +410,12 @@ class Synth:
             run = 0
             mbs.append(mb)
         # ---- slice header (7.3.3), written here ----
-        nal_type = 5 if hdr["idr"] else 1
+        nal_type = 20 if hdr.get("view") else 5 if hdr["idr"] else 1
         bits = 1 << 1
         bits = u(bits, 2, 1 if hdr["is_ref"] else 0)
         bits = u(bits, 5, nal_type)
+        if nal_type == 20:
+            bits = self.mvc_ext(bits, hdr["idr"], 1, 0)
         bits = ue(bits, first)
         bits = ue(bits, st + (5 if self.slices == 1 else 0))
         bits = ue(bits, 0)  # pic_parameter_set_id
@@ -442,7 +479,7 @@ class Synth:
 
     def build(self):
         r = self.rng
-        out = [self.nal(self.sps()), self.nal(self.pps())]
+        out = [self.nal(self.sps())] + ([self.nal(self.subset_sps())] if self.mvc else []) + [self.nal(self.pps())]
         n_mbs = self.W * self.H
         frame_num, nrefs, disp = 0, 0, 0
         # display order: B frames (non-reference) sit between the two reference frames decoded before them
@@ -481,7 +518,24 @@ class Synth:
                 hdr = dict(frame_num=frame_num % (1 << self.log2_fn), poc=p % (1 << self.log2_poc), is_ref=is_ref, idr=idr,
                            nref0=nref0, nref1=nref1, idr_pic_id=0, slice_qp_delta=r.randint(-4, 6),
                            deblock=r.choice(self.deblock), alpha=r.randint(-3, 3), beta=r.randint(-3, 3))
+                if self.mvc:
+                    out.append(self.prefix_nal(is_ref, idr))
                 out.append(self.slice_nal(fc, t, bounds[s], bounds[s + 1], s, hdr))
+            if self.mvc:
+                # second view of the access unit: same frame_num/POC; RefPicList0/1 = its own view's references followed by the
+                # base picture of this access unit (headers.c:784-785), so an I access unit becomes P with the inter-view ref only
+                fc = FrameCtx(self.W, self.H)
+                if self.cabac:
+                    self.cabac_fs = cw.FrameState(self.W, self.H)
+                t1 = "P" if t == "I" else t
+                own = min(nrefs, self.num_refs)
+                v0 = r.randint(1, own + 1)
+                v1 = r.randint(1, own + 1)
+                for s in range(len(bounds) - 1):
+                    hdr = dict(frame_num=frame_num % (1 << self.log2_fn), poc=p % (1 << self.log2_poc), is_ref=is_ref, idr=idr,
+                               nref0=v0, nref1=v1, idr_pic_id=0, slice_qp_delta=r.randint(-4, 6), view=1,
+                               deblock=r.choice(self.deblock), alpha=r.randint(-3, 3), beta=r.randint(-3, 3))
+                    out.append(self.slice_nal(fc, t1, bounds[s], bounds[s + 1], s, hdr))
             if is_ref:
                 frame_num += 1
                 nrefs += 1
@@ -517,6 +571,11 @@ STREAMS = [
     ("cabac_pcm", 5, 4, "IPBP", 41, dict(cabac=True, pcm=0.12, num_refs=2)),
     ("cabac_hd1080_ipp", 120, 68, "IPP", 37, dict(cabac=True, pcm=0.0, num_refs=2, level=4.0, skip=0.45, coef_density=0.12,
                                                    intra_in_inter=0.03, cbp_zero=0.8)),
+    # MVC (Annex H, two views): base view + NAL 20 slices with inter-view prediction; get_frame returns samples_mvc
+    ("mvc_ipp", 5, 4, "IPPP", 51, dict(mvc=True, num_refs=2, pcm=0.0)),
+    ("mvc_ipb", 5, 4, "IPBPB", 52, dict(mvc=True, num_refs=2)),
+    ("mvc_cabac_ipb", 5, 4, "IPBPBB", 51, dict(mvc=True, cabac=True, pcm=0.0, num_refs=3, t8x8=True, slices=2, weighted_bipred=2)),
+    ("cabac_t8x8_slices", 5, 4, "IPBP", 55, dict(cabac=True, pcm=0.0, num_refs=3, t8x8=True, slices=3)),
     ("hd1080_ippb", 120, 68, "IPPB", 13, dict(num_refs=2, level=4.0, skip=0.45, coef_density=0.12, intra_in_inter=0.03, pcm=0.0005, cbp_zero=0.8)),
 ]
 
@@ -545,8 +604,8 @@ def main():
         assert len(out) == len(frames) and all(c in (0, 105, 61) for c in codes), (name, len(out), codes)
         if twin is not None:  # the CABAC writer is right iff the reference decodes both entropy codings to the same frames
             tout, _ = ref.decode(twin)
-            assert len(tout) == len(out) and all((a[p] == b[p]).all() for a, b in zip(tout, out) for p in range(3)), name
-        sums[name] = {"width_mbs": W, "height_mbs": H, "frames": frames, "nal_codes": codes,
+            assert len(tout) == len(out) and all((a[p] == b[p]).all() for a, b in zip(tout, out) for p in range(len(a))), name
+        sums[name] = {"width_mbs": W, "height_mbs": H, "frames": frames, "nal_codes": codes, "views": len(out[0]) // 3,
                       "md5": [hashlib.md5(b"".join(p.tobytes() for p in fr)).hexdigest() for fr in out]}
         print(f"{name}.264: {len(data)} bytes, {W}x{H} MBs, {frames}, {len(out)} frames decoded by the reference")
     with open(os.path.join(OUT, "reference_md5.json"), "w") as f:

@@ -18,8 +18,8 @@ HIP = os.path.join(ROOT, "edge264_amd", "libedge264_hip.so")
 pytestmark = pytest.mark.gpu
 
 
-def frame_md5s(path, w_mbs, h_mbs):
-    n = w_mbs * 16 * h_mbs * 16 * 3 // 2
+def frame_md5s(path, w_mbs, h_mbs, views=1):
+    n = w_mbs * 16 * h_mbs * 16 * 3 // 2 * views
     data = open(path, "rb").read()
     assert len(data) % n == 0
     return [hashlib.md5(data[i:i + n]).hexdigest() for i in range(0, len(data), n)]
@@ -30,6 +30,7 @@ def frame_md5s(path, w_mbs, h_mbs):
     (["hd1080_ippb", "cabac_hd1080_ipp"], 4),
     (["cabac_i", "cabac_ipp", "cabac_t8x8_scaling", "cabac_slices_deblock_idc", "cabac_weighted", "cabac_big_levels",
       "cabac_ipb_spatial", "cabac_ipb_temporal_implicit", "cabac_weighted_b"], 2),
+    (["mvc_ipp", "mvc_cabac_ipb", "cabac_t8x8_slices", "mvc_ipb", "ipp_partitions"], 2),   # two views: two packets per access unit
 ])
 def test_multi_stream_driver(tmp_path, names, repeat):
     for p in (EXE, FRONT, HIP):
@@ -48,7 +49,7 @@ def test_multi_stream_driver(tmp_path, names, repeat):
     k = 0
     for _ in range(repeat):
         for n in names:
-            got = frame_md5s(tmp_path / f"s{k}.yuv", sums[n]["width_mbs"], sums[n]["height_mbs"])
+            got = frame_md5s(tmp_path / f"s{k}.yuv", sums[n]["width_mbs"], sums[n]["height_mbs"], sums[n]["views"])
             assert got == sums[n]["md5"], f"stream {k} ({n})"
             k += 1
     # decode-to-device mode: nothing is copied back, same frame count
