@@ -34,6 +34,11 @@ __device__ __forceinline__ int clip255(int v) { return min(max(v, 0), 255); }
 __device__ __forceinline__ int sat16(int v) { return min(max(v, -32768), 32767); }
 __device__ __forceinline__ int w16(int v) { return (int)(int16_t)v; }
 // build-time experiment switches (`make variant NAME=.. DEFS=-D..` builds one library per setting, tools/gpu_ab.sh compares them)
+#ifdef E264_ABL_NOBH
+#define E264_ABL_BH && false
+#else
+#define E264_ABL_BH
+#endif
 #ifndef E264_LUMA_PACKED
 #define E264_LUMA_PACKED 1 // luma interpolation in packed 16-bit arithmetic (two samples per VALU instruction)
 #endif
@@ -589,7 +594,11 @@ __device__ __forceinline__ void luma_from_rows(const uint32_t d[6][3], int xF, i
 	const bool uses_G = (xF == 0 || yF == 0) && (xo || yo || (xF | yF) == 0);
 	const bool uses_b = (yF == 0 && xF != 0) || (xo && yo) || (xF == 2 && yo);
 	const bool uses_h = (xF == 0 && yF != 0) || (xo && yo) || (yF == 2 && xo);
+#ifdef E264_ABL_NOJ
+	const bool jH = false, jV = false;
+#else
 	const bool jH = uses_j && xF == 2, jV = uses_j && xF != 2;
+#endif
 	const bool row3 = yF == 3, col3 = xF == 3;
 	const s16x2 z = {0, 0};
 	s16x2 G[2], b[2] = {z, z}, h[2] = {z, z}, j[2] = {z, z}; // [0] = outputs 0,1   [1] = outputs 2,3
@@ -611,7 +620,7 @@ __device__ __forceinline__ void luma_from_rows(const uint32_t d[6][3], int xF, i
 		j[1] = centre6p(H1[0], H1[1], H1[2], H1[3], H1[4], H1[5]);
 		b[0] = half5p(row3 ? H0[3] : H0[2]);
 		b[1] = half5p(row3 ? H1[3] : H1[2]);
-	} else if (uses_b) {
+	} else if (uses_b E264_ABL_BH) {
 		const uint32_t w[3] = {row3 ? d[3][0] : d[2][0], row3 ? d[3][1] : d[2][1], row3 ? d[3][2] : d[2][2]};
 		s16x2 Q[8];
 		pairs9(w, Q);
@@ -641,7 +650,7 @@ __device__ __forceinline__ void luma_from_rows(const uint32_t d[6][3], int xF, i
 		j[1] = centre6p(V[1], O[1], V[2], O[2], V[3], O[3]);
 		h[0] = half5p(col3 ? O[1] : V[1]);
 		h[1] = half5p(col3 ? O[2] : V[2]);
-	} else if (uses_h) {
+	} else if (uses_h E264_ABL_BH) {
 		s16x2 C0[6], C1[6];
 #pragma unroll
 		for (int r = 0; r < 6; r++) {
@@ -1663,7 +1672,9 @@ __device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, DbkStage 
 			v[12] = w2 & 255; v[13] = w2 >> 8 & 255; v[14] = w2 >> 16 & 255; v[15] = w2 >> 24;
 			v[6] = v[7] = v[8] = v[9] = v[16] = v[17] = v[18] = v[19] = 0;
 		}
+#ifndef E264_ABL_DBK_NOFILTER
 		filter_line(v, bV, a1, a0, b1, b0, tV, chroma);
+#endif
 		if (!chroma) {
 #pragma unroll
 			for (int d = 0; d < 5; d++)
@@ -1695,7 +1706,9 @@ __device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, DbkStage 
 #pragma unroll
 			for (int i = 0; i < 6; i++) { v[i] = L.DCT(cpl, i - 4, li); v[10 + i] = L.DCT(cpl, i + 2, li); }
 		}
+#ifndef E264_ABL_DBK_NOFILTER
 		filter_line(v, bH, a2, a0, b2, b0, tH, chroma);
+#endif
 		if (!chroma) {
 #pragma unroll
 			for (int i = 1; i < 19; i++) L.DYT(i - 4, li) = (uint8_t)v[i];
