@@ -41,7 +41,8 @@ struct E264Device {
 	int waves;                 // waves per frame workgroup of the deblocking kernel (2 macroblock rows each)
 	int intra_waves;           // waves per frame workgroup of the intra kernel (1 macroblock row each)
 	int dbg_mode;
-	std::mutex lock;
+	std::mutex lock;           // kernel launches + their timing marks
+	std::mutex batch_lock;     // e264hip_submit_batch_host: job ring
 	hipEvent_t ev[16];
 	// per-launch kernel timing
 	bool ktiming;
@@ -107,7 +108,12 @@ API void e264hip_device_close(E264Device *dev)
 	hipSetDevice(dev->ordinal);
 	hipStreamSynchronize(dev->q);
 	for (int i = 0; i < 16; i++) hipEventDestroy(dev->ev[i]);
-	for (auto &p : dev->kev) for (int i = 0; i < 4; i++) hipEventDestroy(p.e[i]);
+	for (auto &p : dev->kev) for (int i = 0; i < 5; i++) hipEventDestroy(p.e[i]);
+	for (auto &jr : dev->jring) {
+		if (jr.h) hipHostFree(jr.h);
+		if (jr.d) hipFree(jr.d);
+		if (jr.done) hipEventDestroy(jr.done);
+	}
 	hipStreamDestroy(dev->q);
 	delete dev;
 }
@@ -327,16 +333,16 @@ API void *e264hip_packet_buffer(E264Stream *s, size_t max_bytes)
 	if (!s || set_device(s->dev)) return nullptr;
 	E264Stream::Stage &st = s->stage[s->stage_next];
 	if (st.busy) { hipEventSynchronize(st.done); st.busy = false; }
+	if (!st.done && hipEventCreateWithFlags(&st.done, hipEventDisableTiming) != hipSuccess) { st.done = nullptr; fail(EIO, "hipEventCreate"); return nullptr; }
+	if (!st.d_job && hipMalloc((void **)&st.d_job, sizeof(E264Job)) != hipSuccess) { st.d_job = nullptr; fail(ENOMEM, "job slot"); return nullptr; }
 	if (st.cap < max_bytes) {
 		if (st.h) hipHostFree(st.h);
 		if (st.d) hipFree(st.d);
 		st.h = nullptr; st.d = nullptr; st.cap = 0;
 		size_t cap = (max_bytes + 65535) & ~(size_t)65535;
-		if (hipHostMalloc(&st.h, cap + 64, hipHostMallocDefault) != hipSuccess) { fail(ENOMEM, "pinned packet buffer"); return nullptr; }
-		if (hipMalloc((void **)&st.d, cap) != hipSuccess) { hipHostFree(st.h); st.h = nullptr; fail(ENOMEM, "device packet buffer"); return nullptr; }
+		if (hipHostMalloc(&st.h, cap + 64, hipHostMallocDefault) != hipSuccess) { st.h = nullptr; fail(ENOMEM, "pinned packet buffer"); return nullptr; }
+		if (hipMalloc((void **)&st.d, cap) != hipSuccess) { hipHostFree(st.h); st.h = nullptr; st.d = nullptr; fail(ENOMEM, "device packet buffer"); return nullptr; }
 		st.cap = cap;
-		if (!st.done) hipEventCreateWithFlags(&st.done, hipEventDisableTiming);
-		if (!st.d_job && hipMalloc((void **)&st.d_job, sizeof(E264Job)) != hipSuccess) { fail(ENOMEM, "job slot"); return nullptr; }
 	}
 	return st.h;
 }
@@ -351,6 +357,7 @@ API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
 	if (set_device(s->dev)) return EIO;
 	if ((r = ensure_dbk(s, n_mbs))) return r;
 	E264Stream::Stage *st = &s->stage[s->stage_next];
+	if (packet == st->h && bytes > st->cap) return fail(EINVAL, "packet larger than the buffer e264hip_packet_buffer returned");
 	if (packet != st->h) { // caller did not use our pinned buffer: stage it
 		void *h = e264hip_packet_buffer(s, bytes);
 		if (!h) return ENOMEM;
@@ -480,6 +487,18 @@ API int e264hip_submit_batch_host(E264Device *dev, E264Stream *const *streams, c
 {
 	if (!dev || !streams || !packets || !bytes || n <= 0) return fail(EINVAL, "submit_batch_host arguments");
 	if (set_device(dev)) return EIO;
+	std::vector<int> mbs_of((size_t)n);
+	for (int i = 0; i < n; i++) { // validate the whole batch before the first side effect
+		E264Stream *s = streams[i];
+		if (!s || s->dev != dev) return fail(EINVAL, "batch entry");
+		for (int j = 0; j < i; j++)
+			if (streams[j] == s) return fail(EINVAL, "a stream may contribute one frame per batch");
+		int dst, r = check_packet(packets[i], bytes[i], &dst, &mbs_of[i]);
+		if (r) return r;
+		if (!s->h_table[dst]) return fail(EINVAL, "destination slot not allocated");
+		if ((r = check_packet_deep(packets[i], bytes[i], s->h_table))) return r;
+	}
+	std::lock_guard<std::mutex> bg(dev->batch_lock); // batches of one device are serialised (their streams are disjoint per batch anyway)
 	E264Device::JobRing &jr = dev->jring[dev->jring_next];
 	dev->jring_next = (dev->jring_next + 1) & 3;
 	if (jr.busy) { hipEventSynchronize(jr.done); jr.busy = false; }
@@ -496,14 +515,9 @@ API int e264hip_submit_batch_host(E264Device *dev, E264Stream *const *streams, c
 	int max_mbs = 0;
 	for (int i = 0; i < n; i++) {
 		E264Stream *s = streams[i];
-		if (!s || s->dev != dev) return fail(EINVAL, "batch entry");
-		for (int j = 0; j < i; j++)
-			if (streams[j] == s) return fail(EINVAL, "a stream may contribute one frame per batch");
-		int dst, n_mbs, r = check_packet(packets[i], bytes[i], &dst, &n_mbs);
+		const int n_mbs = mbs_of[i];
+		int r = ensure_dbk(s, n_mbs);
 		if (r) return r;
-		if (!s->h_table[dst]) return fail(EINVAL, "destination slot not allocated");
-		if ((r = check_packet_deep(packets[i], bytes[i], s->h_table))) return r;
-		if ((r = ensure_dbk(s, n_mbs))) return r;
 		void *h = e264hip_packet_buffer(s, bytes[i]);
 		if (!h) return ENOMEM;
 		E264Stream::Stage *st = &s->stage[s->stage_next];
