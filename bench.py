@@ -55,6 +55,8 @@ def main() -> int:
     ap.add_argument("--other-configs", action="store_true", help="also time short runs of BASELINE configs[1] and configs[3] (off by default: "
                     "the default command launches only the headline workload, so that a rocprofv3 trace of it averages one workload)")
     ap.add_argument("--queues", type=int, default=int(os.environ.get("E264_QUEUES", 1)), help="HIP queues per GPU; streams are split between them so that the wavefront kernels of one group overlap the parallel kernel of another")
+    ap.add_argument("--host-packets", action="store_true", help="also time the path that starts from packets in HOST memory "
+                    "(e264hip_submit_batch_host: staging copy + H2D + kernels); reported as pcie_inclusive, never as value")
     ap.add_argument("--debug-mode", type=int, default=0, help="profiling ablation bits (results are then wrong on purpose)")
     args = ap.parse_args()
 
@@ -252,6 +254,23 @@ def main() -> int:
                 for q in row:
                     q.free()
 
+    # ---- PCIe-inclusive rate (opt-in, informational): the same GOP submitted from host memory -------------------
+    pcie = None
+    if rank == 0 and world == 1 and nq == 1 and args.host_packets:
+        hbs = [dev.prepare_host_batch(streams, [packets[f]] * len(streams)) for f in range(len(packets))]
+        for hb in hbs:
+            dev.submit_host_prepared(hb, backend.RUN_ALL)
+        dev.sync()
+        t2 = time.perf_counter()
+        for _ in range(2):
+            for hb in hbs:
+                dev.submit_host_prepared(hb, backend.RUN_ALL)
+        dev.sync()
+        dt2 = time.perf_counter() - t2
+        pcie = {"value": round(2 * len(packets) * len(streams) / dt2, 1), "unit": "frames/s",
+                "packet_MB_per_frame": round(float(np.mean([len(p) for p in packets])) / 1e6, 3),
+                "what": "host packets -> pinned staging (memcpy on the calling thread) -> H2D -> 4 kernels, asynchronous, one batch per frame index"}
+
     if rank == 0:
         per_launch_bytes = float(np.mean(alg_bytes)) * args.streams / nq
         names = ["e264_dbkparam_kernel", "e264_mbpar_kernel", "e264_intra_kernel", "e264_deblock_kernel"]
@@ -290,6 +309,7 @@ def main() -> int:
             "cpu_baseline": cpu,
             "bit_exact": bit_exact,
             "other_configs": other,
+            "pcie_inclusive": pcie,
             "gpu_event_ms_per_step": round(ev_ms / args.steps, 3),
         }
         os.write(json_fd, (json.dumps(out) + "\n").encode())
