@@ -840,20 +840,19 @@ template <int S, int IT0, int IT1>
 __device__ __forceinline__ void mc_issue_luma(const FrameCtx &f, int lane, int XA, int Y0, int pic, uint32_t *w)
 { // iterations IT0..IT1-1 of the window fetch; w[it - IT0] receives iteration `it`
 	constexpr int ROWS = S + 5, ND = S == 16 ? 6 : S == 8 ? 4 : 3, G = 256 / (S * S), PER = ROWS * ND;
-	constexpr int NIT = (G * PER + 63) / 64;
+	// The 64 / G lanes whose blocks lie in window g fetch that window: every lane works from its OWN origin (no
+	// cross-lane exchange); dword `rem` of window g lands in w[] of lane g * LPW + rem % LPW, iteration rem / LPW.
+	constexpr int LPW = 64 / G, NIT = (PER + LPW - 1) / LPW;
 #pragma unroll
 	for (int it = IT0; it < (IT1 < NIT ? IT1 : NIT); it++) {
-		const int idx = it * 64 + lane;
-		const int g = idx / PER, rem = idx - g * PER, row = rem / ND, dw = rem - row * ND;
-		const int src = (g * (64 / G)) & 63;
-		int xa, y0, pc;
-		if (S == 16) { // one window: its origin is lane 0's (uniform)
+		const int rem = it * LPW + (lane & (LPW - 1));
+		const int row = rem / ND, dw = rem - row * ND;
+		int xa = XA, y0 = Y0, pc = pic;
+		if (S == 16) { // one window: uniform origin (scalar address arithmetic)
 			xa = __builtin_amdgcn_readfirstlane(XA); y0 = __builtin_amdgcn_readfirstlane(Y0); pc = __builtin_amdgcn_readfirstlane(pic);
-		} else {
-			xa = __shfl(XA, src); y0 = __shfl(Y0, src); pc = __shfl(pic, src);
 		}
 		uint32_t v = 0;
-		if (idx < G * PER && pc >= 0) {
+		if (rem < PER && pc >= 0) {
 			const gu8 *rowp = (const gu8 *)f.dpb_lds[pc] + (size_t)clip3i(0, f.H - 1, y0 + row) * f.sY;
 			const int x = xa + dw * 4;
 			if (x >= 0 && x <= f.W - 4) v = *(const gu32 *)(rowp + x);
@@ -907,11 +906,13 @@ __device__ __forceinline__ void mc_commit(WaveLds &L, const McMotion &M, int l, 
 	if (M.refs[l] == 0xffffffffu)
 		return;
 	const int S = (M.S >> (8 * l)) & 255;
-	const int total = S == 16 ? 126 : S == 8 ? 208 : 432;
-	if (lane < total) L.win[lane] = Wn.y0;
-	if (64 + lane < total) L.win[64 + lane] = Wn.y1;
-	if (128 + lane < total) L.win[128 + lane] = Wn.y2;
-	if (192 + lane < total) L.win[192 + lane] = Wn.y3;
+	// same lane -> dword mapping as mc_issue_luma: window g = lane / LPW, dword it * LPW + lane % LPW
+	const int lpw = S == 16 ? 64 : S == 8 ? 16 : 4, per = S == 16 ? 126 : S == 8 ? 52 : 27;
+	const int base = (lane / lpw) * per, r0 = lane & (lpw - 1);
+	if (r0 < per) L.win[base + r0] = Wn.y0;
+	if (lpw + r0 < per) L.win[base + lpw + r0] = Wn.y1;
+	if (2 * lpw + r0 < per) L.win[base + 2 * lpw + r0] = Wn.y2;
+	if (3 * lpw + r0 < per) L.win[base + 3 * lpw + r0] = Wn.y3;
 }
 
 // 4x4 windows (432 dwords) do not fit the 4 prefetch registers: dwords 256..431 are fetched here, at
@@ -926,8 +927,8 @@ __device__ __forceinline__ void mc_commit_tail(WaveLds &L, const FrameCtx &f, co
 	mc_issue_luma<4, 4, 7>(f, lane, G.X0 & ~3, G.Y0, G.pic, t);
 #pragma unroll
 	for (int it = 4; it < 7; it++)
-		if (it * 64 + lane < 432)
-			L.win[it * 64 + lane] = t[it - 4];
+		if (it * 4 + (lane & 3) < 27)
+			L.win[(lane >> 2) * 27 + it * 4 + (lane & 3)] = t[it - 4];
 }
 
 // filters + weights of one list of one macroblock from the LDS window / chroma registers
