@@ -75,24 +75,30 @@ __device__ __forceinline__ int BXf(int k) { return ((k & 1) << 2) | ((k & 4) << 
 __device__ __forceinline__ int BYf(int k) { return ((k & 2) << 1) | ((k & 8)); }
 __device__ __forceinline__ int blk_of(int bx, int by) { return (by >> 1) * 8 + (bx >> 1) * 4 + (by & 1) * 2 + (bx & 1); }
 
-__constant__ uint8_t c_na4[6][3] = {{10, 16, 13}, {11, 18, 14}, {13, 20, 16}, {14, 23, 18}, {16, 25, 20}, {18, 29, 23}};
-__constant__ uint8_t c_na8[6][6] = {{20, 18, 32, 19, 25, 24}, {22, 19, 35, 21, 28, 26}, {26, 23, 42, 24, 33, 31},
-	{28, 25, 45, 26, 35, 33}, {32, 28, 51, 30, 40, 38}, {36, 32, 58, 34, 46, 43}};
+// normAdjust4x4 / normAdjust8x8 (edge264_residual.c:77-98) as arithmetic on immediates: byte m of a 64-bit constant per
+// position class.  (A table in constant memory read with a per-lane index is a vector-memory round trip in the middle
+// of every transform.)
+__device__ __forceinline__ int na_byte(uint64_t t, int m) { return (int)(t >> (8 * m)) & 255; }
+#define NA4_0 0x12100e0d0b0aull /* class 0 (even,even): 10 11 13 14 16 18 */
+#define NA4_1 0x1d1917141210ull /* class 1 (odd,odd)  : 16 18 20 23 25 29 */
 __device__ __forceinline__ int norm4(int m, int pos)
-{ // edge264_residual.c:77-84
+{
 	int i = pos >> 2, j = pos & 3;
-	return c_na4[m][(i & j & 1) ? 1 : ((i | j) & 1) ? 2 : 0];
+	const int a = na_byte(NA4_0, m), b = na_byte(NA4_1, m), c = na_byte(0x171412100e0dull, m);
+	return (i & j & 1) ? b : ((i | j) & 1) ? c : a;
 }
 __device__ __forceinline__ int norm8(int m, int pos)
-{ // edge264_residual.c:85-98
+{
 	int i = pos >> 3, j = pos & 7, k;
-	if ((i & 3) == 0 && (j & 3) == 0) k = 0;
-	else if (i & j & 1) k = 1;
-	else if ((i & 3) == 2 && (j & 3) == 2) k = 2;
-	else if (((i & 3) == 0 && (j & 1)) || ((i & 1) && (j & 3) == 0)) k = 3;
-	else if (((i & 3) == 0 && (j & 3) == 2) || ((i & 3) == 2 && (j & 3) == 0)) k = 4;
-	else k = 5;
-	return c_na8[m][k];
+	const int v0 = na_byte(0x24201c1a1614ull, m), v1 = na_byte(0x201c19171312ull, m), v2 = na_byte(0x3a332d2a2320ull, m);
+	const int v3 = na_byte(0x221e1a181513ull, m), v4 = na_byte(0x2e2823211c19ull, m), v5 = na_byte(0x2b26211f1a18ull, m);
+	if ((i & 3) == 0 && (j & 3) == 0) k = v0;
+	else if (i & j & 1) k = v1;
+	else if ((i & 3) == 2 && (j & 3) == 2) k = v2;
+	else if (((i & 3) == 0 && (j & 1)) || ((i & 1) && (j & 3) == 0)) k = v3;
+	else if (((i & 3) == 0 && (j & 3) == 2) || ((i & 3) == 2 && (j & 3) == 0)) k = v4;
+	else k = v5;
+	return k;
 }
 
 __constant__ uint8_t c_alpha[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 5, 6, 7, 8, 9, 10, 12, 13, 15, 17, 20, 22, 25, 28,
@@ -128,6 +134,11 @@ struct __attribute__((aligned(16))) WaveLds { // reconstruction scratch of one w
 	uint8_t ftop[32];          // intra 8x8 filtered top  ft[-1..15] at [i+1]
 	uint8_t fleft[8];          // intra 8x8 filtered left
 	uint32_t win[432];         // reference windows of inter prediction (one list at a time): 1 x 21x24, 4 x 13x16 or 16 x 9x12 bytes
+	// residual inputs, staged so that the transforms never wait for memory (see coef_issue / slice_cache)
+	__attribute__((aligned(4))) int16_t coef[408]; // the macroblock's payload: [luma DC 16][chroma DC 8][coded blocks], as in the packet
+	__attribute__((aligned(4))) uint8_t ws[224];   // scaling lists of the cached slice: weightScale4x4[6][16], weightScale8x8[0..1][64]
+	int ws_slice;              // slice index the cache holds (-1: none)
+	int ws_idc;                // its weighted_bipred_idc
 };
 
 // Output staging of one strip of the macroblock-parallel kernel: the samples of its (up to) 8
@@ -258,14 +269,14 @@ __device__ __forceinline__ MbInfo mb_from_lds(const uint32_t *rec)
 // (edge264_residual.c:118-134); pass 2 (lane = block k, column x'): vertical butterfly, >>6,
 // saturate to int16 (residual.c:141-158).  dc_only blocks get the add_dc4x4 value (residual.c:174-187).
 __device__ __forceinline__ void idct4x4_blocks(WaveLds &L, int nblk, uint32_t codedmask, bool use_dc, bool dc_valid,
-	const gi16 *coef_base, cu8p wS, int qP, int dc_off, int res_off, int res_stride, int lane)
+	const int16_t *coef_base, const uint8_t *wS, int qP, int dc_off, int res_off, int res_stride, int lane)
 {
 	int k = lane >> 2, y = lane & 3;
 	bool active = k < nblk;
 	bool coded = active && (codedmask >> k & 1);
 	if (coded) {
 		// coefficient blocks are packed in increasing k: offset = popcount of lower coded bits
-		const gi16 *c = coef_base + __builtin_popcount(codedmask & ((1u << k) - 1)) * 16;
+		const int16_t *c = coef_base + __builtin_popcount(codedmask & ((1u << k) - 1)) * 16;
 		int sh = qP / 6, m = qP - sh * 6;
 		int d[4];
 #pragma unroll
@@ -332,7 +343,7 @@ __device__ __forceinline__ void idct8_1d(int16_t d[8])
 	d[4] = (int16_t)(f6 - f1); d[5] = (int16_t)(f4 - f3); d[6] = (int16_t)(f2 - f5); d[7] = (int16_t)(f0 - f7);
 }
 
-__device__ __forceinline__ void idct8x8_blocks(WaveLds &L, uint32_t coded, const gi16 *coef_base, cu8p wS, int qP, int lane)
+__device__ __forceinline__ void idct8x8_blocks(WaveLds &L, uint32_t coded, const int16_t *coef_base, const uint8_t *wS, int qP, int lane)
 {
 	int b = lane >> 3, j = lane & 7;
 	bool on = lane < 32 && (coded >> (b * 4) & 1);
@@ -340,7 +351,7 @@ __device__ __forceinline__ void idct8x8_blocks(WaveLds &L, uint32_t coded, const
 	if (on) {
 		int nb = 0;
 		for (int i = 0; i < b; i++) nb += coded >> (i * 4) & 1;
-		const gi16 *c = coef_base + nb * 64;
+		const int16_t *c = coef_base + nb * 64;
 		int div = qP / 6, m = qP - div * 6;
 		int16_t d[8];
 #pragma unroll
@@ -374,17 +385,74 @@ __device__ __forceinline__ void idct8x8_blocks(WaveLds &L, uint32_t coded, const
 	wave_sync();
 }
 
-__device__ __forceinline__ void compute_residual(WaveLds &L, const FrameCtx &f, const MbInfo &m, cslice_t s, const gu8 *pl, int lane)
+// Residual inputs without a memory round trip inside the transforms:
+//   coef_issue / coef_commit  the macroblock's payload (<= 816 bytes) as 4 coalesced dword loads per lane, issued
+//                             while something else runs (mbpar: one macroblock ahead; intra: before the wait for the
+//                             row above), then dropped into L.coef.  (Before: 2-byte loads at transform positions,
+//                             used at once: one exposed round trip per transform call.)
+//   slice_cache               scaling lists + weighted_bipred_idc of the current slice in LDS, reloaded when the
+//                             slice index changes.
+struct CoefPf { uint32_t v0, v1, v2, v3; };
+__device__ __forceinline__ int coef_dwords(const MbInfo &m)
+{
+	if (m.kind == E264_MB_ABSENT || m.kind == E264_MB_PCM || m.coded == 0)
+		return 0;
+	const uint32_t c = m.coded;
+	int bytes = ((c & E264_CODED_LUMA_DC) ? 32 : 0) + ((c & E264_CODED_CHROMA_DC) ? 16 : 0) + __builtin_popcount(c >> 16 & 0xff) * 32;
+	bytes += (m.kind != E264_MB_I16x16 && (m.flags & E264_MBF_T8x8)) ? __builtin_popcount(c & 0x1111) * 128 : __builtin_popcount(c & 0xffff) * 32;
+	return bytes >> 2;
+}
+__device__ __forceinline__ void coef_issue(const FrameCtx &f, const MbInfo &m, int lane, CoefPf &pf)
+{ // loads only: nothing here may use a loaded value
+	const int ndw = coef_dwords(m);
+	pf.v0 = pf.v1 = pf.v2 = pf.v3 = 0;
+	if (ndw == 0)
+		return;
+	const gu32 *src = (const gu32 *)(f.payload + m.payload_off);
+	if (lane < ndw) pf.v0 = src[lane];
+	if (64 + lane < ndw) pf.v1 = src[64 + lane];
+	if (128 + lane < ndw) pf.v2 = src[128 + lane];
+	if (192 + lane < ndw) pf.v3 = src[192 + lane];
+}
+__device__ __forceinline__ void coef_commit(WaveLds &L, const MbInfo &m, int lane, const CoefPf &pf)
+{ // the caller synchronises the wave before the transforms read L.coef (compute_residual does)
+	const int ndw = coef_dwords(m);
+	if (ndw == 0)
+		return;
+	uint32_t *c = (uint32_t *)L.coef;
+	if (lane < ndw) c[lane] = pf.v0;
+	if (64 + lane < ndw) c[64 + lane] = pf.v1;
+	if (128 + lane < ndw) c[128 + lane] = pf.v2;
+	if (192 + lane < ndw) c[192 + lane] = pf.v3;
+}
+__device__ __forceinline__ void slice_cache(WaveLds &L, const FrameCtx &f, int slice, int lane)
+{
+	if (__builtin_amdgcn_readfirstlane(L.ws_slice) == slice) // uniform
+		return;
+	cslice_t s = f.slices + slice;
+	wave_sync();
+	const gu32 *g4 = (const gu32 *)((const gu8 *)s + offsetof(E264SliceParams, weightScale4x4));
+	const gu32 *g8 = (const gu32 *)((const gu8 *)s + offsetof(E264SliceParams, weightScale8x8));
+	if (lane < 24) ((uint32_t *)L.ws)[lane] = g4[lane];
+	else if (lane < 56) ((uint32_t *)L.ws)[lane] = g8[lane - 24];
+	if (lane == 0) { L.ws_slice = slice; L.ws_idc = s->weighted_bipred_idc; }
+	wave_sync();
+}
+
+// L.coef holds the macroblock's payload (coef_commit), the slice cache is valid (slice_cache)
+__device__ __forceinline__ void compute_residual(WaveLds &L, const FrameCtx &f, const MbInfo &m, int lane)
 {
 	// zero the residual tile (384 int16 = 192 dwords)
 	uint32_t *rz = (uint32_t *)L.res;
 	rz[lane] = 0; rz[lane + 64] = 0; rz[lane + 128] = 0;
 	const uint32_t coded = m.coded;
 	const bool inter = m.kind == E264_MB_INTER;
-	const gi16 *ldc = nullptr, *cdc = nullptr;
-	if (coded & E264_CODED_LUMA_DC) { ldc = (const gi16 *)pl; pl += 32; }
-	if (coded & E264_CODED_CHROMA_DC) { cdc = (const gi16 *)pl; pl += 16; }
-	const gi16 *co = (const gi16 *)pl;
+	const int16_t *pl = L.coef;
+	const int16_t *ldc = nullptr, *cdc = nullptr;
+	if (coded & E264_CODED_LUMA_DC) { ldc = pl; pl += 16; }
+	if (coded & E264_CODED_CHROMA_DC) { cdc = pl; pl += 8; }
+	const int16_t *co = pl;
+	const uint8_t *ws4 = L.ws, *ws8 = L.ws + 96;
 	if (lane < 24) L.dc[lane] = 0;
 	wave_sync();
 	if (!coded) return;
@@ -402,7 +470,7 @@ __device__ __forceinline__ void compute_residual(WaveLds &L, const FrameCtx &f, 
 				acc += neg ? -v : v;
 			}
 		int qP = m.qp[0];
-		int LS = (s->weightScale4x4[0][0] * norm4(qP % 6, 0)) << (qP / 6);
+		int LS = (ws4[0] * norm4(qP % 6, 0)) << (qP / 6);
 		int k = (r >> 1) * 8 + (l >> 1) * 4 + (r & 1) * 2 + (l & 1);
 		L.dc[k] = (int)((uint32_t)acc * (uint32_t)LS + 32u) >> 6;
 	}
@@ -411,7 +479,7 @@ __device__ __forceinline__ void compute_residual(WaveLds &L, const FrameCtx &f, 
 		int c0 = cdc[pc], c4 = cdc[4 + pc], c2 = cdc[2 + pc], c6 = cdc[6 + pc];
 		int v = n == 0 ? c0 + c4 + c2 + c6 : n == 1 ? c0 - c4 + c2 - c6 : n == 2 ? c0 + c4 - c2 - c6 : c0 - c4 - c2 + c6;
 		int qP = pc ? m.qp[2] : m.qp[1];
-		int LS = (s->weightScale4x4[1 + pc + (inter ? 3 : 0)][0] * norm4(qP % 6, 0)) << (qP / 6);
+		int LS = (ws4[(1 + pc + (inter ? 3 : 0)) * 16] * norm4(qP % 6, 0)) << (qP / 6);
 		L.dc[16 + pc * 4 + n] = (int)((uint32_t)v * (uint32_t)LS) >> 5;
 	}
 	wave_sync();
@@ -419,22 +487,22 @@ __device__ __forceinline__ void compute_residual(WaveLds &L, const FrameCtx &f, 
 	// luma
 	if (m.kind == E264_MB_I16x16) {
 		if (coded & (0xffff | E264_CODED_LUMA_DC))
-			idct4x4_blocks(L, 16, coded & 0xffff, true, ldc != nullptr, co, s->weightScale4x4[0], m.qp[0], 0, 0, 16, lane);
+			idct4x4_blocks(L, 16, coded & 0xffff, true, ldc != nullptr, co, ws4, m.qp[0], 0, 0, 16, lane);
 		co += __builtin_popcount(coded & 0xffff) * 16;
 	} else if (m.flags & E264_MBF_T8x8) {
 		if (coded & 0x1111)
-			idct8x8_blocks(L, coded, co, s->weightScale8x8[inter ? 1 : 0], m.qp[0], lane);
+			idct8x8_blocks(L, coded, co, ws8 + (inter ? 64 : 0), m.qp[0], lane);
 		co += __builtin_popcount(coded & 0x1111) * 64;
 	} else {
 		if (coded & 0xffff)
-			idct4x4_blocks(L, 16, coded & 0xffff, false, false, co, s->weightScale4x4[inter ? 3 : 0], m.qp[0], 0, 0, 16, lane);
+			idct4x4_blocks(L, 16, coded & 0xffff, false, false, co, ws4 + (inter ? 3 : 0) * 16, m.qp[0], 0, 0, 16, lane);
 		co += __builtin_popcount(coded & 0xffff) * 16;
 	}
 	// chroma: 8 blocks, Cb 0..3 then Cr 4..7; different QP / scaling list per plane
 	if (coded & (0xff0000 | E264_CODED_CHROMA_DC)) {
 		int k = lane >> 2;
 		int pc = (k >> 2) & 1;
-		idct4x4_blocks(L, 8, coded >> 16 & 0xff, true, cdc != nullptr, co, s->weightScale4x4[1 + pc + (inter ? 3 : 0)], pc ? m.qp[2] : m.qp[1], 16, 256, 8, lane);
+		idct4x4_blocks(L, 8, coded >> 16 & 0xff, true, cdc != nullptr, co, ws4 + (1 + pc + (inter ? 3 : 0)) * 16, pc ? m.qp[2] : m.qp[1], 16, 256, 8, lane);
 	}
 }
 
@@ -922,6 +990,9 @@ __device__ __forceinline__ void mc_commit_tail(WaveLds &L, const FrameCtx &f, co
 {
 	if (M.refs[l] == 0xffffffffu || ((M.S >> (8 * l)) & 255) != 4 || (f.dbg & 256))
 		return;
+#ifdef E264_ABL_NOTAIL
+	return;
+#endif
 	McGeom G = mc_geom(M, l, lane, mbx, mby);
 	uint32_t t[3];
 	mc_issue_luma<4, 4, 7>(f, lane, G.X0 & ~3, G.Y0, G.pic, t);
@@ -938,9 +1009,9 @@ __device__ __forceinline__ void mc_compute(WaveLds &L, const FrameCtx &f, cslice
 	const int k = lane >> 2, r = lane & 3;
 	const int cpl = lane >> 5, cy = (lane >> 2) & 7, cx = (lane & 3) * 2;
 	const int kc = blk_of(cx >> 1, cy >> 1);
-	const int idc = s->weighted_bipred_idc;
 	if (M.refs[l] == 0xffffffffu)
 		return;
+	const int idc = __builtin_amdgcn_readfirstlane(L.ws_idc); // slice_cache ran at the top of the iteration
 	McGeom G = mc_geom(M, l, lane, mbx, mby);
 	if (G.pic >= 0 && !(f.dbg & 256)) {
 		const int nd = G.S == 16 ? 6 : G.S == 8 ? 4 : 3, per = (G.S + 5) * nd;
@@ -1004,10 +1075,15 @@ __device__ __forceinline__ bool mbpar_mb(WaveLds &L, StripOut &O, int slot, cons
 		return true;
 	}
 	cslice_t s = f.slices + m.slice;
+#ifdef E264_ABL_NORES
+	const bool has_res = false;
+#else
 	const bool has_res = m.coded != 0 && !(f.dbg & 1024); // uniform; most inter macroblocks carry no residual
-	if (has_res) compute_residual(L, f, m, s, pl, lane);
+#endif
+	if (has_res) compute_residual(L, f, m, lane); // payload already in L.coef (committed at the top of the iteration)
 	int pY[4] = {0, 0, 0, 0}, pC[2] = {0, 0};
 	mc_compute(L, f, s, M, 0, cc, mbx, mby, lane, pY, pC); // list 0: window already in LDS (prefetched)
+#ifndef E264_ABL_NOL1
 	if (M.refs[1] != 0xffffffffu) { // list 1 (B macroblocks): its windows were prefetched with list 0's; same LDS area, second turn
 		wave_sync();
 		mc_commit(L, M, 1, W1, mbx, mby, lane);
@@ -1017,6 +1093,7 @@ __device__ __forceinline__ bool mbpar_mb(WaveLds &L, StripOut &O, int slot, cons
 		chroma_taps(W1, c1);
 		mc_compute(L, f, s, M, 1, c1, mbx, mby, lane, pY, pC);
 	}
+#endif
 	if (has_res) { // add residual, clip (int16 wrap add then packus: residual.c:160-171)
 		const int16_t *rr = L.res + Yr * 16 + X;
 		const int16_t *rc = L.res + 256 + cpl * 64 + cy * 8 + cx;
@@ -1322,8 +1399,8 @@ __device__ __forceinline__ int intra_chroma_px(const WaveLds &L, int p, int mode
 // ---------------------------------------------------------------------------------
 // WHICH: 1 = inter and PCM macroblocks only (no dependency inside the frame), 2 = intra only, 3 = all
 template <int WHICH>
-__device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, int mbx, int mby, int lane)
-{
+__device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, int mbx, int mby, int lane, const CoefPf &pf)
+{ // pf: the macroblock's payload, issued by the caller (coef_issue) as early as it could
 	if (m.kind == E264_MB_ABSENT)
 		return;
 	const bool par = m.kind == E264_MB_INTER || m.kind == E264_MB_PCM;
@@ -1347,7 +1424,11 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const Mb
 	IntraNb nbv = {0, 0};
 	if (WHICH != 1 && m.kind != E264_MB_INTER)
 		nbv = issue_intra_neighbours(f, mbx, mby, lane); // in flight during the residual
-	if (!(f.dbg & 1024)) compute_residual(L, f, m, s, pl, lane);
+	if (!(f.dbg & 1024)) {
+		slice_cache(L, f, m.slice, lane);
+		coef_commit(L, m, lane, pf);
+		compute_residual(L, f, m, lane);
+	}
 
 	int pY[4], pC[2];
 	bool tile_luma = false;
@@ -1846,6 +1927,8 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 	if (n <= 0)
 		return;
 	WaveLds &L = lds[wave];
+	if (lane == 0) L.ws_slice = -1;
+	wave_sync();
 	const bool recon = mode & 1;
 	// headers of the strip: 8 records x 8 dwords, one dword per lane
 	const gu32 *mbs_g = (const gu32 *)(f.payload - f.h->payload_off + f.h->mbs_off);
@@ -1880,6 +1963,9 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 	//         (luma) and copied out (chroma taps cc) at the top of iteration i+1
 	McRaw raw;
 	McMotion m0, m1;
+	//   pf  : payload (coefficients) of macroblock i+1, loaded during iteration i, committed to LDS at the top of i+1
+	CoefPf pf = {0, 0, 0, 0};
+	if (recon && h0.kind == E264_MB_INTER) coef_issue(f, h0, lane, pf);
 	McWindows w, wb, wbc; // wb: list-1 windows of macroblock i+1 in flight; wbc: those of macroblock i (copied once they arrived)
 	wb.y0 = wb.y1 = wb.y2 = wb.y3 = wb.ca = wb.cb = 0; wbc = wb;
 	int cc[6] = {0, 0, 0, 0, 0, 0};
@@ -1893,7 +1979,9 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 	uint32_t staged = 0;
 	if (recon && h0.kind == E264_MB_INTER) {
 		mc_issue(f, m0, 0, mbx, mby, lane, w);
+#ifndef E264_ABL_NOL1
 		mc_issue(f, m0, 1, mbx, mby, lane, wb);
+#endif
 	}
 #pragma unroll 1
 	for (int i = 0; i < n; i++) {
@@ -1902,20 +1990,29 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 		// every load of the previous iteration is consumed first (the compiler's vmcnt bookkeeping collapses to
 		// vmcnt(0) across these branches: a load issued before this point would be waited for at once) ...
 		if (i + 1 < n) mc_finish(raw, lane, m1);             // motion of macroblock i+1 (loads issued one iteration ago)
+		if (recon && (h0.kind == E264_MB_INTER)) {
+			slice_cache(L, f, h0.slice, lane);
+			coef_commit(L, h0, lane, pf);
+		}
 		if (recon && h0.kind == E264_MB_INTER && !(mode & 8192)) { // 8192: profiling ablation, windows are loaded but never consumed
 			mc_commit(L, m0, 0, w, mbx, mby, lane);
 			mc_commit_tail(L, f, m0, 0, mbx, mby, lane);
 			chroma_taps(w, cc);
+#ifndef E264_ABL_NOL1
 			if (m0.refs[1] != 0xffffffffu) wbc = wb; // list 1 in use (uniform): take over the prefetched registers (they have arrived with list 0's)
+#endif
 		}
 		wave_sync();
 		// ... then the loads of the next stages go out, with the whole reconstruction of macroblock i to hide them
 		if (i + 2 < n) mc_issue_raw(f, base + i + 2, lane, raw);
 		const int i1 = min(i + 1, n - 1);
 		const MbInfo h1 = mb_from_lanes(HV(i1), i1 & 7);
+		if (recon && i + 1 < n && h1.kind == E264_MB_INTER) coef_issue(f, h1, lane, pf);
 		if (recon && i + 1 < n && h1.kind == E264_MB_INTER) {
 			mc_issue(f, m1, 0, nx, ny, lane, w);
+#ifndef E264_ABL_NOL1
 			mc_issue(f, m1, 1, nx, ny, lane, wb);
+#endif
 		}
 		if (recon && mbpar_mb(L, O, i, f, h0, m0, cc, wbc, mbx, mby, lane))
 			staged |= 1u << i;
@@ -1984,6 +2081,8 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 		progress[i] = 0;
 	__syncthreads();
 	WaveLds &L = lds[wave];
+	if (lane == 0) L.ws_slice = -1;
+	wave_sync();
 	const gu8 *mbs_g = f.payload - f.h->payload_off + f.h->mbs_off; // the E264Mb array through a per-lane (global) pointer
 #pragma unroll 1
 	for (int y = wave; y < f.hm; y += NW) {
@@ -2014,13 +2113,16 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 			while (todo) {
 				const int x = x0 + (int)__builtin_ctzll(todo);
 				todo &= todo - 1;
+				const MbInfo mi = mb_from_lds(&hdrs[wave][(x - x0) * 8]);
+				CoefPf pf;
+				coef_issue(f, mi, lane, pf); // the payload does not depend on the neighbours: in flight during the wait below
 				if (y > 0) {
 					int want = min(x + 2, f.wm);
 					while (lds_load_relaxed(&progress[y - 1]) < want)
 						__builtin_amdgcn_s_sleep(1);
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 				}
-				recon_mb<2>(L, f, mb_from_lds(&hdrs[wave][(x - x0) * 8]), x, y, lane);
+				recon_mb<2>(L, f, mi, x, y, lane, pf);
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 				// finished: everything up to the next intra macroblock of the chunk (or the chunk's end)
 				const int upto = todo ? x0 + (int)__builtin_ctzll(todo) : xe;
