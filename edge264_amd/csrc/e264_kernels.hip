@@ -835,7 +835,8 @@ struct McMotion {
 	int S;                   // wave-uniform: window granularity of list 0 (bits 0..7) and list 1 (bits 8..15): 16, 8 or 4
 };
 struct McWindows {          // reference samples of ONE list
-	uint32_t y0, y1, y2, y3; // luma window dwords fetched ahead by this lane (iterations 0..3; 4x4 windows fetch 4..6 late)
+	uint32_t y0, y1, y2, y3; // luma window dwords fetched ahead by this lane (iterations 0..3)
+	uint32_t y4, y5, y6;     // iterations 4..6: only 4x4 windows (16 x 27 dwords = 7 per lane) have them
 	                         // (scalars, not an array: the array form ended up in scratch memory)
 	uint32_t ca, cb;         // chroma samples x..x+2 of rows y and y+1 of this lane, one byte each (RAW loads on the fast path:
 	                         // they are only taken apart by chroma_taps() one macroblock later)
@@ -937,11 +938,11 @@ __device__ __forceinline__ void mc_issue(const FrameCtx &f, const McMotion &M, i
 		return;
 	McGeom G = mc_geom(M, l, lane, mbx, mby);
 	if (!(f.dbg & 256)) {
-		uint32_t t[4] = {0, 0, 0, 0};
+		uint32_t t[7] = {0, 0, 0, 0, 0, 0, 0};
 		if (G.S == 16) mc_issue_luma<16, 0, 4>(f, lane, G.X0 & ~3, G.Y0, G.pic, t);
 		else if (G.S == 8) mc_issue_luma<8, 0, 4>(f, lane, G.X0 & ~3, G.Y0, G.pic, t);
-		else mc_issue_luma<4, 0, 4>(f, lane, G.X0 & ~3, G.Y0, G.pic, t);
-		Wn.y0 = t[0]; Wn.y1 = t[1]; Wn.y2 = t[2]; Wn.y3 = t[3];
+		else mc_issue_luma<4, 0, 7>(f, lane, G.X0 & ~3, G.Y0, G.pic, t);
+		Wn.y0 = t[0]; Wn.y1 = t[1]; Wn.y2 = t[2]; Wn.y3 = t[3]; Wn.y4 = t[4]; Wn.y5 = t[5]; Wn.y6 = t[6];
 	}
 	// chroma: the 3x2 samples around this lane's two outputs (8.4.2.2.2)
 	const int kc = blk_of(cx >> 1, cy >> 1);
@@ -981,25 +982,11 @@ __device__ __forceinline__ void mc_commit(WaveLds &L, const McMotion &M, int l, 
 	if (lpw + r0 < per) L.win[base + lpw + r0] = Wn.y1;
 	if (2 * lpw + r0 < per) L.win[base + 2 * lpw + r0] = Wn.y2;
 	if (3 * lpw + r0 < per) L.win[base + 3 * lpw + r0] = Wn.y3;
-}
-
-// 4x4 windows (432 dwords) do not fit the 4 prefetch registers: dwords 256..431 are fetched here, at
-// commit time, and go straight to LDS (sub-8x8 partitions are rare; they pay one exposed round trip
-// instead of every macroblock paying 3 more live registers per list)
-__device__ __forceinline__ void mc_commit_tail(WaveLds &L, const FrameCtx &f, const McMotion &M, int l, int mbx, int mby, int lane)
-{
-	if (M.refs[l] == 0xffffffffu || ((M.S >> (8 * l)) & 255) != 4 || (f.dbg & 256))
-		return;
-#ifdef E264_ABL_NOTAIL
-	return;
-#endif
-	McGeom G = mc_geom(M, l, lane, mbx, mby);
-	uint32_t t[3];
-	mc_issue_luma<4, 4, 7>(f, lane, G.X0 & ~3, G.Y0, G.pic, t);
-#pragma unroll
-	for (int it = 4; it < 7; it++)
-		if (it * 4 + (lane & 3) < 27)
-			L.win[(lane >> 2) * 27 + it * 4 + (lane & 3)] = t[it - 4];
+	if (S == 4) { // 27 dwords per window, 4 lanes per window: iterations 4..6
+		L.win[base + 16 + r0] = Wn.y4;
+		L.win[base + 20 + r0] = Wn.y5;
+		if (24 + r0 < 27) L.win[base + 24 + r0] = Wn.y6;
+	}
 }
 
 // filters + weights of one list of one macroblock from the LDS window / chroma registers
@@ -1087,7 +1074,6 @@ __device__ __forceinline__ bool mbpar_mb(WaveLds &L, StripOut &O, int slot, cons
 	if (M.refs[1] != 0xffffffffu) { // list 1 (B macroblocks): its windows were prefetched with list 0's; same LDS area, second turn
 		wave_sync();
 		mc_commit(L, M, 1, W1, mbx, mby, lane);
-		mc_commit_tail(L, f, M, 1, mbx, mby, lane);
 		wave_sync();
 		int c1[6];
 		chroma_taps(W1, c1);
@@ -1967,7 +1953,7 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 	CoefPf pf = {0, 0, 0, 0};
 	if (recon && h0.kind == E264_MB_INTER) coef_issue(f, h0, lane, pf);
 	McWindows w, wb, wbc; // wb: list-1 windows of macroblock i+1 in flight; wbc: those of macroblock i (copied once they arrived)
-	wb.y0 = wb.y1 = wb.y2 = wb.y3 = wb.ca = wb.cb = 0; wbc = wb;
+	wb.y0 = wb.y1 = wb.y2 = wb.y3 = wb.y4 = wb.y5 = wb.y6 = wb.ca = wb.cb = 0; wbc = wb;
 	int cc[6] = {0, 0, 0, 0, 0, 0};
 	mc_issue_raw(f, base, lane, raw);
 	mc_finish(raw, lane, m0);
@@ -1996,7 +1982,6 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 		}
 		if (recon && h0.kind == E264_MB_INTER && !(mode & 8192)) { // 8192: profiling ablation, windows are loaded but never consumed
 			mc_commit(L, m0, 0, w, mbx, mby, lane);
-			mc_commit_tail(L, f, m0, 0, mbx, mby, lane);
 			chroma_taps(w, cc);
 #ifndef E264_ABL_NOL1
 			if (m0.refs[1] != 0xffffffffu) wbc = wb; // list 1 in use (uniform): take over the prefetched registers (they have arrived with list 0's)
