@@ -207,6 +207,24 @@ struct FrameCtx {
 	gu8 *dbk;          // per-MB deblocking parameters (E264_DBK_BYTES each), written by the mbpar kernel
 };
 
+// -DE264_PHASE_TIMING: wall cycles of the mbpar kernel's phases, summed over all waves (tools/gpu_phase.sh reads them back
+// through e264_debug_phase_cycles).  s_memtime at the phase boundaries drains the LGKM counter, so the numbers are a
+// profile, not a benchmark.
+#ifdef E264_PHASE_TIMING
+__device__ unsigned long long g_phase[16];
+#define PH_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PH(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); ph_acc[k] += t_ - ph_t; ph_t = t_; } while (0)
+#define PH_FLUSH(lane) do { if ((lane) == 0) for (int k_ = 0; k_ < 14; k_++) atomicAdd(&g_phase[k_], ph_acc[k_]); } while (0)
+#define PH_PARAMS , unsigned long long &ph_t, unsigned long long (&ph_acc)[14]
+#define PH_ARGS , ph_t, ph_acc
+#else
+#define PH_DECL
+#define PH(k)
+#define PH_FLUSH(lane)
+#define PH_PARAMS
+#define PH_ARGS
+#endif
+
 __device__ __forceinline__ gu8 *plane_base(const FrameCtx &f, gu8 *base, int pl)
 {
 	return pl == 0 ? base : base + f.psY + (pl == 2 ? (f.sC >> 1) : 0);
@@ -905,45 +923,47 @@ __device__ __forceinline__ McGeom mc_geom(const McMotion &M, int l, int lane, in
 // requested once per window.  Out-of-frame samples: clamped row index, edge sample replicated over
 // whole dwords (frame width is a multiple of 16, window columns are dword aligned) == the reference's
 // edge emulation (edge264_inter.c:1199-1235).
-template <int S, int IT0, int IT1>
-__device__ __forceinline__ void mc_issue_luma(const FrameCtx &f, int lane, int XA, int Y0, int pic, uint32_t *w)
-{ // iterations IT0..IT1-1 of the window fetch; w[it - IT0] receives iteration `it`
-	constexpr int ROWS = S + 5, ND = S == 16 ? 6 : S == 8 ? 4 : 3, G = 256 / (S * S), PER = ROWS * ND;
-	// The 64 / G lanes whose blocks lie in window g fetch that window: every lane works from its OWN origin (no
-	// cross-lane exchange); dword `rem` of window g lands in w[] of lane g * LPW + rem % LPW, iteration rem / LPW.
-	constexpr int LPW = 64 / G, NIT = (PER + LPW - 1) / LPW;
-#pragma unroll
-	for (int it = IT0; it < (IT1 < NIT ? IT1 : NIT); it++) {
-		const int rem = it * LPW + (lane & (LPW - 1));
-		const int row = rem / ND, dw = rem - row * ND;
-		int xa = XA, y0 = Y0, pc = pic;
-		if (S == 16) { // one window: uniform origin (scalar address arithmetic)
-			xa = __builtin_amdgcn_readfirstlane(XA); y0 = __builtin_amdgcn_readfirstlane(Y0); pc = __builtin_amdgcn_readfirstlane(pic);
-		}
-		uint32_t v = 0;
-		if (rem < PER && pc >= 0) {
-			const gu8 *rowp = (const gu8 *)f.dpb_lds[pc] + (size_t)clip3i(0, f.H - 1, y0 + row) * f.sY;
-			const int x = xa + dw * 4;
-			if (x >= 0 && x <= f.W - 4) v = *(const gu32 *)(rowp + x);
-			else v = (uint32_t)rowp[x < 0 ? 0 : f.W - 1] * 0x01010101u;
-		}
-		w[it - IT0] = v;
+// ONE code path for the three window sizes (the geometry is uniform data, not a template): every load writes straight
+// into its McWindows register.  Three specialised paths merged through copies, and a copy of a register with a load in
+// flight is a wait: the phase profile showed a full memory round trip exposed here on every macroblock.  For the same
+// reason nothing is zeroed: a dword that is not fetched (rem >= per, unused reference) keeps a stale value that
+// mc_commit / mc_compute never look at (same predicates).
+__device__ __forceinline__ void mc_issue_luma(const FrameCtx &f, int lane, int S, int XA, int Y0, int pic, McWindows &Wn)
+{
+	const bool s16 = S == 16, s8 = S == 8;
+	const int nd = s16 ? 6 : s8 ? 4 : 3, per = (S + 5) * nd;       // dwords per row, per window
+	const int lg = s16 ? 6 : s8 ? 4 : 2, nit = s16 ? 2 : s8 ? 4 : 7; // log2(lanes per window), iterations
+	const int inv = s16 ? 171 : s8 ? 256 : 342;                      // rem / nd == rem * inv >> 10 for rem < 128 / 64 / 28
+	const int r0 = lane & ((1 << lg) - 1);
+	if (pic < 0)
+		return;
+	const gu8 *picp = (const gu8 *)f.dpb_lds[pic];
+#define E264_WIN_FETCH(it, dst) \
+	if (it < nit) { \
+		const int rem = (it << lg) + r0; \
+		if (rem < per) { \
+			const int row = (rem * inv) >> 10, dw = rem - row * nd; \
+			const gu8 *rowp = picp + (size_t)clip3i(0, f.H - 1, Y0 + row) * f.sY; \
+			const int x = XA + dw * 4; \
+			if (x >= 0 && x <= f.W - 4) dst = *(const gu32 *)(rowp + x); \
+			else dst = (uint32_t)rowp[x < 0 ? 0 : f.W - 1] * 0x01010101u; /* frame border: replicated edge sample (waits; rare) */ \
+		} \
 	}
+	E264_WIN_FETCH(0, Wn.y0) E264_WIN_FETCH(1, Wn.y1) E264_WIN_FETCH(2, Wn.y2) E264_WIN_FETCH(3, Wn.y3)
+	E264_WIN_FETCH(4, Wn.y4) E264_WIN_FETCH(5, Wn.y5) E264_WIN_FETCH(6, Wn.y6)
+#undef E264_WIN_FETCH
 }
 
-__device__ __forceinline__ void mc_issue(const FrameCtx &f, const McMotion &M, int l, int mbx, int mby, int lane, McWindows &Wn)
+__device__ __forceinline__ void mc_issue(const FrameCtx &f, const McMotion &M, int l, int mbx, int mby, int lane, McWindows &Wn PH_PARAMS)
 {
 	const int cpl = lane >> 5, cy = (lane >> 2) & 7, cx = (lane & 3) * 2;
 	if (M.refs[l] == 0xffffffffu) // list unused by the whole macroblock (uniform): P macroblocks skip list 1
 		return;
 	McGeom G = mc_geom(M, l, lane, mbx, mby);
 	if (!(f.dbg & 256)) {
-		uint32_t t[7] = {0, 0, 0, 0, 0, 0, 0};
-		if (G.S == 16) mc_issue_luma<16, 0, 4>(f, lane, G.X0 & ~3, G.Y0, G.pic, t);
-		else if (G.S == 8) mc_issue_luma<8, 0, 4>(f, lane, G.X0 & ~3, G.Y0, G.pic, t);
-		else mc_issue_luma<4, 0, 7>(f, lane, G.X0 & ~3, G.Y0, G.pic, t);
-		Wn.y0 = t[0]; Wn.y1 = t[1]; Wn.y2 = t[2]; Wn.y3 = t[3]; Wn.y4 = t[4]; Wn.y5 = t[5]; Wn.y6 = t[6];
+		mc_issue_luma(f, lane, G.S, G.X0 & ~3, G.Y0, G.pic, Wn);
 	}
+	PH(11);
 	// chroma: the 3x2 samples around this lane's two outputs (8.4.2.2.2)
 	const int kc = blk_of(cx >> 1, cy >> 1);
 	const int picc = ref_byte(M.refs[l], kc >> 2);
@@ -1047,7 +1067,7 @@ __device__ __forceinline__ void mc_compute(WaveLds &L, const FrameCtx &f, cslice
 
 // stage C of one macroblock of the strip: everything that is not intra prediction
 __device__ __forceinline__ bool mbpar_mb(WaveLds &L, StripOut &O, int slot, const FrameCtx &f, const MbInfo &m, const McMotion &M, const int cc[6], const McWindows &W1,
-	int mbx, int mby, int lane)
+	int mbx, int mby, int lane PH_PARAMS)
 { // returns true when the macroblock's samples were staged in O.y/O.c[slot]
 	if (m.kind != E264_MB_INTER && m.kind != E264_MB_PCM)
 		return false;
@@ -1068,8 +1088,10 @@ __device__ __forceinline__ bool mbpar_mb(WaveLds &L, StripOut &O, int slot, cons
 	const bool has_res = m.coded != 0 && !(f.dbg & 1024); // uniform; most inter macroblocks carry no residual
 #endif
 	if (has_res) compute_residual(L, f, m, lane); // payload already in L.coef (committed at the top of the iteration)
+	PH(5);
 	int pY[4] = {0, 0, 0, 0}, pC[2] = {0, 0};
 	mc_compute(L, f, s, M, 0, cc, mbx, mby, lane, pY, pC); // list 0: window already in LDS (prefetched)
+	PH(6);
 #ifndef E264_ABL_NOL1
 	if (M.refs[1] != 0xffffffffu) { // list 1 (B macroblocks): its windows were prefetched with list 0's; same LDS area, second turn
 		wave_sync();
@@ -1080,6 +1102,7 @@ __device__ __forceinline__ bool mbpar_mb(WaveLds &L, StripOut &O, int slot, cons
 		mc_compute(L, f, s, M, 1, c1, mbx, mby, lane, pY, pC);
 	}
 #endif
+	PH(7);
 	if (has_res) { // add residual, clip (int16 wrap add then packus: residual.c:160-171)
 		const int16_t *rr = L.res + Yr * 16 + X;
 		const int16_t *rc = L.res + 256 + cpl * 64 + cy * 8 + cx;
@@ -1963,19 +1986,28 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 	const int mbx0 = mbx, mby0 = mby;
 	StripOut &O = outs[wave];
 	uint32_t staged = 0;
+	PH_DECL;
 	if (recon && h0.kind == E264_MB_INTER) {
-		mc_issue(f, m0, 0, mbx, mby, lane, w);
+		mc_issue(f, m0, 0, mbx, mby, lane, w PH_ARGS);
 #ifndef E264_ABL_NOL1
-		mc_issue(f, m0, 1, mbx, mby, lane, wb);
+		mc_issue(f, m0, 1, mbx, mby, lane, wb PH_ARGS);
 #endif
 	}
+	PH(0);
 #pragma unroll 1
 	for (int i = 0; i < n; i++) {
 		int nx = mbx + 1, ny = mby;
 		if (nx == f.wm) { nx = 0; ny++; }
 		// every load of the previous iteration is consumed first (the compiler's vmcnt bookkeeping collapses to
 		// vmcnt(0) across these branches: a load issued before this point would be waited for at once) ...
+		// Every load issued one iteration ago is consumed right here, so say so: after an explicit vmcnt(0) the compiler knows
+		// that no load is pending on the prefetch registers.  Without it, it cannot prove that across the back edge and puts
+		// s_waitcnt vmcnt(0) in front of every later (re)initialisation of such a register -- i.e. right AFTER the next
+		// stage's loads have been issued, exposing a full memory round trip twice per macroblock (phase profile: 39% of the
+		// kernel's wave-time sat in those two waits).
+		__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only (expcnt / lgkmcnt unconstrained)
 		if (i + 1 < n) mc_finish(raw, lane, m1);             // motion of macroblock i+1 (loads issued one iteration ago)
+		PH(1);
 		if (recon && (h0.kind == E264_MB_INTER)) {
 			slice_cache(L, f, h0.slice, lane);
 			coef_commit(L, h0, lane, pf);
@@ -1987,25 +2019,34 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 			if (m0.refs[1] != 0xffffffffu) wbc = wb; // list 1 in use (uniform): take over the prefetched registers (they have arrived with list 0's)
 #endif
 		}
+		PH(2);
 		wave_sync();
+		PH(3);
 		// ... then the loads of the next stages go out, with the whole reconstruction of macroblock i to hide them
 		if (i + 2 < n) mc_issue_raw(f, base + i + 2, lane, raw);
+		PH(12);
 		const int i1 = min(i + 1, n - 1);
 		const MbInfo h1 = mb_from_lanes(HV(i1), i1 & 7);
+		PH(13);
 		if (recon && i + 1 < n && h1.kind == E264_MB_INTER) coef_issue(f, h1, lane, pf);
+		PH(10);
 		if (recon && i + 1 < n && h1.kind == E264_MB_INTER) {
-			mc_issue(f, m1, 0, nx, ny, lane, w);
+			mc_issue(f, m1, 0, nx, ny, lane, w PH_ARGS);
 #ifndef E264_ABL_NOL1
-			mc_issue(f, m1, 1, nx, ny, lane, wb);
+			mc_issue(f, m1, 1, nx, ny, lane, wb PH_ARGS);
 #endif
 		}
-		if (recon && mbpar_mb(L, O, i, f, h0, m0, cc, wbc, mbx, mby, lane))
+		PH(4);
+		if (recon && mbpar_mb(L, O, i, f, h0, m0, cc, wbc, mbx, mby, lane PH_ARGS))
 			staged |= 1u << i;
 		wave_sync();
+		PH(8);
 		h0 = h1; m0 = m1;
 		mbx = nx; mby = ny;
 	}
 	strip_flush(O, f, mbx0, mby0, staged, lane);
+	PH(9);
+	PH_FLUSH(lane);
 }
 
 // deblocking parameters (bS, alpha, beta, indexA) of every macroblock: one wave per macroblock, few
@@ -2226,3 +2267,13 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 	if (marks) hipEventRecord(marks[4], stream);
 	return hipGetLastError();
 }
+
+#ifdef E264_PHASE_TIMING
+extern "C" __attribute__((visibility("default"))) int e264_debug_phase_cycles(unsigned long long *out16, int reset)
+{
+	hipDeviceSynchronize();
+	if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase), sizeof(g_phase)) != hipSuccess) return -1;
+	if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return -1; }
+	return 0;
+}
+#endif
