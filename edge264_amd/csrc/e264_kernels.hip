@@ -211,16 +211,18 @@ struct FrameCtx {
 // through e264_debug_phase_cycles).  s_memtime at the phase boundaries drains the LGKM counter, so the numbers are a
 // profile, not a benchmark.
 #ifdef E264_PHASE_TIMING
-__device__ unsigned long long g_phase[16];
+__device__ unsigned long long g_phase[32]; // [0..13] mbpar kernel, [16..29] deblock kernel
 #define PH_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PH(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); ph_acc[k] += t_ - ph_t; ph_t = t_; } while (0)
 #define PH_FLUSH(lane) do { if ((lane) == 0) for (int k_ = 0; k_ < 14; k_++) atomicAdd(&g_phase[k_], ph_acc[k_]); } while (0)
+#define PH_FLUSH_DBK(lane) do { if ((lane) == 0) for (int k_ = 0; k_ < 14; k_++) atomicAdd(&g_phase[16 + k_], ph_acc[k_]); } while (0)
 #define PH_PARAMS , unsigned long long &ph_t, unsigned long long (&ph_acc)[14]
 #define PH_ARGS , ph_t, ph_acc
 #else
 #define PH_DECL
 #define PH(k)
 #define PH_FLUSH(lane)
+#define PH_FLUSH_DBK(lane)
 #define PH_PARAMS
 #define PH_ARGS
 #endif
@@ -1685,6 +1687,9 @@ __device__ __forceinline__ void dbk_load_top(const DbkRing &up, int mbx, int hl,
 // Group g (macroblocks 4g .. 4g+nmb-1) of row mby: staged samples -> frame.
 __device__ __forceinline__ void dbk_flush(const DbkStage &S, const FrameCtx &f, int g, int nmb, int mby, int hl, bool has_top, int nrow, int ncrow)
 {
+	// Runs every 4th step only: its per-lane index arithmetic is kept out of the set of loop invariants (opaque lane
+	// index), where it competed for registers with the per-step code and pushed other invariants into scratch.
+	asm volatile("" : "+v"(hl));
 	gu8 *Yb = f.cur + (size_t)(mby * 16) * f.sY + g * 64;
 #pragma unroll
 	for (int it = 0; it < 3; it++) { // 20 rows x 4 pieces of 16 bytes
@@ -1706,7 +1711,7 @@ __device__ __forceinline__ void dbk_flush(const DbkStage &S, const FrameCtx &f, 
 // Filter the macroblock whose samples are in r, publish its bottom rows in `ring`, store it.
 // S: staging of final samples; self_bottom: this row also writes its rows 12..15 (nobody below takes them from the ring)
 __device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, DbkStage &S, const uint8_t *tc0tab, const FrameCtx &f, int mbx, int mby, int hl,
-	const DbkRegs &r, bool carry, bool last, bool self_bottom)
+	const DbkRegs &r, bool carry, bool last, bool self_bottom PH_PARAMS)
 {
 	const bool has_top = mby > 0;
 	const int pl = hl < 16 ? 0 : hl < 24 ? 1 : 2; // line roles: 0..15 luma, 16..23 Cb, 24..31 Cr
@@ -1733,6 +1738,7 @@ __device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, DbkStage 
 		}
 	}
 	wave_sync();
+	PH(4);
 	int v[20];
 	const int seg = chroma ? li >> 1 : li >> 2;
 	if (r.on) {
@@ -1777,6 +1783,7 @@ __device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, DbkStage 
 		}
 	}
 	wave_sync();
+	PH(5);
 	if (r.on) {
 		// ---- horizontal edges: this lane owns COLUMN li -----------------------------------
 		int bH[4], tH[4];
@@ -1809,6 +1816,7 @@ __device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, DbkStage 
 		}
 	}
 	wave_sync();
+	PH(6);
 	if (!r.act)
 		return;
 	// ---- publish the bottom rows for the row below: this macroblock's columns 0..11 (chroma 0..3)
@@ -1829,6 +1837,7 @@ __device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, DbkStage 
 			else { int j = i - 4; ring.c[j >> 1][j & 1][slot * 2 + 1] = *(const uint32_t *)&L.DCT(j >> 1, 6 + (j & 1), 4); }
 		}
 	}
+	PH(7);
 	// ---- stage what has become final; groups of 4 macroblocks leave as whole 64-byte row pieces ----------
 	const int gxm = mbx & 3;
 	const int nrow = self_bottom ? 16 : 12, ncrow = self_bottom ? 8 : 6;
@@ -2194,6 +2203,7 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 		const bool handoff = wave == NW - 1 && half == 1 && my_y + 1 < f.hm;
 		const bool self_bottom = handoff || my_y == f.hm - 1;
 		DbkRegs cur, nxt;
+		PH_DECL;
 		if (gtop_wave) {
 			while (lds_load_relaxed(&progress[yA - 1]) < min(2, f.wm))
 				__builtin_amdgcn_s_sleep(1);
@@ -2204,6 +2214,7 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 		for (int t = 0; t < f.wm + DBK_LAG; t++) {
 			const int xB = t - DBK_LAG;
 			const int my_x = half ? xB : t;
+			PH(0);
 			if (yA > 0 && t < f.wm) { // the row above must be 2 macroblocks ahead
 				int want = min(t + (gtop_wave ? 3 : 2), f.wm); // wave 0 also prefetches the next macroblock's top rows
 				while (lds_load_relaxed(&progress[yA - 1]) < want)
@@ -2215,11 +2226,15 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 			}
 			if (gtop_wave) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 			else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			PH(1);
 			if (!gtop && my_y > 0)
 				dbk_load_top(upring, my_x, hl, cur);
+			PH(2);
 			const int nx = my_x + 1;
 			dbk_prefetch(f, nx, my_y, hl, row_ok && nx >= 0 && nx < f.wm, gtop, nxt);
-			dbk_process(L.tile[half], myring, L.stage[half], tc0tab, f, my_x, my_y, hl, cur, my_x > 0, my_x == f.wm - 1, self_bottom);
+			PH(3);
+			dbk_process(L.tile[half], myring, L.stage[half], tc0tab, f, my_x, my_y, hl, cur, my_x > 0, my_x == f.wm - 1, self_bottom PH_ARGS);
+			PH(8);
 			// LDS operations of a wave execute in order: the ring is written before the counter.  The last
 			// wave hands its lower row to the next round through global memory: its stores must be visible.
 			if (wave == NW - 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2229,7 +2244,9 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 			if (hl == 0 && cur.act)
 				__hip_atomic_store(&progress[my_y], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			cur = nxt;
+			PH(9);
 		}
+		PH_FLUSH_DBK(lane);
 	}
 }
 
@@ -2269,11 +2286,11 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 }
 
 #ifdef E264_PHASE_TIMING
-extern "C" __attribute__((visibility("default"))) int e264_debug_phase_cycles(unsigned long long *out16, int reset)
+extern "C" __attribute__((visibility("default"))) int e264_debug_phase_cycles(unsigned long long *out32, int reset)
 {
 	hipDeviceSynchronize();
-	if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase), sizeof(g_phase)) != hipSuccess) return -1;
-	if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return -1; }
+	if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_phase), sizeof(g_phase)) != hipSuccess) return -1;
+	if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return -1; }
 	return 0;
 }
 #endif

@@ -13,7 +13,7 @@ sys.path.insert(0, os.getcwd())
 import bench
 r, w = os.pipe()
 bench.main()
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 32)()
 from edge264_amd import backend
 L = backend.load_library()
 L.e264_debug_phase_cycles.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
@@ -24,5 +24,11 @@ names = ["prologue", "top: mc_finish (raw motion)", "top: slice cache + coef/win
 tot = sum(out[:14])
 for n, v in zip(names, out[:14]):
     print(f"{n:70s} {v:16d} {100.0 * v / tot:6.2f}%", file=sys.stderr)
+dn = ["loop top", "wait for the row above / ring back-pressure", "top rows from the ring", "prefetch next macroblock (issue)", "carry + tile fill (consumes the prefetch)",
+      "vertical edges", "horizontal edges", "ring publish", "stage + flush", "fence, progress, cur = nxt (waits for the prefetch)", "-", "-", "-", "-"]
+tot = sum(out[16:30]) or 1
+print("e264_deblock_kernel", file=sys.stderr)
+for n, v in zip(dn, out[16:30]):
+    print(f"{n:70s} {v:16d} {100.0 * v / tot:6.2f}%", file=sys.stderr)
 PY
-cat $OUT/phase.err | grep -v "^$" | tail -14
+cat $OUT/phase.err | grep -v "^$" | tail -30
