@@ -1821,21 +1821,27 @@ __device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, DbkStage 
 		return;
 	// ---- publish the bottom rows for the row below: this macroblock's columns 0..11 (chroma 0..3)
 	// and, now that the left edge has been filtered, the previous macroblock's columns 12..15 (4..7)
-	{
+	{ // branch-free: every lane makes ONE 4-byte copy tile -> ring (source, destination and predicate selected by its role).
+	  // The three-way role branch with its inner cases ran as six serialised divergent paths, each with its own LDS round trip.
 		const int slot = mbx & (DBK_RING - 1), pslot = (mbx - 1) & (DBK_RING - 1);
-		if (hl < 16) {
-			int row = 12 + (hl >> 2), d = hl & 3;
-			if (d == 0) { if (carry) ring.y[hl >> 2][pslot * 4 + 3] = *(const uint32_t *)&L.DYT(row, -4); }
-			else ring.y[hl >> 2][slot * 4 + d - 1] = *(const uint32_t *)&L.DYT(row, (d - 1) * 4);
-		} else if (hl < 24) {
-			int i = hl - 16, pc = i >> 2, rr = (i >> 1) & 1, d = i & 1;
-			if (d == 0) { if (carry) ring.c[pc][rr][pslot * 2 + 1] = *(const uint32_t *)&L.DCT(pc, 6 + rr, -4); }
-			else ring.c[pc][rr][slot * 2] = *(const uint32_t *)&L.DCT(pc, 6 + rr, 0);
-		} else if (last) { // last macroblock of the row: nobody will carry its right columns
-			int i = hl - 24;
-			if (i < 4) ring.y[i][slot * 4 + 3] = *(const uint32_t *)&L.DYT(12 + i, 12);
-			else { int j = i - 4; ring.c[j >> 1][j & 1][slot * 2 + 1] = *(const uint32_t *)&L.DCT(j >> 1, 6 + (j & 1), 4); }
-		}
+		const bool ra = hl < 16, rb = !ra && hl < 24;
+		const int ia = hl & 3, ib = hl - 16, ic = hl - 24, jc = ic - 4;
+		// source: byte offset inside the DbkTile
+		const int srcA = (12 + (hl >> 2) + 4) * DY_STRIDE + 4 + (ia == 0 ? -4 : (ia - 1) * 4);
+		const int srcB = (int)offsetof(DbkTile, dctile) + (ib >> 2) * 12 * DC_STRIDE + (6 + ((ib >> 1) & 1) + 4) * DC_STRIDE + 4 + ((ib & 1) ? 0 : -4);
+		const int srcC = ic < 4 ? (12 + ic + 4) * DY_STRIDE + 4 + 12
+		                        : (int)offsetof(DbkTile, dctile) + (jc >> 1) * 12 * DC_STRIDE + (6 + (jc & 1) + 4) * DC_STRIDE + 4 + 4;
+		// destination: dword index inside the DbkRing (y[4][DBK_RING*4] then c[2][2][DBK_RING*2]) = base + slot * mul
+		const int dstA = (hl >> 2) * DBK_RING * 4 + (ia == 0 ? 3 : ia - 1);
+		const int dstB = 4 * DBK_RING * 4 + ((ib >> 2) * 2 + ((ib >> 1) & 1)) * DBK_RING * 2 + ((ib & 1) ? 0 : 1);
+		const int dstC = ic < 4 ? ic * DBK_RING * 4 + 3 : 4 * DBK_RING * 4 + ((jc >> 1) * 2 + (jc & 1)) * DBK_RING * 2 + 1;
+		const int src = ra ? srcA : rb ? srcB : srcC;
+		const int dst0 = ra ? dstA : rb ? dstB : dstC;
+		const int mul = ra ? 4 : rb ? 2 : (ic < 4 ? 4 : 2);
+		const bool prev = ra ? ia == 0 : rb ? !(ib & 1) : false; // the previous macroblock's last columns (valid once carried)
+		const bool pred = (ra || rb) ? (prev ? carry : true) : last;
+		const uint32_t val = *(const uint32_t *)((const uint8_t *)&L + src);
+		if (pred) ((uint32_t *)&ring)[dst0 + (prev ? pslot : slot) * mul] = val;
 	}
 	PH(7);
 	// ---- stage what has become final; groups of 4 macroblocks leave as whole 64-byte row pieces ----------
