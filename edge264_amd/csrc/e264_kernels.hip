@@ -1640,26 +1640,21 @@ __device__ __forceinline__ void filter_line(int v[20], const int bS[4], int a_ed
 }
 
 // per-lane state of the macroblock a half-wave is about to filter
-struct DbkRegs { uint32_t va0, va1, vc, vp, vt; bool act, hasL, hasT, on, t8; };
+struct DbkRegs { uint32_t va0, va1, vc, vp, vt, hdr; bool act; };
 
 // Loads of macroblock (mbx,mby) that do not depend on the row above.  hl = lane within the half-wave:
-// own luma (2 dwords per lane), own chroma (1), parameters (hl < 16).
+// own luma (2 dwords per lane), own chroma (1), parameters (hl < 16), first header dword (kind, flags).
+// LOADS ONLY: nothing here uses a loaded value (the header used to be decoded here: a memory round trip in the middle
+// of every step) and no register is cleared first (clearing a register that may have a load in flight is a wait too);
+// lanes / cases that do not load keep stale values that dbk_process never looks at (same predicates).
 // gtop: the row above belongs to the previous ROUND of row pairs (last wave -> first wave); that one
 // hand-off goes through global memory (a bounded LDS ring there would close a dependency cycle).
 __device__ __forceinline__ void dbk_prefetch(const FrameCtx &f, int mbx, int mby, int hl, bool act, bool gtop, DbkRegs &r)
 {
 	r.act = act;
-	r.on = r.hasL = r.hasT = r.t8 = false;
-	r.va0 = r.va1 = r.vc = r.vp = r.vt = 0;
 	if (!act)
 		return;
-	cmb_t m = f.mbs + mby * f.wm + mbx;
-	const uint32_t hdr = *(const uint32_t __attribute__((address_space(4))) *)m; // kind, flags, qp0, qp1
-	const uint32_t kind = hdr & 255, flags = hdr >> 8 & 255;
-	r.on = (flags & E264_MBF_DEBLOCK) && kind != E264_MB_ABSENT;
-	r.hasL = r.on && (flags & E264_MBF_EDGE_LEFT);
-	r.hasT = r.on && (flags & E264_MBF_EDGE_TOP);
-	r.t8 = flags & E264_MBF_T8x8;
+	r.hdr = *(const gu32 *)(f.mbs + mby * f.wm + mbx); // kind, flags, qp0, qp1
 	gu8 *Yb = f.cur + (size_t)(mby * 16) * f.sY + mbx * 16;
 	gu8 *Cb0 = plane_base(f, f.cur, 1) + (size_t)(mby * 8) * f.sC + mbx * 8;
 	r.va0 = *(const gu32 *)(Yb + (size_t)(hl >> 2) * f.sY + (hl & 3) * 4);
@@ -1690,20 +1685,32 @@ __device__ __forceinline__ void dbk_flush(const DbkStage &S, const FrameCtx &f, 
 	// Runs every 4th step only: its per-lane index arithmetic is kept out of the set of loop invariants (opaque lane
 	// index), where it competed for registers with the per-step code and pushed other invariants into scratch.
 	asm volatile("" : "+v"(hl));
+	// all LDS reads first (unconditional, clamped indices), then the predicated stores: one LDS round trip instead of five
 	gu8 *Yb = f.cur + (size_t)(mby * 16) * f.sY + g * 64;
+	v4u yv[3], cv[2];
 #pragma unroll
 	for (int it = 0; it < 3; it++) { // 20 rows x 4 pieces of 16 bytes
-		const int idx = it * 32 + hl, row = (idx >> 2) - 4, c = idx & 3;
-		if (idx < 80 && c < nmb && (row < 0 ? has_top : row < nrow))
-			*(gv4u *)(Yb + (ptrdiff_t)row * f.sY + c * 16) = *(const v4u *)&S.y[row + 4][c * 4];
+		const int idx = min(it * 32 + hl, 79);
+		yv[it] = *(const v4u *)&S.y[idx >> 2][(idx & 3) * 4];
 	}
 #pragma unroll
 	for (int it = 0; it < 2; it++) { // 2 planes x 10 rows x 2 pieces of 16 bytes (= 2 macroblocks each)
+		const int idx = min(it * 32 + hl, 39), pc = idx >= 20, rem = idx - pc * 20;
+		cv[it] = *(const v4u *)&S.c[pc][rem >> 1][(rem & 1) * 4];
+	}
+#pragma unroll
+	for (int it = 0; it < 3; it++) {
+		const int idx = it * 32 + hl, row = (idx >> 2) - 4, c = idx & 3;
+		if (idx < 80 && c < nmb && (row < 0 ? has_top : row < nrow))
+			*(gv4u *)(Yb + (ptrdiff_t)row * f.sY + c * 16) = yv[it];
+	}
+#pragma unroll
+	for (int it = 0; it < 2; it++) {
 		const int idx = it * 32 + hl, pc = idx >= 20, rem = idx - pc * 20, row = (rem >> 1) - 2, c = rem & 1;
 		if (idx < 40 && (row < 0 ? has_top : row < ncrow)) {
 			gu8 *dst = plane_base(f, f.cur, 1 + pc) + (ptrdiff_t)(mby * 8 + row) * f.sC + g * 32 + c * 16;
-			if (nmb >= 2 * c + 2) *(gv4u *)dst = *(const v4u *)&S.c[pc][row + 2][c * 4];
-			else if (nmb == 2 * c + 1) *(gv2u *)dst = *(const v2u *)&S.c[pc][row + 2][c * 4];
+			if (nmb >= 2 * c + 2) *(gv4u *)dst = cv[it];
+			else if (nmb == 2 * c + 1) { v2u h = {cv[it].x, cv[it].y}; *(gv2u *)dst = h; }
 		}
 	}
 }
@@ -1714,6 +1721,9 @@ __device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, DbkStage 
 	const DbkRegs &r, bool carry, bool last, bool self_bottom PH_PARAMS)
 {
 	const bool has_top = mby > 0;
+	const uint32_t mkind = r.hdr & 255, mflags = r.hdr >> 8 & 255;
+	const bool r_on = r.act && (mflags & E264_MBF_DEBLOCK) && mkind != E264_MB_ABSENT;
+	const bool r_hasL = r_on && (mflags & E264_MBF_EDGE_LEFT), r_hasT = r_on && (mflags & E264_MBF_EDGE_TOP), r_t8 = mflags & E264_MBF_T8x8;
 	const int pl = hl < 16 ? 0 : hl < 24 ? 1 : 2; // line roles: 0..15 luma, 16..23 Cb, 24..31 Cr
 	const int li = hl < 16 ? hl : (hl & 7);
 	const bool chroma = pl != 0;
@@ -1741,14 +1751,14 @@ __device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, DbkStage 
 	PH(4);
 	int v[20];
 	const int seg = chroma ? li >> 1 : li >> 2;
-	if (r.on) {
+	if (r_on) {
 		// ---- per-lane parameters of the VERTICAL edges crossing this line (those of the horizontal edges are
 		// fetched after the vertical pass: fewer live registers) -------------------------------------------
 		int bV[4], tV[4];
 #pragma unroll
 		for (int e = 0; e < 4; e++) bV[e] = L.prm[e * 4 + seg];
-		if (!r.hasL) bV[0] = 0;
-		if (chroma || r.t8) bV[1] = bV[3] = 0;
+		if (!r_hasL) bV[0] = 0;
+		if (chroma || r_t8) bV[1] = bV[3] = 0;
 		const int a0 = L.prm[32 + pl * 3], a1 = L.prm[32 + pl * 3 + 1];
 		const int b0 = L.prm[41 + pl * 3], b1 = L.prm[41 + pl * 3 + 1];
 		const int i0 = L.prm[50 + pl * 3], i1 = L.prm[50 + pl * 3 + 1];
@@ -1784,13 +1794,13 @@ __device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, DbkStage 
 	}
 	wave_sync();
 	PH(5);
-	if (r.on) {
+	if (r_on) {
 		// ---- horizontal edges: this lane owns COLUMN li -----------------------------------
 		int bH[4], tH[4];
 #pragma unroll
 		for (int e = 0; e < 4; e++) bH[e] = L.prm[16 + e * 4 + seg];
-		if (!r.hasT) bH[0] = 0;
-		if (chroma || r.t8) bH[1] = bH[3] = 0;
+		if (!r_hasT) bH[0] = 0;
+		if (chroma || r_t8) bH[1] = bH[3] = 0;
 		const int a0 = L.prm[32 + pl * 3], a2 = L.prm[32 + pl * 3 + 2];
 		const int b0 = L.prm[41 + pl * 3], b2 = L.prm[41 + pl * 3 + 2];
 		const int i0 = L.prm[50 + pl * 3], i2 = L.prm[50 + pl * 3 + 2];
@@ -1847,27 +1857,48 @@ __device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, DbkStage 
 	// ---- stage what has become final; groups of 4 macroblocks leave as whole 64-byte row pieces ----------
 	const int gxm = mbx & 3;
 	const int nrow = self_bottom ? 16 : 12, ncrow = self_bottom ? 8 : 6;
-	if (carry) { // the left neighbour's last 4 columns (tile columns -4..-1), rows 0..nrow-1
-		if (hl < nrow) S.y[hl + 4][gxm ? gxm * 4 - 1 : 15] = *(const uint32_t *)&L.DYT(hl, -4);
-		else if (hl >= 16 && ((hl - 16) & 7) < ncrow) S.c[(hl - 16) >> 3][((hl - 16) & 7) + 2][gxm ? gxm * 2 - 1 : 7] = *(const uint32_t *)&L.DCT((hl - 16) >> 3, (hl - 16) & 7, -4);
-		if (gxm == 0) { // ... which completes the previous group
+	{ // the left neighbour's last 4 columns (tile columns -4..-1), rows 0..nrow-1: ONE predicated copy per lane
+	  // (lanes 0..15 luma row hl, lanes 16..31 chroma plane (hl-16)>>3 row (hl-16)&7), no divergent paths
+		const bool lu = hl < 16;
+		const int cr = (hl - 16) & 7, cp = (hl - 16) >> 3;
+		const int src = lu ? (hl + 4) * DY_STRIDE : (int)offsetof(DbkTile, dctile) + cp * 12 * DC_STRIDE + (cr + 4) * DC_STRIDE;
+		const uint32_t val = *(const uint32_t *)((const uint8_t *)&L + src);
+		uint32_t *dst = lu ? &S.y[hl + 4][gxm ? gxm * 4 - 1 : 15] : &S.c[cp][cr + 2][gxm ? gxm * 2 - 1 : 7];
+		if (carry && (lu ? hl < nrow : cr < ncrow)) *dst = val;
+		if (carry && gxm == 0) { // ... which completes the previous group
 			wave_sync();
 			dbk_flush(S, f, (mbx >> 2) - 1, 4, mby, hl, has_top, nrow, ncrow);
 		}
 	}
+	PH(10);
 	wave_sync();
+	{ // this macroblock: luma rows -4..15 x 4 dwords, chroma 2 planes x rows -2..7 x 2 dwords.  All LDS reads first
+	  // (unconditional, clamped), then the predicated writes.
+		uint32_t yv[3], cv[2];
 #pragma unroll
-	for (int it = 0; it < 3; it++) { // luma rows -4..15 x 4 dwords of this macroblock
-		const int idx = it * 32 + hl, row = (idx >> 2) - 4, dw = idx & 3;
-		if (idx < 80 && (row < 0 ? has_top : (row < nrow && (dw < 3 || last))))
-			S.y[row + 4][gxm * 4 + dw] = *(const uint32_t *)&L.DYT(row, dw * 4);
-	}
+		for (int it = 0; it < 3; it++) {
+			const int idx = min(it * 32 + hl, 79);
+			yv[it] = *(const uint32_t *)&L.DYT((idx >> 2) - 4, (idx & 3) * 4);
+		}
 #pragma unroll
-	for (int it = 0; it < 2; it++) { // chroma: 2 planes x rows -2..7 x 2 dwords
-		const int idx = it * 32 + hl, pc = idx >= 20, rem = idx - pc * 20, row = (rem >> 1) - 2, dw = rem & 1;
-		if (idx < 40 && (row < 0 ? has_top : (row < ncrow && (dw < 1 || last))))
-			S.c[pc][row + 2][gxm * 2 + dw] = *(const uint32_t *)&L.DCT(pc, row, dw * 4);
+		for (int it = 0; it < 2; it++) {
+			const int idx = min(it * 32 + hl, 39), pc = idx >= 20, rem = idx - pc * 20;
+			cv[it] = *(const uint32_t *)&L.DCT(pc, (rem >> 1) - 2, (rem & 1) * 4);
+		}
+#pragma unroll
+		for (int it = 0; it < 3; it++) {
+			const int idx = it * 32 + hl, row = (idx >> 2) - 4, dw = idx & 3;
+			if (idx < 80 && (row < 0 ? has_top : (row < nrow && (dw < 3 || last))))
+				S.y[row + 4][gxm * 4 + dw] = yv[it];
+		}
+#pragma unroll
+		for (int it = 0; it < 2; it++) {
+			const int idx = it * 32 + hl, pc = idx >= 20, rem = idx - pc * 20, row = (rem >> 1) - 2, dw = rem & 1;
+			if (idx < 40 && (row < 0 ? has_top : (row < ncrow && (dw < 1 || last))))
+				S.c[pc][row + 2][gxm * 2 + dw] = cv[it];
+		}
 	}
+	PH(11);
 	if (last) {
 		wave_sync();
 		dbk_flush(S, f, mbx >> 2, gxm + 1, mby, hl, has_top, nrow, ncrow);
@@ -2208,7 +2239,7 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 		// the lower row of the last wave is read by wave 0 of the next round from memory, not from the ring
 		const bool handoff = wave == NW - 1 && half == 1 && my_y + 1 < f.hm;
 		const bool self_bottom = handoff || my_y == f.hm - 1;
-		DbkRegs cur, nxt;
+		DbkRegs cur = {0, 0, 0, 0, 0, 0, false}, nxt = cur;
 		PH_DECL;
 		if (gtop_wave) {
 			while (lds_load_relaxed(&progress[yA - 1]) < min(2, f.wm))

@@ -25,7 +25,7 @@ tot = sum(out[:14])
 for n, v in zip(names, out[:14]):
     print(f"{n:70s} {v:16d} {100.0 * v / tot:6.2f}%", file=sys.stderr)
 dn = ["loop top", "wait for the row above / ring back-pressure", "top rows from the ring", "prefetch next macroblock (issue)", "carry + tile fill (consumes the prefetch)",
-      "vertical edges", "horizontal edges", "ring publish", "stage + flush", "fence, progress, cur = nxt (waits for the prefetch)", "-", "-", "-", "-"]
+      "vertical edges", "horizontal edges", "ring publish", "flush of the last group (row end)", "fence, progress, cur = nxt (waits for the prefetch)", "stage: carried columns (+ flush of the completed group every 4th step)", "stage: this macroblock", "-", "-"]
 tot = sum(out[16:30]) or 1
 print("e264_deblock_kernel", file=sys.stderr)
 for n, v in zip(dn, out[16:30]):
