@@ -405,6 +405,18 @@ __device__ __forceinline__ void idct8x8_blocks(WaveLds &L, uint32_t coded, const
 	wave_sync();
 }
 
+// LDS copy of the weighting part of E264SliceParams (the three tables are contiguous there), filled by slice_cache when the
+// slice weights anything: select_weights runs in the middle of a macroblock, after the next macroblock's loads have been
+// issued -- a table read from memory at that point waits for all of them.
+struct __attribute__((aligned(4))) SliceW {
+	int16_t explicit_weights[3][64];
+	int8_t explicit_offsets[3][64];
+	uint8_t implicit_weights[32][32];
+	int8_t weighted_bipred_idc, luma_log2_weight_denom, chroma_log2_weight_denom, pad;
+};
+static_assert(offsetof(E264SliceParams, explicit_offsets) == offsetof(E264SliceParams, explicit_weights) + 384 &&
+              offsetof(E264SliceParams, implicit_weights) == offsetof(E264SliceParams, explicit_weights) + 576 &&
+              offsetof(E264SliceParams, explicit_weights) % 4 == 0, "SliceW mirrors a contiguous range of E264SliceParams");
 // Residual inputs without a memory round trip inside the transforms:
 //   coef_issue / coef_commit  the macroblock's payload (<= 816 bytes) as 4 coalesced dword loads per lane, issued
 //                             while something else runs (mbpar: one macroblock ahead; intra: before the wait for the
@@ -445,12 +457,23 @@ __device__ __forceinline__ void coef_commit(WaveLds &L, const MbInfo &m, int lan
 	if (128 + lane < ndw) c[128 + lane] = pf.v2;
 	if (192 + lane < ndw) c[192 + lane] = pf.v3;
 }
-__device__ __forceinline__ void slice_cache(WaveLds &L, const FrameCtx &f, int slice, int lane)
+__device__ __forceinline__ void slice_cache(WaveLds &L, const FrameCtx &f, int slice, int lane, SliceW *W = nullptr)
 {
 	if (__builtin_amdgcn_readfirstlane(L.ws_slice) == slice) // uniform
 		return;
 	cslice_t s = f.slices + slice;
 	wave_sync();
+	if (W && s->weighted_bipred_idc != 0) { // 400 dwords: explicit weights, offsets, implicit weights
+		const gu32 *gw = (const gu32 *)((const gu8 *)s + offsetof(E264SliceParams, explicit_weights));
+#pragma unroll
+		for (int it = 0; it < 7; it++)
+			if (it * 64 + lane < 400) ((uint32_t *)W)[it * 64 + lane] = gw[it * 64 + lane];
+	}
+	if (W && lane == 0) {
+		W->weighted_bipred_idc = s->weighted_bipred_idc;
+		W->luma_log2_weight_denom = s->luma_log2_weight_denom;
+		W->chroma_log2_weight_denom = s->chroma_log2_weight_denom;
+	}
 	const gu32 *g4 = (const gu32 *)((const gu8 *)s + offsetof(E264SliceParams, weightScale4x4));
 	const gu32 *g8 = (const gu32 *)((const gu8 *)s + offsetof(E264SliceParams, weightScale8x8));
 	if (lane < 24) ((uint32_t *)L.ws)[lane] = g4[lane];
@@ -538,7 +561,7 @@ __device__ __forceinline__ int wpred(int q, int p, const Wod &w)
 }
 
 // decode_inter weight selection, edge264_inter.c:1137-1197
-__device__ __forceinline__ void select_weights(cslice_t s, int list, int refIdx, int refIdxX, Wod &wY, Wod &wCb, Wod &wCr)
+__device__ __forceinline__ void select_weights(const SliceW *s, int list, int refIdx, int refIdxX, Wod &wY, Wod &wCb, Wod &wCr)
 {
 	Wod nw = {0, 1, 0, 0};
 	wY = wCb = wCr = nw;
@@ -1012,7 +1035,7 @@ __device__ __forceinline__ void mc_commit(WaveLds &L, const McMotion &M, int l, 
 }
 
 // filters + weights of one list of one macroblock from the LDS window / chroma registers
-__device__ __forceinline__ void mc_compute(WaveLds &L, const FrameCtx &f, cslice_t s, const McMotion &M, int l, const int cc[6],
+__device__ __forceinline__ void mc_compute(WaveLds &L, const FrameCtx &f, const SliceW *s, const McMotion &M, int l, const int cc[6],
 	int mbx, int mby, int lane, int outY[4], int outC[2])
 {
 	const int k = lane >> 2, r = lane & 3;
@@ -1068,7 +1091,7 @@ __device__ __forceinline__ void mc_compute(WaveLds &L, const FrameCtx &f, cslice
 }
 
 // stage C of one macroblock of the strip: everything that is not intra prediction
-__device__ __forceinline__ bool mbpar_mb(WaveLds &L, StripOut &O, int slot, const FrameCtx &f, const MbInfo &m, const McMotion &M, const int cc[6], const McWindows &W1,
+__device__ __forceinline__ bool mbpar_mb(WaveLds &L, const SliceW *s, StripOut &O, int slot, const FrameCtx &f, const MbInfo &m, const McMotion &M, const int cc[6], const McWindows &W1,
 	int mbx, int mby, int lane PH_PARAMS)
 { // returns true when the macroblock's samples were staged in O.y/O.c[slot]
 	if (m.kind != E264_MB_INTER && m.kind != E264_MB_PCM)
@@ -1083,7 +1106,6 @@ __device__ __forceinline__ bool mbpar_mb(WaveLds &L, StripOut &O, int slot, cons
 		*oc = *(const gu16 *)(pl + 256 + cpl * 64 + cy * 8 + cx);
 		return true;
 	}
-	cslice_t s = f.slices + m.slice;
 #ifdef E264_ABL_NORES
 	const bool has_res = false;
 #else
@@ -1962,6 +1984,7 @@ __attribute__((amdgpu_waves_per_eu(E264_MBPAR_WAVES_PER_EU, E264_MBPAR_WAVES_PER
 __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, int mode)
 {
 	__shared__ WaveLds lds[4];
+	__shared__ SliceW slicew[4];
 	__shared__ StripOut outs[4];
 	__shared__ generic_u8p dpbtab[E264_MAX_SLOTS];
 	const int lane = lane_id();
@@ -2055,7 +2078,7 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 		if (i + 1 < n) mc_finish(raw, lane, m1);             // motion of macroblock i+1 (loads issued one iteration ago)
 		PH(1);
 		if (recon && (h0.kind == E264_MB_INTER)) {
-			slice_cache(L, f, h0.slice, lane);
+			slice_cache(L, f, h0.slice, lane, &slicew[wave]);
 			coef_commit(L, h0, lane, pf);
 		}
 		if (recon && h0.kind == E264_MB_INTER && !(mode & 8192)) { // 8192: profiling ablation, windows are loaded but never consumed
@@ -2083,7 +2106,7 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 #endif
 		}
 		PH(4);
-		if (recon && mbpar_mb(L, O, i, f, h0, m0, cc, wbc, mbx, mby, lane PH_ARGS))
+		if (recon && mbpar_mb(L, &slicew[wave], O, i, f, h0, m0, cc, wbc, mbx, mby, lane PH_ARGS))
 			staged |= 1u << i;
 		wave_sync();
 		PH(8);
