@@ -2010,6 +2010,8 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 	const bool recon = mode & 1;
 	// headers of the strip: 8 records x 8 dwords, one dword per lane
 	const gu32 *mbs_g = (const gu32 *)(f.payload - f.h->payload_off + f.h->mbs_off);
+	McRaw raw;
+	mc_issue_raw(f, base, lane, raw); // the first macroblock's motion travels with the headers (its address does not depend on them)
 	uint32_t hvs[E264_MBPAR_STRIP / 8];
 #pragma unroll
 	for (int g = 0; g < E264_MBPAR_STRIP / 8; g++)
@@ -2039,7 +2041,6 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 	//   m1  : finished motion of macroblock i+1 (drives the window loads issued in iteration i)
 	//   w   : reference windows / chroma taps of macroblock i+1, loaded during iteration i, committed to LDS
 	//         (luma) and copied out (chroma taps cc) at the top of iteration i+1
-	McRaw raw;
 	McMotion m0, m1;
 	//   pf  : payload (coefficients) of macroblock i+1, loaded during iteration i, committed to LDS at the top of i+1
 	CoefPf pf = {0, 0, 0, 0};
@@ -2047,7 +2048,6 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 	McWindows w, wb, wbc; // wb: list-1 windows of macroblock i+1 in flight; wbc: those of macroblock i (copied once they arrived)
 	wb.y0 = wb.y1 = wb.y2 = wb.y3 = wb.y4 = wb.y5 = wb.y6 = wb.ca = wb.cb = 0; wbc = wb;
 	int cc[6] = {0, 0, 0, 0, 0, 0};
-	mc_issue_raw(f, base, lane, raw);
 	mc_finish(raw, lane, m0);
 	m1 = m0;
 	if (n > 1) mc_issue_raw(f, base + 1, lane, raw);
