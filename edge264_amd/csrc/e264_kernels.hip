@@ -7,18 +7,27 @@
 //   inter      edge264_inter.c:416-1251     (6-tap luma, bilinear chroma, 5 weighting schemes)
 //   deblock    edge264_deblock.c:927-1123   (bS / alpha / beta / tC0) and :284-895 (filters)
 //
-// Execution model (DESIGN.md "kernels"), three launches per batch of frames:
-//   e264_mbpar_kernel    one wave64 per macroblock, every macroblock of every frame in parallel:
-//                        inter prediction + residual (+ PCM), which depend on nothing inside the
-//                        frame, and the deblocking parameters (bS, alpha, beta, indexA) of EVERY MB.
+// Execution model, four launches per batch of frames (one frame of each of n streams):
+//   e264_dbkparam_kernel one wave64 per 4 macroblocks: deblocking parameters (bS, alpha, beta, indexA) of EVERY
+//                        macroblock from the command packet alone (nothing in the frame is read).
+//   e264_mbpar_kernel    one wave64 per STRIP of E264_MBPAR_STRIP consecutive macroblocks, every strip of every frame
+//                        in parallel: inter prediction + residual (+ PCM), which depend on nothing inside the frame.
+//                        Software pipelined over the strip: motion two macroblocks ahead, reference windows and
+//                        coefficients one ahead; output staged in LDS and written as whole 128-byte rows.
 //   e264_intra_kernel    ONE WORKGROUP PER FRAME, ONE WAVE PER MACROBLOCK ROW: intra MBs only, row y
 //                        may reconstruct macroblock x once row y-1 has finished macroblock x+1.
-//   e264_deblock_kernel  same wavefront, every MB: the 2-MB lag is exactly what H.264 in-loop
-//                        deblocking requires.
+//   e264_deblock_kernel  one workgroup per frame, one HALF-wave per macroblock row, same wavefront over every MB:
+//                        the 2-MB lag is exactly what H.264 in-loop deblocking requires.
 // Progress counters live in LDS, so the hand-off between rows never leaves the CU: no
 // agent-scope fences, no cross-XCD traffic, no placement assumption.  Chip-level parallelism
 // comes from many independent streams (one frame of each per launch), the north-star workload
-// (>=1000 concurrent streams).  Integer / byte work throughout; HBM-bound by design, no MFMA.
+// (>=1000 concurrent streams).  Integer / byte work throughout, no MFMA.
+//
+// Pipeline rule (learnt with the phase profiler, -DE264_PHASE_TIMING / tools/gpu_phase.sh): a stage that ISSUES loads for
+// a later stage must not read, clear or copy any register that may still have a load in flight -- each of those is an
+// s_waitcnt vmcnt(0), i.e. a wait for the loads it has just issued.  Hence: prefetch helpers contain loads only, nothing
+// is zero-initialised in front of a conditional load, one code path fills the pipeline registers, and the place where
+// the prefetches are consumed says so with an explicit vmcnt(0).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/edge264_cmd.h"
