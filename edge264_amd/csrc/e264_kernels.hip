@@ -1187,41 +1187,39 @@ __device__ __forceinline__ void strip_flush(const StripOut &O, const FrameCtx &f
 // Out-of-frame positions are never dereferenced; the remapped modes never use them.
 // In two steps, so that the frame reads are in flight while the residual is computed: issue (loads only, nothing may
 // use the values) and commit (values -> tiles).
-struct IntraNb { uint8_t y, c; };
+struct IntraNb { uint32_t y, c; bool oky, okc; };
+// ONE predicated load per plane group and lane (address and predicate selected by the lane's role), nothing cleared first:
+// the four role branches used to write the same two registers one after the other, which serialised them into two extra
+// memory round trips per intra macroblock (s_waitcnt vmcnt(0) between the loads).
 __device__ __forceinline__ IntraNb issue_intra_neighbours(const FrameCtx &f, int mbx, int mby, int lane)
 {
-	IntraNb n = {0, 0};
+	IntraNb n;
+	const bool left = lane >= 32 && lane < 48;
+	// luma: top row x = -1..23 (lanes 0..24), left column (lanes 32..47)
+	const bool topY = lane < 25;
+	const int x = lane - 1, gx = mbx * 16 + x;
+	n.oky = topY ? (mby > 0 && gx >= 0 && gx < f.W) : (left && mbx > 0);
 	const gu8 *Y = f.cur + (size_t)(mby * 16) * f.sY + mbx * 16;
-	// luma top row x = -1..23 (lanes 0..24), left column (lanes 32..47)
-	if (lane < 25) {
-		int x = lane - 1;
-		int gx = mbx * 16 + x;
-		if (mby > 0 && gx >= 0 && gx < f.W)
-			n.y = Y[x - f.sY];
-	} else if (lane >= 32 && lane < 48) {
-		int y = lane - 32;
-		if (mbx > 0) n.y = Y[(size_t)y * f.sY - 1];
-	}
-	// chroma: top rows of both planes (lanes 0..17), left columns (lanes 32..47)
-	if (lane < 18) {
-		int pl = lane / 9, x = lane % 9 - 1;
-		const gu8 *C = plane_base(f, f.cur, 1 + pl) + (size_t)(mby * 8) * f.sC + mbx * 8;
-		int gx = mbx * 8 + x;
-		if (mby > 0 && gx >= 0)
-			n.c = C[x - f.sC];
-	} else if (lane >= 32 && lane < 48) {
-		int pl = (lane - 32) >> 3, y = lane & 7;
-		const gu8 *C = plane_base(f, f.cur, 1 + pl) + (size_t)(mby * 8) * f.sC + mbx * 8;
-		if (mbx > 0) n.c = C[(size_t)y * f.sC - 1];
-	}
+	const ptrdiff_t offY = topY ? (ptrdiff_t)x - f.sY : (ptrdiff_t)(lane - 32) * f.sY - 1;
+	if (n.oky) n.y = Y[offY];
+	// chroma: top rows of both planes (lanes 0..17: plane lane / 9, x = lane % 9 - 1), left columns (lanes 32..47)
+	const bool topC = lane < 18;
+	const int xc = lane % 9 - 1;
+	const int pl = topC ? lane / 9 : (lane - 32) >> 3;
+	n.okc = topC ? (mby > 0 && mbx * 8 + xc >= 0) : (left && mbx > 0);
+	const gu8 *C = plane_base(f, f.cur, 1 + (pl & 1)) + (size_t)(mby * 8) * f.sC + mbx * 8;
+	const ptrdiff_t offC = topC ? (ptrdiff_t)xc - f.sC : (ptrdiff_t)(lane & 7) * f.sC - 1;
+	if (n.okc) n.c = C[offC];
 	return n;
 }
 __device__ __forceinline__ void commit_intra_neighbours(WaveLds &L, const IntraNb &n, int lane)
-{
-	if (lane < 25) L.YT(-1, lane - 1) = n.y;
-	else if (lane >= 32 && lane < 48) L.YT(lane - 32, -1) = n.y;
-	if (lane < 18) L.CT(lane / 9, -1, lane % 9 - 1) = n.c;
-	else if (lane >= 32 && lane < 48) L.CT((lane - 32) >> 3, lane & 7, -1) = n.c;
+{ // unavailable neighbours read as 0 (never used: the parser resolved the modes against availability)
+	const bool left = lane >= 32 && lane < 48;
+	const uint8_t vy = n.oky ? (uint8_t)n.y : 0, vc = n.okc ? (uint8_t)n.c : 0;
+	if (lane < 25) L.YT(-1, lane - 1) = vy;
+	else if (left) L.YT(lane - 32, -1) = vy;
+	if (lane < 18) L.CT(lane / 9, -1, lane % 9 - 1) = vc;
+	else if (left) L.CT((lane - 32) >> 3, lane & 7, -1) = vc;
 	wave_sync();
 }
 
@@ -1463,7 +1461,8 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const Mb
 		return;
 	}
 	const uint32_t modes_lo = m.modes_lo, modes_hi = m.modes_hi;
-	IntraNb nbv = {0, 0};
+	IntraNb nbv;
+	nbv.oky = nbv.okc = false;
 	if (WHICH != 1 && m.kind != E264_MB_INTER)
 		nbv = issue_intra_neighbours(f, mbx, mby, lane); // in flight during the residual
 	if (!(f.dbg & 1024)) {
