@@ -57,6 +57,7 @@ def main() -> int:
     ap.add_argument("--queues", type=int, default=int(os.environ.get("E264_QUEUES", 1)), help="HIP queues per GPU; streams are split between them so that the wavefront kernels of one group overlap the parallel kernel of another")
     ap.add_argument("--host-packets", action="store_true", help="also time the path that starts from packets in HOST memory "
                     "(e264hip_submit_batch_host: staging copy + H2D + kernels); reported as pcie_inclusive, never as value")
+    ap.add_argument("--side-queue", type=int, default=int(os.environ.get("E264_SIDE_QUEUE", 0)), help="1: deblocking-parameter kernel on a second queue beside the macroblock-parallel kernel")
     ap.add_argument("--debug-mode", type=int, default=0, help="profiling ablation bits (results are then wrong on purpose)")
     args = ap.parse_args()
 
@@ -92,6 +93,7 @@ def main() -> int:
         if args.intra_waves:
             dv.set_option("intra_waves", args.intra_waves)
         dv.set_option("debug_mode", args.debug_mode)
+        dv.set_option("side_queue", args.side_queue)
     dev = devs[0]
     streams, dpk = [], []
     for s in range(args.streams):

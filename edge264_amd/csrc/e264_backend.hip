@@ -41,12 +41,15 @@ struct E264Device {
 	int waves;                 // waves per frame workgroup of the deblocking kernel (2 macroblock rows each)
 	int intra_waves;           // waves per frame workgroup of the intra kernel (1 macroblock row each)
 	int dbg_mode;
+	int side_queue;            // option "side_queue": parameter kernel on a second queue beside the macroblock-parallel kernel
+	hipStream_t q2;
+	hipEvent_t forked, joined;
 	std::mutex lock;           // kernel launches + their timing marks
 	std::mutex batch_lock;     // e264hip_submit_batch_host: job ring
 	hipEvent_t ev[16];
 	// per-launch kernel timing
 	bool ktiming;
-	struct Marks { hipEvent_t e[5]; };
+	struct Marks { hipEvent_t e[5], a[2]; bool side; };
 	std::vector<Marks> kev;
 	size_t kev_used;
 	// job tables of host-packet batches (e264hip_submit_batch_host): a ring of pinned + device buffers
@@ -98,6 +101,11 @@ API int e264hip_device_open(int ordinal, E264Device **out)
 	}
 	for (int i = 0; i < 16; i++)
 		hipEventCreate(&d->ev[i]);
+	d->side_queue = 0; d->q2 = nullptr; d->forked = d->joined = nullptr; // measured: no gain (profiles/r01k_ablation_breakdown.txt), off by default
+	if (hipStreamCreateWithFlags(&d->q2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&d->forked, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&d->joined, hipEventDisableTiming) != hipSuccess) {
+		d->q2 = nullptr; // not fatal: the option then stays off
+	}
 	*out = d;
 	return 0;
 }
@@ -108,7 +116,10 @@ API void e264hip_device_close(E264Device *dev)
 	hipSetDevice(dev->ordinal);
 	hipStreamSynchronize(dev->q);
 	for (int i = 0; i < 16; i++) hipEventDestroy(dev->ev[i]);
-	for (auto &p : dev->kev) for (int i = 0; i < 5; i++) hipEventDestroy(p.e[i]);
+	for (auto &p : dev->kev) { for (int i = 0; i < 5; i++) hipEventDestroy(p.e[i]); for (int i = 0; i < 2; i++) hipEventDestroy(p.a[i]); }
+	if (dev->q2) { hipStreamSynchronize(dev->q2); hipStreamDestroy(dev->q2); }
+	if (dev->forked) hipEventDestroy(dev->forked);
+	if (dev->joined) hipEventDestroy(dev->joined);
 	for (auto &jr : dev->jring) {
 		if (jr.h) hipHostFree(jr.h);
 		if (jr.d) hipFree(jr.d);
@@ -123,6 +134,7 @@ API int e264hip_device_sync(E264Device *dev)
 	if (!dev) return fail(EINVAL, "null device");
 	if (set_device(dev)) return EIO;
 	HIPCHK(hipStreamSynchronize(dev->q), EIO);
+	if (dev->q2) HIPCHK(hipStreamSynchronize(dev->q2), EIO);
 	return 0;
 }
 
@@ -132,6 +144,11 @@ API int e264hip_set_option(E264Device *dev, const char *name, int value)
 	if (!strcmp(name, "debug_mode")) { // profiling ablation bits OR-ed into the kernels' mode argument
 		int prev = dev->dbg_mode;
 		dev->dbg_mode = value;
+		return prev;
+	}
+	if (!strcmp(name, "side_queue")) {
+		int prev = dev->side_queue;
+		dev->side_queue = value && dev->q2;
 		return prev;
 	}
 	if (!strcmp(name, "intra_waves")) {
@@ -316,15 +333,19 @@ static int launch(E264Device *dev, const E264Job *d_jobs, int n, int max_mbs, in
 {
 	std::lock_guard<std::mutex> g(dev->lock);
 	hipEvent_t *marks = nullptr;
+	E264Fork fork = {dev->side_queue ? dev->q2 : nullptr, dev->forked, dev->joined, nullptr};
 	if (dev->ktiming) {
 		if (dev->kev_used == dev->kev.size()) {
 			E264Device::Marks m;
 			for (int i = 0; i < 5; i++) hipEventCreate(&m.e[i]);
+			for (int i = 0; i < 2; i++) hipEventCreate(&m.a[i]);
 			dev->kev.push_back(m);
 		}
-		marks = dev->kev[dev->kev_used++].e;
+		E264Device::Marks &m = dev->kev[dev->kev_used++];
+		m.side = fork.aux != nullptr && (mode & 2) && !((mode | dev->dbg_mode) & 2048);
+		marks = m.e; fork.amarks = m.a;
 	}
-	HIPCHK(e264_launch_frames(d_jobs, n, max_mbs, mode | dev->dbg_mode, dev->waves | dev->intra_waves << 8, dev->q, marks), EIO);
+	HIPCHK(e264_launch_frames(d_jobs, n, max_mbs, mode | dev->dbg_mode, dev->waves | dev->intra_waves << 8, dev->q, marks, &fork), EIO);
 	return 0;
 }
 
@@ -575,7 +596,9 @@ API int e264hip_kernel_time_ms(E264Device *dev, double *ms4, int *launches)
 	for (size_t i = 0; i < dev->kev_used; i++)
 		for (int k = 0; k < 4; k++) {
 			float ms = 0;
-			if (hipEventElapsedTime(&ms, dev->kev[i].e[k], dev->kev[i].e[k + 1]) == hipSuccess) ms4[k] += ms;
+			const E264Device::Marks &m = dev->kev[i];
+			const bool side = k == 0 && m.side; // the parameter kernel ran on the second queue: its own pair of events
+			if (hipEventElapsedTime(&ms, side ? m.a[0] : m.e[k], side ? m.a[1] : m.e[k + 1]) == hipSuccess) ms4[k] += ms;
 		}
 	if (launches) *launches = (int)dev->kev_used;
 	return 0;

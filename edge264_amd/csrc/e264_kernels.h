@@ -15,6 +15,10 @@ struct E264Job {
 
 // mode: bit0 reconstruction, bit1 deblocking.  waves: 4, 8 or 16 macroblock rows in flight per frame.
 // max_mbs: largest macroblock count among the jobs.  marks: NULL or 5 events (boundaries of the 4 kernels).
-extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int max_mbs, int mode, int waves, hipStream_t stream, hipEvent_t *marks);
+// fork: NULL, or a second queue + events on which the parameter kernel runs beside the macroblock-parallel kernel
+// (amarks: 2 events bracketing it there, recorded when marks != NULL).
+struct E264Fork { hipStream_t aux; hipEvent_t forked, joined; hipEvent_t *amarks; };
+extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int max_mbs, int mode, int waves, hipStream_t stream, hipEvent_t *marks,
+	const E264Fork *fork);
 
 #endif

@@ -2318,13 +2318,27 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 	}
 }
 
-extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int max_mbs, int mode, int waves, hipStream_t stream, hipEvent_t *marks)
+extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int max_mbs, int mode, int waves, hipStream_t stream, hipEvent_t *marks,
+	const E264Fork *fork)
 {
 	if (n_jobs <= 0)
 		return hipSuccess;
 	// marks (optional): 5 events recorded before / between / after the four launches
 	if (marks) hipEventRecord(marks[0], stream);
-	if ((mode & 2) && !(mode & 2048))
+	const bool dbkp = (mode & 2) && !(mode & 2048);
+	// fork (optional): the parameter kernel reads nothing but the packet and is needed only by the deblocking kernel, so it
+	// runs on a second queue NEXT TO the macroblock-parallel kernel -- 28 VGPRs per wave, its waves fit beside the two
+	// 215-VGPR waves per SIMD and use issue slots those leave idle.  Ordered after everything enqueued before (the packet
+	// copies, the previous batch's deblocking that still reads the parameter buffer) by `forked`, before deblocking by `joined`.
+	const bool side = dbkp && fork && fork->aux;
+	if (side) {
+		hipEventRecord(fork->forked, stream);
+		hipStreamWaitEvent(fork->aux, fork->forked, 0);
+		if (marks) hipEventRecord(fork->amarks[0], fork->aux);
+		hipLaunchKernelGGL(e264_dbkparam_kernel, dim3((max_mbs + 15) / 16, n_jobs), dim3(256), 0, fork->aux, jobs);
+		if (marks) hipEventRecord(fork->amarks[1], fork->aux);
+		hipEventRecord(fork->joined, fork->aux);
+	} else if (dbkp)
 		hipLaunchKernelGGL(e264_dbkparam_kernel, dim3((max_mbs + 15) / 16, n_jobs), dim3(256), 0, stream, jobs);
 	if (marks) hipEventRecord(marks[1], stream);
 	hipLaunchKernelGGL(e264_mbpar_kernel, dim3((max_mbs + 4 * E264_MBPAR_STRIP - 1) / (4 * E264_MBPAR_STRIP), n_jobs), dim3(256), 0, stream, jobs, mode);
@@ -2339,6 +2353,7 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 		}
 	}
 	if (marks) hipEventRecord(marks[3], stream);
+	if (side) hipStreamWaitEvent(stream, fork->joined, 0);
 	if (mode & 2) {
 		switch (waves) {
 		case 9: hipLaunchKernelGGL(e264_deblock_kernel<9>, dim3(n_jobs), dim3(576), 0, stream, jobs); break;

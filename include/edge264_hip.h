@@ -106,7 +106,9 @@ int  e264hip_event_elapsed_ms(E264Device *dev, int idx_start, int idx_stop, floa
 int  e264hip_kernel_timing(E264Device *dev, int enable);
 int  e264hip_kernel_time_ms(E264Device *dev, double *ms4, int *launches);
 
-/* Tunables (waves per frame workgroup etc.); returns the previous value, -1 if unknown. */
+/* Tunables; returns the previous value, -1 if unknown: "waves" / "intra_waves" (waves per frame workgroup of the two
+ * wavefront kernels), "side_queue" (1 = the deblock-parameter kernel runs on a second HIP queue beside the parallel MB
+ * kernel; its ms4[0] is then measured on that queue), "debug_mode" (profiling ablations: wrong output on purpose). */
 int  e264hip_set_option(E264Device *dev, const char *name, int value);
 
 #ifdef __cplusplus
