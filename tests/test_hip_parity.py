@@ -140,6 +140,12 @@ def test_1080p_ipb(device, oracle):
     run_stream(device, oracle, 21, "IPB", dict(t8x8=True, weighted=1, i_kinds=ALL_I), 120, 68, passes_split=False)
 
 
+def test_max_frame_size(device, oracle):
+    """Level 5.1/5.2 maximum picture (4096 x 2304 = 256 x 144 macroblocks, 36 864 MBs): four 64-macroblock scan
+    chunks per row in the intra kernel, 6 rounds of row pairs in the deblocking kernel, 32-bit offsets into a 14 MB plane."""
+    run_stream(device, oracle, 31, "IPB", dict(t8x8=True, i_kinds=ALL_I), 256, 144, passes_split=False)
+
+
 @pytest.mark.parametrize("waves", [4, 8, 9, 10, 12, 16])
 def test_waves_per_frame(device, oracle, waves):
     """Frames wider than the LDS hand-off ring and taller than one round of row pairs
