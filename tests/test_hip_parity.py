@@ -140,6 +140,43 @@ def test_1080p_ipb(device, oracle):
     run_stream(device, oracle, 21, "IPB", dict(t8x8=True, weighted=1, i_kinds=ALL_I), 120, 68, passes_split=False)
 
 
+def test_missing_macroblocks(device, oracle):
+    """Packets of incomplete pictures (a lost slice leaves its macroblocks E264_MB_ABSENT, include/edge264_cmd.h): absent
+    macroblocks are not written by any kernel and not deblocked, their neighbours still are; a picture with nothing
+    in it leaves the slot untouched."""
+    w, h = 9, 6
+    nb = P.frame_bytes(w, h)
+    for seed, pattern in ((41, "IPB"), (42, "IPP")):
+        s = synth.StreamSynth(w, h, seed, t8x8=True, i_kinds=ALL_I)
+        rng = np.random.default_rng(seed)
+        dpb = [rng.integers(0, 256, nb + 16, dtype=np.uint8) for _ in range(6)] + [None] * 26
+        st = __import__("edge264_amd.backend", fromlist=["Stream"]).Stream(device, w, h)
+        try:
+            for i in range(6):
+                st.alloc(i)
+                st.upload(i, dpb[i][:nb])
+            for i, t in enumerate(pattern):
+                buf = bytearray(s.next_frame(t))
+                pk = P.Packet(buf)
+                mbs = np.frombuffer(buf, P.MB, w * h, int(pk.hdr["mbs_off"]))
+                if i == len(pattern) - 1:
+                    mbs["kind"][:] = P.MB_ABSENT          # nothing arrived
+                else:
+                    a = int(rng.integers(0, w * h - 8))
+                    mbs["kind"][a:a + int(rng.integers(3, 2 * w))] = P.MB_ABSENT  # a lost slice
+                pkt = bytes(buf)
+                d = int(pk.hdr["dst_slot"])
+                before = dpb[d].copy()
+                oracle.decode_frame(pkt, dpb, 3)
+                st.submit(pkt)
+                got = st.download(d)
+                assert np.array_equal(got, dpb[d][:nb]), f"seed {seed} frame {i}{t}: " + describe_mismatch(pk, got, dpb[d][:nb], w, h)
+                if i == len(pattern) - 1:
+                    assert np.array_equal(got, before[:nb])
+        finally:
+            st.close()
+
+
 def test_max_frame_size(device, oracle):
     """Level 5.1/5.2 maximum picture (4096 x 2304 = 256 x 144 macroblocks, 36 864 MBs): four 64-macroblock scan
     chunks per row in the intra kernel, 6 rounds of row pairs in the deblocking kernel, 32-bit offsets into a 14 MB plane."""
