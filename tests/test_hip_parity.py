@@ -22,6 +22,9 @@ CASES = [
     ("ibbp_implicit_wp", "IPBBPBB", dict(weighted=2, t8x8=True, scaling=True)),
     ("slices_idc2", "IPBBP", dict(slices_per_frame=4, deblock_idc=2)),
     ("slices_idc0", "IPBBP", dict(slices_per_frame=4, deblock_idc=0)),
+    # every slice with its own scaling lists and weight tables: the per-wave LDS slice cache is reloaded inside a strip
+    ("slices_scaling_explicit", "IPBBP", dict(slices_per_frame=6, weighted=1, scaling=True, t8x8=True, i_kinds=ALL_I)),
+    ("slices_scaling_implicit", "IPBBP", dict(slices_per_frame=6, weighted=2, scaling=True, t8x8=True, i_kinds=ALL_I)),
     ("filter_offsets", "IPB", dict(filter_offsets=(6, -4))),
     ("no_deblock", "IPB", dict(deblock=False)),
     ("stress_explicit", "IPBBP", dict(stress=True, weighted=1, t8x8=True, scaling=True, i_kinds=ALL_I)),
