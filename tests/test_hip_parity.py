@@ -59,10 +59,11 @@ def run_stream(device, oracle, seed, pattern, kw, w, h, passes_split=True):
     s = synth.StreamSynth(w, h, seed, **kw)
     nb = P.frame_bytes(w, h)
     rng = np.random.default_rng(seed + 1000)
-    dpb = [rng.integers(0, 256, nb + 16, dtype=np.uint8) for _ in range(6)] + [None] * 26
+    ns = kw.get("n_slots", 6)
+    dpb = [rng.integers(0, 256, nb + 16, dtype=np.uint8) for _ in range(ns)] + [None] * (32 - ns)
     st = backend.Stream(device, w, h)
     try:
-        for i in range(6):
+        for i in range(ns):
             st.alloc(i)
             st.upload(i, dpb[i][:nb])
         for i, t in enumerate(pattern):
@@ -141,6 +142,13 @@ def test_padded_strides(device, oracle):
 def test_1080p_ipb(device, oracle):
     """BASELINE geometry (120 x 68 macroblocks) with B frames, 8x8 transform and weighted prediction."""
     run_stream(device, oracle, 21, "IPB", dict(t8x8=True, weighted=1, i_kinds=ALL_I), 120, 68, passes_split=False)
+
+
+def test_many_references(device, oracle):
+    """16 reference pictures per list, 17 DPB slots in use: reference indices up to 15 into the explicit / implicit weight
+    tables ([LX * 32 + refIdx], [refIdxL0][refIdxL1]) and the slot table."""
+    run_stream(device, oracle, 51, "IPPPPPPPPPPPPPPPPBPB", dict(num_refs=16, n_slots=17, weighted=1, i_kinds=ALL_I, t8x8=True), 5, 4, passes_split=False)
+    run_stream(device, oracle, 52, "IPPPPPPPPPPPPPPPPBPB", dict(num_refs=16, n_slots=17, weighted=2), 5, 4, passes_split=False)
 
 
 def test_missing_macroblocks(device, oracle):
