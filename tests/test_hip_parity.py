@@ -144,6 +144,13 @@ def test_1080p_ipb(device, oracle):
     run_stream(device, oracle, 21, "IPB", dict(t8x8=True, weighted=1, i_kinds=ALL_I), 120, 68, passes_split=False)
 
 
+def test_qp_range(device, oracle):
+    """Every qP % 6 / qP / 6 combination of the dequantisers (normAdjust is arithmetic on immediates in the kernels), both
+    transforms, custom scaling lists, and the alpha / beta / tC0 table ends of the deblocking filter."""
+    for qp in range(0, 52, 3):
+        run_stream(device, oracle, 60 + qp, "IPB", dict(qp_base=qp, t8x8=True, scaling=True, i_kinds=ALL_I, residual_prob=0.8), 4, 3, passes_split=False)
+
+
 def test_many_references(device, oracle):
     """16 reference pictures per list, 17 DPB slots in use: reference indices up to 15 into the explicit / implicit weight
     tables ([LX * 32 + refIdx], [refIdxL0][refIdxL1]) and the slot table."""
