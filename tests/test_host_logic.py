@@ -146,3 +146,29 @@ def test_two_rank_sharded_run_gloo(tmp_path):
             orc.decode_frame(p, dpb, 3)
         last = int(P.Packet(pk[-1]).hdr["dst_slot"])
         assert res["digests"][str(sid)] == hashlib.md5(dpb[last][:nb].tobytes()).hexdigest()
+
+
+def test_committed_bench_line_obeys_the_contract():
+    """profiles/r01k_bench_default.json is the stdout of `python bench.py` on the MI355X: the one JSON line the driver parses."""
+    import json
+    path = os.path.join(ROOT, "profiles", "r01k_bench_default.json")
+    lines = [l for l in open(path).read().splitlines() if l.strip()]
+    assert len(lines) == 1, "bench.py prints exactly ONE JSON line on stdout"
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == base["metric"] and d["unit"] == "frames/s" and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "u8" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and (r["traffic"] is None or r["traffic"] > 0)
+    # achieved = algorithmic bytes per launch / average launch duration of the dominant kernel
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1.0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["bit_exact"] is True
+    # whole-job throughput: frames of all streams / wall time
+    assert abs(d["value"] - d["config"]["frames_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
