@@ -173,7 +173,7 @@ def main() -> int:
 
     # ---- CPU baseline: reference SIMD kernels on one core, bounded sample ------------------
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N=1 only (the contract); at N>1 the field is null
         try:
             from oracle.pyoracle import RefKernels
             rk = RefKernels()
