@@ -38,7 +38,8 @@ def run_stream(oracle, refkernels, seed, pattern, kw, w=W, h=H):
     s = synth.StreamSynth(w, h, seed, **kw)
     nb = P.frame_bytes(w, h) + 16
     rng = np.random.default_rng(seed + 1000)
-    dpb_o = [rng.integers(0, 256, nb, dtype=np.uint8) for _ in range(6)] + [None] * 26
+    ns = kw.get("n_slots", 6)
+    dpb_o = [rng.integers(0, 256, nb, dtype=np.uint8) for _ in range(ns)] + [None] * (32 - ns)
     dpb_r = [a.copy() if a is not None else None for a in dpb_o]
     for i, t in enumerate(pattern):
         pkt = s.next_frame(t)
@@ -53,6 +54,33 @@ def run_stream(oracle, refkernels, seed, pattern, kw, w=W, h=H):
 def test_oracle_matches_reference_kernels(oracle, refkernels, name, pattern, kw):
     for seed in range(4):
         run_stream(oracle, refkernels, seed, pattern, kw)
+
+
+def test_qp_range(oracle, refkernels):
+    """The oracle against the reference kernels over the whole QP range (every qP % 6 / qP / 6 dequantiser case of both
+    transforms with custom scaling lists, both ends of the alpha / beta / tC0 tables): the GPU test of the same name
+    compares the kernels with the oracle."""
+    for qp in range(0, 52, 3):
+        run_stream(oracle, refkernels, 60 + qp, "IPB", dict(qp_base=qp, t8x8=True, scaling=True, i_kinds=ALL_I, residual_prob=0.8), 4, 3)
+
+
+def test_many_references(oracle, refkernels):
+    """16 references per list (17 slots), explicit and implicit weights indexed up to refIdx 15."""
+    run_stream(oracle, refkernels, 51, "IPPPPPPPPPPPPPPPPBPB", dict(num_refs=16, n_slots=17, weighted=1, i_kinds=ALL_I, t8x8=True), 5, 4)
+    run_stream(oracle, refkernels, 52, "IPPPPPPPPPPPPPPPPBPB", dict(num_refs=16, n_slots=17, weighted=2), 5, 4)
+
+
+def test_per_slice_tables(oracle, refkernels):
+    """Six slices per picture, each with its own scaling lists and weight tables."""
+    for seed in range(3):
+        run_stream(oracle, refkernels, seed, "IPBBP", dict(slices_per_frame=6, weighted=1, scaling=True, t8x8=True, i_kinds=ALL_I))
+        run_stream(oracle, refkernels, seed, "IPBBP", dict(slices_per_frame=6, weighted=2, scaling=True, t8x8=True, i_kinds=ALL_I))
+
+
+def test_max_frame_size(oracle, refkernels):
+    """4096 x 2304 (256 x 144 macroblocks, the level 5.1/5.2 maximum; padded chroma stride): oracle vs reference kernels;
+    the GPU test of the same name compares the kernels with the oracle on the same picture size."""
+    run_stream(oracle, refkernels, 31, "IP", dict(t8x8=True, i_kinds=ALL_I), 256, 144)
 
 
 def test_odd_geometry(oracle, refkernels):
