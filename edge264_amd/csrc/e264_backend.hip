@@ -32,7 +32,7 @@ struct E264Packet {
 	uint8_t *d_bytes;
 	size_t bytes;
 	int dst_slot;
-	int n_mbs;
+	int n_mbs, n_tiles;
 };
 
 struct E264Device {
@@ -259,7 +259,8 @@ API int e264hip_frame_upload(E264Stream *s, int slot, const void *src, size_t by
 	return 0;
 }
 
-static int check_packet(const void *packet, size_t bytes, int *dst, int *n_mbs)
+// tiles: workgroups e264_pred_kernel needs for this frame (16 x 8 macroblocks each)
+static int check_packet(const void *packet, size_t bytes, int *dst, int *n_mbs, int *tiles = nullptr)
 {
 	const E264FrameHdr *h = (const E264FrameHdr *)packet;
 	if (!packet || bytes < sizeof(*h) || h->magic != E264_MAGIC || h->version != E264_VERSION || h->total_bytes > bytes)
@@ -271,6 +272,7 @@ static int check_packet(const void *packet, size_t bytes, int *dst, int *n_mbs)
 	if (need > h->payload_off || (size_t)h->payload_off + h->payload_bytes > h->total_bytes) return fail(EINVAL, "packet layout");
 	*dst = h->dst_slot;
 	*n_mbs = (int)h->width_mbs * h->height_mbs;
+	if (tiles) *tiles = ((h->width_mbs + 15) / 16) * ((h->height_mbs + 7) / 8);
 	return 0;
 }
 
@@ -329,7 +331,7 @@ static int ensure_dbk(E264Stream *s, int n_mbs)
 }
 
 // Launches the kernels over a job table that already lives in HBM.
-static int launch(E264Device *dev, const E264Job *d_jobs, int n, int max_mbs, int mode)
+static int launch(E264Device *dev, const E264Job *d_jobs, int n, int max_mbs, int max_tiles, int mode)
 {
 	std::lock_guard<std::mutex> g(dev->lock);
 	hipEvent_t *marks = nullptr;
@@ -345,7 +347,7 @@ static int launch(E264Device *dev, const E264Job *d_jobs, int n, int max_mbs, in
 		m.side = fork.aux != nullptr && (mode & 2) && !((mode | dev->dbg_mode) & 2048);
 		marks = m.e; fork.amarks = m.a;
 	}
-	HIPCHK(e264_launch_frames(d_jobs, n, max_mbs, mode | dev->dbg_mode, dev->waves | dev->intra_waves << 8, dev->q, marks, &fork), EIO);
+	HIPCHK(e264_launch_frames(d_jobs, n, max_mbs, max_tiles, mode | dev->dbg_mode, dev->waves | dev->intra_waves << 8, dev->q, marks, &fork), EIO);
 	return 0;
 }
 
@@ -371,7 +373,7 @@ API void *e264hip_packet_buffer(E264Stream *s, size_t max_bytes)
 API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
 {
 	if (!s) return fail(EINVAL, "null stream");
-	int dst, n_mbs, r = check_packet(packet, bytes, &dst, &n_mbs);
+	int dst, n_mbs, n_tiles, r = check_packet(packet, bytes, &dst, &n_mbs, &n_tiles);
 	if (r) return r;
 	if (!s->h_table[dst]) return fail(EINVAL, "destination slot not allocated");
 	if ((r = check_packet_deep(packet, bytes, s->h_table))) return r;
@@ -391,7 +393,7 @@ API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
 	E264Job *job = (E264Job *)((uint8_t *)st->h + st->cap); // pinned, lives as long as the staging slot
 	job->packet = st->d; job->dpb = s->d_table; job->dbk = s->d_dbk;
 	HIPCHK(hipMemcpyAsync(st->d_job, job, sizeof(*job), hipMemcpyHostToDevice, s->dev->q), EIO);
-	r = launch(s->dev, st->d_job, 1, n_mbs, E264_RUN_ALL);
+	r = launch(s->dev, st->d_job, 1, n_mbs, n_tiles, E264_RUN_ALL);
 	if (r) return r;
 	hipEventRecord(st->done, s->dev->q);
 	st->busy = true;
@@ -420,13 +422,13 @@ API int e264hip_frame_download(E264Stream *s, int slot, void *dst, size_t bytes)
 API int e264hip_packet_upload(E264Device *dev, const void *packet, size_t bytes, E264Packet **out)
 {
 	if (!dev || !out) return fail(EINVAL, "null argument");
-	int dst, n_mbs, r = check_packet(packet, bytes, &dst, &n_mbs);
+	int dst, n_mbs, n_tiles, r = check_packet(packet, bytes, &dst, &n_mbs, &n_tiles);
 	if (r) return r;
 	if ((r = check_packet_deep(packet, bytes, nullptr))) return r;
 	if (set_device(dev)) return EIO;
 	E264Packet *p = new (std::nothrow) E264Packet();
 	if (!p) return fail(ENOMEM, "packet object");
-	p->dev = dev; p->bytes = bytes; p->dst_slot = dst; p->n_mbs = n_mbs;
+	p->dev = dev; p->bytes = bytes; p->dst_slot = dst; p->n_mbs = n_mbs; p->n_tiles = n_tiles;
 	if (hipMalloc((void **)&p->d_bytes, bytes) != hipSuccess) { delete p; return fail(ENOMEM, "hipMalloc packet"); }
 	hipError_t e = hipMemcpy(p->d_bytes, packet, bytes, hipMemcpyHostToDevice);
 	if (e != hipSuccess) { hipFree(p->d_bytes); delete p; return fail(EIO, "hipMemcpy packet", e); }
@@ -446,7 +448,7 @@ API void e264hip_packet_free(E264Packet *p)
 struct E264Batch {
 	E264Device *dev;
 	E264Job *d_jobs;
-	int n, max_mbs;
+	int n, max_mbs, max_tiles;
 };
 
 API int e264hip_batch_create(E264Device *dev, E264Stream *const *streams, E264Packet *const *packets, int n, E264Batch **out)
@@ -454,7 +456,7 @@ API int e264hip_batch_create(E264Device *dev, E264Stream *const *streams, E264Pa
 	if (!dev || !streams || !packets || !out || n <= 0) return fail(EINVAL, "batch_create arguments");
 	if (set_device(dev)) return EIO;
 	std::vector<E264Job> jobs((size_t)n);
-	int max_mbs = 0;
+	int max_mbs = 0, max_tiles = 0;
 	for (int i = 0; i < n; i++) {
 		if (!streams[i] || !packets[i] || streams[i]->dev != dev || packets[i]->dev != dev) return fail(EINVAL, "batch entry");
 		if (!streams[i]->h_table[packets[i]->dst_slot]) return fail(EINVAL, "destination slot not allocated");
@@ -464,10 +466,11 @@ API int e264hip_batch_create(E264Device *dev, E264Stream *const *streams, E264Pa
 		jobs[i].dpb = streams[i]->d_table;
 		jobs[i].dbk = streams[i]->d_dbk;
 		if (packets[i]->n_mbs > max_mbs) max_mbs = packets[i]->n_mbs;
+		if (packets[i]->n_tiles > max_tiles) max_tiles = packets[i]->n_tiles;
 	}
 	E264Batch *b = new (std::nothrow) E264Batch();
 	if (!b) return fail(ENOMEM, "batch object");
-	b->dev = dev; b->n = n; b->max_mbs = max_mbs;
+	b->dev = dev; b->n = n; b->max_mbs = max_mbs; b->max_tiles = max_tiles;
 	if (hipMalloc((void **)&b->d_jobs, sizeof(E264Job) * n) != hipSuccess) { delete b; return fail(ENOMEM, "hipMalloc jobs"); }
 	hipError_t e = hipMemcpy(b->d_jobs, jobs.data(), sizeof(E264Job) * n, hipMemcpyHostToDevice);
 	if (e != hipSuccess) { hipFree(b->d_jobs); delete b; return fail(EIO, "hipMemcpy jobs", e); }
@@ -479,7 +482,7 @@ API int e264hip_batch_submit(E264Batch *b, int mode)
 {
 	if (!b) return fail(EINVAL, "null batch");
 	if (set_device(b->dev)) return EIO;
-	return launch(b->dev, b->d_jobs, b->n, b->max_mbs, mode);
+	return launch(b->dev, b->d_jobs, b->n, b->max_mbs, b->max_tiles, mode);
 }
 
 API void e264hip_batch_free(E264Batch *b)
@@ -508,13 +511,13 @@ API int e264hip_submit_batch_host(E264Device *dev, E264Stream *const *streams, c
 {
 	if (!dev || !streams || !packets || !bytes || n <= 0) return fail(EINVAL, "submit_batch_host arguments");
 	if (set_device(dev)) return EIO;
-	std::vector<int> mbs_of((size_t)n);
+	std::vector<int> mbs_of((size_t)n), tiles_of((size_t)n);
 	for (int i = 0; i < n; i++) { // validate the whole batch before the first side effect
 		E264Stream *s = streams[i];
 		if (!s || s->dev != dev) return fail(EINVAL, "batch entry");
 		for (int j = 0; j < i; j++)
 			if (streams[j] == s) return fail(EINVAL, "a stream may contribute one frame per batch");
-		int dst, r = check_packet(packets[i], bytes[i], &dst, &mbs_of[i]);
+		int dst, r = check_packet(packets[i], bytes[i], &dst, &mbs_of[i], &tiles_of[i]);
 		if (r) return r;
 		if (!s->h_table[dst]) return fail(EINVAL, "destination slot not allocated");
 		if ((r = check_packet_deep(packets[i], bytes[i], s->h_table))) return r;
@@ -533,10 +536,11 @@ API int e264hip_submit_batch_host(E264Device *dev, E264Stream *const *streams, c
 		jr.cap = cap;
 		if (!jr.done) hipEventCreateWithFlags(&jr.done, hipEventDisableTiming);
 	}
-	int max_mbs = 0;
+	int max_mbs = 0, max_tiles = 0;
 	for (int i = 0; i < n; i++) {
 		E264Stream *s = streams[i];
 		const int n_mbs = mbs_of[i];
+		if (tiles_of[i] > max_tiles) max_tiles = tiles_of[i];
 		int r = ensure_dbk(s, n_mbs);
 		if (r) return r;
 		void *h = e264hip_packet_buffer(s, bytes[i]);
@@ -549,7 +553,7 @@ API int e264hip_submit_batch_host(E264Device *dev, E264Stream *const *streams, c
 		if (n_mbs > max_mbs) max_mbs = n_mbs;
 	}
 	HIPCHK(hipMemcpyAsync(jr.d, jr.h, sizeof(E264Job) * n, hipMemcpyHostToDevice, dev->q), EIO);
-	int r = launch(dev, jr.d, n, max_mbs, mode);
+	int r = launch(dev, jr.d, n, max_mbs, max_tiles, mode);
 	if (r) return r;
 	hipEventRecord(jr.done, dev->q);
 	jr.busy = true;

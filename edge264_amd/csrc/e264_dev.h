@@ -1,0 +1,201 @@
+// e264_dev.h -- device-side definitions shared by the gfx950 kernels (e264_kernels.hip, e264_pred.h):
+// address-space pointer types, small integer helpers, the spec tables, FrameCtx / open_frame.
+//
+// The kernels' source is also compiled for the HOST by the test suite (tests/emu/: every thread of a workgroup is run
+// phase by phase by a plain C++ loop and the result is compared with the CPU oracle before any GPU time is spent).  That
+// build pre-defines the three hooks below (qualifiers, address spaces, the handful of byte-permute intrinsics); the
+// product build never does.
+#ifndef E264_DEV_H
+#define E264_DEV_H
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/edge264_cmd.h"
+#include "e264_kernels.h"
+
+#ifndef E264_DEV
+#define E264_DEV __device__ __forceinline__
+#endif
+#ifndef E264_AS_GLOBAL
+#define E264_AS_GLOBAL __attribute__((address_space(1)))
+#define E264_AS_CONST __attribute__((address_space(4)))
+#endif
+
+namespace {
+
+
+// ---------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------
+E264_DEV int clip3i(int lo, int hi, int v) { return min(max(v, lo), hi); }
+E264_DEV int clip255(int v) { return min(max(v, 0), 255); }
+E264_DEV int sat16(int v) { return min(max(v, -32768), 32767); }
+E264_DEV int w16(int v) { return (int)(int16_t)v; }
+// build-time experiment switches (`make variant NAME=.. DEFS=-D..` builds one library per setting, tools/gpu_ab.sh compares them)
+#ifdef E264_ABL_NOBH
+#define E264_ABL_BH && false
+#else
+#define E264_ABL_BH
+#endif
+#ifndef E264_LUMA_PACKED
+#define E264_LUMA_PACKED 1 // luma interpolation in packed 16-bit arithmetic (two samples per VALU instruction)
+#endif
+typedef uint8_t E264_AS_GLOBAL gu8;   // global memory, so that loads/stores are global_* not flat_*
+typedef uint32_t E264_AS_GLOBAL gu32;
+typedef uint16_t E264_AS_GLOBAL gu16;
+typedef uint32_t E264_AS_GLOBAL __attribute__((aligned(1))) gu32u;
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef v4u E264_AS_GLOBAL __attribute__((aligned(4))) gv4u; // dword-aligned is all the strides guarantee (stride_C/2 of a 4096-wide frame)
+typedef v2u E264_AS_GLOBAL __attribute__((aligned(4))) gv2u; // unaligned dword (global memory allows it on gfx9+)
+typedef int16_t E264_AS_GLOBAL gi16;
+// the command packet is read-only for every kernel: constant address space => uniform reads become
+// scalar loads (s_load) and the values live in SGPRs
+typedef const E264FrameHdr E264_AS_CONST *chdr_t;
+typedef const E264SliceParams E264_AS_CONST *cslice_t;
+typedef const E264Mb E264_AS_CONST *cmb_t;
+typedef const E264Motion E264_AS_GLOBAL *gmotion_t;
+typedef const uint8_t E264_AS_CONST *cu8p;
+typedef uint8_t *generic_u8p;
+typedef const generic_u8p E264_AS_GLOBAL *gdpb_t;
+#ifndef E264_HOST_INTRINSICS
+E264_DEV int lane_id() { return (int)(threadIdx.x & 63); }
+// All LDS scratch is private to one wave; LDS operations of a wave execute in order, so a
+// compiler-level fence is all that is needed between producer and consumer lanes.
+E264_DEV void wave_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+#endif
+
+__constant__ uint8_t c_BX[16] = {0, 4, 0, 4, 8, 12, 8, 12, 0, 4, 0, 4, 8, 12, 8, 12};
+__constant__ uint8_t c_BY[16] = {0, 0, 4, 4, 0, 0, 4, 4, 8, 8, 12, 12, 8, 8, 12, 12};
+E264_DEV int BXf(int k) { return ((k & 1) << 2) | ((k & 4) << 1); }
+E264_DEV int BYf(int k) { return ((k & 2) << 1) | ((k & 8)); }
+E264_DEV int blk_of(int bx, int by) { return (by >> 1) * 8 + (bx >> 1) * 4 + (by & 1) * 2 + (bx & 1); }
+
+// normAdjust4x4 / normAdjust8x8 (edge264_residual.c:77-98) as arithmetic on immediates: byte m of a 64-bit constant per
+// position class.  (A table in constant memory read with a per-lane index is a vector-memory round trip in the middle
+// of every transform.)
+E264_DEV int na_byte(uint64_t t, int m) { return (int)(t >> (8 * m)) & 255; }
+#define NA4_0 0x12100e0d0b0aull /* class 0 (even,even): 10 11 13 14 16 18 */
+#define NA4_1 0x1d1917141210ull /* class 1 (odd,odd)  : 16 18 20 23 25 29 */
+E264_DEV int norm4(int m, int pos)
+{
+	int i = pos >> 2, j = pos & 3;
+	const int a = na_byte(NA4_0, m), b = na_byte(NA4_1, m), c = na_byte(0x171412100e0dull, m);
+	return (i & j & 1) ? b : ((i | j) & 1) ? c : a;
+}
+E264_DEV int norm8(int m, int pos)
+{
+	int i = pos >> 3, j = pos & 7, k;
+	const int v0 = na_byte(0x24201c1a1614ull, m), v1 = na_byte(0x201c19171312ull, m), v2 = na_byte(0x3a332d2a2320ull, m);
+	const int v3 = na_byte(0x221e1a181513ull, m), v4 = na_byte(0x2e2823211c19ull, m), v5 = na_byte(0x2b26211f1a18ull, m);
+	if ((i & 3) == 0 && (j & 3) == 0) k = v0;
+	else if (i & j & 1) k = v1;
+	else if ((i & 3) == 2 && (j & 3) == 2) k = v2;
+	else if (((i & 3) == 0 && (j & 1)) || ((i & 1) && (j & 3) == 0)) k = v3;
+	else if (((i & 3) == 0 && (j & 3) == 2) || ((i & 3) == 2 && (j & 3) == 0)) k = v4;
+	else k = v5;
+	return k;
+}
+
+__constant__ uint8_t c_alpha[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 5, 6, 7, 8, 9, 10, 12, 13, 15, 17, 20, 22, 25, 28,
+	32, 36, 40, 45, 50, 56, 63, 71, 80, 90, 101, 113, 127, 144, 162, 182, 203, 226, 255, 255};
+__constant__ uint8_t c_beta[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 6, 6, 7, 7, 8, 8,
+	9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 14, 14, 15, 15, 16, 16, 17, 17, 18, 18};
+__constant__ uint8_t c_tc0[3][52] = {
+	{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 6, 6, 7, 8, 9, 10, 11, 13},
+	{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 5, 6, 7, 8, 8, 10, 11, 12, 13, 15, 17},
+	{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 23, 25}};
+
+// ---- the byte-permute / funnel-shift VALU instructions the kernels use by name -------------------------------------
+#ifndef E264_HOST_INTRINSICS
+E264_DEV uint32_t v_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }          // v_perm_b32
+E264_DEV uint32_t v_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); } // ({hi,lo} >> 8*(sh&3))
+E264_DEV uint32_t v_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }   // ({hi,lo} >> (sh&31))
+E264_DEV uint32_t v_lerp_u8(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_lerp(a, b, c); }              // per byte (a + b + (c & 1)) >> 1
+#endif
+// ---- packed 16-bit arithmetic (v_pk_*_i16: two samples per VALU instruction) ------------------------------------------
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+E264_DEV s16x2 as_s2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+E264_DEV uint32_t as_u(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+// pair (byte i, byte i+1) of the 8 bytes {hi, lo}, zero-extended to 16 bits each (v_perm_b32; selector 0x0c = 0x00)
+template <int I>
+E264_DEV s16x2 pair_at(uint32_t hi, uint32_t lo)
+{
+	return as_s2(v_perm(hi, lo, 0x0c000c00u | (uint32_t)I | (uint32_t)(I + 1) << 16));
+}
+// the 8 pairs Q_i = (p_i, p_i+1), i = 0..7, of the 9 samples of one row
+E264_DEV void pairs9(const uint32_t w[3], s16x2 Q[8])
+{
+	Q[0] = pair_at<0>(w[1], w[0]); Q[1] = pair_at<1>(w[1], w[0]); Q[2] = pair_at<2>(w[1], w[0]); Q[3] = pair_at<3>(w[1], w[0]);
+	Q[4] = pair_at<0>(w[2], w[1]); Q[5] = pair_at<1>(w[2], w[1]); Q[6] = pair_at<2>(w[2], w[1]); Q[7] = pair_at<3>(w[2], w[1]);
+}
+E264_DEV s16x2 tap6p(s16x2 a, s16x2 b, s16x2 c, s16x2 d, s16x2 e, s16x2 f)
+{
+	const s16x2 k5 = {5, 5}, k20 = {20, 20};
+	return (a + f) - (b + e) * k5 + (c + d) * k20;
+}
+// sixtapHV + (x + 32) >> 6, clipped: 16-bit lanes wrap exactly like the reference's int16 vectors (inter.c:4-9,14)
+E264_DEV s16x2 centre6p(s16x2 t0, s16x2 t1, s16x2 t2, s16x2 t3, s16x2 t4, s16x2 t5)
+{
+	const s16x2 s2 = {2, 2}, s6 = {6, 6}, r32 = {32, 32}, z = {0, 0}, m = {255, 255};
+	const s16x2 af = t0 + t5, be = t1 + t4, cd = t2 + t3;
+	const s16x2 x1 = af - be;
+	const s16x2 x2 = (x1 >> s2) + (cd - be);
+	const s16x2 x3 = (x2 >> s2) + cd;
+	return __builtin_elementwise_min(__builtin_elementwise_max((x3 + r32) >> s6, z), m);
+}
+E264_DEV s16x2 half5p(s16x2 v) // clip255((v + 16) >> 5)
+{
+	const s16x2 s5 = {5, 5}, r16 = {16, 16}, z = {0, 0}, m = {255, 255};
+	return __builtin_elementwise_min(__builtin_elementwise_max((v + r16) >> s5, z), m);
+}
+struct FrameCtx {
+	chdr_t h;
+	cslice_t slices;
+	cmb_t mbs;
+	gmotion_t motion;  // dense per-MB array, NULL if the frame has no inter macroblock
+	const gu8 *payload;
+	gdpb_t dpb;
+	const generic_u8p *dpb_lds; // the same table staged in LDS (mbpar kernel): no dependent global round trip per reference
+	gu8 *cur;
+	int W, H;          // luma samples
+	int wm, hm;        // macroblocks
+	int sY, sC;        // strides
+	uint32_t psY;      // plane_size_Y
+	int dbg;           // profiling ablations: bit8 no luma MC, bit9 no chroma MC, bit10 no residual, bit11 no bS, bit12 no store
+	gu8 *dbk;          // per-MB deblocking parameters (E264_DBK_BYTES each), written by the mbpar kernel
+};
+
+E264_DEV gu8 *plane_base(const FrameCtx &f, gu8 *base, int pl)
+{
+	return pl == 0 ? base : base + f.psY + (pl == 2 ? (f.sC >> 1) : 0);
+}
+
+E264_DEV bool open_frame(FrameCtx &f, const E264Job &job)
+{
+	const uint8_t *pkt = job.packet;
+	chdr_t h = (chdr_t)pkt;
+	if (h->magic != E264_MAGIC || h->version != E264_VERSION)
+		return false;
+	f.h = h;
+	f.slices = (cslice_t)(pkt + h->slices_off);
+	f.mbs = (cmb_t)(pkt + h->mbs_off);
+	f.payload = (const gu8 *)(pkt + h->payload_off);
+	f.motion = h->motion_off ? (gmotion_t)(pkt + h->motion_off) : nullptr;
+	f.dpb_lds = nullptr;
+	f.dbg = 0;
+	f.dpb = (gdpb_t)job.dpb;
+	f.cur = (gu8 *)job.dpb[h->dst_slot];
+	f.wm = h->width_mbs; f.hm = h->height_mbs;
+	f.W = f.wm * 16; f.H = f.hm * 16;
+	f.sY = (int)h->stride_Y; f.sC = (int)h->stride_C;
+	f.psY = h->plane_size_Y;
+	f.dbk = (gu8 *)job.dbk;
+	return f.cur != nullptr;
+}
+
+} // namespace
+#endif

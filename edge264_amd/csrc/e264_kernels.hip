@@ -32,93 +32,10 @@
 #include <stdint.h>
 #include "../../include/edge264_cmd.h"
 #include "e264_kernels.h"
+#include "e264_dev.h"
+#include "e264_pred.h"
 
 namespace {
-
-// ---------------------------------------------------------------------------------
-// small helpers
-// ---------------------------------------------------------------------------------
-__device__ __forceinline__ int clip3i(int lo, int hi, int v) { return min(max(v, lo), hi); }
-__device__ __forceinline__ int clip255(int v) { return min(max(v, 0), 255); }
-__device__ __forceinline__ int sat16(int v) { return min(max(v, -32768), 32767); }
-__device__ __forceinline__ int w16(int v) { return (int)(int16_t)v; }
-// build-time experiment switches (`make variant NAME=.. DEFS=-D..` builds one library per setting, tools/gpu_ab.sh compares them)
-#ifdef E264_ABL_NOBH
-#define E264_ABL_BH && false
-#else
-#define E264_ABL_BH
-#endif
-#ifndef E264_LUMA_PACKED
-#define E264_LUMA_PACKED 1 // luma interpolation in packed 16-bit arithmetic (two samples per VALU instruction)
-#endif
-typedef uint8_t __attribute__((address_space(1))) gu8;   // global memory, so that loads/stores are global_* not flat_*
-typedef uint32_t __attribute__((address_space(1))) gu32;
-typedef uint16_t __attribute__((address_space(1))) gu16;
-typedef uint32_t __attribute__((address_space(1), aligned(1))) gu32u;
-typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-typedef v4u __attribute__((address_space(1), aligned(4))) gv4u; // dword-aligned is all the strides guarantee (stride_C/2 of a 4096-wide frame)
-typedef v2u __attribute__((address_space(1), aligned(4))) gv2u; // unaligned dword (global memory allows it on gfx9+)
-typedef int16_t __attribute__((address_space(1))) gi16;
-// the command packet is read-only for every kernel: constant address space => uniform reads become
-// scalar loads (s_load) and the values live in SGPRs
-typedef const E264FrameHdr __attribute__((address_space(4))) *chdr_t;
-typedef const E264SliceParams __attribute__((address_space(4))) *cslice_t;
-typedef const E264Mb __attribute__((address_space(4))) *cmb_t;
-typedef const E264Motion __attribute__((address_space(1))) *gmotion_t;
-typedef const uint8_t __attribute__((address_space(4))) *cu8p;
-typedef uint8_t *generic_u8p;
-typedef const generic_u8p __attribute__((address_space(1))) *gdpb_t;
-__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
-// All LDS scratch is private to one wave; LDS operations of a wave execute in order, so a
-// compiler-level fence is all that is needed between producer and consumer lanes.
-__device__ __forceinline__ void wave_sync()
-{
-	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-}
-
-__constant__ uint8_t c_BX[16] = {0, 4, 0, 4, 8, 12, 8, 12, 0, 4, 0, 4, 8, 12, 8, 12};
-__constant__ uint8_t c_BY[16] = {0, 0, 4, 4, 0, 0, 4, 4, 8, 8, 12, 12, 8, 8, 12, 12};
-__device__ __forceinline__ int BXf(int k) { return ((k & 1) << 2) | ((k & 4) << 1); }
-__device__ __forceinline__ int BYf(int k) { return ((k & 2) << 1) | ((k & 8)); }
-__device__ __forceinline__ int blk_of(int bx, int by) { return (by >> 1) * 8 + (bx >> 1) * 4 + (by & 1) * 2 + (bx & 1); }
-
-// normAdjust4x4 / normAdjust8x8 (edge264_residual.c:77-98) as arithmetic on immediates: byte m of a 64-bit constant per
-// position class.  (A table in constant memory read with a per-lane index is a vector-memory round trip in the middle
-// of every transform.)
-__device__ __forceinline__ int na_byte(uint64_t t, int m) { return (int)(t >> (8 * m)) & 255; }
-#define NA4_0 0x12100e0d0b0aull /* class 0 (even,even): 10 11 13 14 16 18 */
-#define NA4_1 0x1d1917141210ull /* class 1 (odd,odd)  : 16 18 20 23 25 29 */
-__device__ __forceinline__ int norm4(int m, int pos)
-{
-	int i = pos >> 2, j = pos & 3;
-	const int a = na_byte(NA4_0, m), b = na_byte(NA4_1, m), c = na_byte(0x171412100e0dull, m);
-	return (i & j & 1) ? b : ((i | j) & 1) ? c : a;
-}
-__device__ __forceinline__ int norm8(int m, int pos)
-{
-	int i = pos >> 3, j = pos & 7, k;
-	const int v0 = na_byte(0x24201c1a1614ull, m), v1 = na_byte(0x201c19171312ull, m), v2 = na_byte(0x3a332d2a2320ull, m);
-	const int v3 = na_byte(0x221e1a181513ull, m), v4 = na_byte(0x2e2823211c19ull, m), v5 = na_byte(0x2b26211f1a18ull, m);
-	if ((i & 3) == 0 && (j & 3) == 0) k = v0;
-	else if (i & j & 1) k = v1;
-	else if ((i & 3) == 2 && (j & 3) == 2) k = v2;
-	else if (((i & 3) == 0 && (j & 1)) || ((i & 1) && (j & 3) == 0)) k = v3;
-	else if (((i & 3) == 0 && (j & 3) == 2) || ((i & 3) == 2 && (j & 3) == 0)) k = v4;
-	else k = v5;
-	return k;
-}
-
-__constant__ uint8_t c_alpha[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 5, 6, 7, 8, 9, 10, 12, 13, 15, 17, 20, 22, 25, 28,
-	32, 36, 40, 45, 50, 56, 63, 71, 80, 90, 101, 113, 127, 144, 162, 182, 203, 226, 255, 255};
-__constant__ uint8_t c_beta[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 6, 6, 7, 7, 8, 8,
-	9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 14, 14, 15, 15, 16, 16, 17, 17, 18, 18};
-__constant__ uint8_t c_tc0[3][52] = {
-	{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 6, 6, 7, 8, 9, 10, 11, 13},
-	{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 5, 6, 7, 8, 8, 10, 11, 12, 13, 15, 17},
-	{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 23, 25}};
-
 // ---------------------------------------------------------------------------------
 // per-wave LDS scratch
 // ---------------------------------------------------------------------------------
@@ -199,23 +116,6 @@ struct __attribute__((aligned(16))) DbkLds { // deblocking scratch of one wave =
 	DbkStage stage[2];   // [half-wave]
 };
 
-struct FrameCtx {
-	chdr_t h;
-	cslice_t slices;
-	cmb_t mbs;
-	gmotion_t motion;  // dense per-MB array, NULL if the frame has no inter macroblock
-	const gu8 *payload;
-	gdpb_t dpb;
-	const generic_u8p *dpb_lds; // the same table staged in LDS (mbpar kernel): no dependent global round trip per reference
-	gu8 *cur;
-	int W, H;          // luma samples
-	int wm, hm;        // macroblocks
-	int sY, sC;        // strides
-	uint32_t psY;      // plane_size_Y
-	int dbg;           // profiling ablations: bit8 no luma MC, bit9 no chroma MC, bit10 no residual, bit11 no bS, bit12 no store
-	gu8 *dbk;          // per-MB deblocking parameters (E264_DBK_BYTES each), written by the mbpar kernel
-};
-
 // -DE264_PHASE_TIMING: wall cycles of the mbpar kernel's phases, summed over all waves (tools/gpu_phase.sh reads them back
 // through e264_debug_phase_cycles).  s_memtime at the phase boundaries drains the LGKM counter, so the numbers are a
 // profile, not a benchmark.
@@ -235,11 +135,6 @@ __device__ unsigned long long g_phase[32]; // [0..13] mbpar kernel, [16..29] deb
 #define PH_PARAMS
 #define PH_ARGS
 #endif
-
-__device__ __forceinline__ gu8 *plane_base(const FrameCtx &f, gu8 *base, int pl)
-{
-	return pl == 0 ? base : base + f.psY + (pl == 2 ? (f.sC >> 1) : 0);
-}
 
 // register copy of one macroblock header (uniform: fetched with scalar loads)
 struct MbInfo {
@@ -561,7 +456,7 @@ __device__ __forceinline__ void compute_residual(WaveLds &L, const FrameCtx &f, 
 // ---------------------------------------------------------------------------------
 // inter prediction
 // ---------------------------------------------------------------------------------
-struct Wod { int w0, w1, o, wd; };
+// struct Wod: e264_pred.h
 __device__ __forceinline__ int wpred(int q, int p, const Wod &w)
 { // maddshrL, edge264_inter.c:17-21: pmaddubsw (int8 weights), adds16, sra, packus
 	int x = sat16(q * (int)(int8_t)w.w0 + p * (int)(int8_t)w.w1);
@@ -672,41 +567,6 @@ __device__ __forceinline__ int avg2(int a, int b) { return (a + b + 1) >> 1; }
 // 16-bit intermediates of the centre wrap as in the reference (sixtapHV, inter.c:4-9).
 #if E264_LUMA_PACKED
 // ---- packed 16-bit arithmetic (v_pk_*_i16: two samples per instruction) --------------------------------------
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ s16x2 as_s2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
-__device__ __forceinline__ uint32_t as_u(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
-// pair (byte i, byte i+1) of the 8 bytes {hi, lo}, zero-extended to 16 bits each (v_perm_b32; selector 0x0c = 0x00)
-template <int I>
-__device__ __forceinline__ s16x2 pair_at(uint32_t hi, uint32_t lo)
-{
-	return as_s2(__builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)I | (uint32_t)(I + 1) << 16));
-}
-// the 8 pairs Q_i = (p_i, p_i+1), i = 0..7, of the 9 samples of one row
-__device__ __forceinline__ void pairs9(const uint32_t w[3], s16x2 Q[8])
-{
-	Q[0] = pair_at<0>(w[1], w[0]); Q[1] = pair_at<1>(w[1], w[0]); Q[2] = pair_at<2>(w[1], w[0]); Q[3] = pair_at<3>(w[1], w[0]);
-	Q[4] = pair_at<0>(w[2], w[1]); Q[5] = pair_at<1>(w[2], w[1]); Q[6] = pair_at<2>(w[2], w[1]); Q[7] = pair_at<3>(w[2], w[1]);
-}
-__device__ __forceinline__ s16x2 tap6p(s16x2 a, s16x2 b, s16x2 c, s16x2 d, s16x2 e, s16x2 f)
-{
-	const s16x2 k5 = {5, 5}, k20 = {20, 20};
-	return (a + f) - (b + e) * k5 + (c + d) * k20;
-}
-// sixtapHV + (x + 32) >> 6, clipped: 16-bit lanes wrap exactly like the reference's int16 vectors (inter.c:4-9,14)
-__device__ __forceinline__ s16x2 centre6p(s16x2 t0, s16x2 t1, s16x2 t2, s16x2 t3, s16x2 t4, s16x2 t5)
-{
-	const s16x2 s2 = {2, 2}, s6 = {6, 6}, r32 = {32, 32}, z = {0, 0}, m = {255, 255};
-	const s16x2 af = t0 + t5, be = t1 + t4, cd = t2 + t3;
-	const s16x2 x1 = af - be;
-	const s16x2 x2 = (x1 >> s2) + (cd - be);
-	const s16x2 x3 = (x2 >> s2) + cd;
-	return __builtin_elementwise_min(__builtin_elementwise_max((x3 + r32) >> s6, z), m);
-}
-__device__ __forceinline__ s16x2 half5p(s16x2 v) // clip255((v + 16) >> 5)
-{
-	const s16x2 s5 = {5, 5}, r16 = {16, 16}, z = {0, 0}, m = {255, 255};
-	return __builtin_elementwise_min(__builtin_elementwise_max((v + r16) >> s5, z), m);
-}
 __device__ __forceinline__ void luma_from_rows(const uint32_t d[6][3], int xF, int yF, int out[4])
 {
 	const bool xo = xF & 1, yo = yF & 1;
@@ -1943,28 +1803,6 @@ __device__ __forceinline__ int lds_load_relaxed(const int *p)
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__device__ __forceinline__ bool open_frame(FrameCtx &f, const E264Job &job)
-{
-	const uint8_t *pkt = job.packet;
-	chdr_t h = (chdr_t)pkt;
-	if (h->magic != E264_MAGIC || h->version != E264_VERSION)
-		return false;
-	f.h = h;
-	f.slices = (cslice_t)(pkt + h->slices_off);
-	f.mbs = (cmb_t)(pkt + h->mbs_off);
-	f.payload = (const gu8 *)(pkt + h->payload_off);
-	f.motion = h->motion_off ? (gmotion_t)(pkt + h->motion_off) : nullptr;
-	f.dpb_lds = nullptr;
-	f.dbg = 0;
-	f.dpb = (gdpb_t)job.dpb;
-	f.cur = (gu8 *)job.dpb[h->dst_slot];
-	f.wm = h->width_mbs; f.hm = h->height_mbs;
-	f.W = f.wm * 16; f.H = f.hm * 16;
-	f.sY = (int)h->stride_Y; f.sC = (int)h->stride_C;
-	f.psY = h->plane_size_Y;
-	f.dbk = (gu8 *)job.dbk;
-	return f.cur != nullptr;
-}
 
 #define E264_MAX_ROWS 1056
 } // namespace
@@ -2124,6 +1962,50 @@ __global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, in
 	strip_flush(O, f, mbx0, mby0, staged, lane);
 	PH(9);
 	PH_FLUSH(lane);
+}
+
+// Inter prediction + residual of every inter / PCM macroblock: one workgroup per tile of 16 x 8 macroblocks, one thread
+// per 8x8 block; the phases are in e264_pred.h (and run on the host by tests/emu).
+#ifndef E264_PRED_WAVES_PER_EU
+#define E264_PRED_WAVES_PER_EU 4 // 128 VGPRs: two 512-thread workgroups per CU, so that one tile's barriers and first loads hide behind the other's arithmetic
+#endif
+__attribute__((amdgpu_waves_per_eu(E264_PRED_WAVES_PER_EU, E264_PRED_WAVES_PER_EU))) __global__ __launch_bounds__(PT_NT) void e264_pred_kernel(const E264Job *jobs, int mode)
+{
+	__shared__ PredLds L;
+	const int tid = (int)threadIdx.x;
+	FrameCtx f;
+	int bx, by;
+	xcd_tile(bx, by);
+	if (!open_frame(f, jobs[by]))
+		return;
+	const int ntx = (f.wm + PT_W - 1) / PT_W, nty = (f.hm + PT_H - 1) / PT_H;
+	if (bx >= ntx * nty)
+		return;
+	const PredTile t = {(bx % ntx) * PT_W, (bx / ntx) * PT_H};
+	pred_phase_setup(L, f, t, tid);
+	__syncthreads();
+	{ // nothing for this kernel in the tile (every tile of an I frame)? leave at once
+		const int kind = tid < PT_MBS ? (int)(L.hdr[tid][0] & 255) : 0;
+		if (!__syncthreads_or(kind == E264_MB_INTER || kind == E264_MB_PCM))
+			return;
+	}
+	pred_phase_classify(L, f, t, 0, tid);
+	__syncthreads();
+	pred_phase_items(L, f, t, 0, tid);
+	__syncthreads();
+	if (L.any_l1) { // uniform: written before the barrier above
+		pred_phase_reset(L, tid);
+		__syncthreads();
+		pred_phase_classify(L, f, t, 1, tid);
+		__syncthreads();
+		pred_phase_items(L, f, t, 1, tid);
+		__syncthreads();
+	}
+	pred_phase_reslist(L, tid);
+	__syncthreads();
+	pred_phase_residual(L, f, tid);
+	__syncthreads();
+	pred_phase_flush(L, f, t, tid);
 }
 
 // deblocking parameters (bS, alpha, beta, indexA) of every macroblock: one wave per macroblock, few
@@ -2318,7 +2200,7 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 	}
 }
 
-extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int max_mbs, int mode, int waves, hipStream_t stream, hipEvent_t *marks,
+extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int max_mbs, int max_tiles, int mode, int waves, hipStream_t stream, hipEvent_t *marks,
 	const E264Fork *fork)
 {
 	if (n_jobs <= 0)
@@ -2341,7 +2223,10 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 	} else if (dbkp)
 		hipLaunchKernelGGL(e264_dbkparam_kernel, dim3((max_mbs + 15) / 16, n_jobs), dim3(256), 0, stream, jobs);
 	if (marks) hipEventRecord(marks[1], stream);
-	hipLaunchKernelGGL(e264_mbpar_kernel, dim3((max_mbs + 4 * E264_MBPAR_STRIP - 1) / (4 * E264_MBPAR_STRIP), n_jobs), dim3(256), 0, stream, jobs, mode);
+	if (mode & 16384) // debug mode bit 14: round 1's strip-per-wave kernel (A/B timing only)
+		hipLaunchKernelGGL(e264_mbpar_kernel, dim3((max_mbs + 4 * E264_MBPAR_STRIP - 1) / (4 * E264_MBPAR_STRIP), n_jobs), dim3(256), 0, stream, jobs, mode);
+	else if (mode & 1)
+		hipLaunchKernelGGL(e264_pred_kernel, dim3(max_tiles, n_jobs), dim3(PT_NT), 0, stream, jobs, mode);
 	if (marks) hipEventRecord(marks[2], stream);
 	const int intra_waves = waves >> 8 ? waves >> 8 : waves & 255;
 	waves &= 255;

@@ -1,0 +1,735 @@
+// e264_pred.h -- e264_pred_kernel: inter prediction + residual of every inter / PCM macroblock (second generation of the
+// macroblock-parallel kernel; replaces the strip-per-wave e264_mbpar_kernel of round 1).
+//
+// Device restatement of (file:line in /root/reference/src):
+//   decode_inter            edge264_inter.c:1108-1251   partition -> reference window, weights, edge emulation
+//   decode_inter_luma       edge264_inter.c:416-968     6-tap luma, 16 quarter-sample positions
+//   decode_inter_chroma     edge264_inter.c:977-1091    bilinear chroma
+//   add_idct4x4 / add_dc4x4 / add_idct8x8 / transform_dc2x2   edge264_residual.c:108-343, 456-538
+//   I_PCM                   edge264_slice.c:914-935
+//
+// Why a rewrite: round 1 walked one macroblock per wave (4 samples per lane per step); its counters showed 430 VALU +
+// 240 SALU wave-instructions per macroblock of which the filter taps were a tenth -- the kernel was bound by issuing
+// per-macroblock bookkeeping, window addressing and LDS round trips (profiles/r01k_ablation_breakdown.txt).  Here:
+//
+//   * ONE LANE = ONE 8x8 LUMA BLOCK (+ its 4x4 Cb and Cr): 96 samples per lane per item, 16 macroblocks per wave-pass.
+//     The lane fetches its OWN 13x13 reference window (13 rows x one 16-byte load, served by L1/L2) and keeps it in
+//     registers: rows, columns, horizontal and vertical taps are all lane-private, so there is no LDS round trip, no
+//     cross-lane traffic and no wave-level pipeline state at all.  Overlapping windows of neighbouring lanes are cache
+//     hits by construction ("6-tap halos are cache hits by definition").
+//   * A WORKGROUP = A TILE of 16 x 8 macroblocks, 512 threads.  The tile's samples are assembled in LDS (48 KB) and leave as
+//     whole 256-byte luma / 128-byte chroma rows (round 1 measured 3.6x write amplification for 16-byte row pieces).
+//   * CLASS-SORTED WORK LISTS.  The 16 quarter-sample positions need three different data flows (reference
+//     edge264_inter.c: "horizontal then vertical" for xFrac == 2, "vertical then horizontal" for yFrac == 2, one-dimensional
+//     otherwise).  The items of a tile are binned by that class in LDS (one atomic per item) and lanes take items in class
+//     order, so a wave runs one flow (two at a class boundary) instead of the union of all three.
+//   * The residual is a second, COMPACTED pass: one lane = one coded 4x4 (or 8x8) block, transformed entirely in registers
+//     and added to the tile in LDS.  Macroblocks without coefficients cost nothing (round 1: the whole wave walked the
+//     transform of every coded macroblock with a quarter of its lanes busy).
+//
+// The kernel is a sequence of PHASES separated by workgroup barriers; threads only communicate through LDS between
+// phases.  Each phase is a plain function of (LDS, frame, tile, thread id): tests/emu/ compiles this very file for the
+// host, runs the phases thread by thread and compares the tile with the CPU oracle (tests/test_pred_emu.py).
+#ifndef E264_PRED_H
+#define E264_PRED_H
+#include "e264_dev.h"
+
+namespace {
+
+#ifndef E264_HOST_INTRINSICS
+E264_DEV int lds_add(int *p, int v) { return atomicAdd(p, v); }
+E264_DEV void lds_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
+#endif
+
+#define PT_W 16                 // tile width in macroblocks (256-byte luma rows, 128-byte chroma rows)
+#define PT_H 8
+#define PT_MBS (PT_W * PT_H)
+#define PT_NT (PT_MBS * 4)      // one thread per 8x8 quadrant
+#define PT_LIST 2048            // items per class list: every quadrant split into four 4x4 partitions
+
+struct __attribute__((aligned(16))) PredLds {
+	uint32_t y[PT_H * 16][PT_W * 4];    // luma samples of the tile
+	uint32_t c[2][PT_H * 8][PT_W * 2];  // Cb, Cr
+	uint32_t hdr[PT_MBS][8];            // E264Mb records (kind 0 = ABSENT for macroblocks outside the frame)
+	uint16_t lst[3][PT_LIST];           // prediction items by class; then the residual lists (4x4: lst[0..1], 8x8: lst[2])
+	int cnt[4];                         // items per class
+	int rcnt[2];                        // residual items: 4x4 blocks, 8x8 blocks
+	uint32_t staged[PT_MBS / 32];       // macroblocks this kernel writes (inter, PCM)
+	int any_l1;                         // some quadrant of the tile uses list 1
+	generic_u8p dpb[E264_MAX_SLOTS];
+};
+
+struct PredTile { int tx0, ty0; };     // first macroblock of the tile
+
+// prediction item: bits 0..8 quadrant slot (macroblock of the tile * 4 + 8x8 index), 9..10 4x4 block of the quadrant the
+// partition starts at, 11..12 shape (0 8x8, 1 8x4, 2 4x8, 3 4x4).  The class is implied by the list.
+#define PI_SLOT(d) ((d) & 511)
+#define PI_SUB(d) ((d) >> 9 & 3)
+#define PI_SHAPE(d) ((d) >> 11 & 3)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// phase 0: headers of the tile, counters
+// ---------------------------------------------------------------------------------------------------------------------
+E264_DEV void pred_phase_setup(PredLds &L, const FrameCtx &f, const PredTile &t, int tid)
+{
+	if (tid < 4) L.cnt[tid] = 0;
+	if (tid < 2) L.rcnt[tid] = 0;
+	if (tid < PT_MBS / 32) L.staged[tid] = 0;
+	if (tid == 0) L.any_l1 = 0;
+	if (tid < E264_MAX_SLOTS) L.dpb[tid] = f.dpb[tid];
+	const gu32 *mbs_g = (const gu32 *)(f.payload - f.h->payload_off + f.h->mbs_off);
+	for (int i = tid; i < PT_MBS * 8; i += PT_NT) {
+		const int mb = i >> 3, mbx = t.tx0 + (mb & (PT_W - 1)), mby = t.ty0 + mb / PT_W;
+		uint32_t v = 0;
+		if (mbx < f.wm && mby < f.hm) v = mbs_g[(size_t)(mby * f.wm + mbx) * 8 + (i & 7)];
+		L.hdr[mb][i & 7] = v;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// phase 1: one thread per quadrant: partition shape of list `list`, items into the class lists; PCM samples
+// ---------------------------------------------------------------------------------------------------------------------
+E264_DEV int pred_class(uint32_t mv)
+{ // 0: one-dimensional (G, b, h and the diagonal positions), 1: xFrac == 2 (horizontal then vertical), 2: yFrac == 2, xFrac odd
+	const int xF = mv & 3, yF = mv >> 16 & 3;
+	return (xF == 2 && yF != 0) ? 1 : ((xF & 1) && yF == 2) ? 2 : 0;
+}
+E264_DEV void pred_push(PredLds &L, uint32_t mv, int desc)
+{
+	const int cls = pred_class(mv);
+	const int slot = lds_add(&L.cnt[cls], 1);
+	L.lst[cls][slot] = (uint16_t)desc;
+}
+E264_DEV void pred_phase_classify(PredLds &L, const FrameCtx &f, const PredTile &t, int list, int tid)
+{
+	const int mb = tid >> 2, q = tid & 3;
+	const uint32_t d0 = L.hdr[mb][0];
+	const int kind = d0 & 255;
+	const int mbx = t.tx0 + (mb & (PT_W - 1)), mby = t.ty0 + mb / PT_W;
+	if (list == 0 && (kind == E264_MB_INTER || kind == E264_MB_PCM) && q == 0)
+		lds_or(&L.staged[mb >> 5], 1u << (mb & 31));
+	if (list == 0 && kind == E264_MB_PCM) { // edge264_slice.c:914-935: this quadrant's 8x8 luma + 4x4 Cb + 4x4 Cr
+		const gu8 *pl = f.payload + L.hdr[mb][4];
+		const int qx = q & 1, qy = q >> 1;
+		for (int r = 0; r < 8; r++) {
+			const gu32 *s = (const gu32 *)(pl + (qy * 8 + r) * 16 + qx * 8);
+			uint32_t *d = &L.y[(mb / PT_W) * 16 + qy * 8 + r][(mb & (PT_W - 1)) * 4 + qx * 2];
+			d[0] = s[0]; d[1] = s[1];
+		}
+		for (int p = 0; p < 2; p++)
+			for (int r = 0; r < 4; r++)
+				L.c[p][(mb / PT_W) * 8 + qy * 4 + r][(mb & (PT_W - 1)) * 2 + qx] = *(const gu32 *)(pl + 256 + p * 64 + (qy * 4 + r) * 8 + qx * 4);
+	}
+	if (kind != E264_MB_INTER || !f.motion)
+		return;
+	gmotion_t mo = f.motion + (mby * f.wm + mbx);
+	if (list == 0 && mo->refPic[4 + q] >= 0)
+		L.any_l1 = 1;
+	if (mo->refPic[list * 4 + q] < 0)
+		return;
+	const v4u m = *(const gv4u *)&mo->mvs[list * 32 + q * 8]; // the quadrant's four 4x4 vectors: (0,0) (4,0) (0,4) (4,4)
+	const int base = tid;
+	if (m.x == m.y && m.x == m.z && m.x == m.w) {
+		pred_push(L, m.x, base);
+	} else if (m.x == m.y && m.z == m.w) { // two 8x4
+		pred_push(L, m.x, base | 1 << 11);
+		pred_push(L, m.z, base | 2 << 9 | 1 << 11);
+	} else if (m.x == m.z && m.y == m.w) { // two 4x8
+		pred_push(L, m.x, base | 2 << 11);
+		pred_push(L, m.y, base | 1 << 9 | 2 << 11);
+	} else {
+		pred_push(L, m.x, base | 3 << 11);
+		pred_push(L, m.y, base | 1 << 9 | 3 << 11);
+		pred_push(L, m.z, base | 2 << 9 | 3 << 11);
+		pred_push(L, m.w, base | 3 << 9 | 3 << 11);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// phase 2: prediction items
+// ---------------------------------------------------------------------------------------------------------------------
+// Reference rows: 16 bytes per row starting at the dword that holds column X (X may be anywhere: the reference's edge
+// emulation == per-sample clamp of the coordinates, edge264_inter.c:1199-1235).  Frame widths are multiples of 16 (8 for
+// chroma), so an aligned dword is either entirely inside the frame or entirely outside; outside dwords replicate the
+// edge sample.
+E264_DEV uint32_t ref_dword(const gu8 *row, int x, int Wb)
+{ // Wb: width of the plane in bytes; x: dword-aligned column, possibly outside
+	const int xc = min(max(x, 0), Wb - 4);
+	uint32_t v = *(const gu32 *)(row + xc);
+	if (x < 0) v = (v & 255u) * 0x01010101u;
+	if (x > Wb - 4) v = (v >> 24) * 0x01010101u;
+	return v;
+}
+struct Row4 { uint32_t a0, a1, a2, a3; };
+// 13 x 16 bytes around (X, Y), byte-aligned so that byte c of row r is sample (X + c, Y + r)
+E264_DEV void load_window13(const gu8 *plane, int sY, int W, int H, int X, int Y, Row4 A[13])
+{
+	const int XA = X & ~3;
+	const uint32_t o = (uint32_t)X & 3u;
+	if (XA >= 0 && XA + 12 <= W - 4) { // the common case: one 16-byte load per row
+#pragma unroll
+		for (int r = 0; r < 13; r++) {
+			const v4u v = *(const gv4u *)(plane + (size_t)min(max(Y + r, 0), H - 1) * sY + XA);
+			A[r].a0 = v.x; A[r].a1 = v.y; A[r].a2 = v.z; A[r].a3 = v.w;
+		}
+	} else {
+#pragma unroll
+		for (int r = 0; r < 13; r++) {
+			const gu8 *row = plane + (size_t)min(max(Y + r, 0), H - 1) * sY;
+			A[r].a0 = ref_dword(row, XA, W); A[r].a1 = ref_dword(row, XA + 4, W); A[r].a2 = ref_dword(row, XA + 8, W); A[r].a3 = ref_dword(row, XA + 12, W);
+		}
+	}
+#pragma unroll
+	for (int r = 0; r < 13; r++) {
+		const uint32_t w0 = A[r].a0, w1 = A[r].a1, w2 = A[r].a2, w3 = A[r].a3;
+		A[r].a0 = v_alignbyte(w1, w0, o); A[r].a1 = v_alignbyte(w2, w1, o); A[r].a2 = v_alignbyte(w3, w2, o); A[r].a3 = w3 >> (8 * o);
+	}
+}
+// the 12 sliding pairs Q_c = (B_c, B_c+1), c = 0..11, of a row
+E264_DEV void pairs12(const Row4 &a, s16x2 Q[12])
+{
+	Q[0] = pair_at<0>(a.a1, a.a0); Q[1] = pair_at<1>(a.a1, a.a0); Q[2] = pair_at<2>(a.a1, a.a0); Q[3] = pair_at<3>(a.a1, a.a0);
+	Q[4] = pair_at<0>(a.a2, a.a1); Q[5] = pair_at<1>(a.a2, a.a1); Q[6] = pair_at<2>(a.a2, a.a1); Q[7] = pair_at<3>(a.a2, a.a1);
+	Q[8] = pair_at<0>(a.a3, a.a2); Q[9] = pair_at<1>(a.a3, a.a2); Q[10] = pair_at<2>(a.a3, a.a2); Q[11] = pair_at<3>(a.a3, a.a2);
+}
+// horizontal 6-tap sums of the 8 outputs of a row (unclipped, 16 bits): T[p] = outputs (2p, 2p+1)
+E264_DEV void htaps8(const Row4 &a, s16x2 T[4])
+{
+	s16x2 Q[12];
+	pairs12(a, Q);
+#pragma unroll
+	for (int p = 0; p < 4; p++)
+		T[p] = tap6p(Q[2 * p], Q[2 * p + 1], Q[2 * p + 2], Q[2 * p + 3], Q[2 * p + 4], Q[2 * p + 5]);
+}
+// two pairs of values 0..255 -> 4 bytes
+E264_DEV uint32_t pack4(s16x2 lo, s16x2 hi) { return v_perm(as_u(hi), as_u(lo), 0x06040200u); }
+#define ONES8 0x01010101u
+
+// Where the rows of a partition go: the tile in LDS, combined with what list 0 left there (edge264_inter.c:1099-1106:
+// bi-prediction is two calls, the second one blends):
+//   mode 0 plain     (anything unweighted; list 1 alone)                  tile = p
+//   mode 1 average   (no weighting, list 1 on top of list 0)              tile = (q + p + 1) >> 1
+//   mode 2 weighted                                                       tile = wpred(q, p)
+struct Wod { int w0, w1, o, wd; };
+E264_DEV int wpred1(int q, int p, const Wod &w)
+{ // maddshrL, edge264_inter.c:17-21: pmaddubsw (int8 weights), adds16, sra, packus
+	int x = sat16(q * (int)(int8_t)w.w0 + p * (int)(int8_t)w.w1);
+	x = sat16(x + (int)(int16_t)w.o);
+	return clip255(x >> w.wd);
+}
+E264_DEV uint32_t wpred4(uint32_t q, uint32_t p, const Wod &w)
+{
+	return (uint32_t)wpred1(q & 255, p & 255, w) | (uint32_t)wpred1(q >> 8 & 255, p >> 8 & 255, w) << 8 |
+	       (uint32_t)wpred1(q >> 16 & 255, p >> 16 & 255, w) << 16 | (uint32_t)wpred1(q >> 24, p >> 24, w) << 24;
+}
+struct LumaSink {
+	uint32_t *ty;  // first dword of the partition in the tile
+	int mode, nr;  // rows of the partition (4 or 8)
+	bool w8;       // 8 samples wide (else 4)
+	Wod w;
+};
+E264_DEV void sink_row(const LumaSink &k, int j, uint32_t v0, uint32_t v1)
+{
+	if (j >= k.nr)
+		return;
+	uint32_t *d = k.ty + j * PT_W * 4;
+	if (k.mode == 1) { v0 = v_lerp_u8(d[0], v0, ONES8); v1 = v_lerp_u8(d[1], v1, ONES8); }
+	else if (k.mode == 2) { v0 = wpred4(d[0], v0, k.w); v1 = wpred4(d[1], v1, k.w); }
+	d[0] = v0;
+	if (k.w8) d[1] = v1;
+}
+
+// One-dimensional positions (edge264_inter.c:439-557): G, b, h and their quarter-sample averages.
+//   yF == 0: b of row 2, averaged with G of column 2 + (xF == 3)        xF == 0: h of column 2, averaged with G of row 2 + (yF == 3)
+//   both odd: b of row 2 + (yF == 3) averaged with h of column 2 + (xF == 3)
+// Rows are consumed as a stream: output row j is complete once window row j + 5 has been taken apart.
+E264_DEV void luma_1d(const Row4 A[13], int xF, int yF, const LumaSink &sink)
+{
+	const bool needB = xF != 0, needH = yF != 0;
+	const uint32_t dx = xF == 3, dy = yF == 3;
+	const bool diag = (xF & 1) && (yF & 1);
+	const bool half_only = (xF == 2 && yF == 0) || (xF == 0 && yF == 2);
+	uint32_t g[13][2]; // columns 2+dx .. 9+dx of every row
+#pragma unroll
+	for (int r = 0; r < 13; r++) {
+		const uint32_t s0 = v_alignbyte(A[r].a1, A[r].a0, dx), s1 = v_alignbyte(A[r].a2, A[r].a1, dx), s2 = v_alignbyte(A[r].a3, A[r].a2, dx);
+		g[r][0] = v_alignbyte(s1, s0, 2); g[r][1] = v_alignbyte(s2, s1, 2);
+		if (r < 5)
+			continue;
+		const int j = r - 5;
+		const uint32_t G0 = dy ? g[j + 3][0] : g[j + 2][0], G1 = dy ? g[j + 3][1] : g[j + 2][1];
+		uint32_t b0 = G0, b1 = G1, h0 = G0, h1 = G1;
+		if (needB) {
+			Row4 s;
+			s.a0 = dy ? A[j + 3].a0 : A[j + 2].a0; s.a1 = dy ? A[j + 3].a1 : A[j + 2].a1;
+			s.a2 = dy ? A[j + 3].a2 : A[j + 2].a2; s.a3 = dy ? A[j + 3].a3 : A[j + 2].a3;
+			s16x2 T[4];
+			htaps8(s, T);
+			b0 = pack4(half5p(T[0]), half5p(T[1])); b1 = pack4(half5p(T[2]), half5p(T[3]));
+		}
+		if (needH) {
+			s16x2 V[4];
+#pragma unroll
+			for (int p = 0; p < 4; p++) {
+				const int w = p >> 1, I = (p & 1) * 2; // bytes I, I+1 of g[r][w]
+				s16x2 c[6];
+#pragma unroll
+				for (int k = 0; k < 6; k++)
+					c[k] = I ? pair_at<2>(0, g[j + k][w]) : pair_at<0>(0, g[j + k][w]);
+				V[p] = half5p(tap6p(c[0], c[1], c[2], c[3], c[4], c[5]));
+			}
+			h0 = pack4(V[0], V[1]); h1 = pack4(V[2], V[3]);
+		}
+		// op1 = b | h | G, op2 = the quarter-sample partner (itself for the half / integer positions)
+		const uint32_t p0 = needB ? b0 : h0, p1 = needB ? b1 : h1;
+		const uint32_t q0 = diag ? h0 : half_only ? p0 : G0, q1 = diag ? h1 : half_only ? p1 : G1;
+		sink_row(sink, j, v_lerp_u8(p0, q0, ONES8), v_lerp_u8(p1, q1, ONES8));
+	}
+}
+
+// xFrac == 2, yFrac != 0 (edge264_inter.c:611-646, 779-802, 929-966): horizontal taps of 13 rows, then sixtapHV down the
+// columns; yFrac odd: averaged with b of row 2 + (yF == 3)
+E264_DEV void luma_2dh(const Row4 A[13], int yF, const LumaSink &sink)
+{
+	const bool dy = yF == 3, q = yF != 2;
+	s16x2 T[13][4];
+#pragma unroll
+	for (int r = 0; r < 13; r++) {
+		htaps8(A[r], T[r]);
+		if (r < 5)
+			continue;
+		const int j = r - 5;
+		s16x2 J[4], B[4];
+#pragma unroll
+		for (int p = 0; p < 4; p++) {
+			J[p] = centre6p(T[j][p], T[j + 1][p], T[j + 2][p], T[j + 3][p], T[j + 4][p], T[j + 5][p]);
+			B[p] = half5p(dy ? T[j + 3][p] : T[j + 2][p]);
+		}
+		const uint32_t j0 = pack4(J[0], J[1]), j1 = pack4(J[2], J[3]);
+		const uint32_t b0 = pack4(B[0], B[1]), b1 = pack4(B[2], B[3]);
+		sink_row(sink, j, v_lerp_u8(j0, q ? b0 : j0, ONES8), v_lerp_u8(j1, q ? b1 : j1, ONES8));
+	}
+}
+
+// yFrac == 2, xFrac odd (edge264_inter.c:559-609, 741-777, 887-927): vertical taps of 13 columns, then sixtapHV along the
+// rows; averaged with h of column 2 + (xF == 3)
+E264_DEV void luma_2dv(const Row4 A[13], int xF, const LumaSink &sink)
+{
+	const bool dx = xF == 3;
+	// column pairs E_k = (B_2k, B_2k+1), k = 0..6 (the second half of E_6 is not a window sample and is never used)
+	s16x2 E[13][7];
+#pragma unroll
+	for (int r = 0; r < 13; r++) {
+		E[r][0] = pair_at<0>(A[r].a1, A[r].a0); E[r][1] = pair_at<2>(A[r].a1, A[r].a0);
+		E[r][2] = pair_at<0>(A[r].a2, A[r].a1); E[r][3] = pair_at<2>(A[r].a2, A[r].a1);
+		E[r][4] = pair_at<0>(A[r].a3, A[r].a2); E[r][5] = pair_at<2>(A[r].a3, A[r].a2);
+		E[r][6] = pair_at<0>(0, A[r].a3);
+		if (r < 5)
+			continue;
+		const int j = r - 5;
+		s16x2 V[7], O[6];
+#pragma unroll
+		for (int k = 0; k < 7; k++)
+			V[k] = tap6p(E[j][k], E[j + 1][k], E[j + 2][k], E[j + 3][k], E[j + 4][k], E[j + 5][k]);
+#pragma unroll
+		for (int k = 0; k < 6; k++) // (V_2k+1, V_2k+2)
+			O[k] = as_s2(v_alignbit(as_u(V[k + 1]), as_u(V[k]), 16));
+		s16x2 J[4], Hh[4];
+#pragma unroll
+		for (int p = 0; p < 4; p++) {
+			J[p] = centre6p(V[p], O[p], V[p + 1], O[p + 1], V[p + 2], O[p + 2]);
+			Hh[p] = half5p(dx ? O[p + 1] : V[p + 1]);
+		}
+		sink_row(sink, j, v_lerp_u8(pack4(J[0], J[1]), pack4(Hh[0], Hh[1]), ONES8), v_lerp_u8(pack4(J[2], J[3]), pack4(Hh[2], Hh[3]), ONES8));
+	}
+}
+
+// bilinear chroma of a 4x4 block of one plane (edge264_inter.c:977-1091; ABCD of :1242 factored into a horizontal and a
+// vertical blend, identical integers): window rows YC..YC+4, columns XC..XC+4
+E264_DEV void chroma4x4(const gu8 *plane, int sC, int Wc, int Hc, int XC, int YC, int xF, int yF, uint32_t out[4])
+{
+	const int XA = XC & ~3;
+	const uint32_t o = (uint32_t)XC & 3u;
+	const bool inside = XA >= 0 && XA + 4 <= Wc - 4;
+	const s16x2 cx0 = {(short)(8 - xF), (short)(8 - xF)}, cx1 = {(short)xF, (short)xF};
+	const s16x2 cy0 = {(short)(8 - yF), (short)(8 - yF)}, cy1 = {(short)yF, (short)yF};
+	s16x2 hr[5][2];
+#pragma unroll
+	for (int r = 0; r < 5; r++) {
+		const gu8 *row = plane + (size_t)min(max(YC + r, 0), Hc - 1) * sC;
+		uint32_t w0, w1;
+		if (inside) {
+			const v2u v = *(const gv2u *)(row + XA);
+			w0 = v.x; w1 = v.y;
+		} else {
+			w0 = ref_dword(row, XA, Wc); w1 = ref_dword(row, XA + 4, Wc);
+		}
+		const uint32_t a0 = v_alignbyte(w1, w0, o), a1 = w1 >> (8 * o);
+		hr[r][0] = pair_at<0>(a1, a0) * cx0 + pair_at<1>(a1, a0) * cx1;
+		hr[r][1] = pair_at<2>(a1, a0) * cx0 + pair_at<3>(a1, a0) * cx1;
+	}
+	const s16x2 r32 = {32, 32}, s6 = {6, 6};
+#pragma unroll
+	for (int j = 0; j < 4; j++)
+		out[j] = pack4((hr[j][0] * cy0 + hr[j + 1][0] * cy1 + r32) >> s6, (hr[j][1] * cy0 + hr[j + 1][1] * cy1 + r32) >> s6);
+}
+
+// decode_inter weight selection, edge264_inter.c:1137-1197 (all schemes except "no weights" and the default average,
+// which the caller handles on packed bytes)
+E264_DEV void pred_weights(cslice_t s, int list, int refIdx, int refIdxX, Wod &wY, Wod &wCb, Wod &wCr)
+{
+	Wod nw = {0, 1, 0, 0};
+	wY = wCb = wCr = nw;
+	const int idc = s->weighted_bipred_idc;
+	if (idc != 1) {
+		if (list == 1 && refIdxX >= 0) {
+			if (idc == 0) {
+				Wod d = {1, 1, 1, 1};
+				wY = wCb = wCr = d;
+			} else {
+				int w1 = (int)s->implicit_weights[refIdxX][refIdx] - 64;
+				Wod d = {64 - w1, w1, 32, 6};
+				if ((unsigned)(w1 + 63) >= 191u) { d.w0 = 2 - (w1 >> 5); d.w1 = w1 >> 5; d.o = 1; d.wd = 1; }
+				wY = wCb = wCr = d;
+			}
+		}
+	} else if (refIdxX < 0) {
+		const int i = refIdx + list * 32;
+		const int lwd = s->luma_log2_weight_denom, cwd = s->chroma_log2_weight_denom;
+		if (s->explicit_weights[0][i] < 128) {
+			wY.w1 = s->explicit_weights[0][i];
+			wY.o = w16(((s->explicit_offsets[0][i] * 2 + 1) << lwd) >> 1);
+			wY.wd = lwd;
+		}
+		if (s->explicit_weights[1][i] < 128) {
+			wCb.w1 = s->explicit_weights[1][i];
+			wCr.w1 = s->explicit_weights[2][i];
+			wCb.o = w16(((s->explicit_offsets[1][i] * 2 + 1) << cwd) >> 1);
+			wCr.o = w16(((s->explicit_offsets[2][i] * 2 + 1) << cwd) >> 1);
+			wCb.wd = wCr.wd = cwd;
+		}
+	} else if (list == 1) {
+		const int i = refIdx + 32, x = refIdxX;
+		const int lwd = s->luma_log2_weight_denom, cwd = s->chroma_log2_weight_denom;
+		const int a = s->explicit_weights[0][x], b = s->explicit_weights[0][i];
+		const int oo = ((s->explicit_offsets[0][x] + s->explicit_offsets[0][i] + 1) | 1) << lwd;
+		if ((a & b) != 128) { wY.w0 = a; wY.w1 = b; wY.o = w16(oo); wY.wd = lwd + 1; }
+		else { wY.w0 = a >> 1; wY.w1 = b >> 1; wY.o = w16(oo >> 1); wY.wd = lwd; }
+		const int a1 = s->explicit_weights[1][x], b1 = s->explicit_weights[1][i];
+		const int a2 = s->explicit_weights[2][x], b2 = s->explicit_weights[2][i];
+		const int o1 = ((s->explicit_offsets[1][x] + s->explicit_offsets[1][i] + 1) | 1) << cwd;
+		const int o2 = ((s->explicit_offsets[2][x] + s->explicit_offsets[2][i] + 1) | 1) << cwd;
+		if ((a1 & b1) != 128) {
+			wCb.w0 = a1; wCb.w1 = b1; wCr.w0 = a2; wCr.w1 = b2;
+			wCb.o = w16(o1); wCr.o = w16(o2); wCb.wd = wCr.wd = cwd + 1;
+		} else {
+			wCb.w0 = a1 >> 1; wCb.w1 = b1 >> 1; wCr.w0 = a2 >> 1; wCr.w1 = b2 >> 1;
+			wCb.o = w16(o1 >> 1); wCr.o = w16(o2 >> 1); wCb.wd = wCr.wd = cwd;
+		}
+	}
+}
+
+// One prediction item of list `list`, class `cls`: luma + chroma of the partition -> the tile in LDS
+E264_DEV void pred_item(PredLds &L, const FrameCtx &f, const PredTile &t, int list, int cls, int desc)
+{
+	const int slot = PI_SLOT(desc), sub = PI_SUB(desc), shape = PI_SHAPE(desc);
+	const int mb = slot >> 2, q = slot & 3;
+	const int mbx = t.tx0 + (mb & (PT_W - 1)), mby = t.ty0 + mb / PT_W;
+	const bool w8 = shape == 0 || shape == 1, h8 = shape == 0 || shape == 2; // width / height 8 (else 4)
+	const int px0 = (mb & (PT_W - 1)) * 16 + (q & 1) * 8 + (sub & 1) * 4, py0 = (mb / PT_W) * 16 + (q >> 1) * 8 + (sub >> 1) * 4; // in the tile
+	gmotion_t mo = f.motion + (mby * f.wm + mbx);
+	const uint32_t mv = *(const gu32 *)&mo->mvs[list * 32 + (q * 4 + sub) * 2];
+	const int mx = (int)(int16_t)(mv & 0xffff), my = (int)mv >> 16;
+	const int pic = mo->refPic[list * 4 + q];
+	const int refIdx = mo->refIdx[list * 4 + q], refIdxX = mo->refIdx[(list ^ 1) * 4 + q];
+	const gu8 *ref = (const gu8 *)L.dpb[pic];
+	const int gx = t.tx0 * 16 + px0, gy = t.ty0 * 16 + py0;
+	// combination with list 0 / weights
+	cslice_t s = f.slices + (L.hdr[mb][2] >> 16);
+	const int idc = s->weighted_bipred_idc;
+	const bool second = list == 1 && refIdxX >= 0;
+	int mode = second ? 1 : 0;
+	Wod wY = {0, 1, 0, 0}, wCb = wY, wCr = wY;
+	if (idc != 0) {
+		mode = (idc == 1 ? (refIdxX < 0 || list == 1) : second) ? 2 : 0;
+		if (mode == 2)
+			pred_weights(s, list, refIdx, refIdxX, wY, wCb, wCr);
+	}
+	{ // chroma first: its window is small and its rows leave at once
+		const gu8 *cb = ref + f.psY;
+		const int XC = (gx >> 1) + (mx >> 3), YC = (gy >> 1) + (my >> 3);
+		uint32_t oc[2][4];
+		chroma4x4(cb, f.sC, f.W >> 1, f.H >> 1, XC, YC, mx & 7, my & 7, oc[0]);
+		chroma4x4(cb + (f.sC >> 1), f.sC, f.W >> 1, f.H >> 1, XC, YC, mx & 7, my & 7, oc[1]);
+		const int ncr = h8 ? 4 : 2;
+#pragma unroll
+		for (int pc = 0; pc < 2; pc++) {
+			uint32_t *tc = &L.c[pc][py0 >> 1][px0 >> 3];
+			uint16_t *hc = (uint16_t *)&L.c[pc][py0 >> 1][0] + (px0 >> 2);
+			const Wod &w = pc ? wCr : wCb;
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+				if (j < ncr) {
+					uint32_t v = oc[pc][j];
+					if (mode != 0) {
+						const uint32_t qv = w8 ? tc[j * PT_W * 2] : hc[j * PT_W * 4];
+						v = mode == 1 ? v_lerp_u8(qv, v, ONES8) : wpred4(qv, v, w);
+					}
+					if (w8) tc[j * PT_W * 2] = v;
+					else hc[j * PT_W * 4] = (uint16_t)v;
+				}
+		}
+	}
+	LumaSink sink;
+	sink.ty = &L.y[py0][px0 >> 2]; sink.mode = mode; sink.nr = h8 ? 8 : 4; sink.w8 = w8; sink.w = wY;
+	Row4 A[13];
+	load_window13(ref, f.sY, f.W, f.H, gx + (mx >> 2) - 2, gy + (my >> 2) - 2, A);
+	if (cls == 0) luma_1d(A, mx & 3, my & 3, sink);
+	else if (cls == 1) luma_2dh(A, my & 3, sink);
+	else luma_2dv(A, mx & 3, sink);
+}
+
+E264_DEV void pred_phase_items(PredLds &L, const FrameCtx &f, const PredTile &t, int list, int tid)
+{
+	const int n0 = L.cnt[0], n1 = L.cnt[1], n2 = L.cnt[2], n = n0 + n1 + n2;
+	for (int p = tid; p < n; p += PT_NT) {
+		const int cls = p < n0 ? 0 : p < n0 + n1 ? 1 : 2;
+		const int idx = p - (cls == 0 ? 0 : cls == 1 ? n0 : n0 + n1);
+		pred_item(L, f, t, list, cls, L.lst[cls][idx]);
+	}
+}
+E264_DEV void pred_phase_reset(PredLds &L, int tid)
+{
+	if (tid < 4) L.cnt[tid] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// phases 5, 6: residual of the inter macroblocks, one lane per coded block
+// ---------------------------------------------------------------------------------------------------------------------
+// residual item: bits 0..4 block (0..15 luma 4x4 in zig order, 16..23 chroma 4x4 Cb 0..3 / Cr 4..7, 24..27 luma 8x8), 5..11 macroblock
+E264_DEV void pred_phase_reslist(PredLds &L, int tid)
+{
+	uint16_t *l4 = &L.lst[0][0], *l8 = &L.lst[2][0];
+	for (int c = tid; c < PT_MBS * 32; c += PT_NT) {
+		const int mb = c >> 5, b = c & 31;
+		const uint32_t d0 = L.hdr[mb][0], coded = L.hdr[mb][3];
+		if ((d0 & 255) != E264_MB_INTER || coded == 0 || b >= 28)
+			continue;
+		const bool t8 = (d0 >> 8) & E264_MBF_T8x8;
+		if (b < 16) {
+			if (!t8 && (coded >> b & 1)) l4[lds_add(&L.rcnt[0], 1)] = (uint16_t)c;
+		} else if (b < 24) {
+			if ((coded >> b & 1) || (coded & E264_CODED_CHROMA_DC)) l4[lds_add(&L.rcnt[0], 1)] = (uint16_t)c;
+		} else if (t8 && (coded >> ((b - 24) * 4) & 1))
+			l8[lds_add(&L.rcnt[1], 1)] = (uint16_t)c;
+	}
+}
+
+// add 4 residuals to 4 samples: int16 wrap add then packus (edge264_residual.c:160-171)
+E264_DEV uint32_t add_res4(uint32_t px, int r0, int r1, int r2, int r3)
+{
+	return (uint32_t)clip255(w16((int)(px & 255) + r0)) | (uint32_t)clip255(w16((int)(px >> 8 & 255) + r1)) << 8 |
+	       (uint32_t)clip255(w16((int)(px >> 16 & 255) + r2)) << 16 | (uint32_t)clip255(w16((int)(px >> 24) + r3)) << 24;
+}
+
+// one 4x4 block (edge264_residual.c:108-187): dequantisation, both butterflies and the add in this lane's registers
+E264_DEV void res_item4(PredLds &L, const FrameCtx &f, int item)
+{
+	const int mb = item >> 5, b = item & 31;
+	const uint32_t d0 = L.hdr[mb][0], d1 = L.hdr[mb][1], coded = L.hdr[mb][3];
+	const bool t8 = (d0 >> 8) & E264_MBF_T8x8;
+	cslice_t s = f.slices + (L.hdr[mb][2] >> 16);
+	const gu8 *pl = f.payload + L.hdr[mb][4];
+	const gi16 *cdc = (const gi16 *)pl;
+	if (coded & E264_CODED_CHROMA_DC) pl += 16;
+	const bool chroma = b >= 16;
+	const int k = b & 15;        // luma block 0..15 / chroma block 0..7
+	const int pc = (k >> 2) & 1; // chroma plane
+	const int lumab = t8 ? __builtin_popcount(coded & 0x1111) * 128 : __builtin_popcount(coded & 0xffff) * 32;
+	const gu8 *co = chroma ? pl + lumab + __builtin_popcount((coded >> 16) & ((1u << k) - 1)) * 32
+	                       : pl + __builtin_popcount(coded & ((1u << k) - 1)) * 32;
+	const int qP = chroma ? (pc ? (int)(d1 & 255) : (int)(d0 >> 24)) : (int)(d0 >> 16 & 255);
+	const int sh = qP / 6, m = qP - sh * 6;
+	const int wl = chroma ? 4 + pc : 3; // weightScale4x4 list of an inter block: Y 3, Cb 4, Cr 5
+	const v4u wsv = *(const gv4u *)((const gu8 *)s + offsetof(E264SliceParams, weightScale4x4) + wl * 16);
+	const uint32_t ws[4] = {wsv.x, wsv.y, wsv.z, wsv.w};
+	const int na = na_byte(NA4_0, m), nb = na_byte(NA4_1, m), nc = na_byte(0x171412100e0dull, m);
+	// chroma DC of this block (transform_dc2x2, edge264_residual.c:456-480)
+	int dc = 0;
+	const bool has_dc = chroma && (coded & E264_CODED_CHROMA_DC);
+	if (has_dc) {
+		const int c0 = cdc[pc], c4 = cdc[4 + pc], c2 = cdc[2 + pc], c6 = cdc[6 + pc], n = k & 3;
+		const int v = n == 0 ? c0 + c4 + c2 + c6 : n == 1 ? c0 - c4 + c2 - c6 : n == 2 ? c0 + c4 - c2 - c6 : c0 - c4 - c2 + c6;
+		const int LS = (int)((ws[0] & 255u) * (uint32_t)na) << sh;
+		dc = (int)((uint32_t)v * (uint32_t)LS) >> 5;
+	}
+	const bool ac = chroma ? (coded >> (16 + k) & 1) : true;
+	int r[4][4]; // [row][col]
+	if (ac) {
+		const v4u cv0 = *(const gv4u *)co, cv1 = *(const gv4u *)(co + 16);
+		const uint32_t cw[8] = {cv0.x, cv0.y, cv0.z, cv0.w, cv1.x, cv1.y, cv1.z, cv1.w};
+		int tt[4][4]; // [xx][y]
+#pragma unroll
+		for (int y = 0; y < 4; y++) {
+			int d[4];
+#pragma unroll
+			for (int x = 0; x < 4; x++) {
+				const int pos = x * 4 + y;
+				const int lev = (int)(int16_t)(cw[pos >> 1] >> ((pos & 1) * 16));
+				const int wsb = (int)(ws[pos >> 2] >> ((pos & 3) * 8) & 255u);
+				const int nrm = (x & y & 1) ? nb : ((x | y) & 1) ? nc : na;
+				d[x] = (int)(((uint32_t)(lev * (wsb * nrm)) << sh) + 8u) >> 4;
+			}
+			if (chroma && y == 0) d[0] = dc; // chroma blocks take their DC from transform_dc2x2 (0 when there is none), residual.c:123-124
+			const int e0 = d[0] + d[2], e1 = d[0] - d[2], e2 = (d[1] >> 1) - d[3], e3 = (d[3] >> 1) + d[1];
+			const int add = y == 0 ? 32 : 0;
+			tt[0][y] = e0 + e3 + add; tt[1][y] = e1 + e2 + add; tt[2][y] = e1 - e2 + add; tt[3][y] = e0 - e3 + add;
+		}
+#pragma unroll
+		for (int x = 0; x < 4; x++) {
+			const int f0 = tt[x][0], f1 = tt[x][1], f2 = tt[x][2], f3 = tt[x][3];
+			const int g0 = f0 + f2, g1 = f0 - f2, g2 = (f1 >> 1) - f3, g3 = (f3 >> 1) + f1;
+			r[0][x] = sat16((g0 + g3) >> 6); r[1][x] = sat16((g1 + g2) >> 6); r[2][x] = sat16((g1 - g2) >> 6); r[3][x] = sat16((g0 - g3) >> 6);
+		}
+	} else { // add_dc4x4
+		const int v = (int)(int16_t)((dc + 32) >> 6);
+#pragma unroll
+		for (int y = 0; y < 4; y++)
+#pragma unroll
+			for (int x = 0; x < 4; x++) r[y][x] = v;
+	}
+	uint32_t *px;
+	int stride;
+	if (chroma) { px = &L.c[pc][(mb / PT_W) * 8 + ((k >> 1) & 1) * 4][(mb & (PT_W - 1)) * 2 + (k & 1)]; stride = PT_W * 2; }
+	else { px = &L.y[(mb / PT_W) * 16 + BYf(k)][(mb & (PT_W - 1)) * 4 + (BXf(k) >> 2)]; stride = PT_W * 4; }
+#pragma unroll
+	for (int y = 0; y < 4; y++)
+		px[y * stride] = add_res4(px[y * stride], r[y][0], r[y][1], r[y][2], r[y][3]);
+}
+
+// one 8x8 block (edge264_residual.c:194-343): int16 arithmetic with wraparound after a saturating dequantisation, as the
+// reference's vectors; packed 16-bit lanes reproduce it exactly
+E264_DEV void idct8_1dp(s16x2 d[8])
+{
+	const s16x2 s1 = {1, 1}, s2 = {2, 2};
+	const s16x2 d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5], d6 = d[6], d7 = d[7];
+	const s16x2 e0 = d0 + d4;
+	const s16x2 e1 = d5 - d3 - ((d7 >> s1) + d7);
+	const s16x2 e2 = d0 - d4;
+	const s16x2 e3 = d1 + d7 - ((d3 >> s1) + d3);
+	const s16x2 e4 = (d2 >> s1) - d6;
+	const s16x2 e5 = d7 - d1 + ((d5 >> s1) + d5);
+	const s16x2 e6 = (d6 >> s1) + d2;
+	const s16x2 e7 = d3 + d5 + ((d1 >> s1) + d1);
+	const s16x2 f0 = e0 + e6, f1 = (e7 >> s2) + e1, f2 = e2 + e4, f3 = (e5 >> s2) + e3;
+	const s16x2 f4 = e2 - e4, f5 = (e3 >> s2) - e5, f6 = e0 - e6, f7 = e7 - (e1 >> s2);
+	d[0] = f0 + f7; d[1] = f2 + f5; d[2] = f4 + f3; d[3] = f6 + f1;
+	d[4] = f6 - f1; d[5] = f4 - f3; d[6] = f2 - f5; d[7] = f0 - f7;
+}
+E264_DEV void res_item8(PredLds &L, const FrameCtx &f, int item)
+{
+	const int mb = item >> 5, bq = (item & 31) - 24;
+	const uint32_t d0 = L.hdr[mb][0], coded = L.hdr[mb][3];
+	cslice_t s = f.slices + (L.hdr[mb][2] >> 16);
+	const gu8 *pl = f.payload + L.hdr[mb][4];
+	if (coded & E264_CODED_CHROMA_DC) pl += 16;
+	const gu8 *co = pl + __builtin_popcount(coded & 0x1111 & ((1u << (bq * 4)) - 1)) * 128;
+	const gu8 *wsp = (const gu8 *)s + offsetof(E264SliceParams, weightScale8x8) + 64; // list 1: inter Y
+	const int qP = (int)(d0 >> 16 & 255), div = qP / 6, m = qP - div * 6;
+	// pass 1 (residual.c:250-296): for every j, the 1-D transform over i of d[i][j] = level c[i*8+j] dequantised; packed pairs (j, j+1)
+	s16x2 t[8][4]; // [i][pair of j]
+#pragma unroll
+	for (int i = 0; i < 8; i++) {
+		const v4u cv = *(const gv4u *)(co + i * 16);
+		const v2u wv = *(const gv2u *)(wsp + i * 8);
+		const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w}, ww[2] = {wv.x, wv.y};
+#pragma unroll
+		for (int jp = 0; jp < 4; jp++) {
+			int dq[2];
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				const int j = jp * 2 + h, pos = i * 8 + j;
+				const int lev = (int)(int16_t)(cw[jp] >> (h * 16));
+				const int LS = (int)(ww[j >> 2] >> ((j & 3) * 8) & 255u) * norm8(m, pos);
+				dq[h] = div < 6 ? sat16((lev * LS + (1 << (5 - div))) >> (6 - div)) : (int)(int16_t)(lev * (int)(int16_t)(LS << (div - 6)));
+			}
+			const s16x2 v = {(short)dq[0], (short)dq[1]};
+			t[i][jp] = v;
+		}
+	}
+#pragma unroll
+	for (int jp = 0; jp < 4; jp++) {
+		s16x2 d[8];
+#pragma unroll
+		for (int i = 0; i < 8; i++) d[i] = t[i][jp];
+		idct8_1dp(d);
+#pragma unroll
+		for (int i = 0; i < 8; i++) t[i][jp] = d[i];
+	}
+	// +32 on the elements with j == 0 (residual.c:298), then pass 2 over j for every i; output sample (row j, column i).
+	// Repack: u[j][pair of i] = (t[i][j], t[i+1][j])
+	s16x2 u[8][4];
+#pragma unroll
+	for (int ip = 0; ip < 4; ip++)
+#pragma unroll
+		for (int jp = 0; jp < 4; jp++) {
+			const uint32_t a = as_u(t[2 * ip][jp]), b = as_u(t[2 * ip + 1][jp]);
+			u[2 * jp][ip] = as_s2(v_perm(b, a, 0x05040100u));     // (a.lo, b.lo)
+			u[2 * jp + 1][ip] = as_s2(v_perm(b, a, 0x07060302u)); // (a.hi, b.hi)
+		}
+	const s16x2 r32 = {32, 32}, s6 = {6, 6};
+#pragma unroll
+	for (int ip = 0; ip < 4; ip++) {
+		s16x2 d[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) d[j] = u[j][ip];
+		d[0] = d[0] + r32;
+		idct8_1dp(d);
+#pragma unroll
+		for (int j = 0; j < 8; j++) u[j][ip] = d[j] >> s6;
+	}
+	uint32_t *px = &L.y[(mb / PT_W) * 16 + (bq >> 1) * 8][(mb & (PT_W - 1)) * 4 + (bq & 1) * 2];
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+#pragma unroll
+		for (int w = 0; w < 2; w++) {
+			const s16x2 ra = u[j][2 * w], rb = u[j][2 * w + 1];
+			px[j * PT_W * 4 + w] = add_res4(px[j * PT_W * 4 + w], ra.x, ra.y, rb.x, rb.y);
+		}
+	}
+}
+E264_DEV void pred_phase_residual(PredLds &L, const FrameCtx &f, int tid)
+{
+	const int n4 = L.rcnt[0], n8 = L.rcnt[1];
+	const uint16_t *l4 = &L.lst[0][0], *l8 = &L.lst[2][0];
+	for (int p = tid; p < n4; p += PT_NT)
+		res_item4(L, f, l4[p]);
+	for (int p = tid; p < n8; p += PT_NT)
+		res_item8(L, f, l8[p]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// phase 7: the tile leaves as whole rows, 16 bytes per lane; pieces of macroblocks this kernel does not own are skipped
+// ---------------------------------------------------------------------------------------------------------------------
+E264_DEV void pred_phase_flush(const PredLds &L, const FrameCtx &f, const PredTile &t, int tid)
+{
+	gu8 *Yb = f.cur + (size_t)(t.ty0 * 16) * f.sY + t.tx0 * 16;
+	for (int i = tid; i < PT_H * 16 * PT_W; i += PT_NT) { // luma: 128 rows x 16 pieces
+		const int row = i / PT_W, c = i & (PT_W - 1), mb = (row >> 4) * PT_W + c;
+		if (L.staged[mb >> 5] >> (mb & 31) & 1)
+			*(gv4u *)(Yb + (size_t)row * f.sY + c * 16) = *(const v4u *)&L.y[row][c * 4];
+	}
+	for (int i = tid; i < 2 * PT_H * 8 * (PT_W / 2); i += PT_NT) { // chroma: 2 planes x 64 rows x 8 pieces (2 macroblocks each)
+		const int pc = i / (PT_H * 8 * (PT_W / 2)), rem = i - pc * (PT_H * 8 * (PT_W / 2));
+		const int row = rem / (PT_W / 2), c = rem & (PT_W / 2 - 1), mb = (row >> 3) * PT_W + c * 2;
+		const uint32_t st = L.staged[mb >> 5] >> (mb & 31) & 3; // mb is even: both bits in the same word
+		gu8 *dst = plane_base(f, f.cur, 1 + pc) + (size_t)(t.ty0 * 8 + row) * f.sC + t.tx0 * 8 + c * 16;
+		const v4u v = *(const v4u *)&L.c[pc][row][c * 4];
+		if (st == 3) *(gv4u *)dst = v;
+		else if (st == 1) { const v2u h = {v.x, v.y}; *(gv2u *)dst = h; }
+		else if (st == 2) { const v2u h = {v.z, v.w}; *(gv2u *)(dst + 8) = h; }
+	}
+}
+
+} // namespace
+#endif
