@@ -211,16 +211,23 @@ E264_DEV uint32_t pack4(s16x2 lo, s16x2 hi) { return v_perm(as_u(hi), as_u(lo), 
 //   mode 1 average   (no weighting, list 1 on top of list 0)              tile = (q + p + 1) >> 1
 //   mode 2 weighted                                                       tile = wpred(q, p)
 struct Wod { int w0, w1, o, wd; };
-E264_DEV int wpred1(int q, int p, const Wod &w)
-{ // maddshrL, edge264_inter.c:17-21: pmaddubsw (int8 weights), adds16, sra, packus
-	int x = sat16(q * (int)(int8_t)w.w0 + p * (int)(int8_t)w.w1);
-	x = sat16(x + (int)(int16_t)w.o);
-	return clip255(x >> w.wd);
+// maddshrL, edge264_inter.c:17-21, on two samples at a time exactly as the reference's vector code runs it: pmaddubsw
+// (int8 weights, the two products added with signed saturation), adds16 (offset, saturating), sra, packus.  Packed
+// 16-bit lanes with the saturating adds spelled out (v_pk_add_i16 clamp).
+E264_DEV s16x2 wpred2(s16x2 q, s16x2 p, const Wod &w)
+{
+	const short w0 = (short)(int8_t)w.w0, w1 = (short)(int8_t)w.w1, o = (short)w.o, wd = (short)w.wd;
+	const s16x2 vw0 = {w0, w0}, vw1 = {w1, w1}, vo = {o, o}, vwd = {wd, wd}, z = {0, 0}, m = {255, 255};
+	s16x2 x = __builtin_elementwise_add_sat(q * vw0, p * vw1); // |255 * 128| fits 16 bits: the products are exact
+	x = __builtin_elementwise_add_sat(x, vo);
+	return __builtin_elementwise_min(__builtin_elementwise_max(x >> vwd, z), m);
 }
 E264_DEV uint32_t wpred4(uint32_t q, uint32_t p, const Wod &w)
 {
-	return (uint32_t)wpred1(q & 255, p & 255, w) | (uint32_t)wpred1(q >> 8 & 255, p >> 8 & 255, w) << 8 |
-	       (uint32_t)wpred1(q >> 16 & 255, p >> 16 & 255, w) << 16 | (uint32_t)wpred1(q >> 24, p >> 24, w) << 24;
+	// (a scalar per-byte version of this -- sat16 / clip255 on ints, four times per dword -- came out of hipcc 7.2 with 255 in
+	// the two upper bytes on the device although the host build of the same source was right; the packed form is also half
+	// the instructions)
+	return pack4(wpred2(pair_at<0>(0, q), pair_at<0>(0, p), w), wpred2(pair_at<2>(0, q), pair_at<2>(0, p), w));
 }
 struct LumaSink {
 	uint32_t *ty;  // first dword of the partition in the tile
