@@ -115,6 +115,12 @@ E264_DEV uint32_t v_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __buil
 E264_DEV uint32_t v_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); } // ({hi,lo} >> 8*(sh&3))
 E264_DEV uint32_t v_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }   // ({hi,lo} >> (sh&31))
 E264_DEV uint32_t v_lerp_u8(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_lerp(a, b, c); }              // per byte (a + b + (c & 1)) >> 1
+E264_DEV uint32_t v_sat_pk_u8_i16(uint32_t v) // two int16 -> two bytes with unsigned saturation in bits 15:0; no builtin
+{
+	uint32_t r;
+	asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(v));
+	return r;
+}
 #endif
 // ---- packed 16-bit arithmetic (v_pk_*_i16: two samples per VALU instruction) ------------------------------------------
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -132,6 +138,17 @@ E264_DEV void pairs9(const uint32_t w[3], s16x2 Q[8])
 	Q[0] = pair_at<0>(w[1], w[0]); Q[1] = pair_at<1>(w[1], w[0]); Q[2] = pair_at<2>(w[1], w[0]); Q[3] = pair_at<3>(w[1], w[0]);
 	Q[4] = pair_at<0>(w[2], w[1]); Q[5] = pair_at<1>(w[2], w[1]); Q[6] = pair_at<2>(w[2], w[1]); Q[7] = pair_at<3>(w[2], w[1]);
 }
+// the same taps on pairs of SAMPLES (0..255 each): the three sums cannot carry from one half into the other, so they are
+// plain 32-bit adds (v_add_u32 issues at twice the rate of the packed and three-operand instructions on gfx950:
+// tools/calib/valu_rate.hip)
+E264_DEV s16x2 tap6u(s16x2 a, s16x2 b, s16x2 c, s16x2 d, s16x2 e, s16x2 f)
+{
+	const s16x2 k5 = {-5, -5}, k20 = {20, 20};
+	const s16x2 af = as_s2(as_u(a) + as_u(f)), be = as_s2(as_u(b) + as_u(e)), cd = as_s2(as_u(c) + as_u(d));
+	return be * k5 + (cd * k20 + af);
+}
+// two pairs of int16 -> 4 bytes, each clipped to 0..255 (packus)
+E264_DEV uint32_t packus4(s16x2 lo, s16x2 hi) { return v_perm(v_sat_pk_u8_i16(as_u(hi)), v_sat_pk_u8_i16(as_u(lo)), 0x05040100u); }
 E264_DEV s16x2 tap6p(s16x2 a, s16x2 b, s16x2 c, s16x2 d, s16x2 e, s16x2 f)
 {
 	const s16x2 k5 = {5, 5}, k20 = {20, 20};

@@ -1982,17 +1982,24 @@ __attribute__((amdgpu_waves_per_eu(E264_PRED_WAVES_PER_EU, E264_PRED_WAVES_PER_E
 	if (bx >= ntx * nty)
 		return;
 	const PredTile t = {(bx % ntx) * PT_W, (bx / ntx) * PT_H};
+	PH_DECL;
 	pred_phase_setup(L, f, t, tid);
+	PH(0);
 	__syncthreads();
 	{ // nothing for this kernel in the tile (every tile of an I frame)? leave at once
 		const int kind = tid < PT_MBS ? (int)(L.hdr[tid][0] & 255) : 0;
 		if (!__syncthreads_or(kind == E264_MB_INTER || kind == E264_MB_PCM))
 			return;
 	}
+	PH(1);
 	pred_phase_classify(L, f, t, 0, tid);
+	PH(2);
 	__syncthreads();
+	PH(3);
 	pred_phase_items(L, f, t, 0, tid);
+	PH(4);
 	__syncthreads();
+	PH(5);
 	if (L.any_l1) { // uniform: written before the barrier above
 		pred_phase_reset(L, tid);
 		__syncthreads();
@@ -2001,11 +2008,18 @@ __attribute__((amdgpu_waves_per_eu(E264_PRED_WAVES_PER_EU, E264_PRED_WAVES_PER_E
 		pred_phase_items(L, f, t, 1, tid);
 		__syncthreads();
 	}
+	PH(6);
 	pred_phase_reslist(L, tid);
+	PH(7);
 	__syncthreads();
+	PH(8);
 	pred_phase_residual(L, f, tid);
+	PH(9);
 	__syncthreads();
+	PH(10);
 	pred_phase_flush(L, f, t, tid);
+	PH(11);
+	PH_FLUSH(tid & 63);
 }
 
 // deblocking parameters (bS, alpha, beta, indexA) of every macroblock: one wave per macroblock, few

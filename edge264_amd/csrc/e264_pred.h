@@ -52,7 +52,9 @@ struct __attribute__((aligned(16))) PredLds {
 	uint32_t c[2][PT_H * 8][PT_W * 2];  // Cb, Cr
 	uint32_t hdr[PT_MBS][8];            // E264Mb records (kind 0 = ABSENT for macroblocks outside the frame)
 	uint16_t lst[3][PT_LIST];           // prediction items by class; then the residual lists (4x4: lst[0..1], 8x8: lst[2])
-	int cnt[4];                         // items per class
+	uint32_t mvq[4][PT_NT];             // motion of every quadrant for the list being predicted: its four 4x4 vectors ...
+	uint32_t refq[PT_NT];               // ... and DPB slot | refIdx << 8 | refIdx of the other list << 16 | weighted_bipred_idc << 24
+	int cnt[6];                         // items per class
 	int rcnt[2];                        // residual items: 4x4 blocks, 8x8 blocks
 	uint32_t staged[PT_MBS / 32];       // macroblocks this kernel writes (inter, PCM)
 	int any_l1;                         // some quadrant of the tile uses list 1
@@ -72,7 +74,7 @@ struct PredTile { int tx0, ty0; };     // first macroblock of the tile
 // ---------------------------------------------------------------------------------------------------------------------
 E264_DEV void pred_phase_setup(PredLds &L, const FrameCtx &f, const PredTile &t, int tid)
 {
-	if (tid < 4) L.cnt[tid] = 0;
+	if (tid < 6) L.cnt[tid] = 0;
 	if (tid < 2) L.rcnt[tid] = 0;
 	if (tid < PT_MBS / 32) L.staged[tid] = 0;
 	if (tid == 0) L.any_l1 = 0;
@@ -89,16 +91,28 @@ E264_DEV void pred_phase_setup(PredLds &L, const FrameCtx &f, const PredTile &t,
 // ---------------------------------------------------------------------------------------------------------------------
 // phase 1: one thread per quadrant: partition shape of list `list`, items into the class lists; PCM samples
 // ---------------------------------------------------------------------------------------------------------------------
+// Class of a partition = the data flow its quarter-sample position needs (edge264_inter.c:416-968):
+//   0 G   integer position                      3 D   both fractions odd: b of one row averaged with h of one column
+//   1 B   yFrac == 0: b (+ G)                   4 JH  xFrac == 2, yFrac != 0: horizontal taps, then sixtapHV down the columns
+//   2 H   xFrac == 0: h (+ G)                   5 JV  yFrac == 2, xFrac odd: vertical taps, then sixtapHV along the rows
+// Lists: class c and class 5 - c share one array (c from the front, 5 - c from the back): the six lists together never hold
+// more than PT_LIST items.
 E264_DEV int pred_class(uint32_t mv)
-{ // 0: one-dimensional (G, b, h and the diagonal positions), 1: xFrac == 2 (horizontal then vertical), 2: yFrac == 2, xFrac odd
+{
 	const int xF = mv & 3, yF = mv >> 16 & 3;
-	return (xF == 2 && yF != 0) ? 1 : ((xF & 1) && yF == 2) ? 2 : 0;
+	if (yF == 0) return xF == 0 ? 0 : 1;
+	if (xF == 0) return 2;
+	if (xF == 2) return 4;
+	return yF == 2 ? 5 : 3;
+}
+E264_DEV uint16_t *pred_list_slot(PredLds &L, int cls, int idx)
+{
+	return cls < 3 ? &L.lst[cls][idx] : &L.lst[5 - cls][PT_LIST - 1 - idx];
 }
 E264_DEV void pred_push(PredLds &L, uint32_t mv, int desc)
 {
 	const int cls = pred_class(mv);
-	const int slot = lds_add(&L.cnt[cls], 1);
-	L.lst[cls][slot] = (uint16_t)desc;
+	*pred_list_slot(L, cls, lds_add(&L.cnt[cls], 1)) = (uint16_t)desc;
 }
 E264_DEV void pred_phase_classify(PredLds &L, const FrameCtx &f, const PredTile &t, int list, int tid)
 {
@@ -125,10 +139,20 @@ E264_DEV void pred_phase_classify(PredLds &L, const FrameCtx &f, const PredTile 
 	gmotion_t mo = f.motion + (mby * f.wm + mbx);
 	if (list == 0 && mo->refPic[4 + q] >= 0)
 		L.any_l1 = 1;
-	if (mo->refPic[list * 4 + q] < 0)
+	const int pic = mo->refPic[list * 4 + q];
+	if (pic < 0)
 		return;
 	const v4u m = *(const gv4u *)&mo->mvs[list * 32 + q * 8]; // the quadrant's four 4x4 vectors: (0,0) (4,0) (0,4) (4,4)
 	const int base = tid;
+	// everything the prediction of this quadrant needs goes to LDS here, so that the item phase starts with ONE round
+	// trip to memory (its reference windows) instead of a chain motion -> slot table -> window.
+	// (Tried: entering the quadrants of one 16x16 / 16x8 partition as neighbours of the class list so that their row
+	// fetches share cache lines within an instruction -- no gain, tools/calib/load_rate.hip: the vector memory path takes
+	// 1.5 - 2.5 cycles per lane-row whether the lanes are neighbours or scattered.)
+	cslice_t s = f.slices + (L.hdr[mb][2] >> 16);
+	L.mvq[0][tid] = m.x; L.mvq[1][tid] = m.y; L.mvq[2][tid] = m.z; L.mvq[3][tid] = m.w;
+	L.refq[tid] = (uint32_t)(uint8_t)pic | (uint32_t)(uint8_t)mo->refIdx[list * 4 + q] << 8 |
+	              (uint32_t)(uint8_t)mo->refIdx[(list ^ 1) * 4 + q] << 16 | (uint32_t)(uint8_t)s->weighted_bipred_idc << 24;
 	if (m.x == m.y && m.x == m.z && m.x == m.w) {
 		pred_push(L, m.x, base);
 	} else if (m.x == m.y && m.z == m.w) { // two 8x4
@@ -161,26 +185,33 @@ E264_DEV uint32_t ref_dword(const gu8 *row, int x, int Wb)
 	return v;
 }
 struct Row4 { uint32_t a0, a1, a2, a3; };
-// 13 x 16 bytes around (X, Y), byte-aligned so that byte c of row r is sample (X + c, Y + r)
-E264_DEV void load_window13(const gu8 *plane, int sY, int W, int H, int X, int Y, Row4 A[13])
+// NR x 16 bytes around (X, Y): the loads (nothing here uses a loaded value) ...
+template <int NR>
+E264_DEV void load_window(const gu8 *plane, int sY, int W, int H, int X, int Y, Row4 *A)
 {
 	const int XA = X & ~3;
-	const uint32_t o = (uint32_t)X & 3u;
-	if (XA >= 0 && XA + 12 <= W - 4) { // the common case: one 16-byte load per row
+	if (XA >= 0 && XA + 12 <= W - 4 && Y >= 0 && Y + NR - 1 <= H - 1) { // the common case: inside the frame, one 16-byte load per row
+		const gu8 *p = plane + (size_t)Y * sY + XA;
 #pragma unroll
-		for (int r = 0; r < 13; r++) {
-			const v4u v = *(const gv4u *)(plane + (size_t)min(max(Y + r, 0), H - 1) * sY + XA);
+		for (int r = 0; r < NR; r++) {
+			const v4u v = *(const gv4u *)(p + (size_t)r * sY);
 			A[r].a0 = v.x; A[r].a1 = v.y; A[r].a2 = v.z; A[r].a3 = v.w;
 		}
 	} else {
 #pragma unroll
-		for (int r = 0; r < 13; r++) {
+		for (int r = 0; r < NR; r++) {
 			const gu8 *row = plane + (size_t)min(max(Y + r, 0), H - 1) * sY;
 			A[r].a0 = ref_dword(row, XA, W); A[r].a1 = ref_dword(row, XA + 4, W); A[r].a2 = ref_dword(row, XA + 8, W); A[r].a3 = ref_dword(row, XA + 12, W);
 		}
 	}
+}
+// ... and the byte alignment: afterwards byte c of row r is sample (X + c, Y + r)
+template <int NR>
+E264_DEV void align_window(Row4 *A, int X)
+{
+	const uint32_t o = (uint32_t)X & 3u;
 #pragma unroll
-	for (int r = 0; r < 13; r++) {
+	for (int r = 0; r < NR; r++) {
 		const uint32_t w0 = A[r].a0, w1 = A[r].a1, w2 = A[r].a2, w3 = A[r].a3;
 		A[r].a0 = v_alignbyte(w1, w0, o); A[r].a1 = v_alignbyte(w2, w1, o); A[r].a2 = v_alignbyte(w3, w2, o); A[r].a3 = w3 >> (8 * o);
 	}
@@ -199,7 +230,7 @@ E264_DEV void htaps8(const Row4 &a, s16x2 T[4])
 	pairs12(a, Q);
 #pragma unroll
 	for (int p = 0; p < 4; p++)
-		T[p] = tap6p(Q[2 * p], Q[2 * p + 1], Q[2 * p + 2], Q[2 * p + 3], Q[2 * p + 4], Q[2 * p + 5]);
+		T[p] = tap6u(Q[2 * p], Q[2 * p + 1], Q[2 * p + 2], Q[2 * p + 3], Q[2 * p + 4], Q[2 * p + 5]);
 }
 // two pairs of values 0..255 -> 4 bytes
 E264_DEV uint32_t pack4(s16x2 lo, s16x2 hi) { return v_perm(as_u(hi), as_u(lo), 0x06040200u); }
@@ -217,17 +248,17 @@ struct Wod { int w0, w1, o, wd; };
 E264_DEV s16x2 wpred2(s16x2 q, s16x2 p, const Wod &w)
 {
 	const short w0 = (short)(int8_t)w.w0, w1 = (short)(int8_t)w.w1, o = (short)w.o, wd = (short)w.wd;
-	const s16x2 vw0 = {w0, w0}, vw1 = {w1, w1}, vo = {o, o}, vwd = {wd, wd}, z = {0, 0}, m = {255, 255};
+	const s16x2 vw0 = {w0, w0}, vw1 = {w1, w1}, vo = {o, o}, vwd = {wd, wd};
 	s16x2 x = __builtin_elementwise_add_sat(q * vw0, p * vw1); // |255 * 128| fits 16 bits: the products are exact
 	x = __builtin_elementwise_add_sat(x, vo);
-	return __builtin_elementwise_min(__builtin_elementwise_max(x >> vwd, z), m);
+	return x >> vwd; // the caller packs with unsigned saturation (packus)
 }
 E264_DEV uint32_t wpred4(uint32_t q, uint32_t p, const Wod &w)
 {
 	// (a scalar per-byte version of this -- sat16 / clip255 on ints, four times per dword -- came out of hipcc 7.2 with 255 in
 	// the two upper bytes on the device although the host build of the same source was right; the packed form is also half
 	// the instructions)
-	return pack4(wpred2(pair_at<0>(0, q), pair_at<0>(0, p), w), wpred2(pair_at<2>(0, q), pair_at<2>(0, p), w));
+	return packus4(wpred2(pair_at<0>(0, q), pair_at<0>(0, p), w), wpred2(pair_at<2>(0, q), pair_at<2>(0, p), w));
 }
 struct LumaSink {
 	uint32_t *ty;  // first dword of the partition in the tile
@@ -246,56 +277,107 @@ E264_DEV void sink_row(const LumaSink &k, int j, uint32_t v0, uint32_t v1)
 	if (k.w8) d[1] = v1;
 }
 
-// One-dimensional positions (edge264_inter.c:439-557): G, b, h and their quarter-sample averages.
-//   yF == 0: b of row 2, averaged with G of column 2 + (xF == 3)        xF == 0: h of column 2, averaged with G of row 2 + (yF == 3)
-//   both odd: b of row 2 + (yF == 3) averaged with h of column 2 + (xF == 3)
-// Rows are consumed as a stream: output row j is complete once window row j + 5 has been taken apart.
-E264_DEV void luma_1d(const Row4 A[13], int xF, int yF, const LumaSink &sink)
+// Rounding tails: (v + 16) >> 5 and the centre's (x3 + 32) >> 6, still 16 bits wide; packus4 clips and packs them.
+E264_DEV s16x2 rs5(s16x2 v) { const s16x2 r = {16, 16}, s = {5, 5}; return (v + r) >> s; }
+E264_DEV s16x2 centre6r(s16x2 t0, s16x2 t1, s16x2 t2, s16x2 t3, s16x2 t4, s16x2 t5)
+{ // sixtapHV + (x + 32) >> 6: 16-bit lanes wrap exactly like the reference's int16 vectors (edge264_inter.c:4-9,14)
+	const s16x2 s2 = {2, 2}, s6 = {6, 6}, r32 = {32, 32};
+	const s16x2 af = t0 + t5, be = t1 + t4, cd = t2 + t3;
+	const s16x2 x1 = af - be;
+	const s16x2 x2 = (x1 >> s2) + (cd - be);
+	const s16x2 x3 = (x2 >> s2) + cd;
+	return (x3 + r32) >> s6;
+}
+// columns 2 + dx .. 9 + dx of an aligned row, as bytes
+E264_DEV void gcols(const Row4 &a, uint32_t dx, uint32_t g[2])
 {
-	const bool needB = xF != 0, needH = yF != 0;
-	const uint32_t dx = xF == 3, dy = yF == 3;
-	const bool diag = (xF & 1) && (yF & 1);
-	const bool half_only = (xF == 2 && yF == 0) || (xF == 0 && yF == 2);
-	uint32_t g[13][2]; // columns 2+dx .. 9+dx of every row
+	const uint32_t s0 = v_alignbyte(a.a1, a.a0, dx), s1 = v_alignbyte(a.a2, a.a1, dx), s2 = v_alignbyte(a.a3, a.a2, dx);
+	g[0] = v_alignbyte(s1, s0, 2); g[1] = v_alignbyte(s2, s1, 2);
+}
+// b of one aligned row: 8 horizontal half samples, clipped, as bytes
+E264_DEV void brow(const Row4 &a, uint32_t b[2])
+{
+	s16x2 T[4];
+	htaps8(a, T);
+	b[0] = packus4(rs5(T[0]), rs5(T[1])); b[1] = packus4(rs5(T[2]), rs5(T[3]));
+}
+// h of one output row from six rows of byte columns
+E264_DEV void hrow(const uint32_t g[][2], int j, uint32_t h[2])
+{
+	s16x2 V[4];
+#pragma unroll
+	for (int p = 0; p < 4; p++) {
+		const int w = p >> 1;
+		s16x2 c[6];
+#pragma unroll
+		for (int k = 0; k < 6; k++)
+			c[k] = (p & 1) ? pair_at<2>(0, g[j + k][w]) : pair_at<0>(0, g[j + k][w]);
+		V[p] = rs5(tap6u(c[0], c[1], c[2], c[3], c[4], c[5]));
+	}
+	h[0] = packus4(V[0], V[1]); h[1] = packus4(V[2], V[3]);
+}
+
+// class 0: integer position.  A holds window rows 2..9 only (8 rows), aligned.
+E264_DEV void luma_g(const Row4 A[8], const LumaSink &sink)
+{
+#pragma unroll
+	for (int j = 0; j < 8; j++)
+		sink_row(sink, j, v_alignbyte(A[j].a1, A[j].a0, 2), v_alignbyte(A[j].a2, A[j].a1, 2));
+}
+// class 1: yFrac == 0 (edge264_inter.c:439-470): b of row 2; xFrac odd: averaged with G of column 2 + (xF == 3).  A: rows 2..9.
+E264_DEV void luma_b(const Row4 A[8], int xF, const LumaSink &sink)
+{
+	const uint32_t dx = xF == 3;
+	const bool q = xF != 2;
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		uint32_t b[2], g[2];
+		brow(A[j], b);
+		gcols(A[j], dx, g);
+		sink_row(sink, j, v_lerp_u8(b[0], q ? g[0] : b[0], ONES8), v_lerp_u8(b[1], q ? g[1] : b[1], ONES8));
+	}
+}
+// class 2: xFrac == 0 (edge264_inter.c:472-508): h of column 2; yFrac odd: averaged with G of row 2 + (yF == 3)
+E264_DEV void luma_h(const Row4 A[13], int yF, const LumaSink &sink)
+{
+	const bool dy = yF == 3, q = yF != 2;
+	uint32_t g[13][2];
 #pragma unroll
 	for (int r = 0; r < 13; r++) {
-		const uint32_t s0 = v_alignbyte(A[r].a1, A[r].a0, dx), s1 = v_alignbyte(A[r].a2, A[r].a1, dx), s2 = v_alignbyte(A[r].a3, A[r].a2, dx);
-		g[r][0] = v_alignbyte(s1, s0, 2); g[r][1] = v_alignbyte(s2, s1, 2);
+		g[r][0] = v_alignbyte(A[r].a1, A[r].a0, 2); g[r][1] = v_alignbyte(A[r].a2, A[r].a1, 2);
 		if (r < 5)
 			continue;
 		const int j = r - 5;
+		uint32_t h[2];
+		hrow(g, j, h);
 		const uint32_t G0 = dy ? g[j + 3][0] : g[j + 2][0], G1 = dy ? g[j + 3][1] : g[j + 2][1];
-		uint32_t b0 = G0, b1 = G1, h0 = G0, h1 = G1;
-		if (needB) {
-			Row4 s;
-			s.a0 = dy ? A[j + 3].a0 : A[j + 2].a0; s.a1 = dy ? A[j + 3].a1 : A[j + 2].a1;
-			s.a2 = dy ? A[j + 3].a2 : A[j + 2].a2; s.a3 = dy ? A[j + 3].a3 : A[j + 2].a3;
-			s16x2 T[4];
-			htaps8(s, T);
-			b0 = pack4(half5p(T[0]), half5p(T[1])); b1 = pack4(half5p(T[2]), half5p(T[3]));
-		}
-		if (needH) {
-			s16x2 V[4];
+		sink_row(sink, j, v_lerp_u8(h[0], q ? G0 : h[0], ONES8), v_lerp_u8(h[1], q ? G1 : h[1], ONES8));
+	}
+}
+// class 3: both fractions odd (edge264_inter.c:510-557): b of row 2 + (yF == 3) averaged with h of column 2 + (xF == 3)
+E264_DEV void luma_d(const Row4 A[13], int xF, int yF, const LumaSink &sink)
+{
+	const uint32_t dx = xF == 3;
+	const bool dy = yF == 3;
+	uint32_t g[13][2];
 #pragma unroll
-			for (int p = 0; p < 4; p++) {
-				const int w = p >> 1, I = (p & 1) * 2; // bytes I, I+1 of g[r][w]
-				s16x2 c[6];
-#pragma unroll
-				for (int k = 0; k < 6; k++)
-					c[k] = I ? pair_at<2>(0, g[j + k][w]) : pair_at<0>(0, g[j + k][w]);
-				V[p] = half5p(tap6p(c[0], c[1], c[2], c[3], c[4], c[5]));
-			}
-			h0 = pack4(V[0], V[1]); h1 = pack4(V[2], V[3]);
-		}
-		// op1 = b | h | G, op2 = the quarter-sample partner (itself for the half / integer positions)
-		const uint32_t p0 = needB ? b0 : h0, p1 = needB ? b1 : h1;
-		const uint32_t q0 = diag ? h0 : half_only ? p0 : G0, q1 = diag ? h1 : half_only ? p1 : G1;
-		sink_row(sink, j, v_lerp_u8(p0, q0, ONES8), v_lerp_u8(p1, q1, ONES8));
+	for (int r = 0; r < 13; r++) {
+		gcols(A[r], dx, g[r]);
+		if (r < 5)
+			continue;
+		const int j = r - 5;
+		Row4 s;
+		s.a0 = dy ? A[j + 3].a0 : A[j + 2].a0; s.a1 = dy ? A[j + 3].a1 : A[j + 2].a1;
+		s.a2 = dy ? A[j + 3].a2 : A[j + 2].a2; s.a3 = dy ? A[j + 3].a3 : A[j + 2].a3;
+		uint32_t b[2], h[2];
+		brow(s, b);
+		hrow(g, j, h);
+		sink_row(sink, j, v_lerp_u8(b[0], h[0], ONES8), v_lerp_u8(b[1], h[1], ONES8));
 	}
 }
 
-// xFrac == 2, yFrac != 0 (edge264_inter.c:611-646, 779-802, 929-966): horizontal taps of 13 rows, then sixtapHV down the
-// columns; yFrac odd: averaged with b of row 2 + (yF == 3)
+// class 4: xFrac == 2, yFrac != 0 (edge264_inter.c:611-646, 779-802, 929-966): horizontal taps of 13 rows, then sixtapHV down
+// the columns; yFrac odd: averaged with b of row 2 + (yF == 3)
 E264_DEV void luma_2dh(const Row4 A[13], int yF, const LumaSink &sink)
 {
 	const bool dy = yF == 3, q = yF != 2;
@@ -309,17 +391,17 @@ E264_DEV void luma_2dh(const Row4 A[13], int yF, const LumaSink &sink)
 		s16x2 J[4], B[4];
 #pragma unroll
 		for (int p = 0; p < 4; p++) {
-			J[p] = centre6p(T[j][p], T[j + 1][p], T[j + 2][p], T[j + 3][p], T[j + 4][p], T[j + 5][p]);
-			B[p] = half5p(dy ? T[j + 3][p] : T[j + 2][p]);
+			J[p] = centre6r(T[j][p], T[j + 1][p], T[j + 2][p], T[j + 3][p], T[j + 4][p], T[j + 5][p]);
+			B[p] = rs5(dy ? T[j + 3][p] : T[j + 2][p]);
 		}
-		const uint32_t j0 = pack4(J[0], J[1]), j1 = pack4(J[2], J[3]);
-		const uint32_t b0 = pack4(B[0], B[1]), b1 = pack4(B[2], B[3]);
+		const uint32_t j0 = packus4(J[0], J[1]), j1 = packus4(J[2], J[3]);
+		const uint32_t b0 = packus4(B[0], B[1]), b1 = packus4(B[2], B[3]);
 		sink_row(sink, j, v_lerp_u8(j0, q ? b0 : j0, ONES8), v_lerp_u8(j1, q ? b1 : j1, ONES8));
 	}
 }
 
-// yFrac == 2, xFrac odd (edge264_inter.c:559-609, 741-777, 887-927): vertical taps of 13 columns, then sixtapHV along the
-// rows; averaged with h of column 2 + (xF == 3)
+// class 5: yFrac == 2, xFrac odd (edge264_inter.c:559-609, 741-777, 887-927): vertical taps of 13 columns, then sixtapHV along
+// the rows; averaged with h of column 2 + (xF == 3)
 E264_DEV void luma_2dv(const Row4 A[13], int xF, const LumaSink &sink)
 {
 	const bool dx = xF == 3;
@@ -330,48 +412,56 @@ E264_DEV void luma_2dv(const Row4 A[13], int xF, const LumaSink &sink)
 		E[r][0] = pair_at<0>(A[r].a1, A[r].a0); E[r][1] = pair_at<2>(A[r].a1, A[r].a0);
 		E[r][2] = pair_at<0>(A[r].a2, A[r].a1); E[r][3] = pair_at<2>(A[r].a2, A[r].a1);
 		E[r][4] = pair_at<0>(A[r].a3, A[r].a2); E[r][5] = pair_at<2>(A[r].a3, A[r].a2);
-		E[r][6] = pair_at<0>(0, A[r].a3);
+		E[r][6] = pair_at<0>(0, A[r].a3 & 255u);
 		if (r < 5)
 			continue;
 		const int j = r - 5;
 		s16x2 V[7], O[6];
 #pragma unroll
 		for (int k = 0; k < 7; k++)
-			V[k] = tap6p(E[j][k], E[j + 1][k], E[j + 2][k], E[j + 3][k], E[j + 4][k], E[j + 5][k]);
+			V[k] = tap6u(E[j][k], E[j + 1][k], E[j + 2][k], E[j + 3][k], E[j + 4][k], E[j + 5][k]);
 #pragma unroll
 		for (int k = 0; k < 6; k++) // (V_2k+1, V_2k+2)
 			O[k] = as_s2(v_alignbit(as_u(V[k + 1]), as_u(V[k]), 16));
 		s16x2 J[4], Hh[4];
 #pragma unroll
 		for (int p = 0; p < 4; p++) {
-			J[p] = centre6p(V[p], O[p], V[p + 1], O[p + 1], V[p + 2], O[p + 2]);
-			Hh[p] = half5p(dx ? O[p + 1] : V[p + 1]);
+			J[p] = centre6r(V[p], O[p], V[p + 1], O[p + 1], V[p + 2], O[p + 2]);
+			Hh[p] = rs5(dx ? O[p + 1] : V[p + 1]);
 		}
-		sink_row(sink, j, v_lerp_u8(pack4(J[0], J[1]), pack4(Hh[0], Hh[1]), ONES8), v_lerp_u8(pack4(J[2], J[3]), pack4(Hh[2], Hh[3]), ONES8));
+		sink_row(sink, j, v_lerp_u8(packus4(J[0], J[1]), packus4(Hh[0], Hh[1]), ONES8), v_lerp_u8(packus4(J[2], J[3]), packus4(Hh[2], Hh[3]), ONES8));
 	}
 }
 
 // bilinear chroma of a 4x4 block of one plane (edge264_inter.c:977-1091; ABCD of :1242 factored into a horizontal and a
-// vertical blend, identical integers): window rows YC..YC+4, columns XC..XC+4
-E264_DEV void chroma4x4(const gu8 *plane, int sC, int Wc, int Hc, int XC, int YC, int xF, int yF, uint32_t out[4])
+// vertical blend, identical integers): window rows YC..YC+4, columns XC..XC+4.  Loads and arithmetic are separate so that
+// the caller can have every load of an item in flight before the first use.
+E264_DEV void chroma_load(const gu8 *plane, int sC, int Wc, int Hc, int XC, int YC, uint32_t w[5][2])
 {
 	const int XA = XC & ~3;
+	if (XA >= 0 && XA + 4 <= Wc - 4) {
+#pragma unroll
+		for (int r = 0; r < 5; r++) {
+			const v2u v = *(const gv2u *)(plane + (size_t)min(max(YC + r, 0), Hc - 1) * sC + XA);
+			w[r][0] = v.x; w[r][1] = v.y;
+		}
+	} else {
+#pragma unroll
+		for (int r = 0; r < 5; r++) {
+			const gu8 *row = plane + (size_t)min(max(YC + r, 0), Hc - 1) * sC;
+			w[r][0] = ref_dword(row, XA, Wc); w[r][1] = ref_dword(row, XA + 4, Wc);
+		}
+	}
+}
+E264_DEV void chroma4x4(const uint32_t w[5][2], int XC, int xF, int yF, uint32_t out[4])
+{
 	const uint32_t o = (uint32_t)XC & 3u;
-	const bool inside = XA >= 0 && XA + 4 <= Wc - 4;
 	const s16x2 cx0 = {(short)(8 - xF), (short)(8 - xF)}, cx1 = {(short)xF, (short)xF};
 	const s16x2 cy0 = {(short)(8 - yF), (short)(8 - yF)}, cy1 = {(short)yF, (short)yF};
 	s16x2 hr[5][2];
 #pragma unroll
 	for (int r = 0; r < 5; r++) {
-		const gu8 *row = plane + (size_t)min(max(YC + r, 0), Hc - 1) * sC;
-		uint32_t w0, w1;
-		if (inside) {
-			const v2u v = *(const gv2u *)(row + XA);
-			w0 = v.x; w1 = v.y;
-		} else {
-			w0 = ref_dword(row, XA, Wc); w1 = ref_dword(row, XA + 4, Wc);
-		}
-		const uint32_t a0 = v_alignbyte(w1, w0, o), a1 = w1 >> (8 * o);
+		const uint32_t a0 = v_alignbyte(w[r][1], w[r][0], o), a1 = w[r][1] >> (8 * o);
 		hr[r][0] = pair_at<0>(a1, a0) * cx0 + pair_at<1>(a1, a0) * cx1;
 		hr[r][1] = pair_at<2>(a1, a0) * cx0 + pair_at<3>(a1, a0) * cx1;
 	}
@@ -441,33 +531,43 @@ E264_DEV void pred_item(PredLds &L, const FrameCtx &f, const PredTile &t, int li
 {
 	const int slot = PI_SLOT(desc), sub = PI_SUB(desc), shape = PI_SHAPE(desc);
 	const int mb = slot >> 2, q = slot & 3;
-	const int mbx = t.tx0 + (mb & (PT_W - 1)), mby = t.ty0 + mb / PT_W;
 	const bool w8 = shape == 0 || shape == 1, h8 = shape == 0 || shape == 2; // width / height 8 (else 4)
 	const int px0 = (mb & (PT_W - 1)) * 16 + (q & 1) * 8 + (sub & 1) * 4, py0 = (mb / PT_W) * 16 + (q >> 1) * 8 + (sub >> 1) * 4; // in the tile
-	gmotion_t mo = f.motion + (mby * f.wm + mbx);
-	const uint32_t mv = *(const gu32 *)&mo->mvs[list * 32 + (q * 4 + sub) * 2];
+	const uint32_t mv = L.mvq[sub][slot], rq = L.refq[slot];
 	const int mx = (int)(int16_t)(mv & 0xffff), my = (int)mv >> 16;
-	const int pic = mo->refPic[list * 4 + q];
-	const int refIdx = mo->refIdx[list * 4 + q], refIdxX = mo->refIdx[(list ^ 1) * 4 + q];
-	const gu8 *ref = (const gu8 *)L.dpb[pic];
+	const int refIdx = (int)(int8_t)(rq >> 8), refIdxX = (int)(int8_t)(rq >> 16), idc = (int)(int8_t)(rq >> 24);
+	const gu8 *ref = (const gu8 *)L.dpb[rq & 255];
 	const int gx = t.tx0 * 16 + px0, gy = t.ty0 * 16 + py0;
+	// every load of the item goes out first: 13 luma rows, 5 + 5 chroma rows
+	const int X = gx + (mx >> 2) - 2, Y = gy + (my >> 2) - 2;
+	const int XC = (gx >> 1) + (mx >> 3), YC = (gy >> 1) + (my >> 3);
+	Row4 A[13];
+	uint32_t cw[2][5][2];
+#ifdef E264_ABL_NOLOAD // timing ablation: no reference fetch at all (results are wrong on purpose)
+	for (int r = 0; r < 13; r++) { A[r].a0 = X + r; A[r].a1 = Y; A[r].a2 = X * r; A[r].a3 = Y - r; }
+#else
+	if (cls <= 1) load_window<8>(ref, f.sY, f.W, f.H, X, Y + 2, A); // G and b only look at rows 2..9
+	else load_window<13>(ref, f.sY, f.W, f.H, X, Y, A);
+#endif
+#ifdef E264_ABL_NOLOAD
+	for (int r = 0; r < 5; r++) { cw[0][r][0] = XC + r; cw[0][r][1] = YC; cw[1][r][0] = XC; cw[1][r][1] = YC * r; }
+#else
+	chroma_load(ref + f.psY, f.sC, f.W >> 1, f.H >> 1, XC, YC, cw[0]);
+	chroma_load(ref + f.psY + (f.sC >> 1), f.sC, f.W >> 1, f.H >> 1, XC, YC, cw[1]);
+#endif
 	// combination with list 0 / weights
-	cslice_t s = f.slices + (L.hdr[mb][2] >> 16);
-	const int idc = s->weighted_bipred_idc;
 	const bool second = list == 1 && refIdxX >= 0;
 	int mode = second ? 1 : 0;
 	Wod wY = {0, 1, 0, 0}, wCb = wY, wCr = wY;
 	if (idc != 0) {
 		mode = (idc == 1 ? (refIdxX < 0 || list == 1) : second) ? 2 : 0;
 		if (mode == 2)
-			pred_weights(s, list, refIdx, refIdxX, wY, wCb, wCr);
+			pred_weights(f.slices + (L.hdr[mb][2] >> 16), list, refIdx, refIdxX, wY, wCb, wCr);
 	}
-	{ // chroma first: its window is small and its rows leave at once
-		const gu8 *cb = ref + f.psY;
-		const int XC = (gx >> 1) + (mx >> 3), YC = (gy >> 1) + (my >> 3);
+	{ // chroma: small, and its rows leave at once
 		uint32_t oc[2][4];
-		chroma4x4(cb, f.sC, f.W >> 1, f.H >> 1, XC, YC, mx & 7, my & 7, oc[0]);
-		chroma4x4(cb + (f.sC >> 1), f.sC, f.W >> 1, f.H >> 1, XC, YC, mx & 7, my & 7, oc[1]);
+		chroma4x4(cw[0], XC, mx & 7, my & 7, oc[0]);
+		chroma4x4(cw[1], XC, mx & 7, my & 7, oc[1]);
 		const int ncr = h8 ? 4 : 2;
 #pragma unroll
 		for (int pc = 0; pc < 2; pc++) {
@@ -489,25 +589,45 @@ E264_DEV void pred_item(PredLds &L, const FrameCtx &f, const PredTile &t, int li
 	}
 	LumaSink sink;
 	sink.ty = &L.y[py0][px0 >> 2]; sink.mode = mode; sink.nr = h8 ? 8 : 4; sink.w8 = w8; sink.w = wY;
-	Row4 A[13];
-	load_window13(ref, f.sY, f.W, f.H, gx + (mx >> 2) - 2, gy + (my >> 2) - 2, A);
-	if (cls == 0) luma_1d(A, mx & 3, my & 3, sink);
-	else if (cls == 1) luma_2dh(A, my & 3, sink);
-	else luma_2dv(A, mx & 3, sink);
+#ifdef E264_ABL_NOLUMA // timing ablation: the windows are fetched but only folded into one row
+	{
+		uint32_t x0 = 0, x1 = 0;
+		for (int r = 0; r < 13; r++) { x0 ^= A[r].a0 ^ A[r].a2; x1 ^= A[r].a1 ^ A[r].a3; }
+		sink_row(sink, 0, x0, x1);
+		return;
+	}
+#endif
+	if (cls <= 1) {
+		align_window<8>(A, X);
+		if (cls == 0) luma_g(A, sink);
+		else luma_b(A, mx & 3, sink);
+	} else {
+		align_window<13>(A, X);
+		if (cls == 2) luma_h(A, my & 3, sink);
+		else if (cls == 3) luma_d(A, mx & 3, my & 3, sink);
+		else if (cls == 4) luma_2dh(A, my & 3, sink);
+		else luma_2dv(A, mx & 3, sink);
+	}
 }
 
 E264_DEV void pred_phase_items(PredLds &L, const FrameCtx &f, const PredTile &t, int list, int tid)
 {
-	const int n0 = L.cnt[0], n1 = L.cnt[1], n2 = L.cnt[2], n = n0 + n1 + n2;
+	int n = 0;
+#pragma unroll
+	for (int c = 0; c < 6; c++) n += L.cnt[c];
 	for (int p = tid; p < n; p += PT_NT) {
-		const int cls = p < n0 ? 0 : p < n0 + n1 ? 1 : 2;
-		const int idx = p - (cls == 0 ? 0 : cls == 1 ? n0 : n0 + n1);
-		pred_item(L, f, t, list, cls, L.lst[cls][idx]);
+		int cls = 0, idx = p;
+#pragma unroll
+		for (int c = 0; c < 5; c++) {
+			const int k = L.cnt[c];
+			if (cls == c && idx >= k) { cls = c + 1; idx -= k; }
+		}
+		pred_item(L, f, t, list, cls, *pred_list_slot(L, cls, idx));
 	}
 }
 E264_DEV void pred_phase_reset(PredLds &L, int tid)
 {
-	if (tid < 4) L.cnt[tid] = 0;
+	if (tid < 6) L.cnt[tid] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -515,20 +635,23 @@ E264_DEV void pred_phase_reset(PredLds &L, int tid)
 // ---------------------------------------------------------------------------------------------------------------------
 // residual item: bits 0..4 block (0..15 luma 4x4 in zig order, 16..23 chroma 4x4 Cb 0..3 / Cr 4..7, 24..27 luma 8x8), 5..11 macroblock
 E264_DEV void pred_phase_reslist(PredLds &L, int tid)
-{
+{ // thread = (macroblock, byte q of its 32-bit candidate mask: luma 4x4 blocks 0..7, 8..15, chroma blocks, 8x8 blocks)
 	uint16_t *l4 = &L.lst[0][0], *l8 = &L.lst[2][0];
-	for (int c = tid; c < PT_MBS * 32; c += PT_NT) {
-		const int mb = c >> 5, b = c & 31;
-		const uint32_t d0 = L.hdr[mb][0], coded = L.hdr[mb][3];
-		if ((d0 & 255) != E264_MB_INTER || coded == 0 || b >= 28)
-			continue;
-		const bool t8 = (d0 >> 8) & E264_MBF_T8x8;
-		if (b < 16) {
-			if (!t8 && (coded >> b & 1)) l4[lds_add(&L.rcnt[0], 1)] = (uint16_t)c;
-		} else if (b < 24) {
-			if ((coded >> b & 1) || (coded & E264_CODED_CHROMA_DC)) l4[lds_add(&L.rcnt[0], 1)] = (uint16_t)c;
-		} else if (t8 && (coded >> ((b - 24) * 4) & 1))
-			l8[lds_add(&L.rcnt[1], 1)] = (uint16_t)c;
+	const int mb = tid >> 2, q = tid & 3;
+	const uint32_t d0 = L.hdr[mb][0], coded = L.hdr[mb][3];
+	if ((d0 & 255) != E264_MB_INTER || coded == 0)
+		return;
+	const bool t8 = (d0 >> 8) & E264_MBF_T8x8;
+	uint32_t bits;
+	if (q < 2) bits = t8 ? 0 : coded >> (q * 8) & 255;
+	else if (q == 2) bits = (coded & E264_CODED_CHROMA_DC) ? 255 : coded >> 16 & 255;
+	else bits = t8 ? ((coded & 1) | (coded >> 3 & 2) | (coded >> 6 & 4) | (coded >> 9 & 8)) : 0;
+	while (bits) {
+		const int b = __builtin_ctz(bits);
+		bits &= bits - 1;
+		const uint16_t item = (uint16_t)(mb << 5 | q << 3 | b);
+		if (q < 3) l4[lds_add(&L.rcnt[0], 1)] = item;
+		else l8[lds_add(&L.rcnt[1], 1)] = item;
 	}
 }
 

@@ -33,6 +33,12 @@ static inline uint32_t v_lerp_u8(uint32_t a, uint32_t b, uint32_t c)
 		out |= (((a >> (8 * i) & 255) + (b >> (8 * i) & 255) + (c >> (8 * i) & 1)) >> 1) << (8 * i);
 	return out;
 }
+static inline uint32_t v_sat_pk_u8_i16(uint32_t v)
+{
+	int a = (int16_t)(v & 0xffff), b = (int16_t)(v >> 16);
+	a = a < 0 ? 0 : a > 255 ? 255 : a; b = b < 0 ? 0 : b > 255 ? 255 : b;
+	return (uint32_t)a | (uint32_t)b << 8;
+}
 static inline int lds_add(int *p, int v) { int o = *p; *p += v; return o; }
 static inline void lds_or(uint32_t *p, uint32_t v) { *p |= v; }
 #include "../../edge264_amd/csrc/e264_pred.h"
