@@ -1,32 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- 1080p frames/s of the MI355X macroblock-reconstruction back end.
 
-One "step" = one pass of the hot path over one batch of synthetic input: every stream of
-this rank decodes one GOP (default IPPPPPPP, 1080p, BASELINE.json configs[2]: 6-tap luma /
-bilinear chroma MC + residual + in-loop deblocking; frame 0 is the all-intra I frame of
-configs[1]).  Command packets and DPBs are resident in HBM before the timed region; each
-stream has its OWN copy of the packets and its own DPB (no cross-stream cache sharing).
+One "step" = one pass of the hot path over one batch of synthetic input: every stream of this rank decodes one GOP
+(default IPPPPPPP, 1080p High profile, BASELINE.json configs[2]: 6-tap luma / bilinear chroma MC + 4x4 and 8x8 residual +
+in-loop deblocking; frame 0 is an all-intra I frame).  Command packets and DPBs are resident in HBM before the timed region;
+each stream has its OWN copy of the packets and its own DPB (no cross-stream cache sharing).
 
-Streams are independent, so N GPUs = N x the same per-GPU work (weak scaling), no collective
-on the data path; torch.distributed (RCCL) is used only for the barrier and the max-over-ranks
-of the elapsed time.
+Streams are independent, so N GPUs = N x the same per-GPU work (weak scaling), no collective on the data path;
+torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the elapsed time.  `--gpus N` without a
+torchrun environment launches the N ranks itself (torch.distributed.run, one process per GPU).
 
-Prints ONE JSON line (rank 0).  One submission of a batch (= one frame of every stream) is four
-kernel launches on the back end's queue: e264_dbkparam_kernel (bS/alpha/beta), e264_mbpar_kernel (inter prediction +
-residual, macroblock-parallel), e264_intra_kernel (intra wavefront) and e264_deblock_kernel
-(deblocking wavefront).  `roofline.achieved` = algorithmic bytes of one submission (SURVEY.md
-8(d): frame written once + reference samples read once per prediction direction used + command
-bytes consumed, summed over the streams of the batch) / average duration of the DOMINANT of the
-four kernels, measured live with HIP events recorded on the back end's own queue around each
-launch.  `roofline.traffic` = HBM bytes per launch of that kernel from the PMC passes committed
-under profiles/ (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), when a summary for this exact
-configuration exists, else null.  `cpu_baseline` = the reference's own SIMD kernels
-(oracle/_ref/libe264_refkernels.so, compiled from /root/reference) replaying the same packets on
-one host core for a bounded sample.
+Prints ONE JSON line (rank 0).  One submission (= one frame of every stream) is four kernel launches on the back end's
+queue: e264_dbkparam_kernel (bS / alpha / beta), e264_pred_kernel (inter prediction + residual, tile-parallel),
+e264_intra_kernel (intra wavefront), e264_deblock_kernel (deblocking wavefront).  Kernel times are measured live with HIP
+events recorded on the back end's own queue around each launch.
+
+roofline (all per submission of one frame of every stream of one GPU; DESIGN.md section 4 states the figures):
+  kernels[k].own_bytes  the bytes kernel k has to move as the pass it is: the samples it writes, the samples it reads,
+                        the command bytes it consumes (sample and command bytes kept apart);
+  kernel / achieved / frac   the DOMINANT kernel (largest share of the submission) against ITS OWN bytes;
+  end_to_end            SURVEY.md 8(d)'s algorithmic bytes of the submission (every sample written once, reference samples
+                        read once per prediction direction, command bytes consumed -- the fused ideal, so the second pass of
+                        the separate deblocking kernel counts as time but not as bytes) / the time of all four kernels;
+  traffic               HBM-side bytes of the dominant kernel from the PMC passes committed under profiles/ (canned, matched
+                        on the configuration), else null.
+cpu_baseline: the unmodified reference decoder on the host cores (oracle/cpu_baseline.py), plus the reference's own SIMD
+kernels replaying the bench packets on one core (`kernel_replay`).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,11 +41,13 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+KERNELS = ["e264_dbkparam_kernel", "e264_pred_kernel", "e264_intra_kernel", "e264_deblock_kernel"]
+DBK_BYTES = 64  # deblocking parameters per macroblock (edge264_amd/csrc/e264_kernels.h)
 
 
-def main() -> int:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node; spawns them when not already under torchrun")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("E264_STREAMS", 256)), help="concurrent streams per GPU")
@@ -49,17 +56,55 @@ def main() -> int:
     ap.add_argument("--height-mbs", type=int, default=68)
     ap.add_argument("--waves", type=int, default=int(os.environ.get("E264_WAVES", 12)))
     ap.add_argument("--intra-waves", type=int, default=int(os.environ.get("E264_INTRA_WAVES", 16)))
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="bounded CPU baseline sample (per leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--other-configs", action="store_true", help="also time short runs of BASELINE configs[1] and configs[3] (off by default: "
-                    "the default command launches only the headline workload, so that a rocprofv3 trace of it averages one workload)")
-    ap.add_argument("--queues", type=int, default=int(os.environ.get("E264_QUEUES", 1)), help="HIP queues per GPU; streams are split between them so that the wavefront kernels of one group overlap the parallel kernel of another")
-    ap.add_argument("--host-packets", action="store_true", help="also time the path that starts from packets in HOST memory "
-                    "(e264hip_submit_batch_host: staging copy + H2D + kernels); reported as pcie_inclusive, never as value")
-    ap.add_argument("--side-queue", type=int, default=int(os.environ.get("E264_SIDE_QUEUE", 0)), help="1: deblocking-parameter kernel on a second queue beside the macroblock-parallel kernel")
-    ap.add_argument("--debug-mode", type=int, default=0, help="profiling ablation bits (results are then wrong on purpose)")
-    args = ap.parse_args()
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs[1] and configs[3] (N=1)")
+    ap.add_argument("--no-host-packets", action="store_true", help="skip the PCIe-inclusive run (N=1)")
+    ap.add_argument("--debug-mode", type=int, default=0, help="profiling ablation bits (results may then be wrong on purpose)")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside torchrun: one process per GPU through torch.distributed.run; rank 0's JSON line
+    is this process's stdout."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")).returncode
+
+
+def kernel_own_bytes(models, n_streams):
+    """Per kernel: (sample bytes, command bytes) of one submission, averaged over the GOP's frames."""
+    out = {}
+    for name in KERNELS:
+        sb = cb = 0.0
+        for m in models:
+            F, n = m["F"], m["n_mbs"]
+            if name == "e264_dbkparam_kernel":  # reads record headers + motion, writes the parameter records
+                c, s_ = 32 * n + m["cmd_motion"] + DBK_BYTES * n, 0
+            elif name == "e264_pred_kernel":  # writes its macroblocks, reads each reference sample once per direction
+                s_ = F * m["inter"] + F * m["dirs"]
+                c = 32 * n + m["cmd_motion"] + m["cmd_payload_inter"]
+            elif name == "e264_intra_kernel":  # writes its macroblocks (neighbour rows are cache hits)
+                s_ = F * m["intra"]
+                c = 32 * n + m["cmd_payload_intra"]
+            else:  # deblocking as a pass of its own: the frame read and written once, parameters read
+                s_ = 2 * F
+                c = 4 * n + DBK_BYTES * n
+            sb += s_
+            cb += c
+        out[name] = (sb / len(models) * n_streams, cb / len(models) * n_streams)
+    return out
+
+
+def main() -> int:
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus and args.gpus > 1:
+        return launch_ranks(args.gpus)
 
     # stdout carries exactly ONE line (the JSON): libraries that chat on fd 1 (the RCCL version banner) go to stderr
     sys.stdout.flush()
@@ -68,153 +113,142 @@ def main() -> int:
 
     from edge264_amd.sharding import rank_info, reduce_elapsed, shard_streams
     rank, local_rank, world = rank_info()
+    if args.gpus is not None and args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for the wrong GPU count", file=sys.stderr)
+        return 2
+    import importlib
+    backend = importlib.import_module(os.environ.get("E264_BENCH_BACKEND", "edge264_amd.backend"))  # tests: a stub device on CPU ranks
+    stub = getattr(backend, "IS_STUB", False)
     import torch
     dist = None
+    tdev = torch.device("cpu") if stub else torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("E264_FORCE_DIST"):  # E264_FORCE_DIST: exercise the RCCL path on one GPU
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=tdev)
 
-    from edge264_amd import backend, packet as P, synth
+    from edge264_amd import packet as P, synth
 
     W, H = args.width_mbs, args.height_mbs
+    ALL_I = (P.MB_I4x4, P.MB_I8x8, P.MB_I16x16)
     # ---- synthetic input (same bytes on every rank: seeded) -------------------------------
-    gen = synth.StreamSynth(W, H, seed=1234, t8x8=False, num_refs=2, residual_prob=0.3)
+    gen = synth.StreamSynth(W, H, seed=1234, t8x8=True, i_kinds=ALL_I, num_refs=2, residual_prob=0.3)
     packets = gen.gop(args.gop)
     parsed = [P.Packet(p) for p in packets]
-    alg_bytes = [pk.algorithmic_bytes() for pk in parsed]
-    n_slots = max(int(pk.hdr["dst_slot"]) for pk in parsed) + 1
-    n_slots = max(n_slots, 3)
+    models = [pk.traffic_model() for pk in parsed]
+    n_slots = max(max(int(pk.hdr["dst_slot"]) for pk in parsed) + 1, 3)
 
-    nq = max(1, min(args.queues, args.streams))
-    devs = [backend.Device(local_rank) for _ in range(nq)]
-    for dv in devs:
-        dv.set_option("waves", args.waves)
-        if args.intra_waves:
-            dv.set_option("intra_waves", args.intra_waves)
-        dv.set_option("debug_mode", args.debug_mode)
-        dv.set_option("side_queue", args.side_queue)
-    dev = devs[0]
+    # weak scaling: rank r owns streams shard_streams(streams * world, r, world) (= `streams` of them)
+    my_streams = len(shard_streams(args.streams * world, rank, world))
+    dev = backend.Device(local_rank)
+    dev.set_option("waves", args.waves)
+    if args.intra_waves:
+        dev.set_option("intra_waves", args.intra_waves)
+    dev.set_option("debug_mode", args.debug_mode)
     streams, dpk = [], []
-    for s in range(args.streams):
-        dv = devs[s % nq]
-        st = backend.Stream(dv, W, H)
+    for s in range(my_streams):
+        st = backend.Stream(dev, W, H)
         for i in range(n_slots):
             st.alloc(i)
             st.fill(i, 128)
         streams.append(st)
-        dpk.append([dv.upload_packet(p) for p in packets])  # per-stream copy of the command bytes
-    # batches[q][f]: frame f of every stream of queue q
-    batches = [[devs[q].make_batch(streams[q::nq], [dpk[s][f] for s in range(q, args.streams, nq)]) for f in range(len(packets))]
-               for q in range(nq)]
-    for dv in devs:
-        dv.sync()
+        dpk.append([dev.upload_packet(p) for p in packets])  # per-stream copy of the command bytes
+    batches = [dev.make_batch(streams, [dpk[s][f] for s in range(my_streams)]) for f in range(len(packets))]
+    dev.sync()
 
     def step():
-        for f in range(len(packets)):
-            for q in range(nq):
-                devs[q].submit_prepared(batches[q][f], backend.RUN_ALL)
-
-    def sync_all():
-        for dv in devs:
-            dv.sync()
+        for b in batches:
+            dev.submit_prepared(b, backend.RUN_ALL)
 
     def barrier():
-        sync_all()
-        torch.cuda.synchronize() if torch.cuda.is_available() else None
+        dev.sync()
+        if not stub and torch.cuda.is_available():
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
     for _ in range(args.warmup):
         step()
     barrier()
-    for dv in devs:
-        dv.kernel_timing(True)
+    dev.kernel_timing(True)
     t0 = time.perf_counter()
     dev.event_record(0)
     for _ in range(args.steps):
         step()
     dev.event_record(1)
-    sync_all()
-    if torch.cuda.is_available():
+    dev.sync()
+    if not stub and torch.cuda.is_available():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    # weak scaling: rank r owns streams shard_streams(streams * world, r, world) (= `streams` of them)
-    my_frames = len(shard_streams(args.streams * world, rank, world)) * len(packets) * args.steps
+    my_frames = my_streams * len(packets) * args.steps
     if dist is not None:
         dist.barrier()
-        elapsed, total_frames = reduce_elapsed(elapsed, my_frames, dist, torch.device("cuda", local_rank))
+        elapsed, total_frames = reduce_elapsed(elapsed, my_frames, dist, tdev)
     else:
         total_frames = my_frames
-    kernel_ms3, launches = [0.0, 0.0, 0.0, 0.0], 0
-    for dv in devs:
-        k3, n = dv.kernel_time_ms()
-        kernel_ms3 = [a + b for a, b in zip(kernel_ms3, k3)]
-        launches += n
-        dv.kernel_timing(False)
-    kernel_ms = sum(kernel_ms3)
+    kernel_ms4, launches = dev.kernel_time_ms()
+    dev.kernel_timing(False)
     ev_ms = dev.event_elapsed_ms(0, 1)
-
     frames_per_step = total_frames // args.steps
     value = total_frames / elapsed
 
-    # ---- bit-exactness at full size (untimed): stream 0's last frame vs the CPU oracle ----
-    bit_exact = None
-    if rank == 0 and not args.no_verify:
+    # ---- bit-exactness at full size (untimed): EVERY stream, EVERY frame of one more GOP against the CPU oracle ----
+    verify, bit_exact = None, None
+    if rank == 0 and not args.no_verify and not stub:
         from oracle.pyoracle import Oracle
         orc = Oracle()
         nb = P.frame_bytes(W, H)
         dpb = [np.full(nb + 16, 128, np.uint8) for _ in range(n_slots)] + [None] * (32 - n_slots)
-        for p in packets:
+        for st in streams:
+            for i in range(n_slots):
+                st.fill(i, 128)
+        bad = 0
+        for f, p in enumerate(packets):
             orc.decode_frame(p, dpb, 3)
-        last = int(parsed[-1].hdr["dst_slot"])
-        bit_exact = bool(np.array_equal(streams[0].download(last), dpb[last][:nb]) and
-                         np.array_equal(streams[-1].download(last), dpb[last][:nb]))
+            dev.submit_prepared(batches[f], backend.RUN_ALL)
+            dev.sync()
+            d = int(parsed[f].hdr["dst_slot"])
+            want = dpb[d][:nb]
+            for st in streams:
+                bad += 0 if np.array_equal(st.download(d), want) else 1
+        verify = {"streams": len(streams), "frames_per_stream": len(packets), "frames_compared": len(streams) * len(packets), "mismatching_frames": bad}
+        bit_exact = bad == 0
 
-    # ---- CPU baseline: reference SIMD kernels on one core, bounded sample ------------------
+    # ---- CPU baseline (N=1 only, the contract) -----------------------------------------------------------------------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N=1 only (the contract); at N>1 the field is null
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not stub:
         try:
+            from oracle.cpu_baseline import reference_decoder_baseline
+            cpu = reference_decoder_baseline(min(args.cpu_seconds, 6.0), args.cpu_seconds)
+        except (OSError, FileNotFoundError) as e:
+            cpu = {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference", "sample": f"unavailable: {e}"}
+        try:  # second figure: the reference's own sample kernels (no entropy decoding) replaying the bench packets, one core
             from oracle.pyoracle import RefKernels
             rk = RefKernels()
-            kind = "reference"
             nb = P.frame_bytes(W, H)
             dpb = [np.full(nb + 16, 128, np.uint8) for _ in range(n_slots)] + [None] * (32 - n_slots)
             n, tc = 0, time.perf_counter()
-            while time.perf_counter() - tc < args.cpu_seconds:
+            while time.perf_counter() - tc < min(args.cpu_seconds, 5.0):
                 for p in packets:
                     rk.replay(p, dpb, W, H, 3)
                 n += len(packets)
-            dt = time.perf_counter() - tc
-            cpu = {"value": round(n / dt, 2), "unit": "frames/s", "cores": 1, "kind": kind,
-                   "sample": f"{n} frames ({n // len(packets)} x the {args.gop} 1080p GOP of one stream) replayed by the "
-                             f"reference's own SSE kernels (residual+intra+inter+deblock, no entropy decoding) in {dt:.1f} s"}
+            cpu["kernel_replay"] = {"value": round(n / (time.perf_counter() - tc), 2), "unit": "frames/s", "cores": 1,
+                                    "what": "reference SSE kernels (residual + intra + inter + deblock) on the bench GOP's packets"}
         except (OSError, FileNotFoundError):
-            from oracle.pyoracle import Oracle
-            orc = Oracle()
-            nb = P.frame_bytes(W, H)
-            dpb = [np.full(nb + 16, 128, np.uint8) for _ in range(n_slots)] + [None] * (32 - n_slots)
-            n, tc = 0, time.perf_counter()
-            while time.perf_counter() - tc < args.cpu_seconds:
-                for p in packets:
-                    orc.decode_frame(p, dpb, 3)
-                n += len(packets)
-            dt = time.perf_counter() - tc
-            cpu = {"value": round(n / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-                   "sample": f"{n} frames of the {args.gop} 1080p GOP by the scalar oracle in {dt:.1f} s"}
+            pass
 
     # ---- the other single-GPU configurations of BASELINE.json, short runs on the same streams (N=1 only) -----
-    # value / roofline above are quoted on configs[2]; these are reported beside it so that every configuration has
-    # a number from the same build:  configs[1] all-intra 4x4 I slices, residual + intra kernels only (no deblocking);
-    # configs[3] IBBP with 8x8 transform, CABAC-style coefficient flags, explicit weighted prediction, scaling lists.
     other = None
-    if rank == 0 and world == 1 and nq == 1 and args.other_configs and args.debug_mode == 0:
+    if rank == 0 and world == 1 and not args.no_other_configs and args.debug_mode == 0 and not stub:
         from oracle.pyoracle import Oracle
         other = {}
-        specs = [("configs[1] all-intra 4x4 I slices, residual + intra only", "IIII", backend.RUN_RECON,
+        specs = [("configs[1] all-intra 4x4 I slices, residual + intra kernels only", "IIII", backend.RUN_RECON,
                   dict(i_kinds=(P.MB_I4x4,), residual_prob=1.0, deblock=False)),
-                 ("configs[3] IBBP, 8x8 transform, weighted bi-prediction, scaling lists, deblocking", "IPBBPBBP", backend.RUN_ALL,
-                  dict(t8x8=True, scaling=True, weighted=1, num_refs=2, residual_prob=0.3))]
+                 ("configs[3] IBBP, 8x8 transform, explicit weighted bi-prediction, scaling lists, deblocking", "IPBBPBBP", backend.RUN_ALL,
+                  dict(t8x8=True, scaling=True, weighted=1, num_refs=2, residual_prob=0.3, i_kinds=ALL_I))]
         for label, gop2, mode2, kw in specs:
             g2 = synth.StreamSynth(W, H, seed=4321, **kw)
             pk2 = g2.gop(gop2)
@@ -229,36 +263,38 @@ def main() -> int:
             b2 = [dev.make_batch(streams, [d2[k][f] for k in range(len(streams))]) for f in range(len(pk2))]
 
             def step2():
-                for f in range(len(pk2)):
-                    dev.submit_prepared(b2[f], mode2)
+                for b in b2:
+                    dev.submit_prepared(b, mode2)
             step2()
             dev.sync()
+            dev.kernel_timing(True)
             t2 = time.perf_counter()
             for _ in range(2):
                 step2()
             dev.sync()
             dt2 = time.perf_counter() - t2
+            k4, l4 = dev.kernel_time_ms()
+            dev.kernel_timing(False)
             ok2 = None
-            if not args.no_verify:
+            if not args.no_verify:  # last frame of the GOP, first / middle / last stream
                 orc = Oracle()
                 nb = P.frame_bytes(W, H)
                 dpb = [np.full(nb + 16, 128, np.uint8) for _ in range(n_slots)] + [None] * (32 - n_slots)
                 for q in pk2:
                     orc.decode_frame(q, dpb, mode2)
                 last2 = int(P.Packet(pk2[-1]).hdr["dst_slot"])
-                ok2 = bool(np.array_equal(streams[0].download(last2), dpb[last2][:nb]) and
-                           np.array_equal(streams[-1].download(last2), dpb[last2][:nb]))
-            other[label] = {"value": round(2 * len(pk2) * len(streams) / dt2, 1), "unit": "frames/s", "gop": gop2, "steps": 2,
-                            "bit_exact": ok2}
+                ok2 = all(bool(np.array_equal(streams[k].download(last2), dpb[last2][:nb])) for k in (0, len(streams) // 2, len(streams) - 1))
+            other[label] = {"value": round(2 * len(pk2) * len(streams) / dt2, 1), "unit": "frames/s", "gop": gop2, "steps": 2, "bit_exact": ok2,
+                            "kernel_ms_per_launch": {n: round(t / max(l4, 1), 4) for n, t in zip(KERNELS, k4)}}
             for b in b2:
                 dev.free_batch(b)
             for row in d2:
                 for q in row:
                     q.free()
 
-    # ---- PCIe-inclusive rate (opt-in, informational): the same GOP submitted from host memory -------------------
+    # ---- PCIe-inclusive rate (informational, never `value`): the same GOP submitted from host memory -------------------
     pcie = None
-    if rank == 0 and world == 1 and nq == 1 and args.host_packets:
+    if rank == 0 and world == 1 and not args.no_host_packets and not stub:
         hbs = [dev.prepare_host_batch(streams, [packets[f]] * len(streams)) for f in range(len(packets))]
         for hb in hbs:
             dev.submit_host_prepared(hb, backend.RUN_ALL)
@@ -273,22 +309,30 @@ def main() -> int:
                 "packet_MB_per_frame": round(float(np.mean([len(p) for p in packets])) / 1e6, 3),
                 "what": "host packets -> pinned staging (memcpy on the calling thread) -> H2D -> 4 kernels, asynchronous, one batch per frame index"}
 
+    rc = 0
     if rank == 0:
-        per_launch_bytes = float(np.mean(alg_bytes)) * args.streams / nq
-        names = ["e264_dbkparam_kernel", "e264_mbpar_kernel", "e264_intra_kernel", "e264_deblock_kernel"]
-        dom = int(np.argmax(kernel_ms3))
-        # the four kernels of one submission together move the algorithmic bytes of the batch once;
-        # the dominant kernel is priced against ALL of them (a conservative fraction of the roofline)
-        avg_launch_s = kernel_ms3[dom] / 1e3 / max(launches, 1)
-        achieved = per_launch_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        L = max(launches, 1)
+        kms = [t / L for t in kernel_ms4]
+        own = kernel_own_bytes(models, my_streams)
+        kern = {}
+        for name, ms in zip(KERNELS, kms):
+            sb, cb = own[name]
+            g = (sb + cb) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            kern[name] = {"ms_per_launch": round(ms, 4), "sample_bytes": int(sb), "command_bytes": int(cb), "gbps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4)}
+        dom = KERNELS[int(np.argmax(kms))]
+        # SURVEY 8(d) bytes of one submission: F + F x dirs (samples) + the packet (commands) per frame, x streams
+        e2e_samples = float(np.mean([m["F"] * (1.0 + m["dirs"]) for m in models])) * my_streams
+        e2e_cmds = float(np.mean([m["cmd_total"] for m in models])) * my_streams
+        tot_ms = sum(kms)
+        e2e_g = (e2e_samples + e2e_cmds) / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
             cfg = tj.get("config", {})
             if (cfg.get("streams"), cfg.get("gop"), cfg.get("width_mbs"), cfg.get("height_mbs")) == (args.streams, args.gop, W, H):
-                k = tj["kernels"].get(names[dom])
+                k = tj["kernels"].get(dom)
                 if k:
                     traffic = int(k["hbm_bytes_per_launch"])
         out = {
@@ -298,30 +342,32 @@ def main() -> int:
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{W * 16}x{H * 16} High-profile {args.gop} GOP (synthetic command packets: "
-                                   "intra 4x4/16x16 I frame + P frames with 6-tap luma / bilinear chroma MC, 30% coded residual, "
+            "config": {"workload": f"{W * 16}x{H * 16} High-profile {args.gop} GOP (synthetic command packets: intra 4x4 / 8x8 / 16x16 I frame + "
+                                   "P frames with 6-tap luma / bilinear chroma MC, 2 references, 4x4 and 8x8 transforms, 30% coded residual, "
                                    "in-loop deblocking), BASELINE configs[2]",
-                       "streams_per_gpu": args.streams, "queues": nq, "frames_per_step": frames_per_step,
+                       "streams_per_gpu": args.streams, "frames_per_step": frames_per_step,
                        "waves_per_frame": args.waves, "parallelism": f"stream-parallel x{world}, no collectives"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": names[dom], "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": launches,
-                         "kernel_ms_per_launch": {n: round(t / max(launches, 1), 4) for n, t in zip(names, kernel_ms3)},
-                         "algorithmic_bytes_per_launch": int(per_launch_bytes)},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": kern[dom]["frac"], "traffic": traffic, "traffic_source": "profiles/r02_hbm_traffic.json (PMC passes, canned)" if traffic else None,
+                         "launches": launches, "kernels": kern,
+                         "end_to_end": {"ms_per_submission": round(tot_ms, 4), "sample_bytes": int(e2e_samples), "command_bytes": int(e2e_cmds),
+                                        "gbps": round(e2e_g, 1), "frac": round(e2e_g / HBM_PEAK_GBS, 4)}},
             "cpu_baseline": cpu,
-            "bit_exact": bit_exact,
+            "bit_exact": bit_exact, "verify": verify,
             "other_configs": other,
             "pcie_inclusive": pcie,
             "gpu_event_ms_per_step": round(ev_ms / args.steps, 3),
         }
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+        if bit_exact is False or (other and any(v["bit_exact"] is False for v in other.values())):
+            print("bench.py: output is NOT bit-exact: the value above is invalid", file=sys.stderr)
+            rc = 3
     for st in streams:
         st.close()
-    for dv in devs:
-        dv.close()
+    dev.close()
     if dist is not None:
         dist.destroy_process_group()
-    return 0
+    return rc
 
 
 if __name__ == "__main__":

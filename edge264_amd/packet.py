@@ -225,6 +225,38 @@ class Packet:
             dirs += ((rp[0] >= 0).sum() + (rp[1] >= 0).sum()) / 4.0
         return int(F + F * dirs / n + int(self.hdr["total_bytes"]))
 
+    def traffic_model(self) -> dict:
+        """The terms of SURVEY.md 8(d) one by one, so that bench.py can price every kernel against the bytes IT has to move
+        and keep sample bytes apart from command bytes (a fatter packet must not raise a roofline fraction):
+          F                frame bytes (luma + chroma)
+          inter / intra    fraction of macroblocks reconstructed by the prediction kernel (inter, PCM) / the intra kernel
+          dirs             prediction directions used, averaged over ALL macroblocks (reference samples read = F x dirs)
+          cmd_*            command bytes by consumer: record headers (32 B per macroblock + frame/slice headers), motion records,
+                           coefficient payload of inter (+ PCM samples) and of intra macroblocks"""
+        F = self.frame_bytes()
+        n = len(self.mbs)
+        kind = self.mbs["kind"]
+        inter = np.nonzero(kind == MB_INTER)[0]
+        dirs = 0.0
+        if len(inter):
+            rp = self.motion["refPic"][inter].reshape(-1, 2, 4)
+            dirs = float((rp >= 0).sum()) / 4.0
+        pay = np.zeros(n, np.int64)
+        coded = self.mbs["coded"].astype(np.int64)
+        t8 = (self.mbs["flags"] & MBF_T8x8) != 0
+        pop16 = np.array([bin(int(c) & 0xffff).count("1") for c in coded])
+        pop8 = np.array([bin(int(c) & 0x1111).count("1") for c in coded])
+        popc = np.array([bin(int(c) >> 16 & 0xff).count("1") for c in coded])
+        pay += np.where(coded & CODED_LUMA_DC, 32, 0) + np.where(coded & CODED_CHROMA_DC, 16, 0) + popc * 32
+        pay += np.where(t8 & (kind != MB_I16x16), pop8 * 128, pop16 * 32)
+        pay = np.where(kind == MB_PCM, 384, pay)
+        own_pred = (kind == MB_INTER) | (kind == MB_PCM)
+        own_intra = (kind == MB_I4x4) | (kind == MB_I8x8) | (kind == MB_I16x16)
+        return dict(F=F, n_mbs=n, inter=float(own_pred.sum()) / n, intra=float(own_intra.sum()) / n, dirs=dirs / n,
+                    cmd_headers=int(self.hdr["mbs_off"]) + 32 * n, cmd_motion=144 * n if int(self.hdr["motion_off"]) else 0,
+                    cmd_payload_inter=int(pay[own_pred].sum()), cmd_payload_intra=int(pay[own_intra].sum()),
+                    cmd_total=int(self.hdr["total_bytes"]))
+
 
 def split_planes(buf: np.ndarray, width_mbs: int, height_mbs: int):
     """Frame buffer bytes -> (Y, Cb, Cr) 2-D views in the reference layout."""

@@ -172,3 +172,26 @@ def test_committed_bench_line_obeys_the_contract():
     assert d["bit_exact"] is True
     # whole-job throughput: frames of all streams / wall time
     assert abs(d["value"] - d["config"]["frames_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+
+
+def test_bench_gpus_flag_spawns_ranks(tmp_path):
+    """`python bench.py --gpus 2` outside torchrun launches 2 ranks itself (torch.distributed.run, here gloo + a stub device):
+    rank 0 prints ONE line with n_gpus 2 and the frames of BOTH ranks' stream shards; a mismatch between --gpus and an
+    inherited WORLD_SIZE is refused instead of silently benchmarking the wrong GPU count."""
+    import json
+    env = dict(os.environ, E264_BENCH_BACKEND="tests.stub_backend", OMP_NUM_THREADS="1", PYTHONPATH=ROOT)
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--streams", "3", "--gop", "IP",
+           "--width-mbs", "4", "--height-mbs", "3"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["frames_per_step"] == 2 * 3 * 2  # ranks x streams per rank x frames of the GOP
+    assert d["roofline"]["kernel"] == "e264_pred_kernel" and d["cpu_baseline"] is None
+    # WORLD_SIZE inherited from a launcher that disagrees with --gpus: refuse
+    env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run(cmd, env=env1, capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert bad.returncode == 2 and "refusing" in bad.stderr
