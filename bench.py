@@ -11,7 +11,7 @@ torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of 
 torchrun environment launches the N ranks itself (torch.distributed.run, one process per GPU).
 
 Prints ONE JSON line (rank 0).  One submission (= one frame of every stream) is four kernel launches on the back end's
-queue: e264_dbkparam_kernel (bS / alpha / beta), e264_pred_kernel (inter prediction + residual, tile-parallel),
+queue: e264_dbkparam2_kernel (bS / alpha / beta), e264_pred_kernel (inter prediction + residual, tile-parallel),
 e264_intra_kernel (intra wavefront), e264_deblock_kernel (deblocking wavefront).  Kernel times are measured live with HIP
 events recorded on the back end's own queue around each launch.
 
@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-KERNELS = ["e264_dbkparam_kernel", "e264_pred_kernel", "e264_intra_kernel", "e264_deblock_kernel"]
+KERNELS = ["e264_dbkparam2_kernel", "e264_pred_kernel", "e264_intra_kernel", "e264_deblock_kernel"]
 DBK_BYTES = 64  # deblocking parameters per macroblock (edge264_amd/csrc/e264_kernels.h)
 
 
@@ -83,7 +83,7 @@ def kernel_own_bytes(models, n_streams):
         sb = cb = 0.0
         for m in models:
             F, n = m["F"], m["n_mbs"]
-            if name == "e264_dbkparam_kernel":  # reads record headers + motion, writes the parameter records
+            if name == "e264_dbkparam2_kernel":  # reads record headers + motion, writes the parameter records
                 c, s_ = 32 * n + m["cmd_motion"] + DBK_BYTES * n, 0
             elif name == "e264_pred_kernel":  # writes its macroblocks, reads each reference sample once per direction
                 s_ = F * m["inter"] + F * m["dirs"]

@@ -34,6 +34,7 @@
 #include "e264_kernels.h"
 #include "e264_dev.h"
 #include "e264_pred.h"
+#include "e264_dbkp.h"
 
 namespace {
 // ---------------------------------------------------------------------------------
@@ -2022,6 +2023,29 @@ __attribute__((amdgpu_waves_per_eu(E264_PRED_WAVES_PER_EU, E264_PRED_WAVES_PER_E
 	PH_FLUSH(tid & 63);
 }
 
+// Deblocking parameters of every macroblock, 64 consecutive macroblocks per workgroup: records in through LDS with
+// contiguous 16-byte loads, parameters out as contiguous 16-byte stores (e264_dbkp.h; the phases run on the host in tests/emu).
+__global__ __launch_bounds__(DP_NT) void e264_dbkparam2_kernel(const E264Job *jobs)
+{
+	__shared__ DbkpLds L;
+	const int tid = (int)threadIdx.x;
+	FrameCtx f;
+	int bx, by;
+	xcd_tile(bx, by);
+	if (!open_frame(f, jobs[by]) || !f.dbk)
+		return;
+	const int a0 = bx * DP_MBS;
+	if (a0 >= f.wm * f.hm)
+		return;
+	dbkp_phase_load(L, f, a0, tid);
+	__syncthreads();
+	dbkp_phase_slices(L, f, tid);
+	__syncthreads();
+	dbkp_phase_compute(L, f, a0, tid);
+	__syncthreads();
+	dbkp_phase_store(L, f, a0, tid);
+}
+
 // deblocking parameters (bS, alpha, beta, indexA) of every macroblock: one wave per macroblock, few
 // registers, all loads independent -> latency hidden by occupancy.  Runs concurrently with nothing
 // it depends on: only the command packet is read.
@@ -2234,8 +2258,10 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 		hipLaunchKernelGGL(e264_dbkparam_kernel, dim3((max_mbs + 15) / 16, n_jobs), dim3(256), 0, fork->aux, jobs);
 		if (marks) hipEventRecord(fork->amarks[1], fork->aux);
 		hipEventRecord(fork->joined, fork->aux);
-	} else if (dbkp)
+	} else if (dbkp && (mode & 32768)) // debug mode bit 15: round 1's per-lane-load parameter kernel (A/B timing only)
 		hipLaunchKernelGGL(e264_dbkparam_kernel, dim3((max_mbs + 15) / 16, n_jobs), dim3(256), 0, stream, jobs);
+	else if (dbkp)
+		hipLaunchKernelGGL(e264_dbkparam2_kernel, dim3((max_mbs + DP_MBS - 1) / DP_MBS, n_jobs), dim3(DP_NT), 0, stream, jobs);
 	if (marks) hipEventRecord(marks[1], stream);
 	if (mode & 16384) // debug mode bit 14: round 1's strip-per-wave kernel (A/B timing only)
 		hipLaunchKernelGGL(e264_mbpar_kernel, dim3((max_mbs + 4 * E264_MBPAR_STRIP - 1) / (4 * E264_MBPAR_STRIP), n_jobs), dim3(256), 0, stream, jobs, mode);

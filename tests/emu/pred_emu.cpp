@@ -42,6 +42,7 @@ static inline uint32_t v_sat_pk_u8_i16(uint32_t v)
 static inline int lds_add(int *p, int v) { int o = *p; *p += v; return o; }
 static inline void lds_or(uint32_t *p, uint32_t v) { *p |= v; }
 #include "../../edge264_amd/csrc/e264_pred.h"
+#include "../../edge264_amd/csrc/e264_dbkp.h"
 
 extern "C" __attribute__((visibility("default"))) int e264emu_pred_frame(const uint8_t *pkt, uint8_t *const *dpb)
 {
@@ -64,6 +65,27 @@ extern "C" __attribute__((visibility("default"))) int e264emu_pred_frame(const u
 		for (int tid = 0; tid < PT_NT; tid++) pred_phase_reslist(L, tid);
 		for (int tid = 0; tid < PT_NT; tid++) pred_phase_residual(L, f, tid);
 		for (int tid = 0; tid < PT_NT; tid++) pred_phase_flush(L, f, t, tid);
+	}
+	return 0;
+}
+
+// e264_dbkparam2_kernel: out = 64 bytes per macroblock
+extern "C" __attribute__((visibility("default"))) int e264emu_dbkparam_frame(const uint8_t *pkt, uint8_t *out)
+{
+	uint8_t dummy = 0;
+	uint8_t *dpb[E264_MAX_SLOTS];
+	for (int i = 0; i < E264_MAX_SLOTS; i++) dpb[i] = &dummy;
+	E264Job job = {pkt, dpb, out};
+	FrameCtx f;
+	if (!open_frame(f, job))
+		return -1;
+	static DbkpLds L;
+	for (int a0 = 0; a0 < f.wm * f.hm; a0 += DP_MBS) {
+		memset(&L, 0xA5, sizeof(L));
+		for (int tid = 0; tid < DP_NT; tid++) dbkp_phase_load(L, f, a0, tid);
+		for (int tid = 0; tid < DP_NT; tid++) dbkp_phase_slices(L, f, tid);
+		for (int tid = 0; tid < DP_NT; tid++) dbkp_phase_compute(L, f, a0, tid);
+		for (int tid = 0; tid < DP_NT; tid++) dbkp_phase_store(L, f, a0, tid);
 	}
 	return 0;
 }

@@ -11,7 +11,7 @@ timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo
 fi
 summ() { python -c "
 import json,sys
-d=json.load(open(sys.argv[1])); print(sys.argv[2], d['value'], d['bit_exact'], d['roofline']['kernel_ms_per_launch'])" $1 $2; }
+d=json.load(open(sys.argv[1])); print(sys.argv[2], d['value'], d['bit_exact'], {k.split('_')[1]: v['ms_per_launch'] for k, v in d['roofline']['kernels'].items()})" $1 $2; }
 timeout 300 python bench.py --no-cpu-baseline > $OUT/bench_main.json 2> $OUT/bench_main.err; summ $OUT/bench_main.json main
 timeout 300 python bench.py --no-cpu-baseline --debug-mode 16384 > $OUT/bench_old.json 2> $OUT/bench_old.err; summ $OUT/bench_old.json old_mbpar
 for lib in edge264_amd/variants/*.so; do
