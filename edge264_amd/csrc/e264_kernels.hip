@@ -111,10 +111,21 @@ struct __attribute__((aligned(16))) DbkStage {
 	uint32_t y[20][16];    // luma rows -4..15 (index row + 4) x 64 columns
 	uint32_t c[2][10][8];  // chroma planes, rows -2..7 (index row + 2) x 32 columns
 };
+// Input of a PAIR of macroblocks of a row (unfiltered samples, deblocking parameters, header words), fetched with one
+// 16-byte load per lane and piece -- 2 load instructions per pair -- instead of six 4-byte loads per lane and MACROBLOCK:
+// the vector memory path spends 1.5 - 2.5 cycles on every lane of a non-contiguous load whatever its width
+// (tools/calib/load_rate.hip), and with 384 lane-loads per step that, not the filter arithmetic, set the pace.
+struct __attribute__((aligned(16))) DbkIn {
+	uint32_t y[16][8];    // luma rows 0..15 x 2 macroblocks
+	uint32_t c[2][8][4];  // chroma planes, rows 0..7
+	uint32_t prm[2][16];  // E264_DBK_BYTES per macroblock
+	uint32_t hdr[2][4];   // first 16 bytes of the E264Mb records
+};
 struct __attribute__((aligned(16))) DbkLds { // deblocking scratch of one wave = two macroblock rows
 	DbkTile tile[2];     // [half-wave]
 	DbkRing ring[2][2];  // [parity of the row-pair round][half-wave]
 	DbkStage stage[2];   // [half-wave]
+	DbkIn in[2];         // [half-wave]
 };
 
 // -DE264_PHASE_TIMING: wall cycles of the mbpar kernel's phases, summed over all waves (tools/gpu_phase.sh reads them back
@@ -1559,6 +1570,52 @@ __device__ __forceinline__ void dbk_prefetch(const FrameCtx &f, int mbx, int mby
 	}
 }
 
+// ---- pair input: loads only (registers), commit to LDS, per-macroblock pick-up -------------------------------------
+struct DbkPf { v4u a, b; };
+__device__ __forceinline__ void dbk_prefetch_pair(const FrameCtx &f, int x0, int mby, int hl, DbkPf &p)
+{ // nothing here uses a loaded value; pieces beyond the row's last macroblock are not fetched (and never looked at)
+#ifdef E264_ABL_DBK_NOLOAD // timing ablation
+	if (f.wm > 0) { p.a.x = x0; p.b.x = mby; return; }
+#endif
+	const int left = f.wm - x0; // macroblocks of the pair inside the row: min(left, 2)
+	const gu8 *Yb = f.cur + (size_t)(mby * 16) * f.sY + x0 * 16;
+	if ((hl & 1) < left) // luma piece hl: row hl >> 1, macroblock hl & 1
+		p.a = *(const gv4u *)(Yb + (size_t)(hl >> 1) * f.sY + (hl & 1) * 16);
+	const int a = mby * f.wm + x0;
+	if (hl < 16) { // chroma piece hl: plane hl >> 3, row hl & 7, both macroblocks (8 bytes each)
+		const gu8 *cp = plane_base(f, f.cur, 1 + (hl >> 3)) + (size_t)(mby * 8 + (hl & 7)) * f.sC + x0 * 8;
+		if (left > 1) p.b = *(const gv4u *)cp;
+		else { const v2u h = *(const gv2u *)cp; p.b.x = h.x; p.b.y = h.y; }
+	} else if (hl < 24) { // parameter records: macroblock (hl - 16) >> 2, piece hl & 3
+		if (((hl - 16) >> 2) < left) p.b = *(const gv4u *)(f.dbk + (size_t)(a + ((hl - 16) >> 2)) * E264_DBK_BYTES + (hl & 3) * 16);
+	} else if (hl < 26) { // header records: macroblock hl - 24
+		if (hl - 24 < left) p.b = *(const gv4u *)((const gu8 *)(f.payload - f.h->payload_off + f.h->mbs_off) + (size_t)(a + hl - 24) * sizeof(E264Mb));
+	}
+}
+__device__ __forceinline__ void dbk_commit_pair(DbkIn &I, int hl, const DbkPf &p)
+{
+	*(v4u *)&I.y[hl >> 1][(hl & 1) * 4] = p.a;
+	if (hl < 16) *(v4u *)&I.c[hl >> 3][hl & 7][0] = p.b;
+	else if (hl < 24) *(v4u *)&I.prm[(hl - 16) >> 2][(hl & 3) * 4] = p.b;
+	else if (hl < 26) *(v4u *)&I.hdr[hl - 24][0] = p.b;
+}
+__device__ __forceinline__ void dbk_fetch_mb(const DbkIn &I, int k, int hl, DbkRegs &r)
+{ // macroblock k (0 / 1) of the committed pair -> the per-lane registers dbk_process consumes
+	r.va0 = I.y[hl >> 2][k * 4 + (hl & 3)];
+	r.va1 = I.y[8 + (hl >> 2)][k * 4 + (hl & 3)];
+	r.vc = I.c[hl >> 4][(hl >> 1) & 7][k * 2 + (hl & 1)];
+	r.vp = I.prm[k][hl & 15];
+	r.hdr = I.hdr[k][0];
+}
+// top rows of macroblock (mbx, mby) from memory (first wave of a round: the row above belongs to the previous round)
+__device__ __forceinline__ void dbk_prefetch_top(const FrameCtx &f, int mbx, int mby, int hl, uint32_t &vt)
+{
+	gu8 *Yb = f.cur + (size_t)(mby * 16) * f.sY + mbx * 16;
+	gu8 *Cb0 = plane_base(f, f.cur, 1) + (size_t)(mby * 8) * f.sC + mbx * 8;
+	if (hl < 16) vt = *(const gu32 *)(Yb + (ptrdiff_t)(-4 + (hl >> 2)) * f.sY + (hl & 3) * 4);
+	else if (hl < 24) { int i = hl - 16; vt = *(const gu32 *)(Cb0 + (i >> 2) * (f.sC >> 1) + (ptrdiff_t)(-2 + ((i >> 1) & 1)) * f.sC + (i & 1) * 4); }
+}
+
 // top rows from the LDS ring of the row above: hl 0..15 luma rows -4..-1 (4 dwords each),
 // hl 16..23 chroma rows -2..-1 (2 planes x 2 rows x 2 dwords)
 __device__ __forceinline__ void dbk_load_top(const DbkRing &up, int mbx, int hl, DbkRegs &r)
@@ -1576,6 +1633,9 @@ __device__ __forceinline__ void dbk_flush(const DbkStage &S, const FrameCtx &f, 
 	// Runs every 4th step only: its per-lane index arithmetic is kept out of the set of loop invariants (opaque lane
 	// index), where it competed for registers with the per-step code and pushed other invariants into scratch.
 	asm volatile("" : "+v"(hl));
+#ifdef E264_ABL_DBK_NOSTORE // timing ablation
+	if (f.wm > 0) return;
+#endif
 	// all LDS reads first (unconditional, clamped indices), then the predicated stores: one LDS round trip instead of five
 	gu8 *Yb = f.cur + (size_t)(mby * 16) * f.sY + g * 64;
 	v4u yv[3], cv[2];
@@ -2190,14 +2250,17 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 		// the lower row of the last wave is read by wave 0 of the next round from memory, not from the ring
 		const bool handoff = wave == NW - 1 && half == 1 && my_y + 1 < f.hm;
 		const bool self_bottom = handoff || my_y == f.hm - 1;
-		DbkRegs cur = {0, 0, 0, 0, 0, 0, false}, nxt = cur;
+		DbkRegs cur = {0, 0, 0, 0, 0, 0, false};
+		DbkPf pf;
+		uint32_t vt_next = 0;
 		PH_DECL;
 		if (gtop_wave) {
 			while (lds_load_relaxed(&progress[yA - 1]) < min(2, f.wm))
 				__builtin_amdgcn_s_sleep(1);
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 		}
-		dbk_prefetch(f, 0, my_y, hl, row_ok && half == 0, gtop, cur);
+		if (row_ok) dbk_prefetch_pair(f, 0, my_y, hl, pf); // the rows' own samples depend on nothing in this kernel
+		if (gtop && row_ok) dbk_prefetch_top(f, 0, my_y, hl, vt_next);
 #pragma unroll 1
 		for (int t = 0; t < f.wm + DBK_LAG; t++) {
 			const int xB = t - DBK_LAG;
@@ -2215,11 +2278,19 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 			if (gtop_wave) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 			else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 			PH(1);
-			if (!gtop && my_y > 0)
+			cur.act = row_ok && my_x >= 0 && my_x < f.wm;
+			if (cur.act && (my_x & 1) == 0) { // a new pair: the prefetched registers -> LDS, the next pair's loads go out
+				__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the pair was requested 2 macroblocks ago
+				dbk_commit_pair(L.in[half], hl, pf);
+				if (my_x + 2 < f.wm) dbk_prefetch_pair(f, my_x + 2, my_y, hl, pf);
+			}
+			wave_sync();
+			if (cur.act) dbk_fetch_mb(L.in[half], my_x & 1, hl, cur);
+			if (gtop) {
+				cur.vt = vt_next;
+				if (row_ok && my_x + 1 < f.wm) dbk_prefetch_top(f, my_x + 1, my_y, hl, vt_next);
+			} else if (my_y > 0)
 				dbk_load_top(upring, my_x, hl, cur);
-			PH(2);
-			const int nx = my_x + 1;
-			dbk_prefetch(f, nx, my_y, hl, row_ok && nx >= 0 && nx < f.wm, gtop, nxt);
 			PH(3);
 			dbk_process(L.tile[half], myring, L.stage[half], tc0tab, f, my_x, my_y, hl, cur, my_x > 0, my_x == f.wm - 1, self_bottom PH_ARGS);
 			PH(8);
@@ -2231,7 +2302,6 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 			const int done = handoff ? (my_x == f.wm - 1 ? f.wm : (my_x & ~3)) : my_x + 1;
 			if (hl == 0 && cur.act)
 				__hip_atomic_store(&progress[my_y], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			cur = nxt;
 			PH(9);
 		}
 		PH_FLUSH_DBK(lane);
@@ -2283,9 +2353,8 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 		switch (waves) {
 		case 9: hipLaunchKernelGGL(e264_deblock_kernel<9>, dim3(n_jobs), dim3(576), 0, stream, jobs); break;
 		case 10: hipLaunchKernelGGL(e264_deblock_kernel<10>, dim3(n_jobs), dim3(640), 0, stream, jobs); break;
-		case 12: hipLaunchKernelGGL(e264_deblock_kernel<12>, dim3(n_jobs), dim3(768), 0, stream, jobs); break;
+		case 12: case 16: hipLaunchKernelGGL(e264_deblock_kernel<12>, dim3(n_jobs), dim3(768), 0, stream, jobs); break; // 16 waves no longer fit the LDS
 		case 4: hipLaunchKernelGGL(e264_deblock_kernel<4>, dim3(n_jobs), dim3(256), 0, stream, jobs); break;
-		case 16: hipLaunchKernelGGL(e264_deblock_kernel<16>, dim3(n_jobs), dim3(1024), 0, stream, jobs); break;
 		default: hipLaunchKernelGGL(e264_deblock_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs); break;
 		}
 	}
