@@ -62,6 +62,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs[1] and configs[3] (N=1)")
     ap.add_argument("--no-host-packets", action="store_true", help="skip the PCIe-inclusive run (N=1)")
     ap.add_argument("--debug-mode", type=int, default=0, help="profiling ablation bits (results may then be wrong on purpose)")
+    ap.add_argument("--capture", default=None, help="capture file (edge264_amd/replay.py): its first stream's packets replace the synthetic GOP, "
+                    "so that the kernels are timed on real motion / partition statistics (tools/make_capture.py writes one from a .264)")
     return ap.parse_args(argv)
 
 
@@ -134,12 +136,28 @@ def main() -> int:
 
     W, H = args.width_mbs, args.height_mbs
     ALL_I = (P.MB_I4x4, P.MB_I8x8, P.MB_I16x16)
-    # ---- synthetic input (same bytes on every rank: seeded) -------------------------------
-    gen = synth.StreamSynth(W, H, seed=1234, t8x8=True, i_kinds=ALL_I, num_refs=2, residual_prob=0.3)
-    packets = gen.gop(args.gop)
-    parsed = [P.Packet(p) for p in packets]
+    fill_value = 128
+    if args.capture:
+        # ---- captured packets of a real bitstream (reference front end -> our emitters), first stream of the file ----
+        from edge264_amd import replay
+        cap = replay.Capture.load(args.capture)
+        packets = cap.of_stream(cap.stream_ids()[0])
+        parsed = [P.Packet(p) for p in packets]
+        W, H = int(parsed[0].hdr["width_mbs"]), int(parsed[0].hdr["height_mbs"])
+        args.gop = f"capture:{os.path.basename(args.capture)}:{len(packets)} pictures"
+        fill_value = 0
+        args.no_other_configs = args.no_host_packets = True
+    else:
+        # ---- synthetic input (same bytes on every rank: seeded) -------------------------------
+        gen = synth.StreamSynth(W, H, seed=1234, t8x8=True, i_kinds=ALL_I, num_refs=2, residual_prob=0.3)
+        packets = gen.gop(args.gop)
+        parsed = [P.Packet(p) for p in packets]
     models = [pk.traffic_model() for pk in parsed]
-    n_slots = max(max(int(pk.hdr["dst_slot"]) for pk in parsed) + 1, 3)
+    used = 0
+    for pk in parsed:
+        used |= 1 << int(pk.hdr["dst_slot"]) | int(pk.hdr["ref_slots"])
+    n_slots = max(used.bit_length(), 3)
+    frame_nb = int(parsed[0].hdr["plane_size_Y"]) + int(parsed[0].hdr["plane_size_C"])
 
     # weak scaling: rank r owns streams shard_streams(streams * world, r, world) (= `streams` of them)
     my_streams = len(shard_streams(args.streams * world, rank, world))
@@ -151,9 +169,10 @@ def main() -> int:
     streams, dpk = [], []
     for s in range(my_streams):
         st = backend.Stream(dev, W, H)
+        st.frame_bytes = frame_nb
         for i in range(n_slots):
             st.alloc(i)
-            st.fill(i, 128)
+            st.fill(i, fill_value)
         streams.append(st)
         dpk.append([dev.upload_packet(p) for p in packets])  # per-stream copy of the command bytes
     batches = [dev.make_batch(streams, [dpk[s][f] for s in range(my_streams)]) for f in range(len(packets))]
@@ -200,11 +219,11 @@ def main() -> int:
     if rank == 0 and not args.no_verify and not stub:
         from oracle.pyoracle import Oracle
         orc = Oracle()
-        nb = P.frame_bytes(W, H)
-        dpb = [np.full(nb + 16, 128, np.uint8) for _ in range(n_slots)] + [None] * (32 - n_slots)
+        nb = frame_nb
+        dpb = [np.full(nb + 64, fill_value, np.uint8) for _ in range(n_slots)] + [None] * (32 - n_slots)
         for st in streams:
             for i in range(n_slots):
-                st.fill(i, 128)
+                st.fill(i, fill_value)
         bad = 0
         for f, p in enumerate(packets):
             orc.decode_frame(p, dpb, 3)
@@ -225,7 +244,9 @@ def main() -> int:
             cpu = reference_decoder_baseline(min(args.cpu_seconds, 6.0), args.cpu_seconds)
         except (OSError, FileNotFoundError) as e:
             cpu = {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference", "sample": f"unavailable: {e}"}
-        try:  # second figure: the reference's own sample kernels (no entropy decoding) replaying the bench packets, one core
+        try:  # second figure (synthetic GOP only): the reference's own sample kernels (no entropy decoding) replaying the bench packets, one core
+            if args.capture:
+                raise FileNotFoundError
             from oracle.pyoracle import RefKernels
             rk = RefKernels()
             nb = P.frame_bytes(W, H)
@@ -341,10 +362,11 @@ def main() -> int:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{W * 16}x{H * 16} High-profile {args.gop} GOP (synthetic command packets: intra 4x4 / 8x8 / 16x16 I frame + "
-                                   "P frames with 6-tap luma / bilinear chroma MC, 2 references, 4x4 and 8x8 transforms, 30% coded residual, "
-                                   "in-loop deblocking), BASELINE configs[2]",
+            "dtype": "u8", "data": "captured bitstream packets" if args.capture else "synthetic",
+            "config": {"workload": (f"{W * 16}x{H * 16} captured packets of a real bitstream ({args.gop}), one copy per stream" if args.capture else
+                                    f"{W * 16}x{H * 16} High-profile {args.gop} GOP (synthetic command packets: intra 4x4 / 8x8 / 16x16 I frame + "
+                                    "P frames with 6-tap luma / bilinear chroma MC, 2 references, 4x4 and 8x8 transforms, 30% coded residual, "
+                                    "in-loop deblocking), BASELINE configs[2]"),
                        "streams_per_gpu": args.streams, "frames_per_step": frames_per_step,
                        "waves_per_frame": args.waves, "parallelism": f"stream-parallel x{world}, no collectives"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -33,6 +33,8 @@ struct E264Packet {
 	size_t bytes;
 	int dst_slot;
 	int n_mbs, n_tiles;
+	uint64_t frame_bytes;  // plane_size_Y + plane_size_C the kernels will touch in every slot the packet names
+	uint32_t ref_mask;     // DPB slots its motion refers to
 };
 
 struct E264Device {
@@ -279,7 +281,10 @@ static int check_packet(const void *packet, size_t bytes, int *dst, int *n_mbs, 
 // Everything a kernel will dereference through the packet, checked on the host before the packet may reach the
 // device (a wild offset would be a GPU memory fault = process abort, not an error code): section layout, per-macroblock
 // kind / slice index / payload bounds, reference slots.  `slots` (may be null): allocated-slot table of the stream.
-static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *slots)
+// `slot_bytes` (with `slots`): size of every allocated slot -- a packet whose header claims a larger picture than the slot
+// it writes or reads (SPS size change, stale capture, foreign packet) would make the kernels run past the allocation.
+// `ref_mask_out` (may be null): DPB slots the packet's motion refers to.
+static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *slots, const size_t *slot_bytes = nullptr, uint32_t *ref_mask_out = nullptr)
 {
 	int dst, n_mbs, r = check_packet(packet, bytes, &dst, &n_mbs);
 	if (r) return r;
@@ -292,13 +297,17 @@ static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *s
 		return fail(EINVAL, "strides");
 	if ((uint64_t)h->plane_size_Y < (uint64_t)h->stride_Y * h->height_mbs * 16 || (uint64_t)h->plane_size_C < (uint64_t)h->stride_C * h->height_mbs * 8)
 		return fail(EINVAL, "plane sizes");
+	const uint64_t frame_need = (uint64_t)h->plane_size_Y + h->plane_size_C;
+	if (slots && slot_bytes && slots[dst] && frame_need > slot_bytes[dst]) return fail(EINVAL, "picture larger than the destination slot");
 	const E264Mb *mbs = (const E264Mb *)(p + h->mbs_off);
 	const E264Motion *mo = h->motion_off ? (const E264Motion *)(p + h->motion_off) : nullptr;
+	uint32_t ref_mask = 0;
 	for (int a = 0; a < n_mbs; a++) {
 		const E264Mb &m = mbs[a];
 		if (m.kind > E264_MB_INTER) return fail(EINVAL, "macroblock kind");
+		if (m.slice >= h->n_slices) return fail(EINVAL, "macroblock slice index"); // every record: the parameter kernel reads the slice of absent macroblocks too
 		if (m.kind == E264_MB_ABSENT) continue;
-		if (m.slice >= h->n_slices) return fail(EINVAL, "macroblock slice index");
+		if ((m.flags & E264_MBF_T8x8) && (m.kind == E264_MB_I16x16 || m.kind == E264_MB_PCM)) return fail(EINVAL, "8x8 transform flag on an Intra16x16 / PCM macroblock");
 		if ((m.payload_off & 7) || (uint64_t)m.payload_off + e264_mb_payload_bytes(&m) > h->payload_bytes) return fail(EINVAL, "macroblock payload");
 		if ((m.flags & E264_MBF_EDGE_LEFT) && a % h->width_mbs == 0) return fail(EINVAL, "left edge flag on the first column");
 		if ((m.flags & E264_MBF_EDGE_TOP) && a < h->width_mbs) return fail(EINVAL, "top edge flag on the first row");
@@ -308,10 +317,13 @@ static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *s
 				int rp = mo[a].refPic[i];
 				if (rp < -1 || rp >= E264_MAX_SLOTS) return fail(EINVAL, "reference slot");
 				if (rp >= 0 && slots && !slots[rp]) return fail(EINVAL, "reference slot not allocated");
+				if (rp >= 0 && slots && slot_bytes && frame_need > slot_bytes[rp]) return fail(EINVAL, "picture larger than a reference slot");
+				if (rp >= 0) ref_mask |= 1u << rp;
 				if (mo[a].refIdx[i] < -1 || mo[a].refIdx[i] > 31) return fail(EINVAL, "reference index");
 			}
 		}
 	}
+	if (ref_mask_out) *ref_mask_out = ref_mask;
 	return 0;
 }
 
@@ -376,7 +388,7 @@ API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
 	int dst, n_mbs, n_tiles, r = check_packet(packet, bytes, &dst, &n_mbs, &n_tiles);
 	if (r) return r;
 	if (!s->h_table[dst]) return fail(EINVAL, "destination slot not allocated");
-	if ((r = check_packet_deep(packet, bytes, s->h_table))) return r;
+	if ((r = check_packet_deep(packet, bytes, s->h_table, s->slot_bytes))) return r;
 	if (set_device(s->dev)) return EIO;
 	if ((r = ensure_dbk(s, n_mbs))) return r;
 	E264Stream::Stage *st = &s->stage[s->stage_next];
@@ -424,11 +436,13 @@ API int e264hip_packet_upload(E264Device *dev, const void *packet, size_t bytes,
 	if (!dev || !out) return fail(EINVAL, "null argument");
 	int dst, n_mbs, n_tiles, r = check_packet(packet, bytes, &dst, &n_mbs, &n_tiles);
 	if (r) return r;
-	if ((r = check_packet_deep(packet, bytes, nullptr))) return r;
+	uint32_t ref_mask = 0;
+	if ((r = check_packet_deep(packet, bytes, nullptr, nullptr, &ref_mask))) return r;
 	if (set_device(dev)) return EIO;
 	E264Packet *p = new (std::nothrow) E264Packet();
 	if (!p) return fail(ENOMEM, "packet object");
-	p->dev = dev; p->bytes = bytes; p->dst_slot = dst; p->n_mbs = n_mbs; p->n_tiles = n_tiles;
+	p->dev = dev; p->bytes = bytes; p->dst_slot = dst; p->n_mbs = n_mbs; p->n_tiles = n_tiles; p->ref_mask = ref_mask;
+	p->frame_bytes = (uint64_t)((const E264FrameHdr *)packet)->plane_size_Y + ((const E264FrameHdr *)packet)->plane_size_C;
 	if (hipMalloc((void **)&p->d_bytes, bytes) != hipSuccess) { delete p; return fail(ENOMEM, "hipMalloc packet"); }
 	hipError_t e = hipMemcpy(p->d_bytes, packet, bytes, hipMemcpyHostToDevice);
 	if (e != hipSuccess) { hipFree(p->d_bytes); delete p; return fail(EIO, "hipMemcpy packet", e); }
@@ -460,6 +474,15 @@ API int e264hip_batch_create(E264Device *dev, E264Stream *const *streams, E264Pa
 	for (int i = 0; i < n; i++) {
 		if (!streams[i] || !packets[i] || streams[i]->dev != dev || packets[i]->dev != dev) return fail(EINVAL, "batch entry");
 		if (!streams[i]->h_table[packets[i]->dst_slot]) return fail(EINVAL, "destination slot not allocated");
+		// the packet was vetted without a stream at upload time: its slots against THIS stream's allocations
+		if (packets[i]->frame_bytes > streams[i]->slot_bytes[packets[i]->dst_slot]) return fail(EINVAL, "picture larger than the destination slot");
+		for (int sl = 0; sl < E264_MAX_SLOTS; sl++)
+			if (packets[i]->ref_mask >> sl & 1) {
+				if (!streams[i]->h_table[sl]) return fail(EINVAL, "reference slot not allocated");
+				if (packets[i]->frame_bytes > streams[i]->slot_bytes[sl]) return fail(EINVAL, "picture larger than a reference slot");
+			}
+		for (int j = 0; j < i; j++) // two jobs of one stream would share its DPB and parameter buffer inside one launch
+			if (streams[j] == streams[i]) return fail(EINVAL, "a stream may contribute one frame per batch");
 		int r = ensure_dbk(streams[i], packets[i]->n_mbs);
 		if (r) return r;
 		jobs[i].packet = packets[i]->d_bytes;
@@ -520,7 +543,7 @@ API int e264hip_submit_batch_host(E264Device *dev, E264Stream *const *streams, c
 		int dst, r = check_packet(packets[i], bytes[i], &dst, &mbs_of[i], &tiles_of[i]);
 		if (r) return r;
 		if (!s->h_table[dst]) return fail(EINVAL, "destination slot not allocated");
-		if ((r = check_packet_deep(packets[i], bytes[i], s->h_table))) return r;
+		if ((r = check_packet_deep(packets[i], bytes[i], s->h_table, s->slot_bytes))) return r;
 	}
 	std::lock_guard<std::mutex> bg(dev->batch_lock); // batches of one device are serialised (their streams are disjoint per batch anyway)
 	E264Device::JobRing &jr = dev->jring[dev->jring_next];

@@ -230,7 +230,11 @@ int main(int argc, char **argv)
 		streams.clear(); hpk.clear(); hsz.clear();
 		for (Stream &s : S)
 			if (s.pkt) {
-				if (dump) fwrite(s.pkt, 1, s.pkt_bytes, dump);
+				if (dump) { // capture file: the packets of all decoders interleaved, each tagged with its decoder (E264FrameHdr.stream_id, byte 76)
+					uint32_t sid = (uint32_t)(&s - &S[0]);
+					memcpy((uint8_t *)s.pkt + 76, &sid, 4);
+					fwrite(s.pkt, 1, s.pkt_bytes, dump);
+				}
 				packets++;
 				if (!parse_only) { streams.push_back(F.stream(s.dec)); hpk.push_back(s.pkt); hsz.push_back(s.pkt_bytes); }
 			}

@@ -35,7 +35,7 @@ FRAME_HDR = np.dtype([
     ("stride_Y", "<u4"), ("stride_C", "<u4"), ("plane_size_Y", "<u4"), ("plane_size_C", "<u4"),
     ("n_slices", "<u4"), ("slices_off", "<u4"), ("mbs_off", "<u4"), ("payload_off", "<u4"),
     ("payload_bytes", "<u4"), ("dst_slot", "<i4"), ("ref_slots", "<u4"), ("frame_id", "<i4"),
-    ("n_coded_mbs", "<u4"), ("n_inter_mbs", "<u4"), ("motion_off", "<u4"), ("reserved", "<u4", (1,)),
+    ("n_coded_mbs", "<u4"), ("n_inter_mbs", "<u4"), ("motion_off", "<u4"), ("stream_id", "<u4"),
 ])
 assert FRAME_HDR.itemsize == 80
 

@@ -90,7 +90,8 @@ typedef struct E264FrameHdr { /* 80 bytes */
 	uint32_t n_coded_mbs;     /* macroblocks with kind != ABSENT */
 	uint32_t n_inter_mbs;
 	uint32_t motion_off;      /* E264Motion[n_mbs], 0 if the frame has no inter macroblock */
-	uint32_t reserved[1];
+	uint32_t stream_id;       /* capture files (a concatenation of packets): which decoder the packet belongs to;
+	                             ignored by the kernels */
 } E264FrameHdr;
 
 typedef struct E264SliceParams { /* 2112 bytes */

@@ -212,3 +212,42 @@ def test_waves_per_frame(device, oracle, waves):
     finally:
         device.set_option("waves", prev)
         device.set_option("intra_waves", 16)  # "waves" sets both kernels; the intra default is 16
+
+
+def test_geometry_and_batch_validation(device):
+    """A packet may not name a picture larger than the slots it writes / reads, a batch may not hold a stream twice nor
+    refer to unallocated reference slots: EINVAL from the C ABI, never a GPU fault (round-1 advisor findings)."""
+    from edge264_amd import backend
+    w, h = 4, 3
+    g = synth.StreamSynth(w, h, 3)
+    i_pkt, p_pkt = g.next_frame("I"), g.next_frame("P")
+    nb = P.frame_bytes(w, h)
+    st, st2 = backend.Stream(device, w, h), backend.Stream(device, w, h)
+    try:
+        small = nb // 2
+        for s_ in (st, st2):
+            for i in range(6):
+                s_.L.e264hip_frame_alloc(s_.h, i, small if s_ is st else nb, None)
+        # 1. destination slot smaller than the picture: front-end path and batch path
+        with pytest.raises(backend.BackendError):
+            st.submit(i_pkt)
+        di, dp = device.upload_packet(i_pkt), device.upload_packet(p_pkt)
+        with pytest.raises(backend.BackendError):
+            device.submit_batch([st], [di], backend.RUN_ALL)
+        # 2. the same stream twice in one batch
+        with pytest.raises(backend.BackendError):
+            device.submit_batch([st2, st2], [di, di], backend.RUN_ALL)
+        # 3. reference slot of the P frame not allocated in this stream
+        ref = int(np.nonzero(P.Packet(p_pkt).motion["refPic"].max(axis=0) >= 0)[0][0]) if False else None
+        used = sorted({int(x) for x in P.Packet(p_pkt).motion["refPic"].ravel() if x >= 0})
+        assert used
+        st2.free(used[0])
+        with pytest.raises(backend.BackendError):
+            device.submit_batch([st2], [dp], backend.RUN_ALL)
+        # the good path still works afterwards
+        st2.alloc(used[0])
+        st2.fill(used[0], 128)
+        device.submit_batch([st2], [di], backend.RUN_ALL)
+        di.free(); dp.free()
+    finally:
+        st.close(); st2.close()

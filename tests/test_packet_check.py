@@ -96,6 +96,8 @@ CORRUPTIONS = [
     ("mb_payload_off", 0, mb_set("payload_off", 1 << 27)),
     ("mb_payload_align", 0, mb_set("payload_off", 4)),
     ("coded_overrun", 0, mb_set("payload_off", None)),     # filled in below: last 8 bytes of the payload
+    ("t8x8_on_i16x16", 0, None),                            # filled in below
+    ("absent_wild_slice", 0, None),                         # filled in below: ABSENT records are read by the parameter kernel too
     ("refPic", 1, motion_set("refPic", 0, 40)),
     ("refPic_neg", 1, motion_set("refPic", 0, -3)),
     ("refIdx", 1, motion_set("refIdx", 0, 77)),
@@ -110,6 +112,15 @@ def test_corruption_is_einval(gop, name, frame, fn):
             mbs = np.frombuffer(buf, P.MB, len(pk.mbs), int(pk.hdr["mbs_off"]))
             a = int(np.nonzero(mbs["coded"] != 0)[0][0])
             mbs["payload_off"][a] = (int(pk.hdr["payload_bytes"]) - 8) & ~7
+    if name == "t8x8_on_i16x16":
+        def fn(pk, buf):
+            mbs = np.frombuffer(buf, P.MB, len(pk.mbs), int(pk.hdr["mbs_off"]))
+            mbs["flags"][first(pk, P.MB_I16x16)] |= P.MBF_T8x8
+    if name == "absent_wild_slice":
+        def fn(pk, buf):
+            mbs = np.frombuffer(buf, P.MB, len(pk.mbs), int(pk.hdr["mbs_off"]))
+            mbs["kind"][3] = P.MB_ABSENT
+            mbs["slice"][3] = 60000
     bad = mutate(raw, fn)
     assert bad != raw
     assert backend.packet_check(bad) == errno.EINVAL
