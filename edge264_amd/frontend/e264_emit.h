@@ -88,7 +88,9 @@ static E264FrameBuilder *e264_builder(E264Emitter *e, int slot)
 	E264FrameBuilder *b = &e->fb[slot];
 	Edge264Decoder *dec = e->dec;
 	int w = dec->sps.pic_width_in_mbs, h = dec->sps.pic_height_in_mbs;
-	if (b->active && (b->width_mbs != w || b->height_mbs != h))
+	/* a new picture in this slot starts from empty records: also when the previous one never completed (a lost slice
+	 * leaves next_deblock_addr short of INT_MAX) and the reference reuses the slot */
+	if (b->active && (b->width_mbs != w || b->height_mbs != h || b->frame_id != dec->FrameIds[slot]))
 		b->active = 0;
 	if (!b->active) {
 		if (b->n_mbs != w * h) {

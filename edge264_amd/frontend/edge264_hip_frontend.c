@@ -75,13 +75,13 @@ static int hip_bind(void)
 		return hip.dev ? 0 : ENODEV;
 	const char *path = getenv("E264_HIP_LIB");
 	char buf[4096];
-	if (!path) { /* <repo>/oracle/_ref/libedge264_hipfront.so -> <repo>/edge264_amd/libedge264_hip.so */
+	if (!path) { /* the back end is the sibling of this library: edge264_amd/libedge264_hipfront.so -> edge264_amd/libedge264_hip.so */
 		Dl_info info;
 		if (dladdr((void *)hip_bind, &info) && info.dli_fname) {
 			snprintf(buf, sizeof(buf), "%s", info.dli_fname);
 			char *s = strrchr(buf, '/');
 			if (s) {
-				snprintf(s, sizeof(buf) - (size_t)(s - buf), "/../../edge264_amd/libedge264_hip.so");
+				snprintf(s, sizeof(buf) - (size_t)(s - buf), "/libedge264_hip.so");
 				path = buf;
 			}
 		}
@@ -191,6 +191,11 @@ static int e264_finish_frame(E264Emitter *e, int slot)
 		}
 		n_coded += m->kind != E264_MB_ABSENT;
 	}
+	/* counted from the final records: a macroblock decoded again by a resent slice is one macroblock (the intra kernel's
+	 * early exit compares these two numbers) */
+	b->n_inter = 0;
+	for (int a = 0; a < b->n_mbs; a++)
+		b->n_inter += b->mbs[a].kind == E264_MB_INTER;
 	if (b->n_slices == 0) { /* cannot happen for a decoded frame; keep the packet well formed */
 		int serial = e->serial;
 		e->serial = -1;
@@ -262,9 +267,18 @@ PUBLIC const uint8_t *edge264_find_start_code(const uint8_t *buf, const uint8_t 
 PUBLIC Edge264Decoder *edge264_alloc(int n_threads, Edge264LogCb log_cb, void *log_arg, int log_mbs,
 	Edge264AllocCb alloc_cb, Edge264FreeCb free_cb, void *alloc_arg)
 {
-	/* frame memory is owned by the back end, parsing is synchronous: caller-provided allocators and
-	 * worker threads do not apply (documented in INTEGRATION.md) */
-	(void)n_threads; (void)alloc_cb; (void)free_cb; (void)alloc_arg; (void)log_mbs;
+	/* What this back end cannot honour is REFUSED (NULL, errno = ENOTSUP), never silently changed:
+	 *   n_threads > 0   slices are parsed synchronously inside edge264_decode_NAL (src/edge264_headers.c:1285-1286 path);
+	 *                   host parallelism = one decoder per stream, which is also what fills the GPU.  n_threads < 0 ("pick
+	 *                   for me", src/edge264.c:222-227) is accepted and means 0 here.
+	 *   alloc_cb / free_cb   frame memory lives in HBM and is owned by the back end (edge264.h:42-43 hands the application
+	 *                   host memory it would then expect the decoder to write). */
+	if (n_threads > 0 || alloc_cb || free_cb) {
+		if (log_cb) log_cb("edge264_alloc: worker threads and caller allocators are not supported by the MI355X back end\n", log_arg);
+		errno = ENOTSUP;
+		return NULL;
+	}
+	(void)alloc_arg; (void)log_mbs;
 	E264Emitter *e = calloc(1, sizeof(*e));
 	if (!e)
 		return NULL;

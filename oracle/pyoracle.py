@@ -198,13 +198,13 @@ def oracle_chroma_mc(o: Oracle, ref: np.ndarray, stride: int, w: int, h: int, x:
 
 
 class HipFront(Edge264Lib):
-    """oracle/_ref/libedge264_hipfront.so: the reference's front end (parsers, DPB, reference lists,
+    """edge264_amd/libedge264_hipfront.so (the PRODUCT's front-end library, built by edge264_amd/frontend/Makefile): the reference's front end (parsers, DPB, reference lists,
     compiled from /root/reference) bound to edge264_amd/frontend's packet emitters behind the edge264.h
     API.  sink 1 = capture (packets handed back, replayed here by the oracle: CPU test of the boundary);
     sink 0 = libedge264_hip.so (GPU)."""
 
     def __init__(self, path: str | None = None):
-        super().__init__(path or os.path.join(HERE, "_ref", "libedge264_hipfront.so"))
+        super().__init__(path or os.path.join(os.path.dirname(HERE), "edge264_amd", "libedge264_hipfront.so"))
         L = self.lib
         L.e264front_set_sink.argtypes = [C.c_int]
         L.e264front_take_packet.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]

@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 DIR = os.environ.get("E264_CONFORMANCE_DIR", os.path.join(ROOT, "conformance"))
 CLIPS = sorted(glob.glob(os.path.join(DIR, "*.264")))
-FRONT = os.path.join(ROOT, "oracle", "_ref", "libedge264_hipfront.so")
+FRONT = os.path.join(ROOT, "edge264_amd", "libedge264_hipfront.so")
 
 pytestmark = pytest.mark.skipif(not CLIPS or not os.path.exists(FRONT), reason=f"no conformance clips in {DIR} (or front end not built)")
 

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(HERE)
 STREAMS = os.path.join(HERE, "golden", "streams")
 REF = os.path.join(ROOT, "oracle", "_ref")
 
-pytestmark = pytest.mark.skipif(not (os.path.exists(os.path.join(REF, "libedge264_hipfront.so")) and
+pytestmark = pytest.mark.skipif(not (os.path.exists(os.path.join(os.path.dirname(REF), "..", "edge264_amd", "libedge264_hipfront.so")) and
                                      os.path.exists(os.path.join(REF, "libedge264_ref.so"))),
                                 reason="oracle/_ref is built from /root/reference (make -C oracle ref)")
 

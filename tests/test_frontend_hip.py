@@ -11,7 +11,7 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 STREAMS = os.path.join(HERE, "golden", "streams")
-FRONT = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libedge264_hipfront.so")
+FRONT = os.path.join(os.path.dirname(HERE), "edge264_amd", "libedge264_hipfront.so")
 NAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(STREAMS, "*.264")))
 
 pytestmark = pytest.mark.gpu

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 STREAMS = os.path.join(HERE, "golden", "streams")
 EXE = os.path.join(ROOT, "edge264_amd", "e264_multi")
-FRONT = os.path.join(ROOT, "oracle", "_ref", "libedge264_hipfront.so")
+FRONT = os.path.join(ROOT, "edge264_amd", "libedge264_hipfront.so")
 HIP = os.path.join(ROOT, "edge264_amd", "libedge264_hip.so")
 
 pytestmark = pytest.mark.gpu

@@ -27,7 +27,7 @@ def test_synth_packets_pass(gop):
         assert backend.packet_check(raw) == 0
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "libedge264_hipfront.so")), reason="front end not built")
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(REF), "..", "edge264_amd", "libedge264_hipfront.so")), reason="front end not built")
 def test_front_end_packets_pass(oracle):
     from oracle.pyoracle import HipFront
     n = 0

@@ -14,8 +14,8 @@ from edge264_amd import packet as P, replay
 HERE = os.path.dirname(os.path.abspath(__file__))
 STREAMS = os.path.join(HERE, "golden", "streams")
 REF = os.path.join(os.path.dirname(HERE), "oracle", "_ref")
-needs_front = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "libedge264_hipfront.so")),
-                                 reason="oracle/_ref/libedge264_hipfront.so is built from /root/reference (make -C oracle ref)")
+needs_front = pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(REF), "..", "edge264_amd", "libedge264_hipfront.so")),
+                                 reason="edge264_amd/libedge264_hipfront.so is built from /root/reference (make -C edge264_amd/frontend)")
 NAMES = ["ipb_spatial", "cabac_ipb_temporal_implicit", "weighted_explicit", "t8x8_scaling", "mvc_ipb"]
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/make_capture.py a.264 [b.264 ...] out.e264 -- decodes Annex-B streams with the reference's front end bound to our
-packet emitters (capture sink, CPU only: oracle/_ref/libedge264_hipfront.so) and writes the command packets as a capture
+packet emitters (capture sink, CPU only: edge264_amd/libedge264_hipfront.so) and writes the command packets as a capture
 file, streams interleaved round-robin and tagged with their index.  `python -m edge264_amd.replay out.e264` replays it on
 the GPU, `python bench.py --capture out.e264` times it."""
 import os
