@@ -305,7 +305,7 @@ static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *s
 	for (int a = 0; a < n_mbs; a++) {
 		const E264Mb &m = mbs[a];
 		if (m.kind > E264_MB_INTER) return fail(EINVAL, "macroblock kind");
-		if (m.slice >= h->n_slices) return fail(EINVAL, "macroblock slice index"); // every record: the parameter kernel reads the slice of absent macroblocks too
+		if (m.slice >= h->n_slices || m.dbk_slice >= h->n_slices) return fail(EINVAL, "macroblock slice index"); // every record: the parameter kernel reads the slice of absent macroblocks too
 		if (m.kind == E264_MB_ABSENT) continue;
 		if ((m.flags & E264_MBF_T8x8) && (m.kind == E264_MB_I16x16 || m.kind == E264_MB_PCM)) return fail(EINVAL, "8x8 transform flag on an Intra16x16 / PCM macroblock");
 		if ((m.payload_off & 7) || (uint64_t)m.payload_off + e264_mb_payload_bytes(&m) > h->payload_bytes) return fail(EINVAL, "macroblock payload");

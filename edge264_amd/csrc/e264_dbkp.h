@@ -58,7 +58,7 @@ E264_DEV void dbkp_phase_load(DbkpLds &L, const FrameCtx &f, int a0, int tid)
 E264_DEV void dbkp_phase_slices(DbkpLds &L, const FrameCtx &f, int tid)
 {
 	if (tid < DP_MBS) {
-		cslice_t s = f.slices + (L.hdr[1 + tid][2] >> 16);
+		cslice_t s = f.slices + (L.hdr[1 + tid][7] & 0xffff); // E264Mb.dbk_slice
 		L.fo[tid][0] = s->FilterOffsetA; L.fo[tid][1] = s->FilterOffsetB;
 	}
 }

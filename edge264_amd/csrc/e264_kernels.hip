@@ -1459,7 +1459,7 @@ __device__ __forceinline__ int dbk_ab_lane(const FrameCtx &f, cmb_t m, int lane)
 {
 	const uint32_t hdr = *(const gu32 *)m;
 	const int flags = hdr >> 8 & 255;
-	cslice_t s = f.slices + m->slice;
+	cslice_t s = f.slices + m->dbk_slice;
 	int idx = lane - 32, what = idx / 9, pt = idx % 9, pl = pt / 3, t = pt % 3;
 	const int mi = (int)(m - f.mbs);
 	cmb_t nb = t == 0 ? m : f.mbs + max(mi - (t == 2 ? f.wm : 1), 0); // addressed without waiting for the flags

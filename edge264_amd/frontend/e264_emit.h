@@ -32,6 +32,7 @@ typedef struct {
 	int frame_id;
 	E264Mb *mbs;
 	E264Motion *motion;
+	uint16_t *dbk_slice;  /* per macroblock: slice entry whose task called deblock_mb on it (0xffff: none yet) */
 	E264SliceParams *slices;
 	int *slice_serial;  /* decode_NAL serial of each slice entry */
 	uint8_t *slice_filled;
@@ -94,13 +95,15 @@ static E264FrameBuilder *e264_builder(E264Emitter *e, int slot)
 		b->active = 0;
 	if (!b->active) {
 		if (b->n_mbs != w * h) {
-			free(b->mbs); free(b->motion);
+			free(b->mbs); free(b->motion); free(b->dbk_slice);
+			b->dbk_slice = malloc(sizeof(uint16_t) * (size_t)(w * h));
 			b->mbs = malloc(sizeof(E264Mb) * (size_t)(w * h));
 			b->motion = malloc(sizeof(E264Motion) * (size_t)(w * h));
 		}
 		b->width_mbs = w; b->height_mbs = h; b->n_mbs = w * h;
 		memset(b->mbs, 0, sizeof(E264Mb) * (size_t)b->n_mbs);
 		memset(b->motion, 0, sizeof(E264Motion) * (size_t)b->n_mbs);
+		memset(b->dbk_slice, 0xff, sizeof(uint16_t) * (size_t)b->n_mbs);
 		for (int i = 0; i < b->n_mbs; i++) {
 			memset(b->motion[i].refPic, -1, 8);
 			memset(b->motion[i].refIdx, -1, 8);

@@ -190,6 +190,7 @@ static int e264_finish_frame(E264Emitter *e, int slot)
 			for (int y = 0; y < 8; y++) e264_payload_append(b, C + (dec->out.stride_C >> 1) + (size_t)y * dec->out.stride_C, 8);
 		}
 		n_coded += m->kind != E264_MB_ABSENT;
+		m->dbk_slice = b->dbk_slice[a] != 0xffff ? b->dbk_slice[a] : m->slice;
 	}
 	/* counted from the final records: a macroblock decoded again by a resent slice is one macroblock (the intra kernel's
 	 * early exit compares these two numbers) */
@@ -359,7 +360,7 @@ PUBLIC void edge264_free(Edge264Decoder **pdec)
 		return;
 	if (ON_DEVICE(e)) hip.stream_close(e->hip_stream);
 	for (int s = 0; s < E264_MAX_SLOTS; s++) {
-		free(e->fb[s].mbs); free(e->fb[s].motion); free(e->fb[s].slices); free(e->fb[s].slice_serial);
+		free(e->fb[s].mbs); free(e->fb[s].motion); free(e->fb[s].dbk_slice); free(e->fb[s].slices); free(e->fb[s].slice_serial);
 		free(e->fb[s].slice_filled); free(e->fb[s].payload);
 	}
 	while (e->cap_head) {

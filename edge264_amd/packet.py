@@ -54,7 +54,7 @@ assert SLICE_PARAMS.itemsize == 2112
 MB = np.dtype([
     ("kind", "u1"), ("flags", "u1"), ("qp", "u1", (3,)), ("chroma_mode", "u1"), ("i16_mode", "u1"),
     ("reserved0", "u1"), ("nz_mask", "<u2"), ("slice", "<u2"), ("coded", "<u4"), ("payload_off", "<u4"),
-    ("modes", "u1", (8,)), ("reserved1", "<u4"),
+    ("modes", "u1", (8,)), ("dbk_slice", "<u2"), ("reserved1", "<u2"),
 ])
 assert MB.itemsize == 32
 
@@ -115,6 +115,7 @@ class PacketBuilder:
                luma_dc=None, chroma_dc=None, luma_blocks=None, chroma_blocks=None) -> None:
         m = self.mbs[addr]
         m["kind"], m["flags"], m["qp"], m["slice"] = kind, flags, qp, slice_idx
+        m["dbk_slice"] = slice_idx
         m["chroma_mode"], m["i16_mode"], m["nz_mask"] = chroma_mode, i16_mode, nz_mask
         if modes is not None:
             mm = np.zeros(8, np.uint8)

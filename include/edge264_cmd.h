@@ -126,7 +126,11 @@ typedef struct E264Mb { /* 32 bytes, one per macroblock in raster order */
 	uint32_t payload_off;    /* byte offset from payload start, multiple of 8 */
 	uint8_t  modes[8];       /* I4x4: 16 x 4-bit internal modes (block k in modes[k>>1] >> 4*(k&1));
 	                            I8x8: 4 x 8-bit internal modes in modes[0..3] */
-	uint32_t reserved1;
+	uint16_t dbk_slice;      /* slice whose FilterOffsetA/B deblock this macroblock.  Normally == slice; the reference filters
+	                            macroblocks whose deblocking had to wait for other slices (arbitrary slice order with
+	                            disable_deblocking_filter_idc 0) with the constants of the slice that COMPLETES the picture
+	                            (src/edge264_headers.c:538-567 run deblock_mb on the last task's context): kept bit-exact */
+	uint16_t reserved1;
 } E264Mb;
 
 /* Payload of one macroblock, in this order (each item only if present):

@@ -895,7 +895,7 @@ static void deblock_mb(const Frame *f, int mbx, int mby)
 	const E264Mb *m = f->mbs + mby * f->h->width_mbs + mbx;
 	if (!(m->flags & E264_MBF_DEBLOCK) || m->kind == E264_MB_ABSENT)
 		return;
-	const E264SliceParams *s = f->slices + m->slice;
+	const E264SliceParams *s = f->slices + m->dbk_slice; /* FilterOffsetA/B: the slice whose task deblocks this macroblock (edge264_cmd.h) */
 	uint8_t bS[2][4][4];
 	e264o_mb_bs(f, mbx, mby, bS);
 	int sY = (int)f->h->stride_Y, sC = (int)f->h->stride_C;

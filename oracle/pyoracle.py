@@ -240,7 +240,7 @@ class HipFront(Edge264Lib):
                 pk = P.Packet(pkt)
                 h = pk.hdr
                 nb = int(h["plane_size_Y"]) + int(h["plane_size_C"])
-                geom.update(stride_Y=int(h["stride_Y"]), stride_C=int(h["stride_C"]), psY=int(h["plane_size_Y"]))
+                geom.update(stride_Y=int(h["stride_Y"]), stride_C=int(h["stride_C"]), psY=int(h["plane_size_Y"]), psC=int(h["plane_size_C"]))
                 for s in range(32):
                     if dpb[s] is None and (s == int(h["dst_slot"]) or int(h["ref_slots"]) >> s & 1):
                         dpb[s] = np.zeros(nb + 64, np.uint8)  # like the HIP sink (frame_fill 0) and a fresh mmap in the reference
@@ -251,9 +251,11 @@ class HipFront(Edge264Lib):
                     slot = L.e264front_slot_of(dec, view[0])
                     assert slot >= 0 and (out.return_arg or 0) >> slot & 1
                     d, sy, sc = dpb[slot], geom["stride_Y"], geom["stride_C"]
-                    y = d[:out.height_Y * sy].reshape(out.height_Y, sy)[:, :out.width_Y].copy()
-                    c = d[geom["psY"]:geom["psY"] + out.height_C * sc].reshape(out.height_C, sc)
-                    planes += [y, c[:, :out.width_C].copy(), c[:, sc // 2:sc // 2 + out.width_C].copy()]
+                    top, _right, _bottom, left = (int(v) for v in out.frame_crop_offsets)  # edge264.h:60: the cropped window inside the coded frame
+                    y = d[:geom["psY"]].reshape(-1, sy)[top:top + out.height_Y, left:left + out.width_Y].copy()
+                    c = d[geom["psY"]:geom["psY"] + geom["psC"]].reshape(-1, sc)[top >> 1:(top >> 1) + out.height_C]
+                    planes += [c_ for c_ in (y, c[:, left >> 1:(left >> 1) + out.width_C].copy(),
+                                             c[:, sc // 2 + (left >> 1):sc // 2 + (left >> 1) + out.width_C].copy())]
                 frames.append(tuple(planes))
 
         nal = L.edge264_find_start_code(base, end, 0)

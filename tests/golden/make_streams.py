@@ -96,7 +96,8 @@ class Synth:
 
     def __init__(self, g, name, W, H, frames, seed, *, t8x8=False, num_refs=2, weighted_pred=0, weighted_bipred=0,
                  slices=1, deblock=(0,), direct_spatial=1, scaling=False, pcm=0.03, qp=28, cqp=(0, 0), level=3.0,
-                 intra_in_inter=0.12, skip=0.15, coef_density=0.35, big_levels=0.03, cbp_zero=0.0, cabac=False, tables=None, mvc=False):
+                 intra_in_inter=0.12, skip=0.15, coef_density=0.35, big_levels=0.03, cbp_zero=0.0, cabac=False, tables=None, mvc=False,
+                 crop=None, longterm=False, mmco_at=(), reorder=0.0, aso=False, pps_switch=False):
         self.g, self.name, self.W, self.H = g, name, W, H
         self.frames, self.rng = frames, random.Random(seed)
         self.t8x8, self.num_refs, self.wp, self.wbp = t8x8, num_refs, weighted_pred, weighted_bipred
@@ -107,6 +108,12 @@ class Synth:
         self.cabac, self.tables, self.cabac_fs = cabac, tables, None
         self.log2_fn, self.log2_poc = 4, 6
         self.mvc = mvc   # two views (Annex H): base view + NAL 20 slices predicted from their own view and from the base picture
+        self.crop = crop            # (left, right, top, bottom) luma samples: frame_cropping (1080 = 1088 - 8)
+        self.longterm = longterm    # the IDR picture is marked long-term (long_term_reference_flag): every later list ends with it
+        self.mmco_at = mmco_at      # reference frames (by count) that carry memory_management_control_operation 1 (drop the oldest short-term)
+        self.reorder = reorder      # probability that a P/B slice moves another short-term picture to the head of list 0
+        self.aso = aso              # arbitrary slice order: the slices of a picture are written in shuffled order
+        self.pps_switch = pps_switch  # two picture parameter sets (own chroma QP offsets + scaling matrix), alternating per picture
 
     # ---- parameter sets (payload bits by gen_avc.py) --------------------------------------------
     def sps(self):
@@ -115,6 +122,8 @@ class Synth:
                  log2_max_frame_num=self.log2_fn, pic_order_cnt_type=0, log2_max_pic_order_cnt_lsb=self.log2_poc,
                  max_num_ref_frames=self.num_refs, gaps_in_frame_num_value_allowed_flag=0,
                  pic_size_in_mbs={"width": self.W, "height": self.H}, frame_mbs_only_flag=1, direct_8x8_inference_flag=1)
+        if self.crop:
+            d["frame_crop_offsets"] = dict(zip(("left", "right", "top", "bottom"), self.crop))
         if self.scaling:
             r = self.rng
             d["seq_scaling_matrix"] = [[r.randint(6, 40) for _ in range(16)], [], [r.randint(6, 40) for _ in range(16)],
@@ -149,8 +158,8 @@ class Synth:
         # prefix_nal_unit_rbsp() is empty when svc_extension_flag = 0 (7.3.2.12): no trailing bits either
         return b"\0\0\0\1" + emulation_prevention((bits ^ 1 << 32).to_bytes(4, "big"))
 
-    def pps(self):
-        d = dict(nal_ref_idc=3, nal_unit_type=8, pic_parameter_set_id=0, entropy_coding_mode_flag=int(self.cabac),
+    def pps(self, pid=0):
+        d = dict(nal_ref_idc=3, nal_unit_type=8, pic_parameter_set_id=pid, entropy_coding_mode_flag=int(self.cabac),
                  bottom_field_pic_order_in_frame_present_flag=0, num_ref_idx_default_active={"l0": 1, "l1": 1},
                  weighted_pred_flag=self.wp, weighted_bipred_idc=self.wbp, pic_init_qp=self.qp,
                  chroma_qp_index_offset=self.cqp[0], deblocking_filter_control_present_flag=1,
@@ -158,6 +167,13 @@ class Synth:
         if self.t8x8 or self.cqp[1] != self.cqp[0]:
             d["transform_8x8_mode_flag"] = int(self.t8x8)
             d["second_chroma_qp_index_offset"] = self.cqp[1]
+        if pid:  # the second parameter set: other chroma QP offsets and its own scaling matrix (needs the High-profile tail)
+            r = random.Random(1000 + pid)
+            d["chroma_qp_index_offset"] = -self.cqp[0] - 1
+            d["transform_8x8_mode_flag"] = int(self.t8x8)
+            d["pic_scaling_matrix"] = [[r.randint(6, 40) for _ in range(16)], [], [r.randint(6, 40) for _ in range(16)],
+                                       [r.randint(6, 40) for _ in range(16)], [], []] + ([[r.randint(6, 40) for _ in range(64)], []] if self.t8x8 else [])
+            d["second_chroma_qp_index_offset"] = self.cqp[1] + 2
         return d
 
     def nal(self, d):
@@ -418,7 +434,7 @@ class Synth:
             bits = self.mvc_ext(bits, hdr["idr"], 1, 0)
         bits = ue(bits, first)
         bits = ue(bits, st + (5 if self.slices == 1 else 0))
-        bits = ue(bits, 0)  # pic_parameter_set_id
+        bits = ue(bits, hdr.get("pps_id", 0))  # pic_parameter_set_id
         bits = u(bits, self.log2_fn, hdr["frame_num"])
         if hdr["idr"]:
             bits = ue(bits, hdr["idr_pic_id"])
@@ -430,7 +446,14 @@ class Synth:
             bits = ue(bits, hdr["nref0"] - 1)
             if st == 1:
                 bits = ue(bits, hdr["nref1"] - 1)
-            bits = u(bits, 1, 0)  # ref_pic_list_modification_flag_l0
+            k = hdr.get("reorder_l0", 0)
+            if k:  # ref_pic_list_modification (7.3.3.1): the short-term picture CurrPicNum - k becomes entry 0
+                bits = u(bits, 1, 1)
+                bits = ue(bits, 0)       # modification_of_pic_nums_idc 0: subtract
+                bits = ue(bits, k - 1)   # abs_diff_pic_num_minus1
+                bits = ue(bits, 3)       # end
+            else:
+                bits = u(bits, 1, 0)  # ref_pic_list_modification_flag_l0
             if st == 1:
                 bits = u(bits, 1, 0)
             if (st == 0 and self.wp) or (st == 1 and self.wbp == 1):
@@ -448,7 +471,12 @@ class Synth:
                                     bits = se(bits, r.choice([0, r.randint(-10, 10), r.randint(-128, 127)]))
         if hdr["is_ref"]:
             if hdr["idr"]:
-                bits = u(bits, 2, 0)  # no_output_of_prior_pics_flag, long_term_reference_flag
+                bits = u(bits, 2, 1 if self.longterm else 0)  # no_output_of_prior_pics_flag, long_term_reference_flag
+            elif hdr.get("mmco1"):  # dec_ref_pic_marking: drop the short-term picture CurrPicNum - mmco1
+                bits = u(bits, 1, 1)  # adaptive_ref_pic_marking_mode_flag
+                bits = ue(bits, 1)
+                bits = ue(bits, hdr["mmco1"] - 1)  # difference_of_pic_nums_minus1
+                bits = ue(bits, 0)
             else:
                 bits = u(bits, 1, 0)  # adaptive_ref_pic_marking_mode_flag
         cabac_init_idc = (first + hdr["frame_num"]) % 3  # deterministic: the CAVLC and CABAC variants of a stream draw the same random sequence
@@ -480,8 +508,11 @@ class Synth:
     def build(self):
         r = self.rng
         out = [self.nal(self.sps())] + ([self.nal(self.subset_sps())] if self.mvc else []) + [self.nal(self.pps())]
+        if self.pps_switch:
+            out.append(self.nal(self.pps(1)))
         n_mbs = self.W * self.H
         frame_num, nrefs, disp = 0, 0, 0
+        n_short, n_long, ref_count = 0, 0, 0  # reference pictures in the DPB after each marking step
         # display order: B frames (non-reference) sit between the two reference frames decoded before them
         order, poc = [], 0
         i = 0
@@ -508,19 +539,24 @@ class Synth:
             if self.cabac:
                 import cabac_writer as cw
                 self.cabac_fs = cw.FrameState(self.W, self.H)
-            nref0 = max(1, min(nrefs, self.num_refs)) if t != "I" else 1
+            nref0 = max(1, n_short + n_long) if t != "I" else 1
             nref1 = nref0
             if t != "I":
                 nref0, nref1 = r.randint(1, nref0), r.randint(1, nref1)
             bounds = sorted(r.sample(range(1, n_mbs), min(self.slices - 1, n_mbs - 1))) if self.slices > 1 else []
             bounds = [0] + bounds + [n_mbs]
+            mmco1 = n_short if (is_ref and not idr and ref_count in self.mmco_at and n_short > 1) else 0  # the oldest short-term picture
+            reorder = r.randint(2, n_short) if (self.reorder and t != "I" and n_short > 1 and r.random() < self.reorder) else 0
+            pic_nals = []
             for s in range(len(bounds) - 1):
                 hdr = dict(frame_num=frame_num % (1 << self.log2_fn), poc=p % (1 << self.log2_poc), is_ref=is_ref, idr=idr,
                            nref0=nref0, nref1=nref1, idr_pic_id=0, slice_qp_delta=r.randint(-4, 6),
-                           deblock=r.choice(self.deblock), alpha=r.randint(-3, 3), beta=r.randint(-3, 3))
-                if self.mvc:
-                    out.append(self.prefix_nal(is_ref, idr))
-                out.append(self.slice_nal(fc, t, bounds[s], bounds[s + 1], s, hdr))
+                           deblock=r.choice(self.deblock), alpha=r.randint(-3, 3), beta=r.randint(-3, 3),
+                           mmco1=mmco1, reorder_l0=reorder, pps_id=(idx & 1) if self.pps_switch else 0)
+                pic_nals.append((self.prefix_nal(is_ref, idr) if self.mvc else b"") + self.slice_nal(fc, t, bounds[s], bounds[s + 1], s, hdr))
+            if self.aso and len(pic_nals) > 1:
+                r.shuffle(pic_nals)
+            out += pic_nals
             if self.mvc:
                 # second view of the access unit: same frame_num/POC; RefPicList0/1 = its own view's references followed by the
                 # base picture of this access unit (headers.c:784-785), so an I access unit becomes P with the inter-view ref only
@@ -539,6 +575,15 @@ class Synth:
             if is_ref:
                 frame_num += 1
                 nrefs += 1
+                ref_count += 1
+                if idr:
+                    n_short, n_long = (0, 1) if self.longterm else (1, 0)
+                else:
+                    if mmco1:
+                        n_short -= 1
+                    elif n_short + n_long == self.num_refs and n_short > 0:
+                        n_short -= 1  # sliding window (8.2.5.3)
+                    n_short += 1
         return b"".join(out)
 
 
@@ -577,6 +622,19 @@ STREAMS = [
     ("mvc_cabac_ipb", 5, 4, "IPBPBB", 51, dict(mvc=True, cabac=True, pcm=0.0, num_refs=3, t8x8=True, slices=2, weighted_bipred=2)),
     ("cabac_t8x8_slices", 5, 4, "IPBP", 55, dict(cabac=True, pcm=0.0, num_refs=3, t8x8=True, slices=3)),
     ("hd1080_ippb", 120, 68, "IPPB", 13, dict(num_refs=2, level=4.0, skip=0.45, coef_density=0.12, intra_in_inter=0.03, pcm=0.0005, cbp_zero=0.8)),
+    # decoder-state features the packets inherit from the reference's front end: cropping, long-term references and MMCO,
+    # reference list modification, arbitrary slice order, parameter-set switches between pictures
+    ("crop_longterm_mmco", 6, 5, "IPPPBPPB", 61, dict(num_refs=3, crop=(2, 4, 0, 6), longterm=True, mmco_at=(3, 5))),
+    ("cabac_reorder_longterm", 5, 4, "IPPPPBP", 62, dict(cabac=True, pcm=0.0, num_refs=3, longterm=True, reorder=0.8, t8x8=True)),
+    ("reorder_weighted", 5, 4, "IPPPBPP", 63, dict(num_refs=4, reorder=0.9, weighted_pred=1, weighted_bipred=2)),
+    ("aso_slices", 6, 5, "IPPBP", 64, dict(slices=4, aso=True, num_refs=2, deblock=(0, 2))),
+    ("pps_switch_scaling", 5, 4, "IPPBPP", 65, dict(pps_switch=True, t8x8=True, scaling=True, num_refs=2, cqp=(1, -2))),
+    ("cabac_pps_switch", 5, 4, "IPPPP", 66, dict(cabac=True, pcm=0.0, pps_switch=True, num_refs=2, slices=2)),
+    # BASELINE configs[2] / configs[3] geometry, 30 pictures, 1080 lines displayed of 1088 coded (crop bottom 8)
+    ("hd1080_ipp30", 120, 68, "I" + "P" * 29, 71, dict(num_refs=2, level=4.0, crop=(0, 0, 0, 8), skip=0.5, coef_density=0.10, intra_in_inter=0.02,
+                                                      pcm=0.0, cbp_zero=0.85)),
+    ("cabac_hd1080_ibbp30", 120, 68, "I" + "PBB" * 9 + "PB", 72, dict(cabac=True, pcm=0.0, num_refs=2, level=4.0, crop=(0, 0, 0, 8), t8x8=True, scaling=True,
+                                                                      weighted_bipred=2, skip=0.5, coef_density=0.10, intra_in_inter=0.02, cbp_zero=0.85)),
 ]
 
 
