@@ -166,6 +166,7 @@ def main() -> int:
     if args.intra_waves:
         dev.set_option("intra_waves", args.intra_waves)
     dev.set_option("debug_mode", args.debug_mode)
+    dev.set_option("side_queue", int(os.environ.get("E264_SIDE_QUEUE", 0)))
     streams, dpk = [], []
     for s in range(my_streams):
         st = backend.Stream(dev, W, H)

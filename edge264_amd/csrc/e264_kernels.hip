@@ -2325,7 +2325,7 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 		hipEventRecord(fork->forked, stream);
 		hipStreamWaitEvent(fork->aux, fork->forked, 0);
 		if (marks) hipEventRecord(fork->amarks[0], fork->aux);
-		hipLaunchKernelGGL(e264_dbkparam_kernel, dim3((max_mbs + 15) / 16, n_jobs), dim3(256), 0, fork->aux, jobs);
+		hipLaunchKernelGGL(e264_dbkparam2_kernel, dim3((max_mbs + DP_MBS - 1) / DP_MBS, n_jobs), dim3(DP_NT), 0, fork->aux, jobs);
 		if (marks) hipEventRecord(fork->amarks[1], fork->aux);
 		hipEventRecord(fork->joined, fork->aux);
 	} else if (dbkp && (mode & 32768)) // debug mode bit 15: round 1's per-lane-load parameter kernel (A/B timing only)

@@ -15,7 +15,7 @@ import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 STREAMS = os.path.join(os.path.dirname(HERE), "tests", "golden", "streams")
-FIXTURES_1080P = ("hd1080_ippb.264", "cabac_hd1080_ipp.264")
+FIXTURES_1080P = ("hd1080_ipp30.264", "cabac_hd1080_ibbp30.264")  # 30 pictures each: CAVLC IPPP, CABAC IBBP with 8x8 transform + scaling lists
 
 
 def cpu_model() -> str:

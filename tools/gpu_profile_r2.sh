@@ -1,0 +1,25 @@
+#!/bin/bash
+# One GPU-box visit that produces everything profiles/r02_* is made of: the default bench line, the rocprofv3 kernel trace
+# of the same command, the HBM-side PMC passes (reads / writes in separate passes), the SQ instruction mix, the two
+# microbenchmarks.   bash tools/gpu_profile_r2.sh TAG
+TAG=${1:-r02}
+REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
+B="python $REPO/bench.py --no-cpu-baseline --no-verify --no-other-configs --no-host-packets"
+cd /tmp
+timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_kt -- $B > $OUT/bench_kt.json 2> $OUT/bench_kt.err; echo "kt rc=$?"
+timeout 400 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B -d $OUT/pmc_rd -- $B --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_rd.err; echo "rd rc=$?"
+timeout 400 rocprofv3 --pmc TCC_EA0_WRREQ TCC_EA0_WRREQ_64B -d $OUT/pmc_wr -- $B --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_wr.err; echo "wr rc=$?"
+timeout 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM -d $OUT/pmc_sq -- $B --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_sq.err; echo "sq rc=$?"
+cd $REPO
+python tools/rocprof_summary.py $(find $OUT/prof_kt -name '*.db' | head -1) > $OUT/kernel_stats.txt 2>&1; cat $OUT/kernel_stats.txt
+python tools/pmc_summary.py $(find $OUT/pmc_rd $OUT/pmc_wr -name '*.db') --traffic $OUT/hbm_traffic.json --streams 256 --gop IPPPPPPP > $OUT/pmc_hbm_requests.txt 2>&1
+python tools/pmc_summary.py $(find $OUT/pmc_sq -name '*.db') > $OUT/pmc_sq_instruction_mix.txt 2>&1
+timeout 60 tools/calib/valu_rate > $OUT/valu_rate.txt 2>&1
+timeout 60 tools/calib/load_rate > $OUT/load_rate.txt 2>&1
+find $OUT -name '*.db' -size +20M -delete
+python -c "
+import json; d=json.load(open('$OUT/bench_default.json')); print(d['value'], d['bit_exact'], d['roofline']['kernel'], d['roofline']['frac'], d['roofline']['end_to_end'], {k.split('_')[1]: v['ms_per_launch'] for k,v in d['roofline']['kernels'].items()}); print(d['cpu_baseline']['value'], d['cpu_baseline']['per_core'], d['cpu_baseline']['single_process']); print(d['pcie_inclusive'])"
+python -c "
+import json; t=json.load(open('$OUT/hbm_traffic.json')); print({k: (round(v['read_bytes']/1e9,3), round(v['write_bytes']/1e9,3)) for k,v in t['kernels'].items()})"
