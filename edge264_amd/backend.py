@@ -56,6 +56,9 @@ def load_library():
         "e264hip_submit_batch": (i, [vp, C.POINTER(vp), C.POINTER(vp), i, i]),
         "e264hip_packet_check": (i, [vp, sz]),
         "e264hip_submit_batch_host": (i, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), i, i]),
+        "e264hip_submit_batch_pinned": (i, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), i, i, i]),
+        "e264hip_host_alloc": (vp, [vp, sz]),
+        "e264hip_host_free": (None, [vp, vp]),
         "e264hip_batch_create": (i, [vp, C.POINTER(vp), C.POINTER(vp), i, C.POINTER(vp)]),
         "e264hip_batch_submit": (i, [vp, i]),
         "e264hip_batch_free": (None, [vp]),
@@ -77,7 +80,7 @@ EXPORTED_SYMBOLS = [
     "e264hip_stream_open", "e264hip_stream_close", "e264hip_stream_flush", "e264hip_frame_alloc",
     "e264hip_frame_free", "e264hip_frame_fill", "e264hip_frame_upload", "e264hip_frame_submit",
     "e264hip_packet_buffer", "e264hip_frame_wait", "e264hip_frame_download", "e264hip_packet_upload",
-    "e264hip_packet_free", "e264hip_packet_check", "e264hip_submit_batch", "e264hip_submit_batch_host", "e264hip_batch_create", "e264hip_batch_submit", "e264hip_batch_free", "e264hip_event_record", "e264hip_event_elapsed_ms",
+    "e264hip_packet_free", "e264hip_packet_check", "e264hip_submit_batch", "e264hip_submit_batch_host", "e264hip_submit_batch_pinned", "e264hip_host_alloc", "e264hip_host_free", "e264hip_batch_create", "e264hip_batch_submit", "e264hip_batch_free", "e264hip_event_record", "e264hip_event_elapsed_ms",
     "e264hip_kernel_timing", "e264hip_kernel_time_ms", "e264hip_set_option",
 ]
 
@@ -145,6 +148,24 @@ class Device:
         bufs = [(C.c_char * len(p)).from_buffer_copy(p) for p in packets]
         return ((C.c_void_p * n)(*[s.h for s in streams]), (C.c_void_p * n)(*[C.cast(b, C.c_void_p) for b in bufs]),
                 (C.c_size_t * n)(*[len(p) for p in packets]), n, bufs)
+
+    def pinned_copy(self, pkt: bytes):
+        """The packet's bytes in page-locked memory of this device (what a front end's emitter writes into directly)."""
+        p = self.L.e264hip_host_alloc(self.h, len(pkt))
+        if not p:
+            raise BackendError("e264hip_host_alloc: " + last_error())
+        C.memmove(p, pkt, len(pkt))
+        return p
+
+    def pinned_free(self, p) -> None:
+        self.L.e264hip_host_free(self.h, p)
+
+    def prepare_pinned_batch(self, streams, pinned_ptrs, sizes):
+        n = len(streams)
+        return ((C.c_void_p * n)(*[s.h for s in streams]), (C.c_void_p * n)(*pinned_ptrs), (C.c_size_t * n)(*sizes), n)
+
+    def submit_pinned_prepared(self, pb, mode: int = RUN_ALL, trusted: bool = True) -> None:
+        _check(self.L, self.L.e264hip_submit_batch_pinned(self.h, pb[0], pb[1], pb[2], pb[3], mode, 1 if trusted else 0), "submit_batch_pinned")
 
     def submit_host_prepared(self, hb, mode: int = RUN_ALL) -> None:
         _check(self.L, self.L.e264hip_submit_batch_host(self.h, hb[0], hb[1], hb[2], hb[3], mode), "submit_batch_host")

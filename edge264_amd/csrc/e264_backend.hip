@@ -530,8 +530,33 @@ API int e264hip_submit_batch(E264Device *dev, E264Stream *const *streams, E264Pa
 // Host packets of MANY streams, one submission, nothing synchronous: every packet is staged through its
 // stream's pinned ring and copied on the device queue, the job table through a device-level ring, then the four
 // kernels are launched.  The caller may reuse / free the host packets on return.
+static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const void *const *packets, const size_t *bytes, int n, int mode, int flags);
 API int e264hip_submit_batch_host(E264Device *dev, E264Stream *const *streams, const void *const *packets, const size_t *bytes, int n, int mode)
 {
+	return submit_host_impl(dev, streams, packets, bytes, n, mode, 0);
+}
+// The same for packets that already sit in page-locked memory (e264hip_host_alloc; what a front end does when it assembles
+// the packet in place): no staging copy, the H2D reads the caller's buffer, which must stay untouched until the submission
+// has retired (e264hip_device_sync / a later e264hip_frame_wait).  E264_SUBMIT_TRUSTED: the caller has run
+// e264hip_packet_check on exactly these bytes (a packet produced by its own emitter, a validated capture): the
+// per-macroblock walk is not repeated on the submitting thread.
+API int e264hip_submit_batch_pinned(E264Device *dev, E264Stream *const *streams, const void *const *packets, const size_t *bytes, int n, int mode, int flags)
+{
+	return submit_host_impl(dev, streams, packets, bytes, n, mode, 1 | (flags & E264_SUBMIT_TRUSTED ? 2 : 0));
+}
+API void *e264hip_host_alloc(E264Device *dev, size_t bytes)
+{
+	void *p = nullptr;
+	if (!dev || set_device(dev) || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { fail(ENOMEM, "hipHostMalloc"); return nullptr; }
+	return p;
+}
+API void e264hip_host_free(E264Device *dev, void *p)
+{
+	if (dev && p && !set_device(dev)) hipHostFree(p);
+}
+static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const void *const *packets, const size_t *bytes, int n, int mode, int flags)
+{
+	const bool pinned = flags & 1, trusted = flags & 2;
 	if (!dev || !streams || !packets || !bytes || n <= 0) return fail(EINVAL, "submit_batch_host arguments");
 	if (set_device(dev)) return EIO;
 	std::vector<int> mbs_of((size_t)n), tiles_of((size_t)n);
@@ -543,7 +568,9 @@ API int e264hip_submit_batch_host(E264Device *dev, E264Stream *const *streams, c
 		int dst, r = check_packet(packets[i], bytes[i], &dst, &mbs_of[i], &tiles_of[i]);
 		if (r) return r;
 		if (!s->h_table[dst]) return fail(EINVAL, "destination slot not allocated");
-		if ((r = check_packet_deep(packets[i], bytes[i], s->h_table, s->slot_bytes))) return r;
+		if (!trusted && (r = check_packet_deep(packets[i], bytes[i], s->h_table, s->slot_bytes))) return r;
+		if (trusted && (uint64_t)((const E264FrameHdr *)packets[i])->plane_size_Y + ((const E264FrameHdr *)packets[i])->plane_size_C > s->slot_bytes[dst])
+			return fail(EINVAL, "picture larger than the destination slot");
 	}
 	std::lock_guard<std::mutex> bg(dev->batch_lock); // batches of one device are serialised (their streams are disjoint per batch anyway)
 	E264Device::JobRing &jr = dev->jring[dev->jring_next];
@@ -570,8 +597,8 @@ API int e264hip_submit_batch_host(E264Device *dev, E264Stream *const *streams, c
 		if (!h) return ENOMEM;
 		E264Stream::Stage *st = &s->stage[s->stage_next];
 		s->stage_next = (s->stage_next + 1) & 3;
-		memcpy(h, packets[i], bytes[i]);
-		HIPCHK(hipMemcpyAsync(st->d, st->h, bytes[i], hipMemcpyHostToDevice, dev->q), EIO);
+		if (!pinned) memcpy(h, packets[i], bytes[i]);
+		HIPCHK(hipMemcpyAsync(st->d, pinned ? packets[i] : st->h, bytes[i], hipMemcpyHostToDevice, dev->q), EIO);
 		jr.h[i].packet = st->d; jr.h[i].dpb = s->d_table; jr.h[i].dbk = s->d_dbk;
 		if (n_mbs > max_mbs) max_mbs = n_mbs;
 	}

@@ -89,6 +89,15 @@ int  e264hip_packet_check(const void *packet, size_t bytes);
  * synchronisation; the host buffers may be reused on return.  This is what a multi-stream front end calls once per
  * round (edge264_amd/driver/e264_multi.cpp). */
 int  e264hip_submit_batch_host(E264Device *dev, E264Stream *const *streams, const void *const *packets, const size_t *bytes, int n, int mode);
+/* Same for packets assembled IN PLACE in page-locked memory (e264hip_host_alloc): no staging copy, the H2D transfer reads
+ * the caller's buffer, which must stay untouched until the submission has retired.  This is the path of a front end whose
+ * emitters write the finished frame straight into pinned memory (the reference's per-frame hand-over point,
+ * src/edge264_headers.c:532-568).  flags: E264_SUBMIT_TRUSTED = these exact bytes have already passed
+ * e264hip_packet_check (on the parser thread that produced them), the per-macroblock walk is not repeated here. */
+#define E264_SUBMIT_TRUSTED 1
+int  e264hip_submit_batch_pinned(E264Device *dev, E264Stream *const *streams, const void *const *packets, const size_t *bytes, int n, int mode, int flags);
+void *e264hip_host_alloc(E264Device *dev, size_t bytes);
+void e264hip_host_free(E264Device *dev, void *p);
 /* Same, with the job table built once and kept in HBM: the launch itself moves no bytes
  * over PCIe (a persistent multi-stream front end re-submits frame i of every stream). */
 typedef struct E264Batch E264Batch;
