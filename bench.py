@@ -12,7 +12,8 @@ torchrun environment launches the N ranks itself (torch.distributed.run, one pro
 
 Prints ONE JSON line (rank 0).  One submission (= one frame of every stream) is four kernel launches on the back end's
 queue: e264_dbkparam2_kernel (bS / alpha / beta), e264_pred_kernel (inter prediction + residual, tile-parallel),
-e264_intra_kernel (intra wavefront), e264_deblock_kernel (deblocking wavefront).  Kernel times are measured live with HIP
+e264_intra_kernel (intra wavefront), e264_deblock_kernel (deblocking wavefront).  (--debug-mode 131072 lets the prediction
+kernel compute the deblocking parameters of its tiles itself: three launches, measured slower.)  Kernel times are measured live with HIP
 events recorded on the back end's own queue around each launch.
 
 roofline (all per submission of one frame of every stream of one GPU; DESIGN.md section 4 states the figures):
@@ -78,8 +79,9 @@ def launch_ranks(n: int) -> int:
     return subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")).returncode
 
 
-def kernel_own_bytes(models, n_streams):
-    """Per kernel: (sample bytes, command bytes) of one submission, averaged over the GOP's frames."""
+def kernel_own_bytes(models, n_streams, folded=True):
+    """Per kernel: (sample bytes, command bytes) of one submission, averaged over the GOP's frames.  folded: the prediction
+    kernel computes the deblocking parameters of its tiles (no separate launch): it also writes the parameter records."""
     out = {}
     for name in KERNELS:
         sb = cb = 0.0
@@ -89,7 +91,7 @@ def kernel_own_bytes(models, n_streams):
                 c, s_ = 32 * n + m["cmd_motion"] + DBK_BYTES * n, 0
             elif name == "e264_pred_kernel":  # writes its macroblocks, reads each reference sample once per direction
                 s_ = F * m["inter"] + F * m["dirs"]
-                c = 32 * n + m["cmd_motion"] + m["cmd_payload_inter"]
+                c = 32 * n + m["cmd_motion"] + m["cmd_payload_inter"] + (DBK_BYTES * n if folded else 0)
             elif name == "e264_intra_kernel":  # writes its macroblocks (neighbour rows are cache hits)
                 s_ = F * m["intra"]
                 c = 32 * n + m["cmd_payload_intra"]
@@ -355,9 +357,12 @@ def main() -> int:
     if rank == 0:
         L = max(launches, 1)
         kms = [t / L for t in kernel_ms4]
-        own = kernel_own_bytes(models, my_streams)
+        folded = kms[0] < 0.005  # no stand-alone parameter launch: e264_pred_kernel did that work
+        own = kernel_own_bytes(models, my_streams, folded)
         kern = {}
         for name, ms in zip(KERNELS, kms):
+            if folded and name == KERNELS[0]:
+                continue
             sb, cb = own[name]
             g = (sb + cb) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             kern[name] = {"ms_per_launch": round(ms, 4), "sample_bytes": int(sb), "command_bytes": int(cb), "gbps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4)}

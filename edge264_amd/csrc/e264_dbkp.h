@@ -64,13 +64,15 @@ E264_DEV void dbkp_phase_slices(DbkpLds &L, const FrameCtx &f, int tid)
 }
 
 struct DbkpMo { int ref0, ref1; uint32_t mv0, mv1; };
-E264_DEV DbkpMo dbkp_motion(const DbkpLds &L, bool has_motion, int rec, int k)
-{ // motion of 4x4 block k of record rec; intra / absent macroblocks count as "no reference, zero vector"
+// motion of 4x4 block k of a record (hdr: its E264Mb dwords, mo: its E264Motion dwords); intra / absent macroblocks count
+// as "no reference, zero vector"
+E264_DEV DbkpMo dbkp_motion(const uint32_t *hdr, const uint32_t *mo, bool has_motion, int k)
+{
 	DbkpMo o = {-1, -1, 0, 0};
-	if (has_motion && (L.hdr[rec][0] & 255) == E264_MB_INTER) {
-		o.ref0 = (int)(int8_t)(L.mo[rec][0] >> (8 * (k >> 2)));
-		o.ref1 = (int)(int8_t)(L.mo[rec][1] >> (8 * (k >> 2)));
-		o.mv0 = L.mo[rec][4 + k]; o.mv1 = L.mo[rec][20 + k];
+	if (has_motion && (hdr[0] & 255) == E264_MB_INTER) {
+		o.ref0 = (int)(int8_t)(mo[0] >> (8 * (k >> 2)));
+		o.ref1 = (int)(int8_t)(mo[1] >> (8 * (k >> 2)));
+		o.mv0 = mo[4 + k]; o.mv1 = mo[20 + k];
 	}
 	return o;
 }
@@ -80,56 +82,61 @@ E264_DEV int dbkp_far(uint32_t a, uint32_t b)
 	const int dx = ax - bx, dy = ay - by;
 	return ((dx < 0 ? -dx : dx) >= 4) | ((dy < 0 ? -dy : dy) >= 4);
 }
+// bS of role hl = (dir, edge, segment) of macroblock m (edge264_deblock.c:958-1118); L / T: records of the left / top neighbour
+// (anything when the edge flag is off); `on`: the macroblock is deblocked at all
+E264_DEV int dbkp_bs_value(const uint32_t *hm, const uint32_t *mm, const uint32_t *hL, const uint32_t *mL, const uint32_t *hT, const uint32_t *mT,
+	bool has_motion, bool on, int hl)
+{
+	const int dir = hl >> 4 & 1, e = hl >> 2 & 3, sg = hl & 3;
+	const uint32_t h0 = hm[0];
+	const int kind = h0 & 255, flags = h0 >> 8 & 255;
+	const bool intra = kind != E264_MB_INTER;
+	const bool has_edge = e != 0 || (flags & (dir ? E264_MBF_EDGE_TOP : E264_MBF_EDGE_LEFT));
+	const uint32_t *hn = e == 0 ? (dir ? hT : hL) : hm, *mn = e == 0 ? (dir ? mT : mL) : mm; // record holding the p side
+	const int nkind = hn[0] & 255;
+	const int kq = dir ? blk_of(sg, e) : blk_of(e, sg);
+	const int kp = dir ? blk_of(sg, (e + 3) & 3) : blk_of((e + 3) & 3, sg);
+	const int coded = ((hn[2] & 0xffff) >> kp & 1) | ((hm[2] & 0xffff) >> kq & 1);
+	const DbkpMo p = dbkp_motion(hn, mn, has_motion, kp), q = dbkp_motion(hm, mm, has_motion, kq);
+	const int refs_p = (p.ref0 != q.ref0) | (p.ref1 != q.ref1), refs_c = (p.ref0 != q.ref1) | (p.ref1 != q.ref0);
+	const int mvs_p = dbkp_far(p.mv0, q.mv0) | dbkp_far(p.mv1, q.mv1), mvs_c = dbkp_far(p.mv0, q.mv1) | dbkp_far(p.mv1, q.mv0);
+	const int bmo = (refs_p | mvs_p) & (refs_c | mvs_c);
+	const bool skip8 = e != 0 && (flags & E264_MBF_T8x8) && (e & 1);
+	int bs = coded ? 2 : bmo;
+	bs = intra ? 3 : bs;
+	bs = (e == 0 && (intra || nkind != E264_MB_INTER)) ? 4 : bs;
+	return (!on || !has_edge || skip8) ? 0 : bs;
+}
+// alpha / beta / indexA value hl (0..26; 27..31 -> 0) of macroblock m (edge264_deblock.c:945-955)
+E264_DEV int dbkp_ab_value(const uint32_t *hm, const uint32_t *hL, const uint32_t *hT, int foA, int foB, const uint8_t *alpha, const uint8_t *beta, bool on, int hl)
+{
+	if (hl >= 27 || !on)
+		return 0;
+	const uint32_t h0 = hm[0], h1 = hm[1];
+	const int flags = h0 >> 8 & 255;
+	const int what = hl / 9, pt = hl - what * 9, pl = pt / 3, t = pt - pl * 3;
+	const uint32_t *hn = t == 0 ? hm : t == 2 ? hT : hL;
+	const uint32_t n0 = hn[0], n1 = hn[1];
+	const int qm = pl == 0 ? (int)(h0 >> 16 & 255) : pl == 1 ? (int)(h0 >> 24) : (int)(h1 & 255);
+	const int qn = pl == 0 ? (int)(n0 >> 16 & 255) : pl == 1 ? (int)(n0 >> 24) : (int)(n1 & 255);
+	const bool use_nb = (t == 1 && (flags & E264_MBF_EDGE_LEFT)) || (t == 2 && (flags & E264_MBF_EDGE_TOP));
+	const int qPav = (qm + (use_nb ? qn : qm) + 1) >> 1;
+	const int iA = min(max(qPav + foA, 0), 51), iB = min(max(qPav + foB, 0), 51);
+	return what == 0 ? alpha[iA] : what == 1 ? beta[iB] : iA;
+}
 
 E264_DEV void dbkp_phase_compute(DbkpLds &L, const FrameCtx &f, int a0, int tid)
 {
 	const bool has_motion = f.motion != nullptr;
 	const int n_mbs = f.wm * f.hm;
 	uint8_t *out8 = (uint8_t *)&L.out[0][0];
-	// bS: 32 values per macroblock (edge264_deblock.c:958-1118)
 	for (int it = 0; it < DP_MBS * 32 / DP_NT; it++) {
 		const int id = it * DP_NT + tid, i = id >> 5, hl = id & 31;
-		const int dir = hl >> 4 & 1, e = hl >> 2 & 3, sg = hl & 3;
-		const int rm = 1 + i, rn = e == 0 ? (dir ? 1 + DP_MBS + i : i) : rm; // own record, record holding the p side
+		const int rm = 1 + i, rl = i, rt = 1 + DP_MBS + i; // own record, left and top neighbours
 		const uint32_t h0 = L.hdr[rm][0];
-		const int kind = h0 & 255, flags = h0 >> 8 & 255;
-		const bool on = a0 + i < n_mbs && (flags & E264_MBF_DEBLOCK) && kind != E264_MB_ABSENT;
-		const bool intra = kind != E264_MB_INTER;
-		const bool has_edge = e != 0 || (flags & (dir ? E264_MBF_EDGE_TOP : E264_MBF_EDGE_LEFT));
-		const int nkind = L.hdr[rn][0] & 255;
-		const int kq = dir ? blk_of(sg, e) : blk_of(e, sg);
-		const int kp = dir ? blk_of(sg, (e + 3) & 3) : blk_of((e + 3) & 3, sg);
-		const int coded = ((L.hdr[rn][2] & 0xffff) >> kp & 1) | ((L.hdr[rm][2] & 0xffff) >> kq & 1);
-		const DbkpMo p = dbkp_motion(L, has_motion, rn, kp), q = dbkp_motion(L, has_motion, rm, kq);
-		const int refs_p = (p.ref0 != q.ref0) | (p.ref1 != q.ref1), refs_c = (p.ref0 != q.ref1) | (p.ref1 != q.ref0);
-		const int mvs_p = dbkp_far(p.mv0, q.mv0) | dbkp_far(p.mv1, q.mv1), mvs_c = dbkp_far(p.mv0, q.mv1) | dbkp_far(p.mv1, q.mv0);
-		const int bmo = (refs_p | mvs_p) & (refs_c | mvs_c);
-		const bool skip8 = e != 0 && (flags & E264_MBF_T8x8) && (e & 1);
-		int bs = coded ? 2 : bmo;
-		bs = intra ? 3 : bs;
-		bs = (e == 0 && (intra || nkind != E264_MB_INTER)) ? 4 : bs;
-		out8[i * 64 + hl] = (uint8_t)((!on || !has_edge || skip8) ? 0 : bs);
-	}
-	// alpha / beta / indexA: 27 values per macroblock, slots 27..31 write the zero tail (edge264_deblock.c:945-955)
-	for (int it = 0; it < DP_MBS * 32 / DP_NT; it++) {
-		const int id = it * DP_NT + tid, i = id >> 5, hl = id & 31;
-		const int rm = 1 + i;
-		const uint32_t h0 = L.hdr[rm][0], h1 = L.hdr[rm][1];
-		const int kind = h0 & 255, flags = h0 >> 8 & 255;
-		const bool on = a0 + i < n_mbs && (flags & E264_MBF_DEBLOCK) && kind != E264_MB_ABSENT;
-		int v = 0;
-		if (hl < 27 && on) {
-			const int what = hl / 9, pt = hl - what * 9, pl = pt / 3, t = pt - pl * 3;
-			const int rn = t == 0 ? rm : t == 2 ? 1 + DP_MBS + i : i;
-			const uint32_t n0 = L.hdr[rn][0], n1 = L.hdr[rn][1];
-			const int qm = pl == 0 ? (int)(h0 >> 16 & 255) : pl == 1 ? (int)(h0 >> 24) : (int)(h1 & 255);
-			const int qn = pl == 0 ? (int)(n0 >> 16 & 255) : pl == 1 ? (int)(n0 >> 24) : (int)(n1 & 255);
-			const bool use_nb = (t == 1 && (flags & E264_MBF_EDGE_LEFT)) || (t == 2 && (flags & E264_MBF_EDGE_TOP));
-			const int qPav = (qm + (use_nb ? qn : qm) + 1) >> 1;
-			const int iA = min(max(qPav + L.fo[i][0], 0), 51), iB = min(max(qPav + L.fo[i][1], 0), 51);
-			v = what == 0 ? L.alpha[iA] : what == 1 ? L.beta[iB] : iA;
-		}
-		out8[i * 64 + 32 + hl] = (uint8_t)v;
+		const bool on = a0 + i < n_mbs && (h0 >> 8 & E264_MBF_DEBLOCK) && (h0 & 255) != E264_MB_ABSENT;
+		out8[i * 64 + hl] = (uint8_t)dbkp_bs_value(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], L.mo[rt], has_motion, on, hl);
+		out8[i * 64 + 32 + hl] = (uint8_t)dbkp_ab_value(L.hdr[rm], L.hdr[rl], L.hdr[rt], L.fo[i][0], L.fo[i][1], L.alpha, L.beta, on, hl);
 	}
 }
 

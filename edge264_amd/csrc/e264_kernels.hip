@@ -34,7 +34,6 @@
 #include "e264_kernels.h"
 #include "e264_dev.h"
 #include "e264_pred.h"
-#include "e264_dbkp.h"
 
 namespace {
 // ---------------------------------------------------------------------------------
@@ -1311,7 +1310,7 @@ __device__ __forceinline__ int intra_chroma_px(const WaveLds &L, int p, int mode
 // ---------------------------------------------------------------------------------
 // WHICH: 1 = inter and PCM macroblocks only (no dependency inside the frame), 2 = intra only, 3 = all
 template <int WHICH>
-__device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, int mbx, int mby, int lane, const CoefPf &pf)
+__device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, int mbx, int mby, int lane, const CoefPf &pf PH_PARAMS)
 { // pf: the macroblock's payload, issued by the caller (coef_issue) as early as it could
 	if (m.kind == E264_MB_ABSENT)
 		return;
@@ -1337,16 +1336,20 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const Mb
 	nbv.oky = nbv.okc = false;
 	if (WHICH != 1 && m.kind != E264_MB_INTER)
 		nbv = issue_intra_neighbours(f, mbx, mby, lane); // in flight during the residual
+	PH(2);
 	if (!(f.dbg & 1024)) {
 		slice_cache(L, f, m.slice, lane);
 		coef_commit(L, m, lane, pf);
+		PH(3);
 		compute_residual(L, f, m, lane);
 	}
+	PH(4);
 
 	int pY[4], pC[2];
 	bool tile_luma = false;
 	if (WHICH != 1 && m.kind != E264_MB_INTER) {
 		commit_intra_neighbours(L, nbv, lane);
+		PH(5);
 		if (m.kind == E264_MB_I16x16) {
 			intra16x16_pred(L, m.i16_mode, X, Yr, pY);
 		} else if (m.kind == E264_MB_I4x4) { // edge264_slice.c:615-635: predict, add residual, next block
@@ -1380,6 +1383,7 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const Mb
 			for (int b = 0; b < 4; b++)
 				intra8x8_block(L, BXf(b * 4), BYf(b * 4), (int)(modes_lo >> (8 * b) & 255), lane);
 		}
+		PH(6);
 		pC[0] = intra_chroma_px(L, cpl, m.chroma_mode, cx, cy);
 		pC[1] = intra_chroma_px(L, cpl, m.chroma_mode, cx + 1, cy);
 	}
@@ -1392,6 +1396,7 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const Mb
 		outw = (uint32_t)clip255(w16(pY[0] + rr[0])) | (uint32_t)clip255(w16(pY[1] + rr[1])) << 8 |
 			(uint32_t)clip255(w16(pY[2] + rr[2])) << 16 | (uint32_t)clip255(w16(pY[3] + rr[3])) << 24;
 	}
+	PH(7);
 	if (f.dbg & 4096) return;
 	*(gu32 *)dY = outw;
 	const int16_t *rc = L.res + 256 + cpl * 64 + cy * 8 + cx;
@@ -2045,9 +2050,19 @@ __attribute__((amdgpu_waves_per_eu(E264_PRED_WAVES_PER_EU, E264_PRED_WAVES_PER_E
 	const PredTile t = {(bx % ntx) * PT_W, (bx / ntx) * PT_H};
 	PH_DECL;
 	pred_phase_setup(L, f, t, tid);
+	// mode bit 17: the deblocking parameters of the tile ride along (one launch less).  Off by default: measured 1.81 ms for the
+	// combined kernel against 1.46 + 0.28 ms for the two launches (two more barriers per tile at this kernel's occupancy).
+	const bool with_dbk = (mode & 2) && (mode & 131072) && f.dbk;
+	if (with_dbk) pred_phase_dbk_load(L, f, t, tid);
 	PH(0);
 	__syncthreads();
-	{ // nothing for this kernel in the tile (every tile of an I frame)? leave at once
+	if (with_dbk) {
+		pred_phase_dbk_compute(L, f, t, tid);
+		__syncthreads();
+		pred_phase_dbk_store(L, f, t, tid);
+		__syncthreads(); // the sample area is free again
+	}
+	{ // nothing more for this kernel in the tile (every tile of an I frame)? leave at once
 		const int kind = tid < PT_MBS ? (int)(L.hdr[tid][0] & 255) : 0;
 		if (!__syncthreads_or(kind == E264_MB_INTER || kind == E264_MB_PCM))
 			return;
@@ -2167,6 +2182,7 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 	if (lane == 0) L.ws_slice = -1;
 	wave_sync();
 	const gu8 *mbs_g = f.payload - f.h->payload_off + f.h->mbs_off; // the E264Mb array through a per-lane (global) pointer
+	PH_DECL;
 #pragma unroll 1
 	for (int y = wave; y < f.hm; y += NW) {
 		// the row is scanned 64 macroblocks at a time (one vector load + ballot) instead of one scalar load per
@@ -2196,6 +2212,7 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 			while (todo) {
 				const int x = x0 + (int)__builtin_ctzll(todo);
 				todo &= todo - 1;
+				PH(0);
 				const MbInfo mi = mb_from_lds(&hdrs[wave][(x - x0) * 8]);
 				CoefPf pf;
 				coef_issue(f, mi, lane, pf); // the payload does not depend on the neighbours: in flight during the wait below
@@ -2205,8 +2222,11 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 						__builtin_amdgcn_s_sleep(1);
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 				}
-				recon_mb<2>(L, f, mi, x, y, lane, pf);
+				PH(1);
+				recon_mb<2>(L, f, mi, x, y, lane, pf PH_ARGS);
+				PH(8);
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				PH(9);
 				// finished: everything up to the next intra macroblock of the chunk (or the chunk's end)
 				const int upto = todo ? x0 + (int)__builtin_ctzll(todo) : xe;
 				if (lane == 0)
@@ -2214,6 +2234,9 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 			}
 		}
 	}
+#ifdef E264_PHASE_INTRA
+	PH_FLUSH_DBK(lane);
+#endif
 }
 
 template <int NW>
@@ -2304,7 +2327,9 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 				__hip_atomic_store(&progress[my_y], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			PH(9);
 		}
+#ifndef E264_PHASE_INTRA
 		PH_FLUSH_DBK(lane);
+#endif
 	}
 }
 
@@ -2321,16 +2346,22 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 	// 215-VGPR waves per SIMD and use issue slots those leave idle.  Ordered after everything enqueued before (the packet
 	// copies, the previous batch's deblocking that still reads the parameter buffer) by `forked`, before deblocking by `joined`.
 	const bool side = dbkp && fork && fork->aux;
-	if (side) {
+	// side queue, second form (mode bit 16): the fork sits AFTER the prediction kernel, so that the parameter kernel (bound by
+	// packet reads) runs beside the intra wavefront kernel (bound by dependency latency) instead of beside the prediction kernel
+	const bool side_late = side && (mode & 65536);
+	auto launch_side = [&]() {
 		hipEventRecord(fork->forked, stream);
 		hipStreamWaitEvent(fork->aux, fork->forked, 0);
 		if (marks) hipEventRecord(fork->amarks[0], fork->aux);
 		hipLaunchKernelGGL(e264_dbkparam2_kernel, dim3((max_mbs + DP_MBS - 1) / DP_MBS, n_jobs), dim3(DP_NT), 0, fork->aux, jobs);
 		if (marks) hipEventRecord(fork->amarks[1], fork->aux);
 		hipEventRecord(fork->joined, fork->aux);
+	};
+	if (side) {
+		if (!side_late) launch_side();
 	} else if (dbkp && (mode & 32768)) // debug mode bit 15: round 1's per-lane-load parameter kernel (A/B timing only)
 		hipLaunchKernelGGL(e264_dbkparam_kernel, dim3((max_mbs + 15) / 16, n_jobs), dim3(256), 0, stream, jobs);
-	else if (dbkp)
+	else if (dbkp && !((mode & 1) && (mode & 131072) && !(mode & 16384))) // (mode bit 17: the prediction kernel computes the parameters of its tiles itself)
 		hipLaunchKernelGGL(e264_dbkparam2_kernel, dim3((max_mbs + DP_MBS - 1) / DP_MBS, n_jobs), dim3(DP_NT), 0, stream, jobs);
 	if (marks) hipEventRecord(marks[1], stream);
 	if (mode & 16384) // debug mode bit 14: round 1's strip-per-wave kernel (A/B timing only)
@@ -2338,6 +2369,7 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 	else if (mode & 1)
 		hipLaunchKernelGGL(e264_pred_kernel, dim3(max_tiles, n_jobs), dim3(PT_NT), 0, stream, jobs, mode);
 	if (marks) hipEventRecord(marks[2], stream);
+	if (side_late) launch_side();
 	const int intra_waves = waves >> 8 ? waves >> 8 : waves & 255;
 	waves &= 255;
 	if (mode & 1) {

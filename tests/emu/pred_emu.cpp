@@ -42,11 +42,11 @@ static inline uint32_t v_sat_pk_u8_i16(uint32_t v)
 static inline int lds_add(int *p, int v) { int o = *p; *p += v; return o; }
 static inline void lds_or(uint32_t *p, uint32_t v) { *p |= v; }
 #include "../../edge264_amd/csrc/e264_pred.h"
-#include "../../edge264_amd/csrc/e264_dbkp.h"
 
-extern "C" __attribute__((visibility("default"))) int e264emu_pred_frame(const uint8_t *pkt, uint8_t *const *dpb)
+// dbk: NULL, or room for 64 bytes per macroblock: the kernel then also computes the deblocking parameters of its tiles
+extern "C" __attribute__((visibility("default"))) int e264emu_pred_frame2(const uint8_t *pkt, uint8_t *const *dpb, uint8_t *dbk)
 {
-	E264Job job = {pkt, dpb, nullptr};
+	E264Job job = {pkt, dpb, dbk};
 	FrameCtx f;
 	if (!open_frame(f, job))
 		return -1;
@@ -56,6 +56,12 @@ extern "C" __attribute__((visibility("default"))) int e264emu_pred_frame(const u
 		PredTile t = {(ti % ntx) * PT_W, (ti / ntx) * PT_H};
 		memset(&L, 0xA5, sizeof(L)); // LDS is not zeroed on the device either
 		for (int tid = 0; tid < PT_NT; tid++) pred_phase_setup(L, f, t, tid);
+		if (dbk) {
+			for (int tid = 0; tid < PT_NT; tid++) pred_phase_dbk_load(L, f, t, tid);
+			for (int tid = 0; tid < PT_NT; tid++) pred_phase_dbk_compute(L, f, t, tid);
+			for (int tid = 0; tid < PT_NT; tid++) pred_phase_dbk_store(L, f, t, tid);
+			memset(L.y, 0xA5, sizeof(L.y)); // nothing may depend on what the scratch left behind
+		}
 		for (int list = 0; list < 2; list++) {
 			if (list == 1 && !L.any_l1) break;
 			if (list == 1) for (int tid = 0; tid < PT_NT; tid++) pred_phase_reset(L, tid);
@@ -67,6 +73,11 @@ extern "C" __attribute__((visibility("default"))) int e264emu_pred_frame(const u
 		for (int tid = 0; tid < PT_NT; tid++) pred_phase_flush(L, f, t, tid);
 	}
 	return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int e264emu_pred_frame(const uint8_t *pkt, uint8_t *const *dpb)
+{
+	return e264emu_pred_frame2(pkt, dpb, nullptr);
 }
 
 // e264_dbkparam2_kernel: out = 64 bytes per macroblock
