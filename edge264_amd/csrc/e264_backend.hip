@@ -270,7 +270,7 @@ static int check_packet(const void *packet, size_t bytes, int *dst, int *n_mbs, 
 	if (h->dst_slot < 0 || h->dst_slot >= E264_MAX_SLOTS) return fail(EINVAL, "dst_slot");
 	size_t n_mb = (size_t)h->width_mbs * h->height_mbs;
 	size_t need = (size_t)h->mbs_off + n_mb * sizeof(E264Mb);
-	if (h->motion_off && (h->motion_off < need || (need = (size_t)h->motion_off + n_mb * sizeof(E264Motion)) > h->total_bytes)) return fail(EINVAL, "motion section");
+	if (h->motion_off && (h->motion_off < need || (need = (size_t)h->motion_off) > h->total_bytes)) return fail(EINVAL, "motion section");
 	if (need > h->payload_off || (size_t)h->payload_off + h->payload_bytes > h->total_bytes) return fail(EINVAL, "packet layout");
 	*dst = h->dst_slot;
 	*n_mbs = (int)h->width_mbs * h->height_mbs;
@@ -300,7 +300,8 @@ static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *s
 	const uint64_t frame_need = (uint64_t)h->plane_size_Y + h->plane_size_C;
 	if (slots && slot_bytes && slots[dst] && frame_need > slot_bytes[dst]) return fail(EINVAL, "picture larger than the destination slot");
 	const E264Mb *mbs = (const E264Mb *)(p + h->mbs_off);
-	const E264Motion *mo = h->motion_off ? (const E264Motion *)(p + h->motion_off) : nullptr;
+	const uint8_t *mot = h->motion_off ? p + h->motion_off : nullptr; // compact motion records, up to payload_off
+	const uint32_t mot_bytes = h->motion_off ? h->payload_off - h->motion_off : 0;
 	uint32_t ref_mask = 0;
 	for (int a = 0; a < n_mbs; a++) {
 		const E264Mb &m = mbs[a];
@@ -312,14 +313,20 @@ static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *s
 		if ((m.flags & E264_MBF_EDGE_LEFT) && a % h->width_mbs == 0) return fail(EINVAL, "left edge flag on the first column");
 		if ((m.flags & E264_MBF_EDGE_TOP) && a < h->width_mbs) return fail(EINVAL, "top edge flag on the first row");
 		if (m.kind == E264_MB_INTER) {
-			if (!mo) return fail(EINVAL, "inter macroblock without motion section");
+			if (!mot) return fail(EINVAL, "inter macroblock without motion section");
+			uint32_t d[2];
+			memcpy(d, m.modes, 8); // motion directory: record offset, shape
+			if ((d[0] & 3) || d[1] >> 26 || (uint64_t)d[0] + e264_mot_record_bytes(d[1]) > mot_bytes) return fail(EINVAL, "macroblock motion record");
+			E264Motion mx;
+			e264_motion_expand(d[1], mot + d[0], &mx);
 			for (int i = 0; i < 8; i++) {
-				int rp = mo[a].refPic[i];
-				if (rp < -1 || rp >= E264_MAX_SLOTS) return fail(EINVAL, "reference slot");
+				int rp = mx.refPic[i];
+				const bool used = E264_MOT_UNI(d[1], i >> 2) || E264_MOT_USED(d[1], i);
+				if (rp < (used ? 0 : -1) || rp >= E264_MAX_SLOTS) return fail(EINVAL, "reference slot"); // a part the directory announces predicts from a picture
 				if (rp >= 0 && slots && !slots[rp]) return fail(EINVAL, "reference slot not allocated");
 				if (rp >= 0 && slots && slot_bytes && frame_need > slot_bytes[rp]) return fail(EINVAL, "picture larger than a reference slot");
 				if (rp >= 0) ref_mask |= 1u << rp;
-				if (mo[a].refIdx[i] < -1 || mo[a].refIdx[i] > 31) return fail(EINVAL, "reference index");
+				if (mx.refIdx[i] < -1 || mx.refIdx[i] > 31) return fail(EINVAL, "reference index");
 			}
 		}
 	}

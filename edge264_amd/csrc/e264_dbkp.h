@@ -25,7 +25,7 @@ namespace {
 #define DP_NT 256
 struct __attribute__((aligned(16))) DbkpLds {
 	uint32_t hdr[2 * DP_MBS + 1][8];   // E264Mb: [0] left neighbour of the first macroblock, [1..64] own, [65..128] top neighbours
-	uint32_t mo[2 * DP_MBS + 1][36];   // E264Motion, same order
+	uint32_t mo[2 * DP_MBS + 1][36];   // motion in expanded (E264Motion) form, same order; filled from the compact records
 	uint32_t out[DP_MBS][16];
 	int8_t fo[DP_MBS][2];              // FilterOffsetA / B of each macroblock's slice
 	uint8_t alpha[52], beta[52];
@@ -46,17 +46,24 @@ E264_DEV void dbkp_phase_load(DbkpLds &L, const FrameCtx &f, int a0, int tid)
 		const int j = i >> 1, part = i & 1;
 		*(v4u *)&L.hdr[j][part * 4] = *(const gv4u *)(mbs_g + (size_t)dbkp_addr(f, a0, j) * 32 + part * 16);
 	}
-	if (f.motion)
-		for (int i = tid; i < (2 * DP_MBS + 1) * 9; i += DP_NT) { // 144-byte records: 9 pieces
-			const int j = i / 9, part = i - j * 9;
-			*(v4u *)&L.mo[j][part * 4] = *(const gv4u *)((const gu8 *)f.motion + (size_t)dbkp_addr(f, a0, j) * 144 + part * 16);
-		}
 	if (tid < 52) { L.alpha[tid] = c_alpha[tid]; L.beta[tid] = c_beta[tid]; }
 }
 
-// after the records have landed: slice offsets (one lane per macroblock)
+// after the records have landed: the motion of the inter macroblocks among them, expanded from the packet's compact
+// records into the per-4x4 form the comparisons index (one task per record, list and quadrant); slice offsets
 E264_DEV void dbkp_phase_slices(DbkpLds &L, const FrameCtx &f, int tid)
 {
+	if (f.motion)
+		for (int i = tid; i < (2 * DP_MBS + 1) * 8; i += DP_NT) {
+			const int j = i >> 3, l = i >> 2 & 1, q = i & 3;
+			if ((L.hdr[j][0] & 255) != E264_MB_INTER)
+				continue;
+			uint32_t refword = 0xffffu, mv[4] = {0, 0, 0, 0};
+			mot_quadrant(f.motion, L.hdr[j][5], L.hdr[j][6], l, q, refword, mv); // unused: no reference (-1), zero vectors
+			((uint8_t *)&L.mo[j][l])[q] = (uint8_t)refword;
+#pragma unroll
+			for (int k = 0; k < 4; k++) L.mo[j][4 + l * 16 + q * 4 + k] = mv[k];
+		}
 	if (tid < DP_MBS) {
 		cslice_t s = f.slices + (L.hdr[1 + tid][7] & 0xffff); // E264Mb.dbk_slice
 		L.fo[tid][0] = s->FilterOffsetA; L.fo[tid][1] = s->FilterOffsetB;

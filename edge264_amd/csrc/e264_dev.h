@@ -169,11 +169,48 @@ E264_DEV s16x2 half5p(s16x2 v) // clip255((v + 16) >> 5)
 	const s16x2 s5 = {5, 5}, r16 = {16, 16}, z = {0, 0}, m = {255, 255};
 	return __builtin_elementwise_min(__builtin_elementwise_max((v + r16) >> s5, z), m);
 }
+// One quadrant (list l, 8x8 block q) of a macroblock's compact motion record (edge264_cmd.h): its reference bytes
+// {refPic, refIdx, 0, 0} and the vectors of its four 4x4 blocks (zig order inside the quadrant).  mot_off / mot_hdr: the
+// directory words of E264Mb.modes.  Returns false when the list does not predict the quadrant.
+E264_DEV uint32_t mot_nmv(uint32_t sub) { return 0x4221u >> (sub * 4) & 15u; } // vectors of a quadrant: 8x8, 8x4, 4x8, 4x4
+E264_DEV bool mot_quadrant(const gu8 *motion, uint32_t mot_off, uint32_t h, int l, int q, uint32_t &refword, uint32_t mv[4])
+{
+	const bool uni = E264_MOT_UNI(h, l);
+	if (!uni && !E264_MOT_USED(h, l * 4 + q))
+		return false;
+	uint32_t off = mot_off;
+	if (l) { // skip the list-0 part
+		uint32_t n0 = 0;
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			n0 += E264_MOT_USED(h, k) ? 4 + 4 * mot_nmv(E264_MOT_SUB(h, k)) : 0;
+		off += E264_MOT_UNI(h, 0) ? 8 : n0;
+	}
+	const gu32 *rec = (const gu32 *)(motion + off);
+	if (uni) {
+		refword = rec[0];
+		mv[0] = mv[1] = mv[2] = mv[3] = rec[1];
+		return true;
+	}
+	uint32_t skip = 0; // dwords of the used quadrants before q
+#pragma unroll
+	for (int k = 0; k < 3; k++)
+		if (k < q && E264_MOT_USED(h, l * 4 + k)) skip += 1 + mot_nmv(E264_MOT_SUB(h, l * 4 + k));
+	rec += skip;
+	refword = rec[0];
+	const uint32_t sub = E264_MOT_SUB(h, l * 4 + q);
+	const uint32_t v0 = rec[1], v1 = sub ? rec[2] : v0;
+	if (sub == 3) { mv[0] = v0; mv[1] = v1; mv[2] = rec[3]; mv[3] = rec[4]; }
+	else if (sub == 2) { mv[0] = v0; mv[1] = v1; mv[2] = v0; mv[3] = v1; }
+	else { mv[0] = v0; mv[1] = v0; mv[2] = v1; mv[3] = v1; }
+	return true;
+}
+
 struct FrameCtx {
 	chdr_t h;
 	cslice_t slices;
 	cmb_t mbs;
-	gmotion_t motion;  // dense per-MB array, NULL if the frame has no inter macroblock
+	const gu8 *motion; // compact motion records (edge264_cmd.h E264_MOT_*), NULL if the frame has no inter macroblock
 	const gu8 *payload;
 	gdpb_t dpb;
 	const generic_u8p *dpb_lds; // the same table staged in LDS (mbpar kernel): no dependent global round trip per reference
@@ -201,7 +238,7 @@ E264_DEV bool open_frame(FrameCtx &f, const E264Job &job)
 	f.slices = (cslice_t)(pkt + h->slices_off);
 	f.mbs = (cmb_t)(pkt + h->mbs_off);
 	f.payload = (const gu8 *)(pkt + h->payload_off);
-	f.motion = h->motion_off ? (gmotion_t)(pkt + h->motion_off) : nullptr;
+	f.motion = h->motion_off ? (const gu8 *)(pkt + h->motion_off) : nullptr;
 	f.dpb_lds = nullptr;
 	f.dbg = 0;
 	f.dpb = (gdpb_t)job.dpb;

@@ -34,6 +34,7 @@
 #include "e264_kernels.h"
 #include "e264_dev.h"
 #include "e264_pred.h"
+#include "e264_dbkp.h"
 
 namespace {
 // ---------------------------------------------------------------------------------
@@ -65,20 +66,6 @@ struct __attribute__((aligned(16))) WaveLds { // reconstruction scratch of one w
 	__attribute__((aligned(4))) uint8_t ws[224];   // scaling lists of the cached slice: weightScale4x4[6][16], weightScale8x8[0..1][64]
 	int ws_slice;              // slice index the cache holds (-1: none)
 	int ws_idc;                // its weighted_bipred_idc
-};
-
-// Output staging of one strip of the macroblock-parallel kernel: the samples of its (up to) 8
-// macroblocks are collected here and written at the end of the strip as 16-byte pieces ordered so
-// that 8 consecutive lanes cover 128 contiguous bytes of a luma row (64 of a chroma row).  Storing
-// each macroblock as it is produced (64 lanes x 4 bytes = sixteen 16-byte row pieces) left every
-// 64-byte segment partially written several times: 3.6x the algorithmic write traffic at the L2
-// memory side (TCC_EA0_WRREQ, profiles/r01_pmc_calibration.txt).
-#ifndef E264_MBPAR_STRIP
-#define E264_MBPAR_STRIP 24 // macroblocks per wave (multiple of 8; measured with the final pipeline 16: 3.64 ms, 24: 3.60, 32: 3.64 per 256-frame launch)
-#endif
-struct __attribute__((aligned(16))) StripOut {
-	uint32_t y[E264_MBPAR_STRIP][64];  // [mb][row * 4 + dword]
-	uint32_t c[E264_MBPAR_STRIP][32];  // [mb][plane * 16 + row * 2 + dword]
 };
 
 #ifndef DBK_RING
@@ -465,590 +452,6 @@ __device__ __forceinline__ void compute_residual(WaveLds &L, const FrameCtx &f, 
 }
 
 // ---------------------------------------------------------------------------------
-// inter prediction
-// ---------------------------------------------------------------------------------
-// struct Wod: e264_pred.h
-__device__ __forceinline__ int wpred(int q, int p, const Wod &w)
-{ // maddshrL, edge264_inter.c:17-21: pmaddubsw (int8 weights), adds16, sra, packus
-	int x = sat16(q * (int)(int8_t)w.w0 + p * (int)(int8_t)w.w1);
-	x = sat16(x + (int)(int16_t)w.o);
-	return clip255(x >> w.wd);
-}
-
-// decode_inter weight selection, edge264_inter.c:1137-1197
-__device__ __forceinline__ void select_weights(const SliceW *s, int list, int refIdx, int refIdxX, Wod &wY, Wod &wCb, Wod &wCr)
-{
-	Wod nw = {0, 1, 0, 0};
-	wY = wCb = wCr = nw;
-	int idc = s->weighted_bipred_idc;
-	if (idc != 1) {
-		if (list == 1 && refIdxX >= 0) {
-			if (idc == 0) {
-				Wod d = {1, 1, 1, 1};
-				wY = wCb = wCr = d;
-			} else {
-				int w1 = (int)s->implicit_weights[refIdxX][refIdx] - 64;
-				Wod d = {64 - w1, w1, 32, 6};
-				if ((unsigned)(w1 + 63) >= 191u) { d.w0 = 2 - (w1 >> 5); d.w1 = w1 >> 5; d.o = 1; d.wd = 1; }
-				wY = wCb = wCr = d;
-			}
-		}
-	} else if (refIdxX < 0) {
-		int i = refIdx + list * 32;
-		int lwd = s->luma_log2_weight_denom, cwd = s->chroma_log2_weight_denom;
-		if (s->explicit_weights[0][i] < 128) {
-			wY.w1 = s->explicit_weights[0][i];
-			wY.o = w16(((s->explicit_offsets[0][i] * 2 + 1) << lwd) >> 1);
-			wY.wd = lwd;
-		}
-		if (s->explicit_weights[1][i] < 128) {
-			wCb.w1 = s->explicit_weights[1][i];
-			wCr.w1 = s->explicit_weights[2][i];
-			wCb.o = w16(((s->explicit_offsets[1][i] * 2 + 1) << cwd) >> 1);
-			wCr.o = w16(((s->explicit_offsets[2][i] * 2 + 1) << cwd) >> 1);
-			wCb.wd = wCr.wd = cwd;
-		}
-	} else if (list == 1) {
-		int i = refIdx + 32, x = refIdxX;
-		int lwd = s->luma_log2_weight_denom, cwd = s->chroma_log2_weight_denom;
-		int a = s->explicit_weights[0][x], b = s->explicit_weights[0][i];
-		int oo = ((s->explicit_offsets[0][x] + s->explicit_offsets[0][i] + 1) | 1) << lwd;
-		if ((a & b) != 128) { wY.w0 = a; wY.w1 = b; wY.o = w16(oo); wY.wd = lwd + 1; }
-		else { wY.w0 = a >> 1; wY.w1 = b >> 1; wY.o = w16(oo >> 1); wY.wd = lwd; }
-		int a1 = s->explicit_weights[1][x], b1 = s->explicit_weights[1][i];
-		int a2 = s->explicit_weights[2][x], b2 = s->explicit_weights[2][i];
-		int o1 = ((s->explicit_offsets[1][x] + s->explicit_offsets[1][i] + 1) | 1) << cwd;
-		int o2 = ((s->explicit_offsets[2][x] + s->explicit_offsets[2][i] + 1) | 1) << cwd;
-		if ((a1 & b1) != 128) {
-			wCb.w0 = a1; wCb.w1 = b1; wCr.w0 = a2; wCr.w1 = b2;
-			wCb.o = w16(o1); wCr.o = w16(o2); wCb.wd = wCr.wd = cwd + 1;
-		} else {
-			wCb.w0 = a1 >> 1; wCb.w1 = b1 >> 1; wCr.w0 = a2 >> 1; wCr.w1 = b2 >> 1;
-			wCb.o = w16(o1 >> 1); wCr.o = w16(o2 >> 1); wCb.wd = wCr.wd = cwd;
-		}
-	}
-}
-
-// 9 consecutive samples x0..x0+8 of row y (clamped coordinates == the reference's edge
-// emulation, edge264_inter.c:1199-1235).  Fast path: three aligned dwords + byte alignment.
-__device__ __forceinline__ void load_row9(const gu8 *plane, int stride, int W, int H, int x0, int y, int px[9])
-{
-	y = clip3i(0, H - 1, y);
-	const gu8 *row = plane + (size_t)y * stride;
-	if (x0 >= 0 && x0 + 8 <= W - 1) {
-		uintptr_t p = (uintptr_t)(row + x0);
-		const gu32 *q = (const gu32 *)(p & ~(uintptr_t)3);
-		uint32_t off = (uint32_t)(p & 3);
-		uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-		uint32_t a = __builtin_amdgcn_alignbyte(d1, d0, off);
-		uint32_t b = __builtin_amdgcn_alignbyte(d2, d1, off);
-		uint32_t c = d2 >> (off * 8);
-		px[0] = a & 255; px[1] = a >> 8 & 255; px[2] = a >> 16 & 255; px[3] = a >> 24;
-		px[4] = b & 255; px[5] = b >> 8 & 255; px[6] = b >> 16 & 255; px[7] = b >> 24;
-		px[8] = c & 255;
-	} else {
-#pragma unroll
-		for (int i = 0; i < 9; i++)
-			px[i] = row[clip3i(0, W - 1, x0 + i)];
-	}
-}
-
-__device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
-// sixtapHV + shrrpus16(.,6): int16 wraparound, edge264_inter.c:4-9,14
-__device__ __forceinline__ int centre6(int t0, int t1, int t2, int t3, int t4, int t5)
-{
-	int af = w16(t0 + t5), be = w16(t1 + t4), cd = w16(t2 + t3);
-	int x1 = w16(af - be);
-	int x2 = w16((x1 >> 2) + w16(cd - be));
-	int x3 = w16((x2 >> 2) + cd);
-	return clip255(w16(x3 + 32) >> 6);
-}
-__device__ __forceinline__ int avg2(int a, int b) { return (a + b + 1) >> 1; }
-
-// 4 horizontally adjacent luma samples displaced by the quarter-pel (xF,yF): 8.4.2.2.1 as organised by
-// decode_inter_luma (edge264_inter.c:416-968).  d[r][0..2] hold the 9 samples x-2..x+6 of row y-2+r (already
-// byte-aligned).  The work is split in blocks guarded by PER-LANE conditions; the compiler turns them into
-// EXEC-masked regions that are skipped when no lane of the wave needs them, so a macroblock with one vector
-// pays only for the taps of its fractional position and a wave with several vectors pays for the union:
-//   G  integer sample                                    (always; 6 ops)
-//   b  horizontal half sample of row 2 or 3              (yF==0 | both odd)
-//   h  vertical half sample of column 2 or 3             (xF==0 | both odd)
-//   jH centre from the horizontal taps of 6 rows (+ b)   (xF==2, yF!=0)   inter.c:611-646, 779-802, 929-966
-//   jV centre from the vertical taps of 9 columns (+ h)  (xF odd, yF==2)  inter.c:559-609, 741-777, 887-927
-// 16-bit intermediates of the centre wrap as in the reference (sixtapHV, inter.c:4-9).
-#if E264_LUMA_PACKED
-// ---- packed 16-bit arithmetic (v_pk_*_i16: two samples per instruction) --------------------------------------
-__device__ __forceinline__ void luma_from_rows(const uint32_t d[6][3], int xF, int yF, int out[4])
-{
-	const bool xo = xF & 1, yo = yF & 1;
-	const bool uses_j = (xF == 2 && yF != 0) || (yF == 2 && xF != 0);
-	const bool uses_G = (xF == 0 || yF == 0) && (xo || yo || (xF | yF) == 0);
-	const bool uses_b = (yF == 0 && xF != 0) || (xo && yo) || (xF == 2 && yo);
-	const bool uses_h = (xF == 0 && yF != 0) || (xo && yo) || (yF == 2 && xo);
-#ifdef E264_ABL_NOJ
-	const bool jH = false, jV = false;
-#else
-	const bool jH = uses_j && xF == 2, jV = uses_j && xF != 2;
-#endif
-	const bool row3 = yF == 3, col3 = xF == 3;
-	const s16x2 z = {0, 0};
-	s16x2 G[2], b[2] = {z, z}, h[2] = {z, z}, j[2] = {z, z}; // [0] = outputs 0,1   [1] = outputs 2,3
-	{ // integer sample: row 2 (3 when yF==3), columns 2..5 (3..6 when xF==3)
-		const uint32_t w0 = row3 ? d[3][0] : d[2][0], w1 = row3 ? d[3][1] : d[2][1];
-		const uint32_t g4 = col3 ? __builtin_amdgcn_alignbyte(w1, w0, 3) : __builtin_amdgcn_alignbyte(w1, w0, 2);
-		G[0] = pair_at<0>(0, g4); G[1] = pair_at<2>(0, g4);
-	}
-	if (jH) {
-		s16x2 H0[6], H1[6];
-#pragma unroll
-		for (int r = 0; r < 6; r++) {
-			s16x2 Q[8];
-			pairs9(d[r], Q);
-			H0[r] = tap6p(Q[0], Q[1], Q[2], Q[3], Q[4], Q[5]);
-			H1[r] = tap6p(Q[2], Q[3], Q[4], Q[5], Q[6], Q[7]);
-		}
-		j[0] = centre6p(H0[0], H0[1], H0[2], H0[3], H0[4], H0[5]);
-		j[1] = centre6p(H1[0], H1[1], H1[2], H1[3], H1[4], H1[5]);
-		b[0] = half5p(row3 ? H0[3] : H0[2]);
-		b[1] = half5p(row3 ? H1[3] : H1[2]);
-	} else if (uses_b E264_ABL_BH) {
-		const uint32_t w[3] = {row3 ? d[3][0] : d[2][0], row3 ? d[3][1] : d[2][1], row3 ? d[3][2] : d[2][2]};
-		s16x2 Q[8];
-		pairs9(w, Q);
-		b[0] = half5p(tap6p(Q[0], Q[1], Q[2], Q[3], Q[4], Q[5]));
-		b[1] = half5p(tap6p(Q[2], Q[3], Q[4], Q[5], Q[6], Q[7]));
-	}
-	if (jV) {
-		// vertical taps of the column pairs (0,1) (2,3) (4,5) (6,7) and of column 8; the odd pairs come from alignbit
-		s16x2 E[5][6];
-#pragma unroll
-		for (int r = 0; r < 6; r++) {
-			E[0][r] = pair_at<0>(d[r][1], d[r][0]); E[1][r] = pair_at<2>(d[r][1], d[r][0]);
-			E[2][r] = pair_at<0>(d[r][2], d[r][1]); E[3][r] = pair_at<2>(d[r][2], d[r][1]);
-			E[4][r] = as_s2(d[r][2] & 255u);
-		}
-		s16x2 V[5];
-#pragma unroll
-		for (int c = 0; c < 5; c++)
-			V[c] = tap6p(E[c][0], E[c][1], E[c][2], E[c][3], E[c][4], E[c][5]);
-		// V[c] = (V_2c, V_2c+1); odd pairs (V_2c+1, V_2c+2)
-		s16x2 O[4];
-#pragma unroll
-		for (int c = 0; c < 4; c++)
-			O[c] = as_s2(__builtin_amdgcn_alignbit(as_u(V[c + 1]), as_u(V[c]), 16));
-		// outputs (0,1): taps at columns (0,1)(1,2)(2,3)(3,4)(4,5)(5,6); outputs (2,3): (2,3)(3,4)(4,5)(5,6)(6,7)(7,8)
-		j[0] = centre6p(V[0], O[0], V[1], O[1], V[2], O[2]);
-		j[1] = centre6p(V[1], O[1], V[2], O[2], V[3], O[3]);
-		h[0] = half5p(col3 ? O[1] : V[1]);
-		h[1] = half5p(col3 ? O[2] : V[2]);
-	} else if (uses_h E264_ABL_BH) {
-		s16x2 C0[6], C1[6];
-#pragma unroll
-		for (int r = 0; r < 6; r++) {
-			const uint32_t g4 = col3 ? __builtin_amdgcn_alignbyte(d[r][1], d[r][0], 3) : __builtin_amdgcn_alignbyte(d[r][1], d[r][0], 2);
-			C0[r] = pair_at<0>(0, g4); C1[r] = pair_at<2>(0, g4);
-		}
-		h[0] = half5p(tap6p(C0[0], C0[1], C0[2], C0[3], C0[4], C0[5]));
-		h[1] = half5p(tap6p(C1[0], C1[1], C1[2], C1[3], C1[4], C1[5]));
-	}
-	const s16x2 one = {1, 1};
-#pragma unroll
-	for (int k = 0; k < 2; k++) {
-		const s16x2 op1 = uses_j ? j[k] : uses_G ? G[k] : uses_b ? b[k] : h[k];
-		const s16x2 op2 = uses_h ? h[k] : uses_b ? b[k] : uses_j ? j[k] : G[k];
-		const s16x2 r = (op1 + op2 + one) >> one;
-		out[2 * k] = r.x; out[2 * k + 1] = r.y;
-	}
-}
-#else
-__device__ __forceinline__ void unpack9(const uint32_t w[3], int px[9])
-{
-	px[0] = w[0] & 255; px[1] = w[0] >> 8 & 255; px[2] = w[0] >> 16 & 255; px[3] = w[0] >> 24;
-	px[4] = w[1] & 255; px[5] = w[1] >> 8 & 255; px[6] = w[1] >> 16 & 255; px[7] = w[1] >> 24;
-	px[8] = w[2] & 255;
-}
-__device__ __forceinline__ void luma_from_rows(const uint32_t d[6][3], int xF, int yF, int out[4])
-{
-	const bool xo = xF & 1, yo = yF & 1;
-	const bool uses_j = (xF == 2 && yF != 0) || (yF == 2 && xF != 0);
-	const bool uses_G = (xF == 0 || yF == 0) && (xo || yo || (xF | yF) == 0);
-	const bool uses_b = (yF == 0 && xF != 0) || (xo && yo) || (xF == 2 && yo);
-	const bool uses_h = (xF == 0 && yF != 0) || (xo && yo) || (yF == 2 && xo);
-	const bool jH = uses_j && xF == 2, jV = uses_j && xF != 2;
-	const bool row3 = yF == 3, col3 = xF == 3;
-	int G[4], b[4] = {0, 0, 0, 0}, h[4] = {0, 0, 0, 0}, j[4] = {0, 0, 0, 0};
-	{ // integer sample: row 2 (3 when yF==3), columns 2..5 (3..6 when xF==3)
-		const uint32_t w0 = row3 ? d[3][0] : d[2][0], w1 = row3 ? d[3][1] : d[2][1];
-		const uint32_t g4 = col3 ? __builtin_amdgcn_alignbyte(w1, w0, 3) : __builtin_amdgcn_alignbyte(w1, w0, 2);
-		G[0] = g4 & 255; G[1] = g4 >> 8 & 255; G[2] = g4 >> 16 & 255; G[3] = g4 >> 24;
-	}
-	if (jH) {
-		int Hc[6][4];
-#pragma unroll
-		for (int r = 0; r < 6; r++) {
-			int px[9];
-			unpack9(d[r], px);
-#pragma unroll
-			for (int i = 0; i < 4; i++)
-				Hc[r][i] = tap6(px[i], px[i + 1], px[i + 2], px[i + 3], px[i + 4], px[i + 5]);
-		}
-#pragma unroll
-		for (int i = 0; i < 4; i++) {
-			j[i] = centre6(Hc[0][i], Hc[1][i], Hc[2][i], Hc[3][i], Hc[4][i], Hc[5][i]);
-			b[i] = clip255(((row3 ? Hc[3][i] : Hc[2][i]) + 16) >> 5);
-		}
-	} else if (uses_b) {
-		const uint32_t w[3] = {row3 ? d[3][0] : d[2][0], row3 ? d[3][1] : d[2][1], row3 ? d[3][2] : d[2][2]};
-		int px[9];
-		unpack9(w, px);
-#pragma unroll
-		for (int i = 0; i < 4; i++)
-			b[i] = clip255((tap6(px[i], px[i + 1], px[i + 2], px[i + 3], px[i + 4], px[i + 5]) + 16) >> 5);
-	}
-	if (jV) {
-		int V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-		const int cw[6] = {1, -5, 20, 20, -5, 1};
-#pragma unroll
-		for (int r = 0; r < 6; r++) {
-			int px[9];
-			unpack9(d[r], px);
-#pragma unroll
-			for (int c = 0; c < 9; c++)
-				V[c] += cw[r] * px[c];
-		}
-#pragma unroll
-		for (int i = 0; i < 4; i++) {
-			j[i] = centre6(V[i], V[i + 1], V[i + 2], V[i + 3], V[i + 4], V[i + 5]);
-			h[i] = clip255(((col3 ? V[i + 3] : V[i + 2]) + 16) >> 5);
-		}
-	} else if (uses_h) {
-		int c4[6][4];
-#pragma unroll
-		for (int r = 0; r < 6; r++) {
-			const uint32_t g4 = col3 ? __builtin_amdgcn_alignbyte(d[r][1], d[r][0], 3) : __builtin_amdgcn_alignbyte(d[r][1], d[r][0], 2);
-			c4[r][0] = g4 & 255; c4[r][1] = g4 >> 8 & 255; c4[r][2] = g4 >> 16 & 255; c4[r][3] = g4 >> 24;
-		}
-#pragma unroll
-		for (int i = 0; i < 4; i++)
-			h[i] = clip255((tap6(c4[0][i], c4[1][i], c4[2][i], c4[3][i], c4[4][i], c4[5][i]) + 16) >> 5);
-	}
-#pragma unroll
-	for (int i = 0; i < 4; i++) {
-		int op1 = uses_j ? j[i] : uses_G ? G[i] : uses_b ? b[i] : h[i];
-		int op2 = uses_h ? h[i] : uses_b ? b[i] : uses_j ? j[i] : G[i];
-		out[i] = avg2(op1, op2);
-	}
-}
-
-#endif
-
-// ---------------------------------------------------------------------------------
-// Inter prediction, software pipelined over a strip of macroblocks (mbpar kernel):
-//   stage A (2 MBs ahead)  motion of the macroblock:   refPic/refIdx (uniform, scalar) + this lane's vectors
-//   stage B (1 MB ahead)   reference samples into registers (luma windows, chroma taps)
-//   stage C                registers -> LDS windows, 6-tap / bilinear filters, weights, residual, store
-// so that every global-memory round trip is overlapped with the arithmetic of earlier macroblocks.
-// Pixel layout of a wave:
-//   luma   lane = (k = lane>>2 : 4x4 block in zig order, r = lane&3 : row) -> 4 samples
-//   chroma lane = (plane = lane>>5, cy = (lane>>2)&7, cx = (lane&3)*2)    -> 2 samples
-// ---------------------------------------------------------------------------------
-struct McMotion {
-	uint32_t refs[4];        // refPic L0, refPic L1, refIdx L0, refIdx L1 (4 x int8 each, per 8x8 block)
-	uint32_t mvY[2], mvC[2]; // packed (x | y<<16) vectors of this lane's luma block and chroma block, per list
-	int S;                   // wave-uniform: window granularity of list 0 (bits 0..7) and list 1 (bits 8..15): 16, 8 or 4
-};
-struct McWindows {          // reference samples of ONE list
-	uint32_t y0, y1, y2, y3; // luma window dwords fetched ahead by this lane (iterations 0..3)
-	uint32_t y4, y5, y6;     // iterations 4..6: only 4x4 windows (16 x 27 dwords = 7 per lane) have them
-	                         // (scalars, not an array: the array form ended up in scratch memory)
-	uint32_t ca, cb;         // chroma samples x..x+2 of rows y and y+1 of this lane, one byte each (RAW loads on the fast path:
-	                         // they are only taken apart by chroma_taps() one macroblock later)
-};
-__device__ __forceinline__ int ref_byte(uint32_t w, int b8) { return (int)(int8_t)(w >> (8 * b8)); }
-
-// Motion of a macroblock in two steps so that the loads stay in flight for a whole macroblock:
-//   mc_issue_raw   only ISSUES the loads (nothing here may use a loaded value: a use is a wait)
-//   mc_finish      one macroblock later: uniform refs through v_readlane, window granularity S
-struct McRaw { uint32_t rv, y0, y1, c0, c1; };
-__device__ __forceinline__ void mc_issue_raw(const FrameCtx &f, int addr, int lane, McRaw &R)
-{
-	const int k = lane >> 2, kc = blk_of((lane & 3), ((lane >> 2) & 7) >> 1);
-	R.rv = 0xffffffffu; R.y0 = R.y1 = R.c0 = R.c1 = 0;
-	if (!f.motion)
-		return;
-	gmotion_t mo = f.motion + addr;
-	R.rv = ((const gu32 *)mo)[lane & 3]; // refPic / refIdx: 16 bytes, uniform; vector load + readlane, not scalar memory (see mb_from_lanes)
-	R.y0 = *(const gu32 *)&mo->mvs[k * 2]; R.y1 = *(const gu32 *)&mo->mvs[32 + k * 2];
-	R.c0 = *(const gu32 *)&mo->mvs[kc * 2]; R.c1 = *(const gu32 *)&mo->mvs[32 + kc * 2];
-}
-__device__ __forceinline__ void mc_finish(const McRaw &R, int lane, McMotion &M)
-{
-	M.refs[0] = __builtin_amdgcn_readlane(R.rv, 0); M.refs[1] = __builtin_amdgcn_readlane(R.rv, 1);
-	M.refs[2] = __builtin_amdgcn_readlane(R.rv, 2); M.refs[3] = __builtin_amdgcn_readlane(R.rv, 3);
-	M.mvY[0] = R.y0; M.mvY[1] = R.y1; M.mvC[0] = R.c0; M.mvC[1] = R.c1;
-	// coarsest uniform granularity per list (the packet carries per-4x4 motion, not partitions)
-	int S = 0;
-#pragma unroll
-	for (int l = 0; l < 2; l++) {
-		const uint32_t mvp = M.mvY[l];
-		// first lane of each 8x8 quadrant through v_readlane (no LDS round trip as with __shfl)
-		const uint32_t q0 = __builtin_amdgcn_readlane(mvp, 0), q1 = __builtin_amdgcn_readlane(mvp, 16);
-		const uint32_t q2 = __builtin_amdgcn_readlane(mvp, 32), q3 = __builtin_amdgcn_readlane(mvp, 48);
-		const uint32_t mvq = lane < 32 ? (lane < 16 ? q0 : q1) : (lane < 48 ? q2 : q3);
-		// refPic is per 8x8 quadrant already: uniform iff the 4 bytes of refs[l] are equal
-		const bool pic_same = M.refs[l] == (M.refs[l] & 255) * 0x01010101u;
-		const bool u16 = pic_same && __all(mvp == q0);
-		const bool u8 = __all(mvp == mvq);
-		S |= (u16 ? 16 : u8 ? 8 : 4) << (8 * l);
-	}
-	M.S = __builtin_amdgcn_readfirstlane(S);
-}
-
-// geometry of the luma reference window this lane's block belongs to (list l)
-struct McGeom { int S, g, gx, gy, X0, Y0, pic, mx, my; };
-__device__ __forceinline__ McGeom mc_geom(const McMotion &M, int l, int lane, int mbx, int mby)
-{
-	McGeom G;
-	const int k = lane >> 2;
-	G.pic = ref_byte(M.refs[l], k >> 2);
-	const uint32_t mvp = M.mvY[l];
-	G.mx = (int)(int16_t)(mvp & 0xffff); G.my = (int)mvp >> 16;
-	G.S = (M.S >> (8 * l)) & 255;
-	const bool u16 = G.S == 16, u8 = G.S == 8;
-	G.g = u16 ? 0 : u8 ? k >> 2 : k;
-	G.gx = u16 ? 0 : u8 ? ((k >> 2) & 1) * 8 : BXf(k);
-	G.gy = u16 ? 0 : u8 ? (k >> 3) * 8 : BYf(k);
-	G.X0 = mbx * 16 + G.gx + (G.mx >> 2) - 2;
-	G.Y0 = mby * 16 + G.gy + (G.my >> 2) - 2;
-	return G;
-}
-
-// Fetch of the luma reference windows of one list: S = 16 (one 21-row window, 6 dwords wide), 8 (four
-// 13-row windows, 4 dwords) or 4 (sixteen 9-row windows, 3 dwords).  Each reference cache line is
-// requested once per window.  Out-of-frame samples: clamped row index, edge sample replicated over
-// whole dwords (frame width is a multiple of 16, window columns are dword aligned) == the reference's
-// edge emulation (edge264_inter.c:1199-1235).
-// ONE code path for the three window sizes (the geometry is uniform data, not a template): every load writes straight
-// into its McWindows register.  Three specialised paths merged through copies, and a copy of a register with a load in
-// flight is a wait: the phase profile showed a full memory round trip exposed here on every macroblock.  For the same
-// reason nothing is zeroed: a dword that is not fetched (rem >= per, unused reference) keeps a stale value that
-// mc_commit / mc_compute never look at (same predicates).
-__device__ __forceinline__ void mc_issue_luma(const FrameCtx &f, int lane, int S, int XA, int Y0, int pic, McWindows &Wn)
-{
-	const bool s16 = S == 16, s8 = S == 8;
-	const int nd = s16 ? 6 : s8 ? 4 : 3, per = (S + 5) * nd;       // dwords per row, per window
-	const int lg = s16 ? 6 : s8 ? 4 : 2, nit = s16 ? 2 : s8 ? 4 : 7; // log2(lanes per window), iterations
-	const int inv = s16 ? 171 : s8 ? 256 : 342;                      // rem / nd == rem * inv >> 10 for rem < 128 / 64 / 28
-	const int r0 = lane & ((1 << lg) - 1);
-	if (pic < 0)
-		return;
-	const gu8 *picp = (const gu8 *)f.dpb_lds[pic];
-#define E264_WIN_FETCH(it, dst) \
-	if (it < nit) { \
-		const int rem = (it << lg) + r0; \
-		if (rem < per) { \
-			const int row = (rem * inv) >> 10, dw = rem - row * nd; \
-			const gu8 *rowp = picp + (size_t)clip3i(0, f.H - 1, Y0 + row) * f.sY; \
-			const int x = XA + dw * 4; \
-			if (x >= 0 && x <= f.W - 4) dst = *(const gu32 *)(rowp + x); \
-			else dst = (uint32_t)rowp[x < 0 ? 0 : f.W - 1] * 0x01010101u; /* frame border: replicated edge sample (waits; rare) */ \
-		} \
-	}
-	E264_WIN_FETCH(0, Wn.y0) E264_WIN_FETCH(1, Wn.y1) E264_WIN_FETCH(2, Wn.y2) E264_WIN_FETCH(3, Wn.y3)
-	E264_WIN_FETCH(4, Wn.y4) E264_WIN_FETCH(5, Wn.y5) E264_WIN_FETCH(6, Wn.y6)
-#undef E264_WIN_FETCH
-}
-
-__device__ __forceinline__ void mc_issue(const FrameCtx &f, const McMotion &M, int l, int mbx, int mby, int lane, McWindows &Wn PH_PARAMS)
-{
-	const int cpl = lane >> 5, cy = (lane >> 2) & 7, cx = (lane & 3) * 2;
-	if (M.refs[l] == 0xffffffffu) // list unused by the whole macroblock (uniform): P macroblocks skip list 1
-		return;
-	McGeom G = mc_geom(M, l, lane, mbx, mby);
-	if (!(f.dbg & 256)) {
-		mc_issue_luma(f, lane, G.S, G.X0 & ~3, G.Y0, G.pic, Wn);
-	}
-	PH(11);
-	// chroma: the 3x2 samples around this lane's two outputs (8.4.2.2.2)
-	const int kc = blk_of(cx >> 1, cy >> 1);
-	const int picc = ref_byte(M.refs[l], kc >> 2);
-	if (picc >= 0 && !(f.dbg & 512)) {
-		const int mx = (int)(int16_t)(M.mvC[l] & 0xffff), my = (int)M.mvC[l] >> 16;
-		const gu8 *rp = plane_base(f, (gu8 *)f.dpb_lds[picc], 1 + cpl);
-		const int X = mbx * 8 + cx + (mx >> 3), Y = mby * 8 + cy + (my >> 3);
-		const int Wc = f.W >> 1, Hc = f.H >> 1;
-		const gu8 *r0 = rp + (size_t)clip3i(0, Hc - 1, Y) * f.sC, *r1 = rp + (size_t)clip3i(0, Hc - 1, Y + 1) * f.sC;
-		if (X >= 0 && X + 3 < Wc) { // the three columns as one unaligned dword per row
-			Wn.ca = *(const gu32u *)(r0 + X); Wn.cb = *(const gu32u *)(r1 + X);
-		} else { // frame border: per-sample clamp == the reference's edge emulation (rare: may wait for its loads)
-			const int x0 = clip3i(0, Wc - 1, X), x1 = clip3i(0, Wc - 1, X + 1), x2 = clip3i(0, Wc - 1, X + 2);
-			Wn.ca = (uint32_t)r0[x0] | (uint32_t)r0[x1] << 8 | (uint32_t)r0[x2] << 16;
-			Wn.cb = (uint32_t)r1[x0] | (uint32_t)r1[x1] << 8 | (uint32_t)r1[x2] << 16;
-		}
-	}
-}
-
-__device__ __forceinline__ void chroma_taps(const McWindows &Wn, int cc[6])
-{
-	cc[0] = Wn.ca & 255; cc[1] = Wn.ca >> 8 & 255; cc[2] = Wn.ca >> 16 & 255;
-	cc[3] = Wn.cb & 255; cc[4] = Wn.cb >> 8 & 255; cc[5] = Wn.cb >> 16 & 255;
-}
-
-// registers -> LDS window (the S of the list is recomputed: cheap and uniform)
-__device__ __forceinline__ void mc_commit(WaveLds &L, const McMotion &M, int l, const McWindows &Wn, int mbx, int mby, int lane)
-{
-	if (M.refs[l] == 0xffffffffu)
-		return;
-	const int S = (M.S >> (8 * l)) & 255;
-	// same lane -> dword mapping as mc_issue_luma: window g = lane / LPW, dword it * LPW + lane % LPW
-	const int lpw = S == 16 ? 64 : S == 8 ? 16 : 4, per = S == 16 ? 126 : S == 8 ? 52 : 27;
-	const int base = (lane / lpw) * per, r0 = lane & (lpw - 1);
-	if (r0 < per) L.win[base + r0] = Wn.y0;
-	if (lpw + r0 < per) L.win[base + lpw + r0] = Wn.y1;
-	if (2 * lpw + r0 < per) L.win[base + 2 * lpw + r0] = Wn.y2;
-	if (3 * lpw + r0 < per) L.win[base + 3 * lpw + r0] = Wn.y3;
-	if (S == 4) { // 27 dwords per window, 4 lanes per window: iterations 4..6
-		L.win[base + 16 + r0] = Wn.y4;
-		L.win[base + 20 + r0] = Wn.y5;
-		if (24 + r0 < 27) L.win[base + 24 + r0] = Wn.y6;
-	}
-}
-
-// filters + weights of one list of one macroblock from the LDS window / chroma registers
-__device__ __forceinline__ void mc_compute(WaveLds &L, const FrameCtx &f, const SliceW *s, const McMotion &M, int l, const int cc[6],
-	int mbx, int mby, int lane, int outY[4], int outC[2])
-{
-	const int k = lane >> 2, r = lane & 3;
-	const int cpl = lane >> 5, cy = (lane >> 2) & 7, cx = (lane & 3) * 2;
-	const int kc = blk_of(cx >> 1, cy >> 1);
-	if (M.refs[l] == 0xffffffffu)
-		return;
-	const int idc = __builtin_amdgcn_readfirstlane(L.ws_idc); // slice_cache ran at the top of the iteration
-	McGeom G = mc_geom(M, l, lane, mbx, mby);
-	if (G.pic >= 0 && !(f.dbg & 256)) {
-		const int nd = G.S == 16 ? 6 : G.S == 8 ? 4 : 3, per = (G.S + 5) * nd;
-		const int o = (G.X0 & 3) + (BXf(k) - G.gx);
-		const int base = G.g * per + (BYf(k) - G.gy + r) * nd + (o >> 2);
-		const uint32_t sh = (uint32_t)(o & 3);
-		uint32_t d[6][3];
-#pragma unroll
-		for (int rr = 0; rr < 6; rr++) {
-			uint32_t w0 = L.win[base + rr * nd], w1 = L.win[base + rr * nd + 1], w2 = L.win[base + rr * nd + 2];
-			d[rr][0] = __builtin_amdgcn_alignbyte(w1, w0, sh);
-			d[rr][1] = __builtin_amdgcn_alignbyte(w2, w1, sh);
-			d[rr][2] = w2 >> (sh * 8);
-		}
-		int p[4];
-		luma_from_rows(d, G.mx & 3, G.my & 3, p);
-		const int refIdxX = ref_byte(M.refs[2 + (l ^ 1)], k >> 2);
-		if (idc == 0 && !(l == 1 && refIdxX >= 0)) {
-#pragma unroll
-			for (int i = 0; i < 4; i++) outY[i] = p[i];
-		} else {
-			Wod wY, wCb, wCr;
-			select_weights(s, l, ref_byte(M.refs[2 + l], k >> 2), refIdxX, wY, wCb, wCr);
-#pragma unroll
-			for (int i = 0; i < 4; i++) outY[i] = wpred(outY[i], p[i], wY);
-		}
-	}
-	const int picc = ref_byte(M.refs[l], kc >> 2);
-	if (picc >= 0 && !(f.dbg & 512)) {
-		const int mx = (int)(int16_t)(M.mvC[l] & 0xffff), my = (int)M.mvC[l] >> 16;
-		const int xF = mx & 7, yF = my & 7;
-		const int A = (8 - xF) * (8 - yF), B = xF * (8 - yF), C = (8 - xF) * yF, D = xF * yF;
-		const int p0 = (A * cc[0] + B * cc[1] + C * cc[3] + D * cc[4] + 32) >> 6;
-		const int p1 = (A * cc[1] + B * cc[2] + C * cc[4] + D * cc[5] + 32) >> 6;
-		const int refIdxX = ref_byte(M.refs[2 + (l ^ 1)], kc >> 2);
-		if (idc == 0 && !(l == 1 && refIdxX >= 0)) {
-			outC[0] = p0; outC[1] = p1;
-		} else {
-			Wod wY, wC[2];
-			select_weights(s, l, ref_byte(M.refs[2 + l], kc >> 2), refIdxX, wY, wC[0], wC[1]);
-			outC[0] = wpred(outC[0], p0, cpl ? wC[1] : wC[0]);
-			outC[1] = wpred(outC[1], p1, cpl ? wC[1] : wC[0]);
-		}
-	}
-}
-
-// stage C of one macroblock of the strip: everything that is not intra prediction
-__device__ __forceinline__ bool mbpar_mb(WaveLds &L, const SliceW *s, StripOut &O, int slot, const FrameCtx &f, const MbInfo &m, const McMotion &M, const int cc[6], const McWindows &W1,
-	int mbx, int mby, int lane PH_PARAMS)
-{ // returns true when the macroblock's samples were staged in O.y/O.c[slot]
-	if (m.kind != E264_MB_INTER && m.kind != E264_MB_PCM)
-		return false;
-	const gu8 *pl = f.payload + m.payload_off;
-	const int k = lane >> 2, r = lane & 3;
-	const int X = BXf(k), Yr = BYf(k) + r;
-	const int cpl = lane >> 5, cy = (lane >> 2) & 7, cx = (lane & 3) * 2;
-	uint16_t *oc = (uint16_t *)O.c[slot] + cpl * 32 + cy * 4 + (cx >> 1);
-	if (m.kind == E264_MB_PCM) { // edge264_slice.c:914-935
-		O.y[slot][Yr * 4 + (X >> 2)] = *(const gu32 *)(pl + Yr * 16 + X);
-		*oc = *(const gu16 *)(pl + 256 + cpl * 64 + cy * 8 + cx);
-		return true;
-	}
-#ifdef E264_ABL_NORES
-	const bool has_res = false;
-#else
-	const bool has_res = m.coded != 0 && !(f.dbg & 1024); // uniform; most inter macroblocks carry no residual
-#endif
-	if (has_res) compute_residual(L, f, m, lane); // payload already in L.coef (committed at the top of the iteration)
-	PH(5);
-	int pY[4] = {0, 0, 0, 0}, pC[2] = {0, 0};
-	mc_compute(L, f, s, M, 0, cc, mbx, mby, lane, pY, pC); // list 0: window already in LDS (prefetched)
-	PH(6);
-#ifndef E264_ABL_NOL1
-	if (M.refs[1] != 0xffffffffu) { // list 1 (B macroblocks): its windows were prefetched with list 0's; same LDS area, second turn
-		wave_sync();
-		mc_commit(L, M, 1, W1, mbx, mby, lane);
-		wave_sync();
-		int c1[6];
-		chroma_taps(W1, c1);
-		mc_compute(L, f, s, M, 1, c1, mbx, mby, lane, pY, pC);
-	}
-#endif
-	PH(7);
-	if (has_res) { // add residual, clip (int16 wrap add then packus: residual.c:160-171)
-		const int16_t *rr = L.res + Yr * 16 + X;
-		const int16_t *rc = L.res + 256 + cpl * 64 + cy * 8 + cx;
-#pragma unroll
-		for (int i = 0; i < 4; i++) pY[i] = clip255(w16(pY[i] + rr[i]));
-		pC[0] = clip255(w16(pC[0] + rc[0])); pC[1] = clip255(w16(pC[1] + rc[1]));
-	}
-	// the predictions are already within 0..255
-	O.y[slot][Yr * 4 + (X >> 2)] = (uint32_t)pY[0] | (uint32_t)pY[1] << 8 | (uint32_t)pY[2] << 16 | (uint32_t)pY[3] << 24;
-	*oc = (uint16_t)(pC[0] | pC[1] << 8);
-	return true;
-}
-
-// end of a strip: staged macroblocks (bit i of `mask`) -> frame, 16 bytes per lane
-__device__ __forceinline__ void strip_flush(const StripOut &O, const FrameCtx &f, int mbx0, int mby0, uint32_t mask, int lane)
-{
-	if (!mask || (f.dbg & 4096))
-		return;
-#pragma unroll
-	for (int g = 0; g < E264_MBPAR_STRIP / 8; g++) {
-		const int mb = g * 8 + (lane & 7);
-		int x = mbx0 + mb, y = mby0;
-		while (x >= f.wm) { x -= f.wm; y++; }
-		if (!(mask >> mb & 1))
-			continue;
-		gu8 *Yb = f.cur + (size_t)(y * 16) * f.sY + x * 16;
-#pragma unroll
-		for (int it = 0; it < 2; it++) {
-			const int row = it * 8 + (lane >> 3);
-			const v4u v = *(const v4u *)&O.y[mb][row * 4];
-			*(gv4u *)(Yb + (size_t)row * f.sY) = v;
-		}
-#pragma unroll
-		for (int it = 0; it < 2; it++) { // it = plane
-			const int row = lane >> 3;
-			const v2u v = *(const v2u *)&O.c[mb][it * 16 + row * 2];
-			*(gv2u *)(plane_base(f, f.cur, 1 + it) + (size_t)(y * 8 + row) * f.sC + x * 8) = v;
-		}
-	}
-}
-
-// ---------------------------------------------------------------------------------
 // intra prediction (modes: edge264_internal.h:564-634; U(navailable) suffixes A left, B top,
 // C top-right, D top-left)
 // ---------------------------------------------------------------------------------
@@ -1401,83 +804,6 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const Mb
 	*(gu32 *)dY = outw;
 	const int16_t *rc = L.res + 256 + cpl * 64 + cy * 8 + cx;
 	*(gu16 *)dC = (uint16_t)(clip255(w16(pC[0] + rc[0])) | clip255(w16(pC[1] + rc[1])) << 8);
-}
-
-// ---------------------------------------------------------------------------------
-// deblocking of one macroblock by one wave
-// ---------------------------------------------------------------------------------
-struct BlkMo { int ref0, ref1, mv0x, mv0y, mv1x, mv1y; };
-// motion of 4x4 block k of macroblock m; BRANCH-FREE loads (the motion array is dense, so the record of a
-// non-inter macroblock can be read and then ignored): the loads of several macroblocks can be in flight together
-__device__ __forceinline__ BlkMo blk_motion(const FrameCtx &f, cmb_t m, int kind, int k)
-{
-	BlkMo o = {-1, -1, 0, 0, 0, 0};
-	if (f.motion) { // uniform
-		gmotion_t mo = f.motion + (m - f.mbs);
-		const int r0 = mo->refPic[k >> 2], r1 = mo->refPic[4 + (k >> 2)];
-		const uint32_t v0 = *(const gu32 *)&mo->mvs[k * 2], v1 = *(const gu32 *)&mo->mvs[32 + k * 2];
-		const bool inter = kind == E264_MB_INTER;
-		o.ref0 = inter ? r0 : -1; o.ref1 = inter ? r1 : -1;
-		o.mv0x = inter ? (int)(int16_t)(v0 & 0xffff) : 0; o.mv0y = inter ? (int)v0 >> 16 : 0;
-		o.mv1x = inter ? (int)(int16_t)(v1 & 0xffff) : 0; o.mv1y = inter ? (int)v1 >> 16 : 0;
-	}
-	return o;
-}
-__device__ __forceinline__ int far4(int ax, int ay, int bx, int by) { return (abs(ax - bx) >= 4) | (abs(ay - by) >= 4); }
-
-__device__ __forceinline__ int mb_bs_lane(const FrameCtx &f, cmb_t m, int lane)
-{ // lane -> (dir, edge, segment); edge264_deblock.c:958-1118.  No early exits: every load is unconditional.
-	const int dir = lane >> 4 & 1, e = lane >> 2 & 3, sg = lane & 3;
-	const uint32_t hdr = *(const gu32 *)m; // kind, flags, qp0, qp1
-	const int kind = hdr & 255, flags = hdr >> 8 & 255;
-	const bool intra = kind != E264_MB_INTER;
-	const bool has_edge = e != 0 || (flags & (dir ? E264_MBF_EDGE_TOP : E264_MBF_EDGE_LEFT));
-	// the neighbour record is addressed from the lane's role alone (index clamped into the array), NOT from the
-	// flags just loaded: all loads of the macroblock then form a single round trip; has_edge gates the result
-	const int mi = (int)(m - f.mbs);
-	cmb_t n = e == 0 ? f.mbs + max(mi - (dir ? f.wm : 1), 0) : m;
-	const int nkind = n->kind;
-	const int kq = dir ? blk_of(sg, e) : blk_of(e, sg);
-	const int kp = dir ? blk_of(sg, (e + 3) & 3) : blk_of((e + 3) & 3, sg);
-	const int coded = (n->nz_mask >> kp & 1) | (m->nz_mask >> kq & 1);
-	BlkMo p = blk_motion(f, n, nkind, kp), q = blk_motion(f, m, kind, kq);
-	int refs_p = (p.ref0 != q.ref0) | (p.ref1 != q.ref1);
-	int refs_c = (p.ref0 != q.ref1) | (p.ref1 != q.ref0);
-	int mvs_p = far4(p.mv0x, p.mv0y, q.mv0x, q.mv0y) | far4(p.mv1x, p.mv1y, q.mv1x, q.mv1y);
-	int mvs_c = far4(p.mv0x, p.mv0y, q.mv1x, q.mv1y) | far4(p.mv1x, p.mv1y, q.mv0x, q.mv0y);
-	const int bmo = (refs_p | mvs_p) & (refs_c | mvs_c);
-	const bool skip8 = e != 0 && (flags & E264_MBF_T8x8) && (e & 1);
-	int bs = coded ? 2 : bmo;
-	bs = intra ? 3 : bs;
-	bs = (e == 0 && (intra || nkind != E264_MB_INTER)) ? 4 : bs;
-	return (!has_edge || skip8) ? 0 : bs;
-}
-
-// ---------------------------------------------------------------------------------
-// deblocking parameters of one macroblock (mbpar kernel): E264_DBK_BYTES = 64 per MB
-//   [0..31]  bS[dir][edge][segment]
-//   [32..40] alpha[plane*3 + t], t = 0 internal edges, 1 left MB edge, 2 top MB edge
-//   [41..49] beta, [50..58] indexA (tC0 lookup)          edge264_deblock.c:945-955
-// ---------------------------------------------------------------------------------
-// alpha / beta / indexA bytes (record bytes 32..58) of macroblock m
-__device__ __forceinline__ int dbk_ab_lane(const FrameCtx &f, cmb_t m, int lane)
-{
-	const uint32_t hdr = *(const gu32 *)m;
-	const int flags = hdr >> 8 & 255;
-	cslice_t s = f.slices + m->dbk_slice;
-	int idx = lane - 32, what = idx / 9, pt = idx % 9, pl = pt / 3, t = pt % 3;
-	const int mi = (int)(m - f.mbs);
-	cmb_t nb = t == 0 ? m : f.mbs + max(mi - (t == 2 ? f.wm : 1), 0); // addressed without waiting for the flags
-	const int qn = nb->qp[pl], qm = m->qp[pl];
-	const bool use_nb = (t == 1 && (flags & E264_MBF_EDGE_LEFT)) || (t == 2 && (flags & E264_MBF_EDGE_TOP));
-	int qPav = (qm + (use_nb ? qn : qm) + 1) >> 1;
-	int iA = clip3i(0, 51, qPav + s->FilterOffsetA), iB = clip3i(0, 51, qPav + s->FilterOffsetB);
-	return what == 0 ? c_alpha[iA] : what == 1 ? c_beta[iB] : iA;
-}
-__device__ __forceinline__ bool mb_deblocked(cmb_t m)
-{
-	const uint32_t hdr = *(const gu32 *)m;
-	return (hdr >> 8 & E264_MBF_DEBLOCK) && (hdr & 255) != E264_MB_ABSENT;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1888,148 +1214,6 @@ static __device__ __forceinline__ void xcd_tile(int &bx, int &by)
 	bx = (int)(v - (unsigned)by * gx);
 }
 
-// every macroblock of every frame in parallel: 4 waves per workgroup, a strip of E264_MBPAR_STRIP
-// consecutive macroblocks per wave, software pipelined (see "Inter prediction" above)
-#ifdef E264_MBPAR_WAVES_PER_EU
-__attribute__((amdgpu_waves_per_eu(E264_MBPAR_WAVES_PER_EU, E264_MBPAR_WAVES_PER_EU)))
-#endif
-__global__ __launch_bounds__(256) void e264_mbpar_kernel(const E264Job *jobs, int mode)
-{
-	__shared__ WaveLds lds[4];
-	__shared__ SliceW slicew[4];
-	__shared__ StripOut outs[4];
-	__shared__ generic_u8p dpbtab[E264_MAX_SLOTS];
-	const int lane = lane_id();
-	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	FrameCtx f;
-	int bx, by;
-	xcd_tile(bx, by);
-	if (!open_frame(f, jobs[by]))
-		return;
-	if (threadIdx.x < E264_MAX_SLOTS)
-		dpbtab[threadIdx.x] = f.dpb[threadIdx.x];
-	__syncthreads();
-	f.dpb_lds = dpbtab;
-	f.dbg = mode;
-	const int n_mbs = f.wm * f.hm;
-	const int base = (bx * 4 + wave) * E264_MBPAR_STRIP;
-	const int n = min(E264_MBPAR_STRIP, n_mbs - base);
-	if (n <= 0)
-		return;
-	WaveLds &L = lds[wave];
-	if (lane == 0) L.ws_slice = -1;
-	wave_sync();
-	const bool recon = mode & 1;
-	// headers of the strip: 8 records x 8 dwords, one dword per lane
-	const gu32 *mbs_g = (const gu32 *)(f.payload - f.h->payload_off + f.h->mbs_off);
-	McRaw raw;
-	mc_issue_raw(f, base, lane, raw); // the first macroblock's motion travels with the headers (its address does not depend on them)
-	uint32_t hvs[E264_MBPAR_STRIP / 8];
-#pragma unroll
-	for (int g = 0; g < E264_MBPAR_STRIP / 8; g++)
-		hvs[g] = g * 8 + (lane >> 3) < n ? mbs_g[(size_t)(base + g * 8) * 8 + lane] : 0;
-	{ // nothing for this kernel in the strip (all intra / absent: every strip of an I frame)? leave at once
-		bool mine = false;
-#pragma unroll
-		for (int g = 0; g < E264_MBPAR_STRIP / 8; g++) {
-			const int kind = hvs[g] & 255;
-			mine |= (lane & 7) == 0 && g * 8 + (lane >> 3) < n && (kind == E264_MB_INTER || kind == E264_MB_PCM);
-		}
-		if (!__any(mine))
-			return;
-	}
-	auto hv_sel = [&](int i) { // header dwords of the group of 8 that holds macroblock i of the strip (i uniform)
-		uint32_t v = hvs[0];
-#pragma unroll
-		for (int g = 1; g < E264_MBPAR_STRIP / 8; g++)
-			v = (i >> 3) == g ? hvs[g] : v;
-		return v;
-	};
-#define HV(i) hv_sel(i)
-	MbInfo h0 = mb_from_lanes(HV(0), 0);
-	// Software pipeline.  ONE register set per stage and no register-to-register hand-over of values that are
-	// still being loaded (a copy is a use, a use is a wait):
-	//   raw : motion loads of macroblock i+2, consumed by mc_finish at the top of the next iteration
-	//   m1  : finished motion of macroblock i+1 (drives the window loads issued in iteration i)
-	//   w   : reference windows / chroma taps of macroblock i+1, loaded during iteration i, committed to LDS
-	//         (luma) and copied out (chroma taps cc) at the top of iteration i+1
-	McMotion m0, m1;
-	//   pf  : payload (coefficients) of macroblock i+1, loaded during iteration i, committed to LDS at the top of i+1
-	CoefPf pf = {0, 0, 0, 0};
-	if (recon && h0.kind == E264_MB_INTER) coef_issue(f, h0, lane, pf);
-	McWindows w, wb, wbc; // wb: list-1 windows of macroblock i+1 in flight; wbc: those of macroblock i (copied once they arrived)
-	wb.y0 = wb.y1 = wb.y2 = wb.y3 = wb.y4 = wb.y5 = wb.y6 = wb.ca = wb.cb = 0; wbc = wb;
-	int cc[6] = {0, 0, 0, 0, 0, 0};
-	mc_finish(raw, lane, m0);
-	m1 = m0;
-	if (n > 1) mc_issue_raw(f, base + 1, lane, raw);
-	int mby = base / f.wm, mbx = base - mby * f.wm;
-	const int mbx0 = mbx, mby0 = mby;
-	StripOut &O = outs[wave];
-	uint32_t staged = 0;
-	PH_DECL;
-	if (recon && h0.kind == E264_MB_INTER) {
-		mc_issue(f, m0, 0, mbx, mby, lane, w PH_ARGS);
-#ifndef E264_ABL_NOL1
-		mc_issue(f, m0, 1, mbx, mby, lane, wb PH_ARGS);
-#endif
-	}
-	PH(0);
-#pragma unroll 1
-	for (int i = 0; i < n; i++) {
-		int nx = mbx + 1, ny = mby;
-		if (nx == f.wm) { nx = 0; ny++; }
-		// every load of the previous iteration is consumed first (the compiler's vmcnt bookkeeping collapses to
-		// vmcnt(0) across these branches: a load issued before this point would be waited for at once) ...
-		// Every load issued one iteration ago is consumed right here, so say so: after an explicit vmcnt(0) the compiler knows
-		// that no load is pending on the prefetch registers.  Without it, it cannot prove that across the back edge and puts
-		// s_waitcnt vmcnt(0) in front of every later (re)initialisation of such a register -- i.e. right AFTER the next
-		// stage's loads have been issued, exposing a full memory round trip twice per macroblock (phase profile: 39% of the
-		// kernel's wave-time sat in those two waits).
-		__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only (expcnt / lgkmcnt unconstrained)
-		if (i + 1 < n) mc_finish(raw, lane, m1);             // motion of macroblock i+1 (loads issued one iteration ago)
-		PH(1);
-		if (recon && (h0.kind == E264_MB_INTER)) {
-			slice_cache(L, f, h0.slice, lane, &slicew[wave]);
-			coef_commit(L, h0, lane, pf);
-		}
-		if (recon && h0.kind == E264_MB_INTER && !(mode & 8192)) { // 8192: profiling ablation, windows are loaded but never consumed
-			mc_commit(L, m0, 0, w, mbx, mby, lane);
-			chroma_taps(w, cc);
-#ifndef E264_ABL_NOL1
-			if (m0.refs[1] != 0xffffffffu) wbc = wb; // list 1 in use (uniform): take over the prefetched registers (they have arrived with list 0's)
-#endif
-		}
-		PH(2);
-		wave_sync();
-		PH(3);
-		// ... then the loads of the next stages go out, with the whole reconstruction of macroblock i to hide them
-		if (i + 2 < n) mc_issue_raw(f, base + i + 2, lane, raw);
-		PH(12);
-		const int i1 = min(i + 1, n - 1);
-		const MbInfo h1 = mb_from_lanes(HV(i1), i1 & 7);
-		PH(13);
-		if (recon && i + 1 < n && h1.kind == E264_MB_INTER) coef_issue(f, h1, lane, pf);
-		PH(10);
-		if (recon && i + 1 < n && h1.kind == E264_MB_INTER) {
-			mc_issue(f, m1, 0, nx, ny, lane, w PH_ARGS);
-#ifndef E264_ABL_NOL1
-			mc_issue(f, m1, 1, nx, ny, lane, wb PH_ARGS);
-#endif
-		}
-		PH(4);
-		if (recon && mbpar_mb(L, &slicew[wave], O, i, f, h0, m0, cc, wbc, mbx, mby, lane PH_ARGS))
-			staged |= 1u << i;
-		wave_sync();
-		PH(8);
-		h0 = h1; m0 = m1;
-		mbx = nx; mby = ny;
-	}
-	strip_flush(O, f, mbx0, mby0, staged, lane);
-	PH(9);
-	PH_FLUSH(lane);
-}
-
 // Inter prediction + residual of every inter / PCM macroblock: one workgroup per tile of 16 x 8 macroblocks, one thread
 // per 8x8 block; the phases are in e264_pred.h (and run on the host by tests/emu).
 #ifndef E264_PRED_WAVES_PER_EU
@@ -2050,18 +1234,8 @@ __attribute__((amdgpu_waves_per_eu(E264_PRED_WAVES_PER_EU, E264_PRED_WAVES_PER_E
 	const PredTile t = {(bx % ntx) * PT_W, (bx / ntx) * PT_H};
 	PH_DECL;
 	pred_phase_setup(L, f, t, tid);
-	// mode bit 17: the deblocking parameters of the tile ride along (one launch less).  Off by default: measured 1.81 ms for the
-	// combined kernel against 1.46 + 0.28 ms for the two launches (two more barriers per tile at this kernel's occupancy).
-	const bool with_dbk = (mode & 2) && (mode & 131072) && f.dbk;
-	if (with_dbk) pred_phase_dbk_load(L, f, t, tid);
 	PH(0);
 	__syncthreads();
-	if (with_dbk) {
-		pred_phase_dbk_compute(L, f, t, tid);
-		__syncthreads();
-		pred_phase_dbk_store(L, f, t, tid);
-		__syncthreads(); // the sample area is free again
-	}
 	{ // nothing more for this kernel in the tile (every tile of an I frame)? leave at once
 		const int kind = tid < PT_MBS ? (int)(L.hdr[tid][0] & 255) : 0;
 		if (!__syncthreads_or(kind == E264_MB_INTER || kind == E264_MB_PCM))
@@ -2119,47 +1293,6 @@ __global__ __launch_bounds__(DP_NT) void e264_dbkparam2_kernel(const E264Job *jo
 	dbkp_phase_compute(L, f, a0, tid);
 	__syncthreads();
 	dbkp_phase_store(L, f, a0, tid);
-}
-
-// deblocking parameters (bS, alpha, beta, indexA) of every macroblock: one wave per macroblock, few
-// registers, all loads independent -> latency hidden by occupancy.  Runs concurrently with nothing
-// it depends on: only the command packet is read.
-__global__ __launch_bounds__(256) void e264_dbkparam_kernel(const E264Job *jobs)
-{
-	const int lane = lane_id();
-	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	FrameCtx f;
-	int bx, by;
-	xcd_tile(bx, by);
-	if (!open_frame(f, jobs[by]) || !f.dbk)
-		return;
-	const int n_mbs = f.wm * f.hm;
-	// 4 macroblocks per wave, TWO per instruction: lanes 0..31 serve macroblock 2*it, lanes 32..63 macroblock
-	// 2*it+1 -- first the 32 bS bytes of each, then the 27 alpha/beta/indexA bytes.  All loads are issued
-	// before the stores (independent, they overlap).
-	const int a0 = (bx * 4 + wave) * 4;
-	const int hl = lane & 31, hi = lane >> 5;
-	int bs[2], ab[2];
-#pragma unroll
-	for (int it = 0; it < 2; it++) {
-		cmb_t m = f.mbs + min(a0 + 2 * it + hi, n_mbs - 1);
-		const int v = mb_bs_lane(f, m, hl);
-		bs[it] = mb_deblocked(m) ? v : 0;
-	}
-#pragma unroll
-	for (int it = 0; it < 2; it++) {
-		cmb_t m = f.mbs + min(a0 + 2 * it + hi, n_mbs - 1);
-		const int v = hl < 27 ? dbk_ab_lane(f, m, 32 + hl) : 0;
-		ab[it] = mb_deblocked(m) ? v : 0;
-	}
-#pragma unroll
-	for (int it = 0; it < 2; it++) {
-		const int addr = a0 + 2 * it + hi;
-		if (addr < n_mbs) {
-			f.dbk[(size_t)addr * E264_DBK_BYTES + hl] = (uint8_t)bs[it];
-			f.dbk[(size_t)addr * E264_DBK_BYTES + 32 + hl] = (uint8_t)ab[it];
-		}
-	}
 }
 
 template <int NW>
@@ -2359,14 +1492,10 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 	};
 	if (side) {
 		if (!side_late) launch_side();
-	} else if (dbkp && (mode & 32768)) // debug mode bit 15: round 1's per-lane-load parameter kernel (A/B timing only)
-		hipLaunchKernelGGL(e264_dbkparam_kernel, dim3((max_mbs + 15) / 16, n_jobs), dim3(256), 0, stream, jobs);
-	else if (dbkp && !((mode & 1) && (mode & 131072) && !(mode & 16384))) // (mode bit 17: the prediction kernel computes the parameters of its tiles itself)
+	} else if (dbkp) // (mode bit 17: the prediction kernel computes the parameters of its tiles itself)
 		hipLaunchKernelGGL(e264_dbkparam2_kernel, dim3((max_mbs + DP_MBS - 1) / DP_MBS, n_jobs), dim3(DP_NT), 0, stream, jobs);
 	if (marks) hipEventRecord(marks[1], stream);
-	if (mode & 16384) // debug mode bit 14: round 1's strip-per-wave kernel (A/B timing only)
-		hipLaunchKernelGGL(e264_mbpar_kernel, dim3((max_mbs + 4 * E264_MBPAR_STRIP - 1) / (4 * E264_MBPAR_STRIP), n_jobs), dim3(256), 0, stream, jobs, mode);
-	else if (mode & 1)
+	if (mode & 1)
 		hipLaunchKernelGGL(e264_pred_kernel, dim3(max_tiles, n_jobs), dim3(PT_NT), 0, stream, jobs, mode);
 	if (marks) hipEventRecord(marks[2], stream);
 	if (side_late) launch_side();

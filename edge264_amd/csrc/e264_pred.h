@@ -33,7 +33,6 @@
 #ifndef E264_PRED_H
 #define E264_PRED_H
 #include "e264_dev.h"
-#include "e264_dbkp.h"
 
 namespace {
 
@@ -63,81 +62,6 @@ struct __attribute__((aligned(16))) PredLds {
 };
 
 struct PredTile { int tx0, ty0; };     // first macroblock of the tile
-
-// The deblocking parameters of the tile's macroblocks (e264_dbkp.h) are computed by this kernel too when a submission runs
-// reconstruction AND deblocking: one launch less, and the packet's motion records cross the memory system once.  The records
-// live in the tile's sample area, which nobody has written yet at that point.
-struct __attribute__((aligned(16))) PredDbkScratch {
-	uint32_t mo[PT_MBS][36];     // E264Motion of the tile's macroblocks
-	uint32_t htop[PT_W][8];      // E264Mb / E264Motion of the row above the tile ...
-	uint32_t mtop[PT_W][36];
-	uint32_t hleft[PT_H][8];     // ... and of the column left of it
-	uint32_t mleft[PT_H][36];
-	uint32_t out[PT_MBS][16];    // parameter records
-	int8_t fo[PT_MBS][2];        // FilterOffsetA / B
-	uint8_t alpha[52], beta[52];
-};
-static_assert(sizeof(PredDbkScratch) <= sizeof(((PredLds *)0)->y), "the parameter scratch borrows the luma tile");
-E264_DEV PredDbkScratch &pred_dbk_scratch(PredLds &L) { return *(PredDbkScratch *)&L.y[0][0]; }
-
-// loads only: motion of the tile, records of the halo, slice offsets, the two tables (runs with pred_phase_setup, before the first barrier)
-E264_DEV void pred_phase_dbk_load(PredLds &L, const FrameCtx &f, const PredTile &t, int tid)
-{
-	PredDbkScratch &D = pred_dbk_scratch(L);
-	const gu8 *mbs_g = f.payload - f.h->payload_off + f.h->mbs_off;
-	const gu8 *mo_g = (const gu8 *)f.motion;
-	if (mo_g)
-		for (int i = tid; i < PT_MBS * 9; i += PT_NT) {
-			const int mb = i / 9, part = i - mb * 9, mbx = t.tx0 + (mb & (PT_W - 1)), mby = t.ty0 + mb / PT_W;
-			if (mbx < f.wm && mby < f.hm)
-				*(v4u *)&D.mo[mb][part * 4] = *(const gv4u *)(mo_g + (size_t)(mby * f.wm + mbx) * 144 + part * 16);
-		}
-	for (int i = tid; i < (PT_W + PT_H) * 11; i += PT_NT) { // halo: 11 pieces of 16 bytes per macroblock (2 header, 9 motion)
-		const int k = i / 11, part = i - k * 11;
-		const bool top = k < PT_W;
-		const int mbx = top ? t.tx0 + k : t.tx0 - 1, mby = top ? t.ty0 - 1 : t.ty0 + (k - PT_W);
-		if (mbx < 0 || mby < 0 || mbx >= f.wm || mby >= f.hm)
-			continue;
-		const size_t a = (size_t)(mby * f.wm + mbx);
-		if (part < 2) *(v4u *)(top ? &D.htop[k][part * 4] : &D.hleft[k - PT_W][part * 4]) = *(const gv4u *)(mbs_g + a * 32 + part * 16);
-		else if (mo_g) *(v4u *)(top ? &D.mtop[k][(part - 2) * 4] : &D.mleft[k - PT_W][(part - 2) * 4]) = *(const gv4u *)(mo_g + a * 144 + (part - 2) * 16);
-	}
-	if (tid < PT_MBS) {
-		const int mbx = t.tx0 + (tid & (PT_W - 1)), mby = t.ty0 + tid / PT_W;
-		if (mbx < f.wm && mby < f.hm) {
-			const uint32_t w7 = ((const gu32 *)mbs_g)[(size_t)(mby * f.wm + mbx) * 8 + 7]; // E264Mb.dbk_slice
-			cslice_t s = f.slices + (w7 & 0xffff);
-			D.fo[tid][0] = s->FilterOffsetA; D.fo[tid][1] = s->FilterOffsetB;
-		}
-	} else if (tid < PT_MBS + 52) {
-		D.alpha[tid - PT_MBS] = c_alpha[tid - PT_MBS]; D.beta[tid - PT_MBS] = c_beta[tid - PT_MBS];
-	}
-}
-E264_DEV void pred_phase_dbk_compute(PredLds &L, const FrameCtx &f, const PredTile &t, int tid)
-{
-	PredDbkScratch &D = pred_dbk_scratch(L);
-	const bool has_motion = f.motion != nullptr;
-	uint8_t *out8 = (uint8_t *)&D.out[0][0];
-	for (int it = 0; it < PT_MBS * 32 / PT_NT; it++) {
-		const int id = it * PT_NT + tid, mb = id >> 5, hl = id & 31;
-		const int c = mb & (PT_W - 1), r = mb / PT_W;
-		const uint32_t *hm = L.hdr[mb], *mm = D.mo[mb];
-		const uint32_t *hL = c ? L.hdr[mb - 1] : D.hleft[r], *mL = c ? D.mo[mb - 1] : D.mleft[r];
-		const uint32_t *hT = r ? L.hdr[mb - PT_W] : D.htop[c], *mT = r ? D.mo[mb - PT_W] : D.mtop[c];
-		const uint32_t h0 = hm[0]; // 0 (ABSENT) for macroblocks outside the frame
-		const bool on = (h0 >> 8 & E264_MBF_DEBLOCK) && (h0 & 255) != E264_MB_ABSENT;
-		out8[mb * 64 + hl] = (uint8_t)dbkp_bs_value(hm, mm, hL, mL, hT, mT, has_motion, on, hl);
-		out8[mb * 64 + 32 + hl] = (uint8_t)dbkp_ab_value(hm, hL, hT, D.fo[mb][0], D.fo[mb][1], D.alpha, D.beta, on, hl);
-	}
-}
-E264_DEV void pred_phase_dbk_store(PredLds &L, const FrameCtx &f, const PredTile &t, int tid)
-{
-	PredDbkScratch &D = pred_dbk_scratch(L);
-	const int mb = tid >> 2, part = tid & 3; // PT_MBS records x 4 pieces of 16 bytes
-	const int mbx = t.tx0 + (mb & (PT_W - 1)), mby = t.ty0 + mb / PT_W;
-	if (mbx < f.wm && mby < f.hm)
-		*(gv4u *)(f.dbk + (size_t)(mby * f.wm + mbx) * E264_DBK_BYTES + part * 16) = *(const v4u *)&D.out[mb][part * 4];
-}
 
 // prediction item: bits 0..8 quadrant slot (macroblock of the tile * 4 + 8x8 index), 9..10 4x4 block of the quadrant the
 // partition starts at, 11..12 shape (0 8x8, 1 8x4, 2 4x8, 3 4x4).  The class is implied by the list.
@@ -212,13 +136,19 @@ E264_DEV void pred_phase_classify(PredLds &L, const FrameCtx &f, const PredTile 
 	}
 	if (kind != E264_MB_INTER || !f.motion)
 		return;
-	gmotion_t mo = f.motion + (mby * f.wm + mbx);
-	if (list == 0 && mo->refPic[4 + q] >= 0)
+	const uint32_t mot_off = L.hdr[mb][5], mot_hdr = L.hdr[mb][6]; // E264Mb.modes of an inter macroblock: its motion directory
+	if (list == 0 && (E264_MOT_UNI(mot_hdr, 1) || E264_MOT_USED(mot_hdr, 4 + q)))
 		L.any_l1 = 1;
-	const int pic = mo->refPic[list * 4 + q];
+	uint32_t refword, mvq[4];
+	if (!mot_quadrant(f.motion, mot_off, mot_hdr, list, q, refword, mvq))
+		return;
+	const int pic = (int)(int8_t)refword;
 	if (pic < 0)
 		return;
-	const v4u m = *(const gv4u *)&mo->mvs[list * 32 + q * 8]; // the quadrant's four 4x4 vectors: (0,0) (4,0) (0,4) (4,4)
+	uint32_t otherref = 0xffffffffu, dummy[4]; // refIdx of the other list decides how the two predictions combine
+	if (E264_MOT_UNI(mot_hdr, list ^ 1) || E264_MOT_USED(mot_hdr, (list ^ 1) * 4 + q))
+		mot_quadrant(f.motion, mot_off, mot_hdr, list ^ 1, q, otherref, dummy);
+	const v4u m = {mvq[0], mvq[1], mvq[2], mvq[3]}; // the quadrant's four 4x4 vectors: (0,0) (4,0) (0,4) (4,4)
 	const int base = tid;
 	// everything the prediction of this quadrant needs goes to LDS here, so that the item phase starts with ONE round
 	// trip to memory (its reference windows) instead of a chain motion -> slot table -> window.
@@ -227,8 +157,7 @@ E264_DEV void pred_phase_classify(PredLds &L, const FrameCtx &f, const PredTile 
 	// 1.5 - 2.5 cycles per lane-row whether the lanes are neighbours or scattered.)
 	cslice_t s = f.slices + (L.hdr[mb][2] >> 16);
 	L.mvq[0][tid] = m.x; L.mvq[1][tid] = m.y; L.mvq[2][tid] = m.z; L.mvq[3][tid] = m.w;
-	L.refq[tid] = (uint32_t)(uint8_t)pic | (uint32_t)(uint8_t)mo->refIdx[list * 4 + q] << 8 |
-	              (uint32_t)(uint8_t)mo->refIdx[(list ^ 1) * 4 + q] << 16 | (uint32_t)(uint8_t)s->weighted_bipred_idc << 24;
+	L.refq[tid] = (refword & 0xffffu) | (otherref >> 8 & 255u) << 16 | (uint32_t)(uint8_t)s->weighted_bipred_idc << 24;
 	if (m.x == m.y && m.x == m.z && m.x == m.w) {
 		pred_push(L, m.x, base);
 	} else if (m.x == m.y && m.z == m.w) { // two 8x4

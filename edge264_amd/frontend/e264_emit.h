@@ -33,6 +33,8 @@ typedef struct {
 	E264Mb *mbs;
 	E264Motion *motion;
 	uint16_t *dbk_slice;  /* per macroblock: slice entry whose task called deblock_mb on it (0xffff: none yet) */
+	uint8_t *mot;         /* scratch of e264_finish_frame: the compact motion records */
+	size_t mot_cap;
 	E264SliceParams *slices;
 	int *slice_serial;  /* decode_NAL serial of each slice entry */
 	uint8_t *slice_filled;

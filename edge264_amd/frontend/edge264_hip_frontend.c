@@ -203,11 +203,27 @@ static int e264_finish_frame(E264Emitter *e, int slot)
 		e264_slice_index(e, b);
 		e->serial = serial;
 	}
-	/* layout: hdr | slices | mbs | motion (if any inter MB) | payload */
+	/* motion sized by partition (edge264_cmd.h): compact records of the inter macroblocks, their directory in E264Mb.modes */
+	uint32_t motion_bytes = 0;
+	if (b->n_inter) {
+		if (b->mot_cap < (size_t)b->n_inter * 160) {
+			free(b->mot);
+			b->mot_cap = (size_t)b->n_inter * 160;
+			b->mot = malloc(b->mot_cap);
+			if (!b->mot) { b->mot_cap = 0; return ENOMEM; }
+		}
+		for (int a = 0; a < b->n_mbs; a++)
+			if (b->mbs[a].kind == E264_MB_INTER) {
+				uint32_t d[2] = {motion_bytes, 0};
+				motion_bytes += e264_motion_compact(&b->motion[a], b->mot + motion_bytes, &d[1]);
+				memcpy(b->mbs[a].modes, d, 8);
+			}
+	}
+	/* layout: hdr | slices | mbs | motion records (if any inter MB) | payload */
 	uint32_t slices_off = E264_ALIGN16((uint32_t)sizeof(E264FrameHdr));
 	uint32_t mbs_off = E264_ALIGN16(slices_off + (uint32_t)sizeof(E264SliceParams) * (uint32_t)b->n_slices);
 	uint32_t motion_off = E264_ALIGN16(mbs_off + (uint32_t)sizeof(E264Mb) * (uint32_t)b->n_mbs);
-	uint32_t payload_off = E264_ALIGN16(motion_off + (b->n_inter ? (uint32_t)sizeof(E264Motion) * (uint32_t)b->n_mbs : 0));
+	uint32_t payload_off = E264_ALIGN16(motion_off + motion_bytes);
 	uint32_t payload_bytes = E264_ALIGN16((uint32_t)b->payload_len);
 	size_t total = (size_t)payload_off + payload_bytes;
 	uint8_t *pkt;
@@ -235,7 +251,7 @@ static int e264_finish_frame(E264Emitter *e, int slot)
 	memcpy(pkt + slices_off, b->slices, sizeof(E264SliceParams) * (size_t)b->n_slices);
 	memcpy(pkt + mbs_off, b->mbs, sizeof(E264Mb) * (size_t)b->n_mbs);
 	if (b->n_inter)
-		memcpy(pkt + motion_off, b->motion, sizeof(E264Motion) * (size_t)b->n_mbs);
+		memcpy(pkt + motion_off, b->mot, motion_bytes);
 	memcpy(pkt + payload_off, b->payload, b->payload_len);
 	memset(pkt + payload_off + b->payload_len, 0, payload_bytes - b->payload_len);
 	b->active = 0;
@@ -360,7 +376,7 @@ PUBLIC void edge264_free(Edge264Decoder **pdec)
 		return;
 	if (ON_DEVICE(e)) hip.stream_close(e->hip_stream);
 	for (int s = 0; s < E264_MAX_SLOTS; s++) {
-		free(e->fb[s].mbs); free(e->fb[s].motion); free(e->fb[s].dbk_slice); free(e->fb[s].slices); free(e->fb[s].slice_serial);
+		free(e->fb[s].mbs); free(e->fb[s].motion); free(e->fb[s].dbk_slice); free(e->fb[s].mot); free(e->fb[s].slices); free(e->fb[s].slice_serial);
 		free(e->fb[s].slice_filled); free(e->fb[s].payload);
 	}
 	while (e->cap_head) {

@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 E264_MAGIC = 0x34363245
-E264_VERSION = 2
+E264_VERSION = 3
 MAX_SLOTS = 32
 
 MB_ABSENT, MB_I4x4, MB_I8x8, MB_I16x16, MB_PCM, MB_INTER = range(6)
@@ -82,6 +82,62 @@ def frame_geometry(width_mbs: int, height_mbs: int):
 def frame_bytes(width_mbs: int, height_mbs: int) -> int:
     g = frame_geometry(width_mbs, height_mbs)
     return g["plane_size_Y"] + g["plane_size_C"]
+
+
+_NMV = (1, 2, 2, 4)
+_SEL = ((0, 0, 0, 0), (0, 0, 1, 1), (0, 1, 0, 1), (0, 1, 2, 3))   # 4x4 block j of a quadrant -> vector of its record
+_IDX = ((0,), (0, 2), (0, 1), (0, 1, 2, 3))                       # vectors stored for each partition shape
+
+
+def motion_compact(mo) -> tuple[bytes, int]:
+    """Expanded motion of one macroblock (MOTION record) -> (compact record bytes, mot_hdr): include/edge264_cmd.h
+    e264_motion_compact, same bytes."""
+    rp, ri = [int(x) for x in mo["refPic"]], [int(x) for x in mo["refIdx"]]
+    mv = np.ascontiguousarray(mo["mvs"]).view("<i4")
+    out, h = bytearray(), 0
+    for l in range(2):
+        v = [int(x) for x in mv[l * 16:l * 16 + 16]]
+        if all(rp[l * 4 + q] >= 0 and rp[l * 4 + q] == rp[l * 4] and ri[l * 4 + q] == ri[l * 4] for q in range(4)) and all(x == v[0] for x in v):
+            h |= 15 << (l * 4) | 1 << (8 + l)
+            out += bytes([rp[l * 4] & 255, ri[l * 4] & 255, 0, 0]) + int(v[0]).to_bytes(4, "little", signed=True)
+            continue
+        for q in range(4):
+            if rp[l * 4 + q] < 0:
+                continue
+            w = v[q * 4:q * 4 + 4]
+            sub = 0 if w[0] == w[1] == w[2] == w[3] else 1 if (w[0] == w[1] and w[2] == w[3]) else 2 if (w[0] == w[2] and w[1] == w[3]) else 3
+            h |= 1 << (l * 4 + q) | sub << (10 + 2 * (l * 4 + q))
+            out += bytes([rp[l * 4 + q] & 255, ri[l * 4 + q] & 255, 0, 0])
+            for j in _IDX[sub]:
+                out += int(w[j]).to_bytes(4, "little", signed=True)
+    return bytes(out), h
+
+
+def motion_expand(h: int, rec, mo) -> int:
+    """Compact record (bytes-like at its first byte) -> expanded MOTION record `mo`; returns the record's size."""
+    n = 0
+    mv = mo["mvs"].view("<i4")
+    for l in range(2):
+        if h >> (8 + l) & 1:
+            mo["refPic"][l * 4:l * 4 + 4] = np.int8(np.uint8(rec[n]).view(np.int8))
+            mo["refIdx"][l * 4:l * 4 + 4] = np.int8(np.uint8(rec[n + 1]).view(np.int8))
+            mv[l * 16:l * 16 + 16] = int.from_bytes(bytes(rec[n + 4:n + 8]), "little", signed=True)
+            n += 8
+            continue
+        for q in range(4):
+            lq = l * 4 + q
+            if not h >> lq & 1:
+                mo["refPic"][lq] = mo["refIdx"][lq] = -1
+                mv[lq * 4:lq * 4 + 4] = 0
+                continue
+            sub = h >> (10 + 2 * lq) & 3
+            mo["refPic"][lq] = np.uint8(rec[n]).view(np.int8)
+            mo["refIdx"][lq] = np.uint8(rec[n + 1]).view(np.int8)
+            vs = [int.from_bytes(bytes(rec[n + 4 + 4 * j:n + 8 + 4 * j]), "little", signed=True) for j in range(_NMV[sub])]
+            n += 4 + 4 * _NMV[sub]
+            for j in range(4):
+                mv[lq * 4 + j] = vs[_SEL[sub][j]]
+    return n
 
 
 class PacketBuilder:
@@ -161,7 +217,12 @@ class PacketBuilder:
         mbs_off = align16(slices_off + SLICE_PARAMS.itemsize * len(self.slices))
         has_motion = bool((self.mbs["kind"] == MB_INTER).any())
         motion_off = align16(mbs_off + MB.itemsize * len(self.mbs))
-        payload_off = align16(motion_off + (self.motion.nbytes if has_motion else 0))
+        mot = bytearray()  # compact motion records of the inter macroblocks; their directory goes into E264Mb.modes
+        for a in np.nonzero(self.mbs["kind"] == MB_INTER)[0]:
+            rec, h = motion_compact(self.motion[a])
+            self.mbs["modes"][a] = np.frombuffer(np.array([len(mot), h], "<u4").tobytes(), np.uint8)
+            mot += rec
+        payload_off = align16(motion_off + len(mot))
         pay = bytes(self.payload) + bytes(-len(self.payload) % 16)
         total = payload_off + len(pay)
         hdr["magic"], hdr["version"], hdr["total_bytes"] = E264_MAGIC, E264_VERSION, total
@@ -181,7 +242,7 @@ class PacketBuilder:
             out[o:o + SLICE_PARAMS.itemsize] = s.tobytes()
         out[mbs_off:mbs_off + self.mbs.nbytes] = self.mbs.tobytes()
         if has_motion:
-            out[motion_off:motion_off + self.motion.nbytes] = self.motion.tobytes()
+            out[motion_off:motion_off + len(mot)] = mot
         out[payload_off:] = pay
         return bytes(out)
 
@@ -200,7 +261,36 @@ class Packet:
         n = int(self.hdr["width_mbs"]) * int(self.hdr["height_mbs"])
         self.mbs = np.frombuffer(data, MB, n, int(self.hdr["mbs_off"]))
         self.payload_off = int(self.hdr["payload_off"])
-        self.motion = (np.frombuffer(data, MOTION, n, int(self.hdr["motion_off"])) if int(self.hdr["motion_off"]) else None)
+        self._motion = None
+
+    @property
+    def motion(self):
+        """Motion of every macroblock in EXPANDED form (one MOTION record per macroblock address; refPic -1 everywhere for
+        macroblocks that are not inter), None if the frame has no inter macroblock."""
+        if self._motion is None and int(self.hdr["motion_off"]):
+            n = len(self.mbs)
+            mo = np.zeros(n, MOTION)
+            mo["refPic"] = -1
+            mo["refIdx"] = -1
+            sec = memoryview(self.data)[int(self.hdr["motion_off"]):self.payload_off]
+            dirs = np.ascontiguousarray(self.mbs["modes"]).view("<u4").reshape(n, 2)
+            for a in np.nonzero(self.mbs["kind"] == MB_INTER)[0]:
+                off, h = int(dirs[a, 0]), int(dirs[a, 1])
+                motion_expand(h, sec[off:off + 160], mo[a])
+            self._motion = mo
+        return self._motion
+
+    def motion_bytes(self) -> int:
+        """Bytes of compact motion records the packet carries."""
+        if not int(self.hdr["motion_off"]):
+            return 0
+        dirs = np.ascontiguousarray(self.mbs["modes"]).view("<u4").reshape(len(self.mbs), 2)
+        tot = 0
+        for a in np.nonzero(self.mbs["kind"] == MB_INTER)[0]:
+            h = int(dirs[a, 1])
+            for l in range(2):
+                tot += 8 if h >> (8 + l) & 1 else sum(4 + 4 * _NMV[h >> (10 + 2 * (l * 4 + q)) & 3] for q in range(4) if h >> (l * 4 + q) & 1)
+        return tot
 
     @property
     def width_mbs(self) -> int:
@@ -254,7 +344,7 @@ class Packet:
         own_pred = (kind == MB_INTER) | (kind == MB_PCM)
         own_intra = (kind == MB_I4x4) | (kind == MB_I8x8) | (kind == MB_I16x16)
         return dict(F=F, n_mbs=n, inter=float(own_pred.sum()) / n, intra=float(own_intra.sum()) / n, dirs=dirs / n,
-                    cmd_headers=int(self.hdr["mbs_off"]) + 32 * n, cmd_motion=144 * n if int(self.hdr["motion_off"]) else 0,
+                    cmd_headers=int(self.hdr["mbs_off"]) + 32 * n, cmd_motion=self.motion_bytes(),
                     cmd_payload_inter=int(pay[own_pred].sum()), cmd_payload_intra=int(pay[own_intra].sum()),
                     cmd_total=int(self.hdr["total_bytes"]))
 

@@ -28,11 +28,11 @@
  *   PCM ..................... raw samples, src/edge264_slice.c:914-935
  *
  * Layout of a packet (all offsets from the first byte of E264FrameHdr):
- *   [E264FrameHdr][E264SliceParams x n_slices][E264Mb x n_mbs][E264Motion x n_mbs (only if the
- *   frame has inter macroblocks)][payload]                      n_mbs = width_mbs*height_mbs
- * Every section starts on a 16-byte boundary.  The fixed-size sections are indexed by macroblock
- * address, so a reader can fetch header AND motion of any macroblock (its own or a neighbour's,
- * for deblocking) without first chasing an offset: one memory round trip instead of two.
+ *   [E264FrameHdr][E264SliceParams x n_slices][E264Mb x n_mbs][motion records of the inter macroblocks
+ *   (only if the frame has any)][payload]                        n_mbs = width_mbs*height_mbs
+ * Every section starts on a 16-byte boundary.  E264Mb is indexed by macroblock address; the motion record of an
+ * inter macroblock is variable-sized (one vector for a 16x16 partition ... 16 for 4x4 partitions, per list) and
+ * found through the directory words its E264Mb carries (see E264Mb.modes).
  */
 #ifndef EDGE264_CMD_H
 #define EDGE264_CMD_H
@@ -44,7 +44,7 @@ extern "C" {
 #endif
 
 #define E264_MAGIC   0x34363245u /* "E264" little endian */
-#define E264_VERSION 2u
+#define E264_VERSION 3u      /* 3: motion sized by partition (a 16x16 macroblock carries one vector, not 32) */
 #define E264_MAX_SLOTS 32        /* DPB slots per decoder, src/edge264_internal.h:402 */
 
 /* Macroblock kinds (what the reconstruction pass has to do). */
@@ -89,7 +89,7 @@ typedef struct E264FrameHdr { /* 80 bytes */
 	int32_t  frame_id;
 	uint32_t n_coded_mbs;     /* macroblocks with kind != ABSENT */
 	uint32_t n_inter_mbs;
-	uint32_t motion_off;      /* E264Motion[n_mbs], 0 if the frame has no inter macroblock */
+	uint32_t motion_off;      /* motion records (up to payload_off), 0 if the frame has no inter macroblock */
 	uint32_t stream_id;       /* capture files (a concatenation of packets): which decoder the packet belongs to;
 	                             ignored by the kernels */
 } E264FrameHdr;
@@ -125,7 +125,10 @@ typedef struct E264Mb { /* 32 bytes, one per macroblock in raster order */
 	uint32_t coded;          /* E264_CODED_* */
 	uint32_t payload_off;    /* byte offset from payload start, multiple of 8 */
 	uint8_t  modes[8];       /* I4x4: 16 x 4-bit internal modes (block k in modes[k>>1] >> 4*(k&1));
-	                            I8x8: 4 x 8-bit internal modes in modes[0..3] */
+	                            I8x8: 4 x 8-bit internal modes in modes[0..3];
+	                            INTER: the motion directory: uint32 mot_off (modes[0..3]) = byte offset of the macroblock's
+	                            motion record from motion_off, multiple of 4; uint32 mot_hdr (modes[4..7]) = its shape,
+	                            E264_MOT_* below */
 	uint16_t dbk_slice;      /* slice whose FilterOffsetA/B deblock this macroblock.  Normally == slice; the reference filters
 	                            macroblocks whose deblocking had to wait for other slices (arbitrary slice order with
 	                            disable_deblocking_filter_idc 0) with the constants of the slice that COMPLETES the picture
@@ -140,11 +143,99 @@ typedef struct E264Mb { /* 32 bytes, one per macroblock in raster order */
  *   luma blocks   : T8x8 ? int16_t[64] per coded 8x8 (bits 0,4,8,12) : int16_t[16] per coded 4x4
  *   chroma blocks : int16_t[16] per coded block k=0..7
  */
+/* Motion of one macroblock in EXPANDED form (what mb->refPic / refIdx / mvs hold in the reference,
+ * src/edge264_internal.h:139-142): the in-memory form of emitters, checkers and tools.  Packets carry the compact
+ * record below; e264_motion_compact / e264_motion_expand convert (lossless for the used lists; vectors of unused
+ * lists read as zero, which is what the reference stores for them). */
 typedef struct E264Motion {
 	int8_t  refPic[8];   /* [LX*4 + i8x8] DPB slot, -1 if the list is unused */
 	int8_t  refIdx[8];   /* [LX*4 + i8x8] index used to look up weights, -1 if unused */
 	int16_t mvs[64];     /* [LX*32 + i4x4*2 + {x,y}] quarter-pel, i4x4 in zig order */
 } E264Motion;
+
+/* mot_hdr (E264Mb.modes[4..7] of an inter macroblock):
+ *   bits 0..7    used[LX*4 + q]   list LX predicts 8x8 quadrant q
+ *   bits 8..9    uni[LX]          the macroblock is ONE 16x16 partition in list LX (all quadrants used, one reference,
+ *                                 one vector): the list's part of the record is {int8 refPic, int8 refIdx, 0, 0, mv}
+ *   bits 10..25  sub[LX*4 + q]    2 bits each: partition of the quadrant: 0 8x8 (1 vector), 1 8x4 (2: top, bottom),
+ *                                 2 4x8 (2: left, right), 3 4x4 (4, zig order)
+ * Motion record = list 0 part, then list 1 part.  A part is the uniform form (8 bytes) or, for every used quadrant in
+ * increasing q, {int8 refPic, int8 refIdx, 0, 0} followed by its 1 / 2 / 4 vectors (int16 x, int16 y). */
+#define E264_MOT_USED(h, lq)  ((h) >> (lq) & 1u)
+#define E264_MOT_UNI(h, l)    ((h) >> (8 + (l)) & 1u)
+#define E264_MOT_SUB(h, lq)   ((h) >> (10 + 2 * (lq)) & 3u)
+static inline uint32_t e264_mot_nmv(uint32_t sub) { return sub == 0 ? 1u : sub == 3 ? 4u : 2u; }
+static inline uint32_t e264_mot_part_bytes(uint32_t h, int l)
+{
+	if (E264_MOT_UNI(h, l)) return 8;
+	uint32_t n = 0;
+	for (int q = 0; q < 4; q++)
+		if (E264_MOT_USED(h, l * 4 + q)) n += 4 + 4 * e264_mot_nmv(E264_MOT_SUB(h, l * 4 + q));
+	return n;
+}
+static inline uint32_t e264_mot_record_bytes(uint32_t h) { return e264_mot_part_bytes(h, 0) + e264_mot_part_bytes(h, 1); }
+
+/* expanded -> compact: writes the record (at most 2 * 4 * 20 = 160 bytes) and its shape word; returns the record's size */
+static inline uint32_t e264_motion_compact(const E264Motion *m, uint8_t *rec, uint32_t *mot_hdr)
+{
+	uint32_t h = 0, n = 0;
+	for (int l = 0; l < 2; l++) {
+		const int32_t *mv = (const int32_t *)(const void *)&m->mvs[l * 32];
+		int uni = 1;
+		for (int q = 0; q < 4; q++) {
+			uni &= m->refPic[l * 4 + q] >= 0 && m->refPic[l * 4 + q] == m->refPic[l * 4] && m->refIdx[l * 4 + q] == m->refIdx[l * 4];
+			for (int j = 0; j < 4; j++) uni &= mv[q * 4 + j] == mv[0];
+		}
+		if (uni) {
+			h |= 15u << (l * 4) | 1u << (8 + l);
+			rec[n] = (uint8_t)m->refPic[l * 4]; rec[n + 1] = (uint8_t)m->refIdx[l * 4]; rec[n + 2] = rec[n + 3] = 0;
+			*(int32_t *)(void *)(rec + n + 4) = mv[0];
+			n += 8;
+			continue;
+		}
+		for (int q = 0; q < 4; q++) {
+			if (m->refPic[l * 4 + q] < 0)
+				continue;
+			const int32_t *v = mv + q * 4;
+			const uint32_t sub = (v[0] == v[1] && v[0] == v[2] && v[0] == v[3]) ? 0 : (v[0] == v[1] && v[2] == v[3]) ? 1 : (v[0] == v[2] && v[1] == v[3]) ? 2 : 3;
+			h |= 1u << (l * 4 + q) | sub << (10 + 2 * (l * 4 + q));
+			rec[n] = (uint8_t)m->refPic[l * 4 + q]; rec[n + 1] = (uint8_t)m->refIdx[l * 4 + q]; rec[n + 2] = rec[n + 3] = 0;
+			n += 4;
+			const int idx[4][4] = {{0, 0, 0, 0}, {0, 2, 0, 0}, {0, 1, 0, 0}, {0, 1, 2, 3}};
+			for (uint32_t j = 0; j < e264_mot_nmv(sub); j++, n += 4)
+				*(int32_t *)(void *)(rec + n) = v[idx[sub][j]];
+		}
+	}
+	*mot_hdr = h;
+	return n;
+}
+/* compact -> expanded */
+static inline void e264_motion_expand(uint32_t h, const uint8_t *rec, E264Motion *m)
+{
+	uint32_t n = 0;
+	for (int l = 0; l < 2; l++) {
+		int32_t *mv = (int32_t *)(void *)&m->mvs[l * 32];
+		if (E264_MOT_UNI(h, l)) {
+			for (int q = 0; q < 4; q++) { m->refPic[l * 4 + q] = (int8_t)rec[n]; m->refIdx[l * 4 + q] = (int8_t)rec[n + 1]; }
+			for (int k = 0; k < 16; k++) mv[k] = *(const int32_t *)(const void *)(rec + n + 4);
+			n += 8;
+			continue;
+		}
+		for (int q = 0; q < 4; q++) {
+			if (!E264_MOT_USED(h, l * 4 + q)) {
+				m->refPic[l * 4 + q] = m->refIdx[l * 4 + q] = -1;
+				mv[q * 4] = mv[q * 4 + 1] = mv[q * 4 + 2] = mv[q * 4 + 3] = 0;
+				continue;
+			}
+			const uint32_t sub = E264_MOT_SUB(h, l * 4 + q);
+			m->refPic[l * 4 + q] = (int8_t)rec[n]; m->refIdx[l * 4 + q] = (int8_t)rec[n + 1];
+			const int32_t *v = (const int32_t *)(const void *)(rec + n + 4);
+			n += 4 + 4 * e264_mot_nmv(sub);
+			const int sel[4][4] = {{0, 0, 0, 0}, {0, 0, 1, 1}, {0, 1, 0, 1}, {0, 1, 2, 3}};
+			for (int j = 0; j < 4; j++) mv[q * 4 + j] = v[sel[sub][j]];
+		}
+	}
+}
 
 #define E264_ALIGN16(x) (((x) + 15u) & ~15u)
 
@@ -173,7 +264,7 @@ static inline uint32_t e264_mb_payload_bytes(const E264Mb *m)
 E264_SIZE_CHECK(sizeof(E264FrameHdr) == 80, "E264FrameHdr");
 E264_SIZE_CHECK(sizeof(E264SliceParams) == 2112, "E264SliceParams");
 E264_SIZE_CHECK(sizeof(E264Mb) == 32, "E264Mb");
-E264_SIZE_CHECK(sizeof(E264Motion) == 144, "E264Motion");
+E264_SIZE_CHECK(sizeof(E264Motion) == 144, "E264Motion (expanded form)");
 
 #ifdef __cplusplus
 }

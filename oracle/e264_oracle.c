@@ -943,11 +943,29 @@ static int open_frame(Frame *f, const uint8_t *pkt, size_t bytes, uint8_t *const
 	f->h = h;
 	f->slices = (const E264SliceParams *)(pkt + h->slices_off);
 	f->mbs = (const E264Mb *)(pkt + h->mbs_off);
-	f->motion = h->motion_off ? (const E264Motion *)(pkt + h->motion_off) : NULL;
+	f->motion = NULL;
+	if (h->motion_off) { /* packets carry compact motion records (edge264_cmd.h): expanded once per frame */
+		int n = h->width_mbs * h->height_mbs;
+		E264Motion *mo = malloc(sizeof(E264Motion) * (size_t)n);
+		if (!mo) return -3;
+		for (int a = 0; a < n; a++) {
+			memset(&mo[a], 0, sizeof(mo[a]));
+			memset(mo[a].refPic, -1, 8);
+			memset(mo[a].refIdx, -1, 8);
+			if (f->mbs[a].kind == E264_MB_INTER) {
+				uint32_t d[2];
+				memcpy(d, f->mbs[a].modes, 8);
+				e264_motion_expand(d[1], pkt + h->motion_off + d[0], &mo[a]);
+			}
+		}
+		f->motion = mo;
+	}
 	f->payload = pkt + h->payload_off;
 	f->dpb = dpb;
-	if (h->dst_slot < 0 || h->dst_slot >= E264_MAX_SLOTS || !dpb[h->dst_slot])
+	if (h->dst_slot < 0 || h->dst_slot >= E264_MAX_SLOTS || !dpb[h->dst_slot]) {
+		free((void *)f->motion);
 		return -2;
+	}
 	f->cur = dpb[h->dst_slot];
 	f->W = h->width_mbs * 16;
 	f->H = h->height_mbs * 16;
@@ -969,6 +987,7 @@ EXPORT int e264_oracle_decode_frame(const uint8_t *pkt, size_t bytes, uint8_t *c
 		for (int y = 0; y < f.h->height_mbs; y++)
 			for (int x = 0; x < f.h->width_mbs; x++)
 				deblock_mb(&f, x, y);
+	free((void *)f.motion);
 	return 0;
 }
 
@@ -985,6 +1004,7 @@ EXPORT int e264_oracle_frame_bs(const uint8_t *pkt, size_t bytes, uint8_t *out)
 	for (int y = 0; y < f.h->height_mbs; y++)
 		for (int x = 0; x < f.h->width_mbs; x++)
 			e264o_mb_bs(&f, x, y, (uint8_t (*)[4][4])(out + (y * f.h->width_mbs + x) * 32));
+	free((void *)f.motion);
 	return 0;
 }
 

@@ -100,7 +100,7 @@ EXPORT int ref_replay_packet(RefHarness *h, const uint8_t *pkt, size_t bytes, ui
 	const E264SliceParams *slices = (const E264SliceParams *)(pkt + fh->slices_off);
 	const E264Mb *mbs = (const E264Mb *)(pkt + fh->mbs_off);
 	const uint8_t *payload = pkt + fh->payload_off;
-	const E264Motion *motion = fh->motion_off ? (const E264Motion *)(pkt + fh->motion_off) : NULL;
+	const uint8_t *motion_sec = fh->motion_off ? pkt + fh->motion_off : NULL; /* compact records, expanded per macroblock below */
 	Edge264Context *ctx = &h->c;
 	uint8_t *cur = dpb[fh->dst_slot];
 	ctx->t.pic_width_in_mbs = h->W;
@@ -137,7 +137,10 @@ EXPORT int ref_replay_packet(RefHarness *h, const uint8_t *pkt, size_t bytes, ui
 			M->refIdx_l = -1;
 			M->refPic_l = -1;
 			if (m->kind == E264_MB_INTER) {
-				const E264Motion *mo = motion + (m - mbs);
+				E264Motion mo_x, *mo = &mo_x;
+				uint32_t mdir[2];
+				memcpy(mdir, m->modes, 8);
+				e264_motion_expand(mdir[1], motion_sec + mdir[0], mo);
 				memcpy(M->refPic, mo->refPic, 8);
 				memcpy(M->refIdx, mo->refIdx, 8);
 				memcpy(M->mvs, mo->mvs, 128);

@@ -42,6 +42,7 @@ static inline uint32_t v_sat_pk_u8_i16(uint32_t v)
 static inline int lds_add(int *p, int v) { int o = *p; *p += v; return o; }
 static inline void lds_or(uint32_t *p, uint32_t v) { *p |= v; }
 #include "../../edge264_amd/csrc/e264_pred.h"
+#include "../../edge264_amd/csrc/e264_dbkp.h"
 
 // dbk: NULL, or room for 64 bytes per macroblock: the kernel then also computes the deblocking parameters of its tiles
 extern "C" __attribute__((visibility("default"))) int e264emu_pred_frame2(const uint8_t *pkt, uint8_t *const *dpb, uint8_t *dbk)
@@ -56,12 +57,6 @@ extern "C" __attribute__((visibility("default"))) int e264emu_pred_frame2(const 
 		PredTile t = {(ti % ntx) * PT_W, (ti / ntx) * PT_H};
 		memset(&L, 0xA5, sizeof(L)); // LDS is not zeroed on the device either
 		for (int tid = 0; tid < PT_NT; tid++) pred_phase_setup(L, f, t, tid);
-		if (dbk) {
-			for (int tid = 0; tid < PT_NT; tid++) pred_phase_dbk_load(L, f, t, tid);
-			for (int tid = 0; tid < PT_NT; tid++) pred_phase_dbk_compute(L, f, t, tid);
-			for (int tid = 0; tid < PT_NT; tid++) pred_phase_dbk_store(L, f, t, tid);
-			memset(L.y, 0xA5, sizeof(L.y)); // nothing may depend on what the scratch left behind
-		}
 		for (int list = 0; list < 2; list++) {
 			if (list == 1 && !L.any_l1) break;
 			if (list == 1) for (int tid = 0; tid < PT_NT; tid++) pred_phase_reset(L, tid);

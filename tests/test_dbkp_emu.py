@@ -76,23 +76,3 @@ def test_dbkparam_emu(emu, name, gop, w, h, kw):
         assert np.array_equal(got[:, :32], bs), f"{name} frame {ft}: bS differs at macroblocks {np.nonzero((got[:, :32] != bs).any(1))[0][:8].tolist()}"
         assert np.array_equal(got[:, 32:], expected_ab(pk, w)), f"{name} frame {ft}: alpha / beta / indexA differ"
 
-
-@pytest.mark.parametrize("name,gop,w,h,kw", CASES, ids=[c[0] for c in CASES])
-def test_pred_kernel_computes_the_same_parameters(emu, name, gop, w, h, kw):
-    """When a submission reconstructs and deblocks, e264_pred_kernel computes the parameter records of its own tiles
-    (records through the tile's LDS, halo rows from the packet): identical bytes to the stand-alone kernel."""
-    from oracle.pyoracle import _dpb_array
-    emu.e264emu_pred_frame2.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p]
-    emu.e264emu_pred_frame2.restype = C.c_int
-    g = synth.StreamSynth(w, h, seed=len(name) * 13, **kw)
-    nb = P.frame_bytes(w, h)
-    rng = np.random.default_rng(5)
-    dpb = [rng.integers(0, 256, nb + 16, dtype=np.uint8) for _ in range(6)] + [None] * 26
-    for ft in gop:
-        pkt = g.next_frame(ft)
-        n = w * h
-        alone = np.full((n, 64), 0x5A, np.uint8)
-        folded = np.full((n, 64), 0xA5, np.uint8)
-        assert emu.e264emu_dbkparam_frame(pkt, alone.ctypes.data) == 0
-        assert emu.e264emu_pred_frame2(pkt, _dpb_array(dpb), folded.ctypes.data) == 0
-        assert np.array_equal(alone, folded), f"{name} frame {ft}: macroblocks {np.nonzero((alone != folded).any(1))[0][:8].tolist()}"

@@ -67,10 +67,22 @@ def mb_set(field, value, kind=None):
     return fn
 
 
-def motion_set(field, idx, value):
+def motion_set(byte, value):
+    """Overwrite one byte of the first inter macroblock's compact motion record (version 3: byte 0 = refPic and byte 1 = refIdx
+    of its first predicted part)."""
     def fn(pk, buf):
-        mo = np.frombuffer(buf, P.MOTION, len(pk.mbs), int(pk.hdr["motion_off"]))
-        mo[field][first(pk, P.MB_INTER)][idx] = value
+        a = first(pk, P.MB_INTER)
+        mbs = np.frombuffer(buf, P.MB, len(pk.mbs), int(pk.hdr["mbs_off"]))
+        off = int(mbs["modes"][a][:4].view("<u4")[0])
+        buf[int(pk.hdr["motion_off"]) + off + byte] = value & 255
+    return fn
+
+
+def directory_set(word, value):
+    def fn(pk, buf):
+        a = first(pk, P.MB_INTER)
+        mbs = np.frombuffer(buf, P.MB, len(pk.mbs), int(pk.hdr["mbs_off"]))
+        mbs["modes"][a][word * 4:word * 4 + 4] = np.frombuffer(np.uint32(value).tobytes(), np.uint8)
     return fn
 
 
@@ -98,9 +110,13 @@ CORRUPTIONS = [
     ("coded_overrun", 0, mb_set("payload_off", None)),     # filled in below: last 8 bytes of the payload
     ("t8x8_on_i16x16", 0, None),                            # filled in below
     ("absent_wild_slice", 0, None),                         # filled in below: ABSENT records are read by the parameter kernel too
-    ("refPic", 1, motion_set("refPic", 0, 40)),
-    ("refPic_neg", 1, motion_set("refPic", 0, -3)),
-    ("refIdx", 1, motion_set("refIdx", 0, 77)),
+    ("refPic", 1, motion_set(0, 40)),
+    ("refPic_neg", 1, motion_set(0, -3)),
+    ("refPic_none", 1, motion_set(0, -1)),                  # a part the directory announces must name a picture
+    ("refIdx", 1, motion_set(1, 77)),
+    ("mot_off_align", 1, directory_set(0, 2)),
+    ("mot_off_overrun", 1, directory_set(0, 1 << 26)),
+    ("mot_hdr_bits", 1, directory_set(1, 1 << 27)),
 ]
 
 

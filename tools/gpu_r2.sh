@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 GPU visit: parity tests, bench of the default build, of round 1's mbpar kernel (debug bit 14) and of every
+# round-2 GPU visit: parity tests, bench of the default build and of every
 # variant library; optional rocprofv3 kernel trace.   bash tools/gpu_r2.sh TAG [prof]
 TAG=${1:-r2}
 REPO=$(pwd)
@@ -13,7 +13,6 @@ summ() { python -c "
 import json,sys
 d=json.load(open(sys.argv[1])); print(sys.argv[2], d['value'], d['bit_exact'], {k.split('_')[1]: v['ms_per_launch'] for k, v in d['roofline']['kernels'].items()})" $1 $2; }
 timeout 300 python bench.py --no-cpu-baseline > $OUT/bench_main.json 2> $OUT/bench_main.err; summ $OUT/bench_main.json main
-timeout 300 python bench.py --no-cpu-baseline --debug-mode 16384 > $OUT/bench_old.json 2> $OUT/bench_old.err; summ $OUT/bench_old.json old_mbpar
 for lib in edge264_amd/variants/*.so; do
   [ -f "$lib" ] || continue
   n=$(basename $lib .so)
