@@ -1,0 +1,366 @@
+// e264_dbk.h -- e264_deblock_kernel, second generation: the in-loop deblocking filter of one picture.
+//
+// Device restatement of deblock_mb's filtering part, /root/reference/src/edge264_deblock.c:284-895 (the per-edge arithmetic:
+// :95-152 bS < 4, :213-276 bS == 4; luma edge order :300-620, chroma :640-890), driven by the parameter records of
+// e264_dbkparam2_kernel (e264_dbkp.h).
+//
+// Why a rewrite.  Round 1 walked a macroblock row with one half-wave, one LINE per lane, in scalar 32-bit arithmetic and
+// moved every sample through LDS byte by byte: ~1000 VALU instructions per pair of macroblocks, and the kernel was bound
+// by VALU issue (34 waves x 122 steps x 1000 instructions x 4 cycles on 4 SIMDs = the 1.8 ms it took per 256 pictures).
+// Here a lane filters TWO adjacent lines at once in packed 16-bit arithmetic (v_pk_*_i16; the two lines of a pair share
+// their 4-line segment, hence bS and tC0), so a macroblock needs 12 lanes -- 8 for luma, 4 for chroma, each chroma lane
+// carrying a line pair of Cb AND of Cr in the four edge slots luma uses for its four edges -- and a wave walks FIVE
+// macroblock rows, each one macroblock behind the row above:
+//
+//   step t, row g of the wave (lanes 12g .. 12g+11), macroblock x = t - g:
+//     V phase  vertical edges: lane = row pair.  Own samples come straight from the registers a prefetch filled one
+//              step earlier, the left neighbour's last 4 columns from the row's strip in LDS; result -> strip.
+//     H phase  horizontal edges: lane = column pair, read from the strip; the 4 rows above are rows 12..15 of the strip
+//              of row g-1 (which filtered macroblock x+1's left edge in this step's V phase: exactly the decoding order
+//              (x+1, y-1) before (x, y) of edge264_deblock.c), or, for the wave's first row, a small top strip that is
+//              fetched from and written back to memory.
+//   every 4th step each row writes the group of 4 macroblocks that has become final as whole 64-byte row pieces.
+//
+// The strip of a row holds 8 macroblocks (two groups of 4): the group being filtered and the one waiting for the row
+// below to finish with its last rows.  Rows of different waves meet through memory: a wave publishes how many
+// macroblocks of its last row have left for memory (progress[]), the wave below fetches the top rows of a group of 4 once
+// that group is there.  Nothing else synchronises: the five rows of a wave run in lockstep by construction.
+//
+// Every function here is a plain function of (LDS, frame, lane role, step): tests/emu runs them on the host.
+#ifndef E264_DBK_H
+#define E264_DBK_H
+#include "e264_dev.h"
+
+namespace {
+
+#define DK_ROWS 5      // macroblock rows per wave
+#define DK_LANES 12    // lanes per row: 8 luma line pairs + 4 chroma line pairs (Cb and Cr)
+#define DK_STRIDE 144  // bytes per strip row: 8 macroblocks x 16 + 16 (keeps the row pairs of a V phase on different banks)
+#define DK_CR 64       // chroma strip row: Cb at +0, Cr at +64
+
+struct __attribute__((aligned(16))) DkWave {
+	uint8_t y[DK_ROWS][16][DK_STRIDE]; // luma strips: macroblock x at columns (x & 7) * 16
+	uint8_t c[DK_ROWS][8][DK_STRIDE];  // chroma strips: macroblock x at columns (x & 7) * 8 (+ DK_CR for Cr)
+	uint8_t ty[4][DK_STRIDE];          // rows -4..-1 above the wave's first row (luma)
+	uint8_t tcp[2][DK_STRIDE];         // never holds samples: the unused taps of chroma lanes land here
+	uint8_t tc[2][DK_STRIDE];          // chroma rows -2, -1 above the wave's first row
+	uint32_t prm[DK_ROWS][2][16];      // parameter records of macroblock x (slot x & 1) of each row
+};
+
+#ifdef E264_HOST_INTRINSICS
+#define DK_ANY(x) true  // skipping an edge no lane filters is an optimisation only: the masked arithmetic leaves the samples alone
+#else
+#define DK_ANY(x) __any((x) != 0)
+#endif
+
+E264_DEV uint32_t dk_bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); } // v_bfi_b32
+E264_DEV s16x2 dk_dup(uint32_t x) { return as_s2(x | x << 16); }
+E264_DEV s16x2 dk_sel(s16x2 mask, s16x2 a, s16x2 b) { return as_s2(dk_bfi(as_u(mask), as_u(a), as_u(b))); }
+E264_DEV s16x2 dk_abs(s16x2 v) { return __builtin_elementwise_max(v, -v); }
+E264_DEV s16x2 dk_clip(s16x2 v, s16x2 lo, s16x2 hi) { return __builtin_elementwise_min(__builtin_elementwise_max(v, lo), hi); }
+
+// What a lane is: constant over the kernel.
+struct DkRole {
+	int g, r;          // row of the wave, lane within the row
+	bool idle, chroma;
+	int pi, seg;       // line pair (luma 0..7: lines 2pi, 2pi+1; chroma 0..3), its 4-line segment in luma units
+	int rowa;          // V phase: byte offset inside DkWave of the first line of the pair at slot 0 (chroma: Cb)
+	int slot_mul;      // bytes per macroblock in a strip row: 16 / 8
+	int cr_off;        // chroma: DK_CR; luma: 0
+	uint32_t a1_mask;  // V phase: bits of the third dword that come from the macroblock itself (chroma: Cb columns 4, 5; the rest is Cr's left neighbour)
+	int hT, hO, hT2, hO2; // H phase: bases of taps 0..3 / 4..9 / 10..11 / 12..19 at slot 0 (see dk_haddr)
+	uint32_t luma_mask;   // all ones for luma lanes
+	uint32_t tc_add;      // chroma: tC = tC0 + 1
+};
+
+E264_DEV DkRole dk_role(int lane)
+{
+	DkRole R;
+	R.g = lane / DK_LANES; R.r = lane - R.g * DK_LANES;
+	R.idle = R.g >= DK_ROWS;
+	if (R.idle) R.g = DK_ROWS - 1; // addresses stay valid; the lane never acts
+	R.chroma = R.r >= 8;
+	R.pi = R.chroma ? R.r - 8 : R.r;
+	R.seg = R.chroma ? R.pi : R.pi >> 1;
+	const int g = R.g, col = 2 * R.pi;
+	const int oy = (int)offsetof(DkWave, y) + g * 16 * DK_STRIDE, oc = (int)offsetof(DkWave, c) + g * 8 * DK_STRIDE;
+	const int uy = g ? oy - 4 * DK_STRIDE : (int)offsetof(DkWave, ty);                    // rows -4..-1: rows 12..15 of the strip above
+	const int uc = g ? oc - 2 * DK_STRIDE : (int)offsetof(DkWave, tc);                    // chroma rows -2, -1
+	R.rowa = (R.chroma ? oc : oy) + 2 * R.pi * DK_STRIDE;
+	R.slot_mul = R.chroma ? 8 : 16;
+	R.cr_off = R.chroma ? DK_CR : 0;
+	R.a1_mask = R.chroma ? 0x0000ffffu : 0xffffffffu;
+	R.luma_mask = R.chroma ? 0u : 0xffffffffu;
+	R.tc_add = R.chroma ? 1u : 0u;
+	if (!R.chroma) {
+		R.hT = uy + col; R.hO = oy + col; R.hT2 = R.hO; R.hO2 = R.hO;
+	} else { // taps 2..5: Cb rows -2..1, 6..9: Cb rows 2..5, 10..13: Cr rows -2..1, 14..17: Cr rows 2..5
+		R.hT = uc - 2 * DK_STRIDE + col;
+		R.hO = oc + col;
+		R.hT2 = uc + DK_CR + col - 6 * DK_STRIDE;
+		R.hO2 = oc + DK_CR + col - 8 * DK_STRIDE;
+	}
+	return R;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One edge on 8 sample pairs p3 p2 p1 p0 | q0 q1 q2 q3 = v[0..7] (edge264_deblock.c:95-152, 213-276).
+//   alphaE  alpha, or 0 where bS == 0 (nothing is below 0: the edge is left alone)
+//   betal   beta for luma lanes, 0 for chroma lanes (ap = aq = false: chroma never touches p1 / q1)
+//   tc0     tC0 (chroma: + 1, its tC); 0 where bS == 4
+//   STRONG  0: no lane of this slot can have bS 4; 1: luma + chroma macroblock edge; 2: chroma macroblock edge only
+// ---------------------------------------------------------------------------------------------------------------------
+template <int STRONG>
+E264_DEV void dk_edge(s16x2 *v, s16x2 alphaE, s16x2 beta, s16x2 betal, s16x2 tc0, s16x2 small_thr, s16x2 strong)
+{
+	s16x2 &p3 = v[0], &p2 = v[1], &p1 = v[2], &p0 = v[3], &q0 = v[4], &q1 = v[5], &q2 = v[6], &q3 = v[7];
+	const s16x2 d = p0 - q0, dpq = dk_abs(d);
+	// filterSamplesFlag: all three differences below their thresholds <=> all three (difference - threshold) negative
+	const s16x2 go = ((dpq - alphaE) & (dk_abs(p1 - p0) - beta) & (dk_abs(q1 - q0) - beta)) >> 15;
+	if (!DK_ANY(as_u(go)))
+		return;
+	const s16x2 ap = ((dk_abs(p2 - p0) - betal) >> 15) & go, aq = ((dk_abs(q2 - q0) - betal) >> 15) & go;
+	// ---- bS < 4
+	const s16x2 tc = tc0 - ap - aq;
+	const s16x2 delta = dk_clip((d * (short)-4 + p1 - q1 + (short)4) >> 3, -tc, tc) & go;
+	const s16x2 avg = as_s2(v_lerp_u8(as_u(p0), as_u(q0), 0x00010001u)); // (p0 + q0 + 1) >> 1
+	const s16x2 z = {0, 0}, m255 = {255, 255};
+	const s16x2 dp1 = dk_clip((p2 + avg - p1 * (short)2) >> 1, -tc0, tc0) & ap; // tc0 is 0 on bS 4 lines: p1 stays
+	const s16x2 dq1 = dk_clip((q2 + avg - q1 * (short)2) >> 1, -tc0, tc0) & aq;
+	s16x2 np0 = dk_clip(p0 + delta, z, m255), nq0 = dk_clip(q0 - delta, z, m255);
+	s16x2 np1 = p1 + dp1, nq1 = q1 + dq1;
+	if (STRONG) {
+		const s16x2 S = strong & go;
+		if (DK_ANY(as_u(S))) { // ---- bS == 4
+			const s16x2 wp0 = (p1 * (short)2 + p0 + q1 + (short)2) >> 2, wq0 = (q1 * (short)2 + q0 + p1 + (short)2) >> 2;
+			np0 = dk_sel(S, wp0, np0); nq0 = dk_sel(S, wq0, nq0);
+			if (STRONG == 1) {
+				const s16x2 sm = (dpq - small_thr) >> 15; // |p0 - q0| < (alpha >> 2) + 2
+				const s16x2 sp = ap & sm & S, sq = aq & sm & S;
+				const s16x2 pq = p0 + q0, tp = p2 + p1 + pq, tq = q2 + q1 + pq;
+				np0 = dk_sel(sp, (tp + p1 + pq + q1 + (short)4) >> 3, np0);
+				nq0 = dk_sel(sq, (tq + q1 + pq + p1 + (short)4) >> 3, nq0);
+				np1 = dk_sel(sp, (tp + (short)2) >> 2, np1);
+				nq1 = dk_sel(sq, (tq + (short)2) >> 2, nq1);
+				p2 = dk_sel(sp, ((p3 + p2) * (short)2 + tp + (short)4) >> 3, p2);
+				q2 = dk_sel(sq, ((q3 + q2) * (short)2 + tq + (short)4) >> 3, q2);
+			}
+		}
+	}
+	p0 = np0; q0 = nq0; p1 = np1; q1 = nq1;
+}
+
+// The four edge slots of a line pair held in v[0..19] (positions -4..15): slot e works on v[4e .. 4e+7].
+// Luma lanes: edge e of the macroblock.  Chroma lanes: slot 0 = Cb macroblock edge, 1 = Cb inner edge, 2 = Cr macroblock
+// edge, 3 = Cr inner edge; only p1 p0 q0 q1 = v[4e+2 .. 4e+5] matter there.
+// prm: the macroblock's 64-byte parameter record in LDS; dir 0 vertical edges, 1 horizontal edges.
+E264_DEV void dk_filter(s16x2 *v, const uint8_t *prm, const uint8_t *tc0tab, const DkRole &R, int dir)
+{
+#pragma unroll
+	for (int e = 0; e < 4; e++) {
+		const bool mbe = R.chroma ? !(e & 1) : e == 0;                                   // a macroblock edge: its own alpha / beta / indexA
+		const int bso = (R.chroma ? (e & 1) * 8 : e * 4) + R.seg;                        // chroma inner edge = luma edge 2
+		const int abi = (R.chroma ? (1 + (e >> 1)) * 3 : 0) + (mbe ? 1 + dir : 0);       // [plane * 3 + {inner, left, top}]
+		const uint32_t bS = prm[dir * 16 + bso];
+		if (!DK_ANY(bS))
+			continue;
+		const uint32_t alpha = prm[32 + abi], beta = prm[41 + abi], ia = prm[50 + abi];
+		const uint32_t tc0 = tc0tab[(bS & 3) * 52 + ia] + R.tc_add; // row 0 of the table (bS 0 and 4) is zero
+		const s16x2 be = dk_dup(beta);
+		const s16x2 al = dk_dup(bS ? alpha : 0u), bl = as_s2(as_u(be) & R.luma_mask), tc = dk_dup(tc0);
+		if (e == 0) dk_edge<1>(v, al, be, bl, tc, dk_dup((alpha >> 2) + 2), dk_dup(bS == 4 ? 0xffffu : 0u));
+		else if (e == 2) dk_edge<2>(v + 8, al, be, bl, tc, al, dk_dup(bS == 4 ? 0xffffu : 0u));
+		else dk_edge<0>(v + 4 * e, al, be, bl, tc, al, al);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// input: the unfiltered samples of macroblock (x, y) -> registers.  Luma lane: its two rows (16 bytes each); chroma lane:
+// a = {Cb row 2pi, Cr row 2pi}, b = the same of row 2pi+1 (8 bytes each).  LOADS ONLY.
+// ---------------------------------------------------------------------------------------------------------------------
+E264_DEV void dk_fetch(const FrameCtx &f, const DkRole &R, int x, int y, v4u &a, v4u &b)
+{
+	if (!R.chroma) {
+		const gu8 *p = f.cur + (size_t)(y * 16 + 2 * R.pi) * f.sY + x * 16;
+		a = *(const gv4u *)p;
+		b = *(const gv4u *)(p + f.sY);
+	} else {
+		const gu8 *cb = plane_base(f, f.cur, 1) + (size_t)(y * 8 + 2 * R.pi) * f.sC + x * 8, *cr = cb + (f.sC >> 1);
+		const v2u t0 = *(const gv2u *)cb, t1 = *(const gv2u *)cr, t2 = *(const gv2u *)(cb + f.sC), t3 = *(const gv2u *)(cr + f.sC);
+		a.x = t0.x; a.y = t0.y; a.z = t1.x; a.w = t1.y;
+		b.x = t2.x; b.y = t2.y; b.z = t3.x; b.w = t3.y;
+	}
+}
+// the parameter record of macroblock (x, y): 4 pieces of 16 bytes, luma lanes 0..3
+E264_DEV void dk_fetch_prm(const FrameCtx &f, const DkRole &R, int x, int y, v4u &p)
+{
+	if (R.r < 4)
+		p = *(const gv4u *)(f.dbk + (size_t)(y * f.wm + x) * E264_DBK_BYTES + R.r * 16);
+}
+E264_DEV void dk_commit_prm(DkWave &W, const DkRole &R, int x, const v4u &p)
+{
+	if (R.r < 4)
+		*(v4u *)&W.prm[R.g][x & 1][R.r * 4] = p;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// V phase: the vertical edges of macroblock x of the lane's row (a, b: dk_fetch's registers)
+// ---------------------------------------------------------------------------------------------------------------------
+E264_DEV void dk_vpass(DkWave &W, const uint8_t *tc0tab, const DkRole &R, const v4u &ra, const v4u &rb, int x)
+{
+	uint8_t *W8 = (uint8_t *)&W;
+	const int own = R.rowa + (x & 7) * R.slot_mul;
+	const int prev = R.rowa + ((x - 1) & 7) * R.slot_mul + R.slot_mul - 4; // the left neighbour's last 4 bytes (garbage at x = 0: its bS is 0)
+	const uint32_t La = *(const uint32_t *)(W8 + prev), Lb = *(const uint32_t *)(W8 + prev + DK_STRIDE);
+	const uint32_t Ca = *(const uint32_t *)(W8 + prev + R.cr_off), Cb = *(const uint32_t *)(W8 + prev + R.cr_off + DK_STRIDE);
+	// the line as 5 dwords.  Chroma: {Cb left, Cb 0..3, Cb 4,5 | Cr left 6,7, Cr 0..3, Cr 4..7}
+	uint32_t A[5] = {La, ra.x, dk_bfi(R.a1_mask, ra.y, Ca), ra.z, ra.w};
+	uint32_t B[5] = {Lb, rb.x, dk_bfi(R.a1_mask, rb.y, Cb), rb.z, rb.w};
+	s16x2 v[20];
+#pragma unroll
+	for (int k = 0; k < 20; k++)
+		v[k] = as_s2(v_perm(B[k >> 2], A[k >> 2], 0x0c040c00u + (uint32_t)(k & 3) * 0x00010001u)); // (a_k, b_k) as two 16-bit lanes
+	dk_filter(v, (const uint8_t *)W.prm[R.g][x & 1], tc0tab, R, 0);
+#pragma unroll
+	for (int d = 0; d < 5; d++) {
+		const uint32_t t01 = v_perm(as_u(v[4 * d + 1]), as_u(v[4 * d]), 0x06020400u), t23 = v_perm(as_u(v[4 * d + 3]), as_u(v[4 * d + 2]), 0x06020400u);
+		A[d] = v_perm(t23, t01, 0x05040100u);
+		B[d] = v_perm(t23, t01, 0x07060302u);
+	}
+	*(uint32_t *)(W8 + prev) = A[0];
+	*(uint32_t *)(W8 + prev + DK_STRIDE) = B[0];
+	if (!R.chroma) {
+		*(v4u *)(W8 + own) = (v4u){A[1], A[2], A[3], A[4]};
+		*(v4u *)(W8 + own + DK_STRIDE) = (v4u){B[1], B[2], B[3], B[4]};
+	} else {
+		*(uint32_t *)(W8 + prev + DK_CR) = dk_bfi(0x0000ffffu, Ca, A[2]);
+		*(uint32_t *)(W8 + prev + DK_CR + DK_STRIDE) = dk_bfi(0x0000ffffu, Cb, B[2]);
+		*(v2u *)(W8 + own) = (v2u){A[1], dk_bfi(0x0000ffffu, A[2], ra.y)};
+		*(v2u *)(W8 + own + DK_STRIDE) = (v2u){B[1], dk_bfi(0x0000ffffu, B[2], rb.y)};
+		*(v2u *)(W8 + own + DK_CR) = (v2u){A[3], A[4]};
+		*(v2u *)(W8 + own + DK_CR + DK_STRIDE) = (v2u){B[3], B[4]};
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// H phase: the horizontal edges; the lane owns columns 2pi, 2pi+1 (chroma: of Cb and of Cr)
+// ---------------------------------------------------------------------------------------------------------------------
+E264_DEV int dk_haddr(int bT, int bO, int bT2, int bO2, int k)
+{
+	return (k < 4 ? bT + k * DK_STRIDE : k < 10 ? bO + (k - 4) * DK_STRIDE : k < 12 ? bT2 + (k - 4) * DK_STRIDE : bO2 + (k - 4) * DK_STRIDE);
+}
+E264_DEV void dk_hpass(DkWave &W, const uint8_t *tc0tab, const DkRole &R, int x)
+{
+	uint8_t *W8 = (uint8_t *)&W;
+	const int sl = (x & 7) * R.slot_mul;
+	const int bT = R.hT + sl, bO = R.hO + sl, bT2 = R.hT2 + sl, bO2 = R.hO2 + sl;
+	s16x2 v[20];
+#pragma unroll
+	for (int k = 0; k < 20; k++)
+		v[k] = as_s2(v_perm(0, *(const uint16_t *)(W8 + dk_haddr(bT, bO, bT2, bO2, k)), 0x0c010c00u));
+	dk_filter(v, (const uint8_t *)W.prm[R.g][x & 1], tc0tab, R, 1);
+#pragma unroll
+	for (int k = 1; k < 19; k++)
+		*(uint16_t *)(W8 + dk_haddr(bT, bO, bT2, bO2, k)) = (uint16_t)v_perm(0, as_u(v[k]), 0x0c0c0200u);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// output: group q (macroblocks 4q .. 4q+3) of row y, all 16 rows, as 64-byte row pieces (32 for a chroma plane)
+// ---------------------------------------------------------------------------------------------------------------------
+E264_DEV void dk_flush(const DkWave &W, const FrameCtx &f, const DkRole &R, int q, int y)
+{
+	const int s0 = (q * 4) & 7, x0 = q * 4;
+#pragma unroll
+	for (int it = 0; it < 6; it++) { // luma: 16 rows x 4 pieces of 16 bytes
+		const int idx = it * DK_LANES + R.r, row = min(idx >> 2, 15), m = idx & 3;
+		const v4u val = *(const v4u *)&W.y[R.g][row][(s0 + m) * 16];
+		if (idx < 64 && x0 + m < f.wm)
+			*(gv4u *)(f.cur + (size_t)(y * 16 + row) * f.sY + (x0 + m) * 16) = val;
+	}
+#pragma unroll
+	for (int it = 0; it < 3; it++) { // chroma: 2 planes x 8 rows x 2 pieces of 16 bytes (two macroblocks each)
+		const int idx = it * DK_LANES + R.r, pl = min(idx >> 4, 1), row = idx >> 1 & 7, h = idx & 1;
+		const v4u val = *(const v4u *)&W.c[R.g][row][pl * DK_CR + (s0 + 2 * h) * 8];
+		const int n = f.wm - (x0 + 2 * h);
+		gu8 *dst = plane_base(f, f.cur, 1 + pl) + (size_t)(y * 8 + row) * f.sC + (x0 + 2 * h) * 8;
+		if (idx < 32 && n >= 2) *(gv4u *)dst = val;
+		else if (idx < 32 && n == 1) *(gv2u *)dst = (v2u){val.x, val.y};
+	}
+}
+
+// The top strip of the wave's first row y0 (> 0): group q, lanes 0..23 of the wave: 16 luma pieces (rows -4..-1) and
+// 8 chroma pieces (2 planes x rows -2, -1 x 2).  fetch: memory -> register; commit: register -> LDS; flush: LDS -> memory.
+struct DkTopAddr { int lds; gu8 *mem; int n; }; // n: 16-byte piece (2), 8-byte piece (1), nothing (0)
+E264_DEV DkTopAddr dk_top_addr(const FrameCtx &f, int lane, int q, int y0)
+{
+	DkTopAddr t;
+	const int s0 = (q * 4) & 7, x0 = q * 4;
+	if (lane < 16) {
+		const int row = lane >> 2, m = lane & 3;
+		t.lds = (int)offsetof(DkWave, ty) + row * DK_STRIDE + (s0 + m) * 16;
+		t.mem = f.cur + (size_t)(y0 * 16 - 4 + row) * f.sY + (x0 + m) * 16;
+		t.n = x0 + m < f.wm ? 2 : 0;
+	} else {
+		const int i = lane - 16, pl = i >> 2 & 1, row = i >> 1 & 1, h = i & 1;
+		t.lds = (int)offsetof(DkWave, tc) + row * DK_STRIDE + pl * DK_CR + (s0 + 2 * h) * 8;
+		t.mem = plane_base(f, f.cur, 1 + pl) + (size_t)(y0 * 8 - 2 + row) * f.sC + (x0 + 2 * h) * 8;
+		t.n = lane < 24 ? min(max(f.wm - (x0 + 2 * h), 0), 2) : 0;
+	}
+	return t;
+}
+E264_DEV void dk_top_fetch(const FrameCtx &f, int lane, int q, int y0, v4u &tt)
+{
+	const DkTopAddr t = dk_top_addr(f, lane, q, y0);
+	if (t.n == 2) tt = *(const gv4u *)t.mem;
+	else if (t.n == 1) { const v2u h = *(const gv2u *)t.mem; tt.x = h.x; tt.y = h.y; }
+}
+E264_DEV void dk_top_commit(DkWave &W, const FrameCtx &f, int lane, int q, int y0, const v4u &tt)
+{
+	const DkTopAddr t = dk_top_addr(f, lane, q, y0);
+	if (t.n) *(v4u *)((uint8_t *)&W + t.lds) = tt;
+}
+E264_DEV void dk_top_flush(const DkWave &W, const FrameCtx &f, int lane, int q, int y0)
+{
+	const DkTopAddr t = dk_top_addr(f, lane, q, y0);
+	const v4u val = *(const v4u *)((const uint8_t *)&W + t.lds);
+	if (t.n == 2) *(gv4u *)t.mem = val;
+	else if (t.n == 1) *(gv2u *)t.mem = (v2u){val.x, val.y};
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// What a lane does at step t of its wave's walk over rows y0 .. y0+4 (t runs from -2: the pipeline fills first).
+// ---------------------------------------------------------------------------------------------------------------------
+struct DkPlan {
+	int x;             // the row's macroblock at this step
+	bool act;          // V and H phases
+	bool prm_commit, prm_fetch, mb_fetch; // parameters of x+1 -> LDS, of x+2 -> register; samples of x+1 -> registers
+	int top_fetch, top_commit;            // group of the top strip to fetch / commit, -1: none (wave lanes 0..23, when the wave has rows above)
+	int flush, top_flush;                 // group to write out after the H phase, -1: none
+};
+E264_DEV int dk_groups(int wm) { return (wm + 3) >> 2; }
+E264_DEV int dk_last_step(int wm) { return 4 * (dk_groups(wm) + 1); }
+E264_DEV DkPlan dk_plan(int t, const DkRole &R, bool row_ok, bool top, int wm)
+{
+	DkPlan p;
+	const int nq = dk_groups(wm);
+	p.x = t - R.g;
+	p.act = row_ok && p.x >= 0 && p.x < wm;
+	p.prm_commit = row_ok && p.x + 1 >= 0 && p.x + 1 < wm;
+	p.prm_fetch = row_ok && p.x + 2 >= 0 && p.x + 2 < wm;
+	p.mb_fetch = p.prm_commit;
+	// the wave's first row filters group Q's first macroblock at t = 4Q: fetched at t = 4Q - 2, committed at t = 4Q - 1
+	p.top_fetch = (top && ((t + 2) & 3) == 0 && (t + 2) >> 2 < nq) ? (t + 2) >> 2 : -1;
+	p.top_commit = (top && ((t + 1) & 3) == 0 && (t + 1) >> 2 < nq) ? (t + 1) >> 2 : -1;
+	// after step t (a multiple of 4) macroblocks 0 .. t-g-1 of row g are final, rows 13..15 included (the row below has
+	// passed them); whole groups: t/4 - 1 for the first row, t/4 - 2 for the others
+	const bool ft = (t & 3) == 0 && t >= 4;
+	const int qf = (t >> 2) - (R.g ? 2 : 1);
+	p.flush = (ft && row_ok && qf >= 0 && qf < nq) ? qf : -1;
+	p.top_flush = (ft && top && (t >> 2) - 1 < nq) ? (t >> 2) - 1 : -1;
+	return p;
+}
+// macroblocks of row g that have left for memory after the flush of step t
+E264_DEV int dk_progress(int t, int g, int wm) { return min(max(((t >> 2) - (g ? 1 : 0)) * 4, 0), wm); }
+
+} // namespace
+#endif

@@ -35,6 +35,7 @@
 #include "e264_dev.h"
 #include "e264_pred.h"
 #include "e264_dbkp.h"
+#include "e264_dbk.h"
 
 namespace {
 // ---------------------------------------------------------------------------------
@@ -66,52 +67,6 @@ struct __attribute__((aligned(16))) WaveLds { // reconstruction scratch of one w
 	__attribute__((aligned(4))) uint8_t ws[224];   // scaling lists of the cached slice: weightScale4x4[6][16], weightScale8x8[0..1][64]
 	int ws_slice;              // slice index the cache holds (-1: none)
 	int ws_idc;                // its weighted_bipred_idc
-};
-
-#ifndef DBK_RING
-#define DBK_RING 8 // macroblocks of bottom rows each row keeps in LDS for the row below (power of two)
-#endif
-#ifndef DBK_LAG
-#define DBK_LAG 2  // the second row of a wave trails the first by this many macroblocks (>= 2; measured 2: 2.03 ms, 3: 2.09, 4: 2.06)
-#endif
-struct __attribute__((aligned(16))) DbkTile {
-	uint8_t dytile[20 * DY_STRIDE];
-	uint8_t dctile[2][12 * DC_STRIDE];
-	uint8_t prm[E264_DBK_BYTES]; // deblocking parameters of the current macroblock
-};
-// Hand-off to the macroblock row below: the last 4 luma rows / 2 chroma rows of the most recent
-// DBK_RING macroblocks, final for the row below once this row is 2 macroblocks further.
-struct __attribute__((aligned(16))) DbkRing {
-	uint32_t y[4][DBK_RING * 4];      // [row 12..15][mb slot * 4 + dword]
-	uint32_t c[2][2][DBK_RING * 2];   // [plane][row 6..7][mb slot * 2 + dword]
-};
-// Samples that have become FINAL, collected per group of 4 macroblocks and written as whole 64-byte row
-// pieces (16 bytes per lane, 4 consecutive lanes per row).  Writing every macroblock as it is filtered (16-byte
-// rows, then its top rows and left columns again one step later) cost 5.7x the frame size in partial
-// 32/64-byte memory-side write requests (TCC_EA0_WRREQ, profiles/r01_pmc_calibration.txt).
-// What is final after macroblock x of a row: the rows above it (-4..-1, filtered by its top edge) over its 16
-// columns, and its rows 0..11 over columns -4..11 (the left neighbour's last 4 columns now have their right
-// edge filtered).  Rows 12..15 belong to the row below, except where that row cannot take them from the
-// LDS ring (last row of the frame; last row of a round, handed to wave 0 through memory).
-struct __attribute__((aligned(16))) DbkStage {
-	uint32_t y[20][16];    // luma rows -4..15 (index row + 4) x 64 columns
-	uint32_t c[2][10][8];  // chroma planes, rows -2..7 (index row + 2) x 32 columns
-};
-// Input of a PAIR of macroblocks of a row (unfiltered samples, deblocking parameters, header words), fetched with one
-// 16-byte load per lane and piece -- 2 load instructions per pair -- instead of six 4-byte loads per lane and MACROBLOCK:
-// the vector memory path spends 1.5 - 2.5 cycles on every lane of a non-contiguous load whatever its width
-// (tools/calib/load_rate.hip), and with 384 lane-loads per step that, not the filter arithmetic, set the pace.
-struct __attribute__((aligned(16))) DbkIn {
-	uint32_t y[16][8];    // luma rows 0..15 x 2 macroblocks
-	uint32_t c[2][8][4];  // chroma planes, rows 0..7
-	uint32_t prm[2][16];  // E264_DBK_BYTES per macroblock
-	uint32_t hdr[2][4];   // first 16 bytes of the E264Mb records
-};
-struct __attribute__((aligned(16))) DbkLds { // deblocking scratch of one wave = two macroblock rows
-	DbkTile tile[2];     // [half-wave]
-	DbkRing ring[2][2];  // [parity of the row-pair round][half-wave]
-	DbkStage stage[2];   // [half-wave]
-	DbkIn in[2];         // [half-wave]
 };
 
 // -DE264_PHASE_TIMING: wall cycles of the mbpar kernel's phases, summed over all waves (tools/gpu_phase.sh reads them back
@@ -807,387 +762,6 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const Mb
 }
 
 // ---------------------------------------------------------------------------------
-// deblocking wavefront (edge264_deblock.c:284-895): ONE HALF-WAVE PER MACROBLOCK ROW.
-// A wave owns two consecutive rows; lanes 0..31 walk the upper row, lanes 32..63 the lower row
-// DBK_LAG macroblocks behind, so that all 64 lanes filter (16 luma + 8 Cb + 8 Cr lines per row).
-// ---------------------------------------------------------------------------------
-// One edge on 8 values p3 p2 p1 p0 | q0 q1 q2 q3 held in registers; chroma lines use the same
-// code with ap/aq/strong forced off and tc = tC0+1 (deblock.c:95-152, 213-276).  Branch-free per
-// lane; `strong_somewhere` is WAVE-UNIFORM: the bS==4 arithmetic (deblock.c:213-276) is only emitted
-// for macroblock edges (EDGE0) and only executed when some line of the wave has bS 4.
-template <bool EDGE0>
-__device__ __forceinline__ void edge_filter(int &p3, int &p2, int &p1, int &p0, int &q0, int &q1, int &q2, int &q3,
-	int bS, int alpha, int beta, int tc0, bool chroma, bool strong_somewhere)
-{
-	const int dpq = abs(p0 - q0);
-	const bool go = (bS != 0) & (dpq < alpha) & (abs(p1 - p0) < beta) & (abs(q1 - q0) < beta);
-	if (!go) // filterSamplesFlag (8.7.2.3): per-lane; the region below is skipped when no line of the wave passes
-		return;
-	const bool ap = !chroma & (abs(p2 - p0) < beta), aq = !chroma & (abs(q2 - q0) < beta);
-	// bS < 4
-	const int tc = tc0 + (chroma ? 1 : (int)ap + (int)aq);
-	const int delta = clip3i(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
-	const int avg = (p0 + q0 + 1) >> 1;
-	const int w_p0 = clip255(p0 + delta), w_q0 = clip255(q0 - delta);
-	const int w_p1 = p1 + clip3i(-tc0, tc0, (p2 + avg - 2 * p1) >> 1);
-	const int w_q1 = q1 + clip3i(-tc0, tc0, (q2 + avg - 2 * q1) >> 1);
-	if (EDGE0 && strong_somewhere) {
-		// bS == 4
-		const bool strong = bS == 4;
-		const bool small = dpq < (alpha >> 2) + 2;
-		const bool sp = ap & small, sq = aq & small;
-		const int s_p0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (2 * p1 + p0 + q1 + 2) >> 2;
-		const int s_p1 = (p2 + p1 + p0 + q0 + 2) >> 2;
-		const int s_p2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
-		const int s_q0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (2 * q1 + q0 + p1 + 2) >> 2;
-		const int s_q1 = (p0 + q0 + q1 + q2 + 2) >> 2;
-		const int s_q2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
-		p0 = strong ? s_p0 : w_p0;
-		q0 = strong ? s_q0 : w_q0;
-		p1 = (strong ? sp : ap) ? (strong ? s_p1 : w_p1) : p1;
-		q1 = (strong ? sq : aq) ? (strong ? s_q1 : w_q1) : q1;
-		p2 = (strong & sp) ? s_p2 : p2;
-		q2 = (strong & sq) ? s_q2 : q2;
-	} else {
-		p0 = w_p0;
-		q0 = w_q0;
-		p1 = ap ? w_p1 : p1;
-		q1 = aq ? w_q1 : q1;
-	}
-}
-
-// A "line" of 20 samples (positions -4..15) crossing the four luma edges at positions 0,4,8,12 lives
-// in v[0..19].  Chroma lines (positions -4..7, edges at 0 and 4) are parked so that their two edges
-// coincide with luma edges 0 and 2: v[0..5] = pos -4..1, v[10..15] = pos 2..7 (v[6..9] unused).
-// An edge whose bS is 0 on every line of the wave is skipped (wave-uniform branch).
-__device__ __forceinline__ void filter_line(int v[20], const int bS[4], int a_edge0, int a_in, int b_edge0, int b_in, const int tc0[4], bool chroma)
-{
-	if (__any(bS[0] != 0))
-		edge_filter<true>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], bS[0], a_edge0, b_edge0, tc0[0], chroma, __any(bS[0] == 4));
-	if (__any(bS[1] != 0))
-		edge_filter<false>(v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], bS[1], a_in, b_in, tc0[1], chroma, false);
-	if (__any(bS[2] != 0))
-		edge_filter<false>(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], bS[2], a_in, b_in, tc0[2], chroma, false);
-	if (__any(bS[3] != 0))
-		edge_filter<false>(v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19], bS[3], a_in, b_in, tc0[3], chroma, false);
-}
-
-// per-lane state of the macroblock a half-wave is about to filter
-struct DbkRegs { uint32_t va0, va1, vc, vp, vt, hdr; bool act; };
-
-// Loads of macroblock (mbx,mby) that do not depend on the row above.  hl = lane within the half-wave:
-// own luma (2 dwords per lane), own chroma (1), parameters (hl < 16), first header dword (kind, flags).
-// LOADS ONLY: nothing here uses a loaded value (the header used to be decoded here: a memory round trip in the middle
-// of every step) and no register is cleared first (clearing a register that may have a load in flight is a wait too);
-// lanes / cases that do not load keep stale values that dbk_process never looks at (same predicates).
-// gtop: the row above belongs to the previous ROUND of row pairs (last wave -> first wave); that one
-// hand-off goes through global memory (a bounded LDS ring there would close a dependency cycle).
-__device__ __forceinline__ void dbk_prefetch(const FrameCtx &f, int mbx, int mby, int hl, bool act, bool gtop, DbkRegs &r)
-{
-	r.act = act;
-	if (!act)
-		return;
-	r.hdr = *(const gu32 *)(f.mbs + mby * f.wm + mbx); // kind, flags, qp0, qp1
-	gu8 *Yb = f.cur + (size_t)(mby * 16) * f.sY + mbx * 16;
-	gu8 *Cb0 = plane_base(f, f.cur, 1) + (size_t)(mby * 8) * f.sC + mbx * 8;
-	r.va0 = *(const gu32 *)(Yb + (size_t)(hl >> 2) * f.sY + (hl & 3) * 4);
-	r.va1 = *(const gu32 *)(Yb + (size_t)(8 + (hl >> 2)) * f.sY + (hl & 3) * 4);
-	r.vc = *(const gu32 *)(Cb0 + (hl >> 4) * (f.sC >> 1) + (size_t)((hl >> 1) & 7) * f.sC + (hl & 1) * 4);
-	if (hl < 16)
-		r.vp = ((const gu32 *)(f.dbk + (size_t)(mby * f.wm + mbx) * E264_DBK_BYTES))[hl];
-	if (gtop) { // (gtop implies mby > 0) needed even without a top edge to filter: this row writes those rows back
-		if (hl < 16) r.vt = *(const gu32 *)(Yb + (ptrdiff_t)(-4 + (hl >> 2)) * f.sY + (hl & 3) * 4);
-		else if (hl < 24) { int i = hl - 16; r.vt = *(const gu32 *)(Cb0 + (i >> 2) * (f.sC >> 1) + (ptrdiff_t)(-2 + ((i >> 1) & 1)) * f.sC + (i & 1) * 4); }
-	}
-}
-
-// ---- pair input: loads only (registers), commit to LDS, per-macroblock pick-up -------------------------------------
-struct DbkPf { v4u a, b; };
-__device__ __forceinline__ void dbk_prefetch_pair(const FrameCtx &f, int x0, int mby, int hl, DbkPf &p)
-{ // nothing here uses a loaded value; pieces beyond the row's last macroblock are not fetched (and never looked at)
-#ifdef E264_ABL_DBK_NOLOAD // timing ablation
-	if (f.wm > 0) { p.a.x = x0; p.b.x = mby; return; }
-#endif
-	const int left = f.wm - x0; // macroblocks of the pair inside the row: min(left, 2)
-	const gu8 *Yb = f.cur + (size_t)(mby * 16) * f.sY + x0 * 16;
-	if ((hl & 1) < left) // luma piece hl: row hl >> 1, macroblock hl & 1
-		p.a = *(const gv4u *)(Yb + (size_t)(hl >> 1) * f.sY + (hl & 1) * 16);
-	const int a = mby * f.wm + x0;
-	if (hl < 16) { // chroma piece hl: plane hl >> 3, row hl & 7, both macroblocks (8 bytes each)
-		const gu8 *cp = plane_base(f, f.cur, 1 + (hl >> 3)) + (size_t)(mby * 8 + (hl & 7)) * f.sC + x0 * 8;
-		if (left > 1) p.b = *(const gv4u *)cp;
-		else { const v2u h = *(const gv2u *)cp; p.b.x = h.x; p.b.y = h.y; }
-	} else if (hl < 24) { // parameter records: macroblock (hl - 16) >> 2, piece hl & 3
-		if (((hl - 16) >> 2) < left) p.b = *(const gv4u *)(f.dbk + (size_t)(a + ((hl - 16) >> 2)) * E264_DBK_BYTES + (hl & 3) * 16);
-	} else if (hl < 26) { // header records: macroblock hl - 24
-		if (hl - 24 < left) p.b = *(const gv4u *)((const gu8 *)(f.payload - f.h->payload_off + f.h->mbs_off) + (size_t)(a + hl - 24) * sizeof(E264Mb));
-	}
-}
-__device__ __forceinline__ void dbk_commit_pair(DbkIn &I, int hl, const DbkPf &p)
-{
-	*(v4u *)&I.y[hl >> 1][(hl & 1) * 4] = p.a;
-	if (hl < 16) *(v4u *)&I.c[hl >> 3][hl & 7][0] = p.b;
-	else if (hl < 24) *(v4u *)&I.prm[(hl - 16) >> 2][(hl & 3) * 4] = p.b;
-	else if (hl < 26) *(v4u *)&I.hdr[hl - 24][0] = p.b;
-}
-__device__ __forceinline__ void dbk_fetch_mb(const DbkIn &I, int k, int hl, DbkRegs &r)
-{ // macroblock k (0 / 1) of the committed pair -> the per-lane registers dbk_process consumes
-	r.va0 = I.y[hl >> 2][k * 4 + (hl & 3)];
-	r.va1 = I.y[8 + (hl >> 2)][k * 4 + (hl & 3)];
-	r.vc = I.c[hl >> 4][(hl >> 1) & 7][k * 2 + (hl & 1)];
-	r.vp = I.prm[k][hl & 15];
-	r.hdr = I.hdr[k][0];
-}
-// top rows of macroblock (mbx, mby) from memory (first wave of a round: the row above belongs to the previous round)
-__device__ __forceinline__ void dbk_prefetch_top(const FrameCtx &f, int mbx, int mby, int hl, uint32_t &vt)
-{
-	gu8 *Yb = f.cur + (size_t)(mby * 16) * f.sY + mbx * 16;
-	gu8 *Cb0 = plane_base(f, f.cur, 1) + (size_t)(mby * 8) * f.sC + mbx * 8;
-	if (hl < 16) vt = *(const gu32 *)(Yb + (ptrdiff_t)(-4 + (hl >> 2)) * f.sY + (hl & 3) * 4);
-	else if (hl < 24) { int i = hl - 16; vt = *(const gu32 *)(Cb0 + (i >> 2) * (f.sC >> 1) + (ptrdiff_t)(-2 + ((i >> 1) & 1)) * f.sC + (i & 1) * 4); }
-}
-
-// top rows from the LDS ring of the row above: hl 0..15 luma rows -4..-1 (4 dwords each),
-// hl 16..23 chroma rows -2..-1 (2 planes x 2 rows x 2 dwords)
-__device__ __forceinline__ void dbk_load_top(const DbkRing &up, int mbx, int hl, DbkRegs &r)
-{
-	if (!r.act)
-		return;
-	const int slot = mbx & (DBK_RING - 1);
-	if (hl < 16) r.vt = up.y[hl >> 2][slot * 4 + (hl & 3)];
-	else if (hl < 24) { int i = hl - 16; r.vt = up.c[i >> 2][(i >> 1) & 1][slot * 2 + (i & 1)]; }
-}
-
-// Group g (macroblocks 4g .. 4g+nmb-1) of row mby: staged samples -> frame.
-__device__ __forceinline__ void dbk_flush(const DbkStage &S, const FrameCtx &f, int g, int nmb, int mby, int hl, bool has_top, int nrow, int ncrow)
-{
-	// Runs every 4th step only: its per-lane index arithmetic is kept out of the set of loop invariants (opaque lane
-	// index), where it competed for registers with the per-step code and pushed other invariants into scratch.
-	asm volatile("" : "+v"(hl));
-#ifdef E264_ABL_DBK_NOSTORE // timing ablation
-	if (f.wm > 0) return;
-#endif
-	// all LDS reads first (unconditional, clamped indices), then the predicated stores: one LDS round trip instead of five
-	gu8 *Yb = f.cur + (size_t)(mby * 16) * f.sY + g * 64;
-	v4u yv[3], cv[2];
-#pragma unroll
-	for (int it = 0; it < 3; it++) { // 20 rows x 4 pieces of 16 bytes
-		const int idx = min(it * 32 + hl, 79);
-		yv[it] = *(const v4u *)&S.y[idx >> 2][(idx & 3) * 4];
-	}
-#pragma unroll
-	for (int it = 0; it < 2; it++) { // 2 planes x 10 rows x 2 pieces of 16 bytes (= 2 macroblocks each)
-		const int idx = min(it * 32 + hl, 39), pc = idx >= 20, rem = idx - pc * 20;
-		cv[it] = *(const v4u *)&S.c[pc][rem >> 1][(rem & 1) * 4];
-	}
-#pragma unroll
-	for (int it = 0; it < 3; it++) {
-		const int idx = it * 32 + hl, row = (idx >> 2) - 4, c = idx & 3;
-		if (idx < 80 && c < nmb && (row < 0 ? has_top : row < nrow))
-			*(gv4u *)(Yb + (ptrdiff_t)row * f.sY + c * 16) = yv[it];
-	}
-#pragma unroll
-	for (int it = 0; it < 2; it++) {
-		const int idx = it * 32 + hl, pc = idx >= 20, rem = idx - pc * 20, row = (rem >> 1) - 2, c = rem & 1;
-		if (idx < 40 && (row < 0 ? has_top : row < ncrow)) {
-			gu8 *dst = plane_base(f, f.cur, 1 + pc) + (ptrdiff_t)(mby * 8 + row) * f.sC + g * 32 + c * 16;
-			if (nmb >= 2 * c + 2) *(gv4u *)dst = cv[it];
-			else if (nmb == 2 * c + 1) { v2u h = {cv[it].x, cv[it].y}; *(gv2u *)dst = h; }
-		}
-	}
-}
-
-// Filter the macroblock whose samples are in r, publish its bottom rows in `ring`, store it.
-// S: staging of final samples; self_bottom: this row also writes its rows 12..15 (nobody below takes them from the ring)
-__device__ __forceinline__ void dbk_process(DbkTile &L, DbkRing &ring, DbkStage &S, const uint8_t *tc0tab, const FrameCtx &f, int mbx, int mby, int hl,
-	const DbkRegs &r, bool carry, bool last, bool self_bottom PH_PARAMS)
-{
-	const bool has_top = mby > 0;
-	const uint32_t mkind = r.hdr & 255, mflags = r.hdr >> 8 & 255;
-	const bool r_on = r.act && (mflags & E264_MBF_DEBLOCK) && mkind != E264_MB_ABSENT;
-	const bool r_hasL = r_on && (mflags & E264_MBF_EDGE_LEFT), r_hasT = r_on && (mflags & E264_MBF_EDGE_TOP), r_t8 = mflags & E264_MBF_T8x8;
-	const int pl = hl < 16 ? 0 : hl < 24 ? 1 : 2; // line roles: 0..15 luma, 16..23 Cb, 24..31 Cr
-	const int li = hl < 16 ? hl : (hl & 7);
-	const bool chroma = pl != 0;
-	const int cpl = chroma ? pl - 1 : 0;
-	// ---- carry the previous macroblock's right 4 columns, then drop the new samples in the tile
-	uint32_t cv = 0;
-	if (r.act && carry)
-		cv = hl < 16 ? *(const uint32_t *)&L.DYT(li, 12) : *(const uint32_t *)&L.DCT(cpl, li, 4);
-	wave_sync();
-	if (r.act) {
-		if (carry) {
-			if (hl < 16) *(uint32_t *)&L.DYT(li, -4) = cv;
-			else *(uint32_t *)&L.DCT(cpl, li, -4) = cv;
-		}
-		*(uint32_t *)&L.DYT(hl >> 2, (hl & 3) * 4) = r.va0;
-		*(uint32_t *)&L.DYT(8 + (hl >> 2), (hl & 3) * 4) = r.va1;
-		*(uint32_t *)&L.DCT(hl >> 4, (hl >> 1) & 7, (hl & 1) * 4) = r.vc;
-		if (hl < 16) ((uint32_t *)L.prm)[hl] = r.vp;
-		if (has_top && hl < 24) {
-			if (hl < 16) *(uint32_t *)&L.DYT(-4 + (hl >> 2), (hl & 3) * 4) = r.vt;
-			else { int i = hl - 16; *(uint32_t *)&L.DCT(i >> 2, -2 + ((i >> 1) & 1), (i & 1) * 4) = r.vt; }
-		}
-	}
-	wave_sync();
-	PH(4);
-	int v[20];
-	const int seg = chroma ? li >> 1 : li >> 2;
-	if (r_on) {
-		// ---- per-lane parameters of the VERTICAL edges crossing this line (those of the horizontal edges are
-		// fetched after the vertical pass: fewer live registers) -------------------------------------------
-		int bV[4], tV[4];
-#pragma unroll
-		for (int e = 0; e < 4; e++) bV[e] = L.prm[e * 4 + seg];
-		if (!r_hasL) bV[0] = 0;
-		if (chroma || r_t8) bV[1] = bV[3] = 0;
-		const int a0 = L.prm[32 + pl * 3], a1 = L.prm[32 + pl * 3 + 1];
-		const int b0 = L.prm[41 + pl * 3], b1 = L.prm[41 + pl * 3 + 1];
-		const int i0 = L.prm[50 + pl * 3], i1 = L.prm[50 + pl * 3 + 1];
-#pragma unroll
-		for (int e = 0; e < 4; e++) // tc0tab has a zero row for bS 0 and 4 (index bS & 3; see kernel prologue)
-			tV[e] = tc0tab[(bV[e] & 3) * 52 + (e ? i0 : i1)] & (bV[e] < 4 ? 255 : 0);
-		// ---- vertical edges: this lane owns ROW li ----------------------------------------
-		if (!chroma) {
-#pragma unroll
-			for (int d = 0; d < 5; d++) {
-				uint32_t w = *(const uint32_t *)&L.DYT(li, d * 4 - 4);
-				v[d * 4] = w & 255; v[d * 4 + 1] = w >> 8 & 255; v[d * 4 + 2] = w >> 16 & 255; v[d * 4 + 3] = w >> 24;
-			}
-		} else {
-			uint32_t w0 = *(const uint32_t *)&L.DCT(cpl, li, -4), w1 = *(const uint32_t *)&L.DCT(cpl, li, 0), w2 = *(const uint32_t *)&L.DCT(cpl, li, 4);
-			v[0] = w0 & 255; v[1] = w0 >> 8 & 255; v[2] = w0 >> 16 & 255; v[3] = w0 >> 24;
-			v[4] = w1 & 255; v[5] = w1 >> 8 & 255; v[10] = w1 >> 16 & 255; v[11] = w1 >> 24;
-			v[12] = w2 & 255; v[13] = w2 >> 8 & 255; v[14] = w2 >> 16 & 255; v[15] = w2 >> 24;
-			v[6] = v[7] = v[8] = v[9] = v[16] = v[17] = v[18] = v[19] = 0;
-		}
-#ifndef E264_ABL_DBK_NOFILTER
-		filter_line(v, bV, a1, a0, b1, b0, tV, chroma);
-#endif
-		if (!chroma) {
-#pragma unroll
-			for (int d = 0; d < 5; d++)
-				*(uint32_t *)&L.DYT(li, d * 4 - 4) = (uint32_t)v[d * 4] | (uint32_t)v[d * 4 + 1] << 8 | (uint32_t)v[d * 4 + 2] << 16 | (uint32_t)v[d * 4 + 3] << 24;
-		} else {
-			*(uint32_t *)&L.DCT(cpl, li, -4) = (uint32_t)v[0] | (uint32_t)v[1] << 8 | (uint32_t)v[2] << 16 | (uint32_t)v[3] << 24;
-			*(uint32_t *)&L.DCT(cpl, li, 0) = (uint32_t)v[4] | (uint32_t)v[5] << 8 | (uint32_t)v[10] << 16 | (uint32_t)v[11] << 24;
-			*(uint32_t *)&L.DCT(cpl, li, 4) = (uint32_t)v[12] | (uint32_t)v[13] << 8 | (uint32_t)v[14] << 16 | (uint32_t)v[15] << 24;
-		}
-	}
-	wave_sync();
-	PH(5);
-	if (r_on) {
-		// ---- horizontal edges: this lane owns COLUMN li -----------------------------------
-		int bH[4], tH[4];
-#pragma unroll
-		for (int e = 0; e < 4; e++) bH[e] = L.prm[16 + e * 4 + seg];
-		if (!r_hasT) bH[0] = 0;
-		if (chroma || r_t8) bH[1] = bH[3] = 0;
-		const int a0 = L.prm[32 + pl * 3], a2 = L.prm[32 + pl * 3 + 2];
-		const int b0 = L.prm[41 + pl * 3], b2 = L.prm[41 + pl * 3 + 2];
-		const int i0 = L.prm[50 + pl * 3], i2 = L.prm[50 + pl * 3 + 2];
-#pragma unroll
-		for (int e = 0; e < 4; e++)
-			tH[e] = tc0tab[(bH[e] & 3) * 52 + (e ? i0 : i2)] & (bH[e] < 4 ? 255 : 0);
-		if (!chroma) {
-#pragma unroll
-			for (int i = 0; i < 20; i++) v[i] = L.DYT(i - 4, li);
-		} else {
-#pragma unroll
-			for (int i = 0; i < 6; i++) { v[i] = L.DCT(cpl, i - 4, li); v[10 + i] = L.DCT(cpl, i + 2, li); }
-		}
-#ifndef E264_ABL_DBK_NOFILTER
-		filter_line(v, bH, a2, a0, b2, b0, tH, chroma);
-#endif
-		if (!chroma) {
-#pragma unroll
-			for (int i = 1; i < 19; i++) L.DYT(i - 4, li) = (uint8_t)v[i];
-		} else {
-			L.DCT(cpl, -1, li) = (uint8_t)v[3]; L.DCT(cpl, 0, li) = (uint8_t)v[4];
-			L.DCT(cpl, 3, li) = (uint8_t)v[11]; L.DCT(cpl, 4, li) = (uint8_t)v[12];
-		}
-	}
-	wave_sync();
-	PH(6);
-	if (!r.act)
-		return;
-	// ---- publish the bottom rows for the row below: this macroblock's columns 0..11 (chroma 0..3)
-	// and, now that the left edge has been filtered, the previous macroblock's columns 12..15 (4..7)
-	{ // branch-free: every lane makes ONE 4-byte copy tile -> ring (source, destination and predicate selected by its role).
-	  // The three-way role branch with its inner cases ran as six serialised divergent paths, each with its own LDS round trip.
-		const int slot = mbx & (DBK_RING - 1), pslot = (mbx - 1) & (DBK_RING - 1);
-		const bool ra = hl < 16, rb = !ra && hl < 24;
-		const int ia = hl & 3, ib = hl - 16, ic = hl - 24, jc = ic - 4;
-		// source: byte offset inside the DbkTile
-		const int srcA = (12 + (hl >> 2) + 4) * DY_STRIDE + 4 + (ia == 0 ? -4 : (ia - 1) * 4);
-		const int srcB = (int)offsetof(DbkTile, dctile) + (ib >> 2) * 12 * DC_STRIDE + (6 + ((ib >> 1) & 1) + 4) * DC_STRIDE + 4 + ((ib & 1) ? 0 : -4);
-		const int srcC = ic < 4 ? (12 + ic + 4) * DY_STRIDE + 4 + 12
-		                        : (int)offsetof(DbkTile, dctile) + (jc >> 1) * 12 * DC_STRIDE + (6 + (jc & 1) + 4) * DC_STRIDE + 4 + 4;
-		// destination: dword index inside the DbkRing (y[4][DBK_RING*4] then c[2][2][DBK_RING*2]) = base + slot * mul
-		const int dstA = (hl >> 2) * DBK_RING * 4 + (ia == 0 ? 3 : ia - 1);
-		const int dstB = 4 * DBK_RING * 4 + ((ib >> 2) * 2 + ((ib >> 1) & 1)) * DBK_RING * 2 + ((ib & 1) ? 0 : 1);
-		const int dstC = ic < 4 ? ic * DBK_RING * 4 + 3 : 4 * DBK_RING * 4 + ((jc >> 1) * 2 + (jc & 1)) * DBK_RING * 2 + 1;
-		const int src = ra ? srcA : rb ? srcB : srcC;
-		const int dst0 = ra ? dstA : rb ? dstB : dstC;
-		const int mul = ra ? 4 : rb ? 2 : (ic < 4 ? 4 : 2);
-		const bool prev = ra ? ia == 0 : rb ? !(ib & 1) : false; // the previous macroblock's last columns (valid once carried)
-		const bool pred = (ra || rb) ? (prev ? carry : true) : last;
-		const uint32_t val = *(const uint32_t *)((const uint8_t *)&L + src);
-		if (pred) ((uint32_t *)&ring)[dst0 + (prev ? pslot : slot) * mul] = val;
-	}
-	PH(7);
-	// ---- stage what has become final; groups of 4 macroblocks leave as whole 64-byte row pieces ----------
-	const int gxm = mbx & 3;
-	const int nrow = self_bottom ? 16 : 12, ncrow = self_bottom ? 8 : 6;
-	{ // the left neighbour's last 4 columns (tile columns -4..-1), rows 0..nrow-1: ONE predicated copy per lane
-	  // (lanes 0..15 luma row hl, lanes 16..31 chroma plane (hl-16)>>3 row (hl-16)&7), no divergent paths
-		const bool lu = hl < 16;
-		const int cr = (hl - 16) & 7, cp = (hl - 16) >> 3;
-		const int src = lu ? (hl + 4) * DY_STRIDE : (int)offsetof(DbkTile, dctile) + cp * 12 * DC_STRIDE + (cr + 4) * DC_STRIDE;
-		const uint32_t val = *(const uint32_t *)((const uint8_t *)&L + src);
-		uint32_t *dst = lu ? &S.y[hl + 4][gxm ? gxm * 4 - 1 : 15] : &S.c[cp][cr + 2][gxm ? gxm * 2 - 1 : 7];
-		if (carry && (lu ? hl < nrow : cr < ncrow)) *dst = val;
-		if (carry && gxm == 0) { // ... which completes the previous group
-			wave_sync();
-			dbk_flush(S, f, (mbx >> 2) - 1, 4, mby, hl, has_top, nrow, ncrow);
-		}
-	}
-	PH(10);
-	wave_sync();
-	{ // this macroblock: luma rows -4..15 x 4 dwords, chroma 2 planes x rows -2..7 x 2 dwords.  All LDS reads first
-	  // (unconditional, clamped), then the predicated writes.
-		uint32_t yv[3], cv[2];
-#pragma unroll
-		for (int it = 0; it < 3; it++) {
-			const int idx = min(it * 32 + hl, 79);
-			yv[it] = *(const uint32_t *)&L.DYT((idx >> 2) - 4, (idx & 3) * 4);
-		}
-#pragma unroll
-		for (int it = 0; it < 2; it++) {
-			const int idx = min(it * 32 + hl, 39), pc = idx >= 20, rem = idx - pc * 20;
-			cv[it] = *(const uint32_t *)&L.DCT(pc, (rem >> 1) - 2, (rem & 1) * 4);
-		}
-#pragma unroll
-		for (int it = 0; it < 3; it++) {
-			const int idx = it * 32 + hl, row = (idx >> 2) - 4, dw = idx & 3;
-			if (idx < 80 && (row < 0 ? has_top : (row < nrow && (dw < 3 || last))))
-				S.y[row + 4][gxm * 4 + dw] = yv[it];
-		}
-#pragma unroll
-		for (int it = 0; it < 2; it++) {
-			const int idx = it * 32 + hl, pc = idx >= 20, rem = idx - pc * 20, row = (rem >> 1) - 2, dw = rem & 1;
-			if (idx < 40 && (row < 0 ? has_top : (row < ncrow && (dw < 1 || last))))
-				S.c[pc][row + 2][gxm * 2 + dw] = cv[it];
-		}
-	}
-	PH(11);
-	if (last) {
-		wave_sync();
-		dbk_flush(S, f, mbx >> 2, gxm + 1, mby, hl, has_top, nrow, ncrow);
-	}
-}
-
-// ---------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ int lds_load_relaxed(const int *p)
@@ -1372,97 +946,64 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 #endif
 }
 
+// In-loop deblocking: one workgroup per picture, NW waves, each walking five macroblock rows at a time (e264_dbk.h; the
+// phases run on the host in tests/emu).  Waves take the groups of five rows round-robin; a wave waits for the wave that
+// owns the rows above through progress[] (macroblocks of that group's last row that have reached memory).
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jobs)
 {
-	__shared__ DbkLds lds[NW];
-	__shared__ int progress[E264_MAX_ROWS];
+	__shared__ DkWave lds[NW];
+	__shared__ int progress[(E264_MAX_ROWS + DK_ROWS - 1) / DK_ROWS];
 	__shared__ uint8_t tc0tab[4 * 52]; // row (bS & 3): row 0 is all zero (bS 0 and 4 have no tC0)
 	const int lane = lane_id();
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	const int half = lane >> 5, hl = lane & 31;
 	FrameCtx f;
 	if (!open_frame(f, jobs[blockIdx.x]) || !f.dbk)
 		return;
-	for (int i = threadIdx.x; i < f.hm; i += NW * 64)
+	const int nquint = (f.hm + DK_ROWS - 1) / DK_ROWS, wm = f.wm;
+	for (int i = threadIdx.x; i < nquint; i += NW * 64)
 		progress[i] = 0;
 	for (int i = threadIdx.x; i < 4 * 52; i += NW * 64)
 		tc0tab[i] = i < 52 ? 0 : c_tc0[i / 52 - 1][i % 52];
 	__syncthreads();
-	DbkLds &L = lds[wave];
-	const int upw = (wave + NW - 1) % NW; // the wave that owns the row pair above
+	DkWave &W = lds[wave];
+	const DkRole R = dk_role(lane);
+	const int last_step = dk_last_step(wm);
 #pragma unroll 1
-	for (int pr = wave; 2 * pr < f.hm; pr += NW) { // row pair: rows 2*pr (lanes 0..31) and 2*pr+1 (lanes 32..63)
-		const int yA = 2 * pr, yB = yA + 1;
-		const int my_y = yA + half;
-		const bool row_ok = my_y < f.hm;
-		const int par = (pr / NW) & 1, uppar = ((pr - 1 + NW) / NW + 1) & 1; // ring buffers alternate per round
-		DbkRing &myring = L.ring[par][half];
-		const DbkRing &upring = half ? L.ring[par][0] : lds[upw].ring[(wave == 0) ? par ^ 1 : par][1];
-		(void)uppar;
-		// wave 0 takes its top rows from global memory (written by the last wave one round earlier)
-		const bool gtop_wave = wave == 0 && yA > 0;
-		const bool gtop = gtop_wave && half == 0;
-		// the lower row of the last wave is read by wave 0 of the next round from memory, not from the ring
-		const bool handoff = wave == NW - 1 && half == 1 && my_y + 1 < f.hm;
-		const bool self_bottom = handoff || my_y == f.hm - 1;
-		DbkRegs cur = {0, 0, 0, 0, 0, 0, false};
-		DbkPf pf;
-		uint32_t vt_next = 0;
-		PH_DECL;
-		if (gtop_wave) {
-			while (lds_load_relaxed(&progress[yA - 1]) < min(2, f.wm))
-				__builtin_amdgcn_s_sleep(1);
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-		}
-		if (row_ok) dbk_prefetch_pair(f, 0, my_y, hl, pf); // the rows' own samples depend on nothing in this kernel
-		if (gtop && row_ok) dbk_prefetch_top(f, 0, my_y, hl, vt_next);
+	for (int q = wave; q < nquint; q += NW) {
+		const int y0 = q * DK_ROWS, y = y0 + R.g;
+		const bool row_ok = !R.idle && y < f.hm, top = q > 0;
+		const int lastg = min(DK_ROWS, f.hm - y0) - 1; // the row the wave below waits for
+		v4u na = {0, 0, 0, 0}, nb = {0, 0, 0, 0}, np = {0, 0, 0, 0}, tt = {0, 0, 0, 0};
 #pragma unroll 1
-		for (int t = 0; t < f.wm + DBK_LAG; t++) {
-			const int xB = t - DBK_LAG;
-			const int my_x = half ? xB : t;
-			PH(0);
-			if (yA > 0 && t < f.wm) { // the row above must be 2 macroblocks ahead
-				int want = min(t + (gtop_wave ? 3 : 2), f.wm); // wave 0 also prefetches the next macroblock's top rows
-				while (lds_load_relaxed(&progress[yA - 1]) < want)
+		for (int t = -2; t <= last_step; t++) {
+			const DkPlan p = dk_plan(t, R, row_ok, top, wm);
+			if (p.top_fetch >= 0) { // (wave-uniform) the rows above this group of 4 must have reached memory
+				const int need = min(p.top_fetch * 4 + 4, wm);
+				while (lds_load_relaxed(&progress[q - 1]) < need)
 					__builtin_amdgcn_s_sleep(1);
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				dk_top_fetch(f, lane, p.top_fetch, y0, tt);
 			}
-			if (wave != NW - 1 && yB + 1 < f.hm && xB >= DBK_RING - 2) { // ring back-pressure: the slot must have been consumed
-				while (lds_load_relaxed(&progress[yB + 1]) < xB - (DBK_RING - 2))
-					__builtin_amdgcn_s_sleep(1);
-			}
-			if (gtop_wave) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-			else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-			PH(1);
-			cur.act = row_ok && my_x >= 0 && my_x < f.wm;
-			if (cur.act && (my_x & 1) == 0) { // a new pair: the prefetched registers -> LDS, the next pair's loads go out
-				__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the pair was requested 2 macroblocks ago
-				dbk_commit_pair(L.in[half], hl, pf);
-				if (my_x + 2 < f.wm) dbk_prefetch_pair(f, my_x + 2, my_y, hl, pf);
-			}
+			if (p.top_commit >= 0) dk_top_commit(W, f, lane, p.top_commit, y0, tt);
+			if (p.prm_commit) dk_commit_prm(W, R, p.x + 1, np);
+			if (p.prm_fetch) dk_fetch_prm(f, R, p.x + 2, y, np);
+			const v4u ra = na, rb = nb; // requested one step ago
+			if (p.mb_fetch) dk_fetch(f, R, p.x + 1, y, na, nb);
 			wave_sync();
-			if (cur.act) dbk_fetch_mb(L.in[half], my_x & 1, hl, cur);
-			if (gtop) {
-				cur.vt = vt_next;
-				if (row_ok && my_x + 1 < f.wm) dbk_prefetch_top(f, my_x + 1, my_y, hl, vt_next);
-			} else if (my_y > 0)
-				dbk_load_top(upring, my_x, hl, cur);
-			PH(3);
-			dbk_process(L.tile[half], myring, L.stage[half], tc0tab, f, my_x, my_y, hl, cur, my_x > 0, my_x == f.wm - 1, self_bottom PH_ARGS);
-			PH(8);
-			// LDS operations of a wave execute in order: the ring is written before the counter.  The last
-			// wave hands its lower row to the next round through global memory: its stores must be visible.
-			if (wave == NW - 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-			// a row handed over through memory counts the macroblocks whose samples have LEFT the staging buffer
-			const int done = handoff ? (my_x == f.wm - 1 ? f.wm : (my_x & ~3)) : my_x + 1;
-			if (hl == 0 && cur.act)
-				__hip_atomic_store(&progress[my_y], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			PH(9);
+			if (p.act) dk_vpass(W, tc0tab, R, ra, rb, p.x);
+			wave_sync();
+			if (p.act) dk_hpass(W, tc0tab, R, p.x);
+			wave_sync();
+			if ((t & 3) == 0 && t >= 4) {
+				if (p.flush >= 0) dk_flush(W, f, R, p.flush, y);
+				if (p.top_flush >= 0) dk_top_flush(W, f, lane, p.top_flush, y0);
+				// the stores above must be visible to the wave below before the counter moves
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				if (lane == lastg * DK_LANES)
+					__hip_atomic_store(&progress[q], dk_progress(t, lastg, wm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
 		}
-#ifndef E264_PHASE_INTRA
-		PH_FLUSH_DBK(lane);
-#endif
 	}
 }
 
@@ -1511,12 +1052,11 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 	if (marks) hipEventRecord(marks[3], stream);
 	if (side) hipStreamWaitEvent(stream, fork->joined, 0);
 	if (mode & 2) {
-		switch (waves) {
-		case 9: hipLaunchKernelGGL(e264_deblock_kernel<9>, dim3(n_jobs), dim3(576), 0, stream, jobs); break;
-		case 10: hipLaunchKernelGGL(e264_deblock_kernel<10>, dim3(n_jobs), dim3(640), 0, stream, jobs); break;
-		case 12: case 16: hipLaunchKernelGGL(e264_deblock_kernel<12>, dim3(n_jobs), dim3(768), 0, stream, jobs); break; // 16 waves no longer fit the LDS
+		switch (waves) { // waves per picture, five macroblock rows each: 7 = two even rounds over the 68 rows of 1080p
+		case 2: hipLaunchKernelGGL(e264_deblock_kernel<2>, dim3(n_jobs), dim3(128), 0, stream, jobs); break;
 		case 4: hipLaunchKernelGGL(e264_deblock_kernel<4>, dim3(n_jobs), dim3(256), 0, stream, jobs); break;
-		default: hipLaunchKernelGGL(e264_deblock_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs); break;
+		case 8: hipLaunchKernelGGL(e264_deblock_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs); break;
+		default: hipLaunchKernelGGL(e264_deblock_kernel<7>, dim3(n_jobs), dim3(448), 0, stream, jobs); break;
 		}
 	}
 	if (marks) hipEventRecord(marks[4], stream);

@@ -95,3 +95,62 @@ extern "C" __attribute__((visibility("default"))) int e264emu_dbkparam_frame(con
 	}
 	return 0;
 }
+
+// e264_deblock_kernel: dbk = the parameter records (e264emu_dbkparam_frame's output); the picture in dpb[dst_slot] is
+// filtered in place.  Waves are run one after the other (a wave only ever waits for the wave above it), the lanes of a
+// wave phase by phase.
+#include "../../edge264_amd/csrc/e264_dbk.h"
+extern "C" __attribute__((visibility("default"))) int e264emu_deblock_frame(const uint8_t *pkt, uint8_t *const *dpb, uint8_t *dbk)
+{
+	E264Job job = {pkt, dpb, dbk};
+	FrameCtx f;
+	if (!open_frame(f, job) || !f.dbk)
+		return -1;
+	static DkWave W;
+	uint8_t tc0tab[4 * 52];
+	for (int i = 0; i < 4 * 52; i++) tc0tab[i] = i < 52 ? 0 : c_tc0[i / 52 - 1][i % 52];
+	DkRole R[64];
+	for (int lane = 0; lane < 64; lane++) R[lane] = dk_role(lane);
+	const int nquint = (f.hm + DK_ROWS - 1) / DK_ROWS;
+	for (int q = 0; q < nquint; q++) {
+		memset(&W, 0xA5, sizeof(W));
+		const int y0 = q * DK_ROWS;
+		const bool top = q > 0;
+		v4u na[64], nb[64], np[64], tt[64], ra[64], rb[64];
+		memset(na, 0x5A, sizeof(na)); memset(nb, 0x5A, sizeof(nb)); memset(np, 0x5A, sizeof(np)); memset(tt, 0x5A, sizeof(tt));
+		for (int t = -2; t <= dk_last_step(f.wm); t++) {
+			DkPlan p[64];
+			for (int lane = 0; lane < 64; lane++) {
+				const int y = y0 + R[lane].g;
+				p[lane] = dk_plan(t, R[lane], !R[lane].idle && y < f.hm, top, f.wm);
+				if (p[lane].top_fetch >= 0) dk_top_fetch(f, lane, p[lane].top_fetch, y0, tt[lane]);
+				if (p[lane].top_commit >= 0) dk_top_commit(W, f, lane, p[lane].top_commit, y0, tt[lane]);
+				if (p[lane].prm_commit) dk_commit_prm(W, R[lane], p[lane].x + 1, np[lane]);
+				if (p[lane].prm_fetch) dk_fetch_prm(f, R[lane], p[lane].x + 2, y, np[lane]);
+				ra[lane] = na[lane]; rb[lane] = nb[lane];
+				if (p[lane].mb_fetch) dk_fetch(f, R[lane], p[lane].x + 1, y, na[lane], nb[lane]);
+			}
+			for (int lane = 0; lane < 64; lane++)
+				if (p[lane].act) dk_vpass(W, tc0tab, R[lane], ra[lane], rb[lane], p[lane].x);
+			for (int lane = 0; lane < 64; lane++)
+				if (p[lane].act) dk_hpass(W, tc0tab, R[lane], p[lane].x);
+			for (int lane = 0; lane < 64; lane++) {
+				if (p[lane].flush >= 0) dk_flush(W, f, R[lane], p[lane].flush, y0 + R[lane].g);
+				if (p[lane].top_flush >= 0) dk_top_flush(W, f, lane, p[lane].top_flush, y0);
+			}
+		}
+	}
+	return 0;
+}
+
+// the four edge slots of one lane: lines[2][20] (positions -4..15 of the lane's two lines) filtered in place
+extern "C" __attribute__((visibility("default"))) void e264emu_dk_filter(uint8_t *lines, const uint8_t *prm, int lane, int dir)
+{
+	uint8_t tc0tab[4 * 52];
+	for (int i = 0; i < 4 * 52; i++) tc0tab[i] = i < 52 ? 0 : c_tc0[i / 52 - 1][i % 52];
+	const DkRole R = dk_role(lane);
+	s16x2 v[20];
+	for (int k = 0; k < 20; k++) v[k] = (s16x2){(short)lines[k], (short)lines[20 + k]};
+	dk_filter(v, prm, tc0tab, R, dir);
+	for (int k = 0; k < 20; k++) { lines[k] = (uint8_t)v[k].x; lines[20 + k] = (uint8_t)v[k].y; }
+}
