@@ -117,6 +117,9 @@ E264_DEV void dk_edge(s16x2 *v, s16x2 alphaE, s16x2 beta, s16x2 betal, s16x2 tc0
 	const s16x2 d = p0 - q0, dpq = dk_abs(d);
 	// filterSamplesFlag: all three differences below their thresholds <=> all three (difference - threshold) negative
 	const s16x2 go = ((dpq - alphaE) & (dk_abs(p1 - p0) - beta) & (dk_abs(q1 - q0) - beta)) >> 15;
+#ifdef E264_ABL_DBK_NOFILTER // timing ablation
+	if (as_u(go) != 0x12345) return;
+#endif
 	if (!DK_ANY(as_u(go)))
 		return;
 	const s16x2 ap = ((dk_abs(p2 - p0) - betal) >> 15) & go, aq = ((dk_abs(q2 - q0) - betal) >> 15) & go;
@@ -150,27 +153,56 @@ E264_DEV void dk_edge(s16x2 *v, s16x2 alphaE, s16x2 beta, s16x2 betal, s16x2 tc0
 	p0 = np0; q0 = nq0; p1 = np1; q1 = nq1;
 }
 
-// The four edge slots of a line pair held in v[0..19] (positions -4..15): slot e works on v[4e .. 4e+7].
-// Luma lanes: edge e of the macroblock.  Chroma lanes: slot 0 = Cb macroblock edge, 1 = Cb inner edge, 2 = Cr macroblock
-// edge, 3 = Cr inner edge; only p1 p0 q0 q1 = v[4e+2 .. 4e+5] matter there.
-// prm: the macroblock's 64-byte parameter record in LDS; dir 0 vertical edges, 1 horizontal edges.
-E264_DEV void dk_filter(s16x2 *v, const uint8_t *prm, const uint8_t *tc0tab, const DkRole &R, int dir)
+// The parameters of the four edge slots of a lane for one direction, ready for dk_edge.  They are fetched for BOTH
+// directions in one batch at the top of a step (two LDS round trips in all: the record's bytes, then the tC0 table) --
+// fetched where they are used, slot by slot behind the branches that skip idle edges, they cost a dozen exposed LDS
+// latencies per step with only two waves per SIMD to hide them.
+struct DkPrm { s16x2 al[4], be[4], tc[4]; uint32_t bS[4]; s16x2 thr, strong0, strong2; };
+// Luma lanes: slot e = edge e of the macroblock.  Chroma lanes: slot 0 = Cb macroblock edge, 1 = Cb inner edge, 2 = Cr
+// macroblock edge, 3 = Cr inner edge.  prm: the macroblock's 64-byte parameter record in LDS.
+E264_DEV void dk_params(const uint8_t *prm, const uint8_t *tc0tab, const DkRole &R, DkPrm P[2])
+{
+	uint32_t alpha[2][4], beta[2][4], ia[2][4], tc0[2][4];
+#pragma unroll
+	for (int dir = 0; dir < 2; dir++)
+#pragma unroll
+		for (int e = 0; e < 4; e++) {
+			const bool mbe = R.chroma ? !(e & 1) : e == 0;                                   // a macroblock edge: its own alpha / beta / indexA
+			const int bso = (R.chroma ? (e & 1) * 8 : e * 4) + R.seg;                        // chroma inner edge = luma edge 2
+			const int abi = (R.chroma ? (1 + (e >> 1)) * 3 : 0) + (mbe ? 1 + dir : 0);       // [plane * 3 + {inner, left, top}]
+			P[dir].bS[e] = prm[dir * 16 + bso];
+			alpha[dir][e] = prm[32 + abi]; beta[dir][e] = prm[41 + abi]; ia[dir][e] = prm[50 + abi];
+		}
+#pragma unroll
+	for (int dir = 0; dir < 2; dir++)
+#pragma unroll
+		for (int e = 0; e < 4; e++)
+			tc0[dir][e] = tc0tab[(P[dir].bS[e] & 3) * 52 + ia[dir][e]]; // row 0 of the table (bS 0 and 4) is zero
+#pragma unroll
+	for (int dir = 0; dir < 2; dir++) {
+#pragma unroll
+		for (int e = 0; e < 4; e++) {
+			P[dir].al[e] = dk_dup(P[dir].bS[e] ? alpha[dir][e] : 0u);
+			P[dir].be[e] = dk_dup(beta[dir][e]);
+			P[dir].tc[e] = dk_dup(tc0[dir][e] + R.tc_add);
+		}
+		P[dir].thr = dk_dup((alpha[dir][0] >> 2) + 2);
+		P[dir].strong0 = dk_dup(P[dir].bS[0] == 4 ? 0xffffu : 0u);
+		P[dir].strong2 = dk_dup(P[dir].bS[2] == 4 ? 0xffffu : 0u);
+	}
+}
+// The four edge slots of a line pair held in v[0..19] (positions -4..15): slot e works on v[4e .. 4e+7]; in chroma lanes
+// only p1 p0 q0 q1 = v[4e+2 .. 4e+5] matter.
+E264_DEV void dk_filter(s16x2 *v, const DkPrm &P, const DkRole &R)
 {
 #pragma unroll
 	for (int e = 0; e < 4; e++) {
-		const bool mbe = R.chroma ? !(e & 1) : e == 0;                                   // a macroblock edge: its own alpha / beta / indexA
-		const int bso = (R.chroma ? (e & 1) * 8 : e * 4) + R.seg;                        // chroma inner edge = luma edge 2
-		const int abi = (R.chroma ? (1 + (e >> 1)) * 3 : 0) + (mbe ? 1 + dir : 0);       // [plane * 3 + {inner, left, top}]
-		const uint32_t bS = prm[dir * 16 + bso];
-		if (!DK_ANY(bS))
+		if (!DK_ANY(P.bS[e]))
 			continue;
-		const uint32_t alpha = prm[32 + abi], beta = prm[41 + abi], ia = prm[50 + abi];
-		const uint32_t tc0 = tc0tab[(bS & 3) * 52 + ia] + R.tc_add; // row 0 of the table (bS 0 and 4) is zero
-		const s16x2 be = dk_dup(beta);
-		const s16x2 al = dk_dup(bS ? alpha : 0u), bl = as_s2(as_u(be) & R.luma_mask), tc = dk_dup(tc0);
-		if (e == 0) dk_edge<1>(v, al, be, bl, tc, dk_dup((alpha >> 2) + 2), dk_dup(bS == 4 ? 0xffffu : 0u));
-		else if (e == 2) dk_edge<2>(v + 8, al, be, bl, tc, al, dk_dup(bS == 4 ? 0xffffu : 0u));
-		else dk_edge<0>(v + 4 * e, al, be, bl, tc, al, al);
+		const s16x2 bl = as_s2(as_u(P.be[e]) & R.luma_mask);
+		if (e == 0) dk_edge<1>(v, P.al[0], P.be[0], bl, P.tc[0], P.thr, P.strong0);
+		else if (e == 2) dk_edge<2>(v + 8, P.al[2], P.be[2], bl, P.tc[2], P.thr, P.strong2);
+		else dk_edge<0>(v + 4 * e, P.al[e], P.be[e], bl, P.tc[e], P.thr, P.thr);
 	}
 }
 
@@ -178,18 +210,26 @@ E264_DEV void dk_filter(s16x2 *v, const uint8_t *prm, const uint8_t *tc0tab, con
 // input: the unfiltered samples of macroblock (x, y) -> registers.  Luma lane: its two rows (16 bytes each); chroma lane:
 // a = {Cb row 2pi, Cr row 2pi}, b = the same of row 2pi+1 (8 bytes each).  LOADS ONLY.
 // ---------------------------------------------------------------------------------------------------------------------
-E264_DEV void dk_fetch(const FrameCtx &f, const DkRole &R, int x, int y, v4u &a, v4u &b)
+// The SAME four 8-byte loads for every lane, at per-lane addresses (luma: the two halves of each row; chroma: Cb and Cr of
+// each row): with one instruction sequence per role the loads of the second role had to wait until those of the first had
+// returned (they share destination registers: s_waitcnt vmcnt(0) between them, a full memory latency in every step).
+struct DkSrc { const gu8 *base; int d1, d2; }; // row y of the lane's wave: address of macroblock 0, distance to the 2nd piece, to the 2nd row
+E264_DEV DkSrc dk_src(const FrameCtx &f, const DkRole &R, int y)
 {
-	if (!R.chroma) {
-		const gu8 *p = f.cur + (size_t)(y * 16 + 2 * R.pi) * f.sY + x * 16;
-		a = *(const gv4u *)p;
-		b = *(const gv4u *)(p + f.sY);
-	} else {
-		const gu8 *cb = plane_base(f, f.cur, 1) + (size_t)(y * 8 + 2 * R.pi) * f.sC + x * 8, *cr = cb + (f.sC >> 1);
-		const v2u t0 = *(const gv2u *)cb, t1 = *(const gv2u *)cr, t2 = *(const gv2u *)(cb + f.sC), t3 = *(const gv2u *)(cr + f.sC);
-		a.x = t0.x; a.y = t0.y; a.z = t1.x; a.w = t1.y;
-		b.x = t2.x; b.y = t2.y; b.z = t3.x; b.w = t3.y;
-	}
+	DkSrc s;
+	if (!R.chroma) { s.base = f.cur + (size_t)(y * 16 + 2 * R.pi) * f.sY; s.d1 = 8; s.d2 = f.sY; }
+	else { s.base = plane_base(f, f.cur, 1) + (size_t)(y * 8 + 2 * R.pi) * f.sC; s.d1 = f.sC >> 1; s.d2 = f.sC; }
+	return s;
+}
+E264_DEV void dk_fetch(const DkSrc &S, const DkRole &R, int x, v4u &a, v4u &b)
+{
+#ifdef E264_ABL_DBK_NOLOAD // timing ablation
+	if (R.slot_mul) { a = (v4u){(uint32_t)x, 1, 2, 3}; b = a; return; }
+#endif
+	const gu8 *p = S.base + x * R.slot_mul;
+	const v2u t0 = *(const gv2u *)p, t1 = *(const gv2u *)(p + S.d1), t2 = *(const gv2u *)(p + S.d2), t3 = *(const gv2u *)(p + S.d2 + S.d1);
+	a.x = t0.x; a.y = t0.y; a.z = t1.x; a.w = t1.y;
+	b.x = t2.x; b.y = t2.y; b.z = t3.x; b.w = t3.y;
 }
 // the parameter record of macroblock (x, y): 4 pieces of 16 bytes, luma lanes 0..3
 E264_DEV void dk_fetch_prm(const FrameCtx &f, const DkRole &R, int x, int y, v4u &p)
@@ -206,7 +246,7 @@ E264_DEV void dk_commit_prm(DkWave &W, const DkRole &R, int x, const v4u &p)
 // ---------------------------------------------------------------------------------------------------------------------
 // V phase: the vertical edges of macroblock x of the lane's row (a, b: dk_fetch's registers)
 // ---------------------------------------------------------------------------------------------------------------------
-E264_DEV void dk_vpass(DkWave &W, const uint8_t *tc0tab, const DkRole &R, const v4u &ra, const v4u &rb, int x)
+E264_DEV void dk_vpass(DkWave &W, const DkPrm &P, const DkRole &R, const v4u &ra, const v4u &rb, int x)
 {
 	uint8_t *W8 = (uint8_t *)&W;
 	const int own = R.rowa + (x & 7) * R.slot_mul;
@@ -220,7 +260,7 @@ E264_DEV void dk_vpass(DkWave &W, const uint8_t *tc0tab, const DkRole &R, const 
 #pragma unroll
 	for (int k = 0; k < 20; k++)
 		v[k] = as_s2(v_perm(B[k >> 2], A[k >> 2], 0x0c040c00u + (uint32_t)(k & 3) * 0x00010001u)); // (a_k, b_k) as two 16-bit lanes
-	dk_filter(v, (const uint8_t *)W.prm[R.g][x & 1], tc0tab, R, 0);
+	dk_filter(v, P, R);
 #pragma unroll
 	for (int d = 0; d < 5; d++) {
 		const uint32_t t01 = v_perm(as_u(v[4 * d + 1]), as_u(v[4 * d]), 0x06020400u), t23 = v_perm(as_u(v[4 * d + 3]), as_u(v[4 * d + 2]), 0x06020400u);
@@ -249,7 +289,7 @@ E264_DEV int dk_haddr(int bT, int bO, int bT2, int bO2, int k)
 {
 	return (k < 4 ? bT + k * DK_STRIDE : k < 10 ? bO + (k - 4) * DK_STRIDE : k < 12 ? bT2 + (k - 4) * DK_STRIDE : bO2 + (k - 4) * DK_STRIDE);
 }
-E264_DEV void dk_hpass(DkWave &W, const uint8_t *tc0tab, const DkRole &R, int x)
+E264_DEV void dk_hpass(DkWave &W, const DkPrm &P, const DkRole &R, int x)
 {
 	uint8_t *W8 = (uint8_t *)&W;
 	const int sl = (x & 7) * R.slot_mul;
@@ -258,7 +298,7 @@ E264_DEV void dk_hpass(DkWave &W, const uint8_t *tc0tab, const DkRole &R, int x)
 #pragma unroll
 	for (int k = 0; k < 20; k++)
 		v[k] = as_s2(v_perm(0, *(const uint16_t *)(W8 + dk_haddr(bT, bO, bT2, bO2, k)), 0x0c010c00u));
-	dk_filter(v, (const uint8_t *)W.prm[R.g][x & 1], tc0tab, R, 1);
+	dk_filter(v, P, R);
 #pragma unroll
 	for (int k = 1; k < 19; k++)
 		*(uint16_t *)(W8 + dk_haddr(bT, bO, bT2, bO2, k)) = (uint16_t)v_perm(0, as_u(v[k]), 0x0c0c0200u);
@@ -270,6 +310,9 @@ E264_DEV void dk_hpass(DkWave &W, const uint8_t *tc0tab, const DkRole &R, int x)
 E264_DEV void dk_flush(const DkWave &W, const FrameCtx &f, const DkRole &R, int q, int y)
 {
 	const int s0 = (q * 4) & 7, x0 = q * 4;
+#ifdef E264_ABL_DBK_NOSTORE // timing ablation
+	if (f.wm > 0) return;
+#endif
 #pragma unroll
 	for (int it = 0; it < 6; it++) { // luma: 16 rows x 4 pieces of 16 bytes
 		const int idx = it * DK_LANES + R.r, row = min(idx >> 2, 15), m = idx & 3;
@@ -328,17 +371,20 @@ E264_DEV void dk_top_flush(const DkWave &W, const FrameCtx &f, int lane, int q, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// What a lane does at step t of its wave's walk over rows y0 .. y0+4 (t runs from -2: the pipeline fills first).
+// What a lane does at step t of its wave's walk over rows y0 .. y0+4 (t runs from DK_FIRST_STEP: the pipeline fills first).
+#define DK_FIRST_STEP (-4)
 // ---------------------------------------------------------------------------------------------------------------------
 struct DkPlan {
 	int x;             // the row's macroblock at this step
 	bool act;          // V and H phases
-	bool prm_commit, prm_fetch, mb_fetch; // parameters of x+1 -> LDS, of x+2 -> register; samples of x+1 -> registers
+	bool prm_commit, prm_fetch, mb_fetch; // parameters of x+1 -> LDS, of x+3 -> register; samples of x+2 -> registers.  Both register
+	                                      // sets alternate with the parity of t: what a step consumes was requested two steps earlier
 	int top_fetch, top_commit;            // group of the top strip to fetch / commit, -1: none (wave lanes 0..23, when the wave has rows above)
-	int flush, top_flush;                 // group to write out after the H phase, -1: none
+	int flush, top_flush;                 // group to write out before the V phase, -1: none
+	bool publish;                         // (wave-uniform) the groups written at the top of this step are announced at its end
 };
 E264_DEV int dk_groups(int wm) { return (wm + 3) >> 2; }
-E264_DEV int dk_last_step(int wm) { return 4 * (dk_groups(wm) + 1); }
+E264_DEV int dk_last_step(int wm) { return 4 * (dk_groups(wm) + 1) + 1; }
 E264_DEV DkPlan dk_plan(int t, const DkRole &R, bool row_ok, bool top, int wm)
 {
 	DkPlan p;
@@ -346,21 +392,24 @@ E264_DEV DkPlan dk_plan(int t, const DkRole &R, bool row_ok, bool top, int wm)
 	p.x = t - R.g;
 	p.act = row_ok && p.x >= 0 && p.x < wm;
 	p.prm_commit = row_ok && p.x + 1 >= 0 && p.x + 1 < wm;
-	p.prm_fetch = row_ok && p.x + 2 >= 0 && p.x + 2 < wm;
-	p.mb_fetch = p.prm_commit;
+	p.prm_fetch = row_ok && p.x + 3 >= 0 && p.x + 3 < wm;
+	p.mb_fetch = row_ok && p.x + 2 >= 0 && p.x + 2 < wm;
 	// the wave's first row filters group Q's first macroblock at t = 4Q: fetched at t = 4Q - 2, committed at t = 4Q - 1
 	p.top_fetch = (top && ((t + 2) & 3) == 0 && (t + 2) >> 2 < nq) ? (t + 2) >> 2 : -1;
 	p.top_commit = (top && ((t + 1) & 3) == 0 && (t + 1) >> 2 < nq) ? (t + 1) >> 2 : -1;
-	// after step t (a multiple of 4) macroblocks 0 .. t-g-1 of row g are final, rows 13..15 included (the row below has
-	// passed them); whole groups: t/4 - 1 for the first row, t/4 - 2 for the others
-	const bool ft = (t & 3) == 0 && t >= 4;
-	const int qf = (t >> 2) - (R.g ? 2 : 1);
-	p.flush = (ft && row_ok && qf >= 0 && qf < nq) ? qf : -1;
-	p.top_flush = (ft && top && (t >> 2) - 1 < nq) ? (t >> 2) - 1 : -1;
+	// after step t0 (a multiple of 4) macroblocks 0 .. t0-g-1 of row g are final, rows 13..15 included (the row below has
+	// passed them); whole groups: t0/4 - 1 for the first row, t0/4 - 2 for the others.  They are written at the TOP of step
+	// t0 + 1 (their strip slots are reused in that step's V phase at the earliest) and announced at its END: the stores
+	// then had a whole step to drain and the release fence does not wait for them.
+	const int t0 = t - 1;
+	p.publish = (t0 & 3) == 0 && t0 >= 4;
+	const int qf = (t0 >> 2) - (R.g ? 2 : 1);
+	p.flush = (p.publish && row_ok && qf >= 0 && qf < nq) ? qf : -1;
+	p.top_flush = (p.publish && top && (t0 >> 2) - 1 < nq) ? (t0 >> 2) - 1 : -1;
 	return p;
 }
-// macroblocks of row g that have left for memory after the flush of step t
-E264_DEV int dk_progress(int t, int g, int wm) { return min(max(((t >> 2) - (g ? 1 : 0)) * 4, 0), wm); }
+// macroblocks of row g that have left for memory with the flush of step t (a publishing step)
+E264_DEV int dk_progress(int t, int g, int wm) { return min(max((((t - 1) >> 2) - (g ? 1 : 0)) * 4, 0), wm); }
 
 } // namespace
 #endif

@@ -974,10 +974,21 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 		const int y0 = q * DK_ROWS, y = y0 + R.g;
 		const bool row_ok = !R.idle && y < f.hm, top = q > 0;
 		const int lastg = min(DK_ROWS, f.hm - y0) - 1; // the row the wave below waits for
-		v4u na = {0, 0, 0, 0}, nb = {0, 0, 0, 0}, np = {0, 0, 0, 0}, tt = {0, 0, 0, 0};
-#pragma unroll 1
-		for (int t = -2; t <= last_step; t++) {
+		const DkSrc src = dk_src(f, R, y);
+		v4u a0 = {0, 0, 0, 0}, b0 = a0, p0 = a0, a1 = a0, b1 = a0, p1 = a0, tt = a0;
+		PH_DECL;
+		// one step; sa / sb / sp: the register set of this step's parity (samples of x, parameters of x+1, requested two steps ago)
+		auto step = [&](const int t, v4u &sa, v4u &sb, v4u &sp) __attribute__((always_inline)) {
 			const DkPlan p = dk_plan(t, R, row_ok, top, wm);
+			// what earlier steps requested is picked up BEFORE this step's stores are issued: the compiler cannot count
+			// conditional stores, any use of a loaded register after them is an s_waitcnt vmcnt(0) = a full drain
+			if (p.top_commit >= 0) dk_top_commit(W, f, lane, p.top_commit, y0, tt);
+			if (p.prm_commit) dk_commit_prm(W, R, p.x + 1, sp);
+			const v4u ra = sa, rb = sb;
+			asm volatile("" :: "v"(ra), "v"(rb)); // the copies happen here
+			if (p.flush >= 0) dk_flush(W, f, R, p.flush, y);
+			if (p.top_flush >= 0) dk_top_flush(W, f, lane, p.top_flush, y0);
+			PH(0);
 			if (p.top_fetch >= 0) { // (wave-uniform) the rows above this group of 4 must have reached memory
 				const int need = min(p.top_fetch * 4 + 4, wm);
 				while (lds_load_relaxed(&progress[q - 1]) < need)
@@ -985,25 +996,38 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 				dk_top_fetch(f, lane, p.top_fetch, y0, tt);
 			}
-			if (p.top_commit >= 0) dk_top_commit(W, f, lane, p.top_commit, y0, tt);
-			if (p.prm_commit) dk_commit_prm(W, R, p.x + 1, np);
-			if (p.prm_fetch) dk_fetch_prm(f, R, p.x + 2, y, np);
-			const v4u ra = na, rb = nb; // requested one step ago
-			if (p.mb_fetch) dk_fetch(f, R, p.x + 1, y, na, nb);
+			PH(1);
+			if (p.prm_fetch) dk_fetch_prm(f, R, p.x + 3, y, sp);
+			if (p.mb_fetch) dk_fetch(src, R, p.x + 2, sa, sb);
 			wave_sync();
-			if (p.act) dk_vpass(W, tc0tab, R, ra, rb, p.x);
+			PH(2);
+			DkPrm P[2];
+			if (p.act) {
+				dk_params((const uint8_t *)W.prm[R.g][p.x & 1], tc0tab, R, P);
+				PH(3);
+				dk_vpass(W, P[0], R, ra, rb, p.x);
+			}
 			wave_sync();
-			if (p.act) dk_hpass(W, tc0tab, R, p.x);
+			PH(4);
+			if (p.act) dk_hpass(W, P[1], R, p.x);
 			wave_sync();
-			if ((t & 3) == 0 && t >= 4) {
-				if (p.flush >= 0) dk_flush(W, f, R, p.flush, y);
-				if (p.top_flush >= 0) dk_top_flush(W, f, lane, p.top_flush, y0);
-				// the stores above must be visible to the wave below before the counter moves
+			PH(5);
+			if (p.publish) {
+				// the stores at the top of this step must be visible to the wave below before the counter moves
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 				if (lane == lastg * DK_LANES)
 					__hip_atomic_store(&progress[q], dk_progress(t, lastg, wm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
+			PH(6);
+		};
+#pragma unroll 1
+		for (int t = DK_FIRST_STEP; t <= last_step; t += 2) { // unrolled by two: the register sets alternate by name, not by copy
+			step(t, a0, b0, p0);
+			step(t + 1, a1, b1, p1);
 		}
+#ifndef E264_PHASE_INTRA
+		PH_FLUSH_DBK(lane);
+#endif
 	}
 }
 

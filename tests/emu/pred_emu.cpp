@@ -116,28 +116,31 @@ extern "C" __attribute__((visibility("default"))) int e264emu_deblock_frame(cons
 		memset(&W, 0xA5, sizeof(W));
 		const int y0 = q * DK_ROWS;
 		const bool top = q > 0;
-		v4u na[64], nb[64], np[64], tt[64], ra[64], rb[64];
+		v4u na[2][64], nb[2][64], np[2][64], tt[64], ra[64], rb[64];
 		memset(na, 0x5A, sizeof(na)); memset(nb, 0x5A, sizeof(nb)); memset(np, 0x5A, sizeof(np)); memset(tt, 0x5A, sizeof(tt));
-		for (int t = -2; t <= dk_last_step(f.wm); t++) {
+		for (int t = DK_FIRST_STEP; t <= dk_last_step(f.wm); t++) {
+			const int par = t & 1; // the register set of this step
 			DkPlan p[64];
 			for (int lane = 0; lane < 64; lane++) {
 				const int y = y0 + R[lane].g;
 				p[lane] = dk_plan(t, R[lane], !R[lane].idle && y < f.hm, top, f.wm);
+				if (p[lane].flush >= 0) dk_flush(W, f, R[lane], p[lane].flush, y);
+				if (p[lane].top_flush >= 0) dk_top_flush(W, f, lane, p[lane].top_flush, y0);
 				if (p[lane].top_fetch >= 0) dk_top_fetch(f, lane, p[lane].top_fetch, y0, tt[lane]);
 				if (p[lane].top_commit >= 0) dk_top_commit(W, f, lane, p[lane].top_commit, y0, tt[lane]);
-				if (p[lane].prm_commit) dk_commit_prm(W, R[lane], p[lane].x + 1, np[lane]);
-				if (p[lane].prm_fetch) dk_fetch_prm(f, R[lane], p[lane].x + 2, y, np[lane]);
-				ra[lane] = na[lane]; rb[lane] = nb[lane];
-				if (p[lane].mb_fetch) dk_fetch(f, R[lane], p[lane].x + 1, y, na[lane], nb[lane]);
+				if (p[lane].prm_commit) dk_commit_prm(W, R[lane], p[lane].x + 1, np[par][lane]);
+				if (p[lane].prm_fetch) dk_fetch_prm(f, R[lane], p[lane].x + 3, y, np[par][lane]);
+				ra[lane] = na[par][lane]; rb[lane] = nb[par][lane];
+				if (p[lane].mb_fetch) dk_fetch(dk_src(f, R[lane], y), R[lane], p[lane].x + 2, na[par][lane], nb[par][lane]);
 			}
+			static DkPrm P[64][2];
 			for (int lane = 0; lane < 64; lane++)
-				if (p[lane].act) dk_vpass(W, tc0tab, R[lane], ra[lane], rb[lane], p[lane].x);
+				if (p[lane].act) {
+					dk_params((const uint8_t *)W.prm[R[lane].g][p[lane].x & 1], tc0tab, R[lane], P[lane]);
+					dk_vpass(W, P[lane][0], R[lane], ra[lane], rb[lane], p[lane].x);
+				}
 			for (int lane = 0; lane < 64; lane++)
-				if (p[lane].act) dk_hpass(W, tc0tab, R[lane], p[lane].x);
-			for (int lane = 0; lane < 64; lane++) {
-				if (p[lane].flush >= 0) dk_flush(W, f, R[lane], p[lane].flush, y0 + R[lane].g);
-				if (p[lane].top_flush >= 0) dk_top_flush(W, f, lane, p[lane].top_flush, y0);
-			}
+				if (p[lane].act) dk_hpass(W, P[lane][1], R[lane], p[lane].x);
 		}
 	}
 	return 0;
@@ -151,6 +154,8 @@ extern "C" __attribute__((visibility("default"))) void e264emu_dk_filter(uint8_t
 	const DkRole R = dk_role(lane);
 	s16x2 v[20];
 	for (int k = 0; k < 20; k++) v[k] = (s16x2){(short)lines[k], (short)lines[20 + k]};
-	dk_filter(v, prm, tc0tab, R, dir);
+	DkPrm P[2];
+	dk_params(prm, tc0tab, R, P);
+	dk_filter(v, P[dir], R);
 	for (int k = 0; k < 20; k++) { lines[k] = (uint8_t)v[k].x; lines[20 + k] = (uint8_t)v[k].y; }
 }

@@ -19,8 +19,7 @@ tot = sum(out[:12])
 for n, v in zip(names, out[:12]):
     print(f"{n:40s} {v:16d} {100.0 * v / tot:6.2f}%", file=sys.stderr)
 import os
-dn = ["scan + header", "wait for the row above", "recon: neighbour issue etc", "slice cache + coef commit", "residual", "neighbour commit", "luma prediction steps", "chroma prediction", "store", "release fence", "-", "-", "-", "-"] if os.environ.get("E264_PHASE_INTRA") else ["loop top", "waits: row above / ring back-pressure", "-", "pair commit + prefetch, fetch_mb, top rows", "carry + tile fill",
-      "vertical edges", "horizontal edges", "ring publish", "flush of the last group (row end)", "fence, progress", "stage: carried columns (+ flush every 4th step)", "stage: this macroblock", "-", "-"]
+dn = ["scan + header", "wait for the row above", "recon: neighbour issue etc", "slice cache + coef commit", "residual", "neighbour commit", "luma prediction steps", "chroma prediction", "store", "release fence", "-", "-", "-", "-"] if os.environ.get("E264_PHASE_INTRA") else ["plan + flush of final groups", "wait for the wave above + top fetch", "commits, prefetch issue, sync", "parameters", "V phase", "H phase", "fence + publish", "-", "-", "-", "-", "-", "-", "-"]
 tot = sum(out[16:30]) or 1
 print("e264_deblock_kernel", file=sys.stderr)
 for n, v in zip(dn, out[16:30]):
