@@ -40,7 +40,7 @@ struct E264Packet {
 struct E264Device {
 	int ordinal;
 	hipStream_t q;
-	int waves;                 // waves per frame workgroup of the deblocking kernel (2 macroblock rows each)
+	int waves;                 // waves per frame workgroup of the deblocking kernel (5 macroblock rows each): 2, 4, 7 or 8
 	int intra_waves;           // waves per frame workgroup of the intra kernel (1 macroblock row each)
 	int dbg_mode;
 	int side_queue;            // option "side_queue": parameter kernel on a second queue beside the macroblock-parallel kernel
@@ -93,7 +93,7 @@ API int e264hip_device_open(int ordinal, E264Device **out)
 	E264Device *d = new (std::nothrow) E264Device();
 	if (!d) return fail(ENOMEM, "device object");
 	d->ordinal = ordinal;
-	d->waves = 12; // 24 macroblock rows in flight: 1080p = 3 rounds (8 waves: 5 rounds); fits 168 VGPRs with a few spills, still faster
+	d->waves = 7; // 35 macroblock rows in flight: a 1080p picture in two even rounds
 	d->intra_waves = 16; // 16 rows in flight: 1.6 -> 1.1 ms per 256-frame launch (the intra kernel fits 128 VGPRs)
 	d->dbg_mode = 0;
 	d->ktiming = false; d->kev_used = 0;
@@ -160,8 +160,7 @@ API int e264hip_set_option(E264Device *dev, const char *name, int value)
 	}
 	if (!strcmp(name, "waves")) {
 		int prev = dev->waves;
-		if (value == 4 || value == 8 || value == 16) dev->waves = dev->intra_waves = value;
-		else if (value == 9 || value == 10 || value == 12) dev->waves = value; // deblocking kernel only
+		if (value == 2 || value == 4 || value == 7 || value == 8) dev->waves = value; // anything else keeps the setting
 		return prev;
 	}
 	return -1;

@@ -157,7 +157,7 @@ E264_DEV void dk_edge(s16x2 *v, s16x2 alphaE, s16x2 beta, s16x2 betal, s16x2 tc0
 // directions in one batch at the top of a step (two LDS round trips in all: the record's bytes, then the tC0 table) --
 // fetched where they are used, slot by slot behind the branches that skip idle edges, they cost a dozen exposed LDS
 // latencies per step with only two waves per SIMD to hide them.
-struct DkPrm { s16x2 al[4], be[4], tc[4]; uint32_t bS[4]; s16x2 thr, strong0, strong2; };
+struct DkPrm { s16x2 al[4], be[4], tc[4]; uint32_t bS[4]; s16x2 thr, strong0, strong2; }; // al: alpha, or 0 where bS is 0
 // Luma lanes: slot e = edge e of the macroblock.  Chroma lanes: slot 0 = Cb macroblock edge, 1 = Cb inner edge, 2 = Cr
 // macroblock edge, 3 = Cr inner edge.  prm: the macroblock's 64-byte parameter record in LDS.
 E264_DEV void dk_params(const uint8_t *prm, const uint8_t *tc0tab, const DkRole &R, DkPrm P[2])
@@ -197,8 +197,6 @@ E264_DEV void dk_filter(s16x2 *v, const DkPrm &P, const DkRole &R)
 {
 #pragma unroll
 	for (int e = 0; e < 4; e++) {
-		if (!DK_ANY(P.bS[e]))
-			continue;
 		const s16x2 bl = as_s2(as_u(P.be[e]) & R.luma_mask);
 		if (e == 0) dk_edge<1>(v, P.al[0], P.be[0], bl, P.tc[0], P.thr, P.strong0);
 		else if (e == 2) dk_edge<2>(v + 8, P.al[2], P.be[2], bl, P.tc[2], P.thr, P.strong2);

@@ -74,6 +74,7 @@ struct __attribute__((aligned(16))) WaveLds { // reconstruction scratch of one w
 // profile, not a benchmark.
 #ifdef E264_PHASE_TIMING
 __device__ unsigned long long g_phase[32]; // [0..13] mbpar kernel, [16..29] deblock kernel
+__device__ unsigned long long g_timeline[128]; // deblock kernel, workgroup 0: start / end of every group of five rows
 #define PH_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PH(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); ph_acc[k] += t_ - ph_t; ph_t = t_; } while (0)
 #define PH_FLUSH(lane) do { if ((lane) == 0) for (int k_ = 0; k_ < 14; k_++) atomicAdd(&g_phase[k_], ph_acc[k_]); } while (0)
@@ -975,6 +976,9 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 		const bool row_ok = !R.idle && y < f.hm, top = q > 0;
 		const int lastg = min(DK_ROWS, f.hm - y0) - 1; // the row the wave below waits for
 		const DkSrc src = dk_src(f, R, y);
+#ifdef E264_PHASE_TIMING
+		if (blockIdx.x == 0 && lane == 0 && q < 64) g_timeline[2 * q] = __builtin_amdgcn_s_memtime();
+#endif
 		v4u a0 = {0, 0, 0, 0}, b0 = a0, p0 = a0, a1 = a0, b1 = a0, p1 = a0, tt = a0;
 		PH_DECL;
 		// one step; sa / sb / sp: the register set of this step's parity (samples of x, parameters of x+1, requested two steps ago)
@@ -1025,6 +1029,9 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 			step(t, a0, b0, p0);
 			step(t + 1, a1, b1, p1);
 		}
+#ifdef E264_PHASE_TIMING
+		if (blockIdx.x == 0 && lane == 0 && q < 64) g_timeline[2 * q + 1] = __builtin_amdgcn_s_memtime();
+#endif
 #ifndef E264_PHASE_INTRA
 		PH_FLUSH_DBK(lane);
 #endif
@@ -1092,6 +1099,7 @@ extern "C" __attribute__((visibility("default"))) int e264_debug_phase_cycles(un
 {
 	hipDeviceSynchronize();
 	if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_phase), sizeof(g_phase)) != hipSuccess) return -1;
+	if (out32 && hipMemcpyFromSymbol(out32 + 32, HIP_SYMBOL(g_timeline), sizeof(g_timeline)) != hipSuccess) return -1; // the caller has room for 32 + 128
 	if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return -1; }
 	return 0;
 }

@@ -201,17 +201,27 @@ def test_max_frame_size(device, oracle):
     run_stream(device, oracle, 31, "IPB", dict(t8x8=True, i_kinds=ALL_I), 256, 144, passes_split=False)
 
 
-@pytest.mark.parametrize("waves", [4, 8, 9, 10, 12, 16])
-def test_waves_per_frame(device, oracle, waves):
-    """Frames wider than the LDS hand-off ring and taller than one round of row pairs
-    (2 x waves rows): exercises ring wrap, back-pressure and the cross-round hand-off."""
+@pytest.mark.parametrize("waves", [2, 4, 7, 8])
+def test_deblock_waves_per_frame(device, oracle, waves):
+    """Frames wider than the LDS strips and taller than one round of the deblocking kernel (5 x waves rows): strip wrap,
+    the hand-off between waves and between rounds through memory, a last group of fewer than five rows."""
     prev = device.set_option("waves", waves)
     try:
         run_stream(device, oracle, 3, "IPB", dict(t8x8=True, i_kinds=ALL_I), 5, 21)
-        run_stream(device, oracle, 4, "IPP", dict(), 26, 2 * waves * 2 + 3)
+        run_stream(device, oracle, 4, "IPP", dict(), 26, 5 * waves * 2 + 3)
     finally:
         device.set_option("waves", prev)
-        device.set_option("intra_waves", 16)  # "waves" sets both kernels; the intra default is 16
+
+
+@pytest.mark.parametrize("waves", [4, 8, 16])
+def test_intra_waves_per_frame(device, oracle, waves):
+    """Frames taller than one round of the intra wavefront kernel (one macroblock row per wave)."""
+    prev = device.set_option("intra_waves", waves)
+    try:
+        run_stream(device, oracle, 5, "IPB", dict(t8x8=True, i_kinds=ALL_I), 5, 21)
+        run_stream(device, oracle, 6, "IIP", dict(i_kinds=ALL_I), 26, 2 * waves + 3)
+    finally:
+        device.set_option("intra_waves", prev)
 
 
 def test_geometry_and_batch_validation(device):
