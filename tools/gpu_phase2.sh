@@ -15,7 +15,7 @@ L = backend.load_library()
 L.e264_debug_phase_cycles.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 assert L.e264_debug_phase_cycles(out, 0) == 0
 names = ["setup", "barrier + early-out vote", "classify list 0", "barrier", "items list 0", "barrier", "list 1 (all of it)", "residual lists", "barrier", "residual items", "barrier", "flush"]
-tot = sum(out[:12])
+tot = sum(out[:12]) or 1
 for n, v in zip(names, out[:12]):
     print(f"{n:40s} {v:16d} {100.0 * v / tot:6.2f}%", file=sys.stderr)
 import os
