@@ -412,6 +412,7 @@ __device__ __forceinline__ void compute_residual(WaveLds &L, const FrameCtx &f, 
 // C top-right, D top-left)
 // ---------------------------------------------------------------------------------
 #define LP(l, m, r) (((l) + 2 * (m) + (r) + 2) >> 2)
+#include "e264_intra_tab.h"
 
 // neighbours of the macroblock from the frame (un-deblocked, pass R) into the tiles.
 // Out-of-frame positions are never dereferenced; the remapped modes never use them.
@@ -451,6 +452,26 @@ __device__ __forceinline__ void commit_intra_neighbours(WaveLds &L, const IntraN
 	if (lane < 18) L.CT(lane / 9, -1, lane % 9 - 1) = vc;
 	else if (left) L.CT((lane - 32) >> 3, lane & 7, -1) = vc;
 	wave_sync();
+}
+
+// One sample of a 4x4 block from the tap table (tools/gen_intra4x4_table.py): one table read and three sample reads per
+// lane, the same instructions for every directional mode.  The 14-way switch below (kept as the readable statement of the
+// modes; the generator checks the table against the same formulas) ran as two divergent paths per step -- one per block
+// of the step -- each a chain of dependent byte reads: 46 % of the kernel's time on I pictures.
+// tab: c_i4tab in LDS; p = y * 4 + x.
+__device__ __forceinline__ int intra4x4_tab(const WaveLds &L, const uint32_t *tab, int X0, int Y0, int mode, int p)
+{
+	const uint8_t *org = &L.YT(Y0 - 1, X0 - 1);
+	if (mode >= 2 && mode <= 5) { // DC variants: top and left, top, left, none (edge264_intra.c DC modes)
+		const uint32_t w = *(const uint32_t *)(org + 1);
+		const int st = (int)((w & 255) + (w >> 8 & 255) + (w >> 16 & 255) + (w >> 24));
+		const int sl = org[YT_STRIDE] + org[2 * YT_STRIDE] + org[3 * YT_STRIDE] + org[4 * YT_STRIDE];
+		return mode == 2 ? (st + sl + 4) >> 3 : mode == 3 ? (st + 2) >> 2 : mode == 4 ? (sl + 2) >> 2 : 128;
+	}
+	const uint32_t e = tab[mode * 16 + p];
+	const int a = org[e & 255], b = org[e >> 8 & 255], c = org[e >> 16 & 255];
+	const int ty = (int)(e >> 24), sh = ty >> 3;
+	return (a + (ty & 3) * b + ((ty & 4) ? c : 0) + ((1 << sh) >> 1)) >> sh;
 }
 
 // one 4x4 block, lanes 0..15 = (y = lane>>2, x = lane&3); reads/writes the luma tile
@@ -669,7 +690,7 @@ __device__ __forceinline__ int intra_chroma_px(const WaveLds &L, int p, int mode
 // ---------------------------------------------------------------------------------
 // WHICH: 1 = inter and PCM macroblocks only (no dependency inside the frame), 2 = intra only, 3 = all
 template <int WHICH>
-__device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, int mbx, int mby, int lane, const CoefPf &pf PH_PARAMS)
+__device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, int mbx, int mby, int lane, const uint32_t *i4tab, const CoefPf &pf PH_PARAMS)
 { // pf: the macroblock's payload, issued by the caller (coef_issue) as early as it could
 	if (m.kind == E264_MB_ABSENT)
 		return;
@@ -729,7 +750,7 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const Mb
 				int v = 0;
 				if (on) {
 					int x = hl16 & 3, y = hl16 >> 2;
-					v = intra4x4_px(L, X0, Y0, mode, x, y);
+					v = intra4x4_tab(L, i4tab, X0, Y0, mode, hl16);
 					v = clip255(w16(v + L.res[(Y0 + y) * 16 + X0 + x]));
 				}
 				wave_sync();
@@ -876,6 +897,7 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 	__shared__ WaveLds lds[NW];
 	__shared__ __attribute__((aligned(16))) uint32_t hdrs[NW][64 * 8]; // E264Mb records of the 64 macroblocks being scanned, per wave
 	__shared__ int progress[E264_MAX_ROWS]; // macroblocks finished per row
+	__shared__ uint32_t i4tab[14 * 16];     // c_i4tab: read with a per-lane index
 	const int lane = lane_id();
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	FrameCtx f;
@@ -885,6 +907,8 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 		return; // nothing intra in this frame (PCM is handled by the parallel kernel but counted as coded: rare)
 	for (int i = threadIdx.x; i < f.hm; i += NW * 64)
 		progress[i] = 0;
+	for (int i = threadIdx.x; i < 14 * 16; i += NW * 64)
+		i4tab[i] = c_i4tab[i];
 	__syncthreads();
 	WaveLds &L = lds[wave];
 	if (lane == 0) L.ws_slice = -1;
@@ -931,7 +955,7 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 				}
 				PH(1);
-				recon_mb<2>(L, f, mi, x, y, lane, pf PH_ARGS);
+				recon_mb<2>(L, f, mi, x, y, lane, i4tab, pf PH_ARGS);
 				PH(8);
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 				PH(9);
