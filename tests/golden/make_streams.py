@@ -97,7 +97,7 @@ class Synth:
     def __init__(self, g, name, W, H, frames, seed, *, t8x8=False, num_refs=2, weighted_pred=0, weighted_bipred=0,
                  slices=1, deblock=(0,), direct_spatial=1, scaling=False, pcm=0.03, qp=28, cqp=(0, 0), level=3.0,
                  intra_in_inter=0.12, skip=0.15, coef_density=0.35, big_levels=0.03, cbp_zero=0.0, cabac=False, tables=None, mvc=False,
-                 crop=None, longterm=False, mmco_at=(), reorder=0.0, aso=False, pps_switch=False):
+                 crop=None, longterm=False, mmco_at=(), reorder=0.0, aso=False, pps_switch=False, gap_at=()):
         self.g, self.name, self.W, self.H = g, name, W, H
         self.frames, self.rng = frames, random.Random(seed)
         self.t8x8, self.num_refs, self.wp, self.wbp = t8x8, num_refs, weighted_pred, weighted_bipred
@@ -110,6 +110,7 @@ class Synth:
         self.mvc = mvc   # two views (Annex H): base view + NAL 20 slices predicted from their own view and from the base picture
         self.crop = crop            # (left, right, top, bottom) luma samples: frame_cropping (1080 = 1088 - 8)
         self.longterm = longterm    # the IDR picture is marked long-term (long_term_reference_flag): every later list ends with it
+        self.gap_at = gap_at        # reference frames (by count) after which frame_num skips one value: the decoder inserts a "non-existing" frame (8.2.5.2)
         self.mmco_at = mmco_at      # reference frames (by count) that carry memory_management_control_operation 1 (drop the oldest short-term)
         self.reorder = reorder      # probability that a P/B slice moves another short-term picture to the head of list 0
         self.aso = aso              # arbitrary slice order: the slices of a picture are written in shuffled order
@@ -120,7 +121,7 @@ class Synth:
         d = dict(nal_ref_idc=3, nal_unit_type=7, profile_idc=100, constraint_set_flags=[0] * 6, level_idc=self.level,
                  chroma_format_idc=1, bit_depth={"luma": 8, "chroma": 8}, qpprime_y_zero_transform_bypass_flag=0,
                  log2_max_frame_num=self.log2_fn, pic_order_cnt_type=0, log2_max_pic_order_cnt_lsb=self.log2_poc,
-                 max_num_ref_frames=self.num_refs, gaps_in_frame_num_value_allowed_flag=0,
+                 max_num_ref_frames=self.num_refs, gaps_in_frame_num_value_allowed_flag=1 if self.gap_at else 0,
                  pic_size_in_mbs={"width": self.W, "height": self.H}, frame_mbs_only_flag=1, direct_8x8_inference_flag=1)
         if self.crop:
             d["frame_crop_offsets"] = dict(zip(("left", "right", "top", "bottom"), self.crop))
@@ -513,6 +514,7 @@ class Synth:
         n_mbs = self.W * self.H
         frame_num, nrefs, disp = 0, 0, 0
         n_short, n_long, ref_count = 0, 0, 0  # reference pictures in the DPB after each marking step
+        ne_left, after_gap = 0, False         # reference pictures until the non-existing frame slides out of the DPB; first picture after a gap
         # display order: B frames (non-reference) sit between the two reference frames decoded before them
         order, poc = [], 0
         i = 0
@@ -543,10 +545,14 @@ class Synth:
             nref1 = nref0
             if t != "I":
                 nref0, nref1 = r.randint(1, nref0), r.randint(1, nref1)
+            if ne_left > 0 and t != "I":
+                nref0 = nref1 = 1  # a conforming stream never predicts from a non-existing frame: only the newest real one is used
             bounds = sorted(r.sample(range(1, n_mbs), min(self.slices - 1, n_mbs - 1))) if self.slices > 1 else []
             bounds = [0] + bounds + [n_mbs]
             mmco1 = n_short if (is_ref and not idr and ref_count in self.mmco_at and n_short > 1) else 0  # the oldest short-term picture
             reorder = r.randint(2, n_short) if (self.reorder and t != "I" and n_short > 1 and r.random() < self.reorder) else 0
+            if after_gap and t != "I":
+                reorder = 2  # list 0 starts with the non-existing frame (PicNum CurrPicNum - 1): move the real one (CurrPicNum - 2) to the front
             pic_nals = []
             for s in range(len(bounds) - 1):
                 hdr = dict(frame_num=frame_num % (1 << self.log2_fn), poc=p % (1 << self.log2_poc), is_ref=is_ref, idr=idr,
@@ -572,10 +578,12 @@ class Synth:
                                nref0=v0, nref1=v1, idr_pic_id=0, slice_qp_delta=r.randint(-4, 6), view=1,
                                deblock=r.choice(self.deblock), alpha=r.randint(-3, 3), beta=r.randint(-3, 3))
                     out.append(self.slice_nal(fc, t1, bounds[s], bounds[s + 1], s, hdr))
+            after_gap = False
             if is_ref:
                 frame_num += 1
                 nrefs += 1
                 ref_count += 1
+                ne_left = max(0, ne_left - 1)
                 if idr:
                     n_short, n_long = (0, 1) if self.longterm else (1, 0)
                 else:
@@ -584,6 +592,12 @@ class Synth:
                     elif n_short + n_long == self.num_refs and n_short > 0:
                         n_short -= 1  # sliding window (8.2.5.3)
                     n_short += 1
+                if ref_count in self.gap_at:  # the next picture's frame_num skips one value: one non-existing short-term frame joins the DPB
+                    frame_num += 1
+                    if n_short + n_long == self.num_refs and n_short > 0:
+                        n_short -= 1
+                    n_short += 1
+                    ne_left, after_gap = self.num_refs, True
         return b"".join(out)
 
 
@@ -630,6 +644,9 @@ STREAMS = [
     ("aso_slices", 6, 5, "IPPBP", 64, dict(slices=4, aso=True, num_refs=2, deblock=(0, 2))),
     ("pps_switch_scaling", 5, 4, "IPPBPP", 65, dict(pps_switch=True, t8x8=True, scaling=True, num_refs=2, cqp=(1, -2))),
     ("cabac_pps_switch", 5, 4, "IPPPP", 66, dict(cabac=True, pcm=0.0, pps_switch=True, num_refs=2, slices=2)),
+    # frame_num gaps: "non-existing" frames enter the DPB (edge264_headers.c:1122-1144) and push real ones out of the window
+    ("frame_num_gaps", 5, 4, "IPPPPPPP", 67, dict(num_refs=2, gap_at=(2, 5))),
+    ("cabac_frame_num_gaps", 5, 4, "IPPPPPP", 68, dict(cabac=True, pcm=0.0, num_refs=3, gap_at=(3,), t8x8=True)),
     # BASELINE configs[2] / configs[3] geometry, 30 pictures, 1080 lines displayed of 1088 coded (crop bottom 8)
     ("hd1080_ipp30", 120, 68, "I" + "P" * 29, 71, dict(num_refs=2, level=4.0, crop=(0, 0, 0, 8), skip=0.5, coef_density=0.10, intra_in_inter=0.02,
                                                       pcm=0.0, cbp_zero=0.85)),
