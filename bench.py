@@ -148,7 +148,7 @@ def main() -> int:
         W, H = int(parsed[0].hdr["width_mbs"]), int(parsed[0].hdr["height_mbs"])
         args.gop = f"capture:{os.path.basename(args.capture)}:{len(packets)} pictures"
         fill_value = 0
-        args.no_other_configs = args.no_host_packets = True
+        args.no_other_configs = True
     else:
         # ---- synthetic input (same bytes on every rank: seeded) -------------------------------
         gen = synth.StreamSynth(W, H, seed=1234, t8x8=True, i_kinds=ALL_I, num_refs=2, residual_prob=0.3)

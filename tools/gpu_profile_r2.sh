@@ -13,6 +13,9 @@ timeout 400 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TC
 timeout 400 rocprofv3 --pmc TCC_EA0_WRREQ TCC_EA0_WRREQ_64B -d $OUT/pmc_wr -- $B --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_wr.err; echo "wr rc=$?"
 timeout 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM -d $OUT/pmc_sq -- $B --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_sq.err; echo "sq rc=$?"
 cd $REPO
+# the same measurement on the packets of a real 1080p bitstream (reference front end + our emitters, CPU): 30 pictures, one copy per stream
+python tools/make_capture.py tests/golden/streams/hd1080_ipp30.264 /tmp/hd1080_ipp30.e264 > $OUT/capture.log 2>&1
+timeout 600 python bench.py --capture /tmp/hd1080_ipp30.e264 --no-cpu-baseline --steps 2 > $OUT/bench_capture.json 2> $OUT/bench_capture.err; echo "capture rc=$?"
 python tools/rocprof_summary.py $(find $OUT/prof_kt -name '*.db' | head -1) > $OUT/kernel_stats.txt 2>&1; cat $OUT/kernel_stats.txt
 python tools/pmc_summary.py $(find $OUT/pmc_rd $OUT/pmc_wr -name '*.db') --traffic $OUT/hbm_traffic.json --streams 256 --gop IPPPPPPP > $OUT/pmc_hbm_requests.txt 2>&1
 python tools/pmc_summary.py $(find $OUT/pmc_sq -name '*.db') > $OUT/pmc_sq_instruction_mix.txt 2>&1
@@ -20,6 +23,7 @@ timeout 60 tools/calib/valu_rate > $OUT/valu_rate.txt 2>&1
 timeout 60 tools/calib/load_rate > $OUT/load_rate.txt 2>&1
 find $OUT -name '*.db' -size +20M -delete
 python -c "
-import json; d=json.load(open('$OUT/bench_default.json')); print(d['value'], d['bit_exact'], d['roofline']['kernel'], d['roofline']['frac'], d['roofline']['end_to_end'], {k.split('_')[1]: v['ms_per_launch'] for k,v in d['roofline']['kernels'].items()}); print(d['cpu_baseline']['value'], d['cpu_baseline']['per_core'], d['cpu_baseline']['single_process']); print(d['pcie_inclusive'])"
+import json; d=json.load(open('$OUT/bench_default.json')); print(d['value'], d['bit_exact'], d['roofline']['kernel'], d['roofline']['frac'], d['roofline']['end_to_end'], {k.split('_')[1]: v['ms_per_launch'] for k,v in d['roofline']['kernels'].items()}); print(d['cpu_baseline']['value'], d['cpu_baseline']['per_core'], d['cpu_baseline']['single_process']); print(d['pcie_inclusive'])
+c=json.load(open('$OUT/bench_capture.json')); print('capture', c['value'], c['bit_exact'], c['pcie_inclusive'])"
 python -c "
 import json; t=json.load(open('$OUT/hbm_traffic.json')); print({k: (round(v['read_bytes']/1e9,3), round(v['write_bytes']/1e9,3)) for k,v in t['kernels'].items()})"
