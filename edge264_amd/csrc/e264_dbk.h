@@ -47,6 +47,14 @@ struct __attribute__((aligned(16))) DkWave {
 	uint32_t prm[DK_ROWS][2][16];      // parameter records of macroblock x (slot x & 1) of each row
 };
 
+// Final samples leave with a streaming hint: nothing in this kernel reads them again, and every line they would occupy in
+// the L2 pushes out a line of samples still waiting for its neighbours (a line is visited over 8 steps, the L2 of an XCD
+// turns over in about 2: PMC read requests 33.4 M -> 26.1 M x 128 B per 256 pictures, same run time).
+#if !defined(E264_DBK_PLAIN_STORE) && !defined(E264_HOST_INTRINSICS)
+#define DK_STORE4(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define DK_STORE4(p, v) (*(p) = (v))
+#endif
 #ifdef E264_HOST_INTRINSICS
 #define DK_ANY(x) true  // skipping an edge no lane filters is an optimisation only: the masked arithmetic leaves the samples alone
 #else
@@ -316,7 +324,7 @@ E264_DEV void dk_flush(const DkWave &W, const FrameCtx &f, const DkRole &R, int 
 		const int idx = it * DK_LANES + R.r, row = min(idx >> 2, 15), m = idx & 3;
 		const v4u val = *(const v4u *)&W.y[R.g][row][(s0 + m) * 16];
 		if (idx < 64 && x0 + m < f.wm)
-			*(gv4u *)(f.cur + (size_t)(y * 16 + row) * f.sY + (x0 + m) * 16) = val;
+			DK_STORE4((gv4u *)(f.cur + (size_t)(y * 16 + row) * f.sY + (x0 + m) * 16), val);
 	}
 #pragma unroll
 	for (int it = 0; it < 3; it++) { // chroma: 2 planes x 8 rows x 2 pieces of 16 bytes (two macroblocks each)
@@ -324,7 +332,7 @@ E264_DEV void dk_flush(const DkWave &W, const FrameCtx &f, const DkRole &R, int 
 		const v4u val = *(const v4u *)&W.c[R.g][row][pl * DK_CR + (s0 + 2 * h) * 8];
 		const int n = f.wm - (x0 + 2 * h);
 		gu8 *dst = plane_base(f, f.cur, 1 + pl) + (size_t)(y * 8 + row) * f.sC + (x0 + 2 * h) * 8;
-		if (idx < 32 && n >= 2) *(gv4u *)dst = val;
+		if (idx < 32 && n >= 2) DK_STORE4((gv4u *)dst, val);
 		else if (idx < 32 && n == 1) *(gv2u *)dst = (v2u){val.x, val.y};
 	}
 }
