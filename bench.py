@@ -331,8 +331,8 @@ def main() -> int:
         dt2 = time.perf_counter() - t2
         pcie = {"value": round(2 * len(packets) * len(streams) / dt2, 1), "unit": "frames/s",
                 "packet_MB_per_frame": round(float(np.mean([len(p) for p in packets])) / 1e6, 3),
-                "what": "pageable host packets -> per-macroblock validation + staging memcpy on the ONE calling thread -> pinned -> H2D -> "
-                        "4 kernels, asynchronous, one batch per frame index"}
+                "what": "pageable host packets -> per-macroblock validation + copy into page-locked staging by the back end's host threads "
+                        "(E264_HOST_THREADS, default min(15, cores / 2)) -> H2D -> 4 kernels, asynchronous, one batch per frame index"}
         # the front end's own path: packets assembled in place in page-locked memory and validated where they are produced
         for p in packets:
             assert backend.packet_check(p) == 0
