@@ -20,6 +20,7 @@
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
+#include <pthread.h>
 #include <stdio.h>
 
 #define edge264_find_start_code e264ref_find_start_code
@@ -62,6 +63,41 @@ static struct {
 } hip;
 
 static int g_sink_kind = 0;
+
+/* ---- packet buffers of the capture / batch sinks: recycled, never returned to the allocator while decoders run.
+ * A 1080p packet is 0.6 - 2 MB; malloc / free of that size per picture means mmap / munmap (or heap growth and trimming)
+ * per picture, i.e. the process-wide mmap lock and a TLB shootdown across every parser thread: with one packet
+ * allocation per picture 16 host threads parsed 5.7 k pictures/s and 128 threads 4.5 k (tools/gpu_multi.sh).  Buffers
+ * carry their capacity in a 64-byte prefix; e264front_free_packet puts them back on one process-wide list. */
+struct E264PktBuf { size_t cap; struct E264PktBuf *next; char pad[64 - sizeof(size_t) - sizeof(void *)]; };
+static pthread_mutex_t g_pkt_lock = PTHREAD_MUTEX_INITIALIZER;
+static struct E264PktBuf *g_pkt_free = NULL;
+static size_t g_pkt_free_bytes = 0;
+#define E264_PKT_POOL_MAX ((size_t)2 << 30) /* bytes kept for reuse; beyond that buffers go back to the allocator */
+static uint8_t *e264_pkt_alloc(size_t bytes)
+{
+	struct E264PktBuf *b = NULL, **pp;
+	pthread_mutex_lock(&g_pkt_lock);
+	for (pp = &g_pkt_free; *pp; pp = &(*pp)->next)
+		if ((*pp)->cap >= bytes) { b = *pp; *pp = b->next; g_pkt_free_bytes -= b->cap; break; }
+	pthread_mutex_unlock(&g_pkt_lock);
+	if (!b) {
+		size_t cap = (bytes + bytes / 4 + 65535) & ~(size_t)65535; /* pictures of one stream differ in size: a quarter of headroom */
+		b = malloc(sizeof(*b) + cap);
+		if (!b) return NULL;
+		b->cap = cap;
+	}
+	return (uint8_t *)(b + 1);
+}
+static void e264_pkt_free(void *data)
+{
+	if (!data) return;
+	struct E264PktBuf *b = (struct E264PktBuf *)data - 1;
+	pthread_mutex_lock(&g_pkt_lock);
+	if (g_pkt_free_bytes + b->cap <= E264_PKT_POOL_MAX) { b->next = g_pkt_free; g_pkt_free = b; g_pkt_free_bytes += b->cap; b = NULL; }
+	pthread_mutex_unlock(&g_pkt_lock);
+	free(b);
+}
 static int g_device_ordinal = 0;
 static int g_download = 1; /* 0: edge264_get_frame leaves the samples in HBM (decode-to-device use, throughput runs) */
 
@@ -228,7 +264,7 @@ static int e264_finish_frame(E264Emitter *e, int slot)
 	size_t total = (size_t)payload_off + payload_bytes;
 	uint8_t *pkt;
 	if (e->sink_kind == 0) pkt = hip.packet_buffer(e->hip_stream, total);
-	else pkt = malloc(total);
+	else pkt = e264_pkt_alloc(total);
 	if (!pkt)
 		return ENOMEM;
 	E264FrameHdr h = {0};
@@ -382,7 +418,7 @@ PUBLIC void edge264_free(Edge264Decoder **pdec)
 	while (e->cap_head) {
 		struct E264Captured *c = e->cap_head;
 		e->cap_head = c->next;
-		free(c->data);
+		e264_pkt_free(c->data);
 		free(c);
 	}
 	free(e);
@@ -404,7 +440,7 @@ PUBLIC int e264front_take_packet(Edge264Decoder *dec, void **data, size_t *bytes
 	return 0;
 }
 
-PUBLIC void e264front_free_packet(void *data) { free(data); }
+PUBLIC void e264front_free_packet(void *data) { e264_pkt_free(data); }
 
 /* sink 2 (external batcher, edge264_amd/driver/e264_multi.cpp): the device stream that holds this decoder's
  * frames and the process-wide device object, so that the driver can hand the queued packets of MANY decoders

@@ -43,6 +43,22 @@ def physical_cores() -> list[int]:
     return out
 
 
+def cpu_quota() -> float | None:
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), None when unlimited: with a quota below
+    the core count, "one process per core" only measures the quota."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else int(q) / int(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def _decode_loop(args):
     """Worker: decode the fixtures round-robin for `seconds`; returns (frames, wall, cpu_user+sys)."""
     core, seconds, lib_path, blobs = args
@@ -97,7 +113,11 @@ def reference_decoder_baseline(seconds_single: float = 6.0, seconds_all: float =
     if not os.path.exists(lib):
         raise FileNotFoundError(lib)
     blobs = [open(os.path.join(STREAMS, n), "rb").read() for n in FIXTURES_1080P]
-    cores = physical_cores()
+    host_cores = physical_cores()
+    quota = cpu_quota()
+    # one process per core the container can actually run at once: more processes than that only share the quota
+    n = len(host_cores) if quota is None else max(1, min(len(host_cores), int(quota)))
+    cores = host_cores[:: max(1, len(host_cores) // n)][:n]  # spread over the sockets
     f1, w1, c1 = _decode_loop((cores[0], seconds_single, lib, blobs))
     ctx = mp.get_context("fork")
     with ctx.Pool(len(cores)) as pool:
@@ -106,7 +126,9 @@ def reference_decoder_baseline(seconds_single: float = 6.0, seconds_all: float =
     wa = max(r[1] for r in res)
     return {"value": round(fa / wa, 1), "unit": "frames/s", "cores": len(cores), "kind": "reference",
             "per_core": round(fa / wa / len(cores), 2), "single_process": round(f1 / w1, 2),
-            "cpu_model": cpu_model(), "cpu_seconds_total": round(sum(r[2] for r in res) + c1, 1),
+            "cpu_model": cpu_model(), "host_physical_cores": len(host_cores), "cpu_quota_cores": quota,
+            "cpu_seconds_total": round(sum(r[2] for r in res) + c1, 1),
             "sample": f"the unmodified reference decoder (edge264_alloc(0, ...), CAVLC/CABAC parsing + reconstruction + deblocking) on the "
                       f"1080p fixtures {', '.join(FIXTURES_1080P)} decoded in a loop: 1 process for {w1:.1f} s ({f1} frames), then "
-                      f"{len(cores)} processes pinned to distinct physical cores for {wa:.1f} s ({fa} frames)"}
+                      f"{len(cores)} processes pinned to distinct physical cores for {wa:.1f} s ({fa} frames)"
+                      + (f"; the container's CPU quota is {quota:g} cores of the host's {len(host_cores)}" if quota is not None else "")}
