@@ -8,16 +8,14 @@
 //   deblock    edge264_deblock.c:927-1123   (bS / alpha / beta / tC0) and :284-895 (filters)
 //
 // Execution model, four launches per batch of frames (one frame of each of n streams):
-//   e264_dbkparam_kernel one wave64 per 4 macroblocks: deblocking parameters (bS, alpha, beta, indexA) of EVERY
-//                        macroblock from the command packet alone (nothing in the frame is read).
-//   e264_mbpar_kernel    one wave64 per STRIP of E264_MBPAR_STRIP consecutive macroblocks, every strip of every frame
-//                        in parallel: inter prediction + residual (+ PCM), which depend on nothing inside the frame.
-//                        Software pipelined over the strip: motion two macroblocks ahead, reference windows and
-//                        coefficients one ahead; output staged in LDS and written as whole 128-byte rows.
-//   e264_intra_kernel    ONE WORKGROUP PER FRAME, ONE WAVE PER MACROBLOCK ROW: intra MBs only, row y
+//   e264_dbkparam2_kernel (e264_dbkp.h)  one workgroup per 64 macroblocks: deblocking parameters (bS, alpha, beta, indexA)
+//                        of EVERY macroblock from the command packet alone (nothing in the frame is read).
+//   e264_pred_kernel (e264_pred.h)       one workgroup per tile of 16 x 8 macroblocks, one lane per 8x8 block: inter
+//                        prediction + residual (+ PCM), which depend on nothing inside the frame.
+//   e264_intra_kernel (this file)        ONE WORKGROUP PER FRAME, ONE WAVE PER MACROBLOCK ROW: intra MBs only, row y
 //                        may reconstruct macroblock x once row y-1 has finished macroblock x+1.
-//   e264_deblock_kernel  one workgroup per frame, one HALF-wave per macroblock row, same wavefront over every MB:
-//                        the 2-MB lag is exactly what H.264 in-loop deblocking requires.
+//   e264_deblock_kernel (e264_dbk.h)     one workgroup per frame, five macroblock rows per wave in lockstep, two lines
+//                        per lane: the raster dependency order of H.264 in-loop deblocking.
 // Progress counters live in LDS, so the hand-off between rows never leaves the CU: no
 // agent-scope fences, no cross-XCD traffic, no placement assumption.  Chip-level parallelism
 // comes from many independent streams (one frame of each per launch), the north-star workload
@@ -61,7 +59,6 @@ struct __attribute__((aligned(16))) WaveLds { // reconstruction scratch of one w
 	uint8_t ctile[2][9 * CT_STRIDE];
 	uint8_t ftop[32];          // intra 8x8 filtered top  ft[-1..15] at [i+1]
 	uint8_t fleft[8];          // intra 8x8 filtered left
-	uint32_t win[432];         // reference windows of inter prediction (one list at a time): 1 x 21x24, 4 x 13x16 or 16 x 9x12 bytes
 	// residual inputs, staged so that the transforms never wait for memory (see coef_issue / slice_cache)
 	__attribute__((aligned(4))) int16_t coef[408]; // the macroblock's payload: [luma DC 16][chroma DC 8][coded blocks], as in the packet
 	__attribute__((aligned(4))) uint8_t ws[224];   // scaling lists of the cached slice: weightScale4x4[6][16], weightScale8x8[0..1][64]
@@ -96,34 +93,6 @@ struct MbInfo {
 	uint8_t qp[3];
 	uint32_t coded, payload_off, modes_lo, modes_hi;
 };
-__device__ __forceinline__ MbInfo load_mb(cmb_t p)
-{
-	MbInfo m;
-	m.kind = p->kind; m.flags = p->flags; m.chroma_mode = p->chroma_mode; m.i16_mode = p->i16_mode; m.slice = p->slice;
-	m.qp[0] = p->qp[0]; m.qp[1] = p->qp[1]; m.qp[2] = p->qp[2];
-	m.coded = p->coded; m.payload_off = p->payload_off;
-	m.modes_lo = *(const uint32_t __attribute__((address_space(4))) *)&p->modes[0];
-	m.modes_hi = *(const uint32_t __attribute__((address_space(4))) *)&p->modes[4];
-	return m;
-}
-
-// The same header out of a lane-distributed copy of 8 consecutive E264Mb records (lane = mb * 8 + dword, one
-// vector load per strip): v_readlane instead of scalar-memory loads.  Scalar loads share the LGKM counter with
-// LDS and return out of order, so every LDS wait of the inner loop also waited for the headers "prefetched" for
-// later macroblocks (ablation: 40% of the kernel's time was spent with all filters switched off).
-__device__ __forceinline__ MbInfo mb_from_lanes(uint32_t hv, int i)
-{
-	MbInfo m;
-	const uint32_t d0 = __builtin_amdgcn_readlane(hv, i * 8), d1 = __builtin_amdgcn_readlane(hv, i * 8 + 1);
-	const uint32_t d2 = __builtin_amdgcn_readlane(hv, i * 8 + 2);
-	m.kind = d0 & 255; m.flags = d0 >> 8 & 255; m.qp[0] = d0 >> 16 & 255; m.qp[1] = d0 >> 24;
-	m.qp[2] = d1 & 255; m.chroma_mode = d1 >> 8 & 255; m.i16_mode = d1 >> 16 & 255;
-	m.slice = d2 >> 16;
-	m.coded = __builtin_amdgcn_readlane(hv, i * 8 + 3); m.payload_off = __builtin_amdgcn_readlane(hv, i * 8 + 4);
-	m.modes_lo = __builtin_amdgcn_readlane(hv, i * 8 + 5); m.modes_hi = __builtin_amdgcn_readlane(hv, i * 8 + 6);
-	return m;
-}
-
 // The same header out of an LDS copy of the record (8 dwords), all lanes reading the same words (intra kernel: the
 // headers of 64 macroblocks of the row are fetched with two vector loads per lane instead of one scalar-memory round
 // trip per macroblock in the middle of the dependency chain)
@@ -266,15 +235,6 @@ __device__ __forceinline__ void idct8x8_blocks(WaveLds &L, uint32_t coded, const
 // LDS copy of the weighting part of E264SliceParams (the three tables are contiguous there), filled by slice_cache when the
 // slice weights anything: select_weights runs in the middle of a macroblock, after the next macroblock's loads have been
 // issued -- a table read from memory at that point waits for all of them.
-struct __attribute__((aligned(4))) SliceW {
-	int16_t explicit_weights[3][64];
-	int8_t explicit_offsets[3][64];
-	uint8_t implicit_weights[32][32];
-	int8_t weighted_bipred_idc, luma_log2_weight_denom, chroma_log2_weight_denom, pad;
-};
-static_assert(offsetof(E264SliceParams, explicit_offsets) == offsetof(E264SliceParams, explicit_weights) + 384 &&
-              offsetof(E264SliceParams, implicit_weights) == offsetof(E264SliceParams, explicit_weights) + 576 &&
-              offsetof(E264SliceParams, explicit_weights) % 4 == 0, "SliceW mirrors a contiguous range of E264SliceParams");
 // Residual inputs without a memory round trip inside the transforms:
 //   coef_issue / coef_commit  the macroblock's payload (<= 816 bytes) as 4 coalesced dword loads per lane, issued
 //                             while something else runs (mbpar: one macroblock ahead; intra: before the wait for the
@@ -315,23 +275,12 @@ __device__ __forceinline__ void coef_commit(WaveLds &L, const MbInfo &m, int lan
 	if (128 + lane < ndw) c[128 + lane] = pf.v2;
 	if (192 + lane < ndw) c[192 + lane] = pf.v3;
 }
-__device__ __forceinline__ void slice_cache(WaveLds &L, const FrameCtx &f, int slice, int lane, SliceW *W = nullptr)
+__device__ __forceinline__ void slice_cache(WaveLds &L, const FrameCtx &f, int slice, int lane)
 {
 	if (__builtin_amdgcn_readfirstlane(L.ws_slice) == slice) // uniform
 		return;
 	cslice_t s = f.slices + slice;
 	wave_sync();
-	if (W && s->weighted_bipred_idc != 0) { // 400 dwords: explicit weights, offsets, implicit weights
-		const gu32 *gw = (const gu32 *)((const gu8 *)s + offsetof(E264SliceParams, explicit_weights));
-#pragma unroll
-		for (int it = 0; it < 7; it++)
-			if (it * 64 + lane < 400) ((uint32_t *)W)[it * 64 + lane] = gw[it * 64 + lane];
-	}
-	if (W && lane == 0) {
-		W->weighted_bipred_idc = s->weighted_bipred_idc;
-		W->luma_log2_weight_denom = s->luma_log2_weight_denom;
-		W->chroma_log2_weight_denom = s->chroma_log2_weight_denom;
-	}
 	const gu32 *g4 = (const gu32 *)((const gu8 *)s + offsetof(E264SliceParams, weightScale4x4));
 	const gu32 *g8 = (const gu32 *)((const gu8 *)s + offsetof(E264SliceParams, weightScale8x8));
 	if (lane < 24) ((uint32_t *)L.ws)[lane] = g4[lane];
@@ -741,6 +690,7 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const Mb
 			// zig-zag indices per step: (0,-)(1,-)(4,2)(5,3)(6,8)(7,9)(12,10)(13,11)(14,-)(15,-)
 			const uint64_t firsts = 0xfedc765410ull, seconds = 0xffba9832ffull; // one nibble per step
 			const int half = lane >> 4, hl16 = lane & 15;
+#pragma unroll 1
 			for (int t = 0; t < 10; t++) {
 				const int b = (int)((half ? seconds : firsts) >> (4 * t) & 15);
 				const bool on = lane < 32 && !(half == 1 && (t < 2 || t > 7));
@@ -760,6 +710,7 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const Mb
 			}
 		} else { // I8x8, edge264_slice.c:645-668
 			tile_luma = true;
+#pragma unroll 1
 			for (int b = 0; b < 4; b++)
 				intra8x8_block(L, BXf(b * 4), BYf(b * 4), (int)(modes_lo >> (8 * b) & 255), lane);
 		}
