@@ -118,7 +118,11 @@ def reference_decoder_baseline(seconds_single: float = 6.0, seconds_all: float =
     # one process per core the container can actually run at once: more processes than that only share the quota
     n = len(host_cores) if quota is None else max(1, min(len(host_cores), int(quota)))
     cores = host_cores[:: max(1, len(host_cores) // n)][:n]  # spread over the sockets
-    f1, w1, c1 = _decode_loop((cores[0], seconds_single, lib, blobs))
+    saved = os.sched_getaffinity(0)
+    try:
+        f1, w1, c1 = _decode_loop((cores[0], seconds_single, lib, blobs))
+    finally:
+        os.sched_setaffinity(0, saved)  # _decode_loop pins its process: the caller (bench.py) must not stay on one core
     ctx = mp.get_context("fork")
     with ctx.Pool(len(cores)) as pool:
         res = pool.map(_decode_loop, [(c, seconds_all, lib, blobs) for c in cores])
