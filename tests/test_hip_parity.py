@@ -261,3 +261,41 @@ def test_geometry_and_batch_validation(device):
         di.free(); dp.free()
     finally:
         st.close(); st2.close()
+
+
+def test_host_batch_is_vetted_on_every_thread(device, oracle):
+    """A batch from pageable memory is validated and staged by the back end's pool of host threads: a corrupt packet
+    anywhere in it is EINVAL with the worker's message, nothing of the batch is submitted, and a good batch of the same
+    size decodes bit-exactly afterwards."""
+    from edge264_amd import backend
+    w, h, n_streams = 7, 4, 12   # >= 4 packets: the pool is used
+    gens = [synth.StreamSynth(w, h, 80 + k, i_kinds=ALL_I) for k in range(n_streams)]
+    nb = P.frame_bytes(w, h)
+    dpbs = [[np.full(nb + 16, 128, np.uint8) for _ in range(6)] + [None] * 26 for _ in range(n_streams)]
+    sts = [backend.Stream(device, w, h) for _ in range(n_streams)]
+    try:
+        for st in sts:
+            for i in range(6):
+                st.alloc(i)
+                st.fill(i, 128)
+        pkts = [g.next_frame("I") for g in gens]
+        for bad_at in (0, 5, n_streams - 1):
+            broken = list(pkts)
+            raw = bytearray(pkts[bad_at])
+            mbs_off = int(P.Packet(pkts[bad_at]).hdr["mbs_off"])
+            raw[mbs_off + 3 * 32] = 9                      # macroblock kind out of range
+            broken[bad_at] = bytes(raw)
+            with pytest.raises(backend.BackendError, match="macroblock kind"):
+                device.submit_batch_host(sts, broken)
+        device.sync()
+        for st in sts:                                     # nothing was written
+            assert (st.download(int(P.Packet(pkts[0]).hdr["dst_slot"])) == 128).all()
+        for k, pkt in enumerate(pkts):
+            oracle.decode_frame(pkt, dpbs[k], 3)
+        device.submit_batch_host(sts, pkts)
+        for k, st in enumerate(sts):
+            slot = int(P.Packet(pkts[k]).hdr["dst_slot"])
+            assert np.array_equal(st.download(slot), dpbs[k][slot][:nb]), f"stream {k}"
+    finally:
+        for st in sts:
+            st.close()
