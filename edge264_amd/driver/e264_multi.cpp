@@ -10,9 +10,11 @@
 // (the first version advanced all decoders by one picture between two barriers: every round took as long as its slowest
 // picture -- an I picture with CABAC -- and 64 threads parsed 4.7 k pictures/s where one parses 400).
 //
-//   e264_multi --front <libedge264_hipfront.so> --hip <libedge264_hip.so> [--device N] [--repeat R]
+//   e264_multi --front <libedge264_hipfront.so> --hip <libedge264_hip.so> [--device N | --devices 0,1,...] [--repeat R]
 //              [--threads T] [--out DIR] [--dump-packets FILE] [--parse-only] [--no-download] a.264 b.264 ...
 //
+// --devices: decoder k lives on GPU devices[k mod N] (streams are independent: no traffic between GPUs); every
+// GPU has its own submitter thread and its own batches.
 // --out writes s<k>.yuv (cropped Y, Cb, Cr planes of every output frame, as README.md:126-155 of the reference
 // does); --dump-packets appends every command packet (self-describing: E264FrameHdr.total_bytes) = the capture
 // format of SURVEY.md 8(f) rank 2.  Prints one JSON line with the throughput.
@@ -59,6 +61,7 @@ struct Front {
 	void (*free_packet)(void *);
 	void *(*stream)(void *);
 	void *(*device)(void);
+	void *(*device_of)(void *);
 };
 struct Hip {
 	int (*submit_batch_host)(void *, void **, const void **, const size_t *, int, int);
@@ -84,6 +87,7 @@ struct Stream {
 	struct Pkt { void *data; size_t bytes; };
 	std::deque<Pkt> q;     // parsed, not yet submitted (guarded by the queue mutex)
 	bool finished = false; // its worker will queue nothing more
+	int dev_index = 0;     // which of --devices holds its frames
 };
 
 static void write_frame(FILE *f, const Edge264Frame &fr)
@@ -111,6 +115,7 @@ int main(int argc, char **argv)
 	signal(SIGSEGV, on_crash);
 	signal(SIGBUS, on_crash);
 	std::string front_path, hip_path, out_dir, dump_path;
+	std::vector<int> devices; // --devices
 	int ahead = 3; // --ahead K: pictures a decoder may be parsed ahead of the device
 	int device = 0, repeat = 1, n_threads = 1, loops = 1; // --loops K: every stream is played K times back to back (steady state)
 	bool no_download = false; // --no-download: output frames stay in HBM (edge264_get_frame does not copy them back)
@@ -119,7 +124,8 @@ int main(int argc, char **argv)
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
 		auto next = [&]() -> std::string { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
-		if (a == "--front") front_path = next();
+		if (a == "--devices") { std::string v = next(); for (size_t p = 0; p < v.size();) { size_t e = v.find(',', p); if (e == std::string::npos) e = v.size(); devices.push_back(atoi(v.substr(p, e - p).c_str())); p = e + 1; } }
+		else if (a == "--front") front_path = next();
 		else if (a == "--hip") hip_path = next();
 		else if (a == "--device") device = atoi(next().c_str());
 		else if (a == "--repeat") repeat = atoi(next().c_str());
@@ -146,13 +152,13 @@ int main(int argc, char **argv)
 	bind(fl, "edge264_free", F.free_dec); bind(fl, "edge264_find_start_code", F.find_start_code);
 	bind(fl, "e264front_set_sink", F.set_sink); bind(fl, "e264front_set_device", F.set_device); bind(fl, "e264front_set_download", F.set_download);
 	bind(fl, "e264front_take_packet", F.take_packet); bind(fl, "e264front_free_packet", F.free_packet);
-	bind(fl, "e264front_stream", F.stream); bind(fl, "e264front_device", F.device);
+	bind(fl, "e264front_stream", F.stream); bind(fl, "e264front_device", F.device); bind(fl, "e264front_device_of", F.device_of);
 	if (!parse_only) {
 	bind(hl, "e264hip_submit_batch_host", H.submit_batch_host); bind(hl, "e264hip_device_sync", H.device_sync);
 	bind(hl, "e264hip_last_error", H.last_error);
 	}
 
-	F.set_device(device);
+	if (devices.empty()) devices.push_back(device);
 	F.set_sink(parse_only ? 1 : 2);
 	F.set_download(no_download ? 0 : 1);
 	std::vector<Stream> S;
@@ -172,6 +178,8 @@ int main(int argc, char **argv)
 			const uint8_t *p = F.find_start_code(t.data.data(), t.end, 0);
 			t.nal = p < t.end ? p + 3 : t.end;
 			t.first_nal = t.nal; t.loops_left = loops - 1;
+			t.dev_index = (int)((S.size() - 1) % devices.size());
+			F.set_device(devices[(size_t)t.dev_index]); // the decoder is bound to the GPU selected when it is allocated
 			t.dec = F.alloc(0, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
 			if (!t.dec) { fprintf(stderr, "e264_multi: edge264_alloc failed (no MI355X / back end?)\n"); return 2; }
 			if (!out_dir.empty()) {
@@ -180,8 +188,12 @@ int main(int argc, char **argv)
 				if (!t.out) { perror(o.c_str()); return 2; }
 			}
 		}
-	void *dev = parse_only ? nullptr : F.device();
-	if (!dev && !parse_only) { fprintf(stderr, "e264_multi: no device\n"); return 2; }
+	std::vector<void *> dev_obj(devices.size(), nullptr);
+	if (!parse_only)
+		for (Stream &s : S) {
+			dev_obj[(size_t)s.dev_index] = F.device_of(s.dec);
+			if (!dev_obj[(size_t)s.dev_index]) { fprintf(stderr, "e264_multi: no device\n"); return 2; }
+		}
 	FILE *dump = dump_path.empty() ? nullptr : fopen(dump_path.c_str(), "wb");
 
 	auto drain = [&](Stream &s) {
@@ -192,10 +204,6 @@ int main(int argc, char **argv)
 		}
 	};
 	long rounds = 0, packets = 0, total_frames = 0;
-	std::vector<void *> streams;
-	std::vector<const void *> hpk;
-	std::vector<size_t> hsz;
-	std::vector<Stream *> owner;
 	std::mutex mu;                       // guards every Stream::q / finished and the counters below
 	std::condition_variable cv_room;     // a packet left a queue (workers wait for room / for their packets to be on the device)
 	std::condition_variable cv_ready;    // a packet entered a queue, or a decoder finished (the submitter waits)
@@ -220,7 +228,7 @@ int main(int argc, char **argv)
 				cv_room.wait(lk, [&] { return (int)s.q.size() < ahead; });
 				s.q.push_back({pkt, bytes});
 				queued++;
-				cv_ready.notify_one();
+				cv_ready.notify_all();
 				return true;
 			}
 		}
@@ -237,13 +245,13 @@ int main(int argc, char **argv)
 				Stream &s = S[i];
 				if (s.finished) continue;
 				if (advance(s)) any = true;
-				else { std::lock_guard<std::mutex> lk(mu); s.finished = true; cv_ready.notify_one(); }
+				else { std::lock_guard<std::mutex> lk(mu); s.finished = true; cv_ready.notify_all(); }
 			}
 		}
 		for (size_t i = (size_t)k; i < S.size(); i += (size_t)n_threads) { wait_submitted(S[i]); drain(S[i]); }
 		std::lock_guard<std::mutex> lk(mu);
 		workers_left--;
-		cv_ready.notify_one();
+		cv_ready.notify_all();
 	};
 	auto t0 = std::chrono::steady_clock::now();
 	std::vector<std::thread> pool;
@@ -251,37 +259,51 @@ int main(int argc, char **argv)
 	// 2. the submitter: one batch = the oldest queued picture of every decoder that has one.  It waits until most of the
 	//    decoders that are still parsing have a picture ready (or 2 ms have passed): a batch costs the device about one
 	//    picture's dependency chain whatever its size, so small batches would only queue up device time.
+	std::mutex dump_mu;
+	auto submitter = [&](int di) {
+	std::vector<void *> streams;
+	std::vector<const void *> hpk;
+	std::vector<size_t> hsz;
+	std::vector<Stream *> owner;
+	long my_packets = 0, my_rounds = 0;
 	for (;;) {
 		streams.clear(); hpk.clear(); hsz.clear(); owner.clear();
 		{
 			std::unique_lock<std::mutex> lk(mu);
-			auto ready = [&] { size_t n = 0; for (Stream &s : S) n += !s.q.empty(); return n; };
-			auto parsing = [&] { size_t n = 0; for (Stream &s : S) n += !s.finished; return n; };
+			auto ready = [&] { size_t n = 0; for (Stream &s : S) n += s.dev_index == di && !s.q.empty(); return n; };
+			auto parsing = [&] { size_t n = 0; for (Stream &s : S) n += s.dev_index == di && !s.finished; return n; };
 			cv_ready.wait(lk, [&] { return ready() > 0 || workers_left == 0; });
 			if (ready() == 0 && workers_left == 0) break;
 			auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
 			cv_ready.wait_until(lk, deadline, [&] { return ready() * 4 >= parsing() * 3 || workers_left == 0; });
 			for (Stream &s : S)
-				if (!s.q.empty()) { owner.push_back(&s); hpk.push_back(s.q.front().data); hsz.push_back(s.q.front().bytes); }
+				if (s.dev_index == di && !s.q.empty()) { owner.push_back(&s); hpk.push_back(s.q.front().data); hsz.push_back(s.q.front().bytes); }
 		}
 		for (size_t i = 0; i < owner.size(); i++) {
-			if (dump) { // capture file: the packets of all decoders interleaved, each tagged with its decoder (E264FrameHdr.stream_id, byte 76)
+			if (dump) { std::lock_guard<std::mutex> dl(dump_mu); // capture file: the packets of all decoders interleaved, each tagged with its decoder (E264FrameHdr.stream_id, byte 76)
 				uint32_t sid = (uint32_t)(owner[i] - &S[0]);
 				memcpy((uint8_t *)hpk[i] + 76, &sid, 4);
 				fwrite(hpk[i], 1, hsz[i], dump);
 			}
 			if (!parse_only) streams.push_back(F.stream(owner[i]->dec));
 		}
-		packets += (long)owner.size();
-		rounds++;
-		if (!parse_only && H.submit_batch_host(dev, streams.data(), hpk.data(), hsz.data(), (int)streams.size(), 3)) { fprintf(stderr, "submit_batch_host: %s\n", H.last_error()); _exit(1); }
+		my_packets += (long)owner.size();
+		my_rounds++;
+		if (!parse_only && H.submit_batch_host(dev_obj[(size_t)di], streams.data(), hpk.data(), hsz.data(), (int)streams.size(), 3)) { fprintf(stderr, "submit_batch_host: %s\n", H.last_error()); _exit(1); }
 		{ // the packets were copied to staging memory: free them, let their decoders go on
 			std::lock_guard<std::mutex> lk(mu);
 			for (Stream *s : owner) { F.free_packet(s->q.front().data); s->q.pop_front(); }
 			cv_room.notify_all();
 		}
 	}
-	if (!parse_only) H.device_sync(dev);
+	if (!parse_only) H.device_sync(dev_obj[(size_t)di]);
+	std::lock_guard<std::mutex> lk(mu);
+	packets += my_packets; rounds += my_rounds;
+	};
+	std::vector<std::thread> subs;
+	for (size_t di = 1; di < devices.size(); di++) subs.emplace_back(submitter, (int)di);
+	submitter(0);
+	for (std::thread &t : subs) t.join();
 	for (std::thread &t : pool) t.join();
 	double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	for (Stream &s : S) {
@@ -291,7 +313,7 @@ int main(int argc, char **argv)
 		F.free_dec(&s.dec);
 	}
 	if (dump) fclose(dump);
-	printf("{\"streams\": %zu, \"threads\": %d, \"frames\": %ld, \"packets\": %ld, \"rounds\": %ld, \"avg_batch\": %.2f, \"seconds\": %.4f, \"frames_per_s\": %.1f}\n",
-		S.size(), n_threads, total_frames, packets, rounds, rounds ? (double)packets / rounds : 0.0, sec, sec > 0 ? total_frames / sec : 0.0);
+	printf("{\"streams\": %zu, \"devices\": %zu, \"threads\": %d, \"frames\": %ld, \"packets\": %ld, \"rounds\": %ld, \"avg_batch\": %.2f, \"seconds\": %.4f, \"frames_per_s\": %.1f}\n",
+		S.size(), devices.size(), n_threads, total_frames, packets, rounds, rounds ? (double)packets / rounds : 0.0, sec, sec > 0 ? total_frames / sec : 0.0);
 	return 0;
 }

@@ -44,6 +44,7 @@
 
 #define PUBLIC __attribute__((visibility("default")))
 #define ON_DEVICE(e) ((e)->sink_kind != 1) /* sinks 0 and 2 keep the frames in HBM */
+#define E264_FRONT_MAX_DEVICES 16
 
 /* ---- back end binding (dlopen) ------------------------------------------------------------ */
 static struct {
@@ -59,8 +60,9 @@ static struct {
 	int (*frame_wait)(E264Stream *, int);
 	int (*frame_download)(E264Stream *, int, void *, size_t);
 	int (*stream_flush)(E264Stream *);
-	E264Device *dev; /* one device object shared by every decoder of the process */
+	E264Device *devs[E264_FRONT_MAX_DEVICES]; /* one device object per GPU ordinal, shared by every decoder bound to that GPU */
 } hip;
+static pthread_mutex_t g_dev_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static int g_sink_kind = 0;
 
@@ -105,15 +107,30 @@ PUBLIC void e264front_set_sink(int kind) { g_sink_kind = kind; }
 PUBLIC void e264front_set_device(int ordinal) { g_device_ordinal = ordinal; }
 PUBLIC void e264front_set_download(int on) { g_download = on; }
 
-static int hip_bind(void)
+/* the device object of GPU `ordinal` (opened on first use); a decoder is bound to the GPU selected by e264front_set_device at
+ * the time of its edge264_alloc -- several GPUs in one process: one decoder population per GPU, SURVEY.md 8(e) */
+static int hip_load(void);
+static int hip_bind_ordinal(int ordinal, E264Device **dev)
+{
+	if (ordinal < 0 || ordinal >= E264_FRONT_MAX_DEVICES)
+		return EINVAL;
+	pthread_mutex_lock(&g_dev_lock);
+	int r = hip_load();
+	if (!r && !hip.devs[ordinal])
+		r = hip.device_open(ordinal, &hip.devs[ordinal]);
+	*dev = r ? NULL : hip.devs[ordinal];
+	pthread_mutex_unlock(&g_dev_lock);
+	return r;
+}
+static int hip_load(void)
 {
 	if (hip.lib)
-		return hip.dev ? 0 : ENODEV;
+		return hip.device_open ? 0 : ENODEV;
 	const char *path = getenv("E264_HIP_LIB");
 	char buf[4096];
 	if (!path) { /* the back end is the sibling of this library: edge264_amd/libedge264_hipfront.so -> edge264_amd/libedge264_hip.so */
 		Dl_info info;
-		if (dladdr((void *)hip_bind, &info) && info.dli_fname) {
+		if (dladdr((void *)hip_load, &info) && info.dli_fname) {
 			snprintf(buf, sizeof(buf), "%s", info.dli_fname);
 			char *s = strrchr(buf, '/');
 			if (s) {
@@ -129,7 +146,7 @@ static int hip_bind(void)
 	BIND(device_open); BIND(stream_open); BIND(stream_close); BIND(frame_alloc); BIND(frame_free); BIND(frame_fill);
 	BIND(frame_submit); BIND(packet_buffer); BIND(frame_wait); BIND(frame_download); BIND(stream_flush);
 #undef BIND
-	return hip.device_open(g_device_ordinal, &hip.dev);
+	return 0;
 }
 
 /* ---- frame memory: the reference's alloc/free hook (src/edge264_headers.c:113-133) -------- */
@@ -336,7 +353,7 @@ PUBLIC Edge264Decoder *edge264_alloc(int n_threads, Edge264LogCb log_cb, void *l
 	if (!e)
 		return NULL;
 	e->sink_kind = g_sink_kind;
-	if (ON_DEVICE(e) && (hip_bind() || hip.stream_open(hip.dev, (E264Stream **)&e->hip_stream))) {
+	if (ON_DEVICE(e) && (hip_bind_ordinal(g_device_ordinal, (E264Device **)&e->hip_dev) || hip.stream_open(e->hip_dev, (E264Stream **)&e->hip_stream))) {
 		free(e);
 		return NULL;
 	}
@@ -450,7 +467,12 @@ PUBLIC void *e264front_stream(Edge264Decoder *dec)
 	E264Emitter *e = emitter_of(dec);
 	return e && ON_DEVICE(e) ? e->hip_stream : NULL;
 }
-PUBLIC void *e264front_device(void) { return hip_bind() ? NULL : hip.dev; }
+PUBLIC void *e264front_device(void) { E264Device *d; return hip_bind_ordinal(g_device_ordinal, &d) ? NULL : d; } /* of the GPU selected now */
+PUBLIC void *e264front_device_of(Edge264Decoder *dec)
+{
+	E264Emitter *e = emitter_of(dec);
+	return e && ON_DEVICE(e) ? e->hip_dev : NULL;
+}
 
 /* DPB slot a sample pointer of Edge264Frame belongs to (samples[] = base view, samples_mvc[] = second view):
  * return_arg only carries the union of both slots (edge264.c:389,398). */

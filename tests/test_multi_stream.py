@@ -67,3 +67,23 @@ def test_multi_stream_driver(tmp_path, names, repeat):
         npk += 1
     assert off == len(data) and npk == stats["packets"]
     print(stats)
+
+
+def test_multi_stream_driver_devices(tmp_path):
+    """--devices: decoder k lives on devices[k mod N], one submitter thread and one batch stream per entry.  One GPU here, so
+    it is named twice: two submitters feed the same device object concurrently; every frame still equals the reference's."""
+    with open(os.path.join(STREAMS, "reference_md5.json")) as f:
+        sums = json.load(f)
+    names = ["ipb_spatial", "cabac_ipp", "t8x8_scaling", "cabac_weighted_b", "slices_deblock_idc"]
+    files = [os.path.join(STREAMS, n + ".264") for n in names]
+    out = subprocess.run([EXE, "--front", FRONT, "--hip", HIP, "--devices", "0,0", "--repeat", "3", "--threads", "4", "--out", str(tmp_path)] + files,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    stats = json.loads(out.stdout.strip().splitlines()[-1])
+    assert stats["devices"] == 2 and stats["streams"] == 15
+    assert stats["frames"] == 3 * sum(len(sums[n]["md5"]) for n in names)
+    k = 0
+    for _ in range(3):
+        for n in names:
+            assert frame_md5s(tmp_path / f"s{k}.yuv", sums[n]["width_mbs"], sums[n]["height_mbs"], sums[n]["views"]) == sums[n]["md5"], f"stream {k} ({n})"
+            k += 1
