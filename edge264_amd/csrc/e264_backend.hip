@@ -31,6 +31,8 @@ static int fail(int code, const char *what, hipError_t e = hipSuccess)
 #define HIPCHK(call, code) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(code, #call, e_); } while (0)
 
 API const char *e264hip_last_error(void) { return g_err; }
+// events a host thread waits on: blocking, so that the waiter sleeps instead of spinning on a core the parser threads could use
+#define E264_WAIT_EVENT (hipEventDisableTiming | hipEventBlockingSync)
 
 // A few host threads for the per-packet work of a batch that arrives in ordinary host memory (validation of every
 // macroblock record + the copy into page-locked staging memory: 0.18 ms per 1080p packet on one thread = 5 k frames/s,
@@ -118,6 +120,13 @@ struct E264Device {
 	// job tables of host-packet batches (e264hip_submit_batch_host): a ring of pinned + device buffers
 	struct JobRing { E264Job *h = nullptr, *d = nullptr; int cap = 0; hipEvent_t done = nullptr; bool busy = false; } jring[4];
 	int jring_next = 0;
+	// Which submission wrote a slot last, and when it has retired: edge264_get_frame of ONE decoder must not wait for the
+	// whole device (every later batch of every other decoder), only for the submission that produced its frame.
+	hipStream_t qc = nullptr;  // copy queue of the downloads (D2H beside the kernels)
+	uint64_t serial = 0;       // submissions so far (guarded by `lock`)
+	enum { NEV = 64 };
+	hipEvent_t sub_ev[NEV] = {};
+	uint64_t sub_serial[NEV] = {};
 };
 
 struct E264Stream {
@@ -131,6 +140,8 @@ struct E264Stream {
 	// packet staging ring (pinned host) + device copies
 	struct Stage { void *h; uint8_t *d; size_t cap; hipEvent_t done; bool busy; E264Job *d_job; } stage[4];
 	int stage_next;
+	uint64_t slot_serial[E264_MAX_SLOTS]; // submission that wrote the slot last (0: none since it was allocated)
+	hipEvent_t dl_done;                   // the stream's last download
 };
 
 static int set_device(E264Device *dev)
@@ -169,6 +180,9 @@ API int e264hip_device_open(int ordinal, E264Device **out)
 	    hipEventCreateWithFlags(&d->joined, hipEventDisableTiming) != hipSuccess) {
 		d->q2 = nullptr; // not fatal: the option then stays off
 	}
+	if (hipStreamCreateWithFlags(&d->qc, hipStreamNonBlocking) != hipSuccess) d->qc = nullptr; // downloads then share the kernels' queue
+	for (int i = 0; i < E264Device::NEV; i++)
+		if (hipEventCreateWithFlags(&d->sub_ev[i], E264_WAIT_EVENT) != hipSuccess) d->sub_ev[i] = nullptr;
 	*out = d;
 	return 0;
 }
@@ -188,6 +202,8 @@ API void e264hip_device_close(E264Device *dev)
 		if (jr.d) hipFree(jr.d);
 		if (jr.done) hipEventDestroy(jr.done);
 	}
+	if (dev->qc) { hipStreamSynchronize(dev->qc); hipStreamDestroy(dev->qc); }
+	for (int i = 0; i < E264Device::NEV; i++) if (dev->sub_ev[i]) hipEventDestroy(dev->sub_ev[i]);
 	hipStreamDestroy(dev->q);
 	delete dev;
 }
@@ -262,6 +278,7 @@ API void e264hip_stream_close(E264Stream *s)
 		if (st.done) hipEventDestroy(st.done);
 	}
 	if (s->d_dbk) hipFree(s->d_dbk);
+	if (s->dl_done) hipEventDestroy(s->dl_done);
 	hipFree(s->d_table);
 	delete s;
 }
@@ -283,6 +300,7 @@ API int e264hip_frame_alloc(E264Stream *s, int slot, size_t samples_bytes, void 
 	// reference's +16 over-read margin, src/edge264_headers.c:115)
 	if (hipMalloc(&s->h_table[slot], samples_bytes + 64) != hipSuccess) { s->h_table[slot] = nullptr; return fail(ENOMEM, "hipMalloc frame"); }
 	s->slot_bytes[slot] = samples_bytes;
+	s->slot_serial[slot] = 0;
 	if (host_mirror) {
 		if (hipHostMalloc(&s->mirror[slot], samples_bytes, hipHostMallocDefault) != hipSuccess) {
 			hipFree(s->h_table[slot]); s->h_table[slot] = nullptr; s->mirror[slot] = nullptr;
@@ -309,6 +327,7 @@ API int e264hip_frame_fill(E264Stream *s, int slot, int value)
 	if (!s || slot < 0 || slot >= E264_MAX_SLOTS || !s->h_table[slot]) return fail(EINVAL, "frame_fill slot");
 	if (set_device(s->dev)) return EIO;
 	HIPCHK(hipMemsetAsync(s->h_table[slot], value, s->slot_bytes[slot], s->dev->q), EIO);
+	s->slot_serial[slot] = 0; // written outside a submission: a later wait falls back to the whole queue
 	return 0;
 }
 
@@ -318,6 +337,7 @@ API int e264hip_frame_upload(E264Stream *s, int slot, const void *src, size_t by
 	if (set_device(s->dev)) return EIO;
 	HIPCHK(hipMemcpyAsync(s->h_table[slot], src, bytes, hipMemcpyHostToDevice, s->dev->q), EIO);
 	HIPCHK(hipStreamSynchronize(s->dev->q), EIO);
+	s->slot_serial[slot] = 0;
 	return 0;
 }
 
@@ -410,7 +430,7 @@ static int ensure_dbk(E264Stream *s, int n_mbs)
 }
 
 // Launches the kernels over a job table that already lives in HBM.
-static int launch(E264Device *dev, const E264Job *d_jobs, int n, int max_mbs, int max_tiles, int mode)
+static int launch(E264Device *dev, const E264Job *d_jobs, int n, int max_mbs, int max_tiles, int mode, uint64_t *serial_out = nullptr)
 {
 	std::lock_guard<std::mutex> g(dev->lock);
 	hipEvent_t *marks = nullptr;
@@ -427,6 +447,27 @@ static int launch(E264Device *dev, const E264Job *d_jobs, int n, int max_mbs, in
 		marks = m.e; fork.amarks = m.a;
 	}
 	HIPCHK(e264_launch_frames(d_jobs, n, max_mbs, max_tiles, mode | dev->dbg_mode, dev->waves | dev->intra_waves << 8, dev->q, marks, &fork), EIO);
+	const uint64_t serial = ++dev->serial;
+	const int idx = (int)(serial % E264Device::NEV);
+	if (dev->sub_ev[idx] && hipEventRecord(dev->sub_ev[idx], dev->q) == hipSuccess) dev->sub_serial[idx] = serial;
+	else dev->sub_serial[idx] = 0;
+	if (serial_out) *serial_out = serial;
+	return 0;
+}
+
+// Blocks until the submission that wrote `slot` last has retired (not until the device is idle).
+static int wait_slot(E264Stream *s, int slot)
+{
+	E264Device *dev = s->dev;
+	const uint64_t serial = s->slot_serial[slot];
+	hipEvent_t ev = nullptr;
+	if (serial) {
+		std::lock_guard<std::mutex> g(dev->lock);
+		const int idx = (int)(serial % E264Device::NEV);
+		if (dev->sub_serial[idx] == serial) ev = dev->sub_ev[idx];
+	}
+	if (!ev) return e264hip_device_sync(dev); // filled / uploaded outside a submission, or the event ring has wrapped: everything queued retires
+	HIPCHK(hipEventSynchronize(ev), EIO);
 	return 0;
 }
 
@@ -435,7 +476,7 @@ API void *e264hip_packet_buffer(E264Stream *s, size_t max_bytes)
 	if (!s || set_device(s->dev)) return nullptr;
 	E264Stream::Stage &st = s->stage[s->stage_next];
 	if (st.busy) { hipEventSynchronize(st.done); st.busy = false; }
-	if (!st.done && hipEventCreateWithFlags(&st.done, hipEventDisableTiming) != hipSuccess) { st.done = nullptr; fail(EIO, "hipEventCreate"); return nullptr; }
+	if (!st.done && hipEventCreateWithFlags(&st.done, E264_WAIT_EVENT) != hipSuccess) { st.done = nullptr; fail(EIO, "hipEventCreate"); return nullptr; }
 	if (!st.d_job && hipMalloc((void **)&st.d_job, sizeof(E264Job)) != hipSuccess) { st.d_job = nullptr; fail(ENOMEM, "job slot"); return nullptr; }
 	if (st.cap < max_bytes) {
 		if (st.h) hipHostFree(st.h);
@@ -472,8 +513,10 @@ API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
 	E264Job *job = (E264Job *)((uint8_t *)st->h + st->cap); // pinned, lives as long as the staging slot
 	job->packet = st->d; job->dpb = s->d_table; job->dbk = s->d_dbk;
 	HIPCHK(hipMemcpyAsync(st->d_job, job, sizeof(*job), hipMemcpyHostToDevice, s->dev->q), EIO);
-	r = launch(s->dev, st->d_job, 1, n_mbs, n_tiles, E264_RUN_ALL);
+	uint64_t serial = 0;
+	r = launch(s->dev, st->d_job, 1, n_mbs, n_tiles, E264_RUN_ALL, &serial);
 	if (r) return r;
+	s->slot_serial[dst] = serial;
 	hipEventRecord(st->done, s->dev->q);
 	st->busy = true;
 	return 0;
@@ -482,8 +525,9 @@ API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
 API int e264hip_frame_wait(E264Stream *s, int slot)
 {
 	if (!s || slot < 0 || slot >= E264_MAX_SLOTS) return fail(EINVAL, "frame_wait");
-	// one in-order queue per device: everything submitted so far has to retire
-	return e264hip_device_sync(s->dev);
+	if (!s->h_table[slot]) return fail(EINVAL, "frame_wait slot");
+	if (set_device(s->dev)) return EIO;
+	return wait_slot(s, slot);
 }
 
 API int e264hip_frame_download(E264Stream *s, int slot, void *dst, size_t bytes)
@@ -493,8 +537,13 @@ API int e264hip_frame_download(E264Stream *s, int slot, void *dst, size_t bytes)
 	if (!dst) dst = s->mirror[slot];
 	if (!dst) return fail(EINVAL, "no destination");
 	if (bytes == 0 || bytes > s->slot_bytes[slot]) bytes = s->slot_bytes[slot];
-	HIPCHK(hipMemcpyAsync(dst, s->h_table[slot], bytes, hipMemcpyDeviceToHost, s->dev->q), EIO);
-	HIPCHK(hipStreamSynchronize(s->dev->q), EIO);
+	int r = wait_slot(s, slot); // the frame is final on the device; the copy runs beside whatever other decoders have queued since
+	if (r) return r;
+	hipStream_t qc = s->dev->qc ? s->dev->qc : s->dev->q;
+	if (!s->dl_done && hipEventCreateWithFlags(&s->dl_done, E264_WAIT_EVENT) != hipSuccess) { s->dl_done = nullptr; return fail(EIO, "hipEventCreate"); }
+	HIPCHK(hipMemcpyAsync(dst, s->h_table[slot], bytes, hipMemcpyDeviceToHost, qc), EIO);
+	HIPCHK(hipEventRecord(s->dl_done, qc), EIO);
+	HIPCHK(hipEventSynchronize(s->dl_done), EIO);
 	return 0;
 }
 
@@ -530,6 +579,7 @@ struct E264Batch {
 	E264Device *dev;
 	E264Job *d_jobs;
 	int n, max_mbs, max_tiles;
+	std::vector<std::pair<E264Stream *, int>> writes; // (stream, destination slot) of every job
 };
 
 API int e264hip_batch_create(E264Device *dev, E264Stream *const *streams, E264Packet *const *packets, int n, E264Batch **out)
@@ -561,6 +611,7 @@ API int e264hip_batch_create(E264Device *dev, E264Stream *const *streams, E264Pa
 	E264Batch *b = new (std::nothrow) E264Batch();
 	if (!b) return fail(ENOMEM, "batch object");
 	b->dev = dev; b->n = n; b->max_mbs = max_mbs; b->max_tiles = max_tiles;
+	for (int i = 0; i < n; i++) b->writes.emplace_back(streams[i], packets[i]->dst_slot);
 	if (hipMalloc((void **)&b->d_jobs, sizeof(E264Job) * n) != hipSuccess) { delete b; return fail(ENOMEM, "hipMalloc jobs"); }
 	hipError_t e = hipMemcpy(b->d_jobs, jobs.data(), sizeof(E264Job) * n, hipMemcpyHostToDevice);
 	if (e != hipSuccess) { hipFree(b->d_jobs); delete b; return fail(EIO, "hipMemcpy jobs", e); }
@@ -572,7 +623,10 @@ API int e264hip_batch_submit(E264Batch *b, int mode)
 {
 	if (!b) return fail(EINVAL, "null batch");
 	if (set_device(b->dev)) return EIO;
-	return launch(b->dev, b->d_jobs, b->n, b->max_mbs, b->max_tiles, mode);
+	uint64_t serial = 0;
+	int r = launch(b->dev, b->d_jobs, b->n, b->max_mbs, b->max_tiles, mode, &serial);
+	if (!r) for (auto &w : b->writes) w.first->slot_serial[w.second] = serial;
+	return r;
 }
 
 API void e264hip_batch_free(E264Batch *b)
@@ -626,7 +680,7 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 	const bool pinned = flags & 1, trusted = flags & 2;
 	if (!dev || !streams || !packets || !bytes || n <= 0) return fail(EINVAL, "submit_batch_host arguments");
 	if (set_device(dev)) return EIO;
-	std::vector<int> mbs_of((size_t)n), tiles_of((size_t)n), rc((size_t)n, 0);
+	std::vector<int> mbs_of((size_t)n), tiles_of((size_t)n), rc((size_t)n, 0), dst_of((size_t)n);
 	std::vector<std::string> why((size_t)n);
 	for (int i = 0; i < n; i++) {
 		if (!streams[i] || streams[i]->dev != dev) return fail(EINVAL, "batch entry");
@@ -638,6 +692,7 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 		g_pool.parallel_for(n, [&](int i) {
 			E264Stream *s = streams[i];
 			int dst, r = check_packet(packets[i], bytes[i], &dst, &mbs_of[i], &tiles_of[i]);
+			dst_of[i] = dst;
 			if (!r && !s->h_table[dst]) r = fail(EINVAL, "destination slot not allocated");
 			if (!r && !trusted) r = check_packet_deep(packets[i], bytes[i], s->h_table, s->slot_bytes);
 			if (!r && trusted && (uint64_t)((const E264FrameHdr *)packets[i])->plane_size_Y + ((const E264FrameHdr *)packets[i])->plane_size_C > s->slot_bytes[dst])
@@ -659,7 +714,7 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 		if (hipHostMalloc((void **)&jr.h, sizeof(E264Job) * cap, hipHostMallocDefault) != hipSuccess) return fail(ENOMEM, "pinned job table");
 		if (hipMalloc((void **)&jr.d, sizeof(E264Job) * cap) != hipSuccess) { hipHostFree(jr.h); jr.h = nullptr; return fail(ENOMEM, "device job table"); }
 		jr.cap = cap;
-		if (!jr.done) hipEventCreateWithFlags(&jr.done, hipEventDisableTiming);
+		if (!jr.done) hipEventCreateWithFlags(&jr.done, E264_WAIT_EVENT);
 	}
 	int max_mbs = 0, max_tiles = 0;
 	std::vector<E264Stream::Stage *> stage_of((size_t)n);
@@ -684,8 +739,10 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 		jr.h[i].packet = st->d; jr.h[i].dpb = streams[i]->d_table; jr.h[i].dbk = streams[i]->d_dbk;
 	}
 	HIPCHK(hipMemcpyAsync(jr.d, jr.h, sizeof(E264Job) * n, hipMemcpyHostToDevice, dev->q), EIO);
-	int r = launch(dev, jr.d, n, max_mbs, max_tiles, mode);
+	uint64_t serial = 0;
+	int r = launch(dev, jr.d, n, max_mbs, max_tiles, mode, &serial);
 	if (r) return r;
+	for (int i = 0; i < n; i++) streams[i]->slot_serial[dst_of[i]] = serial;
 	hipEventRecord(jr.done, dev->q);
 	jr.busy = true;
 	for (int i = 0; i < n; i++) { // the staging slots are free again when this submission has retired
