@@ -6,8 +6,8 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link
  * or call this file; the product (edge264_amd/csrc) never does.
  *
- * Parity status: PINNED.  tests/test_oracle_vs_reference.py checks every
- * function below against (a) the golden vectors of the reference's own unit
+ * Parity status: PINNED.  tests/test_oracle_golden.py, tests/test_oracle_vs_refkernels.py and
+ * tests/test_frontend_capture.py check every function below against (a) the golden vectors of the reference's own unit
  * tests (src/edge264_check.c:169-359, lifted by tests/golden/extract_check_vectors.py),
  * (b) the reference's static kernels compiled from /root/reference by
  * oracle/Makefile into oracle/_ref/libe264_refkernels.so, on randomised inputs,

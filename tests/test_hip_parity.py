@@ -144,6 +144,13 @@ def test_1080p_ipb(device, oracle):
     run_stream(device, oracle, 21, "IPB", dict(t8x8=True, weighted=1, i_kinds=ALL_I), 120, 68, passes_split=False)
 
 
+def test_1080p_config3(device, oracle):
+    """BASELINE configs[3] at its own size: IBBP, 8x8 transform, scaling lists, explicit weighted bi-prediction, two
+    references, deblocking -- two seeds, every frame compared."""
+    for seed in (31, 32):
+        run_stream(device, oracle, seed, "IPBBP", dict(t8x8=True, scaling=True, weighted=1, num_refs=2, i_kinds=ALL_I), 120, 68, passes_split=False)
+
+
 def test_qp_range(device, oracle):
     """Every qP % 6 / qP / 6 combination of the dequantisers (normAdjust is arithmetic on immediates in the kernels), both
     transforms, custom scaling lists, and the alpha / beta / tC0 table ends of the deblocking filter."""
