@@ -12,9 +12,11 @@ torchrun environment launches the N ranks itself (torch.distributed.run, one pro
 
 Prints ONE JSON line (rank 0).  One submission (= one frame of every stream) is four kernel launches on the back end's
 queue: e264_dbkparam2_kernel (bS / alpha / beta), e264_pred_kernel (inter prediction + residual, tile-parallel),
-e264_intra_kernel (intra wavefront), e264_deblock_kernel (deblocking wavefront).  (--debug-mode 131072 lets the prediction
-kernel compute the deblocking parameters of its tiles itself: three launches, measured slower.)  Kernel times are measured live with HIP
-events recorded on the back end's own queue around each launch.
+e264_intra_kernel (intra wavefront), e264_deblock_kernel (deblocking wavefront).  With --lanes L > 1 the streams are split
+into L groups bound to L compute lanes (HIP queues) of the device: group g's submission of frame f runs beside the other
+groups' (streams are independent), the tile-parallel kernels of one lane filling the compute units the wavefront kernels of
+another leave idle.  Kernel times are measured live with HIP events recorded on the lanes around each launch (with several
+lanes a launch's duration includes the time it shares the GPU with the other lanes' kernels).
 
 roofline (all per submission of one frame of every stream of one GPU; DESIGN.md section 4 states the figures):
   kernels[k].own_bytes  the bytes kernel k has to move as the pass it is: the samples it writes, the samples it reads,
@@ -62,7 +64,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs[1] and configs[3] (N=1)")
     ap.add_argument("--no-host-packets", action="store_true", help="skip the PCIe-inclusive run (N=1)")
-    ap.add_argument("--debug-mode", type=int, default=0, help="profiling ablation bits (results may then be wrong on purpose)")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("E264_LANES", 1)), help="compute lanes (HIP queues): the streams are split into this many "
+                    "groups whose submissions overlap on the GPU")
     ap.add_argument("--capture", default=None, help="capture file (edge264_amd/replay.py): its first stream's packets replace the synthetic GOP, "
                     "so that the kernels are timed on real motion / partition statistics (tools/make_capture.py writes one from a .264)")
     return ap.parse_args(argv)
@@ -79,9 +82,8 @@ def launch_ranks(n: int) -> int:
     return subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")).returncode
 
 
-def kernel_own_bytes(models, n_streams, folded=True):
-    """Per kernel: (sample bytes, command bytes) of one submission, averaged over the GOP's frames.  folded: the prediction
-    kernel computes the deblocking parameters of its tiles (no separate launch): it also writes the parameter records."""
+def kernel_own_bytes(models, n_streams):
+    """Per kernel: (sample bytes, command bytes) of one submission, averaged over the GOP's frames."""
     out = {}
     for name in KERNELS:
         sb = cb = 0.0
@@ -91,7 +93,7 @@ def kernel_own_bytes(models, n_streams, folded=True):
                 c, s_ = 32 * n + m["cmd_motion"] + DBK_BYTES * n, 0
             elif name == "e264_pred_kernel":  # writes its macroblocks, reads each reference sample once per direction
                 s_ = F * m["inter"] + F * m["dirs"]
-                c = 32 * n + m["cmd_motion"] + m["cmd_payload_inter"] + (DBK_BYTES * n if folded else 0)
+                c = 32 * n + m["cmd_motion"] + m["cmd_payload_inter"]
             elif name == "e264_intra_kernel":  # writes its macroblocks (neighbour rows are cache hits)
                 s_ = F * m["intra"]
                 c = 32 * n + m["cmd_payload_intra"]
@@ -167,8 +169,8 @@ def main() -> int:
     dev.set_option("waves", args.waves)
     if args.intra_waves:
         dev.set_option("intra_waves", args.intra_waves)
-    dev.set_option("debug_mode", args.debug_mode)
     dev.set_option("side_queue", int(os.environ.get("E264_SIDE_QUEUE", 0)))
+    dev.set_option("upload_queue", int(os.environ.get("E264_UPLOAD_QUEUE", 1)))
     streams, dpk = [], []
     for s in range(my_streams):
         st = backend.Stream(dev, W, H)
@@ -178,12 +180,25 @@ def main() -> int:
             st.fill(i, fill_value)
         streams.append(st)
         dpk.append([dev.upload_packet(p) for p in packets])  # per-stream copy of the command bytes
-    batches = [dev.make_batch(streams, [dpk[s][f] for s in range(my_streams)]) for f in range(len(packets))]
+    # compute lanes: group g = streams g, g + L, g + 2L, ...; one batch per (frame, group)
+    lanes = max(1, min(args.lanes, getattr(backend, "MAX_LANES", 1), my_streams))
+    groups = [list(range(g, my_streams, lanes)) for g in range(lanes)]
+    for g, idx in enumerate(groups):
+        for k in idx:
+            streams[k].bind_lane(g)
+
+    def make_batches(dp):
+        return [[dev.make_batch([streams[k] for k in idx], [dp[k][f] for k in idx]) for idx in groups] for f in range(len(dp[0]))]
+
+    def submit_frame(bs, mode):
+        for b in bs:
+            dev.submit_prepared(b, mode)
+    batches = make_batches(dpk)
     dev.sync()
 
     def step():
-        for b in batches:
-            dev.submit_prepared(b, backend.RUN_ALL)
+        for bs in batches:
+            submit_frame(bs, backend.RUN_ALL)
 
     def barrier():
         dev.sync()
@@ -230,7 +245,7 @@ def main() -> int:
         bad = 0
         for f, p in enumerate(packets):
             orc.decode_frame(p, dpb, 3)
-            dev.submit_prepared(batches[f], backend.RUN_ALL)
+            submit_frame(batches[f], backend.RUN_ALL)
             dev.sync()
             d = int(parsed[f].hdr["dst_slot"])
             want = dpb[d][:nb]
@@ -266,7 +281,7 @@ def main() -> int:
 
     # ---- the other single-GPU configurations of BASELINE.json, short runs on the same streams (N=1 only) -----
     other = None
-    if rank == 0 and world == 1 and not args.no_other_configs and args.debug_mode == 0 and not stub:
+    if rank == 0 and world == 1 and not args.no_other_configs and not stub:
         from oracle.pyoracle import Oracle
         other = {}
         specs = [("configs[1] all-intra 4x4 I slices, residual + intra kernels only", "IIII", backend.RUN_RECON,
@@ -284,11 +299,11 @@ def main() -> int:
                     st.fill(i, 128)
             n_slots = max(n_slots, need)
             d2 = [[dev.upload_packet(q) for q in pk2] for _ in streams]
-            b2 = [dev.make_batch(streams, [d2[k][f] for k in range(len(streams))]) for f in range(len(pk2))]
+            b2 = make_batches(d2)
 
             def step2():
-                for b in b2:
-                    dev.submit_prepared(b, mode2)
+                for bs in b2:
+                    submit_frame(bs, mode2)
             step2()
             dev.sync()
             dev.kernel_timing(True)
@@ -299,18 +314,28 @@ def main() -> int:
             dt2 = time.perf_counter() - t2
             k4, l4 = dev.kernel_time_ms()
             dev.kernel_timing(False)
-            ok2 = None
-            if not args.no_verify:  # last frame of the GOP, first / middle / last stream
+            ok2, cmp2 = None, 0
+            if not args.no_verify:  # one more GOP, untimed: EVERY stream, EVERY frame against the oracle (as the headline)
                 orc = Oracle()
                 nb = P.frame_bytes(W, H)
                 dpb = [np.full(nb + 16, 128, np.uint8) for _ in range(n_slots)] + [None] * (32 - n_slots)
-                for q in pk2:
+                for st in streams:
+                    for i in range(need):
+                        st.fill(i, 128)
+                bad2 = 0
+                for f, q in enumerate(pk2):
                     orc.decode_frame(q, dpb, mode2)
-                last2 = int(P.Packet(pk2[-1]).hdr["dst_slot"])
-                ok2 = all(bool(np.array_equal(streams[k].download(last2), dpb[last2][:nb])) for k in (0, len(streams) // 2, len(streams) - 1))
+                    submit_frame(b2[f], mode2)
+                    dev.sync()
+                    d = int(P.Packet(q).hdr["dst_slot"])
+                    for st in streams:
+                        bad2 += 0 if np.array_equal(st.download(d), dpb[d][:nb]) else 1
+                        cmp2 += 1
+                ok2 = bad2 == 0
             other[label] = {"value": round(2 * len(pk2) * len(streams) / dt2, 1), "unit": "frames/s", "gop": gop2, "steps": 2, "bit_exact": ok2,
+                            "frames_compared": cmp2,
                             "kernel_ms_per_launch": {n: round(t / max(l4, 1), 4) for n, t in zip(KERNELS, k4)}}
-            for b in b2:
+            for b in sum(b2, []):
                 dev.free_batch(b)
             for row in d2:
                 for q in row:
@@ -319,7 +344,7 @@ def main() -> int:
     # ---- PCIe-inclusive rate (informational, never `value`): the same GOP submitted from host memory -------------------
     pcie = None
     if rank == 0 and world == 1 and not args.no_host_packets and not stub:
-        hbs = [dev.prepare_host_batch(streams, [packets[f]] * len(streams)) for f in range(len(packets))]
+        hbs = [dev.prepare_host_batch([streams[k] for k in idx], [packets[f]] * len(idx)) for f in range(len(packets)) for idx in groups]
         for hb in hbs:
             dev.submit_host_prepared(hb, backend.RUN_ALL)
         dev.sync()
@@ -332,12 +357,13 @@ def main() -> int:
         pcie = {"value": round(2 * len(packets) * len(streams) / dt2, 1), "unit": "frames/s",
                 "packet_MB_per_frame": round(float(np.mean([len(p) for p in packets])) / 1e6, 3),
                 "what": "pageable host packets -> per-macroblock validation + copy into page-locked staging by the back end's host threads "
-                        "(E264_HOST_THREADS, default min(15, cores / 2)) -> H2D -> 4 kernels, asynchronous, one batch per frame index"}
+                        "(E264_HOST_THREADS, default min(15, cores / 2)) -> H2D on the upload queue beside the kernels of the batch before -> "
+                        "4 kernels, asynchronous, one batch per frame index and lane"}
         # the front end's own path: packets assembled in place in page-locked memory and validated where they are produced
         for p in packets:
             assert backend.packet_check(p) == 0
         pins = [dev.pinned_copy(p) for p in packets]
-        pbs = [dev.prepare_pinned_batch(streams, [pins[f]] * len(streams), [len(packets[f])] * len(streams)) for f in range(len(packets))]
+        pbs = [dev.prepare_pinned_batch([streams[k] for k in idx], [pins[f]] * len(idx), [len(packets[f])] * len(idx)) for f in range(len(packets)) for idx in groups]
         for pb in pbs:
             dev.submit_pinned_prepared(pb, backend.RUN_ALL)
         dev.sync()
@@ -357,12 +383,9 @@ def main() -> int:
     if rank == 0:
         L = max(launches, 1)
         kms = [t / L for t in kernel_ms4]
-        folded = kms[0] < 0.005  # no stand-alone parameter launch: e264_pred_kernel did that work
-        own = kernel_own_bytes(models, my_streams, folded)
+        own = kernel_own_bytes(models, my_streams / lanes)  # one launch = the frames of one lane's streams
         kern = {}
         for name, ms in zip(KERNELS, kms):
-            if folded and name == KERNELS[0]:
-                continue
             sb, cb = own[name]
             g = (sb + cb) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             kern[name] = {"ms_per_launch": round(ms, 4), "sample_bytes": int(sb), "command_bytes": int(cb), "gbps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4)}
@@ -370,15 +393,17 @@ def main() -> int:
         # SURVEY 8(d) bytes of one submission: F + F x dirs (samples) + the packet (commands) per frame, x streams
         e2e_samples = float(np.mean([m["F"] * (1.0 + m["dirs"]) for m in models])) * my_streams
         e2e_cmds = float(np.mean([m["cmd_total"] for m in models])) * my_streams
-        tot_ms = sum(kms)
+        # time of one submission of ALL streams: the sum of the four launches on one lane; with several lanes the launches of
+        # the groups overlap, so the wall time of the timed region per frame index is the figure
+        tot_ms = sum(kms) if lanes == 1 else elapsed * 1e3 / (args.steps * len(packets))
         e2e_g = (e2e_samples + e2e_cmds) / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
             cfg = tj.get("config", {})
-            if (cfg.get("streams"), cfg.get("gop"), cfg.get("width_mbs"), cfg.get("height_mbs")) == (args.streams, args.gop, W, H):
+            if (cfg.get("streams"), cfg.get("gop"), cfg.get("width_mbs"), cfg.get("height_mbs"), cfg.get("lanes", 1)) == (args.streams, args.gop, W, H, lanes):
                 k = tj["kernels"].get(dom)
                 if k:
                     traffic = int(k["hbm_bytes_per_launch"])
@@ -394,9 +419,9 @@ def main() -> int:
                                     "P frames with 6-tap luma / bilinear chroma MC, 2 references, 4x4 and 8x8 transforms, 30% coded residual, "
                                     "in-loop deblocking), BASELINE configs[2]"),
                        "streams_per_gpu": args.streams, "frames_per_step": frames_per_step,
-                       "waves_per_frame": args.waves, "parallelism": f"stream-parallel x{world}, no collectives"},
+                       "waves_per_frame": args.waves, "compute_lanes": lanes, "parallelism": f"stream-parallel x{world}, no collectives"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": kern[dom]["frac"], "traffic": traffic, "traffic_source": "profiles/r02_hbm_traffic.json (PMC passes, canned)" if traffic else None,
+                         "frac": kern[dom]["frac"], "traffic": traffic, "traffic_source": "profiles/r03_hbm_traffic.json (PMC passes, canned)" if traffic else None,
                          "launches": launches, "kernels": kern,
                          "end_to_end": {"ms_per_submission": round(tot_ms, 4), "sample_bytes": int(e2e_samples), "command_bytes": int(e2e_cmds),
                                         "gbps": round(e2e_g, 1), "frac": round(e2e_g / HBM_PEAK_GBS, 4)}},

@@ -17,6 +17,7 @@ from . import packet as P
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E264_HIP_LIB") or os.path.join(HERE, "libedge264_hip.so")  # E264_HIP_LIB: A/B builds (csrc/Makefile `variant`)
 RUN_RECON, RUN_DEBLOCK, RUN_ALL = 1, 2, 3
+MAX_LANES = 4
 
 _lib = None
 
@@ -42,6 +43,7 @@ def load_library():
         "e264hip_last_error": (C.c_char_p, []),
         "e264hip_stream_open": (i, [vp, C.POINTER(vp)]),
         "e264hip_stream_close": (None, [vp]),
+        "e264hip_stream_bind_lane": (i, [vp, i]),
         "e264hip_stream_flush": (i, [vp]),
         "e264hip_frame_alloc": (i, [vp, i, sz, C.POINTER(vp)]),
         "e264hip_frame_free": (None, [vp, i]),
@@ -77,7 +79,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "e264hip_device_open", "e264hip_device_close", "e264hip_device_sync", "e264hip_last_error",
-    "e264hip_stream_open", "e264hip_stream_close", "e264hip_stream_flush", "e264hip_frame_alloc",
+    "e264hip_stream_open", "e264hip_stream_close", "e264hip_stream_bind_lane", "e264hip_stream_flush", "e264hip_frame_alloc",
     "e264hip_frame_free", "e264hip_frame_fill", "e264hip_frame_upload", "e264hip_frame_submit",
     "e264hip_packet_buffer", "e264hip_frame_wait", "e264hip_frame_download", "e264hip_packet_upload",
     "e264hip_packet_free", "e264hip_packet_check", "e264hip_submit_batch", "e264hip_submit_batch_host", "e264hip_submit_batch_pinned", "e264hip_host_alloc", "e264hip_host_free", "e264hip_batch_create", "e264hip_batch_submit", "e264hip_batch_free", "e264hip_event_record", "e264hip_event_elapsed_ms",
@@ -231,6 +233,10 @@ class Stream:
         if self.h:
             self.L.e264hip_stream_close(self.h)
             self.h = None
+
+    def bind_lane(self, lane: int) -> None:
+        """Compute lane (HIP queue) of the device this stream's work is ordered on; streams of different lanes overlap."""
+        _check(self.L, self.L.e264hip_stream_bind_lane(self.h, lane), "stream_bind_lane")
 
     def alloc(self, slot: int, mirror: bool = False) -> None:
         m = C.c_void_p()

@@ -1,9 +1,20 @@
 // e264_backend.hip -- C-ABI of the MI355X reconstruction back end (include/edge264_hip.h).
 //
 // Host side of the drop-in boundary: owns the device DPB of every decoder ("stream"), moves
-// command packets to HBM with pinned async copies, launches the frame kernels on one HIP
-// queue per device, and copies finished frames back on demand.  No torch types, no CPU
+// command packets to HBM with pinned async copies, launches the frame kernels on the compute
+// lanes (HIP queues) of the device, and copies finished frames back on demand.  No torch types, no CPU
 // fallback: if there is no gfx950 device every entry point fails with ENODEV.
+//
+// Queues of one device:
+//   q[lane]  compute lanes.  A stream is bound to one lane (e264hip_stream_bind_lane, default 0); everything that touches
+//            its DPB is ordered there.  Submissions of streams on different lanes run beside each other on the GPU.
+//   qup      upload queue: the packet and job-table H2D copies of host batches.  A lane waits for ITS batch's copy event
+//            only, so batch n+1 is in flight over PCIe while the kernels of batch n run (round 2: both shared one in-order
+//            queue and a submission cost copy time + kernel time).
+//   qc       download queue (edge264_get_frame's D2H beside the kernels).
+// Nothing a single decoder does (frame_alloc / frame_free / flush / close / get_frame) waits for the device: each waits
+// for that decoder's own last submission at most; memory it gives back is parked and recycled (hipFree would drain every
+// queue of the device).
 #include <hip/hip_runtime.h>
 #include <errno.h>
 #include <stdio.h>
@@ -37,6 +48,7 @@ API const char *e264hip_last_error(void) { return g_err; }
 // A few host threads for the per-packet work of a batch that arrives in ordinary host memory (validation of every
 // macroblock record + the copy into page-locked staging memory: 0.18 ms per 1080p packet on one thread = 5 k frames/s,
 // while PCIe carries 28 k).  No HIP call is ever made from these threads.  E264_HOST_THREADS overrides the count (0: none).
+// One pool per device: the submitter threads of several GPUs (e264_multi --devices) do not queue behind each other.
 namespace {
 struct HostPool {
 	std::vector<std::thread> th;
@@ -86,8 +98,6 @@ struct HostPool {
 		for (auto &t : th) t.join();
 	}
 };
-HostPool g_pool;
-std::mutex g_pool_user; // one batch at a time uses the pool
 }
 
 struct E264Packet {
@@ -102,45 +112,68 @@ struct E264Packet {
 
 struct E264Device {
 	int ordinal;
-	hipStream_t q;
+	enum { NQ = E264_MAX_LANES };
+	hipStream_t q[NQ];         // compute lanes
+	hipStream_t qup = nullptr; // upload queue
+	hipStream_t qc = nullptr;  // download queue
 	int waves;                 // waves per frame workgroup of the deblocking kernel (5 macroblock rows each): 2, 4, 7 or 8
 	int intra_waves;           // waves per frame workgroup of the intra kernel (1 macroblock row each)
-	int dbg_mode;
 	int side_queue;            // option "side_queue": parameter kernel on a second queue beside the macroblock-parallel kernel
+	int upload_queue;          // option "upload_queue" (default 1): the H2D copies of host batches go through qup
 	hipStream_t q2;
 	hipEvent_t forked, joined;
-	std::mutex lock;           // kernel launches + their timing marks
-	std::mutex batch_lock;     // e264hip_submit_batch_host: job ring
+	hipEvent_t lane_ev[NQ];    // e264hip_event_record: joins the other lanes into lane 0
+	std::mutex lock;           // kernel launches + their timing marks + the submission event ring
+	std::mutex batch_lock;     // host batches: job ring, staging
 	hipEvent_t ev[16];
 	// per-launch kernel timing
 	bool ktiming;
 	struct Marks { hipEvent_t e[5], a[2]; bool side; };
 	std::vector<Marks> kev;
 	size_t kev_used;
-	// job tables of host-packet batches (e264hip_submit_batch_host): a ring of pinned + device buffers
-	struct JobRing { E264Job *h = nullptr, *d = nullptr; int cap = 0; hipEvent_t done = nullptr; bool busy = false; } jring[4];
+	// job tables of host-packet batches: a ring of pinned + device buffers, each with the event of its upload and of its kernels
+	struct JobRing { E264Job *h = nullptr, *d = nullptr; int cap = 0; hipEvent_t done = nullptr, up = nullptr; bool busy = false; } jring[8];
 	int jring_next = 0;
 	// Which submission wrote a slot last, and when it has retired: edge264_get_frame of ONE decoder must not wait for the
 	// whole device (every later batch of every other decoder), only for the submission that produced its frame.
-	hipStream_t qc = nullptr;  // copy queue of the downloads (D2H beside the kernels)
 	uint64_t serial = 0;       // submissions so far (guarded by `lock`)
 	enum { NEV = 64 };
 	hipEvent_t sub_ev[NEV] = {};
 	uint64_t sub_serial[NEV] = {};
+	// Memory recycler.  hipFree / hipHostFree drain EVERY queue of the device, so what a decoder gives back (frame slots and
+	// their host mirrors at an SPS change or edge264_free, parameter and staging buffers) is parked with the submission that
+	// may still read it and handed to the next request of the same size once that submission has retired.  Parked memory is
+	// released for real when the device closes (or when more than PARK_MAX blocks wait: the oldest retired ones go).
+	struct Parked { void *p; size_t bytes; uint64_t serial; int lane; bool host; };
+	enum { PARK_MAX = 4096 };
+	std::vector<Parked> parked;
+	std::mutex park_lock;
+	HostPool pool;             // validation + staging copies of this device's host batches
+	std::mutex pool_user;      // one batch at a time uses the pool
 };
 
 struct E264Stream {
 	E264Device *dev;
+	int lane;                             // compute lane of the device everything of this stream is ordered on
 	uint8_t **d_table;                    // device array [E264_MAX_SLOTS] of slot pointers
 	uint8_t *h_table[E264_MAX_SLOTS];     // same, host copy
 	void *mirror[E264_MAX_SLOTS];         // pinned host mirrors
 	size_t slot_bytes[E264_MAX_SLOTS];
 	uint8_t *d_dbk;                       // deblocking parameters, E264_DBK_BYTES per macroblock
 	size_t dbk_mbs;
+	// the slot table reaches the device from a small pinned ring (asynchronous: a pageable source would make hipMemcpyAsync
+	// wait for the queue)
+	enum { NTAB = 4 };
+	uint8_t **tab_pin;                    // [NTAB][E264_MAX_SLOTS]
+	hipEvent_t tab_ev[NTAB];
+	bool tab_busy[NTAB];
+	int tab_next;
 	// packet staging ring (pinned host) + device copies
 	struct Stage { void *h; uint8_t *d; size_t cap; hipEvent_t done; bool busy; E264Job *d_job; } stage[4];
 	int stage_next;
 	uint64_t slot_serial[E264_MAX_SLOTS]; // submission that wrote the slot last (0: none since it was allocated)
+	uint64_t last_serial;                 // the stream's latest submission
+	bool loose;                           // a fill was queued on the lane since then (no event of its own)
 	hipEvent_t dl_done;                   // the stream's last download
 };
 
@@ -148,6 +181,73 @@ static int set_device(E264Device *dev)
 {
 	HIPCHK(hipSetDevice(dev->ordinal), EIO);
 	return 0;
+}
+static hipStream_t lane_of(const E264Stream *s) { return s->dev->q[s->lane]; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// submissions: retired? / wait
+// ---------------------------------------------------------------------------------------------------------------------
+static hipEvent_t serial_event(E264Device *dev, uint64_t serial)
+{
+	if (!serial) return nullptr;
+	std::lock_guard<std::mutex> g(dev->lock);
+	const int idx = (int)(serial % E264Device::NEV);
+	return dev->sub_serial[idx] == serial ? dev->sub_ev[idx] : nullptr;
+}
+// Has submission `serial` of lane `lane` left the GPU?  (serial 0: nothing was ever submitted)
+static bool serial_retired(E264Device *dev, uint64_t serial, int lane)
+{
+	if (!serial) return true;
+	hipEvent_t ev = serial_event(dev, serial);
+	if (ev) return hipEventQuery(ev) == hipSuccess;
+	return hipStreamQuery(dev->q[lane]) == hipSuccess; // the event ring has wrapped: the lane itself
+}
+// Blocks until it has: the submission's own event, else (ring wrapped) the lane -- never the device.
+static int serial_wait(E264Device *dev, uint64_t serial, int lane)
+{
+	if (!serial) return 0;
+	hipEvent_t ev = serial_event(dev, serial);
+	if (ev) { HIPCHK(hipEventSynchronize(ev), EIO); return 0; }
+	HIPCHK(hipStreamSynchronize(dev->q[lane]), EIO);
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// memory recycler
+// ---------------------------------------------------------------------------------------------------------------------
+static void *mem_acquire(E264Device *dev, size_t bytes, bool host)
+{
+	{
+		std::lock_guard<std::mutex> g(dev->park_lock);
+		for (size_t i = 0; i < dev->parked.size(); i++) {
+			E264Device::Parked &k = dev->parked[i];
+			if (k.host == host && k.bytes == bytes && serial_retired(dev, k.serial, k.lane)) {
+				void *p = k.p;
+				dev->parked.erase(dev->parked.begin() + (ptrdiff_t)i);
+				return p;
+			}
+		}
+	}
+	void *p = nullptr;
+	hipError_t e = host ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMalloc(&p, bytes);
+	return e == hipSuccess ? p : nullptr;
+}
+// `serial` / `lane`: the last submission that may touch the block (0: none)
+static void mem_release(E264Device *dev, void *p, size_t bytes, bool host, uint64_t serial, int lane)
+{
+	if (!p) return;
+	std::vector<E264Device::Parked> drop;
+	{
+		std::lock_guard<std::mutex> g(dev->park_lock);
+		dev->parked.push_back({p, bytes, serial, lane, host});
+		if (dev->parked.size() > E264Device::PARK_MAX) { // the oldest retired blocks really go (this drains the device: rare)
+			for (size_t i = 0; i < dev->parked.size() && drop.size() < E264Device::PARK_MAX / 4;) {
+				if (serial_retired(dev, dev->parked[i].serial, dev->parked[i].lane)) { drop.push_back(dev->parked[i]); dev->parked.erase(dev->parked.begin() + (ptrdiff_t)i); }
+				else i++;
+			}
+		}
+	}
+	for (auto &k : drop) { if (k.host) hipHostFree(k.p); else hipFree(k.p); }
 }
 
 API int e264hip_device_open(int ordinal, E264Device **out)
@@ -167,12 +267,16 @@ API int e264hip_device_open(int ordinal, E264Device **out)
 	d->ordinal = ordinal;
 	d->waves = 7; // 35 macroblock rows in flight: a 1080p picture in two even rounds
 	d->intra_waves = 16; // 16 rows in flight: 1.6 -> 1.1 ms per 256-frame launch (the intra kernel fits 128 VGPRs)
-	d->dbg_mode = 0;
 	d->ktiming = false; d->kev_used = 0;
-	if (hipSetDevice(ordinal) != hipSuccess || hipStreamCreateWithFlags(&d->q, hipStreamNonBlocking) != hipSuccess) {
-		delete d;
-		return fail(EIO, "hipStreamCreate");
-	}
+	d->upload_queue = 1;
+	for (int i = 0; i < E264Device::NQ; i++) { d->q[i] = nullptr; d->lane_ev[i] = nullptr; }
+	if (hipSetDevice(ordinal) != hipSuccess) { delete d; return fail(EIO, "hipSetDevice"); }
+	for (int i = 0; i < E264Device::NQ; i++)
+		if (hipStreamCreateWithFlags(&d->q[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&d->lane_ev[i], hipEventDisableTiming) != hipSuccess) {
+			for (int k = 0; k <= i; k++) { if (d->q[k]) hipStreamDestroy(d->q[k]); if (d->lane_ev[k]) hipEventDestroy(d->lane_ev[k]); }
+			delete d;
+			return fail(EIO, "hipStreamCreate");
+		}
 	for (int i = 0; i < 16; i++)
 		hipEventCreate(&d->ev[i]);
 	d->side_queue = 0; d->q2 = nullptr; d->forked = d->joined = nullptr; // measured: no gain (profiles/r01k_ablation_breakdown.txt), off by default
@@ -180,10 +284,22 @@ API int e264hip_device_open(int ordinal, E264Device **out)
 	    hipEventCreateWithFlags(&d->joined, hipEventDisableTiming) != hipSuccess) {
 		d->q2 = nullptr; // not fatal: the option then stays off
 	}
-	if (hipStreamCreateWithFlags(&d->qc, hipStreamNonBlocking) != hipSuccess) d->qc = nullptr; // downloads then share the kernels' queue
+	if (hipStreamCreateWithFlags(&d->qc, hipStreamNonBlocking) != hipSuccess) d->qc = nullptr; // downloads then share the lane
+	if (hipStreamCreateWithFlags(&d->qup, hipStreamNonBlocking) != hipSuccess) d->qup = nullptr; // uploads then share the lane
 	for (int i = 0; i < E264Device::NEV; i++)
 		if (hipEventCreateWithFlags(&d->sub_ev[i], E264_WAIT_EVENT) != hipSuccess) d->sub_ev[i] = nullptr;
 	*out = d;
+	return 0;
+}
+
+API int e264hip_device_sync(E264Device *dev)
+{
+	if (!dev) return fail(EINVAL, "null device");
+	if (set_device(dev)) return EIO;
+	if (dev->qup) HIPCHK(hipStreamSynchronize(dev->qup), EIO);
+	for (int i = 0; i < E264Device::NQ; i++)
+		HIPCHK(hipStreamSynchronize(dev->q[i]), EIO);
+	if (dev->q2) HIPCHK(hipStreamSynchronize(dev->q2), EIO);
 	return 0;
 }
 
@@ -191,43 +307,38 @@ API void e264hip_device_close(E264Device *dev)
 {
 	if (!dev) return;
 	hipSetDevice(dev->ordinal);
-	hipStreamSynchronize(dev->q);
+	e264hip_device_sync(dev);
 	for (int i = 0; i < 16; i++) hipEventDestroy(dev->ev[i]);
 	for (auto &p : dev->kev) { for (int i = 0; i < 5; i++) hipEventDestroy(p.e[i]); for (int i = 0; i < 2; i++) hipEventDestroy(p.a[i]); }
-	if (dev->q2) { hipStreamSynchronize(dev->q2); hipStreamDestroy(dev->q2); }
+	if (dev->q2) hipStreamDestroy(dev->q2);
 	if (dev->forked) hipEventDestroy(dev->forked);
 	if (dev->joined) hipEventDestroy(dev->joined);
 	for (auto &jr : dev->jring) {
 		if (jr.h) hipHostFree(jr.h);
 		if (jr.d) hipFree(jr.d);
 		if (jr.done) hipEventDestroy(jr.done);
+		if (jr.up) hipEventDestroy(jr.up);
 	}
+	for (auto &k : dev->parked) { if (k.host) hipHostFree(k.p); else hipFree(k.p); }
+	dev->parked.clear();
 	if (dev->qc) { hipStreamSynchronize(dev->qc); hipStreamDestroy(dev->qc); }
+	if (dev->qup) hipStreamDestroy(dev->qup);
 	for (int i = 0; i < E264Device::NEV; i++) if (dev->sub_ev[i]) hipEventDestroy(dev->sub_ev[i]);
-	hipStreamDestroy(dev->q);
+	for (int i = 0; i < E264Device::NQ; i++) { hipStreamDestroy(dev->q[i]); hipEventDestroy(dev->lane_ev[i]); }
 	delete dev;
-}
-
-API int e264hip_device_sync(E264Device *dev)
-{
-	if (!dev) return fail(EINVAL, "null device");
-	if (set_device(dev)) return EIO;
-	HIPCHK(hipStreamSynchronize(dev->q), EIO);
-	if (dev->q2) HIPCHK(hipStreamSynchronize(dev->q2), EIO);
-	return 0;
 }
 
 API int e264hip_set_option(E264Device *dev, const char *name, int value)
 {
 	if (!dev || !name) return -1;
-	if (!strcmp(name, "debug_mode")) { // profiling ablation bits OR-ed into the kernels' mode argument
-		int prev = dev->dbg_mode;
-		dev->dbg_mode = value;
-		return prev;
-	}
 	if (!strcmp(name, "side_queue")) {
 		int prev = dev->side_queue;
 		dev->side_queue = value && dev->q2;
+		return prev;
+	}
+	if (!strcmp(name, "upload_queue")) {
+		int prev = dev->upload_queue;
+		dev->upload_queue = value != 0;
 		return prev;
 	}
 	if (!strcmp(name, "intra_waves")) {
@@ -251,43 +362,81 @@ API int e264hip_stream_open(E264Device *dev, E264Stream **out)
 	if (!s) return fail(ENOMEM, "stream object");
 	memset(s, 0, sizeof(*s));
 	s->dev = dev;
-	if (hipMalloc(&s->d_table, sizeof(uint8_t *) * E264_MAX_SLOTS) != hipSuccess) { delete s; return fail(ENOMEM, "slot table"); }
-	hipMemsetAsync(s->d_table, 0, sizeof(uint8_t *) * E264_MAX_SLOTS, dev->q);
+	s->d_table = (uint8_t **)mem_acquire(dev, sizeof(uint8_t *) * E264_MAX_SLOTS, false);
+	s->tab_pin = (uint8_t **)mem_acquire(dev, sizeof(uint8_t *) * E264_MAX_SLOTS * E264Stream::NTAB, true);
+	if (!s->d_table || !s->tab_pin) {
+		mem_release(dev, s->d_table, sizeof(uint8_t *) * E264_MAX_SLOTS, false, 0, 0);
+		mem_release(dev, s->tab_pin, sizeof(uint8_t *) * E264_MAX_SLOTS * E264Stream::NTAB, true, 0, 0);
+		delete s;
+		return fail(ENOMEM, "slot table");
+	}
+	hipMemsetAsync(s->d_table, 0, sizeof(uint8_t *) * E264_MAX_SLOTS, lane_of(s));
 	*out = s;
 	return 0;
 }
 
+API int e264hip_stream_bind_lane(E264Stream *s, int lane)
+{
+	if (!s || lane < 0 || lane >= E264Device::NQ) return fail(EINVAL, "stream_bind_lane");
+	if (lane == s->lane) return 0;
+	if (set_device(s->dev)) return EIO;
+	// what the old lane still has queued for this stream (table updates, fills, submissions) must be over before the new one starts
+	HIPCHK(hipStreamSynchronize(lane_of(s)), EIO);
+	s->lane = lane;
+	return 0;
+}
+
+// Waits for what THIS stream has submitted (edge264_flush, src/edge264.c:261-270), not for the device.
 API int e264hip_stream_flush(E264Stream *s)
 {
 	if (!s) return fail(EINVAL, "null stream");
-	return e264hip_device_sync(s->dev);
+	if (set_device(s->dev)) return EIO;
+	if (!s->last_serial) { HIPCHK(hipStreamSynchronize(lane_of(s)), EIO); return 0; } // fills / uploads only
+	return serial_wait(s->dev, s->last_serial, s->lane);
 }
 
 API void e264hip_stream_close(E264Stream *s)
 {
 	if (!s) return;
-	e264hip_device_sync(s->dev);
+	E264Device *dev = s->dev;
+	set_device(dev);
+	// everything THIS stream has queued on its lane (submissions, fills, table updates) -- not the device, not the other lanes
+	hipEvent_t end = nullptr;
+	if (hipEventCreateWithFlags(&end, E264_WAIT_EVENT) == hipSuccess && hipEventRecord(end, lane_of(s)) == hipSuccess) hipEventSynchronize(end);
+	else hipStreamSynchronize(lane_of(s));
+	if (end) hipEventDestroy(end);
 	for (int i = 0; i < E264_MAX_SLOTS; i++) {
-		if (s->h_table[i]) hipFree(s->h_table[i]);
-		if (s->mirror[i]) hipHostFree(s->mirror[i]);
+		mem_release(dev, s->h_table[i], s->slot_bytes[i] + 64, false, 0, 0);
+		mem_release(dev, s->mirror[i], s->slot_bytes[i], true, 0, 0);
 	}
 	for (auto &st : s->stage) {
-		if (st.h) hipHostFree(st.h);
-		if (st.d) hipFree(st.d);
-		if (st.d_job) hipFree(st.d_job);
+		mem_release(dev, st.h, st.cap + 64, true, 0, 0);
+		mem_release(dev, st.d, st.cap, false, 0, 0);
+		mem_release(dev, st.d_job, sizeof(E264Job), false, 0, 0);
 		if (st.done) hipEventDestroy(st.done);
 	}
-	if (s->d_dbk) hipFree(s->d_dbk);
+	mem_release(dev, s->d_dbk, s->dbk_mbs * E264_DBK_BYTES, false, 0, 0);
 	if (s->dl_done) hipEventDestroy(s->dl_done);
-	hipFree(s->d_table);
+	for (int i = 0; i < E264Stream::NTAB; i++)
+		if (s->tab_ev[i]) hipEventDestroy(s->tab_ev[i]);
+	mem_release(dev, s->tab_pin, sizeof(uint8_t *) * E264_MAX_SLOTS * E264Stream::NTAB, true, 0, 0);
+	mem_release(dev, s->d_table, sizeof(uint8_t *) * E264_MAX_SLOTS, false, 0, 0);
 	delete s;
 }
 
+// The slot table follows the stream's lane: enqueued after every kernel that still reads the old one, before any that
+// needs the new one.  Asynchronous (pinned ring); the host waits only if it laps its own ring.
 static int push_table(E264Stream *s)
 {
-	// small synchronous-looking update, ordered on the queue before any kernel that reads it
-	HIPCHK(hipMemcpyAsync(s->d_table, s->h_table, sizeof(uint8_t *) * E264_MAX_SLOTS, hipMemcpyHostToDevice, s->dev->q), EIO);
-	HIPCHK(hipStreamSynchronize(s->dev->q), EIO); // h_table is pageable and may change right after
+	const int k = s->tab_next;
+	s->tab_next = (k + 1) % E264Stream::NTAB;
+	if (!s->tab_ev[k] && hipEventCreateWithFlags(&s->tab_ev[k], E264_WAIT_EVENT) != hipSuccess) { s->tab_ev[k] = nullptr; return fail(EIO, "hipEventCreate"); }
+	if (s->tab_busy[k]) { HIPCHK(hipEventSynchronize(s->tab_ev[k]), EIO); s->tab_busy[k] = false; }
+	uint8_t **pin = s->tab_pin + (size_t)k * E264_MAX_SLOTS;
+	memcpy(pin, s->h_table, sizeof(uint8_t *) * E264_MAX_SLOTS);
+	HIPCHK(hipMemcpyAsync(s->d_table, pin, sizeof(uint8_t *) * E264_MAX_SLOTS, hipMemcpyHostToDevice, lane_of(s)), EIO);
+	HIPCHK(hipEventRecord(s->tab_ev[k], lane_of(s)), EIO);
+	s->tab_busy[k] = true;
 	return 0;
 }
 
@@ -298,12 +447,14 @@ API int e264hip_frame_alloc(E264Stream *s, int slot, size_t samples_bytes, void 
 	if (s->h_table[slot]) e264hip_frame_free(s, slot);
 	// +64: the MC fast path reads whole dwords up to 3 bytes past a 9-sample span (like the
 	// reference's +16 over-read margin, src/edge264_headers.c:115)
-	if (hipMalloc(&s->h_table[slot], samples_bytes + 64) != hipSuccess) { s->h_table[slot] = nullptr; return fail(ENOMEM, "hipMalloc frame"); }
+	s->h_table[slot] = (uint8_t *)mem_acquire(s->dev, samples_bytes + 64, false);
+	if (!s->h_table[slot]) return fail(ENOMEM, "hipMalloc frame");
 	s->slot_bytes[slot] = samples_bytes;
 	s->slot_serial[slot] = 0;
 	if (host_mirror) {
-		if (hipHostMalloc(&s->mirror[slot], samples_bytes, hipHostMallocDefault) != hipSuccess) {
-			hipFree(s->h_table[slot]); s->h_table[slot] = nullptr; s->mirror[slot] = nullptr;
+		s->mirror[slot] = mem_acquire(s->dev, samples_bytes, true);
+		if (!s->mirror[slot]) {
+			mem_release(s->dev, s->h_table[slot], samples_bytes + 64, false, 0, 0); s->h_table[slot] = nullptr;
 			return fail(ENOMEM, "hipHostMalloc mirror");
 		}
 		*host_mirror = s->mirror[slot];
@@ -315,10 +466,12 @@ API void e264hip_frame_free(E264Stream *s, int slot)
 {
 	if (!s || slot < 0 || slot >= E264_MAX_SLOTS || !s->h_table[slot]) return;
 	set_device(s->dev);
-	hipStreamSynchronize(s->dev->q);
-	hipFree(s->h_table[slot]);
-	if (s->mirror[slot]) hipHostFree(s->mirror[slot]);
-	s->h_table[slot] = nullptr; s->mirror[slot] = nullptr; s->slot_bytes[slot] = 0;
+	// kernels already queued may still read or write the slot: it is parked until the stream's latest submission has retired
+	// (a fill / upload queued since then is not covered by that submission's event: the lane is waited for, rare)
+	if (s->loose) { hipStreamSynchronize(lane_of(s)); s->loose = false; }
+	mem_release(s->dev, s->h_table[slot], s->slot_bytes[slot] + 64, false, s->last_serial, s->lane);
+	mem_release(s->dev, s->mirror[slot], s->slot_bytes[slot], true, 0, 0); // downloads are synchronous: nothing in flight
+	s->h_table[slot] = nullptr; s->mirror[slot] = nullptr; s->slot_bytes[slot] = 0; s->slot_serial[slot] = 0;
 	push_table(s);
 }
 
@@ -326,8 +479,9 @@ API int e264hip_frame_fill(E264Stream *s, int slot, int value)
 {
 	if (!s || slot < 0 || slot >= E264_MAX_SLOTS || !s->h_table[slot]) return fail(EINVAL, "frame_fill slot");
 	if (set_device(s->dev)) return EIO;
-	HIPCHK(hipMemsetAsync(s->h_table[slot], value, s->slot_bytes[slot], s->dev->q), EIO);
-	s->slot_serial[slot] = 0; // written outside a submission: a later wait falls back to the whole queue
+	HIPCHK(hipMemsetAsync(s->h_table[slot], value, s->slot_bytes[slot], lane_of(s)), EIO);
+	s->slot_serial[slot] = 0; // written outside a submission: a later wait falls back to the lane
+	s->loose = true;
 	return 0;
 }
 
@@ -335,8 +489,8 @@ API int e264hip_frame_upload(E264Stream *s, int slot, const void *src, size_t by
 {
 	if (!s || slot < 0 || slot >= E264_MAX_SLOTS || !s->h_table[slot] || bytes > s->slot_bytes[slot]) return fail(EINVAL, "frame_upload");
 	if (set_device(s->dev)) return EIO;
-	HIPCHK(hipMemcpyAsync(s->h_table[slot], src, bytes, hipMemcpyHostToDevice, s->dev->q), EIO);
-	HIPCHK(hipStreamSynchronize(s->dev->q), EIO);
+	HIPCHK(hipMemcpyAsync(s->h_table[slot], src, bytes, hipMemcpyHostToDevice, lane_of(s)), EIO);
+	HIPCHK(hipStreamSynchronize(lane_of(s)), EIO);
 	s->slot_serial[slot] = 0;
 	return 0;
 }
@@ -360,7 +514,9 @@ static int check_packet(const void *packet, size_t bytes, int *dst, int *n_mbs, 
 
 // Everything a kernel will dereference through the packet, checked on the host before the packet may reach the
 // device (a wild offset would be a GPU memory fault = process abort, not an error code): section layout, per-macroblock
-// kind / slice index / payload bounds, reference slots.  `slots` (may be null): allocated-slot table of the stream.
+// kind / slice index / payload bounds / intra modes, reference slots, and the header's summary fields (ref_slots,
+// n_coded_mbs, n_inter_mbs) against the records -- the kernels' early exits and the trusted submission path rely on them.
+// `slots` (may be null): allocated-slot table of the stream.
 // `slot_bytes` (with `slots`): size of every allocated slot -- a packet whose header claims a larger picture than the slot
 // it writes or reads (SPS size change, stale capture, foreign packet) would make the kernels run past the allocation.
 // `ref_mask_out` (may be null): DPB slots the packet's motion refers to.
@@ -382,17 +538,28 @@ static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *s
 	const E264Mb *mbs = (const E264Mb *)(p + h->mbs_off);
 	const uint8_t *mot = h->motion_off ? p + h->motion_off : nullptr; // compact motion records, up to payload_off
 	const uint32_t mot_bytes = h->motion_off ? h->payload_off - h->motion_off : 0;
-	uint32_t ref_mask = 0;
+	uint32_t ref_mask = 0, n_coded = 0, n_inter = 0;
 	for (int a = 0; a < n_mbs; a++) {
 		const E264Mb &m = mbs[a];
 		if (m.kind > E264_MB_INTER) return fail(EINVAL, "macroblock kind");
 		if (m.slice >= h->n_slices || m.dbk_slice >= h->n_slices) return fail(EINVAL, "macroblock slice index"); // every record: the parameter kernel reads the slice of absent macroblocks too
 		if (m.kind == E264_MB_ABSENT) continue;
+		n_coded++;
 		if ((m.flags & E264_MBF_T8x8) && (m.kind == E264_MB_I16x16 || m.kind == E264_MB_PCM)) return fail(EINVAL, "8x8 transform flag on an Intra16x16 / PCM macroblock");
 		if ((m.payload_off & 7) || (uint64_t)m.payload_off + e264_mb_payload_bytes(&m) > h->payload_bytes) return fail(EINVAL, "macroblock payload");
 		if ((m.flags & E264_MBF_EDGE_LEFT) && a % h->width_mbs == 0) return fail(EINVAL, "left edge flag on the first column");
 		if ((m.flags & E264_MBF_EDGE_TOP) && a < h->width_mbs) return fail(EINVAL, "top edge flag on the first row");
+		// internal intra modes (src/edge264_internal.h:564-634): the kernels index tables with them
+		if (m.kind == E264_MB_I4x4) {
+			for (int k = 0; k < 16; k++)
+				if ((m.modes[k >> 1] >> (4 * (k & 1)) & 15) > 13) return fail(EINVAL, "Intra4x4 mode");
+		} else if (m.kind == E264_MB_I8x8) {
+			for (int k = 0; k < 4; k++)
+				if (m.modes[k] > 31) return fail(EINVAL, "Intra8x8 mode");
+		} else if (m.kind == E264_MB_I16x16 && m.i16_mode > 6) return fail(EINVAL, "Intra16x16 mode");
+		if (m.kind >= E264_MB_I4x4 && m.kind <= E264_MB_I16x16 && m.chroma_mode > 6) return fail(EINVAL, "intra chroma mode");
 		if (m.kind == E264_MB_INTER) {
+			n_inter++;
 			if (!mot) return fail(EINVAL, "inter macroblock without motion section");
 			uint32_t d[2];
 			memcpy(d, m.modes, 8); // motion directory: record offset, shape
@@ -410,6 +577,8 @@ static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *s
 			}
 		}
 	}
+	if (h->n_coded_mbs != n_coded || h->n_inter_mbs != n_inter) return fail(EINVAL, "header macroblock counts differ from the records");
+	if (h->ref_slots != ref_mask) return fail(EINVAL, "header ref_slots differs from the motion records");
 	if (ref_mask_out) *ref_mask_out = ref_mask;
 	return 0;
 }
@@ -420,17 +589,32 @@ API int e264hip_packet_check(const void *packet, size_t bytes)
 	return check_packet_deep(packet, bytes, nullptr);
 }
 
-static int ensure_dbk(E264Stream *s, int n_mbs)
+// A packet that has passed e264hip_packet_check (its header summarises its records) against THIS stream's allocations:
+// the destination and every slot of hdr.ref_slots exist and hold a picture of the packet's size.
+static int check_slots_of(const E264Stream *s, const E264FrameHdr *h)
 {
-	if (s->dbk_mbs >= (size_t)n_mbs) return 0;
-	if (s->d_dbk) { hipStreamSynchronize(s->dev->q); hipFree(s->d_dbk); s->d_dbk = nullptr; s->dbk_mbs = 0; }
-	if (hipMalloc((void **)&s->d_dbk, (size_t)n_mbs * E264_DBK_BYTES) != hipSuccess) return fail(ENOMEM, "hipMalloc deblock parameters");
-	s->dbk_mbs = (size_t)n_mbs;
+	const uint64_t need = (uint64_t)h->plane_size_Y + h->plane_size_C;
+	if (!s->h_table[h->dst_slot]) return fail(EINVAL, "destination slot not allocated");
+	if (need > s->slot_bytes[h->dst_slot]) return fail(EINVAL, "picture larger than the destination slot");
+	for (int sl = 0; sl < E264_MAX_SLOTS; sl++)
+		if (h->ref_slots >> sl & 1) {
+			if (!s->h_table[sl]) return fail(EINVAL, "reference slot not allocated");
+			if (need > s->slot_bytes[sl]) return fail(EINVAL, "picture larger than a reference slot");
+		}
 	return 0;
 }
 
-// Launches the kernels over a job table that already lives in HBM.
-static int launch(E264Device *dev, const E264Job *d_jobs, int n, int max_mbs, int max_tiles, int mode, uint64_t *serial_out = nullptr)
+static int ensure_dbk(E264Stream *s, int n_mbs)
+{
+	if (s->dbk_mbs >= (size_t)n_mbs) return 0;
+	mem_release(s->dev, s->d_dbk, s->dbk_mbs * E264_DBK_BYTES, false, s->last_serial, s->lane); // queued kernels may still use it
+	s->d_dbk = (uint8_t *)mem_acquire(s->dev, (size_t)n_mbs * E264_DBK_BYTES, false);
+	s->dbk_mbs = s->d_dbk ? (size_t)n_mbs : 0;
+	return s->d_dbk ? 0 : fail(ENOMEM, "hipMalloc deblock parameters");
+}
+
+// Launches the kernels over a job table that already lives in HBM, on compute lane `lane`.
+static int launch(E264Device *dev, int lane, const E264Job *d_jobs, int n, int max_mbs, int max_tiles, int mode, uint64_t *serial_out = nullptr)
 {
 	std::lock_guard<std::mutex> g(dev->lock);
 	hipEvent_t *marks = nullptr;
@@ -443,13 +627,13 @@ static int launch(E264Device *dev, const E264Job *d_jobs, int n, int max_mbs, in
 			dev->kev.push_back(m);
 		}
 		E264Device::Marks &m = dev->kev[dev->kev_used++];
-		m.side = fork.aux != nullptr && (mode & 2) && !((mode | dev->dbg_mode) & 2048);
+		m.side = fork.aux != nullptr && (mode & 2);
 		marks = m.e; fork.amarks = m.a;
 	}
-	HIPCHK(e264_launch_frames(d_jobs, n, max_mbs, max_tiles, mode | dev->dbg_mode, dev->waves | dev->intra_waves << 8, dev->q, marks, &fork), EIO);
+	HIPCHK(e264_launch_frames(d_jobs, n, max_mbs, max_tiles, mode, dev->waves | dev->intra_waves << 8, dev->q[lane], marks, &fork), EIO);
 	const uint64_t serial = ++dev->serial;
 	const int idx = (int)(serial % E264Device::NEV);
-	if (dev->sub_ev[idx] && hipEventRecord(dev->sub_ev[idx], dev->q) == hipSuccess) dev->sub_serial[idx] = serial;
+	if (dev->sub_ev[idx] && hipEventRecord(dev->sub_ev[idx], dev->q[lane]) == hipSuccess) dev->sub_serial[idx] = serial;
 	else dev->sub_serial[idx] = 0;
 	if (serial_out) *serial_out = serial;
 	return 0;
@@ -458,36 +642,37 @@ static int launch(E264Device *dev, const E264Job *d_jobs, int n, int max_mbs, in
 // Blocks until the submission that wrote `slot` last has retired (not until the device is idle).
 static int wait_slot(E264Stream *s, int slot)
 {
-	E264Device *dev = s->dev;
-	const uint64_t serial = s->slot_serial[slot];
-	hipEvent_t ev = nullptr;
-	if (serial) {
-		std::lock_guard<std::mutex> g(dev->lock);
-		const int idx = (int)(serial % E264Device::NEV);
-		if (dev->sub_serial[idx] == serial) ev = dev->sub_ev[idx];
+	if (!s->slot_serial[slot]) { // filled / uploaded outside a submission: the stream's lane
+		HIPCHK(hipStreamSynchronize(lane_of(s)), EIO);
+		return 0;
 	}
-	if (!ev) return e264hip_device_sync(dev); // filled / uploaded outside a submission, or the event ring has wrapped: everything queued retires
-	HIPCHK(hipEventSynchronize(ev), EIO);
-	return 0;
+	return serial_wait(s->dev, s->slot_serial[slot], s->lane);
+}
+
+// The next slot of the stream's staging ring, large enough for max_bytes: pinned host + device buffer + job slot + event.
+static E264Stream::Stage *stage_prepare(E264Stream *s, size_t max_bytes)
+{
+	E264Stream::Stage &st = s->stage[s->stage_next];
+	if (st.busy) { hipEventSynchronize(st.done); st.busy = false; }
+	if (!st.done && hipEventCreateWithFlags(&st.done, E264_WAIT_EVENT) != hipSuccess) { st.done = nullptr; fail(EIO, "hipEventCreate"); return nullptr; }
+	if (!st.d_job && !(st.d_job = (E264Job *)mem_acquire(s->dev, sizeof(E264Job), false))) { fail(ENOMEM, "job slot"); return nullptr; }
+	if (st.cap < max_bytes) {
+		mem_release(s->dev, st.h, st.cap + 64, true, 0, 0); // not busy: nothing in flight reads it
+		mem_release(s->dev, st.d, st.cap, false, 0, 0);
+		st.h = nullptr; st.d = nullptr; st.cap = 0;
+		size_t cap = (max_bytes + 65535) & ~(size_t)65535;
+		if (!(st.h = mem_acquire(s->dev, cap + 64, true))) { fail(ENOMEM, "pinned packet buffer"); return nullptr; }
+		if (!(st.d = (uint8_t *)mem_acquire(s->dev, cap, false))) { mem_release(s->dev, st.h, cap + 64, true, 0, 0); st.h = nullptr; fail(ENOMEM, "device packet buffer"); return nullptr; }
+		st.cap = cap;
+	}
+	return &st;
 }
 
 API void *e264hip_packet_buffer(E264Stream *s, size_t max_bytes)
 {
 	if (!s || set_device(s->dev)) return nullptr;
-	E264Stream::Stage &st = s->stage[s->stage_next];
-	if (st.busy) { hipEventSynchronize(st.done); st.busy = false; }
-	if (!st.done && hipEventCreateWithFlags(&st.done, E264_WAIT_EVENT) != hipSuccess) { st.done = nullptr; fail(EIO, "hipEventCreate"); return nullptr; }
-	if (!st.d_job && hipMalloc((void **)&st.d_job, sizeof(E264Job)) != hipSuccess) { st.d_job = nullptr; fail(ENOMEM, "job slot"); return nullptr; }
-	if (st.cap < max_bytes) {
-		if (st.h) hipHostFree(st.h);
-		if (st.d) hipFree(st.d);
-		st.h = nullptr; st.d = nullptr; st.cap = 0;
-		size_t cap = (max_bytes + 65535) & ~(size_t)65535;
-		if (hipHostMalloc(&st.h, cap + 64, hipHostMallocDefault) != hipSuccess) { st.h = nullptr; fail(ENOMEM, "pinned packet buffer"); return nullptr; }
-		if (hipMalloc((void **)&st.d, cap) != hipSuccess) { hipHostFree(st.h); st.h = nullptr; st.d = nullptr; fail(ENOMEM, "device packet buffer"); return nullptr; }
-		st.cap = cap;
-	}
-	return st.h;
+	E264Stream::Stage *st = stage_prepare(s, max_bytes);
+	return st ? st->h : nullptr;
 }
 
 API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
@@ -502,23 +687,25 @@ API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
 	E264Stream::Stage *st = &s->stage[s->stage_next];
 	if (packet == st->h && bytes > st->cap) return fail(EINVAL, "packet larger than the buffer e264hip_packet_buffer returned");
 	if (packet != st->h) { // caller did not use our pinned buffer: stage it
-		void *h = e264hip_packet_buffer(s, bytes);
-		if (!h) return ENOMEM;
-		st = &s->stage[s->stage_next];
-		memcpy(h, packet, bytes);
+		st = stage_prepare(s, bytes);
+		if (!st) return ENOMEM;
+		memcpy(st->h, packet, bytes);
 	}
 	s->stage_next = (s->stage_next + 1) & 3;
-	HIPCHK(hipMemcpyAsync(st->d, st->h, bytes, hipMemcpyHostToDevice, s->dev->q), EIO);
-	// the job record rides at the tail of the pinned staging buffer's lifetime: tiny H2D on the same queue
+	hipStream_t q = lane_of(s);
+	// the job record rides at the tail of the pinned staging buffer: tiny H2D on the same queue
 	E264Job *job = (E264Job *)((uint8_t *)st->h + st->cap); // pinned, lives as long as the staging slot
 	job->packet = st->d; job->dpb = s->d_table; job->dbk = s->d_dbk;
-	HIPCHK(hipMemcpyAsync(st->d_job, job, sizeof(*job), hipMemcpyHostToDevice, s->dev->q), EIO);
+	hipError_t e = hipMemcpyAsync(st->d, st->h, bytes, hipMemcpyHostToDevice, q);
+	if (e == hipSuccess) e = hipMemcpyAsync(st->d_job, job, sizeof(*job), hipMemcpyHostToDevice, q);
 	uint64_t serial = 0;
-	r = launch(s->dev, st->d_job, 1, n_mbs, n_tiles, E264_RUN_ALL, &serial);
-	if (r) return r;
-	s->slot_serial[dst] = serial;
-	hipEventRecord(st->done, s->dev->q);
+	r = e == hipSuccess ? launch(s->dev, s->lane, st->d_job, 1, n_mbs, n_tiles, E264_RUN_ALL, &serial) : fail(EIO, "hipMemcpyAsync packet", e);
+	// whatever was queued reads the staging slot: it is busy until the lane has passed this point, error or not
+	hipEventRecord(st->done, q);
 	st->busy = true;
+	if (r) return r;
+	s->slot_serial[dst] = s->last_serial = serial;
+	s->loose = false;
 	return 0;
 }
 
@@ -539,7 +726,7 @@ API int e264hip_frame_download(E264Stream *s, int slot, void *dst, size_t bytes)
 	if (bytes == 0 || bytes > s->slot_bytes[slot]) bytes = s->slot_bytes[slot];
 	int r = wait_slot(s, slot); // the frame is final on the device; the copy runs beside whatever other decoders have queued since
 	if (r) return r;
-	hipStream_t qc = s->dev->qc ? s->dev->qc : s->dev->q;
+	hipStream_t qc = s->dev->qc ? s->dev->qc : lane_of(s);
 	if (!s->dl_done && hipEventCreateWithFlags(&s->dl_done, E264_WAIT_EVENT) != hipSuccess) { s->dl_done = nullptr; return fail(EIO, "hipEventCreate"); }
 	HIPCHK(hipMemcpyAsync(dst, s->h_table[slot], bytes, hipMemcpyDeviceToHost, qc), EIO);
 	HIPCHK(hipEventRecord(s->dl_done, qc), EIO);
@@ -570,7 +757,7 @@ API void e264hip_packet_free(E264Packet *p)
 {
 	if (!p) return;
 	hipSetDevice(p->dev->ordinal);
-	hipStreamSynchronize(p->dev->q);
+	e264hip_device_sync(p->dev); // a resident packet may be named by batches of any lane (benchmarks, tests: not a decoder's path)
 	hipFree(p->d_bytes);
 	delete p;
 }
@@ -578,7 +765,7 @@ API void e264hip_packet_free(E264Packet *p)
 struct E264Batch {
 	E264Device *dev;
 	E264Job *d_jobs;
-	int n, max_mbs, max_tiles;
+	int n, max_mbs, max_tiles, lane;
 	std::vector<std::pair<E264Stream *, int>> writes; // (stream, destination slot) of every job
 };
 
@@ -590,6 +777,7 @@ API int e264hip_batch_create(E264Device *dev, E264Stream *const *streams, E264Pa
 	int max_mbs = 0, max_tiles = 0;
 	for (int i = 0; i < n; i++) {
 		if (!streams[i] || !packets[i] || streams[i]->dev != dev || packets[i]->dev != dev) return fail(EINVAL, "batch entry");
+		if (streams[i]->lane != streams[0]->lane) return fail(EINVAL, "the streams of a batch must be bound to one compute lane");
 		if (!streams[i]->h_table[packets[i]->dst_slot]) return fail(EINVAL, "destination slot not allocated");
 		// the packet was vetted without a stream at upload time: its slots against THIS stream's allocations
 		if (packets[i]->frame_bytes > streams[i]->slot_bytes[packets[i]->dst_slot]) return fail(EINVAL, "picture larger than the destination slot");
@@ -610,7 +798,7 @@ API int e264hip_batch_create(E264Device *dev, E264Stream *const *streams, E264Pa
 	}
 	E264Batch *b = new (std::nothrow) E264Batch();
 	if (!b) return fail(ENOMEM, "batch object");
-	b->dev = dev; b->n = n; b->max_mbs = max_mbs; b->max_tiles = max_tiles;
+	b->dev = dev; b->n = n; b->max_mbs = max_mbs; b->max_tiles = max_tiles; b->lane = streams[0]->lane;
 	for (int i = 0; i < n; i++) b->writes.emplace_back(streams[i], packets[i]->dst_slot);
 	if (hipMalloc((void **)&b->d_jobs, sizeof(E264Job) * n) != hipSuccess) { delete b; return fail(ENOMEM, "hipMalloc jobs"); }
 	hipError_t e = hipMemcpy(b->d_jobs, jobs.data(), sizeof(E264Job) * n, hipMemcpyHostToDevice);
@@ -623,9 +811,11 @@ API int e264hip_batch_submit(E264Batch *b, int mode)
 {
 	if (!b) return fail(EINVAL, "null batch");
 	if (set_device(b->dev)) return EIO;
+	for (auto &w : b->writes)
+		if (w.first->lane != b->lane) return fail(EINVAL, "a stream of the batch was bound to another lane after batch_create");
 	uint64_t serial = 0;
-	int r = launch(b->dev, b->d_jobs, b->n, b->max_mbs, b->max_tiles, mode, &serial);
-	if (!r) for (auto &w : b->writes) w.first->slot_serial[w.second] = serial;
+	int r = launch(b->dev, b->lane, b->d_jobs, b->n, b->max_mbs, b->max_tiles, mode, &serial);
+	if (!r) for (auto &w : b->writes) { w.first->slot_serial[w.second] = w.first->last_serial = serial; w.first->loose = false; }
 	return r;
 }
 
@@ -633,7 +823,7 @@ API void e264hip_batch_free(E264Batch *b)
 {
 	if (!b) return;
 	hipSetDevice(b->dev->ordinal);
-	hipStreamSynchronize(b->dev->q);
+	hipStreamSynchronize(b->dev->q[b->lane]);
 	hipFree(b->d_jobs);
 	delete b;
 }
@@ -644,13 +834,14 @@ API int e264hip_submit_batch(E264Device *dev, E264Stream *const *streams, E264Pa
 	int r = e264hip_batch_create(dev, streams, packets, n, &b);
 	if (r) return r;
 	r = e264hip_batch_submit(b, mode);
-	e264hip_batch_free(b); // synchronises the queue: convenience path for tests
+	e264hip_batch_free(b); // synchronises the lane: convenience path for tests
 	return r;
 }
 
 // Host packets of MANY streams, one submission, nothing synchronous: every packet is staged through its
-// stream's pinned ring and copied on the device queue, the job table through a device-level ring, then the four
-// kernels are launched.  The caller may reuse / free the host packets on return.
+// stream's pinned ring and copied on the upload queue, the job table through a device-level ring, then the four
+// kernels are launched on the streams' lane behind the batch's upload event.  The caller may reuse / free the host
+// packets on return.
 static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const void *const *packets, const size_t *bytes, int n, int mode, int flags);
 API int e264hip_submit_batch_host(E264Device *dev, E264Stream *const *streams, const void *const *packets, const size_t *bytes, int n, int mode)
 {
@@ -660,7 +851,8 @@ API int e264hip_submit_batch_host(E264Device *dev, E264Stream *const *streams, c
 // the packet in place): no staging copy, the H2D reads the caller's buffer, which must stay untouched until the submission
 // has retired (e264hip_device_sync / a later e264hip_frame_wait).  E264_SUBMIT_TRUSTED: the caller has run
 // e264hip_packet_check on exactly these bytes (a packet produced by its own emitter, a validated capture): the
-// per-macroblock walk is not repeated on the submitting thread.
+// per-macroblock walk is not repeated on the submitting thread; the slots the vetted header names (dst_slot, ref_slots)
+// are still checked against this stream's allocations.
 API int e264hip_submit_batch_pinned(E264Device *dev, E264Stream *const *streams, const void *const *packets, const size_t *bytes, int n, int mode, int flags)
 {
 	return submit_host_impl(dev, streams, packets, bytes, n, mode, 1 | (flags & E264_SUBMIT_TRUSTED ? 2 : 0));
@@ -684,80 +876,96 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 	std::vector<std::string> why((size_t)n);
 	for (int i = 0; i < n; i++) {
 		if (!streams[i] || streams[i]->dev != dev) return fail(EINVAL, "batch entry");
+		if (streams[i]->lane != streams[0]->lane) return fail(EINVAL, "the streams of a batch must be bound to one compute lane");
 		for (int j = 0; j < i; j++)
 			if (streams[j] == streams[i]) return fail(EINVAL, "a stream may contribute one frame per batch");
 	}
+	const int lane = streams[0]->lane;
 	{ // validate the whole batch before the first side effect: every packet on its own, in parallel
-		std::lock_guard<std::mutex> pg(g_pool_user);
-		g_pool.parallel_for(n, [&](int i) {
+		std::lock_guard<std::mutex> pg(dev->pool_user);
+		dev->pool.parallel_for(n, [&](int i) {
 			E264Stream *s = streams[i];
 			int dst, r = check_packet(packets[i], bytes[i], &dst, &mbs_of[i], &tiles_of[i]);
 			dst_of[i] = dst;
 			if (!r && !s->h_table[dst]) r = fail(EINVAL, "destination slot not allocated");
 			if (!r && !trusted) r = check_packet_deep(packets[i], bytes[i], s->h_table, s->slot_bytes);
-			if (!r && trusted && (uint64_t)((const E264FrameHdr *)packets[i])->plane_size_Y + ((const E264FrameHdr *)packets[i])->plane_size_C > s->slot_bytes[dst])
-				r = fail(EINVAL, "picture larger than the destination slot");
+			if (!r && trusted) r = check_slots_of(s, (const E264FrameHdr *)packets[i]);
 			if (r) { rc[i] = r; why[i] = g_err; } // the message lives in the worker's thread-local buffer
 		});
 	}
 	for (int i = 0; i < n; i++)
 		if (rc[i]) return fail(rc[i], why[i].c_str());
 	std::lock_guard<std::mutex> bg(dev->batch_lock); // batches of one device are serialised (their streams are disjoint per batch anyway)
+	// ---- every allocation first: a failure below this block would leave copies in flight on buffers nobody guards ----
 	E264Device::JobRing &jr = dev->jring[dev->jring_next];
-	dev->jring_next = (dev->jring_next + 1) & 3;
 	if (jr.busy) { hipEventSynchronize(jr.done); jr.busy = false; }
 	if (jr.cap < n) {
-		if (jr.h) hipHostFree(jr.h);
-		if (jr.d) hipFree(jr.d);
+		if (jr.h) mem_release(dev, jr.h, sizeof(E264Job) * jr.cap, true, 0, 0);
+		if (jr.d) mem_release(dev, jr.d, sizeof(E264Job) * jr.cap, false, 0, 0);
 		jr.h = nullptr; jr.d = nullptr; jr.cap = 0;
 		int cap = (n + 63) & ~63;
-		if (hipHostMalloc((void **)&jr.h, sizeof(E264Job) * cap, hipHostMallocDefault) != hipSuccess) return fail(ENOMEM, "pinned job table");
-		if (hipMalloc((void **)&jr.d, sizeof(E264Job) * cap) != hipSuccess) { hipHostFree(jr.h); jr.h = nullptr; return fail(ENOMEM, "device job table"); }
+		if (!(jr.h = (E264Job *)mem_acquire(dev, sizeof(E264Job) * cap, true))) return fail(ENOMEM, "pinned job table");
+		if (!(jr.d = (E264Job *)mem_acquire(dev, sizeof(E264Job) * cap, false))) { mem_release(dev, jr.h, sizeof(E264Job) * cap, true, 0, 0); jr.h = nullptr; return fail(ENOMEM, "device job table"); }
 		jr.cap = cap;
-		if (!jr.done) hipEventCreateWithFlags(&jr.done, E264_WAIT_EVENT);
 	}
+	if (!jr.done && hipEventCreateWithFlags(&jr.done, E264_WAIT_EVENT) != hipSuccess) { jr.done = nullptr; return fail(EIO, "hipEventCreate"); }
+	if (!jr.up && hipEventCreateWithFlags(&jr.up, hipEventDisableTiming) != hipSuccess) { jr.up = nullptr; return fail(EIO, "hipEventCreate"); }
 	int max_mbs = 0, max_tiles = 0;
 	std::vector<E264Stream::Stage *> stage_of((size_t)n);
-	for (int i = 0; i < n; i++) { // staging slots (HIP calls: this thread only)
+	for (int i = 0; i < n; i++) { // staging slots (HIP calls: this thread only); the rings advance only when everything is there
 		E264Stream *s = streams[i];
-		const int n_mbs = mbs_of[i];
 		if (tiles_of[i] > max_tiles) max_tiles = tiles_of[i];
-		int r = ensure_dbk(s, n_mbs);
+		if (mbs_of[i] > max_mbs) max_mbs = mbs_of[i];
+		int r = ensure_dbk(s, mbs_of[i]);
 		if (r) return r;
-		if (!e264hip_packet_buffer(s, bytes[i])) return ENOMEM;
-		stage_of[i] = &s->stage[s->stage_next];
-		s->stage_next = (s->stage_next + 1) & 3;
-		if (n_mbs > max_mbs) max_mbs = n_mbs;
+		if (!(stage_of[i] = stage_prepare(s, bytes[i]))) return ENOMEM;
 	}
+	dev->jring_next = (dev->jring_next + 1) & 7;
+	for (int i = 0; i < n; i++) streams[i]->stage_next = (streams[i]->stage_next + 1) & 3;
 	if (!pinned) {
-		std::lock_guard<std::mutex> pg(g_pool_user);
-		g_pool.parallel_for(n, [&](int i) { memcpy(stage_of[i]->h, packets[i], bytes[i]); });
+		std::lock_guard<std::mutex> pg(dev->pool_user);
+		dev->pool.parallel_for(n, [&](int i) { memcpy(stage_of[i]->h, packets[i], bytes[i]); });
 	}
-	for (int i = 0; i < n; i++) {
+	// ---- copies on the upload queue, kernels on the lane behind the batch's upload event ----
+	hipStream_t q = dev->q[lane], up = dev->upload_queue && dev->qup ? dev->qup : q;
+	hipError_t e = hipSuccess;
+	for (int i = 0; i < n && e == hipSuccess; i++) {
 		E264Stream::Stage *st = stage_of[i];
-		HIPCHK(hipMemcpyAsync(st->d, pinned ? packets[i] : st->h, bytes[i], hipMemcpyHostToDevice, dev->q), EIO);
+		e = hipMemcpyAsync(st->d, pinned ? packets[i] : st->h, bytes[i], hipMemcpyHostToDevice, up);
 		jr.h[i].packet = st->d; jr.h[i].dpb = streams[i]->d_table; jr.h[i].dbk = streams[i]->d_dbk;
 	}
-	HIPCHK(hipMemcpyAsync(jr.d, jr.h, sizeof(E264Job) * n, hipMemcpyHostToDevice, dev->q), EIO);
-	uint64_t serial = 0;
-	int r = launch(dev, jr.d, n, max_mbs, max_tiles, mode, &serial);
-	if (r) return r;
-	for (int i = 0; i < n; i++) streams[i]->slot_serial[dst_of[i]] = serial;
-	hipEventRecord(jr.done, dev->q);
-	jr.busy = true;
-	for (int i = 0; i < n; i++) { // the staging slots are free again when this submission has retired
-		E264Stream::Stage &st = streams[i]->stage[(streams[i]->stage_next + 3) & 3];
-		hipEventRecord(st.done, dev->q);
-		st.busy = true;
+	if (e == hipSuccess) e = hipMemcpyAsync(jr.d, jr.h, sizeof(E264Job) * n, hipMemcpyHostToDevice, up);
+	if (e == hipSuccess && up != q) {
+		e = hipEventRecord(jr.up, up);
+		if (e == hipSuccess) e = hipStreamWaitEvent(q, jr.up, 0);
 	}
+	uint64_t serial = 0;
+	int r = e == hipSuccess ? launch(dev, lane, jr.d, n, max_mbs, max_tiles, mode, &serial) : fail(EIO, "packet upload", e);
+	if (r && up != q) hipStreamSynchronize(up); // copies already queued must not outlive the error return unguarded
+	// the job table and the staging slots are busy until the lane has passed this point -- also on an error above: whatever
+	// part of the batch was queued still reads them
+	hipEventRecord(jr.done, q);
+	jr.busy = true;
+	for (int i = 0; i < n; i++) {
+		hipEventRecord(stage_of[i]->done, q);
+		stage_of[i]->busy = true;
+	}
+	if (r) return r;
+	for (int i = 0; i < n; i++) { streams[i]->slot_serial[dst_of[i]] = streams[i]->last_serial = serial; streams[i]->loose = false; }
 	return 0;
 }
 
+// Timing events are recorded on lane 0 AFTER everything queued on the other lanes so far (lane 0 waits for them): with one
+// lane in use that is the plain event on the queue of the kernels, with several it brackets all of them.
 API int e264hip_event_record(E264Device *dev, int idx)
 {
 	if (!dev || idx < 0 || idx >= 16) return fail(EINVAL, "event index");
 	if (set_device(dev)) return EIO;
-	HIPCHK(hipEventRecord(dev->ev[idx], dev->q), EIO);
+	for (int i = 1; i < E264Device::NQ; i++) {
+		HIPCHK(hipEventRecord(dev->lane_ev[i], dev->q[i]), EIO);
+		HIPCHK(hipStreamWaitEvent(dev->q[0], dev->lane_ev[i], 0), EIO);
+	}
+	HIPCHK(hipEventRecord(dev->ev[idx], dev->q[0]), EIO);
 	return 0;
 }
 

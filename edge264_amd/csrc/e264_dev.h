@@ -219,8 +219,7 @@ struct FrameCtx {
 	int wm, hm;        // macroblocks
 	int sY, sC;        // strides
 	uint32_t psY;      // plane_size_Y
-	int dbg;           // profiling ablations: bit8 no luma MC, bit9 no chroma MC, bit10 no residual, bit11 no bS, bit12 no store
-	gu8 *dbk;          // per-MB deblocking parameters (E264_DBK_BYTES each), written by the mbpar kernel
+	gu8 *dbk;          // per-MB deblocking parameters (E264_DBK_BYTES each), written by e264_dbkparam2_kernel
 };
 
 E264_DEV gu8 *plane_base(const FrameCtx &f, gu8 *base, int pl)
@@ -240,7 +239,6 @@ E264_DEV bool open_frame(FrameCtx &f, const E264Job &job)
 	f.payload = (const gu8 *)(pkt + h->payload_off);
 	f.motion = h->motion_off ? (const gu8 *)(pkt + h->motion_off) : nullptr;
 	f.dpb_lds = nullptr;
-	f.dbg = 0;
 	f.dpb = (gdpb_t)job.dpb;
 	f.cur = (gu8 *)job.dpb[h->dst_slot];
 	f.wm = h->width_mbs; f.hm = h->height_mbs;

@@ -669,12 +669,10 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const Mb
 	if (WHICH != 1 && m.kind != E264_MB_INTER)
 		nbv = issue_intra_neighbours(f, mbx, mby, lane); // in flight during the residual
 	PH(2);
-	if (!(f.dbg & 1024)) {
-		slice_cache(L, f, m.slice, lane);
-		coef_commit(L, m, lane, pf);
-		PH(3);
-		compute_residual(L, f, m, lane);
-	}
+	slice_cache(L, f, m.slice, lane);
+	coef_commit(L, m, lane, pf);
+	PH(3);
+	compute_residual(L, f, m, lane);
 	PH(4);
 
 	int pY[4], pC[2];
@@ -731,7 +729,6 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const Mb
 			(uint32_t)clip255(w16(pY[2] + rr[2])) << 16 | (uint32_t)clip255(w16(pY[3] + rr[3])) << 24;
 	}
 	PH(7);
-	if (f.dbg & 4096) return;
 	*(gu32 *)dY = outw;
 	const int16_t *rc = L.res + 256 + cpl * 64 + cy * 8 + cx;
 	*(gu16 *)dC = (uint16_t)(clip255(w16(pC[0] + rc[0])) | clip255(w16(pC[1] + rc[1])) << 8);
@@ -1023,15 +1020,12 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 		return hipSuccess;
 	// marks (optional): 5 events recorded before / between / after the four launches
 	if (marks) hipEventRecord(marks[0], stream);
-	const bool dbkp = (mode & 2) && !(mode & 2048);
+	const bool dbkp = (mode & 2) != 0;
 	// fork (optional): the parameter kernel reads nothing but the packet and is needed only by the deblocking kernel, so it
 	// runs on a second queue NEXT TO the macroblock-parallel kernel -- 28 VGPRs per wave, its waves fit beside the two
 	// 215-VGPR waves per SIMD and use issue slots those leave idle.  Ordered after everything enqueued before (the packet
 	// copies, the previous batch's deblocking that still reads the parameter buffer) by `forked`, before deblocking by `joined`.
 	const bool side = dbkp && fork && fork->aux;
-	// side queue, second form (mode bit 16): the fork sits AFTER the prediction kernel, so that the parameter kernel (bound by
-	// packet reads) runs beside the intra wavefront kernel (bound by dependency latency) instead of beside the prediction kernel
-	const bool side_late = side && (mode & 65536);
 	auto launch_side = [&]() {
 		hipEventRecord(fork->forked, stream);
 		hipStreamWaitEvent(fork->aux, fork->forked, 0);
@@ -1040,15 +1034,14 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 		if (marks) hipEventRecord(fork->amarks[1], fork->aux);
 		hipEventRecord(fork->joined, fork->aux);
 	};
-	if (side) {
-		if (!side_late) launch_side();
-	} else if (dbkp) // (mode bit 17: the prediction kernel computes the parameters of its tiles itself)
+	if (side)
+		launch_side();
+	else if (dbkp)
 		hipLaunchKernelGGL(e264_dbkparam2_kernel, dim3((max_mbs + DP_MBS - 1) / DP_MBS, n_jobs), dim3(DP_NT), 0, stream, jobs);
 	if (marks) hipEventRecord(marks[1], stream);
 	if (mode & 1)
 		hipLaunchKernelGGL(e264_pred_kernel, dim3(max_tiles, n_jobs), dim3(PT_NT), 0, stream, jobs, mode);
 	if (marks) hipEventRecord(marks[2], stream);
-	if (side_late) launch_side();
 	const int intra_waves = waves >> 8 ? waves >> 8 : waves & 255;
 	waves &= 255;
 	if (mode & 1) {

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-typedef struct E264Device E264Device; /* one per GPU: HIP stream, kernels, staging */
+typedef struct E264Device E264Device; /* one per GPU: compute lanes (HIP queues), upload / download queues, kernels */
 typedef struct E264Stream E264Stream; /* one per decoder: device DPB slots + host mirrors */
 
 /* ---- device ------------------------------------------------------------ */
@@ -41,6 +41,14 @@ const char *e264hip_last_error(void);
 /* ---- decoder-side objects ---------------------------------------------- */
 int  e264hip_stream_open(E264Device *dev, E264Stream **out);
 void e264hip_stream_close(E264Stream *s);
+/* Compute lanes.  A device has E264_MAX_LANES HIP queues for kernels; a stream is bound to one (default 0) and everything
+ * that touches its DPB is ordered there, like the frames of one Edge264Decoder are ordered by its task queue
+ * (src/edge264_internal.h:396-400).  Streams of different lanes are independent (src/edge264_internal.h:144-151: no shared
+ * state between decoders), so their submissions overlap on the GPU: the tile-parallel kernels of one lane use the compute
+ * units the wavefront kernels of another leave idle.  All streams of one batch must share a lane.  Rebinding waits for
+ * what the stream still has queued on its old lane. */
+#define E264_MAX_LANES 4
+int  e264hip_stream_bind_lane(E264Stream *s, int lane);
 
 /* Frame memory.  Replaces Edge264AllocCb / Edge264FreeCb (edge264.h:42-43; called from
  * alloc_frame, src/edge264_headers.c:113-133): the samples of DPB slot `slot` live in
@@ -66,7 +74,9 @@ void *e264hip_packet_buffer(E264Stream *s, size_t max_bytes);
 int  e264hip_frame_wait(E264Stream *s, int slot);
 /* Copy the finished frame to its host mirror (what get_frame hands out). */
 int  e264hip_frame_download(E264Stream *s, int slot, void *dst, size_t bytes);
-/* edge264_flush (src/edge264.c:261-270): drain the queue, keep allocations. */
+/* edge264_flush (src/edge264.c:261-270): wait for what THIS stream has submitted, keep allocations.  (frame_alloc,
+ * frame_free, stream_close and frame_download likewise never wait for other decoders' work: freed memory is parked and
+ * recycled by the device object instead of hipFree'd, which would drain every queue.) */
 int  e264hip_stream_flush(E264Stream *s);
 
 /* ---- batched, device-resident replay (multi-stream front end, benchmarking) ---- */
@@ -93,7 +103,9 @@ int  e264hip_submit_batch_host(E264Device *dev, E264Stream *const *streams, cons
  * the caller's buffer, which must stay untouched until the submission has retired.  This is the path of a front end whose
  * emitters write the finished frame straight into pinned memory (the reference's per-frame hand-over point,
  * src/edge264_headers.c:532-568).  flags: E264_SUBMIT_TRUSTED = these exact bytes have already passed
- * e264hip_packet_check (on the parser thread that produced them), the per-macroblock walk is not repeated here. */
+ * e264hip_packet_check (on the parser thread that produced them), the per-macroblock walk is not repeated here; the slots
+ * the vetted header names (dst_slot, ref_slots -- packet_check verifies both against the records) are still checked
+ * against the stream's allocations. */
 #define E264_SUBMIT_TRUSTED 1
 int  e264hip_submit_batch_pinned(E264Device *dev, E264Stream *const *streams, const void *const *packets, const size_t *bytes, int n, int mode, int flags);
 void *e264hip_host_alloc(E264Device *dev, size_t bytes);
@@ -105,8 +117,8 @@ int  e264hip_batch_create(E264Device *dev, E264Stream *const *streams, E264Packe
 int  e264hip_batch_submit(E264Batch *b, int mode);
 void e264hip_batch_free(E264Batch *b);
 
-/* Timing on the queue the kernels run on (hipEvents; torch.cuda.Event would only see
- * torch's own stream).  Slots 0..15. */
+/* Timing on the queues the kernels run on (hipEvents; torch.cuda.Event would only see
+ * torch's own stream).  Slots 0..15.  Recorded on lane 0 behind everything queued on the other lanes so far. */
 int  e264hip_event_record(E264Device *dev, int idx);
 int  e264hip_event_elapsed_ms(E264Device *dev, int idx_start, int idx_stop, float *ms);
 /* Accumulated time of each of the four kernels of a submission (ms4[0] deblock-parameter kernel,
@@ -117,7 +129,10 @@ int  e264hip_kernel_time_ms(E264Device *dev, double *ms4, int *launches);
 
 /* Tunables; returns the previous value, -1 if unknown: "waves" / "intra_waves" (waves per frame workgroup of the two
  * wavefront kernels), "side_queue" (1 = the deblock-parameter kernel runs on a second HIP queue beside the parallel MB
- * kernel; its ms4[0] is then measured on that queue), "debug_mode" (profiling ablations: wrong output on purpose). */
+ * kernel; its ms4[0] is then measured on that queue), "upload_queue" (default 1: the H2D copies of host batches run on
+ * the device's upload queue beside the kernels of earlier batches; 0: on the lane itself, in order with them).
+ * Timing ablations that skip work are separate builds of the library (csrc/Makefile `variant`, -DE264_ABL_*), never an
+ * option of the product. */
 int  e264hip_set_option(E264Device *dev, const char *name, int value);
 
 #ifdef __cplusplus

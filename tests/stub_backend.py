@@ -5,6 +5,7 @@ import time
 
 IS_STUB = True
 RUN_RECON, RUN_DEBLOCK, RUN_ALL = 1, 2, 3
+MAX_LANES = 4
 
 
 class _Packet:
@@ -62,6 +63,9 @@ class Stream:
         pass
 
     def close(self):
+        pass
+
+    def bind_lane(self, lane):
         pass
 
     def alloc(self, slot, mirror=False):
