@@ -495,7 +495,7 @@ API int e264hip_frame_upload(E264Stream *s, int slot, const void *src, size_t by
 	return 0;
 }
 
-// tiles: workgroups e264_pred_kernel needs for this frame (16 x 8 macroblocks each)
+// tiles: workgroups e264_pred_kernel needs for this frame
 static int check_packet(const void *packet, size_t bytes, int *dst, int *n_mbs, int *tiles = nullptr)
 {
 	const E264FrameHdr *h = (const E264FrameHdr *)packet;
@@ -508,7 +508,7 @@ static int check_packet(const void *packet, size_t bytes, int *dst, int *n_mbs, 
 	if (need > h->payload_off || (size_t)h->payload_off + h->payload_bytes > h->total_bytes) return fail(EINVAL, "packet layout");
 	*dst = h->dst_slot;
 	*n_mbs = (int)h->width_mbs * h->height_mbs;
-	if (tiles) *tiles = ((h->width_mbs + 15) / 16) * ((h->height_mbs + 7) / 8);
+	if (tiles) *tiles = e264_pred_tiles(h->width_mbs, h->height_mbs);
 	return 0;
 }
 

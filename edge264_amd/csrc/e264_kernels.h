@@ -14,10 +14,12 @@ struct E264Job {
 #define E264_DBK_BYTES 64
 
 // mode: bit0 reconstruction, bit1 deblocking.  waves: 4, 8 or 16 macroblock rows in flight per frame.
-// max_mbs: largest macroblock count among the jobs; max_tiles: largest count of 16x8-macroblock tiles (e264_pred_kernel).  marks: NULL or 5 events (boundaries of the 4 kernels).
+// max_mbs: largest macroblock count among the jobs; max_tiles: largest e264_pred_tiles() among the jobs.  marks: NULL or 5 events (boundaries of the 4 kernels).
 // fork: NULL, or a second queue + events on which the parameter kernel runs beside the macroblock-parallel kernel
 // (amarks: 2 events bracketing it there, recorded when marks != NULL).
 struct E264Fork { hipStream_t aux; hipEvent_t forked, joined; hipEvent_t *amarks; };
+// workgroups e264_pred_kernel needs for a picture of this size (its tile geometry is a build-time choice of the kernels)
+extern "C" int e264_pred_tiles(int width_mbs, int height_mbs);
 extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int max_mbs, int max_tiles, int mode, int waves, hipStream_t stream, hipEvent_t *marks,
 	const E264Fork *fork);
 

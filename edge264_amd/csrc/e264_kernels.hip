@@ -10,7 +10,7 @@
 // Execution model, four launches per batch of frames (one frame of each of n streams):
 //   e264_dbkparam2_kernel (e264_dbkp.h)  one workgroup per 64 macroblocks: deblocking parameters (bS, alpha, beta, indexA)
 //                        of EVERY macroblock from the command packet alone (nothing in the frame is read).
-//   e264_pred_kernel (e264_pred.h)       one workgroup per tile of 16 x 8 macroblocks, one lane per 8x8 block: inter
+//   e264_pred_kernel (e264_pred.h)       one workgroup per tile of 16 x 4 macroblocks, one lane per 8x8 block: inter
 //                        prediction + residual (+ PCM), which depend on nothing inside the frame.
 //   e264_intra_kernel (this file)        ONE WORKGROUP PER FRAME, ONE WAVE PER MACROBLOCK ROW: intra MBs only, row y
 //                        may reconstruct macroblock x once row y-1 has finished macroblock x+1.
@@ -59,8 +59,8 @@ struct __attribute__((aligned(16))) WaveLds { // reconstruction scratch of one w
 	uint8_t ctile[2][9 * CT_STRIDE];
 	uint8_t ftop[32];          // intra 8x8 filtered top  ft[-1..15] at [i+1]
 	uint8_t fleft[8];          // intra 8x8 filtered left
-	// residual inputs, staged so that the transforms never wait for memory (see coef_issue / slice_cache)
-	__attribute__((aligned(4))) int16_t coef[408]; // the macroblock's payload: [luma DC 16][chroma DC 8][coded blocks], as in the packet
+	// residual inputs, staged so that the transforms never wait for memory (see coef_dma / slice_cache; the payload buffers live
+	// in IntraLds.coef)
 	__attribute__((aligned(4))) uint8_t ws[224];   // scaling lists of the cached slice: weightScale4x4[6][16], weightScale8x8[0..1][64]
 	int ws_slice;              // slice index the cache holds (-1: none)
 	int ws_idc;                // its weighted_bipred_idc
@@ -232,17 +232,15 @@ __device__ __forceinline__ void idct8x8_blocks(WaveLds &L, uint32_t coded, const
 	wave_sync();
 }
 
-// LDS copy of the weighting part of E264SliceParams (the three tables are contiguous there), filled by slice_cache when the
-// slice weights anything: select_weights runs in the middle of a macroblock, after the next macroblock's loads have been
-// issued -- a table read from memory at that point waits for all of them.
 // Residual inputs without a memory round trip inside the transforms:
-//   coef_issue / coef_commit  the macroblock's payload (<= 816 bytes) as 4 coalesced dword loads per lane, issued
-//                             while something else runs (mbpar: one macroblock ahead; intra: before the wait for the
-//                             row above), then dropped into L.coef.  (Before: 2-byte loads at transform positions,
-//                             used at once: one exposed round trip per transform call.)
-//   slice_cache               scaling lists + weighted_bipred_idc of the current slice in LDS, reloaded when the
-//                             slice index changes.
-struct CoefPf { uint32_t v0, v1, v2, v3; };
+//   coef_dma      the macroblock's payload (<= 816 bytes) goes from the packet straight into L.coef[buf] by LDS-DMA
+//                 (global_load_lds_dword: 4 instructions of 64 dwords, no register in between), requested while the
+//                 PREVIOUS macroblock of the wave is reconstructed; the consumer waits with vmcnt(0) at the top of its
+//                 macroblock, thousands of cycles later.  (Round 2: four dword loads per lane into registers at the top of the
+//                 same macroblock, then a copy into LDS: the latency stood at the head of every macroblock's chain, and
+//                 keeping a second set of registers for the next macroblock spilled.)
+//   slice_cache   scaling lists + weighted_bipred_idc of the current slice in LDS, reloaded when the
+//                 slice index changes.
 __device__ __forceinline__ int coef_dwords(const MbInfo &m)
 {
 	if (m.kind == E264_MB_ABSENT || m.kind == E264_MB_PCM || m.coded == 0)
@@ -252,28 +250,23 @@ __device__ __forceinline__ int coef_dwords(const MbInfo &m)
 	bytes += (m.kind != E264_MB_I16x16 && (m.flags & E264_MBF_T8x8)) ? __builtin_popcount(c & 0x1111) * 128 : __builtin_popcount(c & 0xffff) * 32;
 	return bytes >> 2;
 }
-__device__ __forceinline__ void coef_issue(const FrameCtx &f, const MbInfo &m, int lane, CoefPf &pf)
-{ // loads only: nothing here may use a loaded value
-	const int ndw = coef_dwords(m);
-	pf.v0 = pf.v1 = pf.v2 = pf.v3 = 0;
+__device__ __forceinline__ void coef_dma(int16_t *dst, const FrameCtx &f, const MbInfo &m, int lane)
+{ // dst: one of the wave's two payload buffers (uniform address); lanes beyond the payload are masked out and write nothing
+	const int ndw = coef_dwords(m); // uniform
 	if (ndw == 0)
 		return;
-	const gu32 *src = (const gu32 *)(f.payload + m.payload_off);
-	if (lane < ndw) pf.v0 = src[lane];
-	if (64 + lane < ndw) pf.v1 = src[64 + lane];
-	if (128 + lane < ndw) pf.v2 = src[128 + lane];
-	if (192 + lane < ndw) pf.v3 = src[192 + lane];
+	const gu32 *src = (const gu32 *)(f.payload + m.payload_off) + lane;
+	typedef __attribute__((address_space(3))) void *lds_p;
+	if (lane < ndw) __builtin_amdgcn_global_load_lds(src, (lds_p)dst, 4, 0, 0);
+	if (ndw > 64 && 64 + lane < ndw) __builtin_amdgcn_global_load_lds(src + 64, (lds_p)(dst + 128), 4, 0, 0);
+	if (ndw > 128 && 128 + lane < ndw) __builtin_amdgcn_global_load_lds(src + 128, (lds_p)(dst + 256), 4, 0, 0);
+	if (ndw > 192 && 192 + lane < ndw) __builtin_amdgcn_global_load_lds(src + 192, (lds_p)(dst + 384), 4, 0, 0);
 }
-__device__ __forceinline__ void coef_commit(WaveLds &L, const MbInfo &m, int lane, const CoefPf &pf)
-{ // the caller synchronises the wave before the transforms read L.coef (compute_residual does)
-	const int ndw = coef_dwords(m);
-	if (ndw == 0)
-		return;
-	uint32_t *c = (uint32_t *)L.coef;
-	if (lane < ndw) c[lane] = pf.v0;
-	if (64 + lane < ndw) c[64 + lane] = pf.v1;
-	if (128 + lane < ndw) c[128 + lane] = pf.v2;
-	if (192 + lane < ndw) c[192 + lane] = pf.v3;
+// every LDS-DMA transfer this wave has requested has landed (they were requested a macroblock ago: no stall in steady state)
+__device__ __forceinline__ void coef_dma_wait()
+{
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	wave_sync();
 }
 __device__ __forceinline__ void slice_cache(WaveLds &L, const FrameCtx &f, int slice, int lane)
 {
@@ -289,15 +282,15 @@ __device__ __forceinline__ void slice_cache(WaveLds &L, const FrameCtx &f, int s
 	wave_sync();
 }
 
-// L.coef holds the macroblock's payload (coef_commit), the slice cache is valid (slice_cache)
-__device__ __forceinline__ void compute_residual(WaveLds &L, const FrameCtx &f, const MbInfo &m, int lane)
+// coefs holds the macroblock's payload (coef_dma + coef_dma_wait), the slice cache is valid (slice_cache)
+__device__ __forceinline__ void compute_residual(WaveLds &L, const int16_t *coefs, const FrameCtx &f, const MbInfo &m, int lane)
 {
 	// zero the residual tile (384 int16 = 192 dwords)
 	uint32_t *rz = (uint32_t *)L.res;
 	rz[lane] = 0; rz[lane + 64] = 0; rz[lane + 128] = 0;
 	const uint32_t coded = m.coded;
 	const bool inter = m.kind == E264_MB_INTER;
-	const int16_t *pl = L.coef;
+	const int16_t *pl = coefs;
 	const int16_t *ldc = nullptr, *cdc = nullptr;
 	if (coded & E264_CODED_LUMA_DC) { ldc = pl; pl += 16; }
 	if (coded & E264_CODED_CHROMA_DC) { cdc = pl; pl += 8; }
@@ -411,7 +404,9 @@ __device__ __forceinline__ void commit_intra_neighbours(WaveLds &L, const IntraN
 // modes; the generator checks the table against the same formulas) ran as two divergent paths per step -- one per block
 // of the step -- each a chain of dependent byte reads: 46 % of the kernel's time on I pictures.
 // tab: c_i4tab in LDS; p = y * 4 + x.
-__device__ __forceinline__ int intra4x4_tab(const WaveLds &L, const uint32_t *tab, int X0, int Y0, int mode, int p)
+// e: the table word tab[mode * 16 + p], fetched by the caller ONE STEP AHEAD (it depends on the mode only, not on samples: read
+// where it is used it was a third LDS round trip in every step of the chain table word -> samples -> store)
+__device__ __forceinline__ int intra4x4_tab(const WaveLds &L, uint32_t e, int X0, int Y0, int mode)
 {
 	const uint8_t *org = &L.YT(Y0 - 1, X0 - 1);
 	if (mode >= 2 && mode <= 5) { // DC variants: top and left, top, left, none (edge264_intra.c DC modes)
@@ -420,7 +415,6 @@ __device__ __forceinline__ int intra4x4_tab(const WaveLds &L, const uint32_t *ta
 		const int sl = org[YT_STRIDE] + org[2 * YT_STRIDE] + org[3 * YT_STRIDE] + org[4 * YT_STRIDE];
 		return mode == 2 ? (st + sl + 4) >> 3 : mode == 3 ? (st + 2) >> 2 : mode == 4 ? (sl + 2) >> 2 : 128;
 	}
-	const uint32_t e = tab[mode * 16 + p];
 	const int a = org[e & 255], b = org[e >> 8 & 255], c = org[e >> 16 & 255];
 	const int ty = (int)(e >> 24), sh = ty >> 3;
 	return (a + (ty & 3) * b + ((ty & 4) ? c : 0) + ((1 << sh) >> 1)) >> sh;
@@ -641,9 +635,14 @@ __device__ __forceinline__ int intra_chroma_px(const WaveLds &L, int p, int mode
 // reconstruction of one macroblock by one wave
 // ---------------------------------------------------------------------------------
 // WHICH: 1 = inter and PCM macroblocks only (no dependency inside the frame), 2 = intra only, 3 = all
+// coefs: this macroblock's payload (the caller has waited for it: coef_dma_wait).
+// next_rec (may be null): LDS copy of the record of the macroblock this wave reconstructs next; its header goes to mn and its
+// payload is requested into coefs_next -- the transfer then has the whole reconstruction (thousands of cycles) to land instead of
+// standing at the head of the next macroblock's chain.
 template <int WHICH>
-__device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, int mbx, int mby, int lane, const uint32_t *i4tab, const CoefPf &pf PH_PARAMS)
-{ // pf: the macroblock's payload, issued by the caller (coef_issue) as early as it could
+__device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, int mbx, int mby, int lane, const uint32_t *i4tab, const int16_t *coefs,
+	int16_t *coefs_next, const uint32_t *next_rec, MbInfo &mn PH_PARAMS)
+{
 	if (m.kind == E264_MB_ABSENT)
 		return;
 	const bool par = m.kind == E264_MB_INTER || m.kind == E264_MB_PCM;
@@ -669,10 +668,13 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const Mb
 	if (WHICH != 1 && m.kind != E264_MB_INTER)
 		nbv = issue_intra_neighbours(f, mbx, mby, lane); // in flight during the residual
 	PH(2);
+	if (next_rec) { // (uniform)
+		mn = mb_from_lds(next_rec);
+		coef_dma(coefs_next, f, mn, lane);
+	}
 	slice_cache(L, f, m.slice, lane);
-	coef_commit(L, m, lane, pf);
 	PH(3);
-	compute_residual(L, f, m, lane);
+	compute_residual(L, coefs, f, m, lane);
 	PH(4);
 
 	int pY[4], pC[2];
@@ -691,17 +693,30 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const Mb
 			// zig-zag indices per step: (0,-)(1,-)(4,2)(5,3)(6,8)(7,9)(12,10)(13,11)(14,-)(15,-)
 			const uint64_t firsts = 0xfedc765410ull, seconds = 0xffba9832ffull; // one nibble per step
 			const int half = lane >> 4, hl16 = lane & 15;
+			const uint64_t order = half ? seconds : firsts;
+			// the lane's block and mode at step t (lanes that idle take block 0: valid addresses, nothing stored)
+			auto step_mode = [&](int t, int &bb) {
+				const bool on_ = lane < 32 && !(half == 1 && (t < 2 || t > 7));
+				bb = on_ ? (int)(order >> (4 * t) & 15) : 0;
+				return (int)(((bb < 8 ? modes_lo : modes_hi) >> (4 * (bb & 7))) & 15);
+			};
+			int bb_n;
+			int mode_n = step_mode(0, bb_n);
+			uint32_t e_n = i4tab[mode_n * 16 + hl16];
 #pragma unroll E264_I4_UNROLL
 			for (int t = 0; t < 10; t++) {
-				const int b = (int)((half ? seconds : firsts) >> (4 * t) & 15);
 				const bool on = lane < 32 && !(half == 1 && (t < 2 || t > 7));
-				const int bb = on ? b : 0;
-				int mode = (int)(((bb < 8 ? modes_lo : modes_hi) >> (4 * (bb & 7))) & 15);
+				const int bb = bb_n, mode = mode_n;
+				const uint32_t e = e_n;
+				if (t < 9) { // next step's table word: in flight during this step's sample reads
+					mode_n = step_mode(t + 1, bb_n);
+					e_n = i4tab[mode_n * 16 + hl16];
+				}
 				int X0 = BXf(bb), Y0 = BYf(bb);
 				int v = 0;
 				if (on) {
 					int x = hl16 & 3, y = hl16 >> 2;
-					v = intra4x4_tab(L, i4tab, X0, Y0, mode, hl16);
+					v = intra4x4_tab(L, e, X0, Y0, mode);
 					v = clip255(w16(v + L.res[(Y0 + y) * 16 + X0 + x]));
 				}
 				wave_sync();
@@ -761,10 +776,10 @@ static __device__ __forceinline__ void xcd_tile(int &bx, int &by)
 	bx = (int)(v - (unsigned)by * gx);
 }
 
-// Inter prediction + residual of every inter / PCM macroblock: one workgroup per tile of 16 x 8 macroblocks, one thread
+// Inter prediction + residual of every inter / PCM macroblock: one workgroup per tile of 16 x PT_H macroblocks, one thread
 // per 8x8 block; the phases are in e264_pred.h (and run on the host by tests/emu).
 #ifndef E264_PRED_WAVES_PER_EU
-#define E264_PRED_WAVES_PER_EU 4 // 128 VGPRs: two 512-thread workgroups per CU, so that one tile's barriers and first loads hide behind the other's arithmetic
+#define E264_PRED_WAVES_PER_EU 4 // 128 VGPRs: 16 waves per CU (four 256-thread workgroups), so that one tile's barriers and first loads hide behind the others' arithmetic
 #endif
 __attribute__((amdgpu_waves_per_eu(E264_PRED_WAVES_PER_EU, E264_PRED_WAVES_PER_EU))) __global__ __launch_bounds__(PT_NT) void e264_pred_kernel(const E264Job *jobs, int mode)
 {
@@ -845,10 +860,19 @@ __global__ __launch_bounds__(DP_NT) void e264_dbkparam2_kernel(const E264Job *jo
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs)
 {
-	__shared__ WaveLds lds[NW];
-	__shared__ __attribute__((aligned(16))) uint32_t hdrs[NW][64 * 8]; // E264Mb records of the 64 macroblocks being scanned, per wave
-	__shared__ int progress[E264_MAX_ROWS]; // macroblocks finished per row
-	__shared__ uint32_t i4tab[14 * 16];     // c_i4tab: read with a per-lane index
+	// one object, the LDS-DMA targets first (lowest LDS addresses)
+	struct __attribute__((aligned(16))) IntraLds {
+		int16_t coef[NW][2][512];            // per wave: the payload of its macroblock and of the next one: [luma DC 16][chroma DC 8][coded blocks], as in the packet
+		uint32_t hdrs[NW][64 * 8];           // E264Mb records of the 64 macroblocks being scanned, per wave
+		WaveLds w[NW];
+		int progress[E264_MAX_ROWS];         // macroblocks finished per row
+		uint32_t i4tab[14 * 16];             // c_i4tab: read with a per-lane index
+	};
+	__shared__ IntraLds S;
+	WaveLds *const lds = S.w;
+	uint32_t (*const hdrs)[64 * 8] = S.hdrs;
+	int *const progress = S.progress;
+	uint32_t *const i4tab = S.i4tab;
 	const int lane = lane_id();
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	FrameCtx f;
@@ -875,9 +899,11 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 			const int xl = x0 + lane;
 			// whole records of the chunk -> LDS (2 x 16 bytes per lane); `kind` for the ballot comes out of the first dword
 			v4u h0v = {0, 0, 0, 0}, h1v = {0, 0, 0, 0};
+			uint32_t kup = E264_MB_ABSENT; // kind of the macroblock above
 			if (xl < f.wm) {
 				const gv4u *rp = (const gv4u *)(mbs_g + (size_t)(y * f.wm + xl) * sizeof(E264Mb));
 				h0v = rp[0]; h1v = rp[1];
+				if (y > 0) kup = *(const gu32 *)(mbs_g + (size_t)((y - 1) * f.wm + xl) * sizeof(E264Mb)) & 255u;
 			}
 			wave_sync(); // the previous chunk's records are no longer read
 			*(v4u *)&hdrs[wave][lane * 8] = h0v;
@@ -885,28 +911,41 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 			wave_sync();
 			const int kind = xl < f.wm ? (int)(h0v.x & 255) : E264_MB_ABSENT;
 			unsigned long long todo = __ballot(kind == E264_MB_I4x4 || kind == E264_MB_I8x8 || kind == E264_MB_I16x16);
+			// Which macroblocks of the row above does THIS kernel write?  Only those make a macroblock below wait: inter and
+			// PCM neighbours were finished by the prediction kernel before this launch (P / B pictures: an isolated intra
+			// macroblock starts at once instead of queueing behind every intra macroblock up and to the left of it).
+			const unsigned long long upi = __ballot(kup == E264_MB_I4x4 || kup == E264_MB_I8x8 || kup == E264_MB_I16x16);
 			const int xe = min(x0 + 64, f.wm);
 			if (todo == 0 || (int)__builtin_ctzll(todo) > 0) { // macroblocks before the first intra one need nothing from this kernel
 				const int upto = todo ? x0 + (int)__builtin_ctzll(todo) : xe;
 				if (lane == 0)
 					__hip_atomic_store(&progress[y], upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
+			// software pipeline over the intra macroblocks of the chunk: the header and payload of the next one are fetched
+			// inside recon_mb of the current one
+			MbInfo mi, mn;
+			int buf = 0;
+			if (todo) {
+				mi = mb_from_lds(&hdrs[wave][__builtin_ctzll(todo) * 8]);
+				coef_dma(S.coef[wave][buf], f, mi, lane); // the payload does not depend on the neighbours: in flight during the wait below
+			}
 #pragma unroll 1
 			while (todo) {
 				const int x = x0 + (int)__builtin_ctzll(todo);
 				todo &= todo - 1;
+				const uint32_t *next_rec = todo ? &hdrs[wave][__builtin_ctzll(todo) * 8] : nullptr;
 				PH(0);
-				const MbInfo mi = mb_from_lds(&hdrs[wave][(x - x0) * 8]);
-				CoefPf pf;
-				coef_issue(f, mi, lane, pf); // the payload does not depend on the neighbours: in flight during the wait below
-				if (y > 0) {
+				const int rx = x - x0; // the neighbours above: x-1 (corner), x, x+1 (top right); outside the chunk: assume intra
+				const bool dep = (upi >> rx & 1) || (rx > 0 ? (int)(upi >> (rx - 1) & 1) : x0 > 0) || (rx < 63 ? (int)(upi >> (rx + 1) & 1) : x + 1 < f.wm);
+				if (y > 0 && dep) {
 					int want = min(x + 2, f.wm);
 					while (lds_load_relaxed(&progress[y - 1]) < want)
 						__builtin_amdgcn_s_sleep(1);
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 				}
 				PH(1);
-				recon_mb<2>(L, f, mi, x, y, lane, i4tab, pf PH_ARGS);
+				coef_dma_wait();
+				recon_mb<2>(L, f, mi, x, y, lane, i4tab, S.coef[wave][buf], S.coef[wave][buf ^ 1], next_rec, mn PH_ARGS);
 				PH(8);
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 				PH(9);
@@ -914,6 +953,7 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 				const int upto = todo ? x0 + (int)__builtin_ctzll(todo) : xe;
 				if (lane == 0)
 					__hip_atomic_store(&progress[y], upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				if (next_rec) { mi = mn; buf ^= 1; }
 			}
 		}
 	}
@@ -1011,6 +1051,11 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 		PH_FLUSH_DBK(lane);
 #endif
 	}
+}
+
+extern "C" int e264_pred_tiles(int width_mbs, int height_mbs)
+{
+	return ((width_mbs + PT_W - 1) / PT_W) * ((height_mbs + PT_H - 1) / PT_H);
 }
 
 extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int max_mbs, int max_tiles, int mode, int waves, hipStream_t stream, hipEvent_t *marks,

@@ -17,8 +17,10 @@
 //     registers: rows, columns, horizontal and vertical taps are all lane-private, so there is no LDS round trip, no
 //     cross-lane traffic and no wave-level pipeline state at all.  Overlapping windows of neighbouring lanes are cache
 //     hits by construction ("6-tap halos are cache hits by definition").
-//   * A WORKGROUP = A TILE of 16 x 8 macroblocks, 512 threads.  The tile's samples are assembled in LDS (48 KB) and leave as
-//     whole 256-byte luma / 128-byte chroma rows (round 1 measured 3.6x write amplification for 16-byte row pieces).
+//   * A WORKGROUP = A TILE of 16 x 4 macroblocks, 256 threads (round 2: 16 x 8, 512 threads; four 37-KB workgroups per CU
+//     instead of two 76-KB ones interleave their fetch-bound and arithmetic-bound phases better: 1.43 -> 1.35 ms, 16 x 2 the
+//     same -- profiles/r03_ablations.txt).  The tile's samples are assembled in LDS (24 KB) and leave as whole 256-byte luma /
+//     128-byte chroma rows (round 1 measured 3.6x write amplification for 16-byte row pieces).
 //   * CLASS-SORTED WORK LISTS.  The 16 quarter-sample positions need three different data flows (reference
 //     edge264_inter.c: "horizontal then vertical" for xFrac == 2, "vertical then horizontal" for yFrac == 2, one-dimensional
 //     otherwise).  The items of a tile are binned by that class in LDS (one atomic per item) and lanes take items in class
@@ -42,10 +44,13 @@ E264_DEV void lds_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
 #endif
 
 #define PT_W 16                 // tile width in macroblocks (256-byte luma rows, 128-byte chroma rows)
-#define PT_H 8
+#ifndef E264_PT_H
+#define E264_PT_H 4             // tile height in macroblocks (build-time: `make variant DEFS=-DE264_PT_H=8` = 512-thread workgroups, 2 per CU)
+#endif
+#define PT_H E264_PT_H
 #define PT_MBS (PT_W * PT_H)
 #define PT_NT (PT_MBS * 4)      // one thread per 8x8 quadrant
-#define PT_LIST 2048            // items per class list: every quadrant split into four 4x4 partitions
+#define PT_LIST (PT_MBS * 16)   // items per class list: every quadrant split into four 4x4 partitions
 
 struct __attribute__((aligned(16))) PredLds {
 	uint32_t y[PT_H * 16][PT_W * 4];    // luma samples of the tile

@@ -349,6 +349,24 @@ class Packet:
                     cmd_total=int(self.hdr["total_bytes"]))
 
 
+def refresh_summary(buf: bytearray) -> None:
+    """Recomputes the header's summary fields (n_coded_mbs, n_inter_mbs, ref_slots) from the records of a packet that was
+    edited in place (tests that drop macroblocks, tools that cut captures): e264hip_packet_check rejects a header that
+    disagrees with its records -- the kernels' early exits and the trusted submission path rely on these fields."""
+    pk = Packet(bytes(buf))
+    hdr = np.frombuffer(buf, FRAME_HDR, 1)
+    kind = pk.mbs["kind"]
+    hdr["n_coded_mbs"] = int((kind != MB_ABSENT).sum())
+    hdr["n_inter_mbs"] = int((kind == MB_INTER).sum())
+    refs = 0
+    inter = np.nonzero(kind == MB_INTER)[0]
+    if len(inter) and pk.motion is not None:
+        for r in np.unique(pk.motion["refPic"][inter]):
+            if r >= 0:
+                refs |= 1 << int(r)
+    hdr["ref_slots"] = refs
+
+
 def split_planes(buf: np.ndarray, width_mbs: int, height_mbs: int):
     """Frame buffer bytes -> (Y, Cb, Cr) 2-D views in the reference layout."""
     g = frame_geometry(width_mbs, height_mbs)

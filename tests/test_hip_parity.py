@@ -189,6 +189,7 @@ def test_missing_macroblocks(device, oracle):
                 else:
                     a = int(rng.integers(0, w * h - 8))
                     mbs["kind"][a:a + int(rng.integers(3, 2 * w))] = P.MB_ABSENT  # a lost slice
+                P.refresh_summary(buf)  # the emitter counts what it emitted
                 pkt = bytes(buf)
                 d = int(pk.hdr["dst_slot"])
                 before = dpb[d].copy()
