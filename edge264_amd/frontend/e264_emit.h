@@ -24,6 +24,7 @@ typedef struct {
 	size_t samples_size;
 	void *mbs;         /* what the reference sees as mb_buffers[slot] */
 	void *mbs_base;    /* start of the allocation (guard bands on both sides of mbs) */
+	void *user_mbs;    /* caller allocators: the mbs block the caller's alloc_cb returned (held, handed back to its free_cb) */
 } E264Slot;
 
 typedef struct {
@@ -66,6 +67,10 @@ typedef struct E264Emitter {
 	/* sink */
 	int sink_kind;      /* 0 HIP back end, 1 capture, 2 HIP frames + queued packets (external batcher) */
 	void *hip_dev, *hip_stream;
+	/* the caller's allocators (edge264.h:42-43), NULL: ours */
+	Edge264AllocCb user_alloc;
+	Edge264FreeCb user_free;
+	void *user_arg;
 	/* capture queue */
 	struct E264Captured { uint8_t *data; size_t bytes; struct E264Captured *next; } *cap_head, *cap_tail;
 } E264Emitter;

@@ -2,11 +2,13 @@
  * edge264_hip_frontend.c -- edge264.h surface in front of the MI355X back end.
  *
  * One translation unit = the reference's front end (parsers, mvpred, DPB bookkeeping; compiled
- * from /root/reference through the include farm of oracle/Makefile, with the four sample-kernel
+ * from /root/reference through the include farm of edge264_amd/frontend/Makefile, with the four sample-kernel
  * files replaced by the emitters of this directory) + thin wrappers around its 7 public
  * functions (edge264.h:64-70).  The wrappers
- *   - force the synchronous mode (n_threads = 0, src/edge264_headers.c:1285-1286) and own the
- *     frame memory through the reference's own Edge264AllocCb hook (edge264.h:42-43),
+ *   - run the reference's synchronous mode (n_threads = 0, src/edge264_headers.c:1285-1286: n_threads is a
+ *     performance hint, the slices are parsed inside edge264_decode_NAL whatever the caller asked for) and own the
+ *     DEVICE frame memory through the reference's own Edge264AllocCb hook (edge264.h:42-43); the HOST side of a frame
+ *     (what Edge264Frame.samples points into) comes from the caller's allocator when one is given,
  *   - number the NAL units so that the emitters can tell slices apart,
  *   - after every NAL, close the frames whose last macroblock has been parsed
  *     (next_deblock_addr[pic]==INT_MAX, src/edge264_headers.c:567) and hand their command packet
@@ -149,7 +151,13 @@ static int hip_load(void)
 	return 0;
 }
 
-/* ---- frame memory: the reference's alloc/free hook (src/edge264_headers.c:113-133) -------- */
+/* ---- frame memory: the reference's alloc/free hook (src/edge264_headers.c:113-133) --------
+ * HOST side of a slot = what the reference dereferences: `samples` (Edge264Frame.samples points into it, I_PCM macroblocks
+ * are written there by the parser) and `mbs` (its per-macroblock records).  DEVICE side = the HBM slot the kernels write.
+ * With caller allocators (edge264.h:42-43) the host samples are the CALLER's memory -- that is where edge264_get_frame
+ * delivers the picture, the point of handing an allocator to a decoder -- and the caller's free_cb gets back exactly the
+ * two pointers its alloc_cb returned.  mbs is always ours (guard bands, see below); the caller's mbs block is held and
+ * returned untouched. */
 static void e264_alloc_cb(void **samples, unsigned samples_size, void **mbs, unsigned mbs_size, int errno_on_fail, void *arg)
 {
 	E264Emitter *e = arg;
@@ -158,14 +166,27 @@ static void e264_alloc_cb(void **samples, unsigned samples_size, void **mbs, uns
 	*mbs = NULL;
 	if (slot < 0 || slot >= E264_MAX_SLOTS)
 		return;
-	void *mirror = NULL;
-	if (ON_DEVICE(e)) {
-		if (hip.frame_alloc(e->hip_stream, slot, samples_size, &mirror))
+	void *mirror = NULL, *user_samples = NULL, *user_mbs = NULL;
+	if (e->user_alloc) {
+		e->user_alloc(&user_samples, samples_size, &user_mbs, mbs_size, errno_on_fail, e->user_arg);
+		if (!user_samples || !user_mbs) {
+			if ((user_samples || user_mbs) && e->user_free) e->user_free(user_samples, user_mbs, e->user_arg);
 			return;
-		hip.frame_fill(e->hip_stream, slot, 0); /* "non-existing" frames are never written (headers.c:1122-1144) */
-	} else {
+		}
+	}
+	if (ON_DEVICE(e)) {
+		if (hip.frame_alloc(e->hip_stream, slot, samples_size, e->user_alloc ? NULL : &mirror)) { /* no pinned mirror beside caller memory */
+			if (e->user_alloc && e->user_free) e->user_free(user_samples, user_mbs, e->user_arg);
+			return;
+		}
+		/* "non-existing" frames are never written (headers.c:1122-1144): the reference leaves their memory as its allocator
+		 * returned it; the device slot is cleared so that what a damaged stream predicts from them is at least deterministic */
+		hip.frame_fill(e->hip_stream, slot, 0);
+	} else if (!e->user_alloc) {
 		mirror = aligned_alloc(64, ((size_t)samples_size + 63) & ~(size_t)63);
 	}
+	if (e->user_alloc)
+		mirror = user_samples;
 	/* The reference's default allocator returns samples and mbs as ONE block, mbs right after samples
 	 * (src/edge264.c:123-130), and its parsers lean on that: the neighbour records of the first macroblock row
 	 * (mb - pic_width_in_mbs - 2 ...) are read -- then masked by the availability flags -- at addresses BEFORE
@@ -177,6 +198,9 @@ static void e264_alloc_cb(void **samples, unsigned samples_size, void **mbs, uns
 	void *m = base ? base + guard : NULL;
 	if (!mirror || !m) {
 		free(base);
+		if (ON_DEVICE(e)) hip.frame_free(e->hip_stream, slot);
+		if (e->user_alloc) { if (e->user_free) e->user_free(user_samples, user_mbs, e->user_arg); }
+		else if (!ON_DEVICE(e)) free(mirror);
 		return;
 	}
 	memset(base, 0, guard);
@@ -185,9 +209,9 @@ static void e264_alloc_cb(void **samples, unsigned samples_size, void **mbs, uns
 	e->slot[slot].samples = mirror;
 	e->slot[slot].samples_size = samples_size;
 	e->slot[slot].mbs = m;
+	e->slot[slot].user_mbs = user_mbs;
 	*samples = mirror;
 	*mbs = m;
-	(void)errno_on_fail;
 }
 
 static void e264_free_cb(void *samples, void *mbs, void *arg)
@@ -199,13 +223,14 @@ static void e264_free_cb(void *samples, void *mbs, void *arg)
 				e->cur.valid = 0;
 			e->fb[s].active = 0;
 			if (ON_DEVICE(e)) hip.frame_free(e->hip_stream, s);
-			else free(samples);
+			if (e->user_alloc) { if (e->user_free) e->user_free(samples, e->slot[s].user_mbs, e->user_arg); }
+			else if (!ON_DEVICE(e)) free(samples);
 			free(e->slot[s].mbs_base);
 			memset(&e->slot[s], 0, sizeof(e->slot[s]));
 			return;
 		}
 	}
-	free(mbs);
+	(void)mbs;
 }
 
 /* ---- closing a frame: assemble the packet, give it to the sink --------------------------- */
@@ -337,22 +362,26 @@ PUBLIC const uint8_t *edge264_find_start_code(const uint8_t *buf, const uint8_t 
 PUBLIC Edge264Decoder *edge264_alloc(int n_threads, Edge264LogCb log_cb, void *log_arg, int log_mbs,
 	Edge264AllocCb alloc_cb, Edge264FreeCb free_cb, void *alloc_arg)
 {
-	/* What this back end cannot honour is REFUSED (NULL, errno = ENOTSUP), never silently changed:
-	 *   n_threads > 0   slices are parsed synchronously inside edge264_decode_NAL (src/edge264_headers.c:1285-1286 path);
-	 *                   host parallelism = one decoder per stream, which is also what fills the GPU.  n_threads < 0 ("pick
-	 *                   for me", src/edge264.c:222-227) is accepted and means 0 here.
-	 *   alloc_cb / free_cb   frame memory lives in HBM and is owned by the back end (edge264.h:42-43 hands the application
-	 *                   host memory it would then expect the decoder to write). */
-	if (n_threads > 0 || alloc_cb || free_cb) {
-		if (log_cb) log_cb("edge264_alloc: worker threads and caller allocators are not supported by the MI355X back end\n", log_arg);
-		errno = ENOTSUP;
+	/* n_threads: a performance hint in the reference (src/edge264.c:222-233: how many pthreads run worker_loop).  Here every
+	 * slice is parsed inside edge264_decode_NAL (the n_threads == 0 path, src/edge264_headers.c:1285-1286) whatever the
+	 * caller asks for: the API contract is the same (return codes, unref_cb once per slice NAL -- from the calling thread
+	 * instead of a worker --, frame order); host parallelism comes from running one decoder per stream, which is also what
+	 * fills the GPU.  Said once through the log callback, not hidden.
+	 * alloc_cb / free_cb (edge264.h:42-43): honoured for the host side of every frame, see e264_alloc_cb; one without the
+	 * other is EINVAL-class misuse and refused. */
+	if ((alloc_cb != NULL) != (free_cb != NULL)) {
+		if (log_cb) log_cb("edge264_alloc: alloc_cb and free_cb must be given together\n", log_arg);
+		errno = EINVAL;
 		return NULL;
 	}
-	(void)alloc_arg; (void)log_mbs;
+	if (n_threads > 0 && log_cb)
+		log_cb("edge264_alloc: n_threads is a hint; the MI355X back end parses slices inside edge264_decode_NAL (run one decoder per stream for host parallelism)\n", log_arg);
+	(void)log_mbs;
 	E264Emitter *e = calloc(1, sizeof(*e));
 	if (!e)
 		return NULL;
 	e->sink_kind = g_sink_kind;
+	e->user_alloc = alloc_cb; e->user_free = free_cb; e->user_arg = alloc_arg;
 	if (ON_DEVICE(e) && (hip_bind_ordinal(g_device_ordinal, (E264Device **)&e->hip_dev) || hip.stream_open(e->hip_dev, (E264Stream **)&e->hip_stream))) {
 		free(e);
 		return NULL;

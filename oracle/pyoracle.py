@@ -118,14 +118,16 @@ class Edge264Lib:
         L.edge264_get_frame.argtypes = [C.c_void_p, C.POINTER(Edge264Frame), C.c_int]
         L.edge264_return_frame.argtypes = [C.c_void_p, C.c_void_p]
 
-    def decode(self, stream: bytes, max_frames: int = 1 << 30, crop: bool = True):
-        """Decodes an Annex-B byte stream; returns (list of (Y,Cb,Cr) arrays, list of NAL return codes)."""
+    def decode(self, stream: bytes, max_frames: int = 1 << 30, crop: bool = True, n_threads: int = 0, allocator=None):
+        """Decodes an Annex-B byte stream; returns (list of (Y,Cb,Cr) arrays, list of NAL return codes).
+        allocator: a CallerAllocator (edge264.h:42-43 alloc_cb / free_cb pair)."""
         import errno
         L = self.lib
         buf = np.frombuffer(stream + b"\0" * 64, np.uint8).copy()
         base = buf.ctypes.data
         end = base + len(stream)
-        dec = C.c_void_p(L.edge264_alloc(0, None, None, 0, None, None, None))
+        a = allocator.args() if allocator else (None, None, None)
+        dec = C.c_void_p(L.edge264_alloc(n_threads, None, None, 0, *a))
         if not dec:
             raise MemoryError("edge264_alloc")
         frames, codes = [], []
@@ -163,6 +165,40 @@ class Edge264Lib:
         return tuple(pl for v in views for pl in (plane(v[0], f.width_Y, f.height_Y, f.stride_Y),
                                                   plane(v[1], f.width_C, f.height_C, f.stride_C),
                                                   plane(v[2], f.width_C, f.height_C, f.stride_C)))
+
+
+class CallerAllocator:
+    """An application-side Edge264AllocCb / Edge264FreeCb pair (edge264.h:42-43) for tests: plain libc memory, every block
+    remembered so that a test can check where the decoder delivered its frames and that everything was given back."""
+    ALLOC = C.CFUNCTYPE(None, C.POINTER(C.c_void_p), C.c_uint, C.POINTER(C.c_void_p), C.c_uint, C.c_int, C.c_void_p)
+    FREE = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p)
+
+    def __init__(self):
+        self.libc = C.CDLL(None)
+        self.libc.malloc.restype = C.c_void_p
+        self.libc.malloc.argtypes = [C.c_size_t]
+        self.libc.free.argtypes = [C.c_void_p]
+        self.live, self.allocs, self.frees = {}, 0, 0   # samples address -> (size, mbs address)
+
+        def alloc(samples, samples_size, mbs, mbs_size, errno_on_fail, arg):
+            sp, mp = self.libc.malloc(samples_size + 64), self.libc.malloc(mbs_size + 64)
+            samples[0], mbs[0] = sp, mp
+            self.live[sp] = (samples_size, mp)
+            self.allocs += 1
+
+        def free(samples, mbs, arg):
+            size, mp = self.live.pop(samples)
+            assert mp == mbs, "free_cb must get back the mbs block alloc_cb returned with these samples"
+            self.libc.free(samples)
+            self.libc.free(mbs)
+            self.frees += 1
+        self._a, self._f = self.ALLOC(alloc), self.FREE(free)
+
+    def args(self):
+        return C.cast(self._a, C.c_void_p), C.cast(self._f, C.c_void_p), None
+
+    def owns(self, address: int) -> bool:
+        return any(sp <= address < sp + size for sp, (size, _) in self.live.items())
 
 
 def ref_decoder() -> Edge264Lib:
@@ -213,7 +249,7 @@ class HipFront(Edge264Lib):
         L.e264front_slot_of.argtypes = [C.c_void_p, C.c_void_p]
         L.e264front_slot_of.restype = C.c_int
 
-    def decode_capture(self, stream: bytes, oracle: "Oracle"):
+    def decode_capture(self, stream: bytes, oracle: "Oracle", n_threads: int = 0, allocator=None):
         """Returns (frames, codes, packets): frames as the HIP sink would return them, with the
         oracle standing in for the GPU (same slot bookkeeping as edge264_get_frame in the shim)."""
         import errno
@@ -223,7 +259,8 @@ class HipFront(Edge264Lib):
         buf = np.frombuffer(stream + b"\0" * 64, np.uint8).copy()
         base = buf.ctypes.data
         end = base + len(stream)
-        dec = C.c_void_p(L.edge264_alloc(0, None, None, 0, None, None, None))
+        a = allocator.args() if allocator else (None, None, None)
+        dec = C.c_void_p(L.edge264_alloc(n_threads, None, None, 0, *a))
         if not dec:
             raise MemoryError("edge264_alloc")
         frames, codes, packets = [], [], []

@@ -71,5 +71,8 @@ def test_damaged_stream(name, seed, flips):
     s = json.loads(shim.stdout.strip().splitlines()[-1])
     assert s["codes"] == r["codes"]
     assert len(s["md5"]) == len(r["md5"])
-    if all(c in (0, 105, 61) for c in r["codes"]):   # the damage went unnoticed by the parser (still a legal stream): frames must match
-        assert s["md5"] == r["md5"]
+    # Every frame the reference OUTPUTS must be bit-identical, damage noticed or not: a picture whose slice failed never
+    # completes in the reference (remaining_mbs is not decremented on error, src/edge264_headers.c:539; recover_frame is
+    # commented out, :435-442) and edge264_get_frame only hands out complete pictures (src/edge264.c:373), so the concealed
+    # samples of recover_slice are not observable through the API -- what IS output are the undamaged pictures.
+    assert s["md5"] == r["md5"]

@@ -76,3 +76,37 @@ def test_two_decoders_interleaved(front):
     for n, s in zip(names, st):
         L.edge264_free(C.byref(s["dec"]))
         assert md5s(s["frames"]) == sums[n]["md5"]
+
+
+def test_caller_allocators_receive_the_frames(front):
+    """edge264_alloc with alloc_cb / free_cb (edge264.h:42-43) on the HIP sink: Edge264Frame.samples point into the CALLER's
+    blocks, edge264_get_frame fills them from HBM, frames equal the reference's; n_threads > 0 at the same time (a hint)."""
+    import ctypes as C
+    import numpy as np
+    from oracle.pyoracle import CallerAllocator, Edge264Frame
+    with open(os.path.join(STREAMS, "reference_md5.json")) as f:
+        sums = json.load(f)
+    L = front.lib
+    for name in ("ipb_spatial", "i_4x4_16x16_pcm"):
+        data = open(os.path.join(STREAMS, name + ".264"), "rb").read()
+        al = CallerAllocator()
+        buf = np.frombuffer(data + b"\0" * 64, np.uint8).copy()
+        base, end = buf.ctypes.data, buf.ctypes.data + len(data)
+        dec = C.c_void_p(L.edge264_alloc(3, None, None, 0, *al.args()))
+        assert dec
+        frames, out = [], Edge264Frame()
+        nal = L.edge264_find_start_code(base, end, 0) + 3
+        while True:
+            nxt = L.edge264_find_start_code(nal, end, 0) if nal < end else end
+            res = L.edge264_decode_NAL(dec, nal, nxt, None, None)
+            while L.edge264_get_frame(dec, C.byref(out), 0) == 0:
+                assert al.owns(out.samples[0]) and al.owns(out.samples[1]) and al.owns(out.samples[2])
+                frames.append(front._copy_frame(out))
+            if res == 105:
+                continue
+            if res == 61 or nal >= end:
+                break
+            nal = min(nxt + 3, end)
+        L.edge264_free(C.byref(dec))
+        assert md5s(frames) == sums[name]["md5"]
+        assert al.allocs == al.frees and not al.live

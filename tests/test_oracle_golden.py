@@ -77,3 +77,18 @@ def test_inter_chroma_golden(oracle):
         for plane in range(2):
             got = oracle_chroma_mc(oracle, src[2 * 21 + 2 + plane * 21:], 42, 64, 64, 0, 0, 7, 5, cw, rows // 2)
             assert np.array_equal(got, exp[plane::2]), (case["w"], case["h"], plane)
+
+
+def test_golden_vectors_as_packets(oracle):
+    """The same vectors as whole-picture command packets (tests/golden_packets.py) through the oracle's FRAME path: pins
+    the packet construction that tests/test_hip_golden.py runs on the GPU."""
+    from edge264_amd import backend
+    from tests import golden_packets as GP
+    n = 0
+    for name, pkt, init, checks in GP.cases():
+        assert backend.packet_check(pkt) == 0, name
+        dpb = [init.get(s) for s in range(32)]
+        oracle.decode_frame(pkt, dpb, 1)
+        GP.check(name, dpb[GP.DST], checks)
+        n += 1
+    assert n == 14 + 31 + 7 + 7 + 48 + 3
