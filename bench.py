@@ -54,6 +54,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("E264_STREAMS", 256)), help="concurrent streams per GPU")
+    ap.add_argument("--total-streams", type=int, default=None, help="streams of the WHOLE job, sharded over the ranks (strong scaling) instead of --streams per GPU")
+    ap.add_argument("--config5", action="store_true", help="BASELINE configs[4]: 256 concurrent 1080p streams over the node's GPUs (= --total-streams 256; 32 per GPU at --gpus 8)")
+    ap.add_argument("--no-numa-bind", action="store_true", help="leave the rank's CPU affinity alone (default: the CPUs of the GPU's NUMA node)")
     ap.add_argument("--gop", default=os.environ.get("E264_GOP", "IPPPPPPP"))
     ap.add_argument("--width-mbs", type=int, default=120)
     ap.add_argument("--height-mbs", type=int, default=68)
@@ -117,8 +120,10 @@ def main() -> int:
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    from edge264_amd.sharding import rank_info, reduce_elapsed, shard_streams
+    from edge264_amd.sharding import bind_rank_to_gpu_socket, gather_rates, rank_info, reduce_elapsed, shard_streams
     rank, local_rank, world = rank_info()
+    if args.config5:
+        args.total_streams = 256
     if args.gpus is not None and args.gpus != world:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for the wrong GPU count", file=sys.stderr)
         return 2
@@ -135,6 +140,9 @@ def main() -> int:
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=tdev)
+
+    # host side of this rank next to its GPU: before the back end creates its threads
+    numa = {"numa_node": -1, "bound": False, "cpus": 0} if (stub or args.no_numa_bind or world == 1) else bind_rank_to_gpu_socket(local_rank)
 
     from edge264_amd import packet as P, synth
 
@@ -163,8 +171,13 @@ def main() -> int:
     n_slots = max(used.bit_length(), 3)
     frame_nb = int(parsed[0].hdr["plane_size_Y"]) + int(parsed[0].hdr["plane_size_C"])
 
-    # weak scaling: rank r owns streams shard_streams(streams * world, r, world) (= `streams` of them)
-    my_streams = len(shard_streams(args.streams * world, rank, world))
+    # weak scaling (default): rank r owns streams shard_streams(streams * world, r, world) (= `streams` of them);
+    # --total-streams / --config5: the job's streams are fixed and sharded (strong scaling)
+    strong = args.total_streams is not None
+    my_streams = len(shard_streams(args.total_streams if strong else args.streams * world, rank, world))
+    if my_streams == 0:
+        print(f"bench.py: rank {rank} of {world} has no stream to decode (--total-streams {args.total_streams})", file=sys.stderr)
+        return 2
     dev = backend.Device(local_rank)
     dev.set_option("waves", args.waves)
     if args.intra_waves:
@@ -221,11 +234,13 @@ def main() -> int:
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     my_frames = my_streams * len(packets) * args.steps
+    my_elapsed = elapsed
     if dist is not None:
         dist.barrier()
         elapsed, total_frames = reduce_elapsed(elapsed, my_frames, dist, tdev)
     else:
         total_frames = my_frames
+    rates = gather_rates(my_elapsed, my_frames, dist, tdev)
     kernel_ms4, launches = dev.kernel_time_ms()
     dev.kernel_timing(False)
     ev_ms = dev.event_elapsed_ms(0, 1)
@@ -412,13 +427,13 @@ def main() -> int:
             "value": round(value, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u8", "data": "captured bitstream packets" if args.capture else "synthetic",
             "config": {"workload": (f"{W * 16}x{H * 16} captured packets of a real bitstream ({args.gop}), one copy per stream" if args.capture else
                                     f"{W * 16}x{H * 16} High-profile {args.gop} GOP (synthetic command packets: intra 4x4 / 8x8 / 16x16 I frame + "
                                     "P frames with 6-tap luma / bilinear chroma MC, 2 references, 4x4 and 8x8 transforms, 30% coded residual, "
-                                    "in-loop deblocking), BASELINE configs[2]"),
-                       "streams_per_gpu": args.streams, "frames_per_step": frames_per_step,
+                                    "in-loop deblocking), BASELINE configs[2]") + (f"; configs[4]: {args.total_streams} streams sharded over {world} GPU(s)" if strong else ""),
+                       "streams_per_gpu": my_streams, "total_streams": frames_per_step // len(packets), "frames_per_step": frames_per_step,
                        "waves_per_frame": args.waves, "compute_lanes": lanes, "parallelism": f"stream-parallel x{world}, no collectives"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kern[dom]["frac"], "traffic": traffic, "traffic_source": "profiles/r03_hbm_traffic.json (PMC passes, canned)" if traffic else None,
@@ -430,6 +445,8 @@ def main() -> int:
             "other_configs": other,
             "pcie_inclusive": pcie,
             "gpu_event_ms_per_step": round(ev_ms / args.steps, 3),
+            "per_rank": {"frames_per_s": [round(r, 1) for r in rates], "min": round(min(rates), 1), "max": round(max(rates), 1),
+                         "numa": numa},
         }
         os.write(json_fd, (json.dumps(out) + "\n").encode())
         if bit_exact is False or (other and any(v["bit_exact"] is False for v in other.values())):

@@ -195,3 +195,34 @@ def test_bench_gpus_flag_spawns_ranks(tmp_path):
     env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     bad = subprocess.run(cmd, env=env1, capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert bad.returncode == 2 and "refusing" in bad.stderr
+
+
+def test_bench_config5_shards_a_fixed_job(tmp_path):
+    """BASELINE configs[4] (`--config5` = `--total-streams 256`, here 5 streams on 2 stub ranks): the job's streams are
+    FIXED and sharded over the ranks (3 + 2), the line says strong scaling, reports every rank's own rate with min / max,
+    and a rank without a stream is refused."""
+    import json
+    env = dict(os.environ, E264_BENCH_BACKEND="tests.stub_backend", OMP_NUM_THREADS="1", PYTHONPATH=ROOT)
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--total-streams", "5", "--gop", "IP",
+           "--width-mbs", "4", "--height-mbs", "3"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["total_streams"] == 5 and d["config"]["frames_per_step"] == 5 * 2
+    assert "configs[4]" in d["config"]["workload"]
+    pr = d["per_rank"]
+    assert len(pr["frames_per_s"]) == 2 and pr["min"] == min(pr["frames_per_s"]) and pr["max"] == max(pr["frames_per_s"])
+    assert abs(sum(pr["frames_per_s"]) - d["value"]) / d["value"] < 0.5   # same order: value uses the slowest rank's time
+    few = subprocess.run(cmd[:-8] + ["--total-streams", "1", "--gop", "IP", "--width-mbs", "4", "--height-mbs", "3"], env=env, capture_output=True, text=True,
+                         timeout=300, cwd=ROOT)
+    assert few.returncode != 0
+
+
+def test_numa_helpers():
+    from edge264_amd.sharding import bind_rank_to_gpu_socket, parse_cpulist
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and parse_cpulist("") == []
+    before = os.sched_getaffinity(0)
+    info = bind_rank_to_gpu_socket(0)   # no GPU here: node unknown, affinity untouched
+    assert info["bound"] is False and os.sched_getaffinity(0) == before
