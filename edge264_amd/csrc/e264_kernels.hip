@@ -903,13 +903,15 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 			if (xl < f.wm) {
 				const gv4u *rp = (const gv4u *)(mbs_g + (size_t)(y * f.wm + xl) * sizeof(E264Mb));
 				h0v = rp[0]; h1v = rp[1];
-				if (y > 0) kup = *(const gu32 *)(mbs_g + (size_t)((y - 1) * f.wm + xl) * sizeof(E264Mb)) & 255u;
+				if (y > 0) kup = *(const gu32 *)(mbs_g + (size_t)((y - 1) * f.wm + xl) * sizeof(E264Mb));
 			}
 			wave_sync(); // the previous chunk's records are no longer read
 			*(v4u *)&hdrs[wave][lane * 8] = h0v;
 			*(v4u *)&hdrs[wave][lane * 8 + 4] = h1v;
 			wave_sync();
-			const int kind = xl < f.wm ? (int)(h0v.x & 255) : E264_MB_ABSENT;
+			if (kup >> 8 & E264_MBF_DONE) kup = E264_MB_ABSENT; // written by an earlier packet of the picture: stable
+			kup &= 255u;
+			const int kind = (xl < f.wm && !(h0v.x >> 8 & E264_MBF_DONE)) ? (int)(h0v.x & 255) : E264_MB_ABSENT;
 			unsigned long long todo = __ballot(kind == E264_MB_I4x4 || kind == E264_MB_I8x8 || kind == E264_MB_I16x16);
 			// Which macroblocks of the row above does THIS kernel write?  Only those make a macroblock below wait: inter and
 			// PCM neighbours were finished by the prediction kernel before this launch (P / B pictures: an isolated intra

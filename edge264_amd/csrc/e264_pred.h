@@ -123,7 +123,7 @@ E264_DEV void pred_phase_classify(PredLds &L, const FrameCtx &f, const PredTile 
 {
 	const int mb = tid >> 2, q = tid & 3;
 	const uint32_t d0 = L.hdr[mb][0];
-	const int kind = d0 & 255;
+	const int kind = (d0 >> 8 & E264_MBF_DONE) ? E264_MB_ABSENT : (int)(d0 & 255); // DONE: written by an earlier packet of the picture, not ours to touch
 	const int mbx = t.tx0 + (mb & (PT_W - 1)), mby = t.ty0 + mb / PT_W;
 	if (list == 0 && (kind == E264_MB_INTER || kind == E264_MB_PCM) && q == 0)
 		lds_or(&L.staged[mb >> 5], 1u << (mb & 31));
@@ -649,7 +649,7 @@ E264_DEV void pred_phase_reslist(PredLds &L, int tid)
 	uint16_t *l4 = &L.lst[0][0], *l8 = &L.lst[2][0];
 	const int mb = tid >> 2, q = tid & 3;
 	const uint32_t d0 = L.hdr[mb][0], coded = L.hdr[mb][3];
-	if ((d0 & 255) != E264_MB_INTER || coded == 0)
+	if ((d0 & 255) != E264_MB_INTER || coded == 0 || (d0 >> 8 & E264_MBF_DONE))
 		return;
 	const bool t8 = (d0 >> 8) & E264_MBF_T8x8;
 	uint32_t bits;

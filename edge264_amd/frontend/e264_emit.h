@@ -34,6 +34,9 @@ typedef struct {
 	E264Mb *mbs;
 	E264Motion *motion;
 	uint16_t *dbk_slice;  /* per macroblock: slice entry whose task called deblock_mb on it (0xffff: none yet) */
+	uint8_t *state;       /* per macroblock, pictures sent in several packets (a slice failed): E264_ST_* */
+	uint8_t *fedges;      /* per macroblock: mb->filter_edges as deblock_mb found it (the emitter clears it like the reference) */
+	int multi;            /* a packet of this picture has already been sent, or a macroblock was decoded twice */
 	uint8_t *mot;         /* scratch of e264_finish_frame: the compact motion records */
 	size_t mot_cap;
 	E264SliceParams *slices;
@@ -44,6 +47,10 @@ typedef struct {
 	size_t payload_len, payload_cap;
 	int n_inter;
 } E264FrameBuilder;
+
+#define E264_ST_RECON 1   /* reconstructed by an earlier packet of the picture */
+#define E264_ST_DBK   2   /* deblocked by an earlier packet */
+#define E264_ST_ERR   4   /* marked erroneous by recover_slice (recovery_bits = flip + 2): may be decoded again */
 
 typedef struct { /* macroblock being assembled: leaf calls arrive in decoding order */
 	int valid, slot, addr, slice;
@@ -64,6 +71,12 @@ typedef struct E264Emitter {
 	E264MbStage cur;
 	int serial;         /* incremented by the API wrapper before every NAL: one slice per serial */
 	int cabac_of_serial;
+	/* a slice that fails (src/edge264_headers.c:527-529) */
+	int trk_serial, trk_slot, trk_addr; /* last macroblock staged by the current NAL: addresses only grow inside a slice ... */
+	int recover_serial;                 /* ... until recover_slice walks it again from first_mb_in_slice (P_Skip / B_Skip
+	                                       concealment, src/edge264_headers.c:399-407): a new generation of those macroblocks */
+	int failed_serial, failed_slot;     /* set by the unref wrapper: the NAL's slice ended with an error */
+	int (*flush_partial)(struct E264Emitter *, int slot); /* sends the picture-so-far as a packet (edge264_hip_frontend.c) */
 	/* sink */
 	int sink_kind;      /* 0 HIP back end, 1 capture, 2 HIP frames + queued packets (external batcher) */
 	void *hip_dev, *hip_stream;
@@ -102,8 +115,10 @@ static E264FrameBuilder *e264_builder(E264Emitter *e, int slot)
 		b->active = 0;
 	if (!b->active) {
 		if (b->n_mbs != w * h) {
-			free(b->mbs); free(b->motion); free(b->dbk_slice);
+			free(b->mbs); free(b->motion); free(b->dbk_slice); free(b->state); free(b->fedges);
 			b->dbk_slice = malloc(sizeof(uint16_t) * (size_t)(w * h));
+			b->state = malloc((size_t)(w * h));
+			b->fedges = malloc((size_t)(w * h));
 			b->mbs = malloc(sizeof(E264Mb) * (size_t)(w * h));
 			b->motion = malloc(sizeof(E264Motion) * (size_t)(w * h));
 		}
@@ -111,6 +126,9 @@ static E264FrameBuilder *e264_builder(E264Emitter *e, int slot)
 		memset(b->mbs, 0, sizeof(E264Mb) * (size_t)b->n_mbs);
 		memset(b->motion, 0, sizeof(E264Motion) * (size_t)b->n_mbs);
 		memset(b->dbk_slice, 0xff, sizeof(uint16_t) * (size_t)b->n_mbs);
+		memset(b->state, 0, (size_t)b->n_mbs);
+		memset(b->fedges, 0, (size_t)b->n_mbs);
+		b->multi = 0;
 		for (int i = 0; i < b->n_mbs; i++) {
 			memset(b->motion[i].refPic, -1, 8);
 			memset(b->motion[i].refIdx, -1, 8);
@@ -252,10 +270,29 @@ static E264MbStage *e264_touch(E264Emitter *e, int slot, int addr)
 	E264MbStage *c = &e->cur;
 	if (c->valid && c->slot == slot && c->addr == addr && c->serial == e->serial)
 		return c;
+	if (e->trk_serial == e->serial && e->trk_slot == slot && addr <= e->trk_addr && e->recover_serial != e->serial) {
+		/* The slice went BACK to a macroblock it has already closed: only recover_slice does that (src/edge264_headers.c:295-305), after
+		 * the slice's own deblocking (:499-525).  What was decoded and deblocked up to here is one state of the picture --
+		 * it goes out as a packet now --, the concealment that starts here writes the next one. */
+		e264_flush_mb(e);
+		e->recover_serial = e->serial;
+		if (e->flush_partial)
+			e->flush_partial(e, slot);
+	}
+	e->trk_serial = e->serial; e->trk_slot = slot; e->trk_addr = addr;
 	if (c->valid && c->slot == slot && c->addr == addr)
 		c->valid = 0; /* the same macroblock decoded again by a later NAL (a slice that failed and is resent): start over */
 	e264_flush_mb(e);
 	E264FrameBuilder *b = e264_builder(e, slot);
+	if (addr < b->n_mbs && (b->mbs[addr].kind != E264_MB_ABSENT || b->state[addr])) {
+		/* decoded before (a slice failed: recover_slice conceals with skips, and recovery_bits let a later copy of the
+		 * slice decode the macroblock again, src/edge264_slice.c:1686): a new generation, reconstructed by the next
+		 * packet and deblocked only if the reference calls deblock_mb on it again with filter_edges set */
+		b->state[addr] = 0;
+		b->dbk_slice[addr] = 0xffff;
+		b->mbs[addr].kind = E264_MB_ABSENT;
+		b->multi = 1;
+	}
 	memset(c, 0, offsetof(E264MbStage, luma_dc));
 	c->valid = 1;
 	c->slot = slot;
@@ -275,8 +312,11 @@ static E264MbStage *e264_touch_ctx(Edge264Context *ctx)
 	int slot = e264_locate(e, ctx->samples_mb[0], &off);
 	if (slot < 0)
 		return NULL;
-	E264MbStage *c = e264_touch(e, slot, ctx->CurrMbAddr);
-	e264_fill_slice(e, &e->fb[slot], c->slice, ctx);
+	/* the position, not ctx->CurrMbAddr: recover_slice walks mbx / mby / samples_mb back over the failed slice while
+	 * CurrMbAddr stays where the error was found (src/edge264_headers.c:297-305, 414-428) */
+	E264MbStage *c = e264_touch(e, slot, ctx->mbx + ctx->mby * ctx->t.pic_width_in_mbs);
+	if (c)
+		e264_fill_slice(e, &e->fb[slot], c->slice, ctx);
 	return c;
 }
 
@@ -305,8 +345,15 @@ static E264MbStage *e264_touch_ptr(const uint8_t *p, int *x_in_mb, int *y_in_mb,
 }
 
 /* ---- helpers referenced by the reference's error concealment (recover_slice, src/edge264_headers.c:295-430),
- * which lived in the kernel files we replace.  Concealment blends samples on the HOST mirror and is not
- * forwarded to the device yet ("next"): streams that decode without error never reach it. */
+ * which lived in the kernel files we replace.  What recover_slice writes (a blend with the neighbours' DC for I slices, on
+ * the host mirror; P_Skip / B_Skip for P / B slices, through decode_inter) never reaches a picture the API hands out: the
+ * picture of a failed slice stays incomplete unless the slice arrives again, and then every concealed macroblock is
+ * decoded again on top -- except macroblocks of OTHER slices that the failed slice ran over, which keep their concealed
+ * (skip) version.  The emitters reproduce every state of the picture that can survive: the picture
+ * as decoded and deblocked up to the failure goes out as a packet of its own, the P_Skip / B_Skip concealment is the next
+ * generation of its macroblocks (e264_touch), and from then on the picture is sent NAL by NAL
+ * (edge264_hip_frontend.c, e264_finish_frame with partial = 1).  The I-slice blend happens on the host mirror only: every
+ * blended macroblock is decoded again before the picture can complete. */
 static inline i8x16 ldleftC(const uint8_t *p, size_t stride, size_t mstride)
 { /* left neighbours of two 8-row planes interleaved row by row: even rows first, then odd rows */
 	i8x16 v;

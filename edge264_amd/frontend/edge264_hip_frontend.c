@@ -233,26 +233,32 @@ static void e264_free_cb(void *samples, void *mbs, void *arg)
 	(void)mbs;
 }
 
-/* ---- closing a frame: assemble the packet, give it to the sink --------------------------- */
-static int e264_finish_frame(E264Emitter *e, int slot)
+/* I_PCM macroblocks issue no leaf call: the parser wrote their samples into the host mirror (src/edge264_slice.c:914-935);
+ * decoded-but-unseen macroblocks are PCM.  Called when a picture is closed, and from the unref callback the moment a slice
+ * fails: recover_slice is about to blend or overwrite those samples (src/edge264_headers.c:527-529 comes after :495-497). */
+static void e264_lift_pcm(E264Emitter *e, int slot)
 {
 	E264FrameBuilder *b = &e->fb[slot];
 	Edge264Decoder *dec = e->dec;
-	if (e->cur.valid && e->cur.slot == slot)
-		e264_flush_mb(e);
-	/* I_PCM macroblocks issue no leaf call: the parser wrote their samples into the host mirror
-	 * (src/edge264_slice.c:914-935); decoded-but-unseen macroblocks are PCM */
+	if (!b->active)
+		return;
 	int flip = dec->frame_flip_bits >> slot & 1;
 	const Edge264Macroblock *mbs = e->slot[slot].mbs;
-	int n_coded = 0;
 	for (int a = 0; a < b->n_mbs; a++) {
 		E264Mb *m = &b->mbs[a];
 		const Edge264Macroblock *M = mbs + a % b->width_mbs + (a / b->width_mbs) * (b->width_mbs + 1);
-		if (m->kind == E264_MB_ABSENT && M->recovery_bits == flip && !M->mbIsInterFlag) {
+		if ((b->state[a] & E264_ST_ERR) && M->recovery_bits == flip) {
+			/* marked erroneous by recover_slice, decoded again since, and no leaf call has started a new record (e264_touch
+			 * clears the mark): it came back as I_PCM.  Reconstructed again from the new samples; not deblocked again unless
+			 * deblock_mb saw it (emit_deblock.c then has already reset the record). */
+			memset(m, 0, sizeof(*m));
+			b->state[a] &= E264_ST_DBK;
+		}
+		if (m->kind == E264_MB_ABSENT && !(b->state[a] & E264_ST_RECON) && M->recovery_bits == flip && !M->mbIsInterFlag) {
 			m->kind = E264_MB_PCM;
 			m->qp[0] = M->QP[0]; m->qp[1] = M->QP[1]; m->qp[2] = M->QP[2];
-			m->flags = (uint8_t)((M->filter_edges & 1 ? E264_MBF_EDGE_LEFT : 0) | (M->filter_edges & 2 ? E264_MBF_EDGE_TOP : 0) |
-				(M->filter_edges ? E264_MBF_DEBLOCK : 0));
+			const int fe = b->dbk_slice[a] != 0xffff ? b->fedges[a] : M->filter_edges; /* deblock_mb has cleared what it filtered */
+			m->flags = (uint8_t)((fe & 1 ? E264_MBF_EDGE_LEFT : 0) | (fe & 2 ? E264_MBF_EDGE_TOP : 0) | (fe ? E264_MBF_DEBLOCK : 0));
 			m->nz_mask = 0xffff;
 			m->slice = 0;
 			for (int i = b->n_slices - 1; i >= 0; i--)
@@ -267,6 +273,30 @@ static int e264_finish_frame(E264Emitter *e, int slot)
 			for (int y = 0; y < 8; y++) e264_payload_append(b, C + (size_t)y * dec->out.stride_C, 8);
 			for (int y = 0; y < 8; y++) e264_payload_append(b, C + (dec->out.stride_C >> 1) + (size_t)y * dec->out.stride_C, 8);
 		}
+	}
+}
+
+/* ---- closing a frame: assemble the packet, give it to the sink ---------------------------
+ * partial = 0: the picture is complete (next_deblock_addr[pic] == INT_MAX, src/edge264_headers.c:567).
+ * partial = 1: a slice of the picture has just FAILED (src/edge264_headers.c:527-529).  By then the reference has
+ *   reconstructed the slice's macroblocks up to the error and deblocked everything it had decoded (:499-525); what that
+ *   deblocking did to macroblocks that are NOT decoded again stays in the picture for good, so it has to happen on the
+ *   device too, on the samples of this moment: the picture-so-far goes out as a packet of its own.  A later packet of the
+ *   same picture (the slice arrives again and the picture completes) carries the macroblocks decoded since; the ones an
+ *   earlier packet has reconstructed are marked E264_MBF_DONE (records kept for their neighbours' bS, no payload, not
+ *   reconstructed again), and a macroblock is deblocked by exactly the packet during which the reference called deblock_mb
+ *   on it (emit_deblock.c) -- a macroblock that was deblocked, concealed and decoded again is NOT deblocked a second time
+ *   unless the reference does so (its next_deblock_addr has moved past it, src/edge264_headers.c:922-925, 531-535). */
+static int e264_finish_frame(E264Emitter *e, int slot, int partial)
+{
+	E264FrameBuilder *b = &e->fb[slot];
+	Edge264Decoder *dec = e->dec;
+	if (e->cur.valid && e->cur.slot == slot)
+		e264_flush_mb(e);
+	e264_lift_pcm(e, slot);
+	int n_coded = 0;
+	for (int a = 0; a < b->n_mbs; a++) {
+		E264Mb *m = &b->mbs[a];
 		n_coded += m->kind != E264_MB_ABSENT;
 		m->dbk_slice = b->dbk_slice[a] != 0xffff ? b->dbk_slice[a] : m->slice;
 	}
@@ -280,6 +310,13 @@ static int e264_finish_frame(E264Emitter *e, int slot)
 		e->serial = -1;
 		e264_slice_index(e, b);
 		e->serial = serial;
+	}
+	if (partial) { /* nothing new since the last packet of the picture? */
+		int dirty = 0;
+		for (int a = 0; a < b->n_mbs && !dirty; a++)
+			dirty = (b->mbs[a].kind != E264_MB_ABSENT && !(b->state[a] & E264_ST_RECON)) || (b->dbk_slice[a] != 0xffff && !(b->state[a] & E264_ST_DBK));
+		if (!dirty)
+			return 0;
 	}
 	/* motion sized by partition (edge264_cmd.h): compact records of the inter macroblocks, their directory in E264Mb.modes */
 	uint32_t motion_bytes = 0;
@@ -332,7 +369,27 @@ static int e264_finish_frame(E264Emitter *e, int slot)
 		memcpy(pkt + motion_off, b->mot, motion_bytes);
 	memcpy(pkt + payload_off, b->payload, b->payload_len);
 	memset(pkt + payload_off + b->payload_len, 0, payload_bytes - b->payload_len);
-	b->active = 0;
+	if (partial || b->multi) {
+		/* a picture in several packets: what THIS packet reconstructs and deblocks, record by record (in the packet's copy) */
+		E264Mb *pm = (E264Mb *)(pkt + mbs_off);
+		for (int a = 0; a < b->n_mbs; a++) {
+			if (pm[a].kind == E264_MB_ABSENT)
+				continue;
+			const int dbk_now = b->dbk_slice[a] != 0xffff && !(b->state[a] & E264_ST_DBK);
+			if (!dbk_now)
+				pm[a].flags &= (uint8_t)~(E264_MBF_DEBLOCK | E264_MBF_EDGE_LEFT | E264_MBF_EDGE_TOP);
+			if (b->state[a] & E264_ST_RECON) {
+				pm[a].flags |= E264_MBF_DONE;
+				pm[a].coded = 0;
+				pm[a].payload_off = 0;
+			}
+			b->state[a] |= (uint8_t)(E264_ST_RECON | (b->dbk_slice[a] != 0xffff ? E264_ST_DBK : 0));
+		}
+		b->multi = 1;
+		b->payload_len = 0; /* the records kept for a later packet carry no payload (DONE) */
+	}
+	if (!partial)
+		b->active = 0;
 	if (e->sink_kind == 0)
 		return hip.frame_submit(e->hip_stream, pkt, total);
 	struct E264Captured *c = malloc(sizeof(*c));
@@ -342,12 +399,14 @@ static int e264_finish_frame(E264Emitter *e, int slot)
 	return 0;
 }
 
+static int e264_flush_partial(E264Emitter *e, int slot) { return e264_finish_frame(e, slot, 1); }
+
 static int e264_close_ready_frames(E264Emitter *e)
 {
 	int ret = 0;
 	for (int s = 0; s < E264_MAX_SLOTS; s++)
 		if (e->fb[s].active && e->dec->next_deblock_addr[s] == INT_MAX) {
-			int r = e264_finish_frame(e, s);
+			int r = e264_finish_frame(e, s, 0);
 			if (r) ret = r;
 		}
 	return ret;
@@ -382,6 +441,7 @@ PUBLIC Edge264Decoder *edge264_alloc(int n_threads, Edge264LogCb log_cb, void *l
 		return NULL;
 	e->sink_kind = g_sink_kind;
 	e->user_alloc = alloc_cb; e->user_free = free_cb; e->user_arg = alloc_arg;
+	e->flush_partial = e264_flush_partial;
 	if (ON_DEVICE(e) && (hip_bind_ordinal(g_device_ordinal, (E264Device **)&e->hip_dev) || hip.stream_open(e->hip_dev, (E264Stream **)&e->hip_stream))) {
 		free(e);
 		return NULL;
@@ -398,6 +458,28 @@ PUBLIC Edge264Decoder *edge264_alloc(int n_threads, Edge264LogCb log_cb, void *l
 
 static E264Emitter *emitter_of(Edge264Decoder *dec) { return dec ? dec->alloc_arg : NULL; }
 
+/* The slice's result reaches the application through unref_cb (src/edge264_headers.c:495-497); edge264_decode_NAL itself
+ * returns the header parser's code.  The wrapper learns from the same callback that a slice failed. */
+struct E264Unref { E264Emitter *e; Edge264UnrefCb user_cb; void *user_arg; };
+static void e264_unref_cb(int ret, void *arg)
+{
+	struct E264Unref *u = arg;
+	E264Emitter *e = u->e;
+	const int slot = e->trk_serial == e->serial ? e->trk_slot : e->dec->currPic; /* a slice may fail before its first leaf call */
+	if (ret && slot >= 0 && slot < E264_MAX_SLOTS && e->slot[slot].samples) {
+		e->failed_serial = e->serial;
+		e->failed_slot = slot;
+		if (e->cur.valid && e->cur.slot == slot)
+			e264_flush_mb(e);
+		/* from here on the picture's deblocking follows the calls the reference actually makes (a failed slice moves its
+		 * next_deblock_addr bookkeeping, src/edge264_headers.c:531-535), not the macroblocks' filter_edges alone */
+		e264_builder(e, slot)->multi = 1;
+		e264_lift_pcm(e, slot); /* before recover_slice touches the samples */
+	}
+	if (u->user_cb)
+		u->user_cb(ret, u->user_arg);
+}
+
 PUBLIC int edge264_decode_NAL(Edge264Decoder *dec, const uint8_t *buf, const uint8_t *end, Edge264UnrefCb unref_cb, void *unref_arg)
 {
 	E264Emitter *e = emitter_of(dec);
@@ -405,8 +487,26 @@ PUBLIC int edge264_decode_NAL(Edge264Decoder *dec, const uint8_t *buf, const uin
 		return EINVAL;
 	e264_tls_emitter = e;
 	e->serial++;
-	int ret = e264ref_decode_NAL(dec, buf, end, unref_cb, unref_arg);
-	int r2 = e264_close_ready_frames(e);
+	struct E264Unref u = {e, unref_cb, unref_arg}; /* synchronous mode: every callback fires before decode_NAL returns */
+	int ret = e264ref_decode_NAL(dec, buf, end, e264_unref_cb, &u);
+	int r2 = 0;
+	if (e->failed_serial == e->serial && e->fb[e->failed_slot].active) { /* what recover_slice has marked (src/edge264_headers.c:411) */
+		E264FrameBuilder *b = &e->fb[e->failed_slot];
+		const int flip = dec->frame_flip_bits >> e->failed_slot & 1;
+		const Edge264Macroblock *Mb = e->slot[e->failed_slot].mbs;
+		for (int a = 0; a < b->n_mbs; a++)
+			if (Mb[a % b->width_mbs + (a / b->width_mbs) * (b->width_mbs + 1)].recovery_bits == flip + 2)
+				b->state[a] |= E264_ST_ERR;
+	}
+	/* a picture with a failed slice goes out NAL by NAL from then on: each packet is one state of the picture as the
+	 * reference builds it (what the NAL decoded, what it deblocked), in the reference's order */
+	for (int s = 0; s < E264_MAX_SLOTS; s++)
+		if (e->fb[s].active && e->fb[s].multi && dec->next_deblock_addr[s] != INT_MAX) {
+			int r = e264_finish_frame(e, s, 1);
+			if (r) r2 = r;
+		}
+	int r3 = e264_close_ready_frames(e);
+	if (!r2) r2 = r3;
 	e264_tls_emitter = NULL;
 	return ret ? ret : (r2 == ENOMEM ? ENOMEM : 0);
 }
@@ -458,7 +558,7 @@ PUBLIC void edge264_free(Edge264Decoder **pdec)
 		return;
 	if (ON_DEVICE(e)) hip.stream_close(e->hip_stream);
 	for (int s = 0; s < E264_MAX_SLOTS; s++) {
-		free(e->fb[s].mbs); free(e->fb[s].motion); free(e->fb[s].dbk_slice); free(e->fb[s].mot); free(e->fb[s].slices); free(e->fb[s].slice_serial);
+		free(e->fb[s].mbs); free(e->fb[s].motion); free(e->fb[s].dbk_slice); free(e->fb[s].state); free(e->fb[s].fedges); free(e->fb[s].mot); free(e->fb[s].slices); free(e->fb[s].slice_serial);
 		free(e->fb[s].slice_filled); free(e->fb[s].payload);
 	}
 	while (e->cap_head) {

@@ -11,17 +11,33 @@
 static noinline void deblock_mb(Edge264Context *ctx)
 {
 	E264Emitter *e = e264_tls_emitter;
+	if (!mb->filter_edges) /* src/edge264_deblock.c:938: already filtered (or never to be) */
+		return;
 	size_t off;
 	int slot = e264_locate(e, ctx->samples_mb[0], &off);
 	if (slot >= 0 && e->fb[slot].active) {
 		E264FrameBuilder *b = &e->fb[slot];
+		if (e->cur.valid && e->cur.slot == slot)
+			e264_flush_mb(e); /* the record takes its flags from filter_edges, which is cleared below */
 		int idx = e264_slice_index(e, b);
 		e264_fill_slice(e, b, idx, ctx);
 		size_t px = off >> 4, stride = (size_t)ctx->t.stride[0]; /* samples_mb[0] = base + (mbx + mby * stride) * 16 */
 		size_t mby = px / stride, mbx = px % stride;
-		/* the first call is the one that filters: the reference clears mb->filter_edges afterwards (deblock.c:500) and the
-		 * picture-completing pass runs over macroblocks that were deblocked earlier without touching them */
-		if (mbx < (size_t)b->width_mbs && mby < (size_t)b->height_mbs && b->dbk_slice[mby * (size_t)b->width_mbs + mbx] == 0xffff)
-			b->dbk_slice[mby * (size_t)b->width_mbs + mbx] = (uint16_t)idx;
+		if (mbx < (size_t)b->width_mbs && mby < (size_t)b->height_mbs) {
+			size_t a = mby * (size_t)b->width_mbs + mbx;
+			if ((b->state[a] & E264_ST_ERR) && mb->recovery_bits == ctx->t.frame_flip_bit) {
+				/* marked erroneous, then decoded again without a single leaf call: as I_PCM (src/edge264_slice.c:914-935).
+				 * Its record starts over; e264_lift_pcm picks the samples up when the packet is closed. */
+				memset(&b->mbs[a], 0, sizeof(E264Mb));
+				b->state[a] = 0;
+				b->dbk_slice[a] = 0xffff;
+			}
+			b->fedges[a] = mb->filter_edges;
+			/* the first call is the one that filters (the picture-completing pass runs over macroblocks that were deblocked
+			 * earlier without touching them) */
+			if (b->dbk_slice[a] == 0xffff)
+				b->dbk_slice[a] = (uint16_t)idx;
+		}
 	}
+	mb->filter_edges = 0; /* src/edge264_deblock.c:500: a macroblock is filtered once per parse */
 }

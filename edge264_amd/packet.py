@@ -14,7 +14,7 @@ E264_VERSION = 3
 MAX_SLOTS = 32
 
 MB_ABSENT, MB_I4x4, MB_I8x8, MB_I16x16, MB_PCM, MB_INTER = range(6)
-MBF_T8x8, MBF_EDGE_LEFT, MBF_EDGE_TOP, MBF_DEBLOCK = 1, 2, 4, 8
+MBF_T8x8, MBF_EDGE_LEFT, MBF_EDGE_TOP, MBF_DEBLOCK, MBF_DONE = 1, 2, 4, 8, 16
 CODED_LUMA_DC = 1 << 24
 CODED_CHROMA_DC = 1 << 25
 

@@ -62,6 +62,11 @@ enum {
 #define E264_MBF_EDGE_LEFT   0x02 /* filter_edges bit0: deblock the left MB edge */
 #define E264_MBF_EDGE_TOP    0x04 /* filter_edges bit1: deblock the top MB edge */
 #define E264_MBF_DEBLOCK     0x08 /* filter_edges != 0: this MB is deblocked at all */
+#define E264_MBF_DONE        0x10 /* the macroblock's samples were written by an EARLIER packet of the same picture: the record is
+                                     here for its neighbours (bS, QP averages), nothing reconstructs it again and it carries no payload.
+                                     Pictures are split into several packets only around a slice that failed (src/edge264_headers.c:
+                                     486-529: the reference deblocks what it decoded, conceals, and a later copy of the slice decodes
+                                     the macroblocks again on top) */
 
 /* E264Mb.coded bit positions */
 #define E264_CODED_LUMA(k)    (1u << (k))        /* k = 4x4 block 0..15 in zig order; for T8x8 only k=0,4,8,12 */
@@ -243,6 +248,7 @@ static inline void e264_motion_expand(uint32_t h, const uint8_t *rec, E264Motion
 static inline uint32_t e264_mb_payload_bytes(const E264Mb *m)
 {
 	uint32_t n = 0;
+	if (m->flags & E264_MBF_DONE) return 0;
 	if (m->kind == E264_MB_PCM) n += 384;
 	if (m->coded & E264_CODED_LUMA_DC) n += 32;
 	if (m->coded & E264_CODED_CHROMA_DC) n += 16;

@@ -707,7 +707,7 @@ static void chroma_residual(const Frame *f, const E264Mb *m, const E264SlicePara
 static void recon_mb(const Frame *f, int mbx, int mby)
 {
 	const E264Mb *m = f->mbs + mby * f->h->width_mbs + mbx;
-	if (m->kind == E264_MB_ABSENT)
+	if (m->kind == E264_MB_ABSENT || (m->flags & E264_MBF_DONE)) /* DONE: an earlier packet of the picture wrote it (edge264_cmd.h) */
 		return;
 	const E264SliceParams *s = f->slices + m->slice;
 	const uint8_t *pl = f->payload + m->payload_off;

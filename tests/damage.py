@@ -1,0 +1,53 @@
+"""Damaged-stream scenarios for the concealment tests: a slice NAL cut short, followed by an intact copy of itself (what an
+application does when it re-requests a lost packet, and the only way concealed samples become observable through the
+reference's API: a picture whose slice failed never completes on its own, src/edge264_headers.c:539, 435-442)."""
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+STREAMS = os.path.join(HERE, "golden", "streams")
+
+
+def nal_units(data: bytes) -> list[bytes]:
+    pos, i = [], 0
+    while True:
+        j = data.find(b"\0\0\1", i)
+        if j < 0:
+            break
+        pos.append(j)
+        i = j + 3
+    return [data[a:b] for a, b in zip(pos, pos[1:] + [len(data)])]
+
+
+def slice_indices(nals: list[bytes]) -> list[int]:
+    return [i for i, n in enumerate(nals) if (n[3] & 31) in (1, 5, 20)]
+
+
+def truncated_then_resent(name: str, which: int, keep: float) -> bytes:
+    """The fixture with slice NAL number `which` (index into its slice NALs) preceded by a copy cut to `keep` of its length."""
+    nals = nal_units(open(os.path.join(STREAMS, name + ".264"), "rb").read())
+    k = slice_indices(nals)[which]
+    bad = nals[k][:max(8, int(len(nals[k]) * keep))]
+    return b"".join(nals[:k] + [bad] + nals[k:])
+
+
+def truncated_only(name: str, which: int, keep: float) -> bytes:
+    """The slice is cut short and never comes again."""
+    nals = nal_units(open(os.path.join(STREAMS, name + ".264"), "rb").read())
+    k = slice_indices(nals)[which]
+    return b"".join(nals[:k] + [nals[k][:max(8, int(len(nals[k]) * keep))]] + nals[k + 1:])
+
+
+# (fixture, slice NAL, fraction kept): I / P / B slices, CAVLC and CABAC, one and several slices per picture, slice-boundary
+# deblocking on and off, arbitrary slice order, 8x8 transform, I_PCM, MVC, weighted prediction
+RESENT = [
+    ("ipp_partitions", 0, 0.3), ("ipp_partitions", 1, 0.7), ("ipp_partitions", 3, 0.5),
+    ("cabac_ipp", 0, 0.6), ("cabac_ipp", 2, 0.3),
+    ("i_4x4_16x16_pcm", 0, 0.3), ("i_4x4_16x16_pcm", 1, 0.7),
+    ("slices_deblock_idc", 1, 0.5), ("slices_deblock_idc", 4, 0.3), ("slices_deblock_idc", 7, 0.7),
+    ("cabac_slices_deblock_idc", 3, 0.3), ("cabac_slices_deblock_idc", 8, 0.7),
+    ("aso_slices", 1, 0.3), ("aso_slices", 6, 0.7), ("aso_slices", 9, 0.3), ("aso_slices", 14, 0.5),
+    ("ipb_spatial", 2, 0.3), ("ipb_spatial", 3, 0.7), ("cabac_ipb_spatial", 2, 0.5),
+    ("t8x8_plain", 1, 0.3), ("cabac_t8x8_slices", 5, 0.3), ("cabac_t8x8_slices", 8, 0.7),
+    ("mvc_ipp", 3, 0.5), ("cabac_weighted_b", 4, 0.4), ("reorder_weighted", 5, 0.6),
+]
+LOST = [("ipp_partitions", 3, 0.5), ("cabac_ipp", 3, 0.4), ("slices_deblock_idc", 11, 0.5), ("cabac_t8x8_slices", 11, 0.5)]

@@ -1,0 +1,68 @@
+"""Error concealment at the drop-in boundary (/root/reference/src/edge264_headers.c:295-430, 486-529).
+
+What the reference does with a slice that fails: it keeps what the slice decoded, deblocks it, conceals it (I slices: a
+blend with the neighbours' DC; P / B slices: P_Skip / B_Skip) and marks the macroblocks erroneous; the picture stays
+incomplete (and is never handed out) unless the slice arrives again, in which case its macroblocks are decoded again ON TOP
+of that state.  The samples that survive are: the deblocking the failed attempt did to macroblocks outside the slice, the
+concealed version of macroblocks of other slices the failed attempt ran over, and the missing second deblocking of the
+macroblocks decoded twice.  The emitters reproduce those states as a sequence of packets per picture
+(E264_MBF_DONE, edge264_cmd.h); here every frame of every scenario must equal the UNMODIFIED reference decoder's, with the
+oracle standing in for the GPU (tests/test_frontend_hip.py::test_concealment_on_the_gpu runs the same on the device)."""
+import hashlib
+import os
+
+import pytest
+
+from tests import damage
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+pytestmark = pytest.mark.skipif(not (os.path.exists(os.path.join(ROOT, "edge264_amd", "libedge264_hipfront.so")) and
+                                     os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libedge264_ref.so"))),
+                                reason="needs the front-end library and oracle/_ref (built from /root/reference)")
+
+
+def md5s(frames):
+    return [hashlib.md5(b"".join(p.tobytes() for p in fr)).hexdigest() for fr in frames]
+
+
+@pytest.mark.parametrize("name,which,keep", damage.RESENT, ids=[f"{n}-{w}-{k}" for n, w, k in damage.RESENT])
+def test_failed_slice_resent(name, which, keep, oracle, refdecoder):
+    from oracle.pyoracle import HipFront
+    data = damage.truncated_then_resent(name, which, keep)
+    f0, c0 = refdecoder.decode(data)
+    f1, c1, packets = HipFront().decode_capture(data, oracle)
+    assert c0 == c1
+    assert md5s(f0) == md5s(f1)
+    assert len(f0) > 0
+
+
+@pytest.mark.parametrize("name,which,keep", damage.LOST, ids=[f"{n}-{w}-{k}" for n, w, k in damage.LOST])
+def test_failed_slice_never_resent(name, which, keep, oracle, refdecoder):
+    """The damaged picture is the last one: the reference never hands it out, neither does the shim; everything else is equal."""
+    from oracle.pyoracle import HipFront
+    data = damage.truncated_only(name, which, keep)
+    f0, c0 = refdecoder.decode(data)
+    f1, c1, _ = HipFront().decode_capture(data, oracle)
+    assert c0 == c1 and md5s(f0) == md5s(f1)
+
+
+def test_damaged_pictures_go_out_in_several_packets(oracle):
+    """The mechanism itself: the failed attempt is a packet of its own, later packets of the picture mark what they must not
+    reconstruct again (E264_MBF_DONE) and every packet passes the back end's validation."""
+    from edge264_amd import backend, packet as P
+    from oracle.pyoracle import HipFront
+    data = damage.truncated_then_resent("slices_deblock_idc", 4, 0.5)
+    _, _, packets = HipFront().decode_capture(data, oracle)
+    ids = [int(P.Packet(p).hdr["frame_id"]) for p in packets]
+    assert len(ids) > len(set(ids)), "no picture was split"
+    assert any((P.Packet(p).mbs["flags"] & P.MBF_DONE).any() for p in packets)
+    for p in packets:
+        assert backend.packet_check(p) == 0
+        pk = P.Packet(p)
+        done = (pk.mbs["flags"] & P.MBF_DONE) != 0
+        assert not (pk.mbs["coded"][done] != 0).any()   # records kept for their neighbours carry no payload
+    # undamaged streams are never split
+    _, _, clean = HipFront().decode_capture(open(os.path.join(damage.STREAMS, "slices_deblock_idc.264"), "rb").read(), oracle)
+    assert len({int(P.Packet(p).hdr["frame_id"]) for p in clean}) == len(clean)
+    assert not any((P.Packet(p).mbs["flags"] & P.MBF_DONE).any() for p in clean)

@@ -110,3 +110,18 @@ def test_caller_allocators_receive_the_frames(front):
         L.edge264_free(C.byref(dec))
         assert md5s(frames) == sums[name]["md5"]
         assert al.allocs == al.frees and not al.live
+
+
+def test_concealment_on_the_gpu(front):
+    """tests/test_frontend_concealment.py on the device: a slice cut short, then sent again -- the failed attempt, its
+    deblocking, the P_Skip / B_Skip concealment and the second decode reach the kernels as a sequence of packets per picture
+    (E264_MBF_DONE); every frame must equal the unmodified reference decoder's (md5s computed in the container by
+    tests/golden/make_damage_md5.py from the reference itself: /root/reference does not travel)."""
+    from tests import damage
+    with open(os.path.join(STREAMS, "damage_md5.json")) as f:
+        sums = json.load(f)
+    for name, which, keep in damage.RESENT:
+        frames, codes = front.decode(damage.truncated_then_resent(name, which, keep))
+        want = sums[f"{name}-{which}-{keep}"]
+        assert codes == want["nal_codes"], (name, which, keep)
+        assert md5s(frames) == want["md5"], (name, which, keep)
