@@ -115,22 +115,27 @@ __device__ __forceinline__ MbInfo mb_from_lds(const uint32_t *rec)
 // One 4x4 block per 4 lanes.  pass 1 (lane = block k, row y): dequant + horizontal butterfly
 // (edge264_residual.c:118-134); pass 2 (lane = block k, column x'): vertical butterfly, >>6,
 // saturate to int16 (residual.c:141-158).  dc_only blocks get the add_dc4x4 value (residual.c:174-187).
+// level `idx` of the coefficient area at `base` (LDS): int16, or int8 with E264_MBF_LEV8
+__device__ __forceinline__ int level_at(const uint8_t *base, int idx, bool l8)
+{
+	return l8 ? (int)((const int8_t *)base)[idx] : (int)((const int16_t *)base)[idx];
+}
 __device__ __forceinline__ void idct4x4_blocks(WaveLds &L, int nblk, uint32_t codedmask, bool use_dc, bool dc_valid,
-	const int16_t *coef_base, const uint8_t *wS, int qP, int dc_off, int res_off, int res_stride, int lane)
+	const uint8_t *coef_base, bool l8, const uint8_t *wS, int qP, int dc_off, int res_off, int res_stride, int lane)
 {
 	int k = lane >> 2, y = lane & 3;
 	bool active = k < nblk;
 	bool coded = active && (codedmask >> k & 1);
 	if (coded) {
 		// coefficient blocks are packed in increasing k: offset = popcount of lower coded bits
-		const int16_t *c = coef_base + __builtin_popcount(codedmask & ((1u << k) - 1)) * 16;
+		const int cb = __builtin_popcount(codedmask & ((1u << k) - 1)) * 16; // levels before this block
 		int sh = qP / 6, m = qP - sh * 6;
 		int d[4];
 #pragma unroll
 		for (int x = 0; x < 4; x++) {
 			int pos = x * 4 + y;
 			int LS = wS[pos] * norm4(m, pos);
-			d[x] = (int)(((uint32_t)((int)c[pos] * LS) << sh) + 8u) >> 4;
+			d[x] = (int)(((uint32_t)(level_at(coef_base, cb + pos, l8) * LS) << sh) + 8u) >> 4;
 		}
 		if (use_dc && y == 0)
 			d[0] = L.dc[dc_off + k];
@@ -190,7 +195,7 @@ __device__ __forceinline__ void idct8_1d(int16_t d[8])
 	d[4] = (int16_t)(f6 - f1); d[5] = (int16_t)(f4 - f3); d[6] = (int16_t)(f2 - f5); d[7] = (int16_t)(f0 - f7);
 }
 
-__device__ __forceinline__ void idct8x8_blocks(WaveLds &L, uint32_t coded, const int16_t *coef_base, const uint8_t *wS, int qP, int lane)
+__device__ __forceinline__ void idct8x8_blocks(WaveLds &L, uint32_t coded, const uint8_t *coef_base, bool l8, const uint8_t *wS, int qP, int lane)
 {
 	int b = lane >> 3, j = lane & 7;
 	bool on = lane < 32 && (coded >> (b * 4) & 1);
@@ -198,17 +203,17 @@ __device__ __forceinline__ void idct8x8_blocks(WaveLds &L, uint32_t coded, const
 	if (on) {
 		int nb = 0;
 		for (int i = 0; i < b; i++) nb += coded >> (i * 4) & 1;
-		const int16_t *c = coef_base + nb * 64;
 		int div = qP / 6, m = qP - div * 6;
 		int16_t d[8];
 #pragma unroll
 		for (int i = 0; i < 8; i++) {
 			int pos = i * 8 + j;
 			int LS = wS[pos] * norm8(m, pos);
+			const int lev = level_at(coef_base, nb * 64 + pos, l8);
 			if (div < 6)
-				d[i] = (int16_t)sat16(((int)c[pos] * LS + (1 << (5 - div))) >> (6 - div));
+				d[i] = (int16_t)sat16((lev * LS + (1 << (5 - div))) >> (6 - div));
 			else
-				d[i] = (int16_t)((int)c[pos] * (int)(int16_t)(LS << (div - 6)));
+				d[i] = (int16_t)(lev * (int)(int16_t)(LS << (div - 6)));
 		}
 		idct8_1d(d);
 		// transposed read in pass 2: element [i][j]; +32 lands on the new vector 0 = all elements with j == 0
@@ -246,9 +251,10 @@ __device__ __forceinline__ int coef_dwords(const MbInfo &m)
 	if (m.kind == E264_MB_ABSENT || m.kind == E264_MB_PCM || m.coded == 0)
 		return 0;
 	const uint32_t c = m.coded;
-	int bytes = ((c & E264_CODED_LUMA_DC) ? 32 : 0) + ((c & E264_CODED_CHROMA_DC) ? 16 : 0) + __builtin_popcount(c >> 16 & 0xff) * 32;
-	bytes += (m.kind != E264_MB_I16x16 && (m.flags & E264_MBF_T8x8)) ? __builtin_popcount(c & 0x1111) * 128 : __builtin_popcount(c & 0xffff) * 32;
-	return bytes >> 2;
+	int ac = __builtin_popcount(c >> 16 & 0xff) * 32;
+	ac += (m.kind != E264_MB_I16x16 && (m.flags & E264_MBF_T8x8)) ? __builtin_popcount(c & 0x1111) * 128 : __builtin_popcount(c & 0xffff) * 32;
+	if (m.flags & E264_MBF_LEV8) ac >>= 1; // one byte per AC level
+	return (((c & E264_CODED_LUMA_DC) ? 32 : 0) + ((c & E264_CODED_CHROMA_DC) ? 16 : 0) + ac + 3) >> 2;
 }
 __device__ __forceinline__ void coef_dma(int16_t *dst, const FrameCtx &f, const MbInfo &m, int lane)
 { // dst: one of the wave's two payload buffers (uniform address); lanes beyond the payload are masked out and write nothing
@@ -294,7 +300,9 @@ __device__ __forceinline__ void compute_residual(WaveLds &L, const int16_t *coef
 	const int16_t *ldc = nullptr, *cdc = nullptr;
 	if (coded & E264_CODED_LUMA_DC) { ldc = pl; pl += 16; }
 	if (coded & E264_CODED_CHROMA_DC) { cdc = pl; pl += 8; }
-	const int16_t *co = pl;
+	const uint8_t *co = (const uint8_t *)pl;          // the AC blocks: int16 levels, or int8 (E264_MBF_LEV8)
+	const bool l8 = m.flags & E264_MBF_LEV8;
+	const int lsz = l8 ? 1 : 2;                         // bytes per level
 	const uint8_t *ws4 = L.ws, *ws8 = L.ws + 96;
 	if (lane < 24) L.dc[lane] = 0;
 	wave_sync();
@@ -330,22 +338,22 @@ __device__ __forceinline__ void compute_residual(WaveLds &L, const int16_t *coef
 	// luma
 	if (m.kind == E264_MB_I16x16) {
 		if (coded & (0xffff | E264_CODED_LUMA_DC))
-			idct4x4_blocks(L, 16, coded & 0xffff, true, ldc != nullptr, co, ws4, m.qp[0], 0, 0, 16, lane);
-		co += __builtin_popcount(coded & 0xffff) * 16;
+			idct4x4_blocks(L, 16, coded & 0xffff, true, ldc != nullptr, co, l8, ws4, m.qp[0], 0, 0, 16, lane);
+		co += __builtin_popcount(coded & 0xffff) * 16 * lsz;
 	} else if (m.flags & E264_MBF_T8x8) {
 		if (coded & 0x1111)
-			idct8x8_blocks(L, coded, co, ws8 + (inter ? 64 : 0), m.qp[0], lane);
-		co += __builtin_popcount(coded & 0x1111) * 64;
+			idct8x8_blocks(L, coded, co, l8, ws8 + (inter ? 64 : 0), m.qp[0], lane);
+		co += __builtin_popcount(coded & 0x1111) * 64 * lsz;
 	} else {
 		if (coded & 0xffff)
-			idct4x4_blocks(L, 16, coded & 0xffff, false, false, co, ws4 + (inter ? 3 : 0) * 16, m.qp[0], 0, 0, 16, lane);
-		co += __builtin_popcount(coded & 0xffff) * 16;
+			idct4x4_blocks(L, 16, coded & 0xffff, false, false, co, l8, ws4 + (inter ? 3 : 0) * 16, m.qp[0], 0, 0, 16, lane);
+		co += __builtin_popcount(coded & 0xffff) * 16 * lsz;
 	}
 	// chroma: 8 blocks, Cb 0..3 then Cr 4..7; different QP / scaling list per plane
 	if (coded & (0xff0000 | E264_CODED_CHROMA_DC)) {
 		int k = lane >> 2;
 		int pc = (k >> 2) & 1;
-		idct4x4_blocks(L, 8, coded >> 16 & 0xff, true, cdc != nullptr, co, ws4 + (1 + pc + (inter ? 3 : 0)) * 16, pc ? m.qp[2] : m.qp[1], 16, 256, 8, lane);
+		idct4x4_blocks(L, 8, coded >> 16 & 0xff, true, cdc != nullptr, co, l8, ws4 + (1 + pc + (inter ? 3 : 0)) * 16, pc ? m.qp[2] : m.qp[1], 16, 256, 8, lane);
 	}
 }
 

@@ -672,6 +672,36 @@ E264_DEV uint32_t add_res4(uint32_t px, int r0, int r1, int r2, int r3)
 	       (uint32_t)clip255(w16((int)(px >> 16 & 255) + r2)) << 16 | (uint32_t)clip255(w16((int)(px >> 24) + r3)) << 24;
 }
 
+// Levels of a block as packed int16 pairs, whatever the packet stores (int16, or int8 with E264_MBF_LEV8): 8 levels ...
+E264_DEV uint32_t sext2(uint32_t w, int hi) // bytes (2 hi, 2 hi + 1) of w, sign-extended to two int16
+{
+	const uint32_t b0 = hi ? w >> 16 : w;
+	return ((uint32_t)(int)(int8_t)b0 & 0xffffu) | (uint32_t)(int)(int8_t)(b0 >> 8) << 16;
+}
+E264_DEV void levels8(const gu8 *co, int l8, uint32_t cw[4])
+{
+	if (l8) {
+		const v2u v = *(const gv2u *)co;
+		cw[0] = sext2(v.x, 0); cw[1] = sext2(v.x, 1); cw[2] = sext2(v.y, 0); cw[3] = sext2(v.y, 1);
+	} else {
+		const v4u v = *(const gv4u *)co;
+		cw[0] = v.x; cw[1] = v.y; cw[2] = v.z; cw[3] = v.w;
+	}
+}
+// ... and 16
+E264_DEV void levels16(const gu8 *co, int l8, uint32_t cw[8])
+{
+	if (l8) {
+		const v4u v = *(const gv4u *)co;
+		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (int i = 0; i < 4; i++) { cw[2 * i] = sext2(w[i], 0); cw[2 * i + 1] = sext2(w[i], 1); }
+	} else {
+		const v4u v0 = *(const gv4u *)co, v1 = *(const gv4u *)(co + 16);
+		cw[0] = v0.x; cw[1] = v0.y; cw[2] = v0.z; cw[3] = v0.w; cw[4] = v1.x; cw[5] = v1.y; cw[6] = v1.z; cw[7] = v1.w;
+	}
+}
+
 // one 4x4 block (edge264_residual.c:108-187): dequantisation, both butterflies and the add in this lane's registers
 E264_DEV void res_item4(PredLds &L, const FrameCtx &f, int item)
 {
@@ -685,9 +715,10 @@ E264_DEV void res_item4(PredLds &L, const FrameCtx &f, int item)
 	const bool chroma = b >= 16;
 	const int k = b & 15;        // luma block 0..15 / chroma block 0..7
 	const int pc = (k >> 2) & 1; // chroma plane
-	const int lumab = t8 ? __builtin_popcount(coded & 0x1111) * 128 : __builtin_popcount(coded & 0xffff) * 32;
-	const gu8 *co = chroma ? pl + lumab + __builtin_popcount((coded >> 16) & ((1u << k) - 1)) * 32
-	                       : pl + __builtin_popcount(coded & ((1u << k) - 1)) * 32;
+	const int l8 = (d0 >> 8 & E264_MBF_LEV8) ? 1 : 0; // one byte per level (edge264_cmd.h): block sizes halve
+	const int lumab = (t8 ? __builtin_popcount(coded & 0x1111) * 128 : __builtin_popcount(coded & 0xffff) * 32) >> l8;
+	const gu8 *co = chroma ? pl + lumab + ((__builtin_popcount((coded >> 16) & ((1u << k) - 1)) * 32) >> l8)
+	                       : pl + ((__builtin_popcount(coded & ((1u << k) - 1)) * 32) >> l8);
 	const int qP = chroma ? (pc ? (int)(d1 & 255) : (int)(d0 >> 24)) : (int)(d0 >> 16 & 255);
 	const int sh = qP / 6, m = qP - sh * 6;
 	const int wl = chroma ? 4 + pc : 3; // weightScale4x4 list of an inter block: Y 3, Cb 4, Cr 5
@@ -706,8 +737,8 @@ E264_DEV void res_item4(PredLds &L, const FrameCtx &f, int item)
 	const bool ac = chroma ? (coded >> (16 + k) & 1) : true;
 	int r[4][4]; // [row][col]
 	if (ac) {
-		const v4u cv0 = *(const gv4u *)co, cv1 = *(const gv4u *)(co + 16);
-		const uint32_t cw[8] = {cv0.x, cv0.y, cv0.z, cv0.w, cv1.x, cv1.y, cv1.z, cv1.w};
+		uint32_t cw[8];
+		levels16(co, l8, cw);
 		int tt[4][4]; // [xx][y]
 #pragma unroll
 		for (int y = 0; y < 4; y++) {
@@ -773,16 +804,18 @@ E264_DEV void res_item8(PredLds &L, const FrameCtx &f, int item)
 	cslice_t s = f.slices + (L.hdr[mb][2] >> 16);
 	const gu8 *pl = f.payload + L.hdr[mb][4];
 	if (coded & E264_CODED_CHROMA_DC) pl += 16;
-	const gu8 *co = pl + __builtin_popcount(coded & 0x1111 & ((1u << (bq * 4)) - 1)) * 128;
+	const int l8 = (d0 >> 8 & E264_MBF_LEV8) ? 1 : 0;
+	const gu8 *co = pl + ((__builtin_popcount(coded & 0x1111 & ((1u << (bq * 4)) - 1)) * 128) >> l8);
 	const gu8 *wsp = (const gu8 *)s + offsetof(E264SliceParams, weightScale8x8) + 64; // list 1: inter Y
 	const int qP = (int)(d0 >> 16 & 255), div = qP / 6, m = qP - div * 6;
 	// pass 1 (residual.c:250-296): for every j, the 1-D transform over i of d[i][j] = level c[i*8+j] dequantised; packed pairs (j, j+1)
 	s16x2 t[8][4]; // [i][pair of j]
 #pragma unroll
 	for (int i = 0; i < 8; i++) {
-		const v4u cv = *(const gv4u *)(co + i * 16);
+		uint32_t cw[4];
+		levels8(co + ((i * 16) >> l8), l8, cw);
 		const v2u wv = *(const gv2u *)(wsp + i * 8);
-		const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w}, ww[2] = {wv.x, wv.y};
+		const uint32_t ww[2] = {wv.x, wv.y};
 #pragma unroll
 		for (int jp = 0; jp < 4; jp++) {
 			int dq[2];

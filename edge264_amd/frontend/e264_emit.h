@@ -199,6 +199,14 @@ static void e264_payload_append(E264FrameBuilder *b, const void *src, size_t n)
 	b->payload_len += n;
 }
 
+static void e264_levels_append(E264FrameBuilder *b, const int16_t *lev, int n, int narrow)
+{
+	if (!narrow) { e264_payload_append(b, lev, (size_t)n * 2); return; }
+	int8_t t[64];
+	for (int i = 0; i < n; i++) t[i] = (int8_t)lev[i];
+	e264_payload_append(b, t, (size_t)n);
+}
+
 /* close the macroblock under assembly: header from the reference's own Edge264Macroblock
  * (src/edge264_internal.h:128-143), payload in the order of include/edge264_cmd.h */
 static void e264_flush_mb(E264Emitter *e)
@@ -250,18 +258,28 @@ static void e264_flush_mb(E264Emitter *e)
 	m->coded = c->coded;
 	if (c->coded & E264_CODED_LUMA_DC) e264_payload_append(b, c->luma_dc, 32);
 	if (c->coded & E264_CODED_CHROMA_DC) e264_payload_append(b, c->chroma_dc, 16);
+	/* AC levels as bytes when every one of them fits (E264_MBF_LEV8): nearly always, and half the coefficient payload */
+	int narrow = (c->coded & 0xffffff) != 0;
+	for (int k = 0; k < 16 && narrow; k++)
+		if (c->coded >> (t8 ? k & ~3 : k) & 1)
+			for (int i = 0; i < 16; i++) narrow &= c->luma[k][i] >= -128 && c->luma[k][i] <= 127;
+	for (int k = 0; k < 8 && narrow; k++)
+		if (c->coded >> (16 + k) & 1)
+			for (int i = 0; i < 16; i++) narrow &= c->chroma[k][i] >= -128 && c->chroma[k][i] <= 127;
+	if (narrow)
+		m->flags |= E264_MBF_LEV8;
 	if (t8) {
 		for (int q = 0; q < 4; q++)
 			if (c->coded >> (q * 4) & 1)
-				e264_payload_append(b, &c->luma[q * 4][0], 128);
+				e264_levels_append(b, &c->luma[q * 4][0], 64, narrow);
 	} else {
 		for (int k = 0; k < 16; k++)
 			if (c->coded >> k & 1)
-				e264_payload_append(b, c->luma[k], 32);
+				e264_levels_append(b, c->luma[k], 16, narrow);
 	}
 	for (int k = 0; k < 8; k++)
 		if (c->coded >> (16 + k) & 1)
-			e264_payload_append(b, c->chroma[k], 32);
+			e264_levels_append(b, c->chroma[k], 16, narrow);
 }
 
 /* make (slot, addr) the macroblock under assembly */

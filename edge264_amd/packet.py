@@ -10,11 +10,11 @@ from __future__ import annotations
 import numpy as np
 
 E264_MAGIC = 0x34363245
-E264_VERSION = 3
+E264_VERSION = 4
 MAX_SLOTS = 32
 
 MB_ABSENT, MB_I4x4, MB_I8x8, MB_I16x16, MB_PCM, MB_INTER = range(6)
-MBF_T8x8, MBF_EDGE_LEFT, MBF_EDGE_TOP, MBF_DEBLOCK, MBF_DONE = 1, 2, 4, 8, 16
+MBF_T8x8, MBF_EDGE_LEFT, MBF_EDGE_TOP, MBF_DEBLOCK, MBF_DONE, MBF_LEV8 = 1, 2, 4, 8, 16, 32
 CODED_LUMA_DC = 1 << 24
 CODED_CHROMA_DC = 1 << 25
 
@@ -168,7 +168,7 @@ class PacketBuilder:
 
     def set_mb(self, addr: int, *, kind: int, slice_idx: int, qp, flags: int = 0, chroma_mode: int = 0,
                i16_mode: int = 0, nz_mask: int = 0, modes=None, motion=None, pcm=None,
-               luma_dc=None, chroma_dc=None, luma_blocks=None, chroma_blocks=None) -> None:
+               luma_dc=None, chroma_dc=None, luma_blocks=None, chroma_blocks=None, lev8=None) -> None:
         m = self.mbs[addr]
         m["kind"], m["flags"], m["qp"], m["slice"] = kind, flags, qp, slice_idx
         m["dbk_slice"] = slice_idx
@@ -200,14 +200,20 @@ class PacketBuilder:
         if chroma_dc is not None:
             coded |= CODED_CHROMA_DC
             self.payload += np.asarray(chroma_dc, "<i2").reshape(8).tobytes()
+        # E264_MBF_LEV8: one byte per AC level when all of them fit (what the C emitters do, e264_emit.h:e264_flush_mb)
+        ac = [np.asarray(v) for v in list((luma_blocks or {}).values()) + list((chroma_blocks or {}).values())]
+        lev8 = bool(ac) and lev8 is not False and all(a.min() >= -128 and a.max() <= 127 for a in ac)
+        dt = "i1" if lev8 else "<i2"
+        if lev8:
+            m["flags"] = flags | MBF_LEV8
         for k in sorted(luma_blocks or {}):
             n = 64 if flags & MBF_T8x8 else 16
             assert not (flags & MBF_T8x8) or k % 4 == 0
             coded |= 1 << k
-            self.payload += np.asarray(luma_blocks[k], "<i2").reshape(n).tobytes()
+            self.payload += np.asarray(luma_blocks[k]).astype(dt).reshape(n).tobytes()
         for k in sorted(chroma_blocks or {}):
             coded |= 1 << (16 + k)
-            self.payload += np.asarray(chroma_blocks[k], "<i2").reshape(16).tobytes()
+            self.payload += np.asarray(chroma_blocks[k]).astype(dt).reshape(16).tobytes()
         m["coded"] = coded
 
     def finish(self) -> bytes:
@@ -338,8 +344,9 @@ class Packet:
         pop16 = np.array([bin(int(c) & 0xffff).count("1") for c in coded])
         pop8 = np.array([bin(int(c) & 0x1111).count("1") for c in coded])
         popc = np.array([bin(int(c) >> 16 & 0xff).count("1") for c in coded])
-        pay += np.where(coded & CODED_LUMA_DC, 32, 0) + np.where(coded & CODED_CHROMA_DC, 16, 0) + popc * 32
-        pay += np.where(t8 & (kind != MB_I16x16), pop8 * 128, pop16 * 32)
+        ac = popc * 32 + np.where(t8 & (kind != MB_I16x16), pop8 * 128, pop16 * 32)
+        pay += np.where(coded & CODED_LUMA_DC, 32, 0) + np.where(coded & CODED_CHROMA_DC, 16, 0)
+        pay += np.where((self.mbs["flags"] & MBF_LEV8) != 0, ac // 2, ac)
         pay = np.where(kind == MB_PCM, 384, pay)
         own_pred = (kind == MB_INTER) | (kind == MB_PCM)
         own_intra = (kind == MB_I4x4) | (kind == MB_I8x8) | (kind == MB_I16x16)

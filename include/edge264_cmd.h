@@ -44,7 +44,8 @@ extern "C" {
 #endif
 
 #define E264_MAGIC   0x34363245u /* "E264" little endian */
-#define E264_VERSION 3u      /* 3: motion sized by partition (a 16x16 macroblock carries one vector, not 32) */
+#define E264_VERSION 4u      /* 3: motion sized by partition (a 16x16 macroblock carries one vector, not 32);
+                                4: E264_MBF_LEV8 (one byte per AC level where they fit), E264_MBF_DONE */
 #define E264_MAX_SLOTS 32        /* DPB slots per decoder, src/edge264_internal.h:402 */
 
 /* Macroblock kinds (what the reconstruction pass has to do). */
@@ -67,6 +68,11 @@ enum {
                                      Pictures are split into several packets only around a slice that failed (src/edge264_headers.c:
                                      486-529: the reference deblocks what it decoded, conceals, and a later copy of the slice decodes
                                      the macroblocks again on top) */
+
+#define E264_MBF_LEV8        0x20 /* every level of the macroblock's AC blocks (4x4 luma / chroma, 8x8 luma) fits a signed byte and is
+                                     stored as one: 16 / 64 bytes per block instead of 32 / 128.  The DC blocks stay int16.  (Almost
+                                     every macroblock of a real stream: the coefficient payload, the largest part of a packet that
+                                     crosses PCIe, halves.) */
 
 /* E264Mb.coded bit positions */
 #define E264_CODED_LUMA(k)    (1u << (k))        /* k = 4x4 block 0..15 in zig order; for T8x8 only k=0,4,8,12 */
@@ -147,6 +153,7 @@ typedef struct E264Mb { /* 32 bytes, one per macroblock in raster order */
  *   coded & CHROMA_DC : int16_t[8]   (c[0..7]  at transform_dc2x2, Cb/Cr interleaved)
  *   luma blocks   : T8x8 ? int16_t[64] per coded 8x8 (bits 0,4,8,12) : int16_t[16] per coded 4x4
  *   chroma blocks : int16_t[16] per coded block k=0..7
+ * With E264_MBF_LEV8 the luma and chroma blocks are int8_t[64] / int8_t[16].
  */
 /* Motion of one macroblock in EXPANDED form (what mb->refPic / refIdx / mvs hold in the reference,
  * src/edge264_internal.h:139-142): the in-memory form of emitters, checkers and tools.  Packets carry the compact
@@ -252,13 +259,14 @@ static inline uint32_t e264_mb_payload_bytes(const E264Mb *m)
 	if (m->kind == E264_MB_PCM) n += 384;
 	if (m->coded & E264_CODED_LUMA_DC) n += 32;
 	if (m->coded & E264_CODED_CHROMA_DC) n += 16;
+	uint32_t ac = 0;
 	if (m->flags & E264_MBF_T8x8) {
-		for (int b = 0; b < 4; b++) n += (m->coded >> (b * 4) & 1) * 128;
+		for (int b = 0; b < 4; b++) ac += (m->coded >> (b * 4) & 1) * 128;
 	} else {
-		n += (uint32_t)__builtin_popcount(m->coded & 0xffff) * 32;
+		ac += (uint32_t)__builtin_popcount(m->coded & 0xffff) * 32;
 	}
-	n += (uint32_t)__builtin_popcount(m->coded >> 16 & 0xff) * 32;
-	return n;
+	ac += (uint32_t)__builtin_popcount(m->coded >> 16 & 0xff) * 32;
+	return n + ((m->flags & E264_MBF_LEV8) ? ac >> 1 : ac);
 }
 
 /* the layout is an ABI shared by C (front end), HIP (back end) and numpy (edge264_amd/packet.py) */

@@ -726,6 +726,15 @@ static void recon_mb(const Frame *f, int mbx, int mby)
 	if (m->coded & E264_CODED_LUMA_DC) { ldc = (const int16_t *)pl; pl += 32; }
 	if (m->coded & E264_CODED_CHROMA_DC) { cdc = (const int16_t *)pl; pl += 16; }
 	const int16_t *co = (const int16_t *)pl;
+	int16_t wide[384]; /* E264_MBF_LEV8: the AC blocks arrive as bytes (edge264_cmd.h) */
+	if (m->flags & E264_MBF_LEV8) {
+		E264Mb dense = *m;
+		dense.flags &= (uint8_t)~E264_MBF_LEV8;
+		dense.coded &= ~(E264_CODED_LUMA_DC | E264_CODED_CHROMA_DC);
+		int n = (int)e264_mb_payload_bytes(&dense) / 2;
+		for (int i = 0; i < n; i++) wide[i] = (int8_t)pl[i];
+		co = wide;
+	}
 	int inter = m->kind == E264_MB_INTER;
 	int t8 = m->flags & E264_MBF_T8x8;
 

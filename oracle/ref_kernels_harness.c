@@ -171,6 +171,17 @@ EXPORT int ref_replay_packet(RefHarness *h, const uint8_t *pkt, size_t bytes, ui
 				if (m->coded & E264_CODED_LUMA_DC) { ldc = (const int16_t *)pl; pl += 32; }
 				if (m->coded & E264_CODED_CHROMA_DC) { cdc = (const int16_t *)pl; pl += 16; }
 				const int16_t *co = (const int16_t *)pl;
+				int16_t wide[384]; /* E264_MBF_LEV8: the AC blocks arrive as bytes (edge264_cmd.h) */
+				if (m->flags & E264_MBF_LEV8) {
+					E264Mb dense = *m;
+					dense.flags &= (uint8_t)~E264_MBF_LEV8;
+					dense.coded &= ~(E264_CODED_LUMA_DC | E264_CODED_CHROMA_DC);
+					int n = (int)e264_mb_payload_bytes(&dense) / 2;
+					for (int i = 0; i < n; i++) wide[i] = (int8_t)pl[i];
+					co = wide;
+				}
+				if (m->flags & E264_MBF_DONE)
+					continue;
 				size_t sY = fh->stride_Y;
 				i16x8 clip = ctx->t.samples_clip_v[0];
 

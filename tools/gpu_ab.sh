@@ -15,7 +15,7 @@ try:
 except Exception as e:
     print(sys.argv[2], 'FAILED', e)" $1 $2; }
 timeout 300 python bench.py --no-cpu-baseline --no-host-packets $BENCH_ARGS > $OUT/bench_main.json 2> $OUT/bench_main.err; summ $OUT/bench_main.json main
-for lib in edge264_amd/variants/*.so; do
+for lib in $(ls edge264_amd/variants/*.so 2>/dev/null); do
   n=$(basename $lib .so)
   E264_HIP_LIB=$REPO/$lib timeout 300 python bench.py --no-cpu-baseline --no-host-packets $BENCH_ARGS > $OUT/bench_$n.json 2> $OUT/bench_$n.err; summ $OUT/bench_$n.json $n
 done
@@ -27,4 +27,14 @@ timeout 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_A
 cd $REPO
 python tools/pmc_summary.py $(find $OUT/bench_WR $OUT/bench_RD $OUT/sq1 -name '*.db') --traffic $OUT/hbm_traffic.json --streams 256 --gop IPPPPPPP > $OUT/pmc.txt 2>&1; grep -v "LEVEL\|_DRAM" $OUT/pmc.txt
 find $OUT -name '*.db' -size +20M -delete
+fi
+# capture bench (packets of a real bitstream through the reference's parser): resident and PCIe-inclusive rates
+if [ -n "$CAPTURE" ]; then
+python tools/make_capture.py tests/golden/streams/hd1080_ipp30.264 /tmp/hd1080_ipp30.e264 > $OUT/capture.log 2>&1
+timeout 600 python bench.py --capture /tmp/hd1080_ipp30.e264 --no-cpu-baseline --steps 2 > $OUT/bench_capture.json 2> $OUT/bench_capture.err
+python -c "
+import json; c=json.load(open('$OUT/bench_capture.json')); print('capture', c['value'], c['bit_exact'], c['pcie_inclusive'])"
+timeout 300 python bench.py --no-cpu-baseline --no-other-configs --no-verify > $OUT/bench_pcie.json 2> $OUT/bench_pcie.err
+python -c "
+import json; c=json.load(open('$OUT/bench_pcie.json')); print('synthetic', c['value'], c['pcie_inclusive'])"
 fi
