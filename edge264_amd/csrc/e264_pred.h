@@ -625,8 +625,29 @@ E264_DEV void pred_phase_items(PredLds &L, const FrameCtx &f, const PredTile &t,
 	int n = 0;
 #pragma unroll
 	for (int c = 0; c < 6; c++) n += L.cnt[c];
+	// The sorted list is walked from its END (the two-dimensional classes first): when the tile has more items than
+	// threads, the extra pass that only the first waves make -- while the others wait at the barrier -- then holds the
+	// cheapest items (integer and one-dimensional positions) instead of the most expensive ones.
+#ifndef E264_PRED_CLASS_PACKED
+	// Every class starts at a wave boundary: a wave runs ONE of the six flows (packed back to back, a wave of a 256-thread tile
+	// straddles two classes more often than not and executes both: 418 M instead of 348 M VALU wave-instructions per launch,
+	// profiles/r03_pmc_sq_instruction_mix.txt).  More partly filled waves, fewer instructions: 1.380 -> 1.312 ms.
+	int np = 0;
+#pragma unroll
+	for (int c = 0; c < 6; c++) np += (L.cnt[c] + 63) & ~63;
+	for (int p = tid; p < np; p += PT_NT) {
+		int cls = 5, idx = p;
+#pragma unroll
+		for (int c = 5; c > 0; c--) { // expensive classes first
+			const int k = (L.cnt[c] + 63) & ~63;
+			if (cls == c && idx >= k) { cls = c - 1; idx -= k; }
+		}
+		if (idx < L.cnt[cls])
+			pred_item(L, f, t, list, cls, *pred_list_slot(L, cls, idx));
+	}
+#else // -DE264_PRED_CLASS_PACKED: the lists back to back (round 2)
 	for (int p = tid; p < n; p += PT_NT) {
-		int cls = 0, idx = p;
+		int cls = 0, idx = n - 1 - p;
 #pragma unroll
 		for (int c = 0; c < 5; c++) {
 			const int k = L.cnt[c];
@@ -634,6 +655,7 @@ E264_DEV void pred_phase_items(PredLds &L, const FrameCtx &f, const PredTile &t,
 		}
 		pred_item(L, f, t, list, cls, *pred_list_slot(L, cls, idx));
 	}
+#endif
 }
 E264_DEV void pred_phase_reset(PredLds &L, int tid)
 {

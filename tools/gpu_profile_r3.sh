@@ -1,0 +1,43 @@
+#!/bin/bash
+# One GPU-box visit that produces everything profiles/r03_* is made of: the GPU tests, the default bench line, the rocprofv3
+# kernel trace of the same command, the HBM-side PMC passes (reads / writes in separate passes, no trace domain beside
+# them), the SQ instruction mix, the capture bench, the staging microbenchmark.   bash tools/gpu_profile_r3.sh TAG
+TAG=${1:-r03}
+REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/pytest_gpu.log
+timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
+B="python $REPO/bench.py --no-cpu-baseline --no-verify --no-other-configs --no-host-packets"
+cd /tmp
+timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_kt -- $B > $OUT/bench_kt.json 2> $OUT/bench_kt.err; echo "kt rc=$?"
+timeout 400 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B -d $OUT/pmc_rd -- $B --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_rd.err; echo "rd rc=$?"
+timeout 400 rocprofv3 --pmc TCC_EA0_WRREQ TCC_EA0_WRREQ_64B -d $OUT/pmc_wr -- $B --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_wr.err; echo "wr rc=$?"
+timeout 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM -d $OUT/pmc_sq -- $B --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_sq.err; echo "sq rc=$?"
+cd $REPO
+python tools/make_capture.py tests/golden/streams/hd1080_ipp30.264 /tmp/hd1080_ipp30.e264 > $OUT/capture.log 2>&1
+timeout 600 python bench.py --capture /tmp/hd1080_ipp30.e264 --no-cpu-baseline --steps 2 > $OUT/bench_capture.json 2> $OUT/bench_capture.err; echo "capture rc=$?"
+python tools/rocprof_summary.py $(find $OUT/prof_kt -name '*.db' | head -1) > $OUT/kernel_stats.txt 2>&1; cat $OUT/kernel_stats.txt
+python tools/pmc_summary.py $(find $OUT/pmc_rd $OUT/pmc_wr -name '*.db') --traffic $OUT/hbm_traffic.json --streams 256 --gop IPPPPPPP > $OUT/pmc_hbm_requests.txt 2>&1
+python tools/pmc_summary.py $(find $OUT/pmc_sq -name '*.db') > $OUT/pmc_sq_instruction_mix.txt 2>&1
+find $OUT -name '*.db' -size +20M -delete
+python -c "
+import json; d=json.load(open('$OUT/bench_default.json')); print(d['value'], d['bit_exact'], d['roofline']['kernel'], d['roofline']['frac'], d['roofline']['end_to_end'], {k.split('_')[1]: v['ms_per_launch'] for k,v in d['roofline']['kernels'].items()}); print(d['cpu_baseline']['value'], d['cpu_baseline']['per_core'], d['cpu_baseline']['single_process']); print(d['pcie_inclusive']); print(d['other_configs'])
+c=json.load(open('$OUT/bench_capture.json')); print('capture', c['value'], c['bit_exact'], c['pcie_inclusive'])"
+python -c "
+import json; t=json.load(open('$OUT/hbm_traffic.json')); print({k: (round(v['read_bytes']/1e9,3), round(v['write_bytes']/1e9,3)) for k,v in t['kernels'].items()})"
+# A/B of library variants left in edge264_amd/variants
+for lib in $(ls edge264_amd/variants/*.so 2>/dev/null); do
+  n=$(basename $lib .so)
+  E264_HIP_LIB=$REPO/$lib timeout 300 $B > $OUT/bench_$n.json 2> $OUT/bench_$n.err
+  python -c "
+import json; d=json.load(open('$OUT/bench_$n.json')); print('$n', d['value'], {k.split('_')[1]: v['ms_per_launch'] for k,v in d['roofline']['kernels'].items()})"
+done
+timeout 300 $B > $OUT/bench_main2.json 2> $OUT/bench_main2.err
+python -c "
+import json; d=json.load(open('$OUT/bench_main2.json')); print('main(again)', d['value'], {k.split('_')[1]: v['ms_per_launch'] for k,v in d['roofline']['kernels'].items()})"
+# the multi-stream driver end to end (reference parser + emitters + GPU)
+if [ -x edge264_amd/e264_multi ]; then
+  M="./edge264_amd/e264_multi --front edge264_amd/libedge264_hipfront.so --hip edge264_amd/libedge264_hip.so"
+  S="tests/golden/streams/hd1080_ipp30.264 tests/golden/streams/cabac_hd1080_ibbp30.264"
+  { echo "e264_multi 128 streams, 64 threads, no read-back"; timeout 300 $M --threads 64 --repeat 64 --loops 4 --no-download $S; } > $OUT/multi.txt 2>&1; tail -5 $OUT/multi.txt
+fi
