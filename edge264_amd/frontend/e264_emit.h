@@ -2,7 +2,7 @@
  * e264_emit.h -- the reference-side half of the drop-in boundary.
  *
  * This header is compiled INSIDE the reference's translation unit (the farm built by
- * oracle/Makefile makes `#include "edge264_inter.c"` etc. of src/edge264_headers.c:3-8
+ * edge264_amd/frontend/Makefile makes `#include "edge264_inter.c"` etc. of src/edge264_headers.c:3-8
  * resolve to emit_*.c of this directory), exactly like the reference's own ISA variants
  * are built by recompiling edge264_headers.c (Makefile:322-329).  The four sample-kernel
  * files are replaced by EMITTERS with the same static signatures
