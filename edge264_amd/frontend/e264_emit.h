@@ -32,13 +32,17 @@ typedef struct {
 	int width_mbs, height_mbs, n_mbs;
 	int frame_id;
 	E264Mb *mbs;
-	E264Motion *motion;
 	uint16_t *dbk_slice;  /* per macroblock: slice entry whose task called deblock_mb on it (0xffff: none yet) */
 	uint8_t *state;       /* per macroblock, pictures sent in several packets (a slice failed): E264_ST_* */
 	uint8_t *fedges;      /* per macroblock: mb->filter_edges as deblock_mb found it (the emitter clears it like the reference) */
 	int multi;            /* a packet of this picture has already been sent, or a macroblock was decoded twice */
-	uint8_t *mot;         /* scratch of e264_finish_frame: the compact motion records */
-	size_t mot_cap;
+	int n_flushed;        /* records written by e264_flush_mb since the builder was reset (every macroblock once: no I_PCM to look for) */
+	int n_lifted;         /* I_PCM records lifted from the host mirror */
+	uint8_t *mot;         /* the compact motion records of the picture, appended macroblock by macroblock (edge264_cmd.h) */
+	size_t mot_len, mot_cap;
+	uint32_t ref_slots;   /* DPB slots the records refer to (exact while every macroblock is written once: !multi) */
+	uint64_t recip_w1;    /* 2^40 / (width_mbs + 1), rounded up: row of a macroblock from its index in the parser's array */
+	uint32_t recip_sY, recip_sC; /* 2^32 / stride, rounded up: row of a sample inside a macroblock */
 	E264SliceParams *slices;
 	int *slice_serial;  /* decode_NAL serial of each slice entry */
 	uint8_t *slice_filled;
@@ -58,6 +62,8 @@ typedef struct { /* macroblock being assembled: leaf calls arrive in decoding or
 	uint8_t modes[16];
 	uint32_t coded;
 	int serial; /* NAL serial of the slice that staged this macroblock */
+	unsigned wide; /* OR of (level + 128) & 0xff00 over the AC levels staged so far: 0 <=> every one fits a signed byte */
+	const uint8_t *ybase, *cbase; /* first luma / Cb sample of the macroblock in the host mirror (intra leaves only get a pointer) */
 	int16_t luma_dc[16], chroma_dc[8];
 	int16_t luma[16][16];   /* 4x4 blocks, or 4 x 64 coefficients of 8x8 blocks (flat view) */
 	int16_t chroma[8][16];
@@ -71,6 +77,7 @@ typedef struct E264Emitter {
 	E264MbStage cur;
 	int serial;         /* incremented by the API wrapper before every NAL: one slice per serial */
 	int cabac_of_serial;
+	int last_slot;      /* e264_locate: the slot of the previous hit */
 	/* a slice that fails (src/edge264_headers.c:527-529) */
 	int trk_serial, trk_slot, trk_addr; /* last macroblock staged by the current NAL: addresses only grow inside a slice ... */
 	int recover_serial;                 /* ... until recover_slice walks it again from first_mb_in_slice (P_Skip / B_Skip
@@ -95,9 +102,15 @@ static inline int16_t e264_sat16(int32_t v) { return v < -32768 ? -32768 : v > 3
 /* which DPB slot / plane position does a sample pointer belong to */
 static int e264_locate(E264Emitter *e, const uint8_t *p, size_t *off)
 {
-	for (int s = 0; s < E264_MAX_SLOTS; s++) {
+	int s = e->last_slot; /* nearly every call is for the picture being decoded */
+	if ((size_t)(p - e->slot[s].samples) < e->slot[s].samples_size && e->slot[s].samples) {
+		*off = (size_t)(p - e->slot[s].samples);
+		return s;
+	}
+	for (s = 0; s < E264_MAX_SLOTS; s++) {
 		if (e->slot[s].samples && p >= e->slot[s].samples && p < e->slot[s].samples + e->slot[s].samples_size) {
 			*off = (size_t)(p - e->slot[s].samples);
+			e->last_slot = s;
 			return s;
 		}
 	}
@@ -115,24 +128,24 @@ static E264FrameBuilder *e264_builder(E264Emitter *e, int slot)
 		b->active = 0;
 	if (!b->active) {
 		if (b->n_mbs != w * h) {
-			free(b->mbs); free(b->motion); free(b->dbk_slice); free(b->state); free(b->fedges);
+			free(b->mbs); free(b->dbk_slice); free(b->state); free(b->fedges);
 			b->dbk_slice = malloc(sizeof(uint16_t) * (size_t)(w * h));
 			b->state = malloc((size_t)(w * h));
 			b->fedges = malloc((size_t)(w * h));
 			b->mbs = malloc(sizeof(E264Mb) * (size_t)(w * h));
-			b->motion = malloc(sizeof(E264Motion) * (size_t)(w * h));
 		}
 		b->width_mbs = w; b->height_mbs = h; b->n_mbs = w * h;
 		memset(b->mbs, 0, sizeof(E264Mb) * (size_t)b->n_mbs);
-		memset(b->motion, 0, sizeof(E264Motion) * (size_t)b->n_mbs);
 		memset(b->dbk_slice, 0xff, sizeof(uint16_t) * (size_t)b->n_mbs);
 		memset(b->state, 0, (size_t)b->n_mbs);
 		memset(b->fedges, 0, (size_t)b->n_mbs);
 		b->multi = 0;
-		for (int i = 0; i < b->n_mbs; i++) {
-			memset(b->motion[i].refPic, -1, 8);
-			memset(b->motion[i].refIdx, -1, 8);
-		}
+		b->n_flushed = b->n_lifted = 0;
+		b->mot_len = 0;
+		b->ref_slots = 0;
+		b->recip_w1 = ((((uint64_t)1 << 40) + (uint64_t)w) / (uint64_t)(w + 1));
+		b->recip_sY = (uint32_t)((((uint64_t)1 << 32) + (uint64_t)dec->out.stride_Y - 1) / (uint64_t)dec->out.stride_Y);
+		b->recip_sC = (uint32_t)((((uint64_t)1 << 32) + (uint64_t)dec->out.stride_C - 1) / (uint64_t)dec->out.stride_C);
 		b->n_slices = 0;
 		b->payload_len = 0;
 		b->n_inter = 0;
@@ -198,17 +211,61 @@ static void e264_payload_append(E264FrameBuilder *b, const void *src, size_t n)
 	memcpy(b->payload + b->payload_len, src, n);
 	b->payload_len += n;
 }
-
-static void e264_levels_append(E264FrameBuilder *b, const int16_t *lev, int n, int narrow)
+/* room for the largest macroblock payload (816 bytes of levels / 384 of I_PCM + alignment) */
+static uint8_t *e264_payload_reserve(E264FrameBuilder *b)
 {
-	if (!narrow) { e264_payload_append(b, lev, (size_t)n * 2); return; }
-	int8_t t[64];
-	for (int i = 0; i < n; i++) t[i] = (int8_t)lev[i];
-	e264_payload_append(b, t, (size_t)n);
+	if (b->payload_len + 1024 > b->payload_cap) {
+		b->payload_cap = (b->payload_len + 1024) * 2 + 65536;
+		b->payload = realloc(b->payload, b->payload_cap);
+	}
+	size_t pad = (size_t)-(ptrdiff_t)b->payload_len & 7;
+	memset(b->payload + b->payload_len, 0, pad);
+	b->payload_len += pad;
+	return b->payload + b->payload_len;
+}
+
+/* mb->refPic / refIdx / mvs (src/edge264_internal.h:139-142) -> the compact record of edge264_cmd.h, same bytes as
+ * e264_motion_compact produces from the expanded form (tests replay the packets through the oracle and the kernels, which
+ * parse them with the header's own definitions), with the common shapes decided by block compares. */
+static uint32_t e264_motion_emit(const int8_t *refPic, const int8_t *refIdx, const int32_t *mvs, uint8_t *rec, uint32_t *mot_hdr, uint32_t *ref_slots)
+{
+	uint32_t h = 0, n = 0;
+	for (int l = 0; l < 2; l++) {
+		const int32_t *mv = mvs + l * 16;
+		uint32_t rp, ri;
+		memcpy(&rp, refPic + l * 4, 4);
+		memcpy(&ri, refIdx + l * 4, 4);
+		if (rp == 0xffffffffu)
+			continue; /* list unused */
+		if (!(rp & 0x80u) && rp == (rp & 255u) * 0x01010101u && ri == (ri & 255u) * 0x01010101u && !memcmp(mv, mv + 1, 60)) {
+			h |= 15u << (l * 4) | 1u << (8 + l);
+			rec[n] = (uint8_t)rp; rec[n + 1] = (uint8_t)ri; rec[n + 2] = rec[n + 3] = 0;
+			memcpy(rec + n + 4, mv, 4);
+			n += 8;
+			*ref_slots |= 1u << (rp & 31u);
+			continue;
+		}
+		for (int q = 0; q < 4; q++) {
+			if (refPic[l * 4 + q] < 0)
+				continue;
+			const int32_t *v = mv + q * 4;
+			const uint32_t sub = (v[0] == v[1] && v[2] == v[3]) ? (v[0] == v[2] ? 0 : 1) : (v[0] == v[2] && v[1] == v[3]) ? 2 : 3;
+			h |= 1u << (l * 4 + q) | sub << (10 + 2 * (l * 4 + q));
+			rec[n] = (uint8_t)refPic[l * 4 + q]; rec[n + 1] = (uint8_t)refIdx[l * 4 + q]; rec[n + 2] = rec[n + 3] = 0;
+			*ref_slots |= 1u << (refPic[l * 4 + q] & 31);
+			n += 4;
+			memcpy(rec + n, v, 4); n += 4;
+			if (sub == 1) { memcpy(rec + n, v + 2, 4); n += 4; }
+			else if (sub == 2) { memcpy(rec + n, v + 1, 4); n += 4; }
+			else if (sub == 3) { memcpy(rec + n, v + 1, 12); n += 12; }
+		}
+	}
+	*mot_hdr = h;
+	return n;
 }
 
 /* close the macroblock under assembly: header from the reference's own Edge264Macroblock
- * (src/edge264_internal.h:128-143), payload in the order of include/edge264_cmd.h */
+ * (src/edge264_internal.h:128-143), motion record and payload in the order of include/edge264_cmd.h */
 static void e264_flush_mb(E264Emitter *e)
 {
 	E264MbStage *c = &e->cur;
@@ -220,21 +277,27 @@ static void e264_flush_mb(E264Emitter *e)
 		return;
 	const Edge264Macroblock *M = c->mbptr;
 	E264Mb *m = &b->mbs[c->addr];
+	b->n_flushed += c->kind != E264_MB_ABSENT;
 	memset(m, 0, sizeof(*m));
 	m->kind = (uint8_t)c->kind;
 	m->qp[0] = M->QP[0]; m->qp[1] = M->QP[1]; m->qp[2] = M->QP[2];
 	m->chroma_mode = (uint8_t)c->chroma_mode;
 	m->i16_mode = (uint8_t)c->i16_mode;
-	m->slice = (uint16_t)c->slice;
-	int t8 = M->f.transform_size_8x8_flag;
-	m->flags = (uint8_t)((t8 ? E264_MBF_T8x8 : 0) | (M->filter_edges & 1 ? E264_MBF_EDGE_LEFT : 0) |
-		(M->filter_edges & 2 ? E264_MBF_EDGE_TOP : 0) | (M->filter_edges ? E264_MBF_DEBLOCK : 0));
+	m->slice = m->dbk_slice = (uint16_t)c->slice; /* dbk_slice: until deblock_mb says otherwise (emit_deblock.c) */
+	const int t8 = M->f.transform_size_8x8_flag, fe = M->filter_edges;
+	const int narrow = (c->coded & 0xffffff) != 0 && c->wide == 0; /* E264_MBF_LEV8: every AC level fits a signed byte */
+	m->flags = (uint8_t)((t8 ? E264_MBF_T8x8 : 0) | (fe & 1 ? E264_MBF_EDGE_LEFT : 0) | (fe & 2 ? E264_MBF_EDGE_TOP : 0) |
+		(fe ? E264_MBF_DEBLOCK : 0) | (narrow ? E264_MBF_LEV8 : 0));
 	/* bS=2 test reads mb->nC (deblock.c:1093-1108) after the CAVLC 8x8 broadcast (deblock.c:1094-1096),
 	 * which the reference only applies to macroblocks it deblocks */
+#ifdef __SSE2__
+	unsigned nz = (unsigned)__builtin_ia32_pmovmskb128((i8x16)(M->nC_v[0] != (i8x16){})) & 0xffffu;
+#else
 	unsigned nz = 0;
 	for (int k = 0; k < 16; k++)
 		nz |= (unsigned)(M->nC[k] != 0) << k;
-	if (t8 && M->filter_edges && !b->slices[c->slice].cabac)
+#endif
+	if (t8 && fe && nz && !b->slices[c->slice].cabac)
 		for (int q = 0; q < 4; q++)
 			if (nz >> (q * 4) & 15)
 				nz |= 15u << (q * 4);
@@ -246,40 +309,38 @@ static void e264_flush_mb(E264Emitter *e)
 		for (int q = 0; q < 4; q++)
 			m->modes[q] = c->modes[q];
 	if (c->kind == E264_MB_INTER) {
-		E264Motion *mo = &b->motion[c->addr];
-		memcpy(mo->refPic, M->refPic, 8);
-		memcpy(mo->refIdx, M->refIdx, 8);
-		memcpy(mo->mvs, M->mvs, 128);
+		if (b->mot_len + 160 > b->mot_cap) {
+			b->mot_cap = b->mot_cap * 2 + (size_t)b->n_mbs * 24 + 4096;
+			b->mot = realloc(b->mot, b->mot_cap);
+		}
+		uint32_t d[2] = {(uint32_t)b->mot_len, 0};
+		b->mot_len += e264_motion_emit(M->refPic, M->refIdx, (const int32_t *)(const void *)M->mvs, b->mot + b->mot_len, &d[1], &b->ref_slots);
+		memcpy(m->modes, d, 8);
 		b->n_inter++;
 	}
-	while (b->payload_len & 7)
-		e264_payload_append(b, "\0", 1);
-	m->payload_off = (uint32_t)b->payload_len;
 	m->coded = c->coded;
-	if (c->coded & E264_CODED_LUMA_DC) e264_payload_append(b, c->luma_dc, 32);
-	if (c->coded & E264_CODED_CHROMA_DC) e264_payload_append(b, c->chroma_dc, 16);
-	/* AC levels as bytes when every one of them fits (E264_MBF_LEV8): nearly always, and half the coefficient payload */
-	int narrow = (c->coded & 0xffffff) != 0;
-	for (int k = 0; k < 16 && narrow; k++)
-		if (c->coded >> (t8 ? k & ~3 : k) & 1)
-			for (int i = 0; i < 16; i++) narrow &= c->luma[k][i] >= -128 && c->luma[k][i] <= 127;
-	for (int k = 0; k < 8 && narrow; k++)
-		if (c->coded >> (16 + k) & 1)
-			for (int i = 0; i < 16; i++) narrow &= c->chroma[k][i] >= -128 && c->chroma[k][i] <= 127;
-	if (narrow)
-		m->flags |= E264_MBF_LEV8;
+	if (!c->coded) {
+		m->payload_off = (uint32_t)(b->payload_len & ~(size_t)7); /* nothing stored: any aligned offset inside the payload will do */
+		return;
+	}
+	uint8_t *w = e264_payload_reserve(b), *w0 = w;
+	m->payload_off = (uint32_t)b->payload_len;
+	if (c->coded & E264_CODED_LUMA_DC) { memcpy(w, c->luma_dc, 32); w += 32; }
+	if (c->coded & E264_CODED_CHROMA_DC) { memcpy(w, c->chroma_dc, 16); w += 16; }
+#define E264_PUT(src, n) do { if (narrow) { for (int i_ = 0; i_ < (n); i_++) w[i_] = (uint8_t)(int8_t)(src)[i_]; w += (n); } \
+		else { memcpy(w, (src), (size_t)(n) * 2); w += (n) * 2; } } while (0)
 	if (t8) {
 		for (int q = 0; q < 4; q++)
 			if (c->coded >> (q * 4) & 1)
-				e264_levels_append(b, &c->luma[q * 4][0], 64, narrow);
+				E264_PUT(&c->luma[q * 4][0], 64);
 	} else {
-		for (int k = 0; k < 16; k++)
-			if (c->coded >> k & 1)
-				e264_levels_append(b, c->luma[k], 16, narrow);
+		for (unsigned bits = c->coded & 0xffff; bits; bits &= bits - 1)
+			E264_PUT(c->luma[__builtin_ctz(bits)], 16);
 	}
-	for (int k = 0; k < 8; k++)
-		if (c->coded >> (16 + k) & 1)
-			e264_levels_append(b, c->chroma[k], 16, narrow);
+	for (unsigned bits = c->coded >> 16 & 0xff; bits; bits &= bits - 1)
+		E264_PUT(c->chroma[__builtin_ctz(bits)], 16);
+#undef E264_PUT
+	b->payload_len += (size_t)(w - w0);
 }
 
 /* make (slot, addr) the macroblock under assembly */
@@ -326,13 +387,16 @@ static E264MbStage *e264_touch(E264Emitter *e, int slot, int addr)
 static E264MbStage *e264_touch_ctx(Edge264Context *ctx)
 {
 	E264Emitter *e = e264_tls_emitter;
+	E264MbStage *c = &e->cur;
+	if (c->valid && c->mbptr == ctx->_mb && c->serial == e->serial)
+		return c; /* the macroblock under assembly (most calls: one per coded block) */
 	size_t off;
 	int slot = e264_locate(e, ctx->samples_mb[0], &off);
 	if (slot < 0)
 		return NULL;
 	/* the position, not ctx->CurrMbAddr: recover_slice walks mbx / mby / samples_mb back over the failed slice while
 	 * CurrMbAddr stays where the error was found (src/edge264_headers.c:297-305, 414-428) */
-	E264MbStage *c = e264_touch(e, slot, ctx->mbx + ctx->mby * ctx->t.pic_width_in_mbs);
+	c = e264_touch(e, slot, ctx->mbx + ctx->mby * ctx->t.pic_width_in_mbs);
 	if (c)
 		e264_fill_slice(e, &e->fb[slot], c->slice, ctx);
 	return c;
@@ -342,24 +406,47 @@ static E264MbStage *e264_touch_ctx(Edge264Context *ctx)
 static E264MbStage *e264_touch_ptr(const uint8_t *p, int *x_in_mb, int *y_in_mb, int *plane)
 {
 	E264Emitter *e = e264_tls_emitter;
+	Edge264Decoder *dec = e->dec;
+	E264MbStage *c = &e->cur;
+	if (c->valid && c->serial == e->serial && c->ybase) { /* inside the macroblock under assembly?  (no division: rows by reciprocal) */
+		const E264FrameBuilder *b = &e->fb[c->slot];
+		size_t d = (size_t)(p - c->ybase);
+		if (d < (size_t)dec->out.stride_Y * 16) {
+			unsigned y = (unsigned)(((uint64_t)d * b->recip_sY) >> 32), x = (unsigned)(d - (size_t)y * dec->out.stride_Y);
+			if (x < 16) { *plane = 0; *x_in_mb = (int)x; *y_in_mb = (int)y; return c; }
+		}
+		d = (size_t)(p - c->cbase);
+		if (d < (size_t)dec->out.stride_C * 8) {
+			unsigned y = (unsigned)(((uint64_t)d * b->recip_sC) >> 32), x = (unsigned)(d - (size_t)y * dec->out.stride_C);
+			const unsigned half = (unsigned)dec->out.stride_C >> 1;
+			if (x < 8) { *plane = 1; *x_in_mb = (int)x; *y_in_mb = (int)y; return c; }
+			if (x - half < 8) { *plane = 2; *x_in_mb = (int)(x - half); *y_in_mb = (int)y; return c; }
+		}
+	}
 	size_t off;
 	int slot = e264_locate(e, p, &off);
 	if (slot < 0)
 		return NULL;
-	Edge264Decoder *dec = e->dec;
-	int x, y;
+	int x, y, mbx, mby;
 	if (off < (size_t)dec->plane_size_Y) {
 		*plane = 0;
 		y = (int)(off / (size_t)dec->out.stride_Y); x = (int)(off % (size_t)dec->out.stride_Y);
 		*x_in_mb = x & 15; *y_in_mb = y & 15;
-		return e264_touch(e, slot, (y >> 4) * dec->sps.pic_width_in_mbs + (x >> 4));
+		mbx = x >> 4; mby = y >> 4;
+	} else {
+		off -= (size_t)dec->plane_size_Y;
+		y = (int)(off / (size_t)dec->out.stride_C); x = (int)(off % (size_t)dec->out.stride_C);
+		*plane = 1 + (x >= (dec->out.stride_C >> 1));
+		x %= dec->out.stride_C >> 1;
+		*x_in_mb = x & 7; *y_in_mb = y & 7;
+		mbx = x >> 3; mby = y >> 3;
 	}
-	off -= (size_t)dec->plane_size_Y;
-	y = (int)(off / (size_t)dec->out.stride_C); x = (int)(off % (size_t)dec->out.stride_C);
-	*plane = 1 + (x >= (dec->out.stride_C >> 1));
-	x %= dec->out.stride_C >> 1;
-	*x_in_mb = x & 7; *y_in_mb = y & 7;
-	return e264_touch(e, slot, (y >> 3) * dec->sps.pic_width_in_mbs + (x >> 3));
+	c = e264_touch(e, slot, mby * dec->sps.pic_width_in_mbs + mbx);
+	if (c && !c->ybase) {
+		c->ybase = e->slot[slot].samples + (size_t)(mby * 16) * dec->out.stride_Y + mbx * 16;
+		c->cbase = e->slot[slot].samples + dec->plane_size_Y + (size_t)(mby * 8) * dec->out.stride_C + mbx * 8;
+	}
+	return c;
 }
 
 /* ---- helpers referenced by the reference's error concealment (recover_slice, src/edge264_headers.c:295-430),

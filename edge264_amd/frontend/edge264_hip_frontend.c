@@ -242,10 +242,15 @@ static void e264_lift_pcm(E264Emitter *e, int slot)
 	Edge264Decoder *dec = e->dec;
 	if (!b->active)
 		return;
+	if (!b->multi && b->n_flushed >= b->n_mbs)
+		return; /* every macroblock of the picture issued leaf calls exactly once: none is I_PCM (the usual case; the scan
+		         * below reads 304 bytes of parser state per macroblock) */
 	int flip = dec->frame_flip_bits >> slot & 1;
 	const Edge264Macroblock *mbs = e->slot[slot].mbs;
 	for (int a = 0; a < b->n_mbs; a++) {
 		E264Mb *m = &b->mbs[a];
+		if (m->kind != E264_MB_ABSENT && !(b->state[a] & E264_ST_ERR))
+			continue;
 		const Edge264Macroblock *M = mbs + a % b->width_mbs + (a / b->width_mbs) * (b->width_mbs + 1);
 		if ((b->state[a] & E264_ST_ERR) && M->recovery_bits == flip) {
 			/* marked erroneous by recover_slice, decoded again since, and no leaf call has started a new record (e264_touch
@@ -256,6 +261,7 @@ static void e264_lift_pcm(E264Emitter *e, int slot)
 		}
 		if (m->kind == E264_MB_ABSENT && !(b->state[a] & E264_ST_RECON) && M->recovery_bits == flip && !M->mbIsInterFlag) {
 			m->kind = E264_MB_PCM;
+			b->n_lifted++;
 			m->qp[0] = M->QP[0]; m->qp[1] = M->QP[1]; m->qp[2] = M->QP[2];
 			const int fe = b->dbk_slice[a] != 0xffff ? b->fedges[a] : M->filter_edges; /* deblock_mb has cleared what it filtered */
 			m->flags = (uint8_t)((fe & 1 ? E264_MBF_EDGE_LEFT : 0) | (fe & 2 ? E264_MBF_EDGE_TOP : 0) | (fe ? E264_MBF_DEBLOCK : 0));
@@ -263,6 +269,7 @@ static void e264_lift_pcm(E264Emitter *e, int slot)
 			m->slice = 0;
 			for (int i = b->n_slices - 1; i >= 0; i--)
 				if (b->slices[i].first_mb <= (uint32_t)a && b->slice_filled[i]) { m->slice = (uint16_t)i; break; }
+			m->dbk_slice = b->dbk_slice[a] != 0xffff ? b->dbk_slice[a] : m->slice;
 			while (b->payload_len & 7)
 				e264_payload_append(b, "\0", 1);
 			m->payload_off = (uint32_t)b->payload_len;
@@ -294,17 +301,27 @@ static int e264_finish_frame(E264Emitter *e, int slot, int partial)
 	if (e->cur.valid && e->cur.slot == slot)
 		e264_flush_mb(e);
 	e264_lift_pcm(e, slot);
-	int n_coded = 0;
-	for (int a = 0; a < b->n_mbs; a++) {
-		E264Mb *m = &b->mbs[a];
-		n_coded += m->kind != E264_MB_ABSENT;
-		m->dbk_slice = b->dbk_slice[a] != 0xffff ? b->dbk_slice[a] : m->slice;
+	/* what the header says about the records (e264hip_packet_check holds it against them).  Every macroblock written once:
+	 * counted as they were closed.  A picture with a failed slice (records superseded, motion records orphaned): counted here. */
+	int n_coded = b->n_flushed + b->n_lifted, n_inter = b->n_inter;
+	uint32_t ref_slots = b->ref_slots;
+	if (b->multi) {
+		n_coded = n_inter = 0;
+		ref_slots = 0;
+		for (int a = 0; a < b->n_mbs; a++) {
+			const E264Mb *m = &b->mbs[a];
+			n_coded += m->kind != E264_MB_ABSENT;
+			if (m->kind != E264_MB_INTER)
+				continue;
+			n_inter++;
+			uint32_t d[2];
+			E264Motion mx;
+			memcpy(d, m->modes, 8);
+			e264_motion_expand(d[1], b->mot + d[0], &mx);
+			for (int i = 0; i < 8; i++)
+				if (mx.refPic[i] >= 0) ref_slots |= 1u << mx.refPic[i];
+		}
 	}
-	/* counted from the final records: a macroblock decoded again by a resent slice is one macroblock (the intra kernel's
-	 * early exit compares these two numbers) */
-	b->n_inter = 0;
-	for (int a = 0; a < b->n_mbs; a++)
-		b->n_inter += b->mbs[a].kind == E264_MB_INTER;
 	if (b->n_slices == 0) { /* cannot happen for a decoded frame; keep the packet well formed */
 		int serial = e->serial;
 		e->serial = -1;
@@ -318,22 +335,7 @@ static int e264_finish_frame(E264Emitter *e, int slot, int partial)
 		if (!dirty)
 			return 0;
 	}
-	/* motion sized by partition (edge264_cmd.h): compact records of the inter macroblocks, their directory in E264Mb.modes */
-	uint32_t motion_bytes = 0;
-	if (b->n_inter) {
-		if (b->mot_cap < (size_t)b->n_inter * 160) {
-			free(b->mot);
-			b->mot_cap = (size_t)b->n_inter * 160;
-			b->mot = malloc(b->mot_cap);
-			if (!b->mot) { b->mot_cap = 0; return ENOMEM; }
-		}
-		for (int a = 0; a < b->n_mbs; a++)
-			if (b->mbs[a].kind == E264_MB_INTER) {
-				uint32_t d[2] = {motion_bytes, 0};
-				motion_bytes += e264_motion_compact(&b->motion[a], b->mot + motion_bytes, &d[1]);
-				memcpy(b->mbs[a].modes, d, 8);
-			}
-	}
+	const uint32_t motion_bytes = n_inter ? (uint32_t)b->mot_len : 0;
 	/* layout: hdr | slices | mbs | motion records (if any inter MB) | payload */
 	uint32_t slices_off = E264_ALIGN16((uint32_t)sizeof(E264FrameHdr));
 	uint32_t mbs_off = E264_ALIGN16(slices_off + (uint32_t)sizeof(E264SliceParams) * (uint32_t)b->n_slices);
@@ -352,20 +354,16 @@ static int e264_finish_frame(E264Emitter *e, int slot, int partial)
 	h.stride_Y = (uint32_t)dec->out.stride_Y; h.stride_C = (uint32_t)dec->out.stride_C;
 	h.plane_size_Y = (uint32_t)dec->plane_size_Y; h.plane_size_C = (uint32_t)dec->plane_size_C;
 	h.n_slices = (uint32_t)b->n_slices; h.slices_off = slices_off; h.mbs_off = mbs_off;
-	h.motion_off = b->n_inter ? motion_off : 0;
+	h.motion_off = n_inter ? motion_off : 0;
 	h.payload_off = payload_off; h.payload_bytes = payload_bytes;
 	h.dst_slot = slot; h.frame_id = b->frame_id;
-	h.n_coded_mbs = (uint32_t)n_coded; h.n_inter_mbs = (uint32_t)b->n_inter;
-	for (int a = 0; a < b->n_mbs; a++)
-		if (b->mbs[a].kind == E264_MB_INTER)
-			for (int i = 0; i < 8; i++)
-				if (b->motion[a].refPic[i] >= 0)
-					h.ref_slots |= 1u << b->motion[a].refPic[i];
+	h.n_coded_mbs = (uint32_t)n_coded; h.n_inter_mbs = (uint32_t)n_inter;
+	h.ref_slots = ref_slots;
 	memset(pkt, 0, payload_off);
 	memcpy(pkt, &h, sizeof(h));
 	memcpy(pkt + slices_off, b->slices, sizeof(E264SliceParams) * (size_t)b->n_slices);
 	memcpy(pkt + mbs_off, b->mbs, sizeof(E264Mb) * (size_t)b->n_mbs);
-	if (b->n_inter)
+	if (motion_bytes)
 		memcpy(pkt + motion_off, b->mot, motion_bytes);
 	memcpy(pkt + payload_off, b->payload, b->payload_len);
 	memset(pkt + payload_off + b->payload_len, 0, payload_bytes - b->payload_len);
@@ -558,7 +556,7 @@ PUBLIC void edge264_free(Edge264Decoder **pdec)
 		return;
 	if (ON_DEVICE(e)) hip.stream_close(e->hip_stream);
 	for (int s = 0; s < E264_MAX_SLOTS; s++) {
-		free(e->fb[s].mbs); free(e->fb[s].motion); free(e->fb[s].dbk_slice); free(e->fb[s].state); free(e->fb[s].fedges); free(e->fb[s].mot); free(e->fb[s].slices); free(e->fb[s].slice_serial);
+		free(e->fb[s].mbs); free(e->fb[s].dbk_slice); free(e->fb[s].state); free(e->fb[s].fedges); free(e->fb[s].mot); free(e->fb[s].slices); free(e->fb[s].slice_serial);
 		free(e->fb[s].slice_filled); free(e->fb[s].payload);
 	}
 	while (e->cap_head) {

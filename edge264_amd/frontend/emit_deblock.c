@@ -21,8 +21,10 @@ static noinline void deblock_mb(Edge264Context *ctx)
 			e264_flush_mb(e); /* the record takes its flags from filter_edges, which is cleared below */
 		int idx = e264_slice_index(e, b);
 		e264_fill_slice(e, b, idx, ctx);
-		size_t px = off >> 4, stride = (size_t)ctx->t.stride[0]; /* samples_mb[0] = base + (mbx + mby * stride) * 16 */
-		size_t mby = px / stride, mbx = px % stride;
+		/* which macroblock: from its record's place in the parser's array ((width + 1) entries per row, src/edge264_headers.c:
+		 * 114-125); the row by reciprocal, exact for any picture the reference accepts */
+		const size_t i = (size_t)(mb - (const Edge264Macroblock *)e->slot[slot].mbs);
+		const size_t mby = (size_t)(((uint64_t)i * b->recip_w1) >> 40), mbx = i - mby * (size_t)(b->width_mbs + 1);
 		if (mbx < (size_t)b->width_mbs && mby < (size_t)b->height_mbs) {
 			size_t a = mby * (size_t)b->width_mbs + mbx;
 			if ((b->state[a] & E264_ST_ERR) && mb->recovery_bits == ctx->t.frame_flip_bit) {
@@ -35,8 +37,10 @@ static noinline void deblock_mb(Edge264Context *ctx)
 			b->fedges[a] = mb->filter_edges;
 			/* the first call is the one that filters (the picture-completing pass runs over macroblocks that were deblocked
 			 * earlier without touching them) */
-			if (b->dbk_slice[a] == 0xffff)
+			if (b->dbk_slice[a] == 0xffff) {
 				b->dbk_slice[a] = (uint16_t)idx;
+				b->mbs[a].dbk_slice = (uint16_t)idx; /* (a record that does not exist yet -- I_PCM -- takes it from the array when it is lifted) */
+			}
 		}
 	}
 	mb->filter_edges = 0; /* src/edge264_deblock.c:500: a macroblock is filtered once per parse */

@@ -23,8 +23,12 @@ static noinline void add_idct4x4(Edge264Context *ctx, int iYCbCr, int DCidx, uin
 			c->coded |= E264_CODED_CHROMA(DCidx & 7);
 			dst = c->chroma[DCidx & 7];
 		}
-		for (int i = 0; i < 16; i++)
+		unsigned wide = 0;
+		for (int i = 0; i < 16; i++) {
 			dst[i] = e264_sat16(ctx->c[i]);
+			wide |= (unsigned)(dst[i] + 128) & 0xff00u; /* outside a signed byte? (E264_MBF_LEV8) */
+		}
+		c->wide |= wide;
 	}
 	ctx->c_v[0] = ctx->c_v[1] = ctx->c_v[2] = ctx->c_v[3] = (i8x16){};
 }
@@ -43,8 +47,12 @@ static void add_idct8x8(Edge264Context *ctx, int iYCbCr, uint8_t *p)
 		int k = e264_blk((int)(d % ctx->t.stride[0]), (int)(d / ctx->t.stride[0])) & ~3;
 		c->coded |= E264_CODED_LUMA(k);
 		int16_t *dst = &c->luma[k][0]; /* 64 coefficients span luma[k..k+3] */
-		for (int i = 0; i < 64; i++)
+		unsigned wide = 0;
+		for (int i = 0; i < 64; i++) {
 			dst[i] = e264_sat16(ctx->c[i]);
+			wide |= (unsigned)(dst[i] + 128) & 0xff00u;
+		}
+		c->wide |= wide;
 	}
 	for (int i = 0; i < 16; i++)
 		ctx->c_v[i] = (i8x16){};
