@@ -159,40 +159,3 @@ extern "C" __attribute__((visibility("default"))) void e264emu_dk_filter(uint8_t
 	dk_filter(v, P[dir], R);
 	for (int k = 0; k < 20; k++) { lines[k] = (uint8_t)v[k].x; lines[20 + k] = (uint8_t)v[k].y; }
 }
-
-// e264_intra_kernel: every intra macroblock of the picture in raster order (the order the waves' progress counters enforce
-// on the device), each through intra_recon_mb's phases, 64 lanes one after the other per phase.
-#include "../../edge264_amd/csrc/e264_intra.h"
-extern "C" __attribute__((visibility("default"))) int e264emu_intra_frame(const uint8_t *pkt, uint8_t *const *dpb)
-{
-	E264Job job = {pkt, dpb, nullptr};
-	FrameCtx f;
-	if (!open_frame(f, job))
-		return -1;
-	static IntraWave L;
-	static int16_t coefs[512];
-	memset(&L, 0xA5, sizeof(L));
-	L.ws_slice = -1;
-	const uint8_t *mbs_g = f.payload - f.h->payload_off + f.h->mbs_off;
-	for (int y = 0; y < f.hm; y++)
-		for (int x = 0; x < f.wm; x++) {
-			uint32_t rec[8];
-			memcpy(rec, mbs_g + (size_t)(y * f.wm + x) * sizeof(E264Mb), sizeof(rec));
-			const MbInfo m = mb_from_rec(rec);
-			if ((m.flags & E264_MBF_DONE) || !(m.kind == E264_MB_I4x4 || m.kind == E264_MB_I8x8 || m.kind == E264_MB_I16x16))
-				continue;
-			memset(coefs, 0x5A, sizeof(coefs));
-			memcpy(coefs, f.payload + m.payload_off, (size_t)coef_dwords(m) * 4); // coef_dma
-			if (L.ws_slice != m.slice) { // slice_cache
-				const E264SliceParams *s = f.slices + m.slice;
-				memcpy(L.ws, s->weightScale4x4, 96);
-				memcpy(L.ws + 96, s->weightScale8x8, 128);
-				L.ws_slice = m.slice; L.ws_idc = s->weighted_bipred_idc;
-			}
-			IrLane st[64];
-			memset(st, 0x5A, sizeof(st));
-			for (int lane = 0; lane < 64; lane++) st[lane].nb = issue_intra_neighbours(f, x, y, lane);
-			intra_recon_mb(L, f, m, x, y, c_i4tab, coefs, st);
-		}
-	return 0;
-}
