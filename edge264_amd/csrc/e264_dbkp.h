@@ -70,58 +70,68 @@ E264_DEV void dbkp_phase_slices(DbkpLds &L, const FrameCtx &f, int tid)
 	}
 }
 
-struct DbkpMo { int ref0, ref1; uint32_t mv0, mv1; };
-// motion of 4x4 block k of a record (hdr: its E264Mb dwords, mo: its E264Motion dwords); intra / absent macroblocks count
-// as "no reference, zero vector"
-E264_DEV DbkpMo dbkp_motion(const uint32_t *hdr, const uint32_t *mo, bool has_motion, int k)
+// |a - b| of both 16-bit halves at once; A, B: int16 pairs biased by 0x8000 (unsigned order), so the saturating unsigned
+// subtractions are exact for any pair of vectors
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+E264_DEV uint32_t dbkp_absdiff2(uint32_t A, uint32_t B)
 {
-	DbkpMo o = {-1, -1, 0, 0};
-	if (has_motion && (hdr[0] & 255) == E264_MB_INTER) {
-		o.ref0 = (int)(int8_t)(mo[0] >> (8 * (k >> 2)));
-		o.ref1 = (int)(int8_t)(mo[1] >> (8 * (k >> 2)));
-		o.mv0 = mo[4 + k]; o.mv1 = mo[20 + k];
-	}
-	return o;
+	const u16x2 a = __builtin_bit_cast(u16x2, A), b = __builtin_bit_cast(u16x2, B);
+	return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(a, b)) | __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(b, a));
 }
-E264_DEV int dbkp_far(uint32_t a, uint32_t b)
-{ // either component differs by 4 quarter samples or more (deblock.c:981-991)
-	const int ax = (int16_t)(a & 0xffff), ay = (int)a >> 16, bx = (int16_t)(b & 0xffff), by = (int)b >> 16;
-	const int dx = ax - bx, dy = ay - by;
-	return ((dx < 0 ? -dx : dx) >= 4) | ((dy < 0 ? -dy : dy) >= 4);
-}
-// bS of role hl = (dir, edge, segment) of macroblock m (edge264_deblock.c:958-1118); L / T: records of the left / top neighbour
-// (anything when the edge flag is off); `on`: the macroblock is deblocked at all
-E264_DEV int dbkp_bs_value(const uint32_t *hm, const uint32_t *mm, const uint32_t *hL, const uint32_t *mL, const uint32_t *hT, const uint32_t *mT,
-	bool has_motion, bool on, int hl)
+#define DBKP_FAR 0xfffcfffcu // bits of dbkp_absdiff2 that say "4 quarter samples or more" (edge264_deblock.c:981-991)
+#define DBKP_BIAS 0x80008000u
+
+// The four bS of edge e in direction dir of a macroblock, one per byte (edge264_deblock.c:958-1118).  hm / mm: the
+// macroblock's E264Mb dwords and expanded motion; L / T: the left / top neighbour's (anything when the edge flag is off);
+// `on`: the macroblock is deblocked at all.
+// Round 2 computed one bS per task (32 tasks per macroblock): neighbour selection, flags and the block numbering were
+// worked out 32 times, every vector difference in 32-bit arithmetic -- the kernel ran at the VALU issue limit (170 M
+// wave-instructions per 256 pictures, profiles/r03_pmc_sq_instruction_mix.txt).
+E264_DEV uint32_t dbkp_bs4(const uint32_t *hm, const uint32_t *mm, const uint32_t *hL, const uint32_t *mL, const uint32_t *hT, const uint32_t *mT,
+	bool has_motion, bool on, int dir, int e)
 {
-	const int dir = hl >> 4 & 1, e = hl >> 2 & 3, sg = hl & 3;
 	const uint32_t h0 = hm[0];
 	const int kind = h0 & 255, flags = h0 >> 8 & 255;
 	const bool intra = kind != E264_MB_INTER;
 	const bool has_edge = e != 0 || (flags & (dir ? E264_MBF_EDGE_TOP : E264_MBF_EDGE_LEFT));
-	const uint32_t *hn = e == 0 ? (dir ? hT : hL) : hm, *mn = e == 0 ? (dir ? mT : mL) : mm; // record holding the p side
-	const int nkind = hn[0] & 255;
-	const int kq = dir ? blk_of(sg, e) : blk_of(e, sg);
-	const int kp = dir ? blk_of(sg, (e + 3) & 3) : blk_of((e + 3) & 3, sg);
-	const int coded = ((hn[2] & 0xffff) >> kp & 1) | ((hm[2] & 0xffff) >> kq & 1);
-	const DbkpMo p = dbkp_motion(hn, mn, has_motion, kp), q = dbkp_motion(hm, mm, has_motion, kq);
-	const int refs_p = (p.ref0 != q.ref0) | (p.ref1 != q.ref1), refs_c = (p.ref0 != q.ref1) | (p.ref1 != q.ref0);
-	const int mvs_p = dbkp_far(p.mv0, q.mv0) | dbkp_far(p.mv1, q.mv1), mvs_c = dbkp_far(p.mv0, q.mv1) | dbkp_far(p.mv1, q.mv0);
-	const int bmo = (refs_p | mvs_p) & (refs_c | mvs_c);
 	const bool skip8 = e != 0 && (flags & E264_MBF_T8x8) && (e & 1);
-	int bs = coded ? 2 : bmo;
-	bs = intra ? 3 : bs;
-	bs = (e == 0 && (intra || nkind != E264_MB_INTER)) ? 4 : bs;
-	return (!on || !has_edge || skip8) ? 0 : bs;
-}
-// alpha / beta / indexA value hl (0..26; 27..31 -> 0) of macroblock m (edge264_deblock.c:945-955)
-E264_DEV int dbkp_ab_value(const uint32_t *hm, const uint32_t *hL, const uint32_t *hT, int foA, int foB, const uint8_t *alpha, const uint8_t *beta, bool on, int hl)
-{
-	if (hl >= 27 || !on)
+	if (!on || !has_edge || skip8)
 		return 0;
+	const uint32_t *hn = e == 0 ? (dir ? hT : hL) : hm, *mn = e == 0 ? (dir ? mT : mL) : mm; // record holding the p side
+	if (e == 0 && (intra || (hn[0] & 255) != E264_MB_INTER))
+		return 0x04040404u;
+	if (intra)
+		return 0x03030303u;
+	// both sides are inter macroblocks.  Blocks in zig order: q side x = e (dir 0) or y = e (dir 1), the p side one column / row before
+	const int pe = (e + 3) & 3;
+	const int qb = dir ? (e >> 1) * 8 + (e & 1) * 2 : (e >> 1) * 4 + (e & 1);
+	const int pb = dir ? (pe >> 1) * 8 + (pe & 1) * 2 : (pe >> 1) * 4 + (pe & 1);
+	const uint32_t offs = dir ? 0x5410u : 0xa820u; // + what the segment adds: x = 0..3 / y = 0..3
+	const uint32_t nzq = hm[2] & 0xffffu, nzp = hn[2] & 0xffffu;
+	uint32_t out = 0;
+#pragma unroll
+	for (int sg = 0; sg < 4; sg++) {
+		const int o = (int)(offs >> (4 * sg) & 15u), kq = qb + o, kp = pb + o;
+		uint32_t bs = ((nzp >> kp | nzq >> kq) & 1u) ? 2u : 0u;
+		if (has_motion) { // (uniform) references as bytes (unused list: 0xff), vectors biased for dbkp_absdiff2 (unused list: 0)
+			const int sq = (kq >> 2) * 8, sp = (kp >> 2) * 8;
+			const uint32_t q0 = mm[0] >> sq & 255u, q1 = mm[1] >> sq & 255u, p0 = mn[0] >> sp & 255u, p1 = mn[1] >> sp & 255u;
+			const uint32_t vq0 = mm[4 + kq] ^ DBKP_BIAS, vq1 = mm[20 + kq] ^ DBKP_BIAS, vp0 = mn[4 + kp] ^ DBKP_BIAS, vp1 = mn[20 + kp] ^ DBKP_BIAS;
+			// same lists, or crossed (deblock.c:913-925): a difference either way
+			const uint32_t par = (p0 ^ q0) | (p1 ^ q1) | ((dbkp_absdiff2(vp0, vq0) | dbkp_absdiff2(vp1, vq1)) & DBKP_FAR);
+			const uint32_t crs = (p0 ^ q1) | (p1 ^ q0) | ((dbkp_absdiff2(vp0, vq1) | dbkp_absdiff2(vp1, vq0)) & DBKP_FAR);
+			if (bs == 0) bs = (par != 0 && crs != 0) ? 1u : 0u;
+		}
+		out |= bs << (8 * sg);
+	}
+	return out;
+}
+// alpha, beta, indexA (edge264_deblock.c:945-955) of plane pl against neighbour class t = 0 internal edges, 1 left, 2 top
+E264_DEV void dbkp_ab3(const uint32_t *hm, const uint32_t *hL, const uint32_t *hT, int foA, int foB, const uint8_t *alpha, const uint8_t *beta, bool on, int pl, int t,
+	int &a, int &b, int &ia)
+{
 	const uint32_t h0 = hm[0], h1 = hm[1];
 	const int flags = h0 >> 8 & 255;
-	const int what = hl / 9, pt = hl - what * 9, pl = pt / 3, t = pt - pl * 3;
 	const uint32_t *hn = t == 0 ? hm : t == 2 ? hT : hL;
 	const uint32_t n0 = hn[0], n1 = hn[1];
 	const int qm = pl == 0 ? (int)(h0 >> 16 & 255) : pl == 1 ? (int)(h0 >> 24) : (int)(h1 & 255);
@@ -129,21 +139,35 @@ E264_DEV int dbkp_ab_value(const uint32_t *hm, const uint32_t *hL, const uint32_
 	const bool use_nb = (t == 1 && (flags & E264_MBF_EDGE_LEFT)) || (t == 2 && (flags & E264_MBF_EDGE_TOP));
 	const int qPav = (qm + (use_nb ? qn : qm) + 1) >> 1;
 	const int iA = min(max(qPav + foA, 0), 51), iB = min(max(qPav + foB, 0), 51);
-	return what == 0 ? alpha[iA] : what == 1 ? beta[iB] : iA;
+	a = on ? alpha[iA] : 0; b = on ? beta[iB] : 0; ia = on ? iA : 0;
 }
 
+// four threads per macroblock: thread r computes the bS of two (direction, edge) pairs -- 8 bytes of the record -- and, r < 3,
+// alpha / beta / indexA of plane r; r == 3 clears the tail of the record
 E264_DEV void dbkp_phase_compute(DbkpLds &L, const FrameCtx &f, int a0, int tid)
 {
 	const bool has_motion = f.motion != nullptr;
 	const int n_mbs = f.wm * f.hm;
-	uint8_t *out8 = (uint8_t *)&L.out[0][0];
-	for (int it = 0; it < DP_MBS * 32 / DP_NT; it++) {
-		const int id = it * DP_NT + tid, i = id >> 5, hl = id & 31;
-		const int rm = 1 + i, rl = i, rt = 1 + DP_MBS + i; // own record, left and top neighbours
-		const uint32_t h0 = L.hdr[rm][0];
-		const bool on = a0 + i < n_mbs && (h0 >> 8 & E264_MBF_DEBLOCK) && (h0 & 255) != E264_MB_ABSENT;
-		out8[i * 64 + hl] = (uint8_t)dbkp_bs_value(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], L.mo[rt], has_motion, on, hl);
-		out8[i * 64 + 32 + hl] = (uint8_t)dbkp_ab_value(L.hdr[rm], L.hdr[rl], L.hdr[rt], L.fo[i][0], L.fo[i][1], L.alpha, L.beta, on, hl);
+	const int i = tid >> 2, r = tid & 3;
+	const int rm = 1 + i, rl = i, rt = 1 + DP_MBS + i; // own record, left and top neighbours
+	const uint32_t h0 = L.hdr[rm][0];
+	const bool on = a0 + i < n_mbs && (h0 >> 8 & E264_MBF_DEBLOCK) && (h0 & 255) != E264_MB_ABSENT;
+	const int dir = r >> 1, e0 = (r & 1) * 2;
+	v2u bs;
+	bs.x = dbkp_bs4(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], L.mo[rt], has_motion, on, dir, e0);
+	bs.y = dbkp_bs4(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], L.mo[rt], has_motion, on, dir, e0 + 1);
+	*(v2u *)&L.out[i][2 * r] = bs;
+	uint8_t *o8 = (uint8_t *)&L.out[i][0];
+	if (r < 3) {
+#pragma unroll
+		for (int t = 0; t < 3; t++) {
+			int a, b, ia;
+			dbkp_ab3(L.hdr[rm], L.hdr[rl], L.hdr[rt], L.fo[i][0], L.fo[i][1], L.alpha, L.beta, on, r, t, a, b, ia);
+			o8[32 + r * 3 + t] = (uint8_t)a; o8[41 + r * 3 + t] = (uint8_t)b; o8[50 + r * 3 + t] = (uint8_t)ia;
+		}
+	} else {
+#pragma unroll
+		for (int k = 59; k < 64; k++) o8[k] = 0;
 	}
 }
 

@@ -59,6 +59,8 @@ CASES = [
     ("t8x8_pcm", "IPB", 7, 5, dict(t8x8=True, pcm_prob=0.2, i_kinds=(P.MB_I4x4, P.MB_I8x8, P.MB_I16x16))),
     ("no_deblock", "IP", 5, 4, dict(deblock=False)),
     ("tiny", "IPB", 1, 1, dict()),
+    ("extreme_vectors", "IPBB", 8, 5, dict(mv_range=2047, num_refs=2, p_skip=0.0)),  # differences beyond int16: the packed compare must not wrap
+    ("small_differences", "IPBB", 9, 6, dict(mv_range=3, num_refs=1, residual_prob=0.05)),  # |dx|, |dy| around the threshold of 4
 ]
 
 
