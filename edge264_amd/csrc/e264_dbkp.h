@@ -49,20 +49,55 @@ E264_DEV void dbkp_phase_load(DbkpLds &L, const FrameCtx &f, int a0, int tid)
 	if (tid < 52) { L.alpha[tid] = c_alpha[tid]; L.beta[tid] = c_beta[tid]; }
 }
 
-// after the records have landed: the motion of the inter macroblocks among them, expanded from the packet's compact
-// records into the per-4x4 form the comparisons index (one task per record, list and quadrant); slice offsets
+// One list of a macroblock's compact motion record (edge264_cmd.h E264_MOT_*) -> the per-4x4 form the comparisons index:
+// mo[l] = the four quadrants' DPB slots as bytes (0xff: unused), mo[4 + l * 16 + k] = vector of 4x4 block k (unused: 0).
+// Every offset follows from the shape word alone, so the loads do not wait for one another.
+E264_DEV void dbkp_expand_list(const gu8 *motion, uint32_t mot_off, uint32_t h, int l, uint32_t *mo)
+{
+	uint32_t off = mot_off;
+	if (l) { // skip the list-0 part
+		uint32_t n0 = 0;
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			n0 += E264_MOT_USED(h, k) ? 4 + 4 * mot_nmv(E264_MOT_SUB(h, k)) : 0;
+		off += E264_MOT_UNI(h, 0) ? 8 : n0;
+	}
+	const gu32 *rec = (const gu32 *)(motion + off);
+	uint32_t refs = 0xffffffffu;
+	v4u mv[4];
+	if (E264_MOT_UNI(h, l)) {
+		const uint32_t r = rec[0], v = rec[1];
+		refs = (r & 255u) * 0x01010101u;
+#pragma unroll
+		for (int q = 0; q < 4; q++) mv[q] = (v4u){v, v, v, v};
+	} else {
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			mv[q] = (v4u){0, 0, 0, 0};
+			if (!E264_MOT_USED(h, l * 4 + q))
+				continue;
+			const uint32_t sub = E264_MOT_SUB(h, l * 4 + q);
+			const uint32_t r = rec[0], v0 = rec[1], v1 = sub ? rec[2] : v0;
+			refs = (refs & ~(255u << (8 * q))) | (r & 255u) << (8 * q);
+			if (sub == 3) mv[q] = (v4u){v0, v1, rec[3], rec[4]};
+			else if (sub == 2) mv[q] = (v4u){v0, v1, v0, v1};
+			else mv[q] = (v4u){v0, v0, v1, v1};
+			rec += 1 + mot_nmv(sub);
+		}
+	}
+	mo[l] = refs;
+#pragma unroll
+	for (int q = 0; q < 4; q++) *(v4u *)&mo[4 + l * 16 + q * 4] = mv[q];
+}
+
+// after the records have landed: the motion of the inter macroblocks among them (one task per record and list); slice offsets
 E264_DEV void dbkp_phase_slices(DbkpLds &L, const FrameCtx &f, int tid)
 {
 	if (f.motion)
-		for (int i = tid; i < (2 * DP_MBS + 1) * 8; i += DP_NT) {
-			const int j = i >> 3, l = i >> 2 & 1, q = i & 3;
-			if ((L.hdr[j][0] & 255) != E264_MB_INTER)
-				continue;
-			uint32_t refword = 0xffffu, mv[4] = {0, 0, 0, 0};
-			mot_quadrant(f.motion, L.hdr[j][5], L.hdr[j][6], l, q, refword, mv); // unused: no reference (-1), zero vectors
-			((uint8_t *)&L.mo[j][l])[q] = (uint8_t)refword;
-#pragma unroll
-			for (int k = 0; k < 4; k++) L.mo[j][4 + l * 16 + q * 4 + k] = mv[k];
+		for (int i = tid; i < (2 * DP_MBS + 1) * 2; i += DP_NT) {
+			const int j = i >> 1, l = i & 1;
+			if ((L.hdr[j][0] & 255) == E264_MB_INTER)
+				dbkp_expand_list(f.motion, L.hdr[j][5], L.hdr[j][6], l, L.mo[j]);
 		}
 	if (tid < DP_MBS) {
 		cslice_t s = f.slices + (L.hdr[1 + tid][7] & 0xffff); // E264Mb.dbk_slice

@@ -147,6 +147,13 @@ E264_DEV s16x2 tap6u(s16x2 a, s16x2 b, s16x2 c, s16x2 d, s16x2 e, s16x2 f)
 	const s16x2 af = as_s2(as_u(a) + as_u(f)), be = as_s2(as_u(b) + as_u(e)), cd = as_s2(as_u(c) + as_u(d));
 	return be * k5 + (cd * k20 + af);
 }
+// the same + 16 (the rounding of (x + 16) >> 5), folded into the first sum: one three-operand add instead of an add and a packed add
+E264_DEV s16x2 tap6u16(s16x2 a, s16x2 b, s16x2 c, s16x2 d, s16x2 e, s16x2 f)
+{
+	const s16x2 k5 = {-5, -5}, k20 = {20, 20};
+	const s16x2 af = as_s2(as_u(a) + as_u(f) + 0x00100010u), be = as_s2(as_u(b) + as_u(e)), cd = as_s2(as_u(c) + as_u(d));
+	return be * k5 + (cd * k20 + af);
+}
 // two pairs of int16 -> 4 bytes, each clipped to 0..255 (packus)
 E264_DEV uint32_t packus4(s16x2 lo, s16x2 hi) { return v_perm(v_sat_pk_u8_i16(as_u(hi)), v_sat_pk_u8_i16(as_u(lo)), 0x05040100u); }
 E264_DEV s16x2 tap6p(s16x2 a, s16x2 b, s16x2 c, s16x2 d, s16x2 e, s16x2 f)

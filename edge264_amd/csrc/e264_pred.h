@@ -307,13 +307,18 @@ E264_DEV void gcols(const Row4 &a, uint32_t dx, uint32_t g[2])
 // b of one aligned row: 8 horizontal half samples, clipped, as bytes
 E264_DEV void brow(const Row4 &a, uint32_t b[2])
 {
-	s16x2 T[4];
-	htaps8(a, T);
-	b[0] = packus4(rs5(T[0]), rs5(T[1])); b[1] = packus4(rs5(T[2]), rs5(T[3]));
+	const s16x2 s5 = {5, 5};
+	s16x2 Q[12], T[4];
+	pairs12(a, Q);
+#pragma unroll
+	for (int p = 0; p < 4; p++)
+		T[p] = tap6u16(Q[2 * p], Q[2 * p + 1], Q[2 * p + 2], Q[2 * p + 3], Q[2 * p + 4], Q[2 * p + 5]) >> s5;
+	b[0] = packus4(T[0], T[1]); b[1] = packus4(T[2], T[3]);
 }
 // h of one output row from six rows of byte columns
 E264_DEV void hrow(const uint32_t g[][2], int j, uint32_t h[2])
 {
+	const s16x2 s5 = {5, 5};
 	s16x2 V[4];
 #pragma unroll
 	for (int p = 0; p < 4; p++) {
@@ -322,7 +327,7 @@ E264_DEV void hrow(const uint32_t g[][2], int j, uint32_t h[2])
 #pragma unroll
 		for (int k = 0; k < 6; k++)
 			c[k] = (p & 1) ? pair_at<2>(0, g[j + k][w]) : pair_at<0>(0, g[j + k][w]);
-		V[p] = rs5(tap6u(c[0], c[1], c[2], c[3], c[4], c[5]));
+		V[p] = tap6u16(c[0], c[1], c[2], c[3], c[4], c[5]) >> s5;
 	}
 	h[0] = packus4(V[0], V[1]); h[1] = packus4(V[2], V[3]);
 }
@@ -687,11 +692,15 @@ E264_DEV void pred_phase_reslist(PredLds &L, int tid)
 	}
 }
 
-// add 4 residuals to 4 samples: int16 wrap add then packus (edge264_residual.c:160-171)
+// add 4 residuals to 4 samples: int16 wrap add then packus (edge264_residual.c:160-171), two samples per instruction
+E264_DEV uint32_t add_res4p(uint32_t px, s16x2 r01, s16x2 r23)
+{
+	return packus4(pair_at<0>(0, px) + r01, pair_at<2>(0, px) + r23);
+}
 E264_DEV uint32_t add_res4(uint32_t px, int r0, int r1, int r2, int r3)
 {
-	return (uint32_t)clip255(w16((int)(px & 255) + r0)) | (uint32_t)clip255(w16((int)(px >> 8 & 255) + r1)) << 8 |
-	       (uint32_t)clip255(w16((int)(px >> 16 & 255) + r2)) << 16 | (uint32_t)clip255(w16((int)(px >> 24) + r3)) << 24;
+	const s16x2 r01 = {(short)r0, (short)r1}, r23 = {(short)r2, (short)r3};
+	return add_res4p(px, r01, r23);
 }
 
 // Levels of a block as packed int16 pairs, whatever the packet stores (int16, or int8 with E264_MBF_LEV8): 8 levels ...
@@ -888,8 +897,7 @@ E264_DEV void res_item8(PredLds &L, const FrameCtx &f, int item)
 	for (int j = 0; j < 8; j++) {
 #pragma unroll
 		for (int w = 0; w < 2; w++) {
-			const s16x2 ra = u[j][2 * w], rb = u[j][2 * w + 1];
-			px[j * PT_W * 4 + w] = add_res4(px[j * PT_W * 4 + w], ra.x, ra.y, rb.x, rb.y);
+			px[j * PT_W * 4 + w] = add_res4p(px[j * PT_W * 4 + w], u[j][2 * w], u[j][2 * w + 1]);
 		}
 	}
 }
