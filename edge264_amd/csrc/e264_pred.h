@@ -200,6 +200,16 @@ template <int NR>
 E264_DEV void load_window(const gu8 *plane, int sY, int W, int H, int X, int Y, Row4 *A)
 {
 	const int XA = X & ~3;
+#ifdef E264_ABL_NOEDGE // timing ablation: no edge emulation (windows outside the frame read the wrong samples)
+	if (true) {
+		const gu8 *p = plane + (size_t)min(max(Y, 0), H - NR) * sY + min(max(XA, 0), W - 16);
+#pragma unroll
+		for (int r = 0; r < NR; r++) {
+			const v4u v = *(const gv4u *)(p + (size_t)r * sY);
+			A[r].a0 = v.x; A[r].a1 = v.y; A[r].a2 = v.z; A[r].a3 = v.w;
+		}
+	} else
+#endif
 	if (XA >= 0 && XA + 12 <= W - 4 && Y >= 0 && Y + NR - 1 <= H - 1) { // the common case: inside the frame, one 16-byte load per row
 		const gu8 *p = plane + (size_t)Y * sY + XA;
 #pragma unroll
