@@ -39,5 +39,9 @@ import json; d=json.load(open('$OUT/bench_main2.json')); print('main(again)', d[
 if [ -x edge264_amd/e264_multi ]; then
   M="./edge264_amd/e264_multi --front edge264_amd/libedge264_hipfront.so --hip edge264_amd/libedge264_hip.so"
   S="tests/golden/streams/hd1080_ipp30.264 tests/golden/streams/cabac_hd1080_ibbp30.264"
-  { echo "e264_multi 128 streams, 64 threads, no read-back"; timeout 300 $M --threads 64 --repeat 64 --loops 4 --no-download $S; } > $OUT/multi.txt 2>&1; tail -5 $OUT/multi.txt
+  for T in 16 32 64; do
+    { echo "e264_multi 128 streams, $T threads, no read-back"; timeout 300 $M --threads $T --repeat 64 --loops 8 --no-download $S; } >> $OUT/multi.txt 2>&1
+  done
+  { echo "e264_multi 128 streams, 32 threads, parse only (no device)"; timeout 300 $M --threads 32 --repeat 64 --loops 8 --parse-only $S; } >> $OUT/multi.txt 2>&1
+  grep -h "frames_per_s\|e264_multi" $OUT/multi.txt
 fi
