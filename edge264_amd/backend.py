@@ -66,6 +66,7 @@ def load_library():
         "e264hip_batch_free": (None, [vp]),
         "e264hip_event_record": (i, [vp, i]),
         "e264hip_event_elapsed_ms": (i, [vp, i, i, C.POINTER(C.c_float)]),
+        "e264hip_event_query": (i, [vp, i]),
         "e264hip_kernel_timing": (i, [vp, i]),
         "e264hip_kernel_time_ms": (i, [vp, C.POINTER(C.c_double), C.POINTER(i)]),
         "e264hip_set_option": (i, [vp, C.c_char_p, i]),
@@ -82,7 +83,7 @@ EXPORTED_SYMBOLS = [
     "e264hip_stream_open", "e264hip_stream_close", "e264hip_stream_bind_lane", "e264hip_stream_flush", "e264hip_frame_alloc",
     "e264hip_frame_free", "e264hip_frame_fill", "e264hip_frame_upload", "e264hip_frame_submit",
     "e264hip_packet_buffer", "e264hip_frame_wait", "e264hip_frame_download", "e264hip_packet_upload",
-    "e264hip_packet_free", "e264hip_packet_check", "e264hip_submit_batch", "e264hip_submit_batch_host", "e264hip_submit_batch_pinned", "e264hip_host_alloc", "e264hip_host_free", "e264hip_batch_create", "e264hip_batch_submit", "e264hip_batch_free", "e264hip_event_record", "e264hip_event_elapsed_ms",
+    "e264hip_packet_free", "e264hip_packet_check", "e264hip_submit_batch", "e264hip_submit_batch_host", "e264hip_submit_batch_pinned", "e264hip_host_alloc", "e264hip_host_free", "e264hip_batch_create", "e264hip_batch_submit", "e264hip_batch_free", "e264hip_event_record", "e264hip_event_elapsed_ms", "e264hip_event_query",
     "e264hip_kernel_timing", "e264hip_kernel_time_ms", "e264hip_set_option",
 ]
 
@@ -194,6 +195,13 @@ class Device:
         ms = C.c_float()
         _check(self.L, self.L.e264hip_event_elapsed_ms(self.h, a, b, C.byref(ms)), "event_elapsed")
         return float(ms.value)
+
+    def event_done(self, idx: int) -> bool:
+        """Has everything queued before event_record(idx) left the GPU?  Never blocks."""
+        r = self.L.e264hip_event_query(self.h, idx)
+        if r not in (0, errno.EBUSY):
+            _check(self.L, r, "event_query")
+        return r == 0
 
     def kernel_timing(self, enable: bool) -> None:
         _check(self.L, self.L.e264hip_kernel_timing(self.h, int(enable)), "kernel_timing")

@@ -978,6 +978,17 @@ API int e264hip_event_elapsed_ms(E264Device *dev, int a, int b, float *ms)
 	return 0;
 }
 
+// has everything queued before e264hip_event_record(dev, idx) left the GPU?  0 yes, EBUSY not yet (never blocks)
+API int e264hip_event_query(E264Device *dev, int idx)
+{
+	if (!dev || idx < 0 || idx >= 16) return fail(EINVAL, "event index");
+	if (set_device(dev)) return EIO;
+	const hipError_t e = hipEventQuery(dev->ev[idx]);
+	if (e == hipSuccess) return 0;
+	if (e == hipErrorNotReady) { (void)hipGetLastError(); return EBUSY; }
+	return fail(EIO, "hipEventQuery");
+}
+
 API int e264hip_kernel_timing(E264Device *dev, int enable)
 {
 	if (!dev) return fail(EINVAL, "null device");

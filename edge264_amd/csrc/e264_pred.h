@@ -637,9 +637,6 @@ E264_DEV void pred_item(PredLds &L, const FrameCtx &f, const PredTile &t, int li
 
 E264_DEV void pred_phase_items(PredLds &L, const FrameCtx &f, const PredTile &t, int list, int tid)
 {
-	int n = 0;
-#pragma unroll
-	for (int c = 0; c < 6; c++) n += L.cnt[c];
 	// The sorted list is walked from its END (the two-dimensional classes first): when the tile has more items than
 	// threads, the extra pass that only the first waves make -- while the others wait at the barrier -- then holds the
 	// cheapest items (integer and one-dimensional positions) instead of the most expensive ones.
@@ -661,6 +658,9 @@ E264_DEV void pred_phase_items(PredLds &L, const FrameCtx &f, const PredTile &t,
 			pred_item(L, f, t, list, cls, *pred_list_slot(L, cls, idx));
 	}
 #else // -DE264_PRED_CLASS_PACKED: the lists back to back (round 2)
+	int n = 0;
+#pragma unroll
+	for (int c = 0; c < 6; c++) n += L.cnt[c];
 	for (int p = tid; p < n; p += PT_NT) {
 		int cls = 0, idx = n - 1 - p;
 #pragma unroll

@@ -57,6 +57,7 @@ struct Front {
 	void (*set_sink)(int);
 	void (*set_device)(int);
 	void (*set_download)(int);
+	void (*set_pinned)(int);
 	int (*take_packet)(void *, void **, size_t *);
 	void (*free_packet)(void *);
 	void *(*stream)(void *);
@@ -65,6 +66,9 @@ struct Front {
 };
 struct Hip {
 	int (*submit_batch_host)(void *, void **, const void **, const size_t *, int, int);
+	int (*submit_batch_pinned)(void *, void **, const void **, const size_t *, int, int, int);
+	int (*event_record)(void *, int);
+	int (*event_query)(void *, int);
 	int (*device_sync)(void *);
 	const char *(*last_error)(void);
 };
@@ -110,6 +114,8 @@ static void on_crash(int sig)
 	_exit(128 + sig);
 }
 
+static bool g_pinned = true;
+
 int main(int argc, char **argv)
 {
 	signal(SIGSEGV, on_crash);
@@ -119,6 +125,9 @@ int main(int argc, char **argv)
 	int ahead = 3; // --ahead K: pictures a decoder may be parsed ahead of the device
 	int device = 0, repeat = 1, n_threads = 1, loops = 1; // --loops K: every stream is played K times back to back (steady state)
 	bool no_download = false; // --no-download: output frames stay in HBM (edge264_get_frame does not copy them back)
+	bool &pinned = g_pinned; // --pageable turns it off: packets are assembled in page-locked buffers (e264front_set_pinned) and submitted in place
+	                    // (e264hip_submit_batch_pinned, E264_SUBMIT_TRUSTED: the producer is the emitter) instead of being validated
+	                    // again and copied into staging memory by the back end
 	bool parse_only = false; // --parse-only: sink 1, no GPU: packets are produced and dropped (front-end speed / debugging)
 	std::vector<std::string> files;
 	for (int i = 1; i < argc; i++) {
@@ -131,6 +140,7 @@ int main(int argc, char **argv)
 		else if (a == "--repeat") repeat = atoi(next().c_str());
 		else if (a == "--parse-only") parse_only = true;
 		else if (a == "--no-download") no_download = true;
+		else if (a == "--pageable") pinned = false;
 		else if (a == "--threads") n_threads = atoi(next().c_str());
 		else if (a == "--loops") loops = atoi(next().c_str());
 		else if (a == "--ahead") ahead = std::max(1, atoi(next().c_str()));
@@ -151,16 +161,20 @@ int main(int argc, char **argv)
 	bind(fl, "edge264_alloc", F.alloc); bind(fl, "edge264_decode_NAL", F.decode_NAL); bind(fl, "edge264_get_frame", F.get_frame);
 	bind(fl, "edge264_free", F.free_dec); bind(fl, "edge264_find_start_code", F.find_start_code);
 	bind(fl, "e264front_set_sink", F.set_sink); bind(fl, "e264front_set_device", F.set_device); bind(fl, "e264front_set_download", F.set_download);
+	bind(fl, "e264front_set_pinned", F.set_pinned);
 	bind(fl, "e264front_take_packet", F.take_packet); bind(fl, "e264front_free_packet", F.free_packet);
 	bind(fl, "e264front_stream", F.stream); bind(fl, "e264front_device", F.device); bind(fl, "e264front_device_of", F.device_of);
 	if (!parse_only) {
 	bind(hl, "e264hip_submit_batch_host", H.submit_batch_host); bind(hl, "e264hip_device_sync", H.device_sync);
+	bind(hl, "e264hip_submit_batch_pinned", H.submit_batch_pinned); bind(hl, "e264hip_event_record", H.event_record); bind(hl, "e264hip_event_query", H.event_query);
 	bind(hl, "e264hip_last_error", H.last_error);
 	}
 
 	if (devices.empty()) devices.push_back(device);
 	F.set_sink(parse_only ? 1 : 2);
 	F.set_download(no_download ? 0 : 1);
+	if (parse_only) pinned = false;
+	F.set_pinned(pinned ? 1 : 0);
 	std::vector<Stream> S;
 	S.reserve((size_t)repeat * files.size()); // Stream keeps pointers into its own data: the vector must never reallocate (std::deque has no noexcept move: elements would be COPIED)
 	for (int r = 0; r < repeat; r++)
@@ -266,8 +280,32 @@ int main(int argc, char **argv)
 	std::vector<size_t> hsz;
 	std::vector<Stream *> owner;
 	long my_packets = 0, my_rounds = 0;
+	// packets submitted in place stay untouched until their batch has left the GPU: a ring of events (slots 8..15 of the device), the
+	// packets of each round parked behind its event
+	enum { NPEND = 4 };
+	std::vector<void *> parked[NPEND];
+	bool parked_busy[NPEND] = {};
+	int pend_next = 0;
+	// (--devices may name a GPU twice: its submitters share the device object and its 16 event slots; the first two get 4 slots
+	// each, any further one submits pageable packets)
+	int share = 0;
+	for (int d = 0; d < di; d++) share += dev_obj[(size_t)d] == dev_obj[(size_t)di];
+	const bool pinned = ::g_pinned && share < 2;
+	const int ev0 = 8 + share * NPEND;
+	auto release_round = [&](int k, bool block) {
+		if (!parked_busy[k]) return true;
+		while (H.event_query(dev_obj[(size_t)di], ev0 + k) != 0) {
+			if (!block) return false;
+			std::this_thread::sleep_for(std::chrono::microseconds(100));
+		}
+		for (void *p : parked[k]) F.free_packet(p);
+		parked[k].clear();
+		parked_busy[k] = false;
+		return true;
+	};
 	for (;;) {
 		streams.clear(); hpk.clear(); hsz.clear(); owner.clear();
+		if (pinned) for (int k = 0; k < NPEND; k++) release_round(k, false);
 		{
 			std::unique_lock<std::mutex> lk(mu);
 			auto ready = [&] { size_t n = 0; for (Stream &s : S) n += s.dev_index == di && !s.q.empty(); return n; };
@@ -289,14 +327,22 @@ int main(int argc, char **argv)
 		}
 		my_packets += (long)owner.size();
 		my_rounds++;
-		if (!parse_only && H.submit_batch_host(dev_obj[(size_t)di], streams.data(), hpk.data(), hsz.data(), (int)streams.size(), 3)) { fprintf(stderr, "submit_batch_host: %s\n", H.last_error()); _exit(1); }
-		{ // the packets were copied to staging memory: free them, let their decoders go on
+		if (pinned) {
+			release_round(pend_next, true);
+			if (H.submit_batch_pinned(dev_obj[(size_t)di], streams.data(), hpk.data(), hsz.data(), (int)streams.size(), 3, 1 /* E264_SUBMIT_TRUSTED */)) { fprintf(stderr, "submit_batch_pinned: %s\n", H.last_error()); _exit(1); }
+			if (H.event_record(dev_obj[(size_t)di], ev0 + pend_next)) { fprintf(stderr, "event_record: %s\n", H.last_error()); _exit(1); }
+			for (const void *p : hpk) parked[pend_next].push_back(const_cast<void *>(p));
+			parked_busy[pend_next] = true;
+			pend_next = (pend_next + 1) % NPEND;
+		} else if (!parse_only && H.submit_batch_host(dev_obj[(size_t)di], streams.data(), hpk.data(), hsz.data(), (int)streams.size(), 3)) { fprintf(stderr, "submit_batch_host: %s\n", H.last_error()); _exit(1); }
+		{ // the packets are on their way (copied to staging memory, or parked until their batch has retired): let their decoders go on
 			std::lock_guard<std::mutex> lk(mu);
-			for (Stream *s : owner) { F.free_packet(s->q.front().data); s->q.pop_front(); }
+			for (Stream *s : owner) { if (!pinned) F.free_packet(s->q.front().data); s->q.pop_front(); }
 			cv_room.notify_all();
 		}
 	}
 	if (!parse_only) H.device_sync(dev_obj[(size_t)di]);
+	for (int k = 0; k < NPEND; k++) release_round(k, true);
 	std::lock_guard<std::mutex> lk(mu);
 	packets += my_packets; rounds += my_rounds;
 	};

@@ -62,6 +62,8 @@ static struct {
 	int (*frame_wait)(E264Stream *, int);
 	int (*frame_download)(E264Stream *, int, void *, size_t);
 	int (*stream_flush)(E264Stream *);
+	void *(*host_alloc)(E264Device *, size_t);
+	void (*host_free)(E264Device *, void *);
 	E264Device *devs[E264_FRONT_MAX_DEVICES]; /* one device object per GPU ordinal, shared by every decoder bound to that GPU */
 } hip;
 static pthread_mutex_t g_dev_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -73,23 +75,28 @@ static int g_sink_kind = 0;
  * per picture, i.e. the process-wide mmap lock and a TLB shootdown across every parser thread: with one packet
  * allocation per picture 16 host threads parsed 5.7 k pictures/s and 128 threads 4.5 k (tools/gpu_multi.sh).  Buffers
  * carry their capacity in a 64-byte prefix; e264front_free_packet puts them back on one process-wide list. */
-struct E264PktBuf { size_t cap; struct E264PktBuf *next; char pad[64 - sizeof(size_t) - sizeof(void *)]; };
+struct E264PktBuf { size_t cap; struct E264PktBuf *next; E264Device *pinned_by; char pad[64 - sizeof(size_t) - 2 * sizeof(void *)]; };
 static pthread_mutex_t g_pkt_lock = PTHREAD_MUTEX_INITIALIZER;
 static struct E264PktBuf *g_pkt_free = NULL;
 static size_t g_pkt_free_bytes = 0;
+static int g_pkt_pinned = 0; /* e264front_set_pinned: the pool's buffers are page-locked (e264hip_host_alloc) -- the "pinned-arena ring" of
+                              * the emitters assemble a picture's packet where the H2D transfer reads it, and the batch
+                              * front end submits it in place (e264hip_submit_batch_pinned) instead of having it validated again and copied */
 #define E264_PKT_POOL_MAX ((size_t)2 << 30) /* bytes kept for reuse; beyond that buffers go back to the allocator */
-static uint8_t *e264_pkt_alloc(size_t bytes)
+static uint8_t *e264_pkt_alloc_on(size_t bytes, E264Device *dev)
 {
 	struct E264PktBuf *b = NULL, **pp;
+	const int pinned = g_pkt_pinned && dev != NULL;
 	pthread_mutex_lock(&g_pkt_lock);
 	for (pp = &g_pkt_free; *pp; pp = &(*pp)->next)
-		if ((*pp)->cap >= bytes) { b = *pp; *pp = b->next; g_pkt_free_bytes -= b->cap; break; }
+		if ((*pp)->cap >= bytes && ((*pp)->pinned_by != NULL) == pinned) { b = *pp; *pp = b->next; g_pkt_free_bytes -= b->cap; break; }
 	pthread_mutex_unlock(&g_pkt_lock);
 	if (!b) {
 		size_t cap = (bytes + bytes / 4 + 65535) & ~(size_t)65535; /* pictures of one stream differ in size: a quarter of headroom */
-		b = malloc(sizeof(*b) + cap);
+		b = pinned ? hip.host_alloc(dev, sizeof(*b) + cap) : malloc(sizeof(*b) + cap);
 		if (!b) return NULL;
 		b->cap = cap;
+		b->pinned_by = pinned ? dev : NULL;
 	}
 	return (uint8_t *)(b + 1);
 }
@@ -98,7 +105,8 @@ static void e264_pkt_free(void *data)
 	if (!data) return;
 	struct E264PktBuf *b = (struct E264PktBuf *)data - 1;
 	pthread_mutex_lock(&g_pkt_lock);
-	if (g_pkt_free_bytes + b->cap <= E264_PKT_POOL_MAX) { b->next = g_pkt_free; g_pkt_free = b; g_pkt_free_bytes += b->cap; b = NULL; }
+	/* page-locked buffers always stay in the pool: hipHostFree drains every queue of the device */
+	if (b->pinned_by || g_pkt_free_bytes + b->cap <= E264_PKT_POOL_MAX) { b->next = g_pkt_free; g_pkt_free = b; g_pkt_free_bytes += b->cap; b = NULL; }
 	pthread_mutex_unlock(&g_pkt_lock);
 	free(b);
 }
@@ -108,6 +116,7 @@ static int g_download = 1; /* 0: edge264_get_frame leaves the samples in HBM (de
 PUBLIC void e264front_set_sink(int kind) { g_sink_kind = kind; }
 PUBLIC void e264front_set_device(int ordinal) { g_device_ordinal = ordinal; }
 PUBLIC void e264front_set_download(int on) { g_download = on; }
+PUBLIC void e264front_set_pinned(int on) { g_pkt_pinned = on; }
 
 /* the device object of GPU `ordinal` (opened on first use); a decoder is bound to the GPU selected by e264front_set_device at
  * the time of its edge264_alloc -- several GPUs in one process: one decoder population per GPU, SURVEY.md 8(e) */
@@ -147,6 +156,7 @@ static int hip_load(void)
 #define BIND(n) if (!(*(void **)&hip.n = dlsym(hip.lib, "e264hip_" #n))) return ENODEV
 	BIND(device_open); BIND(stream_open); BIND(stream_close); BIND(frame_alloc); BIND(frame_free); BIND(frame_fill);
 	BIND(frame_submit); BIND(packet_buffer); BIND(frame_wait); BIND(frame_download); BIND(stream_flush);
+	BIND(host_alloc); BIND(host_free);
 #undef BIND
 	return 0;
 }
@@ -345,7 +355,7 @@ static int e264_finish_frame(E264Emitter *e, int slot, int partial)
 	size_t total = (size_t)payload_off + payload_bytes;
 	uint8_t *pkt;
 	if (e->sink_kind == 0) pkt = hip.packet_buffer(e->hip_stream, total);
-	else pkt = e264_pkt_alloc(total);
+	else pkt = e264_pkt_alloc_on(total, ON_DEVICE(e) ? (E264Device *)e->hip_dev : NULL);
 	if (!pkt)
 		return ENOMEM;
 	E264FrameHdr h = {0};

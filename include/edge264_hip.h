@@ -121,6 +121,9 @@ void e264hip_batch_free(E264Batch *b);
  * torch's own stream).  Slots 0..15.  Recorded on lane 0 behind everything queued on the other lanes so far. */
 int  e264hip_event_record(E264Device *dev, int idx);
 int  e264hip_event_elapsed_ms(E264Device *dev, int idx_start, int idx_stop, float *ms);
+/* 0 when everything queued before e264hip_event_record(dev, idx) has left the GPU, EBUSY while it has not; never blocks.
+ * (How a front end that submits packets in place, e264hip_submit_batch_pinned, learns when their buffers may be reused.) */
+int  e264hip_event_query(E264Device *dev, int idx);
 /* Accumulated time of each of the four kernels of a submission (ms4[0] deblock-parameter kernel,
  * ms4[1] parallel MB kernel, ms4[2] intra wavefront, ms4[3] deblocking wavefront), measured with
  * events recorded on the queue between the launches (only when enabled). */

@@ -49,6 +49,9 @@ class Device:
     def event_elapsed_ms(self, a, b):
         return 1.0
 
+    def event_done(self, idx):
+        return True
+
     def kernel_timing(self, enable):
         self.timing = bool(enable)
         if enable:

@@ -52,8 +52,9 @@ def test_multi_stream_driver(tmp_path, names, repeat):
             got = frame_md5s(tmp_path / f"s{k}.yuv", sums[n]["width_mbs"], sums[n]["height_mbs"], sums[n]["views"])
             assert got == sums[n]["md5"], f"stream {k} ({n})"
             k += 1
-    # decode-to-device mode: nothing is copied back, same frame count
-    out2 = subprocess.run([EXE, "--front", FRONT, "--hip", HIP, "--repeat", str(repeat), "--threads", "2", "--no-download"] + files,
+    # decode-to-device mode: nothing is copied back, same frame count (and the other packet path: pageable packets, validated and
+    # copied to staging memory by the back end, instead of page-locked ones submitted in place)
+    out2 = subprocess.run([EXE, "--front", FRONT, "--hip", HIP, "--repeat", str(repeat), "--threads", "2", "--no-download", "--pageable"] + files,
                           capture_output=True, text=True, timeout=600)
     assert out2.returncode == 0, out2.stderr[-2000:]
     assert json.loads(out2.stdout.strip().splitlines()[-1])["frames"] == stats["frames"]
