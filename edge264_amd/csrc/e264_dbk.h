@@ -216,26 +216,56 @@ E264_DEV void dk_filter(s16x2 *v, const DkPrm &P, const DkRole &R)
 // input: the unfiltered samples of macroblock (x, y) -> registers.  Luma lane: its two rows (16 bytes each); chroma lane:
 // a = {Cb row 2pi, Cr row 2pi}, b = the same of row 2pi+1 (8 bytes each).  LOADS ONLY.
 // ---------------------------------------------------------------------------------------------------------------------
-// The SAME four 8-byte loads for every lane, at per-lane addresses (luma: the two halves of each row; chroma: Cb and Cr of
-// each row): with one instruction sequence per role the loads of the second role had to wait until those of the first had
-// returned (they share destination registers: s_waitcnt vmcnt(0) between them, a full memory latency in every step).
-struct DkSrc { const gu8 *base; int d1, d2; }; // row y of the lane's wave: address of macroblock 0, distance to the 2nd piece, to the 2nd row
+// FOUR macroblocks per fetch (round 3; round 2 fetched one macroblock per step with four 8-byte loads per lane).  A lane's row of
+// samples is 16 bytes per macroblock (8 + 8 for a chroma lane: Cb and Cr), so the 128-byte line it sits in was asked for at
+// eight different steps ~36 us apart -- longer than a line survives in the XCD's L2 under the 4.6 MB of lines the 32 CUs
+// have open at any time: the L2 re-fetched it (26 M read requests of 128 B per 256 pictures = 4.2 x the samples,
+// profiles/r03_pmc_hbm_requests.txt).  Now every fourth step a lane fetches the next four macroblocks of its two rows with
+// EIGHT 16-byte loads (64 contiguous bytes per row; a chroma lane: 32 of Cb + 32 of Cr per row), the same instruction
+// sequence for every lane at per-lane addresses (one sequence per role would make the second role's loads wait for the
+// first's: they share destination registers).  Pieces outside the picture are fetched from clamped addresses and never used.
+//   load k = 0..7:  address = row base + ((k & 1) * 16 + (k >> 1 & 1) * e1) + (k >> 2) * d2
+//     luma lane:    e1 = 32: pieces k & 3 = macroblock k & 3 of row (k >> 2);          chroma lane: e1 = distance Cb -> Cr:
+//                   piece k & 1 = macroblocks (2 (k & 1), 2 (k & 1) + 1) of plane (k >> 1 & 1), row (k >> 2)
+struct DkSrc { const gu8 *base; int e1, d2; }; // row y of the lane's wave: address of macroblock 0, see above
 E264_DEV DkSrc dk_src(const FrameCtx &f, const DkRole &R, int y)
 {
 	DkSrc s;
-	if (!R.chroma) { s.base = f.cur + (size_t)(y * 16 + 2 * R.pi) * f.sY; s.d1 = 8; s.d2 = f.sY; }
-	else { s.base = plane_base(f, f.cur, 1) + (size_t)(y * 8 + 2 * R.pi) * f.sC; s.d1 = f.sC >> 1; s.d2 = f.sC; }
+	if (!R.chroma) { s.base = f.cur + (size_t)(y * 16 + 2 * R.pi) * f.sY; s.e1 = 32; s.d2 = f.sY; }
+	else { s.base = plane_base(f, f.cur, 1) + (size_t)(y * 8 + 2 * R.pi) * f.sC; s.e1 = f.sC >> 1; s.d2 = f.sC; }
 	return s;
 }
-E264_DEV void dk_fetch(const DkSrc &S, const DkRole &R, int x, v4u &a, v4u &b)
+// macroblocks x0 .. x0 + 3 of the lane's row -> N[0..7].  LOADS ONLY.  A chroma piece may start one macroblock before the row
+// (x0 = -1: its second half is macroblock 0) or end one after it: 8 bytes before / after the row, which are the previous /
+// next row, the end of the luma plane, or the slack every frame allocation ends with (e264hip_frame_alloc).
+E264_DEV void dk_fetch4(const DkSrc &S, const DkRole &R, int x0, int wm, v4u N[8])
 {
 #ifdef E264_ABL_DBK_NOLOAD // timing ablation
-	if (R.slot_mul) { a = (v4u){(uint32_t)x, 1, 2, 3}; b = a; return; }
+	if (R.slot_mul) { for (int k = 0; k < 8; k++) N[k] = (v4u){(uint32_t)x0, 1, 2, 3}; return; }
 #endif
-	const gu8 *p = S.base + x * R.slot_mul;
-	const v2u t0 = *(const gv2u *)p, t1 = *(const gv2u *)(p + S.d1), t2 = *(const gv2u *)(p + S.d2), t3 = *(const gv2u *)(p + S.d2 + S.d1);
-	a.x = t0.x; a.y = t0.y; a.z = t1.x; a.w = t1.y;
-	b.x = t2.x; b.y = t2.y; b.z = t3.x; b.w = t3.y;
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		// first macroblock of the piece: luma piece k & 3; chroma piece (k & 1) = two macroblocks
+		const int mb = R.chroma ? min(max(x0 + 2 * (k & 1), -1), wm - 1) : min(max(x0 + (k & 3), 0), wm - 1);
+		const int plane_off = R.chroma ? (k >> 1 & 1) * S.e1 : 0;
+		N[k] = *(const gv4u *)(S.base + mb * R.slot_mul + plane_off + (k >> 2) * S.d2);
+	}
+}
+// the registers of macroblock x0 + k out of a fetched group: a = the lane's first row (luma: 16 bytes; chroma: Cb 8 bytes, Cr 8
+// bytes), b = its second row
+E264_DEV void dk_pick(const v4u N[8], const DkRole &R, int k, v4u &a, v4u &b)
+{
+#pragma unroll
+	for (int row = 0; row < 2; row++) {
+		const v4u *L = N + 4 * row;
+		const v4u lu = L[k];                        // luma: piece k
+		const v4u cb = L[k >> 1], cr = L[2 + (k >> 1)]; // chroma: half (k & 1) of the plane's piece k >> 1
+		v4u ch;
+		if (k & 1) { ch.x = cb.z; ch.y = cb.w; ch.z = cr.z; ch.w = cr.w; }
+		else { ch.x = cb.x; ch.y = cb.y; ch.z = cr.x; ch.w = cr.y; }
+		v4u &o = row ? b : a;
+		o.x = R.chroma ? ch.x : lu.x; o.y = R.chroma ? ch.y : lu.y; o.z = R.chroma ? ch.z : lu.z; o.w = R.chroma ? ch.w : lu.w;
+	}
 }
 // the parameter record of macroblock (x, y): 4 pieces of 16 bytes, luma lanes 0..3
 E264_DEV void dk_fetch_prm(const FrameCtx &f, const DkRole &R, int x, int y, v4u &p)
@@ -383,8 +413,8 @@ E264_DEV void dk_top_flush(const DkWave &W, const FrameCtx &f, int lane, int q, 
 struct DkPlan {
 	int x;             // the row's macroblock at this step
 	bool act;          // V and H phases
-	bool prm_commit, prm_fetch, mb_fetch; // parameters of x+1 -> LDS, of x+3 -> register; samples of x+2 -> registers.  Both register
-	                                      // sets alternate with the parity of t: what a step consumes was requested two steps earlier
+	bool prm_commit, prm_fetch;           // parameters of x+1 -> LDS, of x+3 -> register (two register sets alternating with the parity of t)
+	bool grp_fetch;                       // (t % 4 == 0) samples of x+2 .. x+5 -> registers: consumed at steps t+2 .. t+5
 	int top_fetch, top_commit;            // group of the top strip to fetch / commit, -1: none (wave lanes 0..23, when the wave has rows above)
 	int flush, top_flush;                 // group to write out before the V phase, -1: none
 	bool publish;                         // (wave-uniform) the groups written at the top of this step are announced at its end
@@ -399,7 +429,7 @@ E264_DEV DkPlan dk_plan(int t, const DkRole &R, bool row_ok, bool top, int wm)
 	p.act = row_ok && p.x >= 0 && p.x < wm;
 	p.prm_commit = row_ok && p.x + 1 >= 0 && p.x + 1 < wm;
 	p.prm_fetch = row_ok && p.x + 3 >= 0 && p.x + 3 < wm;
-	p.mb_fetch = row_ok && p.x + 2 >= 0 && p.x + 2 < wm;
+	p.grp_fetch = (t & 3) == 0 && row_ok && p.x + 5 >= 0 && p.x + 2 < wm;
 	// the wave's first row filters group Q's first macroblock at t = 4Q: fetched at t = 4Q - 2, committed at t = 4Q - 1
 	p.top_fetch = (top && ((t + 2) & 3) == 0 && (t + 2) >> 2 < nq) ? (t + 2) >> 2 : -1;
 	p.top_commit = (top && ((t + 1) & 3) == 0 && (t + 1) >> 2 < nq) ? (t + 1) >> 2 : -1;

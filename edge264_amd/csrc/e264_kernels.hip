@@ -1004,17 +1004,23 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 #ifdef E264_PHASE_TIMING
 		if (blockIdx.x == 0 && lane == 0 && q < 64) g_timeline[2 * q] = __builtin_amdgcn_s_memtime();
 #endif
-		v4u a0 = {0, 0, 0, 0}, b0 = a0, p0 = a0, a1 = a0, b1 = a0, p1 = a0, tt = a0;
+		v4u p0 = {0, 0, 0, 0}, p1 = p0, tt = p0;
+		v4u N[8];               // samples of four macroblocks of the lane's two rows (dk_fetch4), requested at steps t = 0 mod 4
+		v4u K2a = p0, K2b = p0, K3a = p0, K3b = p0; // the last two of them, kept while the next group is on its way
 		PH_DECL;
-		// one step; sa / sb / sp: the register set of this step's parity (samples of x, parameters of x+1, requested two steps ago)
-		auto step = [&](const int t, v4u &sa, v4u &sb, v4u &sp) __attribute__((always_inline)) {
+		// one step; k = (t + 2) & 3: which macroblock of its group the step filters (k = 2, 3: of the group before, out of K2 / K3);
+		// sp: the parameter register set of this step's parity (parameters of x+1, requested two steps ago)
+		auto step = [&](const int t, const int k, v4u &sp) __attribute__((always_inline)) {
 			const DkPlan p = dk_plan(t, R, row_ok, top, wm);
 			// what earlier steps requested is picked up BEFORE this step's stores are issued: the compiler cannot count
 			// conditional stores, any use of a loaded register after them is an s_waitcnt vmcnt(0) = a full drain
 			if (p.top_commit >= 0) dk_top_commit(W, f, lane, p.top_commit, y0, tt);
 			if (p.prm_commit) dk_commit_prm(W, R, p.x + 1, sp);
-			const v4u ra = sa, rb = sb;
-			asm volatile("" :: "v"(ra), "v"(rb)); // the copies happen here
+			v4u ra, rb;
+			if (k < 2) dk_pick(N, R, k, ra, rb);
+			else { ra = k == 2 ? K2a : K3a; rb = k == 2 ? K2b : K3b; }
+			if (k == 1) { dk_pick(N, R, 2, K2a, K2b); dk_pick(N, R, 3, K3a, K3b); } // N is overwritten in the next step
+			asm volatile("" :: "v"(ra), "v"(rb), "v"(K2a), "v"(K2b), "v"(K3a), "v"(K3b)); // the copies happen here
 			if (p.flush >= 0) dk_flush(W, f, R, p.flush, y);
 			if (p.top_flush >= 0) dk_top_flush(W, f, lane, p.top_flush, y0);
 			PH(0);
@@ -1027,7 +1033,7 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 			}
 			PH(1);
 			if (p.prm_fetch) dk_fetch_prm(f, R, p.x + 3, y, sp);
-			if (p.mb_fetch) dk_fetch(src, R, p.x + 2, sa, sb);
+			if (k == 2 && p.grp_fetch) dk_fetch4(src, R, p.x + 2, wm, N);
 			wave_sync();
 			PH(2);
 			DkPrm P[2];
@@ -1050,9 +1056,11 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 			PH(6);
 		};
 #pragma unroll 1
-		for (int t = DK_FIRST_STEP; t <= last_step; t += 2) { // unrolled by two: the register sets alternate by name, not by copy
-			step(t, a0, b0, p0);
-			step(t + 1, a1, b1, p1);
+		for (int t = DK_FIRST_STEP; t <= last_step; t += 4) { // unrolled by four: a group of four macroblocks per fetch, registers by name
+			step(t, 2, p0);
+			step(t + 1, 3, p1);
+			step(t + 2, 0, p0);
+			step(t + 3, 1, p1);
 		}
 #ifdef E264_PHASE_TIMING
 		if (blockIdx.x == 0 && lane == 0 && q < 64) g_timeline[2 * q + 1] = __builtin_amdgcn_s_memtime();

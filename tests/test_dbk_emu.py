@@ -36,6 +36,9 @@ CASES = [
     ("t8x8_pcm", "IPB", 7, 5, dict(t8x8=True, pcm_prob=0.2, i_kinds=(P.MB_I4x4, P.MB_I8x8, P.MB_I16x16))),
     ("intra_in_inter", "IPP", 10, 12, dict(intra_in_inter=0.4, filter_offsets=(-6, 6))),
     ("smooth", "IPP", 8, 6, dict(residual_prob=0.1, p_skip=0.5)),
+    ("two_wide", "IPB", 2, 6, dict()),                          # one chroma piece (two macroblocks) is the whole row
+    ("five_wide", "IPP", 5, 3, dict(residual_prob=0.8)),        # a group of four + one: the chroma piece of the last macroblock hangs over the row
+    ("six_wide", "IPB", 6, 4, dict(num_refs=2)),
 ]
 
 
