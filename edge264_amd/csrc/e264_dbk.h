@@ -13,8 +13,9 @@
 // macroblock rows, each one macroblock behind the row above:
 //
 //   step t, row g of the wave (lanes 12g .. 12g+11), macroblock x = t - g:
-//     V phase  vertical edges: lane = row pair.  Own samples come straight from the registers a prefetch filled one
-//              step earlier, the left neighbour's last 4 columns from the row's strip in LDS; result -> strip.
+//     V phase  vertical edges: lane = row pair.  Own samples come straight from registers: every fourth step a lane fetches
+//              the next FOUR macroblocks of its two rows (dk_fetch4, two or more steps ahead of their use); the left
+//              neighbour's last 4 columns come from the row's strip in LDS; result -> strip.
 //     H phase  horizontal edges: lane = column pair, read from the strip; the 4 rows above are rows 12..15 of the strip
 //              of row g-1 (which filtered macroblock x+1's left edge in this step's V phase: exactly the decoding order
 //              (x+1, y-1) before (x, y) of edge264_deblock.c), or, for the wave's first row, a small top strip that is
