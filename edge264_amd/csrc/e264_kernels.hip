@@ -363,7 +363,8 @@ __device__ __forceinline__ void compute_residual(WaveLds &L, const int16_t *coef
 // ---------------------------------------------------------------------------------
 #define LP(l, m, r) (((l) + 2 * (m) + (r) + 2) >> 2)
 #ifndef E264_I4_UNROLL
-#define E264_I4_UNROLL 5 // steps of the Intra4x4 anti-diagonal loop unrolled together (1: 3.43 ms on 4x4-only I pictures, 10: spills, 3.95 ms on mixed ones)
+#define E264_I4_UNROLL 10 // steps of the Intra4x4 anti-diagonal loop unrolled together: all ten (what a lane does in a step is then a handful of
+                          // loop-invariant registers; affordable since E264_INTRA_LAUNDER freed the registers: round 2 spilled with it)
 #endif
 #include "e264_intra_tab.h"
 
@@ -647,6 +648,16 @@ __device__ __forceinline__ int intra_chroma_px(const WaveLds &L, int p, int mode
 // next_rec (may be null): LDS copy of the record of the macroblock this wave reconstructs next; its header goes to mn and its
 // payload is requested into coefs_next -- the transfer then has the whole reconstruction (thousands of cycles) to land instead of
 // standing at the head of the next macroblock's chain.
+// What a lane is in every part of recon_mb (pixel, block, tile and frame addresses) is hoisted out of the macroblock loop by the
+// compiler: ~130 registers where a 16-wave workgroup has 128.  Hiding the lane number from it in ONE part makes that part derive its
+// addresses again per macroblock (a few VALU instructions) and the rest fit: bit 0 = the Intra8x8 blocks, 1 = the neighbour fetch,
+// 2 = the residual, 3 = the neighbour commit.  Default 5: no spill left even with the Intra4x4 loop fully unrolled
+// (profiles/r03_ablations.txt item 14: the bench GOP's intra time unchanged, 4x4-only pictures +12 %).
+#ifndef E264_INTRA_LAUNDER
+#define E264_INTRA_LAUNDER 5
+#endif
+__device__ __forceinline__ int relane(int lane) { asm volatile("" : "+v"(lane)); return lane; }
+
 template <int WHICH>
 __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, int mbx, int mby, int lane, const uint32_t *i4tab, const int16_t *coefs,
 	int16_t *coefs_next, const uint32_t *next_rec, MbInfo &mn PH_PARAMS)
@@ -674,7 +685,7 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const Mb
 	IntraNb nbv;
 	nbv.oky = nbv.okc = false;
 	if (WHICH != 1 && m.kind != E264_MB_INTER)
-		nbv = issue_intra_neighbours(f, mbx, mby, lane); // in flight during the residual
+		nbv = issue_intra_neighbours(f, mbx, mby, (E264_INTRA_LAUNDER & 2) ? relane(lane) : lane); // in flight during the residual
 	PH(2);
 	if (next_rec) { // (uniform)
 		mn = mb_from_lds(next_rec);
@@ -682,13 +693,13 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const Mb
 	}
 	slice_cache(L, f, m.slice, lane);
 	PH(3);
-	compute_residual(L, coefs, f, m, lane);
+	compute_residual(L, coefs, f, m, (E264_INTRA_LAUNDER & 4) ? relane(lane) : lane);
 	PH(4);
 
 	int pY[4], pC[2];
 	bool tile_luma = false;
 	if (WHICH != 1 && m.kind != E264_MB_INTER) {
-		commit_intra_neighbours(L, nbv, lane);
+		commit_intra_neighbours(L, nbv, (E264_INTRA_LAUNDER & 8) ? relane(lane) : lane);
 		PH(5);
 		if (m.kind == E264_MB_I16x16) {
 			intra16x16_pred(L, m.i16_mode, X, Yr, pY);
@@ -736,7 +747,7 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const Mb
 			tile_luma = true;
 #pragma unroll 1
 			for (int b = 0; b < 4; b++)
-				intra8x8_block(L, BXf(b * 4), BYf(b * 4), (int)(modes_lo >> (8 * b) & 255), lane);
+				intra8x8_block(L, BXf(b * 4), BYf(b * 4), (int)(modes_lo >> (8 * b) & 255), (E264_INTRA_LAUNDER & 1) ? relane(lane) : lane);
 		}
 		PH(6);
 		pC[0] = intra_chroma_px(L, cpl, m.chroma_mode, cx, cy);
