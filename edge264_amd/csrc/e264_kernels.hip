@@ -420,7 +420,7 @@ __device__ __forceinline__ int intra4x4_tab(const WaveLds &L, uint32_t e, int X0
 	const uint8_t *org = &L.YT(Y0 - 1, X0 - 1);
 	if (mode >= 2 && mode <= 5) { // DC variants: top and left, top, left, none (edge264_intra.c DC modes)
 		const uint32_t w = *(const uint32_t *)(org + 1);
-		const int st = (int)((w & 255) + (w >> 8 & 255) + (w >> 16 & 255) + (w >> 24));
+		const int st = (int)__builtin_amdgcn_sad_u8(w, 0, 0); // the four samples above, summed
 		const int sl = org[YT_STRIDE] + org[2 * YT_STRIDE] + org[3 * YT_STRIDE] + org[4 * YT_STRIDE];
 		return mode == 2 ? (st + sl + 4) >> 3 : mode == 3 ? (st + 2) >> 2 : mode == 4 ? (sl + 2) >> 2 : 128;
 	}
@@ -735,8 +735,9 @@ __device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const Mb
 				int v = 0;
 				if (on) {
 					int x = hl16 & 3, y = hl16 >> 2;
+					const int rres = L.res[(Y0 + y) * 16 + X0 + x]; // requested in front of the prediction's reads, not behind its branches
 					v = intra4x4_tab(L, e, X0, Y0, mode);
-					v = clip255(w16(v + L.res[(Y0 + y) * 16 + X0 + x]));
+					v = clip255(w16(v + rres));
 				}
 				wave_sync();
 				if (on)
