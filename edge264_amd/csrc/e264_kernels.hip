@@ -418,15 +418,20 @@ __device__ __forceinline__ void commit_intra_neighbours(WaveLds &L, const IntraN
 __device__ __forceinline__ int intra4x4_tab(const WaveLds &L, uint32_t e, int X0, int Y0, int mode)
 {
 	const uint8_t *org = &L.YT(Y0 - 1, X0 - 1);
-	if (mode >= 2 && mode <= 5) { // DC variants: top and left, top, left, none (edge264_intra.c DC modes)
+	const bool dc = mode >= 2 && mode <= 5;
+	// the three taps of the directional modes are requested by every lane (DC lanes: table word 0, a valid position) BEFORE the
+	// DC modes' branch, so that their latency runs under it instead of behind it
+	const int a = org[e & 255], b = org[e >> 8 & 255], c = org[e >> 16 & 255];
+	int vd = 128;
+	if (dc) { // DC variants: top and left, top, left, none (edge264_intra.c DC modes)
 		const uint32_t w = *(const uint32_t *)(org + 1);
 		const int st = (int)__builtin_amdgcn_sad_u8(w, 0, 0); // the four samples above, summed
 		const int sl = org[YT_STRIDE] + org[2 * YT_STRIDE] + org[3 * YT_STRIDE] + org[4 * YT_STRIDE];
-		return mode == 2 ? (st + sl + 4) >> 3 : mode == 3 ? (st + 2) >> 2 : mode == 4 ? (sl + 2) >> 2 : 128;
+		vd = mode == 2 ? (st + sl + 4) >> 3 : mode == 3 ? (st + 2) >> 2 : mode == 4 ? (sl + 2) >> 2 : 128;
 	}
-	const int a = org[e & 255], b = org[e >> 8 & 255], c = org[e >> 16 & 255];
 	const int ty = (int)(e >> 24), sh = ty >> 3;
-	return (a + (ty & 3) * b + ((ty & 4) ? c : 0) + ((1 << sh) >> 1)) >> sh;
+	const int v = (a + (ty & 3) * b + ((ty & 4) ? c : 0) + ((1 << sh) >> 1)) >> sh;
+	return dc ? vd : v;
 }
 
 // one 4x4 block, lanes 0..15 = (y = lane>>2, x = lane&3); reads/writes the luma tile
@@ -590,7 +595,7 @@ __device__ __forceinline__ void intra16x16_pred(const WaveLds &L, int mode, int 
 	case 1: for (int i = 0; i < 4; i++) out[i] = Lf(Yr); return;
 	case 2: case 3: case 4: case 5: {
 		int st = 0, sl = 0;
-		if (mode == 2 || mode == 3) for (int i = 0; i < 16; i++) st += T(i);
+		if (mode == 2 || mode == 3) for (int i = 0; i < 4; i++) st = (int)__builtin_amdgcn_sad_u8(*(const uint32_t *)&L.YT(-1, 4 * i), 0, (uint32_t)st); // the row above, four samples per instruction
 		if (mode == 2 || mode == 4) for (int i = 0; i < 16; i++) sl += Lf(i);
 		int v = mode == 2 ? (st + sl + 16) >> 5 : mode == 3 ? (st + 8) >> 4 : mode == 4 ? (sl + 8) >> 4 : 128;
 		for (int i = 0; i < 4; i++) out[i] = v;
@@ -620,7 +625,8 @@ __device__ __forceinline__ int intra_chroma_px(const WaveLds &L, int p, int mode
 		if (mode == 3) return 128;
 		int bx = x >> 2, by = y >> 2;
 		int t = 0, l = 0;
-		for (int i = 0; i < 4; i++) { t += T(bx * 4 + i); l += Lf(by * 4 + i); }
+		t = (int)__builtin_amdgcn_sad_u8(*(const uint32_t *)&L.CT(p, -1, bx * 4), 0, 0);
+		for (int i = 0; i < 4; i++) l += Lf(by * 4 + i);
 		if (mode == 1) return (t + 2) >> 2;
 		if (mode == 2) return (l + 2) >> 2;
 		if (bx == by) return (t + l + 4) >> 3;
