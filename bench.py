@@ -60,7 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--gop", default=os.environ.get("E264_GOP", "IPPPPPPP"))
     ap.add_argument("--width-mbs", type=int, default=120)
     ap.add_argument("--height-mbs", type=int, default=68)
-    ap.add_argument("--waves", type=int, default=int(os.environ.get("E264_WAVES", 7)))
+    ap.add_argument("--waves", type=int, default=int(os.environ.get("E264_WAVES", 8)))
     ap.add_argument("--intra-waves", type=int, default=int(os.environ.get("E264_INTRA_WAVES", 16)))
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="bounded CPU baseline sample (per leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

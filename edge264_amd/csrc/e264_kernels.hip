@@ -1135,7 +1135,7 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 	if (marks) hipEventRecord(marks[3], stream);
 	if (side) hipStreamWaitEvent(stream, fork->joined, 0);
 	if (mode & 2) {
-		switch (waves) { // waves per picture, five macroblock rows each: 7 = two even rounds over the 68 rows of 1080p
+		switch (waves) { // waves per picture, five macroblock rows each (default 8, set by the back end)
 		case 2: hipLaunchKernelGGL(e264_deblock_kernel<2>, dim3(n_jobs), dim3(128), 0, stream, jobs); break;
 		case 4: hipLaunchKernelGGL(e264_deblock_kernel<4>, dim3(n_jobs), dim3(256), 0, stream, jobs); break;
 		case 8: hipLaunchKernelGGL(e264_deblock_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs); break;
