@@ -65,6 +65,9 @@ E264_DEV void dbkp_expand_list(const gu8 *motion, uint32_t mot_off, uint32_t h, 
 	const gu32 *rec = (const gu32 *)(motion + off);
 	uint32_t refs = 0xffffffffu;
 	v4u mv[4];
+#ifdef E264_ABL_DBKP_NOMOT // timing ablation: the motion records are not read (wrong bS): 0.225 -> 0.157 ms, profiles/r03_ablations.txt item 17
+	if (off != 0xfffffffcu) { mo[l] = off; for (int q = 0; q < 4; q++) *(v4u *)&mo[4 + l * 16 + q * 4] = (v4u){off, h, off, h}; return; }
+#endif
 	if (E264_MOT_UNI(h, l)) {
 		const uint32_t r = rec[0], v = rec[1];
 		refs = (r & 255u) * 0x01010101u;
