@@ -224,12 +224,27 @@ int main(int argc, char **argv)
 	long queued = 0;
 	// the output frames of a decoder may only be fetched when all its parsed pictures are on the device
 	auto wait_submitted = [&](Stream &s) { std::unique_lock<std::mutex> lk(mu); cv_room.wait(lk, [&] { return s.q.empty(); }); };
-	// 1. advance a decoder until its next picture is complete (or its stream ends); returns false when nothing more comes
-	auto advance = [&](Stream &s) -> bool {
+	// 1. advance a decoder until its next picture is complete (or its stream ends).  Never waits for the device side: a decoder that
+	//    cannot go on right now -- it is `ahead` pictures ahead, or it must hand out frames (ENOBUFS, edge264.h) while some of its
+	//    pictures are still only queued -- reports BLOCKED and its thread turns to its next decoder (round 3; before, the thread
+	//    slept until the next batch had taken the decoder's packet, with its other decoders idle)
+	enum Adv { GOT, ENDED, BLOCKED };
+	auto advance = [&](Stream &s) -> Adv {
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			if ((int)s.q.size() >= ahead) return BLOCKED;
+		}
 		while (!s.done) {
 			const uint8_t *nxt = s.nal < s.end ? F.find_start_code(s.nal, s.end, 0) : s.end;
 			int res = F.decode_NAL(s.dec, s.nal, nxt, nullptr, nullptr);
-			if (res == ENOBUFS) { wait_submitted(s); drain(s); continue; }
+			if (res == ENOBUFS) { // the same NAL again once frames have been fetched; they may only be fetched when all parsed pictures are on the device
+				{
+					std::lock_guard<std::mutex> lk(mu);
+					if (!s.q.empty()) return BLOCKED;
+				}
+				drain(s);
+				continue;
+			}
 			void *pkt = nullptr; size_t bytes = 0;
 			bool got = F.take_packet(s.dec, &pkt, &bytes) == 0;
 			if (res == ENODATA || s.nal >= s.end) s.done = true;
@@ -238,28 +253,34 @@ int main(int argc, char **argv)
 				if (s.nal >= s.end && s.loops_left > 0) { s.loops_left--; s.nal = s.first_nal; } // play it again (starts with SPS/PPS/IDR)
 			}
 			if (got) {
-				std::unique_lock<std::mutex> lk(mu);
-				cv_room.wait(lk, [&] { return (int)s.q.size() < ahead; });
+				std::lock_guard<std::mutex> lk(mu); // (room was checked on entry; only this thread adds to the queue)
 				s.q.push_back({pkt, bytes});
 				queued++;
 				cv_ready.notify_all();
-				return true;
+				return GOT;
 			}
 		}
-		return false;
+		return ENDED;
 	};
 	// worker threads: thread k owns decoders k, k+T, k+2T, ... and keeps each of them up to `ahead` pictures ahead
 	if (n_threads < 1) n_threads = 1;
 	if ((size_t)n_threads > S.size()) n_threads = (int)S.size();
 	int workers_left = n_threads;
 	auto worker = [&](int k) {
-		for (bool any = true; any;) {
-			any = false;
+		for (;;) {
+			bool progressed = false, unfinished = false;
 			for (size_t i = (size_t)k; i < S.size(); i += (size_t)n_threads) {
 				Stream &s = S[i];
 				if (s.finished) continue;
-				if (advance(s)) any = true;
-				else { std::lock_guard<std::mutex> lk(mu); s.finished = true; cv_ready.notify_all(); }
+				const Adv a = advance(s);
+				if (a == GOT) progressed = true;
+				if (a == ENDED) { std::lock_guard<std::mutex> lk(mu); s.finished = true; cv_ready.notify_all(); }
+				else unfinished = true;
+			}
+			if (!unfinished) break;
+			if (!progressed) { // every decoder of this thread waits for a batch to take its packets
+				std::unique_lock<std::mutex> lk(mu);
+				cv_room.wait_for(lk, std::chrono::milliseconds(1));
 			}
 		}
 		for (size_t i = (size_t)k; i < S.size(); i += (size_t)n_threads) { wait_submitted(S[i]); drain(S[i]); }
