@@ -186,3 +186,32 @@ def test_upload_queue_orders_copies_and_kernels(device, oracle):
             for st in sts:
                 st.close()
             device.set_option("upload_queue", prev)
+
+
+def test_event_query_never_blocks_and_settles(device, oracle):
+    """e264hip_event_query (how a front end that submits packets in place learns that their buffers may be reused): EBUSY or 0
+    right after the record, 0 once the device has been waited for; an index outside the 16 slots is refused."""
+    w, h, n = 20, 12, 4
+    nb = P.frame_bytes(w, h)
+    gens = [synth.StreamSynth(w, h, 900 + k, i_kinds=ALL_I) for k in range(n)]
+    dpbs = [[np.full(nb + 16, 128, np.uint8) for _ in range(6)] + [None] * 26 for _ in range(n)]
+    sts = _streams(device, n, w, h)
+    try:
+        for t in "IPP":
+            pkts = [g.next_frame(t) for g in gens]
+            for k, pkt in enumerate(pkts):
+                oracle.decode_frame(pkt, dpbs[k], 3)
+            device.submit_batch_host(sts, pkts)
+        device.event_record(9)
+        first = device.L.e264hip_event_query(device.h, 9)
+        assert first in (0, errno.EBUSY)
+        device.sync()
+        assert device.event_done(9)
+        assert device.L.e264hip_event_query(device.h, 16) == errno.EINVAL
+        assert device.L.e264hip_event_query(device.h, -1) == errno.EINVAL
+        for k, st in enumerate(sts):
+            for slot in range(6):
+                assert np.array_equal(st.download(slot), dpbs[k][slot][:nb]), f"stream {k} slot {slot}"
+    finally:
+        for st in sts:
+            st.close()
