@@ -100,7 +100,8 @@ int  e264hip_packet_check(const void *packet, size_t bytes);
  * round (edge264_amd/driver/e264_multi.cpp). */
 int  e264hip_submit_batch_host(E264Device *dev, E264Stream *const *streams, const void *const *packets, const size_t *bytes, int n, int mode);
 /* Same for packets assembled IN PLACE in page-locked memory (e264hip_host_alloc): no staging copy, the H2D transfer reads
- * the caller's buffer, which must stay untouched until the submission has retired.  This is the path of a front end whose
+ * the caller's buffer, which must stay untouched until the submission has retired (e264hip_event_record after the call, then
+ * e264hip_event_query / e264hip_frame_wait / e264hip_device_sync).  This is the path of a front end whose
  * emitters write the finished frame straight into pinned memory (the reference's per-frame hand-over point,
  * src/edge264_headers.c:532-568).  flags: E264_SUBMIT_TRUSTED = these exact bytes have already passed
  * e264hip_packet_check (on the parser thread that produced them), the per-macroblock walk is not repeated here; the slots
