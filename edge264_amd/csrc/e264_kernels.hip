@@ -36,36 +36,6 @@
 #include "e264_dbk.h"
 
 namespace {
-// ---------------------------------------------------------------------------------
-// per-wave LDS scratch
-// ---------------------------------------------------------------------------------
-// luma tile: rows -1..15, columns -8..23 (top-right of an 8x8 block reaches x=23), 32-byte rows
-#define YT_STRIDE 32
-#define YT(y, x) ytile[((y) + 1) * YT_STRIDE + (x) + 8]
-// chroma tiles: rows -1..7, columns -4..11
-#define CT_STRIDE 16
-#define CT(p, y, x) ctile[p][((y) + 1) * CT_STRIDE + (x) + 4]
-// deblock tiles: luma rows -4..15, cols -4..15 (stride 20 bytes, dword aligned); chroma rows -4..7, cols -4..7
-#define DY_STRIDE 20
-#define DYT(y, x) dytile[((y) + 4) * DY_STRIDE + (x) + 4]
-#define DC_STRIDE 12
-#define DCT(p, y, x) dctile[p][((y) + 4) * DC_STRIDE + (x) + 4]
-
-struct __attribute__((aligned(16))) WaveLds { // reconstruction scratch of one wave
-	int16_t res[384];          // residual: luma [y*16+x], Cb at 256 [y*8+x], Cr at 320
-	int32_t tmp[256];          // IDCT intermediate (4x4: 16 blocks x 16 int32; 8x8: int16 view)
-	int32_t dc[24];            // 16 luma DC (zig order), 4 Cb, 4 Cr
-	uint8_t ytile[17 * YT_STRIDE];
-	uint8_t ctile[2][9 * CT_STRIDE];
-	uint8_t ftop[32];          // intra 8x8 filtered top  ft[-1..15] at [i+1]
-	uint8_t fleft[8];          // intra 8x8 filtered left
-	// residual inputs, staged so that the transforms never wait for memory (see coef_dma / slice_cache; the payload buffers live
-	// in IntraLds.coef)
-	__attribute__((aligned(4))) uint8_t ws[224];   // scaling lists of the cached slice: weightScale4x4[6][16], weightScale8x8[0..1][64]
-	int ws_slice;              // slice index the cache holds (-1: none)
-	int ws_idc;                // its weighted_bipred_idc
-};
-
 // -DE264_PHASE_TIMING: wall cycles of the mbpar kernel's phases, summed over all waves (tools/gpu_phase.sh reads them back
 // through e264_debug_phase_cycles).  s_memtime at the phase boundaries drains the LGKM counter, so the numbers are a
 // profile, not a benchmark.
@@ -87,705 +57,10 @@ __device__ unsigned long long g_timeline[128]; // deblock kernel, workgroup 0: s
 #define PH_ARGS
 #endif
 
-// register copy of one macroblock header (uniform: fetched with scalar loads)
-struct MbInfo {
-	int kind, flags, chroma_mode, i16_mode, slice;
-	uint8_t qp[3];
-	uint32_t coded, payload_off, modes_lo, modes_hi;
-};
-// The same header out of an LDS copy of the record (8 dwords), all lanes reading the same words (intra kernel: the
-// headers of 64 macroblocks of the row are fetched with two vector loads per lane instead of one scalar-memory round
-// trip per macroblock in the middle of the dependency chain)
-__device__ __forceinline__ MbInfo mb_from_lds(const uint32_t *rec)
-{
-	MbInfo m;
-	const uint32_t d0 = __builtin_amdgcn_readfirstlane(rec[0]), d1 = __builtin_amdgcn_readfirstlane(rec[1]);
-	const uint32_t d2 = __builtin_amdgcn_readfirstlane(rec[2]);
-	m.kind = d0 & 255; m.flags = d0 >> 8 & 255; m.qp[0] = d0 >> 16 & 255; m.qp[1] = d0 >> 24;
-	m.qp[2] = d1 & 255; m.chroma_mode = d1 >> 8 & 255; m.i16_mode = d1 >> 16 & 255;
-	m.slice = d2 >> 16;
-	m.coded = __builtin_amdgcn_readfirstlane(rec[3]); m.payload_off = __builtin_amdgcn_readfirstlane(rec[4]);
-	m.modes_lo = __builtin_amdgcn_readfirstlane(rec[5]); m.modes_hi = __builtin_amdgcn_readfirstlane(rec[6]);
-	return m;
-}
-
-// ---------------------------------------------------------------------------------
-// residual: fills lds.res for the whole macroblock
-// ---------------------------------------------------------------------------------
-// One 4x4 block per 4 lanes.  pass 1 (lane = block k, row y): dequant + horizontal butterfly
-// (edge264_residual.c:118-134); pass 2 (lane = block k, column x'): vertical butterfly, >>6,
-// saturate to int16 (residual.c:141-158).  dc_only blocks get the add_dc4x4 value (residual.c:174-187).
-// level `idx` of the coefficient area at `base` (LDS): int16, or int8 with E264_MBF_LEV8
-__device__ __forceinline__ int level_at(const uint8_t *base, int idx, bool l8)
-{
-	return l8 ? (int)((const int8_t *)base)[idx] : (int)((const int16_t *)base)[idx];
-}
-__device__ __forceinline__ void idct4x4_blocks(WaveLds &L, int nblk, uint32_t codedmask, bool use_dc, bool dc_valid,
-	const uint8_t *coef_base, bool l8, const uint8_t *wS, int qP, int dc_off, int res_off, int res_stride, int lane)
-{
-	int k = lane >> 2, y = lane & 3;
-	bool active = k < nblk;
-	bool coded = active && (codedmask >> k & 1);
-	if (coded) {
-		// coefficient blocks are packed in increasing k: offset = popcount of lower coded bits
-		const int cb = __builtin_popcount(codedmask & ((1u << k) - 1)) * 16; // levels before this block
-		int sh = qP / 6, m = qP - sh * 6;
-		int d[4];
-#pragma unroll
-		for (int x = 0; x < 4; x++) {
-			int pos = x * 4 + y;
-			int LS = wS[pos] * norm4(m, pos);
-			d[x] = (int)(((uint32_t)(level_at(coef_base, cb + pos, l8) * LS) << sh) + 8u) >> 4;
-		}
-		if (use_dc && y == 0)
-			d[0] = L.dc[dc_off + k];
-		int e0 = d[0] + d[2], e1 = d[0] - d[2], e2 = (d[1] >> 1) - d[3], e3 = (d[3] >> 1) + d[1];
-		int32_t *t = L.tmp + k * 16;
-		int add = (y == 0) ? 32 : 0;
-		t[0 * 4 + y] = e0 + e3 + add;
-		t[1 * 4 + y] = e1 + e2 + add;
-		t[2 * 4 + y] = e1 - e2 + add;
-		t[3 * 4 + y] = e0 - e3 + add;
-	}
-	wave_sync();
-	if (active) {
-		int x = y; // second role of the low lane bits: column x'
-		int16_t *r;
-		if (nblk == 16) // luma: block k in zig order inside the 16x16 tile
-			r = L.res + res_off + BYf(k) * res_stride + BXf(k) + x;
-		else            // chroma: plane k>>2 (64 samples each), 2x2 blocks of an 8x8 tile
-			r = L.res + res_off + (k >> 2) * 64 + ((k >> 1) & 1) * 4 * res_stride + (k & 1) * 4 + x;
-		if (coded) {
-			const int32_t *t = L.tmp + k * 16 + x * 4;
-			int f0 = t[0], f1 = t[1], f2 = t[2], f3 = t[3];
-			int g0 = f0 + f2, g1 = f0 - f2, g2 = (f1 >> 1) - f3, g3 = (f3 >> 1) + f1;
-			r[0 * res_stride] = (int16_t)sat16((g0 + g3) >> 6);
-			r[1 * res_stride] = (int16_t)sat16((g1 + g2) >> 6);
-			r[2 * res_stride] = (int16_t)sat16((g1 - g2) >> 6);
-			r[3 * res_stride] = (int16_t)sat16((g0 - g3) >> 6);
-		} else if (dc_valid) {
-			int16_t v = (int16_t)((L.dc[dc_off + k] + 32) >> 6);
-			r[0 * res_stride] = v; r[1 * res_stride] = v; r[2 * res_stride] = v; r[3 * res_stride] = v;
-		}
-	}
-	wave_sync();
-}
-
-// 8x8: lanes 0..31, (block b, lane index j).  int16 arithmetic with wraparound (residual.c:250-316).
-__device__ __forceinline__ void idct8_1d(int16_t d[8])
-{
-	int16_t d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5], d6 = d[6], d7 = d[7];
-	int16_t e0 = (int16_t)(d0 + d4);
-	int16_t e1 = (int16_t)(d5 - d3 - (int16_t)((d7 >> 1) + d7));
-	int16_t e2 = (int16_t)(d0 - d4);
-	int16_t e3 = (int16_t)(d1 + d7 - (int16_t)((d3 >> 1) + d3));
-	int16_t e4 = (int16_t)((d2 >> 1) - d6);
-	int16_t e5 = (int16_t)(d7 - d1 + (int16_t)((d5 >> 1) + d5));
-	int16_t e6 = (int16_t)((d6 >> 1) + d2);
-	int16_t e7 = (int16_t)(d3 + d5 + (int16_t)((d1 >> 1) + d1));
-	int16_t f0 = (int16_t)(e0 + e6);
-	int16_t f1 = (int16_t)((e7 >> 2) + e1);
-	int16_t f2 = (int16_t)(e2 + e4);
-	int16_t f3 = (int16_t)((e5 >> 2) + e3);
-	int16_t f4 = (int16_t)(e2 - e4);
-	int16_t f5 = (int16_t)((e3 >> 2) - e5);
-	int16_t f6 = (int16_t)(e0 - e6);
-	int16_t f7 = (int16_t)(e7 - (e1 >> 2));
-	d[0] = (int16_t)(f0 + f7); d[1] = (int16_t)(f2 + f5); d[2] = (int16_t)(f4 + f3); d[3] = (int16_t)(f6 + f1);
-	d[4] = (int16_t)(f6 - f1); d[5] = (int16_t)(f4 - f3); d[6] = (int16_t)(f2 - f5); d[7] = (int16_t)(f0 - f7);
-}
-
-__device__ __forceinline__ void idct8x8_blocks(WaveLds &L, uint32_t coded, const uint8_t *coef_base, bool l8, const uint8_t *wS, int qP, int lane)
-{
-	int b = lane >> 3, j = lane & 7;
-	bool on = lane < 32 && (coded >> (b * 4) & 1);
-	int16_t *t16 = (int16_t *)L.tmp;
-	if (on) {
-		int nb = 0;
-		for (int i = 0; i < b; i++) nb += coded >> (i * 4) & 1;
-		int div = qP / 6, m = qP - div * 6;
-		int16_t d[8];
-#pragma unroll
-		for (int i = 0; i < 8; i++) {
-			int pos = i * 8 + j;
-			int LS = wS[pos] * norm8(m, pos);
-			const int lev = level_at(coef_base, nb * 64 + pos, l8);
-			if (div < 6)
-				d[i] = (int16_t)sat16((lev * LS + (1 << (5 - div))) >> (6 - div));
-			else
-				d[i] = (int16_t)(lev * (int)(int16_t)(LS << (div - 6)));
-		}
-		idct8_1d(d);
-		// transposed read in pass 2: element [i][j]; +32 lands on the new vector 0 = all elements with j == 0
-#pragma unroll
-		for (int i = 0; i < 8; i++)
-			t16[b * 64 + i * 8 + j] = (int16_t)(d[i] + (j == 0 ? 32 : 0));
-	}
-	wave_sync();
-	if (on) {
-		int i = j; // this lane now owns vector-lane i = pixel column i
-		int16_t d[8];
-#pragma unroll
-		for (int jj = 0; jj < 8; jj++)
-			d[jj] = t16[b * 64 + i * 8 + jj];
-		idct8_1d(d);
-		int16_t *r = L.res + BYf(b * 4) * 16 + BXf(b * 4) + i;
-#pragma unroll
-		for (int jj = 0; jj < 8; jj++)
-			r[jj * 16] = (int16_t)(d[jj] >> 6);
-	}
-	wave_sync();
-}
-
-// Residual inputs without a memory round trip inside the transforms:
-//   coef_dma      the macroblock's payload (<= 816 bytes) goes from the packet straight into L.coef[buf] by LDS-DMA
-//                 (global_load_lds_dword: 4 instructions of 64 dwords, no register in between), requested while the
-//                 PREVIOUS macroblock of the wave is reconstructed; the consumer waits with vmcnt(0) at the top of its
-//                 macroblock, thousands of cycles later.  (Round 2: four dword loads per lane into registers at the top of the
-//                 same macroblock, then a copy into LDS: the latency stood at the head of every macroblock's chain, and
-//                 keeping a second set of registers for the next macroblock spilled.)
-//   slice_cache   scaling lists + weighted_bipred_idc of the current slice in LDS, reloaded when the
-//                 slice index changes.
-__device__ __forceinline__ int coef_dwords(const MbInfo &m)
-{
-	if (m.kind == E264_MB_ABSENT || m.kind == E264_MB_PCM || m.coded == 0)
-		return 0;
-	const uint32_t c = m.coded;
-	int ac = __builtin_popcount(c >> 16 & 0xff) * 32;
-	ac += (m.kind != E264_MB_I16x16 && (m.flags & E264_MBF_T8x8)) ? __builtin_popcount(c & 0x1111) * 128 : __builtin_popcount(c & 0xffff) * 32;
-	if (m.flags & E264_MBF_LEV8) ac >>= 1; // one byte per AC level
-	return (((c & E264_CODED_LUMA_DC) ? 32 : 0) + ((c & E264_CODED_CHROMA_DC) ? 16 : 0) + ac + 3) >> 2;
-}
-__device__ __forceinline__ void coef_dma(int16_t *dst, const FrameCtx &f, const MbInfo &m, int lane)
-{ // dst: one of the wave's two payload buffers (uniform address); lanes beyond the payload are masked out and write nothing
-	const int ndw = coef_dwords(m); // uniform
-	if (ndw == 0)
-		return;
-	const gu32 *src = (const gu32 *)(f.payload + m.payload_off) + lane;
-	typedef __attribute__((address_space(3))) void *lds_p;
-	if (lane < ndw) __builtin_amdgcn_global_load_lds(src, (lds_p)dst, 4, 0, 0);
-	if (ndw > 64 && 64 + lane < ndw) __builtin_amdgcn_global_load_lds(src + 64, (lds_p)(dst + 128), 4, 0, 0);
-	if (ndw > 128 && 128 + lane < ndw) __builtin_amdgcn_global_load_lds(src + 128, (lds_p)(dst + 256), 4, 0, 0);
-	if (ndw > 192 && 192 + lane < ndw) __builtin_amdgcn_global_load_lds(src + 192, (lds_p)(dst + 384), 4, 0, 0);
-}
-// every LDS-DMA transfer this wave has requested has landed (they were requested a macroblock ago: no stall in steady state)
-__device__ __forceinline__ void coef_dma_wait()
-{
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	wave_sync();
-}
-__device__ __forceinline__ void slice_cache(WaveLds &L, const FrameCtx &f, int slice, int lane)
-{
-	if (__builtin_amdgcn_readfirstlane(L.ws_slice) == slice) // uniform
-		return;
-	cslice_t s = f.slices + slice;
-	wave_sync();
-	const gu32 *g4 = (const gu32 *)((const gu8 *)s + offsetof(E264SliceParams, weightScale4x4));
-	const gu32 *g8 = (const gu32 *)((const gu8 *)s + offsetof(E264SliceParams, weightScale8x8));
-	if (lane < 24) ((uint32_t *)L.ws)[lane] = g4[lane];
-	else if (lane < 56) ((uint32_t *)L.ws)[lane] = g8[lane - 24];
-	if (lane == 0) { L.ws_slice = slice; L.ws_idc = s->weighted_bipred_idc; }
-	wave_sync();
-}
-
-// coefs holds the macroblock's payload (coef_dma + coef_dma_wait), the slice cache is valid (slice_cache)
-__device__ __forceinline__ void compute_residual(WaveLds &L, const int16_t *coefs, const FrameCtx &f, const MbInfo &m, int lane)
-{
-	// zero the residual tile (384 int16 = 192 dwords)
-	uint32_t *rz = (uint32_t *)L.res;
-	rz[lane] = 0; rz[lane + 64] = 0; rz[lane + 128] = 0;
-	const uint32_t coded = m.coded;
-	const bool inter = m.kind == E264_MB_INTER;
-	const int16_t *pl = coefs;
-	const int16_t *ldc = nullptr, *cdc = nullptr;
-	if (coded & E264_CODED_LUMA_DC) { ldc = pl; pl += 16; }
-	if (coded & E264_CODED_CHROMA_DC) { cdc = pl; pl += 8; }
-	const uint8_t *co = (const uint8_t *)pl;          // the AC blocks: int16 levels, or int8 (E264_MBF_LEV8)
-	const bool l8 = m.flags & E264_MBF_LEV8;
-	const int lsz = l8 ? 1 : 2;                         // bytes per level
-	const uint8_t *ws4 = L.ws, *ws8 = L.ws + 96;
-	if (lane < 24) L.dc[lane] = 0;
-	wave_sync();
-	if (!coded) return;
-
-	// DC transforms (residual.c:352-399 and :456-480): one output per lane
-	if (ldc && lane < 16) {
-		int r = lane >> 2, l = lane & 3, acc = 0;
-		// f[r][l] = sum_m sum_i A[r][m] A[l][i] c[4i+m], A = rows {++++, ++--, +--+, +-+-}
-#pragma unroll
-		for (int i = 0; i < 4; i++)
-#pragma unroll
-			for (int mm = 0; mm < 4; mm++) {
-				int v = ldc[4 * i + mm];
-				bool neg = (((0xA6C0 >> (4 * r)) >> mm) ^ ((0xA6C0 >> (4 * l)) >> i)) & 1; // rows of A: bit set => negative
-				acc += neg ? -v : v;
-			}
-		int qP = m.qp[0];
-		int LS = (ws4[0] * norm4(qP % 6, 0)) << (qP / 6);
-		int k = (r >> 1) * 8 + (l >> 1) * 4 + (r & 1) * 2 + (l & 1);
-		L.dc[k] = (int)((uint32_t)acc * (uint32_t)LS + 32u) >> 6;
-	}
-	if (cdc && lane >= 16 && lane < 24) {
-		int n = lane & 3, pc = (lane >> 2) & 1; // pc: 0 Cb, 1 Cr
-		int c0 = cdc[pc], c4 = cdc[4 + pc], c2 = cdc[2 + pc], c6 = cdc[6 + pc];
-		int v = n == 0 ? c0 + c4 + c2 + c6 : n == 1 ? c0 - c4 + c2 - c6 : n == 2 ? c0 + c4 - c2 - c6 : c0 - c4 - c2 + c6;
-		int qP = pc ? m.qp[2] : m.qp[1];
-		int LS = (ws4[(1 + pc + (inter ? 3 : 0)) * 16] * norm4(qP % 6, 0)) << (qP / 6);
-		L.dc[16 + pc * 4 + n] = (int)((uint32_t)v * (uint32_t)LS) >> 5;
-	}
-	wave_sync();
-
-	// luma
-	if (m.kind == E264_MB_I16x16) {
-		if (coded & (0xffff | E264_CODED_LUMA_DC))
-			idct4x4_blocks(L, 16, coded & 0xffff, true, ldc != nullptr, co, l8, ws4, m.qp[0], 0, 0, 16, lane);
-		co += __builtin_popcount(coded & 0xffff) * 16 * lsz;
-	} else if (m.flags & E264_MBF_T8x8) {
-		if (coded & 0x1111)
-			idct8x8_blocks(L, coded, co, l8, ws8 + (inter ? 64 : 0), m.qp[0], lane);
-		co += __builtin_popcount(coded & 0x1111) * 64 * lsz;
-	} else {
-		if (coded & 0xffff)
-			idct4x4_blocks(L, 16, coded & 0xffff, false, false, co, l8, ws4 + (inter ? 3 : 0) * 16, m.qp[0], 0, 0, 16, lane);
-		co += __builtin_popcount(coded & 0xffff) * 16 * lsz;
-	}
-	// chroma: 8 blocks, Cb 0..3 then Cr 4..7; different QP / scaling list per plane
-	if (coded & (0xff0000 | E264_CODED_CHROMA_DC)) {
-		int k = lane >> 2;
-		int pc = (k >> 2) & 1;
-		idct4x4_blocks(L, 8, coded >> 16 & 0xff, true, cdc != nullptr, co, l8, ws4 + (1 + pc + (inter ? 3 : 0)) * 16, pc ? m.qp[2] : m.qp[1], 16, 256, 8, lane);
-	}
-}
-
-// ---------------------------------------------------------------------------------
-// intra prediction (modes: edge264_internal.h:564-634; U(navailable) suffixes A left, B top,
-// C top-right, D top-left)
-// ---------------------------------------------------------------------------------
-#define LP(l, m, r) (((l) + 2 * (m) + (r) + 2) >> 2)
-#ifndef E264_I4_UNROLL
-#define E264_I4_UNROLL 10 // steps of the Intra4x4 anti-diagonal loop unrolled together: all ten (what a lane does in a step is then a handful of
-                          // loop-invariant registers; affordable since E264_INTRA_LAUNDER freed the registers: round 2 spilled with it)
-#endif
-#include "e264_intra_tab.h"
-
-// neighbours of the macroblock from the frame (un-deblocked, pass R) into the tiles.
-// Out-of-frame positions are never dereferenced; the remapped modes never use them.
-// In two steps, so that the frame reads are in flight while the residual is computed: issue (loads only, nothing may
-// use the values) and commit (values -> tiles).
-struct IntraNb { uint32_t y, c; bool oky, okc; };
-// ONE predicated load per plane group and lane (address and predicate selected by the lane's role), nothing cleared first:
-// the four role branches used to write the same two registers one after the other, which serialised them into two extra
-// memory round trips per intra macroblock (s_waitcnt vmcnt(0) between the loads).
-__device__ __forceinline__ IntraNb issue_intra_neighbours(const FrameCtx &f, int mbx, int mby, int lane)
-{
-	IntraNb n;
-	const bool left = lane >= 32 && lane < 48;
-	// luma: top row x = -1..23 (lanes 0..24), left column (lanes 32..47)
-	const bool topY = lane < 25;
-	const int x = lane - 1, gx = mbx * 16 + x;
-	n.oky = topY ? (mby > 0 && gx >= 0 && gx < f.W) : (left && mbx > 0);
-	const gu8 *Y = f.cur + (size_t)(mby * 16) * f.sY + mbx * 16;
-	const ptrdiff_t offY = topY ? (ptrdiff_t)x - f.sY : (ptrdiff_t)(lane - 32) * f.sY - 1;
-	if (n.oky) n.y = Y[offY];
-	// chroma: top rows of both planes (lanes 0..17: plane lane / 9, x = lane % 9 - 1), left columns (lanes 32..47)
-	const bool topC = lane < 18;
-	const int xc = lane % 9 - 1;
-	const int pl = topC ? lane / 9 : (lane - 32) >> 3;
-	n.okc = topC ? (mby > 0 && mbx * 8 + xc >= 0) : (left && mbx > 0);
-	const gu8 *C = plane_base(f, f.cur, 1 + (pl & 1)) + (size_t)(mby * 8) * f.sC + mbx * 8;
-	const ptrdiff_t offC = topC ? (ptrdiff_t)xc - f.sC : (ptrdiff_t)(lane & 7) * f.sC - 1;
-	if (n.okc) n.c = C[offC];
-	return n;
-}
-__device__ __forceinline__ void commit_intra_neighbours(WaveLds &L, const IntraNb &n, int lane)
-{ // unavailable neighbours read as 0 (never used: the parser resolved the modes against availability)
-	const bool left = lane >= 32 && lane < 48;
-	const uint8_t vy = n.oky ? (uint8_t)n.y : 0, vc = n.okc ? (uint8_t)n.c : 0;
-	if (lane < 25) L.YT(-1, lane - 1) = vy;
-	else if (left) L.YT(lane - 32, -1) = vy;
-	if (lane < 18) L.CT(lane / 9, -1, lane % 9 - 1) = vc;
-	else if (left) L.CT((lane - 32) >> 3, lane & 7, -1) = vc;
-	wave_sync();
-}
-
-// One sample of a 4x4 block from the tap table (tools/gen_intra4x4_table.py): one table read and three sample reads per
-// lane, the same instructions for every directional mode.  The 14-way switch below (kept as the readable statement of the
-// modes; the generator checks the table against the same formulas) ran as two divergent paths per step -- one per block
-// of the step -- each a chain of dependent byte reads: 46 % of the kernel's time on I pictures.
-// tab: c_i4tab in LDS; p = y * 4 + x.
-// e: the table word tab[mode * 16 + p], fetched by the caller ONE STEP AHEAD (it depends on the mode only, not on samples: read
-// where it is used it was a third LDS round trip in every step of the chain table word -> samples -> store)
-__device__ __forceinline__ int intra4x4_tab(const WaveLds &L, uint32_t e, int X0, int Y0, int mode)
-{
-	const uint8_t *org = &L.YT(Y0 - 1, X0 - 1);
-	const bool dc = mode >= 2 && mode <= 5;
-	// the three taps of the directional modes are requested by every lane (DC lanes: table word 0, a valid position) BEFORE the
-	// DC modes' branch, so that their latency runs under it instead of behind it
-	const int a = org[e & 255], b = org[e >> 8 & 255], c = org[e >> 16 & 255];
-	int vd = 128;
-	if (dc) { // DC variants: top and left, top, left, none (edge264_intra.c DC modes)
-		const uint32_t w = *(const uint32_t *)(org + 1);
-		const int st = (int)__builtin_amdgcn_sad_u8(w, 0, 0); // the four samples above, summed
-		const int sl = org[YT_STRIDE] + org[2 * YT_STRIDE] + org[3 * YT_STRIDE] + org[4 * YT_STRIDE];
-		vd = mode == 2 ? (st + sl + 4) >> 3 : mode == 3 ? (st + 2) >> 2 : mode == 4 ? (sl + 2) >> 2 : 128;
-	}
-	const int ty = (int)(e >> 24), sh = ty >> 3;
-	const int v = (a + (ty & 3) * b + ((ty & 4) ? c : 0) + ((1 << sh) >> 1)) >> sh;
-	return dc ? vd : v;
-}
-
-// one 4x4 block, lanes 0..15 = (y = lane>>2, x = lane&3); reads/writes the luma tile
-__device__ __forceinline__ int intra4x4_px(const WaveLds &L, int X0, int Y0, int mode, int x, int y)
-{
-#define T(i) ((int)L.YT(Y0 - 1, X0 + (i)))
-#define Lf(i) ((int)L.YT(Y0 + (i), X0 - 1))
-#define TR(i) ((i) < 4 || has_tr ? T(i) : T(3))
-	const bool has_tr = (mode == 6 || mode == 11);
-	switch (mode) {
-	default:
-	case 0: return T(x);
-	case 1: return Lf(y);
-	case 2: return (T(0) + T(1) + T(2) + T(3) + Lf(0) + Lf(1) + Lf(2) + Lf(3) + 4) >> 3;
-	case 3: return (T(0) + T(1) + T(2) + T(3) + 2) >> 2;
-	case 4: return (Lf(0) + Lf(1) + Lf(2) + Lf(3) + 2) >> 2;
-	case 5: return 128;
-	case 6: case 7:
-		return (x == 3 && y == 3) ? (TR(6) + 3 * TR(7) + 2) >> 2 : LP(TR(x + y), TR(x + y + 1), TR(x + y + 2));
-	case 8:
-		if (x > y) return LP(T(x - y - 2), T(x - y - 1), T(x - y));
-		if (x < y) return LP(y - x - 2 < 0 ? T(-1) : Lf(y - x - 2), Lf(y - x - 1), Lf(y - x));
-		return LP(T(0), T(-1), Lf(0));
-	case 9: {
-		int z = 2 * x - y, i = x - (y >> 1);
-		if (z >= 0 && !(z & 1)) return (T(i - 1) + T(i) + 1) >> 1;
-		if (z >= 0) return LP(T(i - 2), T(i - 1), T(i));
-		if (z == -1) return LP(Lf(0), T(-1), T(0));
-		return LP(Lf(y - 1), Lf(y - 2), y - 3 < 0 ? T(-1) : Lf(y - 3)); }
-	case 10: {
-		int z = 2 * y - x, i = y - (x >> 1);
-#define L_(j) ((j) < 0 ? T(-1) : Lf(j))
-		if (z >= 0 && !(z & 1)) return (L_(i - 1) + L_(i) + 1) >> 1;
-		if (z >= 0) return LP(L_(i - 2), L_(i - 1), L_(i));
-		if (z == -1) return LP(Lf(0), T(-1), T(0));
-		return LP(T(x - 1), T(x - 2), T(x - 3));
-#undef L_
-		}
-	case 11: case 12: {
-		int i = x + (y >> 1);
-		return (y & 1) ? LP(TR(i), TR(i + 1), TR(i + 2)) : (TR(i) + TR(i + 1) + 1) >> 1; }
-	case 13: {
-		int z = x + 2 * y, i = y + (x >> 1);
-		if (z > 5) return Lf(3);
-		if (z == 5) return (Lf(2) + 3 * Lf(3) + 2) >> 2;
-		if (z & 1) return LP(Lf(i), Lf(i + 1), Lf(i + 2));
-		return (Lf(i) + Lf(i + 1) + 1) >> 1; }
-	}
-#undef T
-#undef Lf
-#undef TR
-}
-
-__constant__ int8_t c_i8spec[32] = {0, 0, 0, 0, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 5, 5, 6, 7, 7, 7, 7, 8, 8};
-__constant__ int8_t c_i8unav[32] = {0, 4, 8, 12, 0, 8, 0, 1, 5, 9, 13, 2, 10, 4, 8, 12, 3, 0, 4, 8, 12, 0, 4, 0, 4, 0, 0, 4, 8, 12, 0, 8};
-
-// one 8x8 block: all 64 lanes = (y = lane>>3, x = lane&7).  8.3.2.2.1 filtering into L.ftop/L.fleft first.
-__device__ __forceinline__ void intra8x8_block(WaveLds &L, int X0, int Y0, int mode, int lane)
-{
-	const int sm = c_i8spec[mode], un = c_i8unav[mode];
-	const bool useA = !(un & 1) && (sm == 1 || sm == 2 || sm == 4 || sm == 5 || sm == 6 || sm == 8);
-	const bool useB = !(un & 2) && (sm == 0 || sm == 2 || sm == 3 || sm == 4 || sm == 5 || sm == 6 || sm == 7);
-	const bool useC = useB && !(un & 4) && sm != 6;
-	const bool cornerAvail = !(un & 8) && (useA || useB);
-#define T(i) ((int)L.YT(Y0 - 1, X0 + (i)))
-#define TC(i) ((i) < 8 || useC ? T(i) : T(7))
-#define Lf(i) ((int)L.YT(Y0 + (i), X0 - 1))
-	if (lane < 16) { // filtered top ft[0..15]
-		int i = lane, v = 0;
-		if (useB) {
-			if (i == 0) v = cornerAvail ? LP(T(-1), T(0), T(1)) : (3 * T(0) + T(1) + 2) >> 2;
-			else if (i == 15) v = (TC(14) + 3 * TC(15) + 2) >> 2;
-			else v = LP(TC(i - 1), TC(i), TC(i + 1));
-		}
-		L.ftop[i + 1] = (uint8_t)v;
-	} else if (lane < 24) { // filtered left
-		int i = lane - 16, v = 0;
-		if (useA) {
-			if (i == 0) v = cornerAvail ? LP(T(-1), Lf(0), Lf(1)) : (3 * Lf(0) + Lf(1) + 2) >> 2;
-			else if (i == 7) v = (Lf(6) + 3 * Lf(7) + 2) >> 2;
-			else v = LP(Lf(i - 1), Lf(i), Lf(i + 1));
-		}
-		L.fleft[i] = (uint8_t)v;
-	} else if (lane == 24) {
-		int v = 0;
-		if (cornerAvail) {
-			if (!useB) v = (3 * T(-1) + Lf(0) + 2) >> 2;
-			else if (!useA) v = (3 * T(-1) + T(0) + 2) >> 2;
-			else v = LP(T(0), T(-1), Lf(0));
-		}
-		L.ftop[0] = (uint8_t)v;
-	}
-#undef T
-#undef TC
-#undef Lf
-	wave_sync();
-	const int x = lane & 7, y = lane >> 3;
-#define FT(i) ((int)L.ftop[(i) + 1])
-#define FL(i) ((i) < 0 ? (int)L.ftop[0] : (int)L.fleft[i])
-	int v;
-	if (mode == 16) v = 128;
-	else switch (sm) {
-	default:
-	case 0: v = FT(x); break;
-	case 1: v = FL(y); break;
-	case 2: {
-		int st = 0, sl = 0;
-#pragma unroll
-		for (int i = 0; i < 8; i++) { st += FT(i); sl += FL(i); }
-		v = useA && useB ? (st + sl + 8) >> 4 : useB ? (st + 4) >> 3 : useA ? (sl + 4) >> 3 : 128;
-		} break;
-	case 3: v = (x == 7 && y == 7) ? (FT(14) + 3 * FT(15) + 2) >> 2 : LP(FT(x + y), FT(x + y + 1), FT(x + y + 2)); break;
-	case 4:
-		if (x > y) v = LP(FT(x - y - 2), FT(x - y - 1), FT(x - y));
-		else if (x < y) v = LP(FL(y - x - 2), FL(y - x - 1), FL(y - x));
-		else v = LP(FT(0), FT(-1), FL(0));
-		break;
-	case 5: {
-		int z = 2 * x - y, i = x - (y >> 1);
-		if (z >= 0 && !(z & 1)) v = (FT(i - 1) + FT(i) + 1) >> 1;
-		else if (z >= 0) v = LP(FT(i - 2), FT(i - 1), FT(i));
-		else if (z == -1) v = LP(FL(0), FT(-1), FT(0));
-		else v = LP(FL(y - 2 * x - 1), FL(y - 2 * x - 2), FL(y - 2 * x - 3));
-		} break;
-	case 6: {
-		int z = 2 * y - x, i = y - (x >> 1);
-		if (z >= 0 && !(z & 1)) v = (FL(i - 1) + FL(i) + 1) >> 1;
-		else if (z >= 0) v = LP(FL(i - 2), FL(i - 1), FL(i));
-		else if (z == -1) v = LP(FL(0), FT(-1), FT(0));
-		else v = LP(FT(x - 2 * y - 1), FT(x - 2 * y - 2), FT(x - 2 * y - 3));
-		} break;
-	case 7: {
-		int i = x + (y >> 1);
-		v = (y & 1) ? LP(FT(i), FT(i + 1), FT(i + 2)) : (FT(i) + FT(i + 1) + 1) >> 1;
-		} break;
-	case 8: {
-		int z = x + 2 * y, i = y + (x >> 1);
-		if (z > 13) v = FL(7);
-		else if (z == 13) v = (FL(6) + 3 * FL(7) + 2) >> 2;
-		else if (z & 1) v = LP(FL(i), FL(i + 1), FL(i + 2));
-		else v = (FL(i) + FL(i + 1) + 1) >> 1;
-		} break;
-	}
-#undef FT
-#undef FL
-	// add residual (add_idct8x8 tail, residual.c:318-342) and write the tile
-	int rres = L.res[(Y0 + y) * 16 + X0 + x];
-	wave_sync();
-	L.YT(Y0 + y, X0 + x) = (uint8_t)clip255(w16(v + rres));
-	wave_sync();
-}
-
-// Intra 16x16 in the pixel layout: returns 4 predicted samples for (row Yr, cols X..X+3)
-__device__ __forceinline__ void intra16x16_pred(const WaveLds &L, int mode, int X, int Yr, int out[4])
-{
-#define T(i) ((int)L.YT(-1, (i)))
-#define Lf(i) ((int)L.YT((i), -1))
-	switch (mode) {
-	default:
-	case 0: for (int i = 0; i < 4; i++) out[i] = T(X + i); return;
-	case 1: for (int i = 0; i < 4; i++) out[i] = Lf(Yr); return;
-	case 2: case 3: case 4: case 5: {
-		int st = 0, sl = 0;
-		if (mode == 2 || mode == 3) for (int i = 0; i < 4; i++) st = (int)__builtin_amdgcn_sad_u8(*(const uint32_t *)&L.YT(-1, 4 * i), 0, (uint32_t)st); // the row above, four samples per instruction
-		if (mode == 2 || mode == 4) for (int i = 0; i < 16; i++) sl += Lf(i);
-		int v = mode == 2 ? (st + sl + 16) >> 5 : mode == 3 ? (st + 8) >> 4 : mode == 4 ? (sl + 8) >> 4 : 128;
-		for (int i = 0; i < 4; i++) out[i] = v;
-		return; }
-	case 6: {
-		int Hh = 0, V = 0;
-		for (int i = 0; i < 8; i++) {
-			Hh += (i + 1) * (T(8 + i) - (i == 7 ? T(-1) : T(6 - i)));
-			V += (i + 1) * (Lf(8 + i) - (i == 7 ? T(-1) : Lf(6 - i)));
-		}
-		int a = 16 * (Lf(15) + T(15)), b = (5 * Hh + 32) >> 6, c = (5 * V + 32) >> 6;
-		for (int i = 0; i < 4; i++) out[i] = clip255((a + b * (X + i - 7) + c * (Yr - 7) + 16) >> 5);
-		return; }
-	}
-#undef T
-#undef Lf
-}
-
-// Intra chroma for plane p, sample (x,y)
-__device__ __forceinline__ int intra_chroma_px(const WaveLds &L, int p, int mode, int x, int y)
-{
-#define T(i) ((int)L.CT(p, -1, (i)))
-#define Lf(i) ((int)L.CT(p, (i), -1))
-	switch (mode) {
-	default:
-	case 0: case 1: case 2: case 3: {
-		if (mode == 3) return 128;
-		int bx = x >> 2, by = y >> 2;
-		int t = 0, l = 0;
-		t = (int)__builtin_amdgcn_sad_u8(*(const uint32_t *)&L.CT(p, -1, bx * 4), 0, 0);
-		for (int i = 0; i < 4; i++) l += Lf(by * 4 + i);
-		if (mode == 1) return (t + 2) >> 2;
-		if (mode == 2) return (l + 2) >> 2;
-		if (bx == by) return (t + l + 4) >> 3;
-		return bx ? (t + 2) >> 2 : (l + 2) >> 2; }
-	case 4: return Lf(y);
-	case 5: return T(x);
-	case 6: {
-		int Hh = 0, V = 0;
-		for (int i = 0; i < 4; i++) {
-			Hh += (i + 1) * (T(4 + i) - (i == 3 ? T(-1) : T(2 - i)));
-			V += (i + 1) * (Lf(4 + i) - (i == 3 ? T(-1) : Lf(2 - i)));
-		}
-		int a = 16 * (Lf(7) + T(7)), b = (34 * Hh + 32) >> 6, c = (34 * V + 32) >> 6;
-		return clip255((a + b * (x - 3) + c * (y - 3) + 16) >> 5); }
-	}
-#undef T
-#undef Lf
-}
-
-// ---------------------------------------------------------------------------------
-// reconstruction of one macroblock by one wave
-// ---------------------------------------------------------------------------------
-// WHICH: 1 = inter and PCM macroblocks only (no dependency inside the frame), 2 = intra only, 3 = all
-// coefs: this macroblock's payload (the caller has waited for it: coef_dma_wait).
-// next_rec (may be null): LDS copy of the record of the macroblock this wave reconstructs next; its header goes to mn and its
-// payload is requested into coefs_next -- the transfer then has the whole reconstruction (thousands of cycles) to land instead of
-// standing at the head of the next macroblock's chain.
-// What a lane is in every part of recon_mb (pixel, block, tile and frame addresses) is hoisted out of the macroblock loop by the
-// compiler: ~130 registers where a 16-wave workgroup has 128.  Hiding the lane number from it in ONE part makes that part derive its
-// addresses again per macroblock (a few VALU instructions) and the rest fit: bit 0 = the Intra8x8 blocks, 1 = the neighbour fetch,
-// 2 = the residual, 3 = the neighbour commit.  Default 5: no spill left even with the Intra4x4 loop fully unrolled
-// (profiles/r03_ablations.txt item 14: the bench GOP's intra time unchanged, 4x4-only pictures +12 %).
-#ifndef E264_INTRA_LAUNDER
-#define E264_INTRA_LAUNDER 5
-#endif
-__device__ __forceinline__ int relane(int lane) { asm volatile("" : "+v"(lane)); return lane; }
-
-template <int WHICH>
-__device__ __forceinline__ void recon_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, int mbx, int mby, int lane, const uint32_t *i4tab, const int16_t *coefs,
-	int16_t *coefs_next, const uint32_t *next_rec, MbInfo &mn PH_PARAMS)
-{
-	if (m.kind == E264_MB_ABSENT)
-		return;
-	const bool par = m.kind == E264_MB_INTER || m.kind == E264_MB_PCM;
-	if ((WHICH == 1 && !par) || (WHICH == 2 && par))
-		return;
-	cslice_t s = f.slices + m.slice;
-	const gu8 *pl = f.payload + m.payload_off;
-	// pixel layout
-	const int k = lane >> 2, r = lane & 3;
-	const int X = BXf(k), Yr = BYf(k) + r;
-	gu8 *dY = f.cur + (size_t)(mby * 16 + Yr) * f.sY + mbx * 16 + X;
-	const int cpl = lane >> 5, cy = (lane >> 2) & 7, cx = (lane & 3) * 2;
-	gu8 *dC = plane_base(f, f.cur, 1 + cpl) + (size_t)(mby * 8 + cy) * f.sC + mbx * 8 + cx;
-
-	if (m.kind == E264_MB_PCM) { // edge264_slice.c:914-935
-		*(gu32 *)dY = *(const gu32 *)(pl + Yr * 16 + X);
-		*(gu16 *)dC = *(const gu16 *)(pl + 256 + cpl * 64 + cy * 8 + cx);
-		return;
-	}
-	const uint32_t modes_lo = m.modes_lo, modes_hi = m.modes_hi;
-	IntraNb nbv;
-	nbv.oky = nbv.okc = false;
-	if (WHICH != 1 && m.kind != E264_MB_INTER)
-		nbv = issue_intra_neighbours(f, mbx, mby, (E264_INTRA_LAUNDER & 2) ? relane(lane) : lane); // in flight during the residual
-	PH(2);
-	if (next_rec) { // (uniform)
-		mn = mb_from_lds(next_rec);
-		coef_dma(coefs_next, f, mn, lane);
-	}
-	slice_cache(L, f, m.slice, lane);
-	PH(3);
-	compute_residual(L, coefs, f, m, (E264_INTRA_LAUNDER & 4) ? relane(lane) : lane);
-	PH(4);
-
-	int pY[4], pC[2];
-	bool tile_luma = false;
-	if (WHICH != 1 && m.kind != E264_MB_INTER) {
-		commit_intra_neighbours(L, nbv, (E264_INTRA_LAUNDER & 8) ? relane(lane) : lane);
-		PH(5);
-		if (m.kind == E264_MB_I16x16) {
-			intra16x16_pred(L, m.i16_mode, X, Yr, pY);
-		} else if (m.kind == E264_MB_I4x4) { // edge264_slice.c:615-635: predict, add residual, next block
-			tile_luma = true;
-			// The 16 blocks are decoded in 10 steps instead of 16: block (x,y) of the 4x4 grid only needs its left, top,
-			// top-left and (when the standard counts it as available, i.e. when it precedes in zig-zag order) top-right
-			// neighbours, all of which belong to earlier anti-diagonals x + 2y.  Lanes 0..15 take the first block of a
-			// diagonal, lanes 16..31 the second one; the modes are already resolved against availability by the parser.
-			// zig-zag indices per step: (0,-)(1,-)(4,2)(5,3)(6,8)(7,9)(12,10)(13,11)(14,-)(15,-)
-			const uint64_t firsts = 0xfedc765410ull, seconds = 0xffba9832ffull; // one nibble per step
-			const int half = lane >> 4, hl16 = lane & 15;
-			const uint64_t order = half ? seconds : firsts;
-			// the lane's block and mode at step t (lanes that idle take block 0: valid addresses, nothing stored)
-			auto step_mode = [&](int t, int &bb) {
-				const bool on_ = lane < 32 && !(half == 1 && (t < 2 || t > 7));
-				bb = on_ ? (int)(order >> (4 * t) & 15) : 0;
-				return (int)(((bb < 8 ? modes_lo : modes_hi) >> (4 * (bb & 7))) & 15);
-			};
-			int bb_n;
-			int mode_n = step_mode(0, bb_n);
-			uint32_t e_n = i4tab[mode_n * 16 + hl16];
-#pragma unroll E264_I4_UNROLL
-			for (int t = 0; t < 10; t++) {
-				const bool on = lane < 32 && !(half == 1 && (t < 2 || t > 7));
-				const int bb = bb_n, mode = mode_n;
-				const uint32_t e = e_n;
-				if (t < 9) { // next step's table word: in flight during this step's sample reads
-					mode_n = step_mode(t + 1, bb_n);
-					e_n = i4tab[mode_n * 16 + hl16];
-				}
-				int X0 = BXf(bb), Y0 = BYf(bb);
-				int v = 0;
-				if (on) {
-					int x = hl16 & 3, y = hl16 >> 2;
-					const int rres = L.res[(Y0 + y) * 16 + X0 + x]; // requested in front of the prediction's reads, not behind its branches
-					v = intra4x4_tab(L, e, X0, Y0, mode);
-					v = clip255(w16(v + rres));
-				}
-				wave_sync();
-				if (on)
-					L.YT(Y0 + (hl16 >> 2), X0 + (hl16 & 3)) = (uint8_t)v;
-				wave_sync();
-			}
-		} else { // I8x8, edge264_slice.c:645-668
-			tile_luma = true;
-#pragma unroll 1
-			for (int b = 0; b < 4; b++)
-				intra8x8_block(L, BXf(b * 4), BYf(b * 4), (int)(modes_lo >> (8 * b) & 255), (E264_INTRA_LAUNDER & 1) ? relane(lane) : lane);
-		}
-		PH(6);
-		pC[0] = intra_chroma_px(L, cpl, m.chroma_mode, cx, cy);
-		pC[1] = intra_chroma_px(L, cpl, m.chroma_mode, cx + 1, cy);
-	}
-	// add residual, clip, store (int16 wrap add then packus: residual.c:160-171)
-	uint32_t outw;
-	if (tile_luma) {
-		outw = *(const uint32_t *)&L.YT(Yr, X);
-	} else {
-		const int16_t *rr = L.res + Yr * 16 + X;
-		outw = (uint32_t)clip255(w16(pY[0] + rr[0])) | (uint32_t)clip255(w16(pY[1] + rr[1])) << 8 |
-			(uint32_t)clip255(w16(pY[2] + rr[2])) << 16 | (uint32_t)clip255(w16(pY[3] + rr[3])) << 24;
-	}
-	PH(7);
-	*(gu32 *)dY = outw;
-	const int16_t *rc = L.res + 256 + cpl * 64 + cy * 8 + cx;
-	*(gu16 *)dC = (uint16_t)(clip255(w16(pC[0] + rc[0])) | clip255(w16(pC[1] + rc[1])) << 8);
-}
-
-// ---------------------------------------------------------------------------------
-// kernels
-// ---------------------------------------------------------------------------------
-__device__ __forceinline__ int lds_load_relaxed(const int *p)
-{
-	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-
-#define E264_MAX_ROWS 1056
 } // namespace
+
+#include "e264_intra.h"
+
 
 // XCD-aware workgroup order.  The dispatcher places linear workgroup b on XCD b % 8, each with a private
 // 4 MiB L2; in launch order the strips that share reference rows (vertical neighbours of one frame,
@@ -886,109 +161,10 @@ __global__ __launch_bounds__(DP_NT) void e264_dbkparam2_kernel(const E264Job *jo
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs)
 {
-	// one object, the LDS-DMA targets first (lowest LDS addresses)
-	struct __attribute__((aligned(16))) IntraLds {
-		int16_t coef[NW][2][512];            // per wave: the payload of its macroblock and of the next one: [luma DC 16][chroma DC 8][coded blocks], as in the packet
-		uint32_t hdrs[NW][64 * 8];           // E264Mb records of the 64 macroblocks being scanned, per wave
-		WaveLds w[NW];
-		int progress[E264_MAX_ROWS];         // macroblocks finished per row
-		uint32_t i4tab[14 * 16];             // c_i4tab: read with a per-lane index
-	};
-	__shared__ IntraLds S;
-	WaveLds *const lds = S.w;
-	uint32_t (*const hdrs)[64 * 8] = S.hdrs;
-	int *const progress = S.progress;
-	uint32_t *const i4tab = S.i4tab;
-	const int lane = lane_id();
-	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	FrameCtx f;
-	if (!open_frame(f, jobs[blockIdx.x]))
-		return;
-	if (f.h->n_coded_mbs == f.h->n_inter_mbs)
-		return; // nothing intra in this frame (PCM is handled by the parallel kernel but counted as coded: rare)
-	for (int i = threadIdx.x; i < f.hm; i += NW * 64)
-		progress[i] = 0;
-	for (int i = threadIdx.x; i < 14 * 16; i += NW * 64)
-		i4tab[i] = c_i4tab[i];
-	__syncthreads();
-	WaveLds &L = lds[wave];
-	if (lane == 0) L.ws_slice = -1;
-	wave_sync();
-	const gu8 *mbs_g = f.payload - f.h->payload_off + f.h->mbs_off; // the E264Mb array through a per-lane (global) pointer
-	PH_DECL;
-#pragma unroll 1
-	for (int y = wave; y < f.hm; y += NW) {
-		// the row is scanned 64 macroblocks at a time (one vector load + ballot) instead of one scalar load per
-		// macroblock: in P/B frames, where few macroblocks are intra, the scan WAS the kernel's run time
-#pragma unroll 1
-		for (int x0 = 0; x0 < f.wm; x0 += 64) {
-			const int xl = x0 + lane;
-			// whole records of the chunk -> LDS (2 x 16 bytes per lane); `kind` for the ballot comes out of the first dword
-			v4u h0v = {0, 0, 0, 0}, h1v = {0, 0, 0, 0};
-			uint32_t kup = E264_MB_ABSENT; // kind of the macroblock above
-			if (xl < f.wm) {
-				const gv4u *rp = (const gv4u *)(mbs_g + (size_t)(y * f.wm + xl) * sizeof(E264Mb));
-				h0v = rp[0]; h1v = rp[1];
-				if (y > 0) kup = *(const gu32 *)(mbs_g + (size_t)((y - 1) * f.wm + xl) * sizeof(E264Mb));
-			}
-			wave_sync(); // the previous chunk's records are no longer read
-			*(v4u *)&hdrs[wave][lane * 8] = h0v;
-			*(v4u *)&hdrs[wave][lane * 8 + 4] = h1v;
-			wave_sync();
-			if (kup >> 8 & E264_MBF_DONE) kup = E264_MB_ABSENT; // written by an earlier packet of the picture: stable
-			kup &= 255u;
-			const int kind = (xl < f.wm && !(h0v.x >> 8 & E264_MBF_DONE)) ? (int)(h0v.x & 255) : E264_MB_ABSENT;
-			unsigned long long todo = __ballot(kind == E264_MB_I4x4 || kind == E264_MB_I8x8 || kind == E264_MB_I16x16);
-			// Which macroblocks of the row above does THIS kernel write?  Only those make a macroblock below wait: inter and
-			// PCM neighbours were finished by the prediction kernel before this launch (P / B pictures: an isolated intra
-			// macroblock starts at once instead of queueing behind every intra macroblock up and to the left of it).
-			const unsigned long long upi = __ballot(kup == E264_MB_I4x4 || kup == E264_MB_I8x8 || kup == E264_MB_I16x16);
-			const int xe = min(x0 + 64, f.wm);
-			if (todo == 0 || (int)__builtin_ctzll(todo) > 0) { // macroblocks before the first intra one need nothing from this kernel
-				const int upto = todo ? x0 + (int)__builtin_ctzll(todo) : xe;
-				if (lane == 0)
-					__hip_atomic_store(&progress[y], upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			}
-			// software pipeline over the intra macroblocks of the chunk: the header and payload of the next one are fetched
-			// inside recon_mb of the current one
-			MbInfo mi, mn;
-			int buf = 0;
-			if (todo) {
-				mi = mb_from_lds(&hdrs[wave][__builtin_ctzll(todo) * 8]);
-				coef_dma(S.coef[wave][buf], f, mi, lane); // the payload does not depend on the neighbours: in flight during the wait below
-			}
-#pragma unroll 1
-			while (todo) {
-				const int x = x0 + (int)__builtin_ctzll(todo);
-				todo &= todo - 1;
-				const uint32_t *next_rec = todo ? &hdrs[wave][__builtin_ctzll(todo) * 8] : nullptr;
-				PH(0);
-				const int rx = x - x0; // the neighbours above: x-1 (corner), x, x+1 (top right); outside the chunk: assume intra
-				const bool dep = (upi >> rx & 1) || (rx > 0 ? (int)(upi >> (rx - 1) & 1) : x0 > 0) || (rx < 63 ? (int)(upi >> (rx + 1) & 1) : x + 1 < f.wm);
-				if (y > 0 && dep) {
-					int want = min(x + 2, f.wm);
-					while (lds_load_relaxed(&progress[y - 1]) < want)
-						__builtin_amdgcn_s_sleep(1);
-					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-				}
-				PH(1);
-				coef_dma_wait();
-				recon_mb<2>(L, f, mi, x, y, lane, i4tab, S.coef[wave][buf], S.coef[wave][buf ^ 1], next_rec, mn PH_ARGS);
-				PH(8);
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-				PH(9);
-				// finished: everything up to the next intra macroblock of the chunk (or the chunk's end)
-				const int upto = todo ? x0 + (int)__builtin_ctzll(todo) : xe;
-				if (lane == 0)
-					__hip_atomic_store(&progress[y], upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				if (next_rec) { mi = mn; buf ^= 1; }
-			}
-		}
-	}
-#ifdef E264_PHASE_INTRA
-	PH_FLUSH_DBK(lane);
-#endif
+	__shared__ IntraLds<NW> S;
+	intra_kernel_body<NW>(S, jobs[blockIdx.x], (int)threadIdx.x);
 }
+
 
 // In-loop deblocking: one workgroup per picture, NW waves, each walking five macroblock rows at a time (e264_dbk.h; the
 // phases run on the host in tests/emu).  Waves take the groups of five rows round-robin; a wave waits for the wave that
