@@ -12,7 +12,7 @@
 //                        of EVERY macroblock from the command packet alone (nothing in the frame is read).
 //   e264_pred_kernel (e264_pred.h)       one workgroup per tile of 16 x 4 macroblocks, one lane per 8x8 block: inter
 //                        prediction + residual (+ PCM), which depend on nothing inside the frame.
-//   e264_intra_kernel (this file)        ONE WORKGROUP PER FRAME, ONE WAVE PER MACROBLOCK ROW: intra MBs only, row y
+//   e264_intra_kernel (e264_intra.h)     ONE WORKGROUP PER FRAME, ONE WAVE PER MACROBLOCK ROW: intra MBs only, row y
 //                        may reconstruct macroblock x once row y-1 has finished macroblock x+1.
 //   e264_deblock_kernel (e264_dbk.h)     one workgroup per frame, five macroblock rows per wave in lockstep, two lines
 //                        per lane: the raster dependency order of H.264 in-loop deblocking.
