@@ -195,11 +195,21 @@ E264_DEV uint32_t ref_dword(const gu8 *row, int x, int Wb)
 	return v;
 }
 struct Row4 { uint32_t a0, a1, a2, a3; };
-// NR x 16 bytes around (X, Y): the loads (nothing here uses a loaded value) ...
+// A register that holds SOMETHING, at no cost: rows a partition does not need are not fetched (the fetch is what this kernel's time
+// is, profiles/r03_ablations.txt item 19) but still run through the arithmetic of the wave, whose results for them are dropped.
+#ifndef E264_HOST_INTRINSICS
+E264_DEV uint32_t any_u32() { uint32_t v; asm("" : "=v"(v)); return v; }
+#else
+E264_DEV uint32_t any_u32() { return 0xa55a5aa5u; } // (host build: something that would show in a result that depended on it)
+#endif
+// NR x 16 bytes around (X, Y): the loads (nothing here uses a loaded value) ...  all: the partition is 8 rows high; else (4 rows)
+// the last four rows of the window are not needed and not fetched
 template <int NR>
-E264_DEV void load_window(const gu8 *plane, int sY, int W, int H, int X, int Y, Row4 *A)
+E264_DEV void load_window(const gu8 *plane, int sY, int W, int H, int X, int Y, bool all, Row4 *A)
 {
 	const int XA = X & ~3;
+#pragma unroll
+	for (int r = NR - 4; r < NR; r++) { A[r].a0 = any_u32(); A[r].a1 = any_u32(); A[r].a2 = any_u32(); A[r].a3 = any_u32(); }
 #ifdef E264_ABL_NOEDGE // timing ablation: no edge emulation (windows outside the frame read the wrong samples)
 	if (true) {
 		const gu8 *p = plane + (size_t)min(max(Y, 0), H - NR) * sY + min(max(XA, 0), W - 16);
@@ -214,12 +224,16 @@ E264_DEV void load_window(const gu8 *plane, int sY, int W, int H, int X, int Y, 
 		const gu8 *p = plane + (size_t)Y * sY + XA;
 #pragma unroll
 		for (int r = 0; r < NR; r++) {
+			if (r >= NR - 4 && !all)
+				continue;
 			const v4u v = *(const gv4u *)(p + (size_t)r * sY);
 			A[r].a0 = v.x; A[r].a1 = v.y; A[r].a2 = v.z; A[r].a3 = v.w;
 		}
 	} else {
 #pragma unroll
 		for (int r = 0; r < NR; r++) {
+			if (r >= NR - 4 && !all)
+				continue;
 			const gu8 *row = plane + (size_t)min(max(Y + r, 0), H - 1) * sY;
 			A[r].a0 = ref_dword(row, XA, W); A[r].a1 = ref_dword(row, XA + 4, W); A[r].a2 = ref_dword(row, XA + 8, W); A[r].a3 = ref_dword(row, XA + 12, W);
 		}
@@ -461,18 +475,25 @@ E264_DEV void luma_2dv(const Row4 A[13], int xF, const LumaSink &sink)
 // bilinear chroma of a 4x4 block of one plane (edge264_inter.c:977-1091; ABCD of :1242 factored into a horizontal and a
 // vertical blend, identical integers): window rows YC..YC+4, columns XC..XC+4.  Loads and arithmetic are separate so that
 // the caller can have every load of an item in flight before the first use.
-E264_DEV void chroma_load(const gu8 *plane, int sC, int Wc, int Hc, int XC, int YC, uint32_t w[5][2])
-{
+E264_DEV void chroma_load(const gu8 *plane, int sC, int Wc, int Hc, int XC, int YC, bool all, bool frac, uint32_t w[5][2])
+{ // all: 4 output rows (else 2); frac: the vertical fraction is not zero, one more row below is blended in.  Rows nobody needs are not fetched
 	const int XA = XC & ~3;
+	const bool need[5] = {true, true, all || frac, all, all && frac};
+#pragma unroll
+	for (int r = 2; r < 5; r++) { w[r][0] = any_u32(); w[r][1] = any_u32(); }
 	if (XA >= 0 && XA + 4 <= Wc - 4) {
 #pragma unroll
 		for (int r = 0; r < 5; r++) {
+			if (!need[r])
+				continue;
 			const v2u v = *(const gv2u *)(plane + (size_t)min(max(YC + r, 0), Hc - 1) * sC + XA);
 			w[r][0] = v.x; w[r][1] = v.y;
 		}
 	} else {
 #pragma unroll
 		for (int r = 0; r < 5; r++) {
+			if (!need[r])
+				continue;
 			const gu8 *row = plane + (size_t)min(max(YC + r, 0), Hc - 1) * sC;
 			w[r][0] = ref_dword(row, XA, Wc); w[r][1] = ref_dword(row, XA + 4, Wc);
 		}
@@ -571,14 +592,14 @@ E264_DEV void pred_item(PredLds &L, const FrameCtx &f, const PredTile &t, int li
 #ifdef E264_ABL_NOLOAD // timing ablation: no reference fetch at all (results are wrong on purpose)
 	for (int r = 0; r < 13; r++) { A[r].a0 = X + r; A[r].a1 = Y; A[r].a2 = X * r; A[r].a3 = Y - r; }
 #else
-	if (cls <= 1) load_window<8>(ref, f.sY, f.W, f.H, X, Y + 2, A); // G and b only look at rows 2..9
-	else load_window<13>(ref, f.sY, f.W, f.H, X, Y, A);
+	if (cls <= 1) load_window<8>(ref, f.sY, f.W, f.H, X, Y + 2, h8, A); // G and b only look at rows 2..9
+	else load_window<13>(ref, f.sY, f.W, f.H, X, Y, h8, A);
 #endif
 #ifdef E264_ABL_NOLOAD
 	for (int r = 0; r < 5; r++) { cw[0][r][0] = XC + r; cw[0][r][1] = YC; cw[1][r][0] = XC; cw[1][r][1] = YC * r; }
 #else
-	chroma_load(ref + f.psY, f.sC, f.W >> 1, f.H >> 1, XC, YC, cw[0]);
-	chroma_load(ref + f.psY + (f.sC >> 1), f.sC, f.W >> 1, f.H >> 1, XC, YC, cw[1]);
+	chroma_load(ref + f.psY, f.sC, f.W >> 1, f.H >> 1, XC, YC, h8, (my & 7) != 0, cw[0]);
+	chroma_load(ref + f.psY + (f.sC >> 1), f.sC, f.W >> 1, f.H >> 1, XC, YC, h8, (my & 7) != 0, cw[1]);
 #endif
 	// combination with list 0 / weights
 	const bool second = list == 1 && refIdxX >= 0;
