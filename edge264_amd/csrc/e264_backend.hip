@@ -110,6 +110,7 @@ struct E264Packet {
 	uint32_t ref_mask;     // DPB slots its motion refers to
 };
 
+#define E264_JOB_RING 4 // batches in flight per device: one uploading, one in the kernels, one retiring
 struct E264Device {
 	int ordinal;
 	enum { NQ = E264_MAX_LANES };
@@ -132,7 +133,12 @@ struct E264Device {
 	std::vector<Marks> kev;
 	size_t kev_used;
 	// job tables of host-packet batches: a ring of pinned + device buffers, each with the event of its upload and of its kernels
-	struct JobRing { E264Job *h = nullptr, *d = nullptr; int cap = 0; hipEvent_t done = nullptr, up = nullptr; bool busy = false; } jring[8];
+	struct JobRing {
+		E264Job *h = nullptr, *d = nullptr; int cap = 0; hipEvent_t done = nullptr, up = nullptr; bool busy = false;
+		// pageable batches: the packets of the WHOLE batch back to back in one page-locked buffer and one device buffer, so that a
+		// batch crosses PCIe as ONE transfer (256 copies of 1 MB each reached 35 GB/s, and cost the submitting thread 257 driver calls)
+		uint8_t *ph = nullptr, *pd = nullptr; size_t pcap = 0;
+	} jring[E264_JOB_RING];
 	int jring_next = 0;
 	// Which submission wrote a slot last, and when it has retired: edge264_get_frame of ONE decoder must not wait for the
 	// whole device (every later batch of every other decoder), only for the submission that produced its frame.
@@ -317,6 +323,8 @@ API void e264hip_device_close(E264Device *dev)
 	for (auto &jr : dev->jring) {
 		if (jr.h) hipHostFree(jr.h);
 		if (jr.d) hipFree(jr.d);
+		if (jr.ph) hipHostFree(jr.ph);
+		if (jr.pd) hipFree(jr.pd);
 		if (jr.done) hipEventDestroy(jr.done);
 		if (jr.up) hipEventDestroy(jr.up);
 	}
@@ -540,7 +548,7 @@ static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *s
 	const uint8_t *mot = h->motion_off ? p + h->motion_off : nullptr; // compact motion records, up to payload_off
 	const uint32_t mot_bytes = h->motion_off ? h->payload_off - h->motion_off : 0;
 	uint32_t ref_mask = 0, n_coded = 0, n_inter = 0;
-	for (int a = 0; a < n_mbs; a++) {
+	for (int a = 0, col = 0; a < n_mbs; a++, col = col + 1 == h->width_mbs ? 0 : col + 1) {
 		const E264Mb &m = mbs[a];
 		if (m.kind > E264_MB_INTER) return fail(EINVAL, "macroblock kind");
 		if (m.slice >= h->n_slices || m.dbk_slice >= h->n_slices) return fail(EINVAL, "macroblock slice index"); // every record: the parameter kernel reads the slice of absent macroblocks too
@@ -548,12 +556,13 @@ static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *s
 		n_coded++;
 		if ((m.flags & E264_MBF_T8x8) && (m.kind == E264_MB_I16x16 || m.kind == E264_MB_PCM)) return fail(EINVAL, "8x8 transform flag on an Intra16x16 / PCM macroblock");
 		if ((m.payload_off & 7) || (uint64_t)m.payload_off + e264_mb_payload_bytes(&m) > h->payload_bytes) return fail(EINVAL, "macroblock payload");
-		if ((m.flags & E264_MBF_EDGE_LEFT) && a % h->width_mbs == 0) return fail(EINVAL, "left edge flag on the first column");
+		if ((m.flags & E264_MBF_EDGE_LEFT) && col == 0) return fail(EINVAL, "left edge flag on the first column");
 		if ((m.flags & E264_MBF_EDGE_TOP) && a < h->width_mbs) return fail(EINVAL, "top edge flag on the first row");
 		// internal intra modes (src/edge264_internal.h:564-634): the kernels index tables with them
 		if (m.kind == E264_MB_I4x4) {
-			for (int k = 0; k < 16; k++)
-				if ((m.modes[k >> 1] >> (4 * (k & 1)) & 15) > 13) return fail(EINVAL, "Intra4x4 mode");
+			uint64_t mm;
+			memcpy(&mm, m.modes, 8); // 16 nibbles: above 13 <=> bits 1, 2 and 3 all set
+			if ((mm >> 1) & (mm >> 2) & (mm >> 3) & 0x1111111111111111ull) return fail(EINVAL, "Intra4x4 mode");
 		} else if (m.kind == E264_MB_I8x8) {
 			for (int k = 0; k < 4; k++)
 				if (m.modes[k] > 31) return fail(EINVAL, "Intra8x8 mode");
@@ -565,16 +574,22 @@ static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *s
 			uint32_t d[2];
 			memcpy(d, m.modes, 8); // motion directory: record offset, shape
 			if ((d[0] & 3) || d[1] >> 26 || (uint64_t)d[0] + e264_mot_record_bytes(d[1]) > mot_bytes) return fail(EINVAL, "macroblock motion record");
-			E264Motion mx;
-			e264_motion_expand(d[1], mot + d[0], &mx);
-			for (int i = 0; i < 8; i++) {
-				int rp = mx.refPic[i];
-				const bool used = E264_MOT_UNI(d[1], i >> 2) || E264_MOT_USED(d[1], i);
-				if (rp < (used ? 0 : -1) || rp >= E264_MAX_SLOTS) return fail(EINVAL, "reference slot"); // a part the directory announces predicts from a picture
-				if (rp >= 0 && slots && !slots[rp]) return fail(EINVAL, "reference slot not allocated");
-				if (rp >= 0 && slots && slot_bytes && frame_need > slot_bytes[rp]) return fail(EINVAL, "picture larger than a reference slot");
-				if (rp >= 0) ref_mask |= 1u << rp;
-				if (mx.refIdx[i] < -1 || mx.refIdx[i] > 31) return fail(EINVAL, "reference index");
+			// the record's reference dwords, where they lie (what e264_motion_expand would spread over 8 parts: the uniform form repeats
+			// one dword, an unused quadrant of a partitioned list reads as -1, which is always admissible)
+			const uint8_t *rec = mot + d[0];
+			uint32_t n = 0;
+			for (int l = 0; l < 2; l++) {
+				const bool uni = E264_MOT_UNI(d[1], l);
+				for (int q = 0; q < (uni ? 1 : 4); q++) {
+					if (!uni && !E264_MOT_USED(d[1], l * 4 + q)) continue;
+					const int rp = (int8_t)rec[n], ri = (int8_t)rec[n + 1];
+					if (rp < 0 || rp >= E264_MAX_SLOTS) return fail(EINVAL, "reference slot"); // a part the directory announces predicts from a picture
+					if (slots && !slots[rp]) return fail(EINVAL, "reference slot not allocated");
+					if (slots && slot_bytes && frame_need > slot_bytes[rp]) return fail(EINVAL, "picture larger than a reference slot");
+					ref_mask |= 1u << rp;
+					if (ri < -1 || ri > 31) return fail(EINVAL, "reference index");
+					n += uni ? 8 : 4 + 4 * e264_mot_nmv(E264_MOT_SUB(d[1], l * 4 + q));
+				}
 			}
 		}
 	}
@@ -882,20 +897,19 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 			if (streams[j] == streams[i]) return fail(EINVAL, "a stream may contribute one frame per batch");
 	}
 	const int lane = streams[0]->lane;
-	{ // validate the whole batch before the first side effect: every packet on its own, in parallel
-		std::lock_guard<std::mutex> pg(dev->pool_user);
-		dev->pool.parallel_for(n, [&](int i) {
-			E264Stream *s = streams[i];
-			int dst, r = check_packet(packets[i], bytes[i], &dst, &mbs_of[i], &tiles_of[i]);
-			dst_of[i] = dst;
-			if (!r && !s->h_table[dst]) r = fail(EINVAL, "destination slot not allocated");
-			if (!r && !trusted) r = check_packet_deep(packets[i], bytes[i], s->h_table, s->slot_bytes);
-			if (!r && trusted) r = check_slots_of(s, (const E264FrameHdr *)packets[i]);
-			if (r) { rc[i] = r; why[i] = g_err; } // the message lives in the worker's thread-local buffer
-		});
+	// headers first (cheap, serial): sizes, destination slots
+	int max_mbs = 0, max_tiles = 0;
+	std::vector<size_t> off_of((size_t)n);
+	size_t total = 0;
+	for (int i = 0; i < n; i++) {
+		int r = check_packet(packets[i], bytes[i], &dst_of[i], &mbs_of[i], &tiles_of[i]);
+		if (r) return r;
+		if (!streams[i]->h_table[dst_of[i]]) return fail(EINVAL, "destination slot not allocated");
+		if (tiles_of[i] > max_tiles) max_tiles = tiles_of[i];
+		if (mbs_of[i] > max_mbs) max_mbs = mbs_of[i];
+		off_of[i] = total;
+		total += (bytes[i] + 255) & ~(size_t)255;
 	}
-	for (int i = 0; i < n; i++)
-		if (rc[i]) return fail(rc[i], why[i].c_str());
 	std::lock_guard<std::mutex> bg(dev->batch_lock); // batches of one device are serialised (their streams are disjoint per batch anyway)
 	// ---- every allocation first: a failure below this block would leave copies in flight on buffers nobody guards ----
 	E264Device::JobRing &jr = dev->jring[dev->jring_next];
@@ -909,32 +923,50 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 		if (!(jr.d = (E264Job *)mem_acquire(dev, sizeof(E264Job) * cap, false))) { mem_release(dev, jr.h, sizeof(E264Job) * cap, true, 0, 0); jr.h = nullptr; return fail(ENOMEM, "device job table"); }
 		jr.cap = cap;
 	}
+	if (!pinned && jr.pcap < total) { // the batch's staging: a quarter of headroom, pictures of a stream differ in size
+		if (jr.ph) mem_release(dev, jr.ph, jr.pcap, true, 0, 0);
+		if (jr.pd) mem_release(dev, jr.pd, jr.pcap, false, 0, 0);
+		jr.ph = jr.pd = nullptr; jr.pcap = 0;
+		const size_t cap = (total + total / 4 + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+		if (!(jr.ph = (uint8_t *)mem_acquire(dev, cap, true))) return fail(ENOMEM, "pinned batch staging");
+		if (!(jr.pd = (uint8_t *)mem_acquire(dev, cap, false))) { mem_release(dev, jr.ph, cap, true, 0, 0); jr.ph = nullptr; return fail(ENOMEM, "device batch staging"); }
+		jr.pcap = cap;
+	}
 	if (!jr.done && hipEventCreateWithFlags(&jr.done, E264_WAIT_EVENT) != hipSuccess) { jr.done = nullptr; return fail(EIO, "hipEventCreate"); }
 	if (!jr.up && hipEventCreateWithFlags(&jr.up, hipEventDisableTiming) != hipSuccess) { jr.up = nullptr; return fail(EIO, "hipEventCreate"); }
-	int max_mbs = 0, max_tiles = 0;
-	std::vector<E264Stream::Stage *> stage_of((size_t)n);
-	for (int i = 0; i < n; i++) { // staging slots (HIP calls: this thread only); the rings advance only when everything is there
+	std::vector<E264Stream::Stage *> stage_of((size_t)n, nullptr);
+	for (int i = 0; i < n; i++) { // per-stream buffers (HIP calls: this thread only); the rings advance only when everything is there
 		E264Stream *s = streams[i];
-		if (tiles_of[i] > max_tiles) max_tiles = tiles_of[i];
-		if (mbs_of[i] > max_mbs) max_mbs = mbs_of[i];
 		int r = ensure_dbk(s, mbs_of[i]);
 		if (r) return r;
-		if (!(stage_of[i] = stage_prepare(s, bytes[i]))) return ENOMEM;
+		if (pinned && !(stage_of[i] = stage_prepare(s, bytes[i]))) return ENOMEM;
 	}
-	dev->jring_next = (dev->jring_next + 1) & 7;
-	for (int i = 0; i < n; i++) streams[i]->stage_next = (streams[i]->stage_next + 1) & 3;
-	if (!pinned) {
+	{ // every packet on its own, in parallel: the per-macroblock walk, and -- while its lines are still in the core's cache -- the copy
+	  // into the batch's staging buffer.  Nothing has been queued yet: a packet that fails leaves no trace (the ring has not advanced).
 		std::lock_guard<std::mutex> pg(dev->pool_user);
-		dev->pool.parallel_for(n, [&](int i) { memcpy(stage_of[i]->h, packets[i], bytes[i]); });
+		dev->pool.parallel_for(n, [&](int i) {
+			E264Stream *s = streams[i];
+			int r = trusted ? check_slots_of(s, (const E264FrameHdr *)packets[i]) : check_packet_deep(packets[i], bytes[i], s->h_table, s->slot_bytes);
+			if (r) { rc[i] = r; why[i] = g_err; return; } // the message lives in the worker's thread-local buffer
+			if (!pinned) memcpy(jr.ph + off_of[i], packets[i], bytes[i]);
+		});
 	}
+	for (int i = 0; i < n; i++)
+		if (rc[i]) return fail(rc[i], why[i].c_str());
+	dev->jring_next = (dev->jring_next + 1) % E264_JOB_RING;
+	if (pinned) for (int i = 0; i < n; i++) streams[i]->stage_next = (streams[i]->stage_next + 1) & 3;
 	// ---- copies on the upload queue, kernels on the lane behind the batch's upload event ----
 	hipStream_t q = dev->q[lane], up = dev->upload_queue && dev->qup ? dev->qup : q;
 	hipError_t e = hipSuccess;
-	for (int i = 0; i < n && e == hipSuccess; i++) {
-		E264Stream::Stage *st = stage_of[i];
-		e = hipMemcpyAsync(st->d, pinned ? packets[i] : st->h, bytes[i], hipMemcpyHostToDevice, up);
-		jr.h[i].packet = st->d; jr.h[i].dpb = streams[i]->d_table; jr.h[i].dbk = streams[i]->d_dbk;
+	for (int i = 0; i < n; i++) {
+		jr.h[i].packet = pinned ? stage_of[i]->d : jr.pd + off_of[i];
+		jr.h[i].dpb = streams[i]->d_table; jr.h[i].dbk = streams[i]->d_dbk;
 	}
+	if (pinned)
+		for (int i = 0; i < n && e == hipSuccess; i++)
+			e = hipMemcpyAsync(stage_of[i]->d, packets[i], bytes[i], hipMemcpyHostToDevice, up);
+	else
+		e = hipMemcpyAsync(jr.pd, jr.ph, total, hipMemcpyHostToDevice, up);
 	if (e == hipSuccess) e = hipMemcpyAsync(jr.d, jr.h, sizeof(E264Job) * n, hipMemcpyHostToDevice, up);
 	if (e == hipSuccess && up != q) {
 		e = hipEventRecord(jr.up, up);
@@ -947,10 +979,11 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 	// part of the batch was queued still reads them
 	hipEventRecord(jr.done, q);
 	jr.busy = true;
-	for (int i = 0; i < n; i++) {
-		hipEventRecord(stage_of[i]->done, q);
-		stage_of[i]->busy = true;
-	}
+	if (pinned)
+		for (int i = 0; i < n; i++) {
+			hipEventRecord(stage_of[i]->done, q);
+			stage_of[i]->busy = true;
+		}
 	if (r) return r;
 	for (int i = 0; i < n; i++) { streams[i]->slot_serial[dst_of[i]] = streams[i]->last_serial = serial; streams[i]->loose = false; }
 	return 0;

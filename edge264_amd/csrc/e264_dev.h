@@ -47,6 +47,8 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 typedef v4u E264_AS_GLOBAL __attribute__((aligned(4))) gv4u; // dword-aligned is all the strides guarantee (stride_C/2 of a 4096-wide frame)
 typedef v2u E264_AS_GLOBAL __attribute__((aligned(4))) gv2u; // unaligned dword (global memory allows it on gfx9+)
+typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+typedef v3u E264_AS_GLOBAL __attribute__((aligned(4))) gv3u;
 typedef int16_t E264_AS_GLOBAL gi16;
 // the command packet is read-only for every kernel: constant address space => uniform reads become
 // scalar loads (s_load) and the values live in SGPRs

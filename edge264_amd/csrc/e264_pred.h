@@ -70,6 +70,7 @@ struct PredTile { int tx0, ty0; };     // first macroblock of the tile
 
 // prediction item: bits 0..8 quadrant slot (macroblock of the tile * 4 + 8x8 index), 9..10 4x4 block of the quadrant the
 // partition starts at, 11..12 shape (0 8x8, 1 8x4, 2 4x8, 3 4x4).  The class is implied by the list.
+#define PRED_NO_REF 0xffffffffu // L.refq of a quadrant the list does not predict (a DPB slot is 0..31: no valid word looks like it)
 #define PI_SLOT(d) ((d) & 511)
 #define PI_SUB(d) ((d) >> 9 & 3)
 #define PI_SHAPE(d) ((d) >> 11 & 3)
@@ -125,6 +126,7 @@ E264_DEV void pred_phase_classify(PredLds &L, const FrameCtx &f, const PredTile 
 	const uint32_t d0 = L.hdr[mb][0];
 	const int kind = (d0 >> 8 & E264_MBF_DONE) ? E264_MB_ABSENT : (int)(d0 & 255); // DONE: written by an earlier packet of the picture, not ours to touch
 	const int mbx = t.tx0 + (mb & (PT_W - 1)), mby = t.ty0 + mb / PT_W;
+	L.refq[tid] = PRED_NO_REF; // until proven otherwise this list does not predict the quadrant (pred_item looks at the neighbour's word)
 	if (list == 0 && (kind == E264_MB_INTER || kind == E264_MB_PCM) && q == 0)
 		lds_or(&L.staged[mb >> 5], 1u << (mb & 31));
 	if (list == 0 && kind == E264_MB_PCM) { // edge264_slice.c:914-935: this quadrant's 8x8 luma + 4x4 Cb + 4x4 Cr
@@ -499,6 +501,28 @@ E264_DEV void chroma_load(const gu8 *plane, int sC, int Wc, int Hc, int XC, int 
 		}
 	}
 }
+// The same rows 12 bytes wide: the 8 x 4 chroma block of ONE plane that two horizontally adjacent quadrants with the same motion
+// share (16x16 and 16x8 partitions).  Each of the two lanes takes one plane: 5 lane-rows instead of 10 (the fetch is what this
+// kernel waits for: one lane-row costs the vector memory path 1.5 - 2.5 cycles whatever its width).
+E264_DEV void chroma_load12(const gu8 *plane, int sC, int Wc, int Hc, int XC, int YC, bool frac, uint32_t w[5][3])
+{
+	const int XA = XC & ~3;
+	if (XA >= 0 && XA + 8 <= Wc - 4) {
+#pragma unroll
+		for (int r = 0; r < 5; r++) {
+			if (r == 4 && !frac) { w[r][0] = any_u32(); w[r][1] = any_u32(); w[r][2] = any_u32(); continue; }
+			const v3u v = *(const gv3u *)(plane + (size_t)min(max(YC + r, 0), Hc - 1) * sC + XA);
+			w[r][0] = v.x; w[r][1] = v.y; w[r][2] = v.z;
+		}
+	} else {
+#pragma unroll
+		for (int r = 0; r < 5; r++) {
+			if (r == 4 && !frac) { w[r][0] = any_u32(); w[r][1] = any_u32(); w[r][2] = any_u32(); continue; }
+			const gu8 *row = plane + (size_t)min(max(YC + r, 0), Hc - 1) * sC;
+			w[r][0] = ref_dword(row, XA, Wc); w[r][1] = ref_dword(row, XA + 4, Wc); w[r][2] = ref_dword(row, XA + 8, Wc);
+		}
+	}
+}
 E264_DEV void chroma4x4(const uint32_t w[5][2], int XC, int xF, int yF, uint32_t out[4])
 {
 	const uint32_t o = (uint32_t)XC & 3u;
@@ -589,17 +613,40 @@ E264_DEV void pred_item(PredLds &L, const FrameCtx &f, const PredTile &t, int li
 	const int XC = (gx >> 1) + (mx >> 3), YC = (gy >> 1) + (my >> 3);
 	Row4 A[13];
 	uint32_t cw[2][5][2];
+	// -DE264_PRED_HPAIR (measured, NOT the default: profiles/r04_ablations.txt item 1): chroma by PLANE where the quadrant beside this
+	// one (q ^ 1: same macroblock, same rows) has the same motion -- 16x16 and 16x8 partitions, /root/reference/src/edge264_inter.c:977-1091
+	// predicts the chroma of a partition in one call --: this lane predicts the 8 x 4 block of plane q & 1 for both, its neighbour the
+	// other plane's (5 lane-rows of 12 bytes instead of 10 of 8).  Both lanes decide alike (the test is symmetric).  Bit-exact, 18 % fewer
+	// lane-rows on the bench GOP -- and 11 % SLOWER (1.266 -> 1.407 ms): a wave of one class holds paired and unpaired items side by side
+	// and runs both chroma paths; the kernel's time follows its VALU count, not its lane-rows.
+#ifdef E264_PRED_HPAIR
+	const bool hp = shape == 0 && L.refq[slot ^ 1] == rq && L.mvq[0][slot ^ 1] == mv && L.mvq[1][slot ^ 1] == mv && L.mvq[2][slot ^ 1] == mv && L.mvq[3][slot ^ 1] == mv;
+#else
+	const bool hp = false;
+#endif
+	const int XCp = ((gx & ~15) >> 1) + (mx >> 3); // the partition's first chroma column
+	uint32_t (*cw3)[3] = (uint32_t (*)[3])&cw[0][0][0]; // the same registers as rows of three dwords
+	const gu8 *cplane = ref + f.psY + ((q & 1) ? (f.sC >> 1) : 0);
 #ifdef E264_ABL_NOLOAD // timing ablation: no reference fetch at all (results are wrong on purpose)
 	for (int r = 0; r < 13; r++) { A[r].a0 = X + r; A[r].a1 = Y; A[r].a2 = X * r; A[r].a3 = Y - r; }
-#else
-	if (cls <= 1) load_window<8>(ref, f.sY, f.W, f.H, X, Y + 2, h8, A); // G and b only look at rows 2..9
-	else load_window<13>(ref, f.sY, f.W, f.H, X, Y, h8, A);
-#endif
-#ifdef E264_ABL_NOLOAD
 	for (int r = 0; r < 5; r++) { cw[0][r][0] = XC + r; cw[0][r][1] = YC; cw[1][r][0] = XC; cw[1][r][1] = YC * r; }
 #else
-	chroma_load(ref + f.psY, f.sC, f.W >> 1, f.H >> 1, XC, YC, h8, (my & 7) != 0, cw[0]);
-	chroma_load(ref + f.psY + (f.sC >> 1), f.sC, f.W >> 1, f.H >> 1, XC, YC, h8, (my & 7) != 0, cw[1]);
+#ifndef E264_PRED_CHROMA_LAST // the chroma rows are consumed first: requested first, their arithmetic runs while the luma rows arrive (1.266 -> 1.249 ms, profiles/r04_ablations.txt item 1)
+	if (hp) chroma_load12(cplane, f.sC, f.W >> 1, f.H >> 1, XCp, YC, (my & 7) != 0, cw3);
+	else {
+		chroma_load(ref + f.psY, f.sC, f.W >> 1, f.H >> 1, XC, YC, h8, (my & 7) != 0, cw[0]);
+		chroma_load(ref + f.psY + (f.sC >> 1), f.sC, f.W >> 1, f.H >> 1, XC, YC, h8, (my & 7) != 0, cw[1]);
+	}
+#endif
+	if (cls <= 1) load_window<8>(ref, f.sY, f.W, f.H, X, Y + 2, h8, A); // G and b only look at rows 2..9
+	else load_window<13>(ref, f.sY, f.W, f.H, X, Y, h8, A);
+#ifdef E264_PRED_CHROMA_LAST
+	if (hp) chroma_load12(cplane, f.sC, f.W >> 1, f.H >> 1, XCp, YC, (my & 7) != 0, cw3);
+	else {
+		chroma_load(ref + f.psY, f.sC, f.W >> 1, f.H >> 1, XC, YC, h8, (my & 7) != 0, cw[0]);
+		chroma_load(ref + f.psY + (f.sC >> 1), f.sC, f.W >> 1, f.H >> 1, XC, YC, h8, (my & 7) != 0, cw[1]);
+	}
+#endif
 #endif
 	// combination with list 0 / weights
 	const bool second = list == 1 && refIdxX >= 0;
@@ -610,7 +657,26 @@ E264_DEV void pred_item(PredLds &L, const FrameCtx &f, const PredTile &t, int li
 		if (mode == 2)
 			pred_weights(f.slices + (L.hdr[mb][2] >> 16), list, refIdx, refIdxX, wY, wCb, wCr);
 	}
-	{ // chroma: small, and its rows leave at once
+	if (hp) { // the 8 x 4 block of plane q & 1: two 4 x 4 blocks out of the same rows
+		uint32_t oc[2][4], wl[5][2], wr[5][2];
+#pragma unroll
+		for (int r = 0; r < 5; r++) { wl[r][0] = cw3[r][0]; wl[r][1] = cw3[r][1]; wr[r][0] = cw3[r][1]; wr[r][1] = cw3[r][2]; }
+		chroma4x4(wl, XCp, mx & 7, my & 7, oc[0]);
+		chroma4x4(wr, XCp, mx & 7, my & 7, oc[1]);
+		const Wod w = (q & 1) ? wCr : wCb;
+		uint32_t *tc = &L.c[q & 1][py0 >> 1][(px0 >> 4) * 2];
+#pragma unroll
+		for (int j = 0; j < 4; j++)
+#pragma unroll
+			for (int hx = 0; hx < 2; hx++) {
+				uint32_t v = oc[hx][j];
+				if (mode != 0) {
+					const uint32_t qv = tc[j * PT_W * 2 + hx];
+					v = mode == 1 ? v_lerp_u8(qv, v, ONES8) : wpred4(qv, v, w);
+				}
+				tc[j * PT_W * 2 + hx] = v;
+			}
+	} else { // chroma: small, and its rows leave at once
 		uint32_t oc[2][4];
 		chroma4x4(cw[0], XC, mx & 7, my & 7, oc[0]);
 		chroma4x4(cw[1], XC, mx & 7, my & 7, oc[1]);

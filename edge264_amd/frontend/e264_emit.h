@@ -32,9 +32,11 @@ typedef struct {
 	int width_mbs, height_mbs, n_mbs;
 	int frame_id;
 	E264Mb *mbs;
-	uint16_t *dbk_slice;  /* per macroblock: slice entry whose task called deblock_mb on it (0xffff: none yet) */
-	uint8_t *state;       /* per macroblock, pictures sent in several packets (a slice failed): E264_ST_* */
-	uint8_t *fedges;      /* per macroblock: mb->filter_edges as deblock_mb found it (the emitter clears it like the reference) */
+	struct E264MbSide {   /* per macroblock, beside its record (one array: deblock_mb touches all three for a macroblock of the row above) */
+		uint16_t dbk_slice;  /* slice entry whose task called deblock_mb on it (0xffff: none yet) */
+		uint8_t state;       /* pictures sent in several packets (a slice failed): E264_ST_* */
+		uint8_t fedges;      /* mb->filter_edges as deblock_mb found it (the emitter clears it like the reference) */
+	} *side;
 	int multi;            /* a packet of this picture has already been sent, or a macroblock was decoded twice */
 	int n_flushed;        /* records written by e264_flush_mb since the builder was reset (every macroblock once: no I_PCM to look for) */
 	int n_lifted;         /* I_PCM records lifted from the host mirror */
@@ -51,6 +53,18 @@ typedef struct {
 	size_t payload_len, payload_cap;
 	int n_inter;
 } E264FrameBuilder;
+
+/* -DE264_EMIT_PROFILE (tools/hostprof): cycle counters around the emitters' own work, printed by edge264_free.  Off in the product. */
+#ifdef E264_EMIT_PROFILE
+#include <x86intrin.h>
+enum { E264_PF_TOUCH, E264_PF_LEVELS, E264_PF_FLUSH, E264_PF_FINISH, E264_PF_DEBLOCK, E264_PF_INTRA, E264_PF_N };
+static __thread unsigned long long e264_pf[E264_PF_N], e264_pf_calls[E264_PF_N];
+#define E264_PF_BEGIN unsigned long long pf_t0_ = __rdtsc()
+#define E264_PF_END(k) do { e264_pf[k] += __rdtsc() - pf_t0_; e264_pf_calls[k]++; } while (0)
+#else
+#define E264_PF_BEGIN do {} while (0)
+#define E264_PF_END(k) do {} while (0)
+#endif
 
 #define E264_ST_RECON 1   /* reconstructed by an earlier packet of the picture */
 #define E264_ST_DBK   2   /* deblocked by an earlier packet */
@@ -128,17 +142,14 @@ static E264FrameBuilder *e264_builder(E264Emitter *e, int slot)
 		b->active = 0;
 	if (!b->active) {
 		if (b->n_mbs != w * h) {
-			free(b->mbs); free(b->dbk_slice); free(b->state); free(b->fedges);
-			b->dbk_slice = malloc(sizeof(uint16_t) * (size_t)(w * h));
-			b->state = malloc((size_t)(w * h));
-			b->fedges = malloc((size_t)(w * h));
+			free(b->mbs); free(b->side);
+			b->side = malloc(sizeof(*b->side) * (size_t)(w * h));
 			b->mbs = malloc(sizeof(E264Mb) * (size_t)(w * h));
 		}
 		b->width_mbs = w; b->height_mbs = h; b->n_mbs = w * h;
 		memset(b->mbs, 0, sizeof(E264Mb) * (size_t)b->n_mbs);
-		memset(b->dbk_slice, 0xff, sizeof(uint16_t) * (size_t)b->n_mbs);
-		memset(b->state, 0, (size_t)b->n_mbs);
-		memset(b->fedges, 0, (size_t)b->n_mbs);
+		for (int i = 0; i < b->n_mbs; i++)
+			b->side[i] = (struct E264MbSide){0xffff, 0, 0};
 		b->multi = 0;
 		b->n_flushed = b->n_lifted = 0;
 		b->mot_len = 0;
@@ -266,12 +277,22 @@ static uint32_t e264_motion_emit(const int8_t *refPic, const int8_t *refIdx, con
 
 /* close the macroblock under assembly: header from the reference's own Edge264Macroblock
  * (src/edge264_internal.h:128-143), motion record and payload in the order of include/edge264_cmd.h */
+static void e264_flush_mb_(E264Emitter *e);
 static void e264_flush_mb(E264Emitter *e)
 {
-	E264MbStage *c = &e->cur;
-	if (!c->valid)
+	if (!e->cur.valid)
 		return;
+	E264_PF_BEGIN;
+	e264_flush_mb_(e);
+	E264_PF_END(E264_PF_FLUSH);
+}
+static void e264_flush_mb_(E264Emitter *e)
+{
+	E264MbStage *c = &e->cur;
 	c->valid = 0;
+#ifdef E264_X_NOFLUSH
+	return;
+#endif
 	E264FrameBuilder *b = &e->fb[c->slot];
 	if (!b->active || c->addr >= b->n_mbs)
 		return;
@@ -344,7 +365,15 @@ static void e264_flush_mb(E264Emitter *e)
 }
 
 /* make (slot, addr) the macroblock under assembly */
-static E264MbStage *e264_touch(E264Emitter *e, int slot, int addr)
+static E264MbStage *e264_touch_(E264Emitter *e, int slot, int mbx, int mby, int addr);
+static E264MbStage *e264_touch(E264Emitter *e, int slot, int mbx, int mby, int width_mbs)
+{
+	E264_PF_BEGIN;
+	E264MbStage *c = e264_touch_(e, slot, mbx, mby, mbx + mby * width_mbs);
+	E264_PF_END(E264_PF_TOUCH);
+	return c;
+}
+static E264MbStage *e264_touch_(E264Emitter *e, int slot, int mbx, int mby, int addr)
 {
 	E264MbStage *c = &e->cur;
 	if (c->valid && c->slot == slot && c->addr == addr && c->serial == e->serial)
@@ -363,12 +392,12 @@ static E264MbStage *e264_touch(E264Emitter *e, int slot, int addr)
 		c->valid = 0; /* the same macroblock decoded again by a later NAL (a slice that failed and is resent): start over */
 	e264_flush_mb(e);
 	E264FrameBuilder *b = e264_builder(e, slot);
-	if (addr < b->n_mbs && (b->mbs[addr].kind != E264_MB_ABSENT || b->state[addr])) {
+	if (addr < b->n_mbs && (b->mbs[addr].kind != E264_MB_ABSENT || b->side[addr].state)) {
 		/* decoded before (a slice failed: recover_slice conceals with skips, and recovery_bits let a later copy of the
 		 * slice decode the macroblock again, src/edge264_slice.c:1686): a new generation, reconstructed by the next
 		 * packet and deblocked only if the reference calls deblock_mb on it again with filter_edges set */
-		b->state[addr] = 0;
-		b->dbk_slice[addr] = 0xffff;
+		b->side[addr].state = 0;
+		b->side[addr].dbk_slice = 0xffff;
 		b->mbs[addr].kind = E264_MB_ABSENT;
 		b->multi = 1;
 	}
@@ -379,8 +408,7 @@ static E264MbStage *e264_touch(E264Emitter *e, int slot, int addr)
 	c->serial = e->serial;
 	c->slice = e264_slice_index(e, b);
 	c->kind = E264_MB_ABSENT;
-	int mbx = addr % b->width_mbs, mby = addr / b->width_mbs;
-	c->mbptr = (Edge264Macroblock *)e->slot[slot].mbs + mbx + mby * (b->width_mbs + 1);
+	c->mbptr = (Edge264Macroblock *)e->slot[slot].mbs + mbx + mby * (b->width_mbs + 1); /* (no division: the callers know the column and the row) */
 	return c;
 }
 
@@ -396,7 +424,7 @@ static E264MbStage *e264_touch_ctx(Edge264Context *ctx)
 		return NULL;
 	/* the position, not ctx->CurrMbAddr: recover_slice walks mbx / mby / samples_mb back over the failed slice while
 	 * CurrMbAddr stays where the error was found (src/edge264_headers.c:297-305, 414-428) */
-	c = e264_touch(e, slot, ctx->mbx + ctx->mby * ctx->t.pic_width_in_mbs);
+	c = e264_touch(e, slot, ctx->mbx, ctx->mby, ctx->t.pic_width_in_mbs);
 	if (c)
 		e264_fill_slice(e, &e->fb[slot], c->slice, ctx);
 	return c;
@@ -441,13 +469,25 @@ static E264MbStage *e264_touch_ptr(const uint8_t *p, int *x_in_mb, int *y_in_mb,
 		*x_in_mb = x & 7; *y_in_mb = y & 7;
 		mbx = x >> 3; mby = y >> 3;
 	}
-	c = e264_touch(e, slot, mby * dec->sps.pic_width_in_mbs + mbx);
+	c = e264_touch(e, slot, mbx, mby, dec->sps.pic_width_in_mbs);
 	if (c && !c->ybase) {
 		c->ybase = e->slot[slot].samples + (size_t)(mby * 16) * dec->out.stride_Y + mbx * 16;
 		c->cbase = e->slot[slot].samples + dec->plane_size_Y + (size_t)(mby * 8) * dec->out.stride_C + mbx * 8;
 	}
 	return c;
 }
+
+/* tools/hostprof builds this translation unit with -DE264_NULL_LEAVES: every leaf returns after the clearing the parser relies
+ * on, nothing is located, staged or emitted -- the parse floor the emitters' cost is measured against.  Never set in the product. */
+#ifdef E264_NULL_LEAVES
+#define E264_NULL_LEAF 1
+#define E264_TOUCH_CTX(ctx) ((void)(ctx), (E264MbStage *)NULL)
+#define E264_TOUCH_PTR(p, x, y, pl) ((void)(p), *(x) = *(y) = *(pl) = 0, (E264MbStage *)NULL)
+#else
+#define E264_NULL_LEAF 0
+#define E264_TOUCH_CTX(ctx) e264_touch_ctx(ctx)
+#define E264_TOUCH_PTR(p, x, y, pl) e264_touch_ptr(p, x, y, pl)
+#endif
 
 /* ---- helpers referenced by the reference's error concealment (recover_slice, src/edge264_headers.c:295-430),
  * which lived in the kernel files we replace.  What recover_slice writes (a blend with the neighbours' DC for I slices, on

@@ -259,27 +259,27 @@ static void e264_lift_pcm(E264Emitter *e, int slot)
 	const Edge264Macroblock *mbs = e->slot[slot].mbs;
 	for (int a = 0; a < b->n_mbs; a++) {
 		E264Mb *m = &b->mbs[a];
-		if (m->kind != E264_MB_ABSENT && !(b->state[a] & E264_ST_ERR))
+		if (m->kind != E264_MB_ABSENT && !(b->side[a].state & E264_ST_ERR))
 			continue;
 		const Edge264Macroblock *M = mbs + a % b->width_mbs + (a / b->width_mbs) * (b->width_mbs + 1);
-		if ((b->state[a] & E264_ST_ERR) && M->recovery_bits == flip) {
+		if ((b->side[a].state & E264_ST_ERR) && M->recovery_bits == flip) {
 			/* marked erroneous by recover_slice, decoded again since, and no leaf call has started a new record (e264_touch
 			 * clears the mark): it came back as I_PCM.  Reconstructed again from the new samples; not deblocked again unless
 			 * deblock_mb saw it (emit_deblock.c then has already reset the record). */
 			memset(m, 0, sizeof(*m));
-			b->state[a] &= E264_ST_DBK;
+			b->side[a].state &= E264_ST_DBK;
 		}
-		if (m->kind == E264_MB_ABSENT && !(b->state[a] & E264_ST_RECON) && M->recovery_bits == flip && !M->mbIsInterFlag) {
+		if (m->kind == E264_MB_ABSENT && !(b->side[a].state & E264_ST_RECON) && M->recovery_bits == flip && !M->mbIsInterFlag) {
 			m->kind = E264_MB_PCM;
 			b->n_lifted++;
 			m->qp[0] = M->QP[0]; m->qp[1] = M->QP[1]; m->qp[2] = M->QP[2];
-			const int fe = b->dbk_slice[a] != 0xffff ? b->fedges[a] : M->filter_edges; /* deblock_mb has cleared what it filtered */
+			const int fe = b->side[a].dbk_slice != 0xffff ? b->side[a].fedges : M->filter_edges; /* deblock_mb has cleared what it filtered */
 			m->flags = (uint8_t)((fe & 1 ? E264_MBF_EDGE_LEFT : 0) | (fe & 2 ? E264_MBF_EDGE_TOP : 0) | (fe ? E264_MBF_DEBLOCK : 0));
 			m->nz_mask = 0xffff;
 			m->slice = 0;
 			for (int i = b->n_slices - 1; i >= 0; i--)
 				if (b->slices[i].first_mb <= (uint32_t)a && b->slice_filled[i]) { m->slice = (uint16_t)i; break; }
-			m->dbk_slice = b->dbk_slice[a] != 0xffff ? b->dbk_slice[a] : m->slice;
+			m->dbk_slice = b->side[a].dbk_slice != 0xffff ? b->side[a].dbk_slice : m->slice;
 			while (b->payload_len & 7)
 				e264_payload_append(b, "\0", 1);
 			m->payload_off = (uint32_t)b->payload_len;
@@ -304,7 +304,15 @@ static void e264_lift_pcm(E264Emitter *e, int slot)
  *   reconstructed again), and a macroblock is deblocked by exactly the packet during which the reference called deblock_mb
  *   on it (emit_deblock.c) -- a macroblock that was deblocked, concealed and decoded again is NOT deblocked a second time
  *   unless the reference does so (its next_deblock_addr has moved past it, src/edge264_headers.c:922-925, 531-535). */
+static int e264_finish_frame_(E264Emitter *e, int slot, int partial);
 static int e264_finish_frame(E264Emitter *e, int slot, int partial)
+{
+	E264_PF_BEGIN;
+	const int r = e264_finish_frame_(e, slot, partial);
+	E264_PF_END(E264_PF_FINISH);
+	return r;
+}
+static int e264_finish_frame_(E264Emitter *e, int slot, int partial)
 {
 	E264FrameBuilder *b = &e->fb[slot];
 	Edge264Decoder *dec = e->dec;
@@ -341,10 +349,13 @@ static int e264_finish_frame(E264Emitter *e, int slot, int partial)
 	if (partial) { /* nothing new since the last packet of the picture? */
 		int dirty = 0;
 		for (int a = 0; a < b->n_mbs && !dirty; a++)
-			dirty = (b->mbs[a].kind != E264_MB_ABSENT && !(b->state[a] & E264_ST_RECON)) || (b->dbk_slice[a] != 0xffff && !(b->state[a] & E264_ST_DBK));
+			dirty = (b->mbs[a].kind != E264_MB_ABSENT && !(b->side[a].state & E264_ST_RECON)) || (b->side[a].dbk_slice != 0xffff && !(b->side[a].state & E264_ST_DBK));
 		if (!dirty)
 			return 0;
 	}
+#ifdef E264_X_NOFINISH
+	if (!partial) { b->active = 0; return 0; }
+#endif
 	const uint32_t motion_bytes = n_inter ? (uint32_t)b->mot_len : 0;
 	/* layout: hdr | slices | mbs | motion records (if any inter MB) | payload */
 	uint32_t slices_off = E264_ALIGN16((uint32_t)sizeof(E264FrameHdr));
@@ -383,15 +394,15 @@ static int e264_finish_frame(E264Emitter *e, int slot, int partial)
 		for (int a = 0; a < b->n_mbs; a++) {
 			if (pm[a].kind == E264_MB_ABSENT)
 				continue;
-			const int dbk_now = b->dbk_slice[a] != 0xffff && !(b->state[a] & E264_ST_DBK);
+			const int dbk_now = b->side[a].dbk_slice != 0xffff && !(b->side[a].state & E264_ST_DBK);
 			if (!dbk_now)
 				pm[a].flags &= (uint8_t)~(E264_MBF_DEBLOCK | E264_MBF_EDGE_LEFT | E264_MBF_EDGE_TOP);
-			if (b->state[a] & E264_ST_RECON) {
+			if (b->side[a].state & E264_ST_RECON) {
 				pm[a].flags |= E264_MBF_DONE;
 				pm[a].coded = 0;
 				pm[a].payload_off = 0;
 			}
-			b->state[a] |= (uint8_t)(E264_ST_RECON | (b->dbk_slice[a] != 0xffff ? E264_ST_DBK : 0));
+			b->side[a].state |= (uint8_t)(E264_ST_RECON | (b->side[a].dbk_slice != 0xffff ? E264_ST_DBK : 0));
 		}
 		b->multi = 1;
 		b->payload_len = 0; /* the records kept for a later packet carry no payload (DONE) */
@@ -504,7 +515,7 @@ PUBLIC int edge264_decode_NAL(Edge264Decoder *dec, const uint8_t *buf, const uin
 		const Edge264Macroblock *Mb = e->slot[e->failed_slot].mbs;
 		for (int a = 0; a < b->n_mbs; a++)
 			if (Mb[a % b->width_mbs + (a / b->width_mbs) * (b->width_mbs + 1)].recovery_bits == flip + 2)
-				b->state[a] |= E264_ST_ERR;
+				b->side[a].state |= E264_ST_ERR;
 	}
 	/* a picture with a failed slice goes out NAL by NAL from then on: each packet is one state of the picture as the
 	 * reference builds it (what the NAL decoded, what it deblocked), in the reference's order */
@@ -559,6 +570,14 @@ PUBLIC void edge264_free(Edge264Decoder **pdec)
 	if (!pdec || !*pdec)
 		return;
 	E264Emitter *e = emitter_of(*pdec);
+#ifdef E264_EMIT_PROFILE
+	{
+		static const char *nm[E264_PF_N] = {"touch(incl. flush)", "levels", "flush_mb", "finish_frame", "deblock_mb", "intra leaves"};
+		for (int k = 0; k < E264_PF_N; k++)
+			if (e264_pf_calls[k]) fprintf(stderr, "emit-profile %-20s calls %10llu  cycles %14llu  (%.0f per call)\n", nm[k], e264_pf_calls[k], e264_pf[k], (double)e264_pf[k] / (double)e264_pf_calls[k]);
+		memset(e264_pf, 0, sizeof(e264_pf)); memset(e264_pf_calls, 0, sizeof(e264_pf_calls));
+	}
+#endif
 	e264_tls_emitter = e;
 	e264ref_free(pdec); /* releases every slot through e264_free_cb */
 	e264_tls_emitter = NULL;
@@ -566,7 +585,7 @@ PUBLIC void edge264_free(Edge264Decoder **pdec)
 		return;
 	if (ON_DEVICE(e)) hip.stream_close(e->hip_stream);
 	for (int s = 0; s < E264_MAX_SLOTS; s++) {
-		free(e->fb[s].mbs); free(e->fb[s].dbk_slice); free(e->fb[s].state); free(e->fb[s].fedges); free(e->fb[s].mot); free(e->fb[s].slices); free(e->fb[s].slice_serial);
+		free(e->fb[s].mbs); free(e->fb[s].side); free(e->fb[s].mot); free(e->fb[s].slices); free(e->fb[s].slice_serial);
 		free(e->fb[s].slice_filled); free(e->fb[s].payload);
 	}
 	while (e->cap_head) {

@@ -11,10 +11,14 @@
 static noinline void deblock_mb(Edge264Context *ctx)
 {
 	E264Emitter *e = e264_tls_emitter;
+	E264_PF_BEGIN;
+#ifdef E264_X_NODBK
+	{ mb->filter_edges = 0; return; }
+#endif
 	if (!mb->filter_edges) /* src/edge264_deblock.c:938: already filtered (or never to be) */
 		return;
 	size_t off;
-	int slot = e264_locate(e, ctx->samples_mb[0], &off);
+	int slot = E264_NULL_LEAF ? -1 : e264_locate(e, ctx->samples_mb[0], &off);
 	if (slot >= 0 && e->fb[slot].active) {
 		E264FrameBuilder *b = &e->fb[slot];
 		if (e->cur.valid && e->cur.slot == slot)
@@ -27,21 +31,22 @@ static noinline void deblock_mb(Edge264Context *ctx)
 		const size_t mby = (size_t)(((uint64_t)i * b->recip_w1) >> 40), mbx = i - mby * (size_t)(b->width_mbs + 1);
 		if (mbx < (size_t)b->width_mbs && mby < (size_t)b->height_mbs) {
 			size_t a = mby * (size_t)b->width_mbs + mbx;
-			if ((b->state[a] & E264_ST_ERR) && mb->recovery_bits == ctx->t.frame_flip_bit) {
+			if ((b->side[a].state & E264_ST_ERR) && mb->recovery_bits == ctx->t.frame_flip_bit) {
 				/* marked erroneous, then decoded again without a single leaf call: as I_PCM (src/edge264_slice.c:914-935).
 				 * Its record starts over; e264_lift_pcm picks the samples up when the packet is closed. */
 				memset(&b->mbs[a], 0, sizeof(E264Mb));
-				b->state[a] = 0;
-				b->dbk_slice[a] = 0xffff;
+				b->side[a].state = 0;
+				b->side[a].dbk_slice = 0xffff;
 			}
-			b->fedges[a] = mb->filter_edges;
+			b->side[a].fedges = mb->filter_edges;
 			/* the first call is the one that filters (the picture-completing pass runs over macroblocks that were deblocked
 			 * earlier without touching them) */
-			if (b->dbk_slice[a] == 0xffff) {
-				b->dbk_slice[a] = (uint16_t)idx;
+			if (b->side[a].dbk_slice == 0xffff) {
+				b->side[a].dbk_slice = (uint16_t)idx;
 				b->mbs[a].dbk_slice = (uint16_t)idx; /* (a record that does not exist yet -- I_PCM -- takes it from the array when it is lifted) */
 			}
 		}
 	}
 	mb->filter_edges = 0; /* src/edge264_deblock.c:500: a macroblock is filtered once per parse */
+	E264_PF_END(E264_PF_DEBLOCK);
 }

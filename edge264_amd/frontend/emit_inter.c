@@ -8,7 +8,7 @@
 
 static void noinline decode_inter(Edge264Context *ctx, int i, int w, int h)
 {
-	E264MbStage *c = e264_touch_ctx(ctx);
+	E264MbStage *c = E264_TOUCH_CTX(ctx);
 	if (c)
 		c->kind = E264_MB_INTER;
 	(void)i; (void)w; (void)h;
