@@ -67,6 +67,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs[1] and configs[3] (N=1)")
     ap.add_argument("--no-host-packets", action="store_true", help="skip the PCIe-inclusive run (N=1)")
+    ap.add_argument("--no-same-input", action="store_true", help="skip the same-input leg (the 1080p bitstream fixtures on the GPU next to the CPU reference, N=1)")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("E264_LANES", 1)), help="compute lanes (HIP queues): the streams are split into this many "
                     "groups whose submissions overlap on the GPU")
     ap.add_argument("--capture", default=None, help="capture file (edge264_amd/replay.py): its first stream's packets replace the synthetic GOP, "
@@ -109,6 +110,137 @@ def kernel_own_bytes(models, n_streams):
     return out
 
 
+def newest_traffic(dom, streams, gop, W, H, lanes, live_ms):
+    """HBM-side bytes per launch of the dominant kernel from the NEWEST profiles/r*_hbm_traffic.json taken on this configuration
+    (PMC passes cannot run inside a timed bench: separate rocprofv3 --pmc runs, tools/gpu_profile_r4.sh).  Returns (bytes or None,
+    a description that names the file, the kernel times it was taken at when it records them, and says so when the live
+    times have moved more than 10 % away from them)."""
+    import glob
+    import re
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")):
+        m = re.match(r"r(\d+)([a-z]?)_", os.path.basename(path))
+        try:
+            with open(path) as f:
+                tj = json.load(f)
+        except (OSError, ValueError):
+            continue
+        cfg = tj.get("config", {})
+        if (cfg.get("streams"), cfg.get("gop"), cfg.get("width_mbs"), cfg.get("height_mbs"), cfg.get("lanes", 1)) != (streams, gop, W, H, lanes):
+            continue
+        key = (int(m.group(1)) if m else -1, m.group(2) if m else "", os.path.getmtime(path))
+        if best is None or key > best[0]:
+            best = (key, path, tj)
+    if best is None or dom not in best[2].get("kernels", {}):
+        return None, None
+    _, path, tj = best
+    src = {"file": os.path.relpath(path, ROOT), "how": "PMC passes (TCC_EA0_RDREQ* / WRREQ*), canned: not measured by this run"}
+    at = tj.get("kernel_ms_per_launch")
+    if at:
+        src["taken_at_kernel_ms"] = at
+        drift = {k: round(live / at[k] - 1.0, 3) for k, live in zip(KERNELS, live_ms) if at.get(k)}
+        src["live_vs_taken"] = drift
+        src["stale"] = any(abs(v) > 0.10 for v in drift.values())
+    else:
+        src["stale"] = None  # the file does not say which build it was taken on
+    return int(best[2]["kernels"][dom]["hbm_bytes_per_launch"]), src
+
+
+def same_input_leg(dev, backend, n_streams, cpu):
+    """SAME INPUT on both sides (the shape of the reference's own `edge264_test -b`, /root/reference/src/edge264_test.c:482-542):
+    the two committed 1080p Annex-B fixtures -- the files oracle/cpu_baseline.py times the unmodified CPU decoder on -- are
+    parsed HERE by the reference's front end + our emitters (edge264_amd/front.py, capture sink), and the resulting command
+    packets are decoded on the GPU by `n_streams` decoders at once: resident in HBM, and from pageable host memory with the
+    H2D copy inside the timed region.  Every picture of four of the streams is compared with the oracle's replay of the packets."""
+    from edge264_amd import front, packet as P
+    from oracle.pyoracle import Oracle  # checker only: the comparison below
+    sdir = os.path.join(ROOT, "tests", "golden", "streams")
+    files = ["hd1080_ipp30.264", "cabac_hd1080_ibbp30.264"]
+    res = {"files": files, "streams": n_streams, "per_file": {}}
+    tot_frames = tot_res = tot_host = tot_parse = 0.0
+    all_ok = True
+    for name in files:
+        with open(os.path.join(sdir, name), "rb") as f:
+            data = f.read()
+        packets, out_frames, parse_s = front.capture_packets(data)
+        parsed = [P.Packet(p) for p in packets]
+        h0 = parsed[0].hdr
+        W, H = int(h0["width_mbs"]), int(h0["height_mbs"])
+        nb = int(h0["plane_size_Y"]) + int(h0["plane_size_C"])
+        used = 0
+        for pk in parsed:
+            used |= 1 << int(pk.hdr["dst_slot"]) | int(pk.hdr["ref_slots"])
+        slots = [i for i in range(32) if used >> i & 1]
+        sts = []
+        for _ in range(n_streams):
+            st = backend.Stream(dev, W, H)
+            st.frame_bytes = nb
+            for i in slots:
+                st.alloc(i)
+                st.fill(i, 0)
+            sts.append(st)
+        dpk = [[dev.upload_packet(p) for p in packets] for _ in sts]
+        bs = [dev.make_batch(sts, [dpk[k][f] for k in range(n_streams)]) for f in range(len(packets))]
+        for b in bs:  # warm-up pass
+            dev.submit_prepared(b, backend.RUN_ALL)
+        dev.sync()
+        t0 = time.perf_counter()
+        for b in bs:
+            dev.submit_prepared(b, backend.RUN_ALL)
+        dev.sync()
+        t_res = time.perf_counter() - t0
+        hbs = [dev.prepare_host_batch(sts, [packets[f]] * n_streams) for f in range(len(packets))]
+        for hb in hbs[:2]:
+            dev.submit_host_prepared(hb, backend.RUN_ALL)
+        dev.sync()
+        t0 = time.perf_counter()
+        for hb in hbs:
+            dev.submit_host_prepared(hb, backend.RUN_ALL)
+        dev.sync()
+        t_host = time.perf_counter() - t0
+        # verification (untimed): one more pass from cleared slots, four streams, every picture
+        orc = Oracle()
+        dpb = [np.zeros(nb + 64, np.uint8) if used >> i & 1 else None for i in range(32)]
+        for st in sts:
+            for i in slots:
+                st.fill(i, 0)
+        probe = sorted({0, n_streams // 3, 2 * n_streams // 3, n_streams - 1})
+        bad = 0
+        for f, p in enumerate(packets):
+            orc.decode_frame(p, dpb, 3)
+            dev.submit_prepared(bs[f], backend.RUN_ALL)
+            dev.sync()
+            d = int(parsed[f].hdr["dst_slot"])
+            for k in probe:
+                bad += 0 if np.array_equal(sts[k].download(d), dpb[d][:nb]) else 1
+        all_ok &= bad == 0
+        n = len(packets) * n_streams
+        res["per_file"][name] = {"pictures": len(packets), "packet_MB_per_picture": round(float(np.mean([len(p) for p in packets])) / 1e6, 3),
+                                 "gpu_resident_frames_per_s": round(n / t_res, 1), "gpu_pcie_inclusive_frames_per_s": round(n / t_host, 1),
+                                 "host_parse_emit_frames_per_s_one_core": round(len(packets) / parse_s, 1),
+                                 "pictures_compared": len(packets) * len(probe), "mismatching": bad}
+        tot_frames += n; tot_res += t_res; tot_host += t_host; tot_parse += parse_s
+        for b in bs:
+            dev.free_batch(b)
+        for row in dpk:
+            for q in row:
+                q.free()
+        for st in sts:
+            st.close()
+    res.update({"gpu_resident_frames_per_s": round(tot_frames / tot_res, 1), "gpu_pcie_inclusive_frames_per_s": round(tot_frames / tot_host, 1),
+                "host_parse_emit_frames_per_s_one_core": round(60 / tot_parse, 1) if tot_parse else None, "bit_exact": bool(all_ok),
+                "what": "both sides decode the SAME two files: GPU = their command packets (reference parser + emitters, parsed in this process) decoded by "
+                        f"{n_streams} concurrent decoders, packets resident in HBM / pageable host packets with validation + H2D inside the timed region; "
+                        "CPU = the unmodified reference decoder on these files (cpu_baseline, same run).  The parser itself is host work on both sides: "
+                        "host_parse_emit is what ONE core delivers, the GPU figures are what the device sustains behind enough parsing cores"})
+    if cpu and cpu.get("value"):
+        res["cpu_reference_frames_per_s"] = cpu["value"]
+        res["cpu_cores"] = cpu["cores"]
+        res["gpu_resident_vs_cpu_all_cores"] = round(res["gpu_resident_frames_per_s"] / cpu["value"], 2)
+        res["gpu_pcie_inclusive_vs_cpu_all_cores"] = round(res["gpu_pcie_inclusive_frames_per_s"] / cpu["value"], 2)
+    return res
+
+
 def main() -> int:
     args = parse_args()
     env_world = os.environ.get("WORLD_SIZE")
@@ -142,7 +274,7 @@ def main() -> int:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=tdev)
 
     # host side of this rank next to its GPU: before the back end creates its threads
-    numa = {"numa_node": -1, "bound": False, "cpus": 0} if (stub or args.no_numa_bind or world == 1) else bind_rank_to_gpu_socket(local_rank)
+    numa = {"numa_node": -1, "bound": False, "cpus": 0} if (stub or args.no_numa_bind) else bind_rank_to_gpu_socket(local_rank)
 
     from edge264_amd import packet as P, synth
 
@@ -356,6 +488,16 @@ def main() -> int:
                 for q in row:
                     q.free()
 
+    # ---- same input on the GPU and on the CPU (N=1 only): the two 1080p bitstream fixtures ---------------------------------
+    same = None
+    if rank == 0 and world == 1 and not args.no_same_input and not stub and not args.capture:
+        try:
+            same = same_input_leg(dev, backend, my_streams, cpu)
+            if cpu is not None:
+                cpu["same_input"] = True  # the files of `same_input` are the files this baseline decodes
+        except Exception as e:  # noqa: BLE001 -- the front-end library is built from the reference tree; without it the leg says so
+            same = {"unavailable": f"{type(e).__name__}: {e}"}
+
     # ---- PCIe-inclusive rate (informational, never `value`): the same GOP submitted from host memory -------------------
     pcie = None
     if rank == 0 and world == 1 and not args.no_host_packets and not stub:
@@ -371,9 +513,9 @@ def main() -> int:
         dt2 = time.perf_counter() - t2
         pcie = {"value": round(2 * len(packets) * len(streams) / dt2, 1), "unit": "frames/s",
                 "packet_MB_per_frame": round(float(np.mean([len(p) for p in packets])) / 1e6, 3),
-                "what": "pageable host packets -> per-macroblock validation + copy into page-locked staging by the back end's host threads "
-                        "(E264_HOST_THREADS, default min(15, cores / 2)) -> H2D on the upload queue beside the kernels of the batch before -> "
-                        "4 kernels, asynchronous, one batch per frame index and lane"}
+                "what": "pageable host packets -> per-macroblock validation + copy into the batch's page-locked staging buffer by the back end's host "
+                        "threads (E264_HOST_THREADS, default min(15, cores / 2)) -> ONE H2D per batch on the upload queue beside the kernels of the batch "
+                        "before -> 4 kernels, asynchronous, one batch per frame index and lane"}
         # the front end's own path: packets assembled in place in page-locked memory and validated where they are produced
         for p in packets:
             assert backend.packet_check(p) == 0
@@ -412,16 +554,7 @@ def main() -> int:
         # the groups overlap, so the wall time of the timed region per frame index is the figure
         tot_ms = sum(kms) if lanes == 1 else elapsed * 1e3 / (args.steps * len(packets))
         e2e_g = (e2e_samples + e2e_cmds) / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            cfg = tj.get("config", {})
-            if (cfg.get("streams"), cfg.get("gop"), cfg.get("width_mbs"), cfg.get("height_mbs"), cfg.get("lanes", 1)) == (args.streams, args.gop, W, H, lanes):
-                k = tj["kernels"].get(dom)
-                if k:
-                    traffic = int(k["hbm_bytes_per_launch"])
+        traffic, traffic_src = newest_traffic(dom, args.streams, args.gop, W, H, lanes, kms)
         out = {
             "metric": "1080p frames/s/GPU (bit-exact YUV) + achieved HBM GB/s vs 8 TB/s peak",
             "value": round(value, 1), "unit": "frames/s",
@@ -429,14 +562,16 @@ def main() -> int:
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u8", "data": "captured bitstream packets" if args.capture else "synthetic",
-            "config": {"workload": (f"{W * 16}x{H * 16} captured packets of a real bitstream ({args.gop}), one copy per stream" if args.capture else
+            "config": {"workload": (f"{W * 16}x{H * 16} captured packets of a real bitstream ({args.gop}), one copy per stream, resident in HBM (H2D excluded, see pcie_inclusive)" if args.capture else
                                     f"{W * 16}x{H * 16} High-profile {args.gop} GOP (synthetic command packets: intra 4x4 / 8x8 / 16x16 I frame + "
                                     "P frames with 6-tap luma / bilinear chroma MC, 2 references, 4x4 and 8x8 transforms, 30% coded residual, "
-                                    "in-loop deblocking), BASELINE configs[2]") + (f"; configs[4]: {args.total_streams} streams sharded over {world} GPU(s)" if strong else ""),
+                                    "in-loop deblocking), BASELINE configs[2]; command packets and DPBs RESIDENT IN HBM before the timed region: the H2D copy of the "
+                                    "packets is excluded from `value` -- see `pcie_inclusive` (host packets, copy included) and `same_input` (packets of real "
+                                    "bitstreams through the reference's parser)") + (f"; configs[4]: {args.total_streams} streams sharded over {world} GPU(s)" if strong else ""),
                        "streams_per_gpu": my_streams, "total_streams": frames_per_step // len(packets), "frames_per_step": frames_per_step,
                        "waves_per_frame": args.waves, "compute_lanes": lanes, "parallelism": f"stream-parallel x{world}, no collectives"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": kern[dom]["frac"], "traffic": traffic, "traffic_source": "profiles/r03_hbm_traffic.json (PMC passes, canned)" if traffic else None,
+                         "frac": kern[dom]["frac"], "traffic": traffic, "traffic_source": traffic_src,
                          "launches": launches, "kernels": kern,
                          "end_to_end": {"ms_per_submission": round(tot_ms, 4), "sample_bytes": int(e2e_samples), "command_bytes": int(e2e_cmds),
                                         "gbps": round(e2e_g, 1), "frac": round(e2e_g / HBM_PEAK_GBS, 4)}},
@@ -444,12 +579,13 @@ def main() -> int:
             "bit_exact": bit_exact, "verify": verify,
             "other_configs": other,
             "pcie_inclusive": pcie,
+            "same_input": same,
             "gpu_event_ms_per_step": round(ev_ms / args.steps, 3),
             "per_rank": {"frames_per_s": [round(r, 1) for r in rates], "min": round(min(rates), 1), "max": round(max(rates), 1),
                          "numa": numa},
         }
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-        if bit_exact is False or (other and any(v["bit_exact"] is False for v in other.values())):
+        if bit_exact is False or (other and any(v["bit_exact"] is False for v in other.values())) or (same and same.get("bit_exact") is False):
             print("bench.py: output is NOT bit-exact: the value above is invalid", file=sys.stderr)
             rc = 3
     for st in streams:

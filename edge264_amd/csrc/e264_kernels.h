@@ -20,6 +20,8 @@ struct E264Job {
 struct E264Fork { hipStream_t aux; hipEvent_t forked, joined; hipEvent_t *amarks; };
 // workgroups e264_pred_kernel needs for a picture of this size (its tile geometry is a build-time choice of the kernels)
 extern "C" int e264_pred_tiles(int width_mbs, int height_mbs);
+// build-time switches of the kernels ("" = product build; e264hip_build_flags hands it out)
+extern "C" const char *e264_kernel_build_flags(void);
 extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int max_mbs, int max_tiles, int mode, int waves, hipStream_t stream, hipEvent_t *marks,
 	const E264Fork *fork);
 

@@ -265,6 +265,54 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 	}
 }
 
+// Build-time switches this code object was compiled with, as a space-separated list ("" = the product build).  The timing
+// ablations (E264_ABL_*, E264_PHASE_*) produce WRONG SAMPLES on purpose: a library that reports one is refused by every loader
+// (e264hip_device_open, edge264_amd/backend.py, the front end) unless E264_ALLOW_ABLATION=1 is set -- the A/B tooling sets it.
+extern "C" const char *e264_kernel_build_flags(void)
+{
+	return ""
+#ifdef E264_ABL_NOBH
+		" E264_ABL_NOBH"
+#endif
+#ifdef E264_ABL_NOEDGE
+		" E264_ABL_NOEDGE"
+#endif
+#ifdef E264_ABL_NOLOAD
+		" E264_ABL_NOLOAD"
+#endif
+#ifdef E264_ABL_NOLUMA
+		" E264_ABL_NOLUMA"
+#endif
+#ifdef E264_ABL_DBKP_NOMOT
+		" E264_ABL_DBKP_NOMOT"
+#endif
+#ifdef E264_ABL_DBK_NOFILTER
+		" E264_ABL_DBK_NOFILTER"
+#endif
+#ifdef E264_ABL_DBK_NOLOAD
+		" E264_ABL_DBK_NOLOAD"
+#endif
+#ifdef E264_ABL_DBK_NOSTORE
+		" E264_ABL_DBK_NOSTORE"
+#endif
+#ifdef E264_PHASE_TIMING
+		" E264_PHASE_TIMING"
+#endif
+#ifdef E264_PHASE_INTRA
+		" E264_PHASE_INTRA"
+#endif
+#ifdef E264_PRED_HPAIR
+		" E264_PRED_HPAIR"
+#endif
+#ifdef E264_PRED_CHROMA_LAST
+		" E264_PRED_CHROMA_LAST"
+#endif
+#ifdef E264_PRED_CLASS_PACKED
+		" E264_PRED_CLASS_PACKED"
+#endif
+		;
+}
+
 extern "C" int e264_pred_tiles(int width_mbs, int height_mbs)
 {
 	return ((width_mbs + PT_W - 1) / PT_W) * ((height_mbs + PT_H - 1) / PT_H);

@@ -228,6 +228,7 @@ int main(int argc, char **argv)
 	//    cannot go on right now -- it is `ahead` pictures ahead, or it must hand out frames (ENOBUFS, edge264.h) while some of its
 	//    pictures are still only queued -- reports BLOCKED and its thread turns to its next decoder (round 3; before, the thread
 	//    slept until the next batch had taken the decoder's packet, with its other decoders idle)
+	const bool must_submit_before_fetch = !parse_only && !no_download;
 	enum Adv { GOT, ENDED, BLOCKED };
 	auto advance = [&](Stream &s) -> Adv {
 		{
@@ -237,8 +238,11 @@ int main(int argc, char **argv)
 		while (!s.done) {
 			const uint8_t *nxt = s.nal < s.end ? F.find_start_code(s.nal, s.end, 0) : s.end;
 			int res = F.decode_NAL(s.dec, s.nal, nxt, nullptr, nullptr);
-			if (res == ENOBUFS) { // the same NAL again once frames have been fetched; they may only be fetched when all parsed pictures are on the device
-				{
+			if (res == ENOBUFS) { // the same NAL again once frames have been fetched.  With read-back (edge264_get_frame downloads the picture)
+				// they may only be fetched when all parsed pictures are on the device; without it (--no-download, --parse-only) fetching a
+				// frame touches nothing on the device: the decoder goes on at once (round 4: before, every decoder stalled here until a
+				// batch had taken its last packet, and the batches in turn waited for packets -- 4.6 k pictures/s where the same cores parse 9.3 k)
+				if (must_submit_before_fetch) {
 					std::lock_guard<std::mutex> lk(mu);
 					if (!s.q.empty()) return BLOCKED;
 				}
@@ -280,7 +284,7 @@ int main(int argc, char **argv)
 			if (!unfinished) break;
 			if (!progressed) { // every decoder of this thread waits for a batch to take its packets
 				std::unique_lock<std::mutex> lk(mu);
-				cv_room.wait_for(lk, std::chrono::milliseconds(1));
+				cv_room.wait_for(lk, std::chrono::milliseconds(2));
 			}
 		}
 		for (size_t i = (size_t)k; i < S.size(); i += (size_t)n_threads) { wait_submitted(S[i]); drain(S[i]); }
@@ -312,6 +316,7 @@ int main(int argc, char **argv)
 	int share = 0;
 	for (int d = 0; d < di; d++) share += dev_obj[(size_t)d] == dev_obj[(size_t)di];
 	const bool pinned = ::g_pinned && share < 2;
+	if (share >= 2 && !parse_only) { fprintf(stderr, "e264_multi: a GPU may be named at most twice in --devices\n"); _exit(2); }
 	const int ev0 = 8 + share * NPEND;
 	auto release_round = [&](int k, bool block) {
 		if (!parked_busy[k]) return true;
@@ -326,15 +331,22 @@ int main(int argc, char **argv)
 	};
 	for (;;) {
 		streams.clear(); hpk.clear(); hsz.clear(); owner.clear();
-		if (pinned) for (int k = 0; k < NPEND; k++) release_round(k, false);
+		if (!parse_only) for (int k = 0; k < NPEND; k++) release_round(k, false);
+		// Pacing by the DEVICE, not by a timer: at most two batches in flight (one in the kernels, one crossing PCIe behind it).  A batch
+		// costs the GPU one picture's dependency chain whatever its size (~3 ms for 1 or 256 pictures), so while the batch before
+		// runs, the parsers' packets pile up and the next batch takes ALL of them: batch size = what the cores parse in one batch
+		// time, no tuning.  (Round 3 waited 2 ms or for 3/4 of the decoders: with 128 decoders on 16 cores neither ever came true
+		// in time, batches of 11-19 pictures left every 2.4 ms and the decoders queued behind them.)
+		if (!parse_only) release_round((pend_next + NPEND - 2) % NPEND, true);
 		{
 			std::unique_lock<std::mutex> lk(mu);
 			auto ready = [&] { size_t n = 0; for (Stream &s : S) n += s.dev_index == di && !s.q.empty(); return n; };
-			auto parsing = [&] { size_t n = 0; for (Stream &s : S) n += s.dev_index == di && !s.finished; return n; };
 			cv_ready.wait(lk, [&] { return ready() > 0 || workers_left == 0; });
 			if (ready() == 0 && workers_left == 0) break;
-			auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
-			cv_ready.wait_until(lk, deadline, [&] { return ready() * 4 >= parsing() * 3 || workers_left == 0; });
+			if (parse_only) { // no device to pace the loop: a short pause so that a round is more than one packet
+				auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(500);
+				cv_ready.wait_until(lk, deadline, [&] { return workers_left == 0; });
+			}
 			for (Stream &s : S)
 				if (s.dev_index == di && !s.q.empty()) { owner.push_back(&s); hpk.push_back(s.q.front().data); hsz.push_back(s.q.front().bytes); }
 		}
@@ -348,14 +360,16 @@ int main(int argc, char **argv)
 		}
 		my_packets += (long)owner.size();
 		my_rounds++;
-		if (pinned) {
+		if (!parse_only) {
 			release_round(pend_next, true);
-			if (H.submit_batch_pinned(dev_obj[(size_t)di], streams.data(), hpk.data(), hsz.data(), (int)streams.size(), 3, 1 /* E264_SUBMIT_TRUSTED */)) { fprintf(stderr, "submit_batch_pinned: %s\n", H.last_error()); _exit(1); }
+			if (pinned) {
+				if (H.submit_batch_pinned(dev_obj[(size_t)di], streams.data(), hpk.data(), hsz.data(), (int)streams.size(), 3, 1 /* E264_SUBMIT_TRUSTED: the front end ran e264hip_packet_check on them */)) { fprintf(stderr, "submit_batch_pinned: %s\n", H.last_error()); _exit(1); }
+				for (const void *p : hpk) parked[pend_next].push_back(const_cast<void *>(p)); // untouched until the batch has left the GPU
+			} else if (H.submit_batch_host(dev_obj[(size_t)di], streams.data(), hpk.data(), hsz.data(), (int)streams.size(), 3)) { fprintf(stderr, "submit_batch_host: %s\n", H.last_error()); _exit(1); }
 			if (H.event_record(dev_obj[(size_t)di], ev0 + pend_next)) { fprintf(stderr, "event_record: %s\n", H.last_error()); _exit(1); }
-			for (const void *p : hpk) parked[pend_next].push_back(const_cast<void *>(p));
 			parked_busy[pend_next] = true;
 			pend_next = (pend_next + 1) % NPEND;
-		} else if (!parse_only && H.submit_batch_host(dev_obj[(size_t)di], streams.data(), hpk.data(), hsz.data(), (int)streams.size(), 3)) { fprintf(stderr, "submit_batch_host: %s\n", H.last_error()); _exit(1); }
+		}
 		{ // the packets are on their way (copied to staging memory, or parked until their batch has retired): let their decoders go on
 			std::lock_guard<std::mutex> lk(mu);
 			for (Stream *s : owner) { if (!pinned) F.free_packet(s->q.front().data); s->q.pop_front(); }

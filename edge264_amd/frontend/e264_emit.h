@@ -290,9 +290,6 @@ static void e264_flush_mb_(E264Emitter *e)
 {
 	E264MbStage *c = &e->cur;
 	c->valid = 0;
-#ifdef E264_X_NOFLUSH
-	return;
-#endif
 	E264FrameBuilder *b = &e->fb[c->slot];
 	if (!b->active || c->addr >= b->n_mbs)
 		return;

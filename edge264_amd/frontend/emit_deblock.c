@@ -12,9 +12,6 @@ static noinline void deblock_mb(Edge264Context *ctx)
 {
 	E264Emitter *e = e264_tls_emitter;
 	E264_PF_BEGIN;
-#ifdef E264_X_NODBK
-	{ mb->filter_edges = 0; return; }
-#endif
 	if (!mb->filter_edges) /* src/edge264_deblock.c:938: already filtered (or never to be) */
 		return;
 	size_t off;

@@ -93,6 +93,11 @@ void e264hip_packet_free(E264Packet *p);
 int  e264hip_submit_batch(E264Device *dev, E264Stream *const *streams, E264Packet *const *packets, int n, int mode);
 /* Host-only validation of a command packet (layout, per-macroblock offsets and indices): what every host-packet entry
  * point below runs before the packet may reach the device.  0 or EINVAL (e264hip_last_error() names the field). */
+/* Build-time switches of the library, space separated ("" = the product build).  E264_ABL_* and E264_PHASE_* entries are timing
+ * ablations whose samples are wrong by design: e264hip_device_open refuses such a build (ENOTSUP) unless E264_ALLOW_ABLATION=1 is in
+ * the environment, and so do the loaders (edge264_amd/backend.py, the front end).  No counterpart in the reference (its variants are
+ * all correct decoders, src/edge264.c:161-216). */
+const char *e264hip_build_flags(void);
 int  e264hip_packet_check(const void *packet, size_t bytes);
 /* Same for packets that still live in HOST memory (the finished frames of many decoders, src/edge264_headers.c:532-568,
  * one per stream): staged through each stream's pinned ring, copied and launched on the device queue without any

@@ -215,3 +215,28 @@ def test_event_query_never_blocks_and_settles(device, oracle):
     finally:
         for st in sts:
             st.close()
+
+
+@pytest.mark.gpu
+def test_bench_distributed_path_on_one_gpu():
+    """The multi-GPU code path of bench.py on the one GPU there is: E264_FORCE_DIST=1 makes
+    rank 0 of a world of 1 create the RCCL process group (backend "nccl", device_id), run the barrier and the all_gather / all_reduce
+    of the rates, and bind itself to the CPUs of the GPU's NUMA node like every rank of an 8-GPU run does."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, E264_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--streams", "4", "--no-cpu-baseline",
+                        "--no-other-configs", "--no-host-packets", "--no-same-input"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["bit_exact"] is True
+    assert line["per_rank"]["frames_per_s"] and line["per_rank"]["min"] > 0
+    numa = line["per_rank"]["numa"]
+    assert set(numa) >= {"numa_node", "bound", "cpus"}
+    if os.path.isdir("/sys/devices/system/node/node0") and numa["numa_node"] < 0:
+        # the platform has NUMA nodes in sysfs: the GPU's node must have been found through its PCI address
+        pytest.fail(f"NUMA node of the GPU not found: {numa}")
