@@ -39,6 +39,10 @@ namespace {
 // -DE264_PHASE_TIMING: wall cycles of the mbpar kernel's phases, summed over all waves (tools/gpu_phase.sh reads them back
 // through e264_debug_phase_cycles).  s_memtime at the phase boundaries drains the LGKM counter, so the numbers are a
 // profile, not a benchmark.
+#if defined(E264_DBK_TIMELINE) && !defined(E264_PHASE_TIMING) // only the start / end stamps of the deblocking kernel's groups of rows (workgroup 0): two s_memtime per 130 steps
+__device__ unsigned long long g_phase[32];
+__device__ unsigned long long g_timeline[128];
+#endif
 #ifdef E264_PHASE_TIMING
 __device__ unsigned long long g_phase[32]; // [0..13] mbpar kernel, [16..29] deblock kernel
 __device__ unsigned long long g_timeline[128]; // deblock kernel, workgroup 0: start / end of every group of five rows
@@ -189,13 +193,24 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 	DkWave &W = lds[wave];
 	const DkRole R = dk_role(lane);
 	const int last_step = dk_last_step(wm);
+#ifdef E264_DBK_WAVE_PERM // groups 0, 1 on the waves of one SIMD (waves w and w + NW / 2 share one), 2, 3 on the next, ...
+	const int wslot = NW >= 4 && NW % 2 == 0 ? ((wave % (NW / 2)) * 2 + wave / (NW / 2)) : wave;
+#else
+	const int wslot = wave;
+#endif
 #pragma unroll 1
-	for (int q = wave; q < nquint; q += NW) {
+	for (int q = wslot; q < nquint; q += NW) {
+#ifndef E264_DBK_NO_PRIO // (1.045 - 1.059 -> 1.039 ms: profiles/r04_ablations.txt item 5)
+		// Groups of rows form ONE dependency chain (a wave waits for the group above), and two waves share a SIMD: with equal priority the
+		// OLDER wave wins the issue slots -- in its second pass (group w + NW) that is the wave whose work depends on its partner's
+		// first-pass group (w + NW / 2).  Earlier passes get the higher priority, whatever the wave's age.
+		{ const int pass = q / NW; if (pass == 0) __builtin_amdgcn_s_setprio(3); else if (pass == 1) __builtin_amdgcn_s_setprio(2); else if (pass == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
 		const int y0 = q * DK_ROWS, y = y0 + R.g;
 		const bool row_ok = !R.idle && y < f.hm, top = q > 0;
 		const int lastg = min(DK_ROWS, f.hm - y0) - 1; // the row the wave below waits for
 		const DkSrc src = dk_src(f, R, y);
-#ifdef E264_PHASE_TIMING
+#if defined(E264_PHASE_TIMING) || defined(E264_DBK_TIMELINE)
 		if (blockIdx.x == 0 && lane == 0 && q < 64) g_timeline[2 * q] = __builtin_amdgcn_s_memtime();
 #endif
 		v4u p0 = {0, 0, 0, 0}, p1 = p0, tt = p0;
@@ -256,7 +271,7 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 			step(t + 2, 0, p0);
 			step(t + 3, 1, p1);
 		}
-#ifdef E264_PHASE_TIMING
+#if defined(E264_PHASE_TIMING) || defined(E264_DBK_TIMELINE)
 		if (blockIdx.x == 0 && lane == 0 && q < 64) g_timeline[2 * q + 1] = __builtin_amdgcn_s_memtime();
 #endif
 #ifndef E264_PHASE_INTRA
@@ -297,6 +312,9 @@ extern "C" const char *e264_kernel_build_flags(void)
 #endif
 #ifdef E264_PHASE_TIMING
 		" E264_PHASE_TIMING"
+#endif
+#ifdef E264_DBK_TIMELINE
+		" E264_DBK_TIMELINE"
 #endif
 #ifdef E264_PHASE_INTRA
 		" E264_PHASE_INTRA"
@@ -370,7 +388,7 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 	return hipGetLastError();
 }
 
-#ifdef E264_PHASE_TIMING
+#if defined(E264_PHASE_TIMING) || defined(E264_DBK_TIMELINE)
 extern "C" __attribute__((visibility("default"))) int e264_debug_phase_cycles(unsigned long long *out32, int reset)
 {
 	hipDeviceSynchronize();

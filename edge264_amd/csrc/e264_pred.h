@@ -241,6 +241,32 @@ E264_DEV void load_window(const gu8 *plane, int sY, int W, int H, int X, int Y, 
 		}
 	}
 }
+// Rows lo .. hi-1 of the 13-row window at (X, Y), the others left alone (per lane: the one-dimensional classes run in ONE flow, its
+// integer / horizontal-only lanes need rows 2..9, the others 0..12; a partition 4 rows high needs 4 rows fewer).  LOADS ONLY.
+E264_DEV void load_window_rows(const gu8 *plane, int sY, int W, int H, int X, int Y, int lo, int hi, Row4 *A)
+{
+	const int XA = X & ~3;
+#pragma unroll
+	for (int r = 0; r < 13; r++) { A[r].a0 = any_u32(); A[r].a1 = any_u32(); A[r].a2 = any_u32(); A[r].a3 = any_u32(); }
+	if (XA >= 0 && XA + 12 <= W - 4 && Y + lo >= 0 && Y + hi - 1 <= H - 1) { // inside the frame: one 16-byte load per row
+		const gu8 *p = plane + (ptrdiff_t)Y * sY + XA;
+#pragma unroll
+		for (int r = 0; r < 13; r++) {
+			if (r < lo || r >= hi)
+				continue;
+			const v4u v = *(const gv4u *)(p + (ptrdiff_t)r * sY);
+			A[r].a0 = v.x; A[r].a1 = v.y; A[r].a2 = v.z; A[r].a3 = v.w;
+		}
+	} else {
+#pragma unroll
+		for (int r = 0; r < 13; r++) {
+			if (r < lo || r >= hi)
+				continue;
+			const gu8 *row = plane + (size_t)min(max(Y + r, 0), H - 1) * sY;
+			A[r].a0 = ref_dword(row, XA, W); A[r].a1 = ref_dword(row, XA + 4, W); A[r].a2 = ref_dword(row, XA + 8, W); A[r].a3 = ref_dword(row, XA + 12, W);
+		}
+	}
+}
 // ... and the byte alignment: afterwards byte c of row r is sample (X + c, Y + r)
 template <int NR>
 E264_DEV void align_window(Row4 *A, int X)
@@ -414,6 +440,56 @@ E264_DEV void luma_d(const Row4 A[13], int xF, int yF, const LumaSink &sink)
 		brow(s, b);
 		hrow(g, j, h);
 		sink_row(sink, j, v_lerp_u8(b[0], h[0], ONES8), v_lerp_u8(b[1], h[1], ONES8));
+	}
+}
+
+// Classes 0 .. 3 as ONE flow (round 4).  A tile's items are few per class (a 16 x 4 tile of a P picture: ~20 / 65 / 65 / 90 of the
+// four), every class list padded to whole waves left most waves half empty: 7 class-waves where the items fill 4.  The four flows
+// nest -- G is a byte shuffle, class 1 is b (+ G), class 2 is h (+ G), class 3 is b + h -- so here they are one list, sorted by
+// class, and a wave computes the PARTS its lanes need (wave-uniform branches) and every lane selects: a wave that straddles two
+// classes costs what its dearer class costs, not the sum.  A: the 13-row window, aligned (rows the lane did not fetch are
+// never selected).
+//   out = lerp(P, Q):  class 0: G, G   class 1: b, (xF == 2 ? b : G(dx = xF == 3))   class 2: h, (yF == 2 ? h : G(dy = yF == 3))
+//                      class 3: b of row 2 + (yF == 3), h of column 2 + (xF == 3)
+#ifdef E264_HOST_INTRINSICS
+#define PRED_ANY(x) true // (host build: every part computed; the selects decide)
+#else
+#define PRED_ANY(x) __any(x)
+#endif
+E264_DEV void luma_1d(const Row4 A[13], int xF, int yF, const LumaSink &sink)
+{
+	const bool use_b = xF != 0, use_h = yF != 0;
+	const bool any_b = PRED_ANY(use_b), any_h = PRED_ANY(use_h), any_g = PRED_ANY(!(use_b && use_h));
+	const uint32_t dxh = use_b && xF == 3;          // class 3: h of column 2 + dx (class 2: column 2)
+	const bool dyb = use_h && yF == 3;              // class 3: b of row 2 + dy (class 1: row 2)
+	const uint32_t dxg = !use_h && xF == 3;         // class 1: G of column 2 + dx
+	const bool dyg = !use_b && yF == 3;             // class 2: G of row 2 + dy
+	const bool q_is_p = xF == 2 || yF == 2;         // no quarter-sample average: the half sample itself
+	uint32_t g[13][2];
+#pragma unroll
+	for (int r = 0; r < 13; r++) {
+		if (any_h) gcols(A[r], dxh, g[r]);
+		else { g[r][0] = any_u32(); g[r][1] = any_u32(); }
+		if (r < 5)
+			continue;
+		const int j = r - 5;
+		uint32_t b[2] = {any_u32(), any_u32()}, h[2] = {any_u32(), any_u32()}, G[2] = {any_u32(), any_u32()};
+		if (any_b) {
+			Row4 s;
+			s.a0 = dyb ? A[j + 3].a0 : A[j + 2].a0; s.a1 = dyb ? A[j + 3].a1 : A[j + 2].a1;
+			s.a2 = dyb ? A[j + 3].a2 : A[j + 2].a2; s.a3 = dyb ? A[j + 3].a3 : A[j + 2].a3;
+			brow(s, b);
+		}
+		if (any_h) hrow(g, j, h);
+		if (any_g) {
+			Row4 s;
+			s.a0 = dyg ? A[j + 3].a0 : A[j + 2].a0; s.a1 = dyg ? A[j + 3].a1 : A[j + 2].a1;
+			s.a2 = dyg ? A[j + 3].a2 : A[j + 2].a2; s.a3 = dyg ? A[j + 3].a3 : A[j + 2].a3;
+			gcols(s, dxg, G);
+		}
+		const uint32_t P0 = use_b ? b[0] : use_h ? h[0] : G[0], P1 = use_b ? b[1] : use_h ? h[1] : G[1];
+		const uint32_t Q0 = (use_b && use_h) ? h[0] : q_is_p ? P0 : G[0], Q1 = (use_b && use_h) ? h[1] : q_is_p ? P1 : G[1];
+		sink_row(sink, j, v_lerp_u8(P0, Q0, ONES8), v_lerp_u8(P1, Q1, ONES8));
 	}
 }
 
@@ -638,8 +714,13 @@ E264_DEV void pred_item(PredLds &L, const FrameCtx &f, const PredTile &t, int li
 		chroma_load(ref + f.psY + (f.sC >> 1), f.sC, f.W >> 1, f.H >> 1, XC, YC, h8, (my & 7) != 0, cw[1]);
 	}
 #endif
+#ifdef E264_PRED_MERGE1D
+	if (cls <= 3) load_window_rows(ref, f.sY, f.W, f.H, X, Y, cls <= 1 ? 2 : 0, (cls <= 1 ? 10 : 13) - (h8 ? 0 : 4), A); // (per lane: G and b only look at rows 2..9)
+	else load_window<13>(ref, f.sY, f.W, f.H, X, Y, h8, A);
+#else
 	if (cls <= 1) load_window<8>(ref, f.sY, f.W, f.H, X, Y + 2, h8, A); // G and b only look at rows 2..9
 	else load_window<13>(ref, f.sY, f.W, f.H, X, Y, h8, A);
+#endif
 #ifdef E264_PRED_CHROMA_LAST
 	if (hp) chroma_load12(cplane, f.sC, f.W >> 1, f.H >> 1, XCp, YC, (my & 7) != 0, cw3);
 	else {
@@ -709,6 +790,13 @@ E264_DEV void pred_item(PredLds &L, const FrameCtx &f, const PredTile &t, int li
 		return;
 	}
 #endif
+#ifdef E264_PRED_MERGE1D
+	if (cls <= 3) { // (wave-uniform: the one-dimensional classes share their waves with nobody else)
+		align_window<13>(A, X);
+		luma_1d(A, mx & 3, my & 3, sink);
+	} else if (cls == 4) { align_window<13>(A, X); luma_2dh(A, my & 3, sink); }
+	else { align_window<13>(A, X); luma_2dv(A, mx & 3, sink); }
+#else
 	if (cls <= 1) {
 		align_window<8>(A, X);
 		if (cls == 0) luma_g(A, sink);
@@ -720,6 +808,7 @@ E264_DEV void pred_item(PredLds &L, const FrameCtx &f, const PredTile &t, int li
 		else if (cls == 4) luma_2dh(A, my & 3, sink);
 		else luma_2dv(A, mx & 3, sink);
 	}
+#endif
 }
 
 E264_DEV void pred_phase_items(PredLds &L, const FrameCtx &f, const PredTile &t, int list, int tid)
@@ -727,7 +816,21 @@ E264_DEV void pred_phase_items(PredLds &L, const FrameCtx &f, const PredTile &t,
 	// The sorted list is walked from its END (the two-dimensional classes first): when the tile has more items than
 	// threads, the extra pass that only the first waves make -- while the others wait at the barrier -- then holds the
 	// cheapest items (integer and one-dimensional positions) instead of the most expensive ones.
-#ifndef E264_PRED_CLASS_PACKED
+#ifdef E264_PRED_MERGE1D
+	// the two-dimensional classes (5, 4) each from a wave boundary, then classes 2, 3, 1, 0 back to back (luma_1d): dear items first
+	const int c5 = L.cnt[5], c4 = L.cnt[4], c2 = L.cnt[2], c3 = L.cnt[3], c1 = L.cnt[1], c0 = L.cnt[0];
+	const int k5 = (c5 + 63) & ~63, k4 = (c4 + 63) & ~63, n1d = c2 + c3 + c1 + c0;
+	for (int p = tid; p < k5 + k4 + n1d; p += PT_NT) {
+		int cls, idx;
+		if (p < k5) { cls = 5; idx = p; if (idx >= c5) continue; }
+		else if (p < k5 + k4) { cls = 4; idx = p - k5; if (idx >= c4) continue; }
+		else {
+			idx = p - k5 - k4; cls = 2;
+			if (idx >= c2) { idx -= c2; cls = 3; if (idx >= c3) { idx -= c3; cls = 1; if (idx >= c1) { idx -= c1; cls = 0; } } }
+		}
+		pred_item(L, f, t, list, cls, *pred_list_slot(L, cls, idx));
+	}
+#elif !defined(E264_PRED_CLASS_PACKED)
 	// Every class starts at a wave boundary: a wave runs ONE of the six flows (packed back to back, a wave of a 256-thread tile
 	// straddles two classes more often than not and executes both: 418 M instead of 348 M VALU wave-instructions per launch,
 	// profiles/r03_pmc_sq_instruction_mix.txt).  More partly filled waves, fewer instructions: 1.380 -> 1.312 ms.
@@ -1004,8 +1107,15 @@ E264_DEV void pred_phase_residual(PredLds &L, const FrameCtx &f, int tid)
 	const uint16_t *l4 = &L.lst[0][0], *l8 = &L.lst[2][0];
 	for (int p = tid; p < n4; p += PT_NT)
 		res_item4(L, f, l4[p]);
+#ifdef E264_PRED_RES8_FIRST_WAVES
 	for (int p = tid; p < n8; p += PT_NT)
 		res_item8(L, f, l8[p]);
+#else
+	// the 8x8 blocks from the workgroup's LAST threads: the 4x4 list rarely fills all four waves, so the long 8x8 transforms run beside
+	// the 4x4 ones instead of behind them on the first wave (the others wait at the barrier for the slowest: 20 % of the kernel's wave time)
+	for (int p = PT_NT - 1 - tid; p < n8; p += PT_NT)
+		res_item8(L, f, l8[p]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

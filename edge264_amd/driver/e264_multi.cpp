@@ -343,8 +343,8 @@ int main(int argc, char **argv)
 			auto ready = [&] { size_t n = 0; for (Stream &s : S) n += s.dev_index == di && !s.q.empty(); return n; };
 			cv_ready.wait(lk, [&] { return ready() > 0 || workers_left == 0; });
 			if (ready() == 0 && workers_left == 0) break;
-			if (parse_only) { // no device to pace the loop: a short pause so that a round is more than one packet
-				auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(500);
+			{ // a short pause so that a round is more than the first packet that turned up (an idle device, or none: --parse-only)
+				auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(parse_only ? 500 : 300);
 				cv_ready.wait_until(lk, deadline, [&] { return workers_left == 0; });
 			}
 			for (Stream &s : S)

@@ -21,7 +21,8 @@ DIR = os.environ.get("E264_CONFORMANCE_DIR", os.path.join(ROOT, "conformance"))
 CLIPS = sorted(glob.glob(os.path.join(DIR, "*.264")))
 FRONT = os.path.join(ROOT, "edge264_amd", "libedge264_hipfront.so")
 
-pytestmark = pytest.mark.skipif(not CLIPS or not os.path.exists(FRONT), reason=f"no conformance clips in {DIR} (or front end not built)")
+# (the clip tests parametrise over CLIPS: none collected when the directory is empty; tests/test_conformance_harness.py proves on
+# generated clips, laid out the same way, that the code below is alive)
 
 
 def check(clip, frames, codes):
@@ -39,18 +40,28 @@ def check(clip, frames, codes):
             pytest.fail(f"{os.path.basename(path)}: first difference in frame {first // per} at byte {first % per}")
 
 
-@pytest.mark.parametrize("clip", CLIPS, ids=[os.path.basename(c) for c in CLIPS])
-def test_clip_capture_oracle(clip, oracle):
+def run_capture(clip, oracle):
+    """one clip through reference front end + emitters + oracle replay (CPU)"""
     from oracle.pyoracle import HipFront
     frames, codes, _ = HipFront().decode_capture(open(clip, "rb").read(), oracle)
     check(clip, frames, codes)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("clip", CLIPS, ids=[os.path.basename(c) for c in CLIPS])
-def test_clip_hip(clip):
+def run_hip(clip):
+    """one clip through reference front end + emitters + libedge264_hip.so (GPU)"""
     from oracle.pyoracle import HipFront
     h = HipFront()
     h.lib.e264front_set_sink(0)
     frames, codes = h.decode(open(clip, "rb").read())
     check(clip, frames, codes)
+
+
+@pytest.mark.parametrize("clip", CLIPS, ids=[os.path.basename(c) for c in CLIPS])
+def test_clip_capture_oracle(clip, oracle):
+    run_capture(clip, oracle)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip", CLIPS, ids=[os.path.basename(c) for c in CLIPS])
+def test_clip_hip(clip):
+    run_hip(clip)

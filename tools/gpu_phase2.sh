@@ -2,7 +2,7 @@
 # phase profile of e264_pred_kernel: make -C edge264_amd/csrc variant NAME=phase DEFS=-DE264_PHASE_TIMING
 TAG=${1:-ph}; shift
 REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
-export E264_HIP_LIB=$REPO/edge264_amd/variants/libedge264_hip_phase.so
+export E264_ALLOW_ABLATION=1 E264_HIP_LIB=${E264_HIP_LIB:-$REPO/edge264_amd/variants/libedge264_hip_phase.so}
 timeout 300 python - "$@" > $OUT/phase.txt 2>$OUT/phase.err <<'PY'
 import ctypes as C, os, sys
 sys.argv = ["bench.py", "--no-cpu-baseline", "--no-verify", "--steps", "2", "--warmup", "1"] + sys.argv[1:]
