@@ -26,6 +26,8 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <execinfo.h>
+#include <pthread.h>
+#include <sched.h>
 #include <signal.h>
 #include <unistd.h>
 #include <atomic>
@@ -91,6 +93,7 @@ struct Stream {
 	struct Pkt { void *data; size_t bytes; };
 	std::deque<Pkt> q;     // parsed, not yet submitted (guarded by the queue mutex)
 	bool finished = false; // its worker will queue nothing more
+	std::atomic<bool> held{false}; // a parser thread is inside this decoder right now
 	int dev_index = 0;     // which of --devices holds its frames
 };
 
@@ -128,6 +131,7 @@ int main(int argc, char **argv)
 	bool &pinned = g_pinned; // --pageable turns it off: packets are assembled in page-locked buffers (e264front_set_pinned) and submitted in place
 	                    // (e264hip_submit_batch_pinned, E264_SUBMIT_TRUSTED: the producer is the emitter) instead of being validated
 	                    // again and copied into staging memory by the back end
+	bool pin = false; // --pin: parser thread k runs on the k-th CPU this process may use (the submitters float): no migration, warm caches
 	bool parse_only = false; // --parse-only: sink 1, no GPU: packets are produced and dropped (front-end speed / debugging)
 	std::vector<std::string> files;
 	for (int i = 1; i < argc; i++) {
@@ -144,6 +148,7 @@ int main(int argc, char **argv)
 		else if (a == "--threads") n_threads = atoi(next().c_str());
 		else if (a == "--loops") loops = atoi(next().c_str());
 		else if (a == "--ahead") ahead = std::max(1, atoi(next().c_str()));
+		else if (a == "--pin") pin = true;
 		else if (a == "--out") out_dir = next();
 		else if (a == "--dump-packets") dump_path = next();
 		else files.push_back(a);
@@ -175,19 +180,17 @@ int main(int argc, char **argv)
 	F.set_download(no_download ? 0 : 1);
 	if (parse_only) pinned = false;
 	F.set_pinned(pinned ? 1 : 0);
-	std::vector<Stream> S;
-	S.reserve((size_t)repeat * files.size()); // Stream keeps pointers into its own data: the vector must never reallocate (std::deque has no noexcept move: elements would be COPIED)
+	std::deque<Stream> S; // (a deque never moves its elements: Stream keeps pointers into its own data and is not movable)
 	for (int r = 0; r < repeat; r++)
 		for (const std::string &path : files) {
-			Stream s;
 			FILE *f = fopen(path.c_str(), "rb");
 			if (!f) { perror(path.c_str()); return 2; }
 			fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
-			s.data.resize((size_t)n + 64);
-			if (fread(s.data.data(), 1, (size_t)n, f) != (size_t)n) { perror("fread"); return 2; }
-			fclose(f);
-			S.push_back(std::move(s));
+			S.emplace_back();
 			Stream &t = S.back();
+			t.data.resize((size_t)n + 64);
+			if (fread(t.data.data(), 1, (size_t)n, f) != (size_t)n) { perror("fread"); return 2; }
+			fclose(f);
 			t.end = t.data.data() + n;
 			const uint8_t *p = F.find_start_code(t.data.data(), t.end, 0);
 			t.nal = p < t.end ? p + 3 : t.end;
@@ -218,6 +221,9 @@ int main(int argc, char **argv)
 		}
 	};
 	long rounds = 0, packets = 0, total_frames = 0;
+	// where the parser threads' time goes (summed over threads, seconds): inside edge264_decode_NAL, fetching frames, asleep with nothing to do
+	std::atomic<long long> ns_decode{0}, ns_drain{0}, ns_idle{0}, ns_submit{0};
+	auto now_ns = [] { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	std::mutex mu;                       // guards every Stream::q / finished and the counters below
 	std::condition_variable cv_room;     // a packet left a queue (workers wait for room / for their packets to be on the device)
 	std::condition_variable cv_ready;    // a packet entered a queue, or a decoder finished (the submitter waits)
@@ -237,7 +243,9 @@ int main(int argc, char **argv)
 		}
 		while (!s.done) {
 			const uint8_t *nxt = s.nal < s.end ? F.find_start_code(s.nal, s.end, 0) : s.end;
+			const long long t_dec = now_ns();
 			int res = F.decode_NAL(s.dec, s.nal, nxt, nullptr, nullptr);
+			ns_decode += now_ns() - t_dec;
 			if (res == ENOBUFS) { // the same NAL again once frames have been fetched.  With read-back (edge264_get_frame downloads the picture)
 				// they may only be fetched when all parsed pictures are on the device; without it (--no-download, --parse-only) fetching a
 				// frame touches nothing on the device: the decoder goes on at once (round 4: before, every decoder stalled here until a
@@ -246,7 +254,9 @@ int main(int argc, char **argv)
 					std::lock_guard<std::mutex> lk(mu);
 					if (!s.q.empty()) return BLOCKED;
 				}
+				const long long t_dr = now_ns();
 				drain(s);
+				ns_drain += now_ns() - t_dr;
 				continue;
 			}
 			void *pkt = nullptr; size_t bytes = 0;
@@ -266,25 +276,35 @@ int main(int argc, char **argv)
 		}
 		return ENDED;
 	};
-	// worker threads: thread k owns decoders k, k+T, k+2T, ... and keeps each of them up to `ahead` pictures ahead
 	if (n_threads < 1) n_threads = 1;
 	if ((size_t)n_threads > S.size()) n_threads = (int)S.size();
 	int workers_left = n_threads;
+	// Any thread advances any decoder (round 4; before: thread k owned decoders k, k + T, ... -- with two input files and an even T half
+	// the threads held only the CABAC B-picture stream, which parses at 460 pictures/s against 1150 for the CAVLC one, and the run
+	// waited for them).  A thread walks the decoders from where it left off and takes the first one nobody holds that can go on.
+	std::atomic<size_t> unfinished_count{S.size()};
 	auto worker = [&](int k) {
-		for (;;) {
-			bool progressed = false, unfinished = false;
-			for (size_t i = (size_t)k; i < S.size(); i += (size_t)n_threads) {
-				Stream &s = S[i];
-				if (s.finished) continue;
-				const Adv a = advance(s);
-				if (a == GOT) progressed = true;
-				if (a == ENDED) { std::lock_guard<std::mutex> lk(mu); s.finished = true; cv_ready.notify_all(); }
-				else unfinished = true;
+		size_t at = (size_t)k * S.size() / (size_t)n_threads;
+		while (unfinished_count.load() > 0) {
+			bool progressed = false;
+			for (size_t n = 0; n < S.size(); n++) {
+				Stream &s = S[(at + n) % S.size()];
+				if (s.finished || s.held.exchange(true)) continue;
+				if (!s.finished) {
+					const Adv a = advance(s);
+					if (a == ENDED) { // its last packets still have to reach the device before its frames are fetched: wait_submitted below
+						std::lock_guard<std::mutex> lk(mu);
+						s.finished = true; unfinished_count--; cv_ready.notify_all();
+					}
+					if (a == GOT) { progressed = true; at = (at + n + 1) % S.size(); s.held = false; break; }
+				}
+				s.held = false;
 			}
-			if (!unfinished) break;
-			if (!progressed) { // every decoder of this thread waits for a batch to take its packets
+			if (!progressed && unfinished_count.load() > 0) { // every decoder waits for a batch to take its packets (or is in another thread's hands)
+				const long long t_id = now_ns();
 				std::unique_lock<std::mutex> lk(mu);
-				cv_room.wait_for(lk, std::chrono::milliseconds(2));
+				cv_room.wait_for(lk, std::chrono::milliseconds(1));
+				ns_idle += now_ns() - t_id;
 			}
 		}
 		for (size_t i = (size_t)k; i < S.size(); i += (size_t)n_threads) { wait_submitted(S[i]); drain(S[i]); }
@@ -295,6 +315,17 @@ int main(int argc, char **argv)
 	auto t0 = std::chrono::steady_clock::now();
 	std::vector<std::thread> pool;
 	for (int k = 0; k < n_threads; k++) pool.emplace_back(worker, k);
+	if (pin) {
+		cpu_set_t allowed;
+		if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) {
+			std::vector<int> cpus;
+			for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &allowed)) cpus.push_back(c);
+			for (int k = 0; k < n_threads && !cpus.empty(); k++) {
+				cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpus[(size_t)k % cpus.size()], &one);
+				pthread_setaffinity_np(pool[(size_t)k].native_handle(), sizeof(one), &one);
+			}
+		}
+	}
 	// 2. the submitter: one batch = the oldest queued picture of every decoder that has one.  It waits until most of the
 	//    decoders that are still parsing have a picture ready (or 2 ms have passed): a batch costs the device about one
 	//    picture's dependency chain whatever its size, so small batches would only queue up device time.
@@ -360,6 +391,7 @@ int main(int argc, char **argv)
 		}
 		my_packets += (long)owner.size();
 		my_rounds++;
+		const long long t_sub = now_ns();
 		if (!parse_only) {
 			release_round(pend_next, true);
 			if (pinned) {
@@ -370,6 +402,7 @@ int main(int argc, char **argv)
 			parked_busy[pend_next] = true;
 			pend_next = (pend_next + 1) % NPEND;
 		}
+		ns_submit += now_ns() - t_sub;
 		{ // the packets are on their way (copied to staging memory, or parked until their batch has retired): let their decoders go on
 			std::lock_guard<std::mutex> lk(mu);
 			for (Stream *s : owner) { if (!pinned) F.free_packet(s->q.front().data); s->q.pop_front(); }
@@ -394,7 +427,9 @@ int main(int argc, char **argv)
 		F.free_dec(&s.dec);
 	}
 	if (dump) fclose(dump);
-	printf("{\"streams\": %zu, \"devices\": %zu, \"threads\": %d, \"frames\": %ld, \"packets\": %ld, \"rounds\": %ld, \"avg_batch\": %.2f, \"seconds\": %.4f, \"frames_per_s\": %.1f}\n",
-		S.size(), devices.size(), n_threads, total_frames, packets, rounds, rounds ? (double)packets / rounds : 0.0, sec, sec > 0 ? total_frames / sec : 0.0);
+	printf("{\"streams\": %zu, \"devices\": %zu, \"threads\": %d, \"frames\": %ld, \"packets\": %ld, \"rounds\": %ld, \"avg_batch\": %.2f, \"seconds\": %.4f, \"frames_per_s\": %.1f, "
+		"\"thread_seconds\": {\"decode_NAL\": %.2f, \"get_frame\": %.2f, \"idle\": %.2f, \"submit_calls\": %.2f}, \"decode_ms_per_picture\": %.3f}\n",
+		S.size(), devices.size(), n_threads, total_frames, packets, rounds, rounds ? (double)packets / rounds : 0.0, sec, sec > 0 ? total_frames / sec : 0.0,
+		ns_decode.load() * 1e-9, ns_drain.load() * 1e-9, ns_idle.load() * 1e-9, ns_submit.load() * 1e-9, packets ? ns_decode.load() * 1e-6 / (double)packets : 0.0);
 	return 0;
 }

@@ -58,9 +58,8 @@ typedef struct {
 #ifdef E264_EMIT_PROFILE
 #include <x86intrin.h>
 enum { E264_PF_TOUCH, E264_PF_LEVELS, E264_PF_FLUSH, E264_PF_FINISH, E264_PF_DEBLOCK, E264_PF_INTRA, E264_PF_N };
-static __thread unsigned long long e264_pf[E264_PF_N], e264_pf_calls[E264_PF_N];
 #define E264_PF_BEGIN unsigned long long pf_t0_ = __rdtsc()
-#define E264_PF_END(k) do { e264_pf[k] += __rdtsc() - pf_t0_; e264_pf_calls[k]++; } while (0)
+#define E264_PF_END(k) do { if (e264_tls_emitter) { e264_tls_emitter->pf[k] += __rdtsc() - pf_t0_; e264_tls_emitter->pf_calls[k]++; } } while (0)
 #else
 #define E264_PF_BEGIN do {} while (0)
 #define E264_PF_END(k) do {} while (0)
@@ -105,6 +104,9 @@ typedef struct E264Emitter {
 	Edge264AllocCb user_alloc;
 	Edge264FreeCb user_free;
 	void *user_arg;
+#ifdef E264_EMIT_PROFILE
+	unsigned long long pf[8], pf_calls[8]; /* per decoder (one thread at a time is inside a decoder) */
+#endif
 	/* capture queue */
 	struct E264Captured { uint8_t *data; size_t bytes; struct E264Captured *next; } *cap_head, *cap_tail;
 } E264Emitter;

@@ -584,8 +584,7 @@ PUBLIC void edge264_free(Edge264Decoder **pdec)
 	{
 		static const char *nm[E264_PF_N] = {"touch(incl. flush)", "levels", "flush_mb", "finish_frame", "deblock_mb", "intra leaves"};
 		for (int k = 0; k < E264_PF_N; k++)
-			if (e264_pf_calls[k]) fprintf(stderr, "emit-profile %-20s calls %10llu  cycles %14llu  (%.0f per call)\n", nm[k], e264_pf_calls[k], e264_pf[k], (double)e264_pf[k] / (double)e264_pf_calls[k]);
-		memset(e264_pf, 0, sizeof(e264_pf)); memset(e264_pf_calls, 0, sizeof(e264_pf_calls));
+			if (e && e->pf_calls[k]) fprintf(stderr, "emit-profile %-20s calls %10llu  cycles %14llu  (%.0f per call)\n", nm[k], e->pf_calls[k], e->pf[k], (double)e->pf[k] / (double)e->pf_calls[k]);
 	}
 #endif
 	e264_tls_emitter = e;
