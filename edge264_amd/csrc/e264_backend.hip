@@ -156,6 +156,7 @@ struct E264Device {
 	enum { NEV = 64 };
 	hipEvent_t sub_ev[NEV] = {};
 	uint64_t sub_serial[NEV] = {};
+	int sub_lane[NEV] = {};
 	// Memory recycler.  hipFree / hipHostFree drain EVERY queue of the device, so what a decoder gives back (frame slots and
 	// their host mirrors at an SPS change or edge264_free, parameter and staging buffers) is parked with the submission that
 	// may still read it and handed to the next request of the same size once that submission has retired.  Parked memory is
@@ -187,12 +188,21 @@ struct E264Stream {
 	// packet staging ring (pinned host) + device copies
 	struct Stage { void *h; uint8_t *d; size_t cap; hipEvent_t done; bool busy; E264Job *d_job; } stage[4];
 	int stage_next;
-	uint64_t slot_serial[E264_MAX_SLOTS]; // submission that wrote the slot last (0: none since it was allocated)
-	uint64_t last_serial;                 // the stream's latest submission
-	bool loose;                           // a fill was queued on the lane since then (no event of its own)
+	// Written by the decoder's own thread (fills, frees) AND by the thread that submits its batches (e264_multi: another one), hence
+	// atomic and only ever raised: serials are handed out in queue order, so "the latest thing queued for this stream" is a maximum,
+	// whichever thread's bookkeeping lands last.  (Round 3 kept a `loose` flag beside a plain serial: a submitter's late "no fill
+	// pending" could erase a parser's "fill pending" and a freed slot went to another lane with the fill still queued.)
+	std::atomic<uint64_t> slot_serial[E264_MAX_SLOTS]; // what wrote the slot last: a submission or a fill (0: nothing since it was allocated)
+	std::atomic<uint64_t> last_serial;                 // the latest submission or fill of the stream
 	hipEvent_t dl_done;                   // the stream's last download
 };
 
+static uint64_t mark_lane(E264Device *dev, int lane);
+static void raise_serial(std::atomic<uint64_t> &a, uint64_t v)
+{
+	uint64_t cur = a.load(std::memory_order_relaxed);
+	while (cur < v && !a.compare_exchange_weak(cur, v, std::memory_order_relaxed)) {}
+}
 static int set_device(E264Device *dev)
 {
 	HIPCHK(hipSetDevice(dev->ordinal), EIO);
@@ -216,7 +226,15 @@ static bool serial_retired(E264Device *dev, uint64_t serial, int lane)
 	if (!serial) return true;
 	hipEvent_t ev = serial_event(dev, serial);
 	if (ev) return hipEventQuery(ev) == hipSuccess;
-	return hipStreamQuery(dev->q[lane]) == hipSuccess; // the event ring has wrapped: the lane itself
+	// the event ring has wrapped past this serial.  A lane runs its work in order: any NEWER entry of the same lane that has retired
+	// proves this one has (a continuously busy lane is never idle, hipStreamQuery alone would keep old blocks parked for good)
+	{
+		std::lock_guard<std::mutex> g(dev->lock);
+		for (int i = 0; i < E264Device::NEV; i++)
+			if (dev->sub_serial[i] > serial && dev->sub_lane[i] == lane && dev->sub_ev[i] && hipEventQuery(dev->sub_ev[i]) == hipSuccess) return true;
+	}
+	(void)hipGetLastError(); // (hipErrorNotReady is not an error to keep)
+	return hipStreamQuery(dev->q[lane]) == hipSuccess;
 }
 // Blocks until it has: the submission's own event, else (ring wrapped) the lane -- never the device.
 static int serial_wait(E264Device *dev, uint64_t serial, int lane)
@@ -246,7 +264,24 @@ static void *mem_acquire(E264Device *dev, size_t bytes, bool host)
 	}
 	void *p = nullptr;
 	hipError_t e = host ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMalloc(&p, bytes);
-	return e == hipSuccess ? p : nullptr;
+	if (e == hipSuccess) return p;
+	// out of memory with blocks of other sizes parked (SPS size changes, many open / close cycles): the retired ones go back to the
+	// driver (this drains the device's queues: the price of running out), then once more
+	(void)hipGetLastError();
+	std::vector<E264Device::Parked> drop;
+	{
+		std::lock_guard<std::mutex> g(dev->park_lock);
+		for (size_t i = 0; i < dev->parked.size();) {
+			if (serial_retired(dev, dev->parked[i].serial, dev->parked[i].lane)) { drop.push_back(dev->parked[i]); dev->parked.erase(dev->parked.begin() + (ptrdiff_t)i); }
+			else i++;
+		}
+	}
+	if (drop.empty()) return nullptr;
+	for (auto &k : drop) { if (k.host) hipHostFree(k.p); else hipFree(k.p); }
+	p = nullptr;
+	e = host ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMalloc(&p, bytes);
+	if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	return p;
 }
 // `serial` / `lane`: the last submission that may touch the block (0: none)
 static void mem_release(E264Device *dev, void *p, size_t bytes, bool host, uint64_t serial, int lane)
@@ -489,9 +524,7 @@ API void e264hip_frame_free(E264Stream *s, int slot)
 {
 	if (!s || slot < 0 || slot >= E264_MAX_SLOTS || !s->h_table[slot]) return;
 	set_device(s->dev);
-	// kernels already queued may still read or write the slot: it is parked until the stream's latest submission has retired
-	// (a fill / upload queued since then is not covered by that submission's event: the lane is waited for, rare)
-	if (s->loose) { hipStreamSynchronize(lane_of(s)); s->loose = false; }
+	// kernels and fills already queued may still read or write the slot: it is parked until the stream's latest work has retired
 	mem_release(s->dev, s->h_table[slot], s->slot_bytes[slot] + 64, false, s->last_serial, s->lane);
 	mem_release(s->dev, s->mirror[slot], s->slot_bytes[slot], true, 0, 0); // downloads are synchronous: nothing in flight
 	s->h_table[slot] = nullptr; s->mirror[slot] = nullptr; s->slot_bytes[slot] = 0; s->slot_serial[slot] = 0;
@@ -503,8 +536,9 @@ API int e264hip_frame_fill(E264Stream *s, int slot, int value)
 	if (!s || slot < 0 || slot >= E264_MAX_SLOTS || !s->h_table[slot]) return fail(EINVAL, "frame_fill slot");
 	if (set_device(s->dev)) return EIO;
 	HIPCHK(hipMemsetAsync(s->h_table[slot], value, s->slot_bytes[slot], lane_of(s)), EIO);
-	s->slot_serial[slot] = 0; // written outside a submission: a later wait falls back to the lane
-	s->loose = true;
+	const uint64_t serial = mark_lane(s->dev, s->lane); // the fill has a serial and an event of its own
+	raise_serial(s->slot_serial[slot], serial);
+	raise_serial(s->last_serial, serial);
 	return 0;
 }
 
@@ -663,10 +697,22 @@ static int launch(E264Device *dev, int lane, const E264Job *d_jobs, int n, int m
 	HIPCHK(e264_launch_frames(d_jobs, n, max_mbs, max_tiles, mode, dev->waves | dev->intra_waves << 8, dev->q[lane], marks, &fork), EIO);
 	const uint64_t serial = ++dev->serial;
 	const int idx = (int)(serial % E264Device::NEV);
-	if (dev->sub_ev[idx] && hipEventRecord(dev->sub_ev[idx], dev->q[lane]) == hipSuccess) dev->sub_serial[idx] = serial;
+	if (dev->sub_ev[idx] && hipEventRecord(dev->sub_ev[idx], dev->q[lane]) == hipSuccess) { dev->sub_serial[idx] = serial; dev->sub_lane[idx] = lane; }
 	else dev->sub_serial[idx] = 0;
 	if (serial_out) *serial_out = serial;
 	return 0;
+}
+
+// A serial for work queued on a lane OUTSIDE a batch submission (a fill): same numbering, same event ring, so that whatever
+// waits for "the stream's latest work" or parks memory behind it covers the fill too.
+static uint64_t mark_lane(E264Device *dev, int lane)
+{
+	std::lock_guard<std::mutex> g(dev->lock);
+	const uint64_t serial = ++dev->serial;
+	const int idx = (int)(serial % E264Device::NEV);
+	if (dev->sub_ev[idx] && hipEventRecord(dev->sub_ev[idx], dev->q[lane]) == hipSuccess) { dev->sub_serial[idx] = serial; dev->sub_lane[idx] = lane; }
+	else dev->sub_serial[idx] = 0;
+	return serial;
 }
 
 // Blocks until the submission that wrote `slot` last has retired (not until the device is idle).
@@ -734,8 +780,8 @@ API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
 	hipEventRecord(st->done, q);
 	st->busy = true;
 	if (r) return r;
-	s->slot_serial[dst] = s->last_serial = serial;
-	s->loose = false;
+	raise_serial(s->slot_serial[dst], serial);
+	raise_serial(s->last_serial, serial);
 	return 0;
 }
 
@@ -845,7 +891,7 @@ API int e264hip_batch_submit(E264Batch *b, int mode)
 		if (w.first->lane != b->lane) return fail(EINVAL, "a stream of the batch was bound to another lane after batch_create");
 	uint64_t serial = 0;
 	int r = launch(b->dev, b->lane, b->d_jobs, b->n, b->max_mbs, b->max_tiles, mode, &serial);
-	if (!r) for (auto &w : b->writes) { w.first->slot_serial[w.second] = w.first->last_serial = serial; w.first->loose = false; }
+	if (!r) for (auto &w : b->writes) { raise_serial(w.first->slot_serial[w.second], serial); raise_serial(w.first->last_serial, serial); }
 	return r;
 }
 
@@ -1002,7 +1048,7 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 			stage_of[i]->busy = true;
 		}
 	if (r) return r;
-	for (int i = 0; i < n; i++) { streams[i]->slot_serial[dst_of[i]] = streams[i]->last_serial = serial; streams[i]->loose = false; }
+	for (int i = 0; i < n; i++) { raise_serial(streams[i]->slot_serial[dst_of[i]], serial); raise_serial(streams[i]->last_serial, serial); }
 	return 0;
 }
 

@@ -52,6 +52,7 @@ typedef struct {
 	uint8_t *payload;
 	size_t payload_len, payload_cap;
 	int n_inter;
+	int oom;              /* a realloc failed while the picture was assembled: e264_finish_frame returns ENOMEM instead of a packet */
 } E264FrameBuilder;
 
 /* -DE264_EMIT_PROFILE (tools/hostprof): cycle counters around the emitters' own work, printed by edge264_free.  Off in the product. */
@@ -162,6 +163,7 @@ static E264FrameBuilder *e264_builder(E264Emitter *e, int slot)
 		b->n_slices = 0;
 		b->payload_len = 0;
 		b->n_inter = 0;
+		b->oom = 0;
 		b->frame_id = dec->FrameIds[slot];
 		b->active = 1;
 	}
@@ -174,10 +176,26 @@ static int e264_slice_index(E264Emitter *e, E264FrameBuilder *b)
 		if (b->slice_serial[i] == e->serial)
 			return i;
 	if (b->n_slices == b->cap_slices) {
-		b->cap_slices = b->cap_slices ? b->cap_slices * 2 : 8;
-		b->slices = realloc(b->slices, sizeof(E264SliceParams) * (size_t)b->cap_slices);
-		b->slice_serial = realloc(b->slice_serial, sizeof(int) * (size_t)b->cap_slices);
-		b->slice_filled = realloc(b->slice_filled, (size_t)b->cap_slices);
+		const int cap = b->cap_slices ? b->cap_slices * 2 : 8;
+		E264SliceParams *ns = malloc(sizeof(E264SliceParams) * (size_t)cap);
+		int *nser = malloc(sizeof(int) * (size_t)cap);
+		uint8_t *nf = malloc((size_t)cap);
+		if (!ns || !nser || !nf) { /* out of memory: the picture is dropped (ENOMEM from e264_finish_frame); keep the tables usable */
+			free(ns); free(nser); free(nf);
+			b->oom = 1;
+			if (b->n_slices > 0) return b->n_slices - 1;
+			static E264SliceParams spare_slice; static int spare_serial; static uint8_t spare_filled;
+			b->slices = &spare_slice; b->slice_serial = &spare_serial; b->slice_filled = &spare_filled; /* never freed through these (cap_slices stays 0: see edge264_free) */
+			b->slice_filled[0] = 1; b->n_slices = 1;
+			return 0;
+		}
+		if (b->n_slices) {
+			memcpy(ns, b->slices, sizeof(E264SliceParams) * (size_t)b->n_slices);
+			memcpy(nser, b->slice_serial, sizeof(int) * (size_t)b->n_slices);
+			memcpy(nf, b->slice_filled, (size_t)b->n_slices);
+		}
+		if (b->cap_slices) { free(b->slices); free(b->slice_serial); free(b->slice_filled); }
+		b->slices = ns; b->slice_serial = nser; b->slice_filled = nf; b->cap_slices = cap;
 	}
 	E264SliceParams *s = &b->slices[b->n_slices];
 	memset(s, 0, sizeof(*s));
@@ -218,8 +236,10 @@ static void e264_fill_slice(E264Emitter *e, E264FrameBuilder *b, int idx, const 
 static void e264_payload_append(E264FrameBuilder *b, const void *src, size_t n)
 {
 	if (b->payload_len + n > b->payload_cap) {
-		b->payload_cap = (b->payload_len + n) * 2 + 4096;
-		b->payload = realloc(b->payload, b->payload_cap);
+		const size_t cap = (b->payload_len + n) * 2 + 4096;
+		uint8_t *p = realloc(b->payload, cap);
+		if (!p) { b->oom = 1; return; }
+		b->payload = p; b->payload_cap = cap;
 	}
 	memcpy(b->payload + b->payload_len, src, n);
 	b->payload_len += n;
@@ -228,8 +248,10 @@ static void e264_payload_append(E264FrameBuilder *b, const void *src, size_t n)
 static uint8_t *e264_payload_reserve(E264FrameBuilder *b)
 {
 	if (b->payload_len + 1024 > b->payload_cap) {
-		b->payload_cap = (b->payload_len + 1024) * 2 + 65536;
-		b->payload = realloc(b->payload, b->payload_cap);
+		const size_t cap = (b->payload_len + 1024) * 2 + 65536;
+		uint8_t *p = realloc(b->payload, cap);
+		if (!p) { b->oom = 1; return NULL; }
+		b->payload = p; b->payload_cap = cap;
 	}
 	size_t pad = (size_t)-(ptrdiff_t)b->payload_len & 7;
 	memset(b->payload + b->payload_len, 0, pad);
@@ -330,8 +352,10 @@ static void e264_flush_mb_(E264Emitter *e)
 			m->modes[q] = c->modes[q];
 	if (c->kind == E264_MB_INTER) {
 		if (b->mot_len + 160 > b->mot_cap) {
-			b->mot_cap = b->mot_cap * 2 + (size_t)b->n_mbs * 24 + 4096;
-			b->mot = realloc(b->mot, b->mot_cap);
+			const size_t cap = b->mot_cap * 2 + (size_t)b->n_mbs * 24 + 4096;
+			uint8_t *p = realloc(b->mot, cap);
+			if (!p) { b->oom = 1; m->kind = E264_MB_ABSENT; return; }
+			b->mot = p; b->mot_cap = cap;
 		}
 		uint32_t d[2] = {(uint32_t)b->mot_len, 0};
 		b->mot_len += e264_motion_emit(M->refPic, M->refIdx, (const int32_t *)(const void *)M->mvs, b->mot + b->mot_len, &d[1], &b->ref_slots);
@@ -344,6 +368,7 @@ static void e264_flush_mb_(E264Emitter *e)
 		return;
 	}
 	uint8_t *w = e264_payload_reserve(b), *w0 = w;
+	if (!w) { m->coded = 0; m->payload_off = 0; return; } /* (b->oom is set: the picture will not be sent) */
 	m->payload_off = (uint32_t)b->payload_len;
 	if (c->coded & E264_CODED_LUMA_DC) { memcpy(w, c->luma_dc, 32); w += 32; }
 	if (c->coded & E264_CODED_CHROMA_DC) { memcpy(w, c->chroma_dc, 16); w += 16; }

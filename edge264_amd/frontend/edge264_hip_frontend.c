@@ -85,13 +85,19 @@ static int g_pkt_pinned = 0; /* e264front_set_pinned: the pool's buffers are pag
                               * the emitters assemble a picture's packet where the H2D transfer reads it, and the batch
                               * front end submits it in place (e264hip_submit_batch_pinned) instead of having it validated again and copied */
 #define E264_PKT_POOL_MAX ((size_t)2 << 30) /* bytes kept for reuse; beyond that buffers go back to the allocator */
+static size_t g_pkt_pinned_bytes = 0; /* page-locked buffers in the pool: counted apart (they are never handed back: hipHostFree drains every queue of the
+                                       * device), so that they do not push ordinary buffers out of the pool's budget */
 static uint8_t *e264_pkt_alloc_on(size_t bytes, E264Device *dev)
 {
 	struct E264PktBuf *b = NULL, **pp;
-	const int pinned = g_pkt_pinned && dev != NULL;
+	const int pinned = g_pkt_pinned && dev != NULL && hip.host_alloc != NULL;
 	pthread_mutex_lock(&g_pkt_lock);
 	for (pp = &g_pkt_free; *pp; pp = &(*pp)->next)
-		if ((*pp)->cap >= bytes && ((*pp)->pinned_by != NULL) == pinned) { b = *pp; *pp = b->next; g_pkt_free_bytes -= b->cap; break; }
+		if ((*pp)->cap >= bytes && (*pp)->pinned_by == (pinned ? dev : NULL)) { /* page-locked through THIS device (its H2D engine reads it in place) */
+			b = *pp; *pp = b->next;
+			if (b->pinned_by) g_pkt_pinned_bytes -= b->cap; else g_pkt_free_bytes -= b->cap;
+			break;
+		}
 	pthread_mutex_unlock(&g_pkt_lock);
 	if (!b) {
 		size_t cap = (bytes + bytes / 4 + 65535) & ~(size_t)65535; /* pictures of one stream differ in size: a quarter of headroom */
@@ -107,8 +113,8 @@ static void e264_pkt_free(void *data)
 	if (!data) return;
 	struct E264PktBuf *b = (struct E264PktBuf *)data - 1;
 	pthread_mutex_lock(&g_pkt_lock);
-	/* page-locked buffers always stay in the pool: hipHostFree drains every queue of the device */
-	if (b->pinned_by || g_pkt_free_bytes + b->cap <= E264_PKT_POOL_MAX) { b->next = g_pkt_free; g_pkt_free = b; g_pkt_free_bytes += b->cap; b = NULL; }
+	if (b->pinned_by) { b->next = g_pkt_free; g_pkt_free = b; g_pkt_pinned_bytes += b->cap; b = NULL; } /* always pooled */
+	else if (g_pkt_free_bytes + b->cap <= E264_PKT_POOL_MAX) { b->next = g_pkt_free; g_pkt_free = b; g_pkt_free_bytes += b->cap; b = NULL; }
 	pthread_mutex_unlock(&g_pkt_lock);
 	free(b);
 }
@@ -325,6 +331,10 @@ static int e264_finish_frame_(E264Emitter *e, int slot, int partial)
 	if (e->cur.valid && e->cur.slot == slot)
 		e264_flush_mb(e);
 	e264_lift_pcm(e, slot);
+	if (b->oom) { /* a record or payload buffer could not grow: the picture's packet would be short of macroblocks */
+		b->active = 0; b->oom = 0;
+		return ENOMEM;
+	}
 	/* what the header says about the records (e264hip_packet_check holds it against them).  Every macroblock written once:
 	 * counted as they were closed.  A picture with a failed slice (records superseded, motion records orphaned): counted here. */
 	int n_coded = b->n_flushed + b->n_lifted, n_inter = b->n_inter;
@@ -594,8 +604,8 @@ PUBLIC void edge264_free(Edge264Decoder **pdec)
 		return;
 	if (ON_DEVICE(e)) hip.stream_close(e->hip_stream);
 	for (int s = 0; s < E264_MAX_SLOTS; s++) {
-		free(e->fb[s].mbs); free(e->fb[s].side); free(e->fb[s].mot); free(e->fb[s].slices); free(e->fb[s].slice_serial);
-		free(e->fb[s].slice_filled); free(e->fb[s].payload);
+		free(e->fb[s].mbs); free(e->fb[s].side); free(e->fb[s].mot); free(e->fb[s].payload);
+		if (e->fb[s].cap_slices) { free(e->fb[s].slices); free(e->fb[s].slice_serial); free(e->fb[s].slice_filled); }
 	}
 	while (e->cap_head) {
 		struct E264Captured *c = e->cap_head;
