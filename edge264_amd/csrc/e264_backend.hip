@@ -406,7 +406,7 @@ API int e264hip_set_option(E264Device *dev, const char *name, int value)
 	}
 	if (!strcmp(name, "waves")) {
 		int prev = dev->waves;
-		if (value == 2 || value == 4 || value == 7 || value == 8) dev->waves = value; // anything else keeps the setting
+		if (value == 2 || value == 4 || value == 7 || value == 8 || value == 106 || value == 107 || value == 108) dev->waves = value; // 100 + n: n luma / chroma waves (e264_deblock_split_kernel) // anything else keeps the setting
 		return prev;
 	}
 	return -1;

@@ -34,18 +34,30 @@
 
 namespace {
 
-#define DK_ROWS 5      // macroblock rows per wave
-#define DK_LANES 12    // lanes per row: 8 luma line pairs + 4 chroma line pairs (Cb and Cr)
+// Geometry of a wave's walk, a build-time kind K (round 4):
+//   K = 2  "mixed" (rounds 2 and 3): 5 macroblock rows x 12 lanes (8 luma line pairs + 4 chroma line pairs) = 60 lanes
+//   K = 0  luma only:   8 rows x 8 lanes = 64 lanes          K = 1  chroma only: 15 rows x 4 lanes = 60 lanes
+// Luma and chroma deblocking never read each other's samples (edge264_deblock.c filters the three planes in turn): with waves of
+// their own the luma instruction stream -- which every lane of a mixed wave executes, chroma lanes included -- serves 8 macroblocks per
+// step instead of 5, and the chroma waves run a third of it (no p1 / q1 updates, no bS 4 luma filter) for 16.
+template <int K> struct DkGeom {
+	static constexpr int ROWS = K == 0 ? 8 : K == 1 ? 15 : 5;     // macroblock rows per wave (chroma: 15, not 16 -- 60 lanes -- so that EIGHT waves' strips fit the CU's 160 KB; a 1080p picture is 5 chroma groups either way)
+	static constexpr int LANES = K == 0 ? 8 : K == 1 ? 4 : 12;    // lanes per row
+	static constexpr int NLUMA = K == 1 ? 0 : 8;                  // of which luma line pairs (the others: chroma line pairs, Cb and Cr)
+	static constexpr bool LUMA = K != 1, CHROMA = K != 0;
+	static constexpr int YROWS = LUMA ? ROWS : 1, CROWS = CHROMA ? ROWS : 1; // strips that exist
+};
+#define DK_ROWS_OF(K) (DkGeom<K>::ROWS)
 #define DK_STRIDE 144  // bytes per strip row: 8 macroblocks x 16 + 16 (keeps the row pairs of a V phase on different banks)
 #define DK_CR 64       // chroma strip row: Cb at +0, Cr at +64
 
-struct __attribute__((aligned(16))) DkWave {
-	uint8_t y[DK_ROWS][16][DK_STRIDE]; // luma strips: macroblock x at columns (x & 7) * 16
-	uint8_t c[DK_ROWS][8][DK_STRIDE];  // chroma strips: macroblock x at columns (x & 7) * 8 (+ DK_CR for Cr)
-	uint8_t ty[4][DK_STRIDE];          // rows -4..-1 above the wave's first row (luma)
-	uint8_t tcp[2][DK_STRIDE];         // never holds samples: the unused taps of chroma lanes land here
-	uint8_t tc[2][DK_STRIDE];          // chroma rows -2, -1 above the wave's first row
-	uint32_t prm[DK_ROWS][2][16];      // parameter records of macroblock x (slot x & 1) of each row
+template <int K> struct __attribute__((aligned(16))) DkWaveT { // (the members a kind does not use shrink to 16 bytes)
+	uint8_t y[DkGeom<K>::YROWS][DkGeom<K>::LUMA ? 16 : 1][DkGeom<K>::LUMA ? DK_STRIDE : 16];   // luma strips: macroblock x at columns (x & 7) * 16
+	uint8_t c[DkGeom<K>::CROWS][DkGeom<K>::CHROMA ? 8 : 1][DkGeom<K>::CHROMA ? DK_STRIDE : 16]; // chroma strips: macroblock x at columns (x & 7) * 8 (+ DK_CR for Cr)
+	uint8_t ty[DkGeom<K>::LUMA ? 4 : 1][DkGeom<K>::LUMA ? DK_STRIDE : 16];          // rows -4..-1 above the wave's first row (luma)
+	uint8_t tcp[DkGeom<K>::CHROMA ? 2 : 1][DkGeom<K>::CHROMA ? DK_STRIDE : 16];     // never holds samples: the unused taps of chroma lanes land here
+	uint8_t tc[DkGeom<K>::CHROMA ? 2 : 1][DkGeom<K>::CHROMA ? DK_STRIDE : 16];      // chroma rows -2, -1 above the wave's first row (right behind tcp)
+	uint32_t prm[DkGeom<K>::ROWS][2][16];      // parameter records of macroblock x (slot x & 1) of each row
 };
 
 // Final samples leave with a streaming hint: nothing in this kernel reads them again, and every line they would occupy in
@@ -82,17 +94,20 @@ struct DkRole {
 	uint32_t tc_add;      // chroma: tC = tC0 + 1
 };
 
-E264_DEV DkRole dk_role(int lane)
+template <int K> E264_DEV bool dk_chroma(const DkRole &R) { return K == 0 ? false : K == 1 ? true : R.chroma; } // (a constant for the one-plane kinds)
+template <int K> E264_DEV DkRole dk_role(int lane)
 {
+	typedef DkGeom<K> G;
+	typedef DkWaveT<K> DkWave;
 	DkRole R;
-	R.g = lane / DK_LANES; R.r = lane - R.g * DK_LANES;
-	R.idle = R.g >= DK_ROWS;
-	if (R.idle) R.g = DK_ROWS - 1; // addresses stay valid; the lane never acts
-	R.chroma = R.r >= 8;
-	R.pi = R.chroma ? R.r - 8 : R.r;
+	R.g = lane / G::LANES; R.r = lane - R.g * G::LANES;
+	R.idle = R.g >= G::ROWS;
+	if (R.idle) R.g = G::ROWS - 1; // addresses stay valid; the lane never acts
+	R.chroma = R.r >= G::NLUMA;
+	R.pi = R.chroma ? R.r - G::NLUMA : R.r;
 	R.seg = R.chroma ? R.pi : R.pi >> 1;
 	const int g = R.g, col = 2 * R.pi;
-	const int oy = (int)offsetof(DkWave, y) + g * 16 * DK_STRIDE, oc = (int)offsetof(DkWave, c) + g * 8 * DK_STRIDE;
+	const int oy = (int)offsetof(DkWave, y) + (G::LUMA ? g : 0) * 16 * DK_STRIDE, oc = (int)offsetof(DkWave, c) + (G::CHROMA ? g : 0) * 8 * DK_STRIDE;
 	const int uy = g ? oy - 4 * DK_STRIDE : (int)offsetof(DkWave, ty);                    // rows -4..-1: rows 12..15 of the strip above
 	const int uc = g ? oc - 2 * DK_STRIDE : (int)offsetof(DkWave, tc);                    // chroma rows -2, -1
 	R.rowa = (R.chroma ? oc : oy) + 2 * R.pi * DK_STRIDE;
@@ -119,7 +134,8 @@ E264_DEV DkRole dk_role(int lane)
 //   tc0     tC0 (chroma: + 1, its tC); 0 where bS == 4
 //   STRONG  0: no lane of this slot can have bS 4; 1: luma + chroma macroblock edge; 2: chroma macroblock edge only
 // ---------------------------------------------------------------------------------------------------------------------
-template <int STRONG>
+//   LUMA    false: every lane of the wave is a chroma lane (K = 1): ap = aq = 0 at compile time, the p1 / q1 updates and the luma bS 4 filter fall away
+template <int STRONG, bool LUMA>
 E264_DEV void dk_edge(s16x2 *v, s16x2 alphaE, s16x2 beta, s16x2 betal, s16x2 tc0, s16x2 small_thr, s16x2 strong)
 {
 	s16x2 &p3 = v[0], &p2 = v[1], &p1 = v[2], &p0 = v[3], &q0 = v[4], &q1 = v[5], &q2 = v[6], &q3 = v[7];
@@ -131,14 +147,15 @@ E264_DEV void dk_edge(s16x2 *v, s16x2 alphaE, s16x2 beta, s16x2 betal, s16x2 tc0
 #endif
 	if (!DK_ANY(as_u(go)))
 		return;
-	const s16x2 ap = ((dk_abs(p2 - p0) - betal) >> 15) & go, aq = ((dk_abs(q2 - q0) - betal) >> 15) & go;
+	const s16x2 zero2 = {0, 0};
+	const s16x2 ap = LUMA ? ((dk_abs(p2 - p0) - betal) >> 15) & go : zero2, aq = LUMA ? ((dk_abs(q2 - q0) - betal) >> 15) & go : zero2;
 	// ---- bS < 4
 	const s16x2 tc = tc0 - ap - aq;
 	const s16x2 delta = dk_clip((d * (short)-4 + p1 - q1 + (short)4) >> 3, -tc, tc) & go;
 	const s16x2 avg = as_s2(v_lerp_u8(as_u(p0), as_u(q0), 0x00010001u)); // (p0 + q0 + 1) >> 1
 	const s16x2 z = {0, 0}, m255 = {255, 255};
-	const s16x2 dp1 = dk_clip((p2 + avg - p1 * (short)2) >> 1, -tc0, tc0) & ap; // tc0 is 0 on bS 4 lines: p1 stays
-	const s16x2 dq1 = dk_clip((q2 + avg - q1 * (short)2) >> 1, -tc0, tc0) & aq;
+	const s16x2 dp1 = LUMA ? dk_clip((p2 + avg - p1 * (short)2) >> 1, -tc0, tc0) & ap : zero2; // tc0 is 0 on bS 4 lines: p1 stays
+	const s16x2 dq1 = LUMA ? dk_clip((q2 + avg - q1 * (short)2) >> 1, -tc0, tc0) & aq : zero2;
 	s16x2 np0 = dk_clip(p0 + delta, z, m255), nq0 = dk_clip(q0 - delta, z, m255);
 	s16x2 np1 = p1 + dp1, nq1 = q1 + dq1;
 	if (STRONG) {
@@ -169,8 +186,10 @@ E264_DEV void dk_edge(s16x2 *v, s16x2 alphaE, s16x2 beta, s16x2 betal, s16x2 tc0
 struct DkPrm { s16x2 al[4], be[4], tc[4]; uint32_t bS[4]; s16x2 thr, strong0, strong2; }; // al: alpha, or 0 where bS is 0
 // Luma lanes: slot e = edge e of the macroblock.  Chroma lanes: slot 0 = Cb macroblock edge, 1 = Cb inner edge, 2 = Cr
 // macroblock edge, 3 = Cr inner edge.  prm: the macroblock's 64-byte parameter record in LDS.
-E264_DEV void dk_params(const uint8_t *prm, const uint8_t *tc0tab, const DkRole &R, DkPrm P[2])
+template <int K> E264_DEV void dk_params(const uint8_t *prm, const uint8_t *tc0tab, const DkRole &R0, DkPrm P[2])
 {
+	DkRole R = R0;
+	R.chroma = dk_chroma<K>(R0);
 	uint32_t alpha[2][4], beta[2][4], ia[2][4], tc0[2][4];
 #pragma unroll
 	for (int dir = 0; dir < 2; dir++)
@@ -202,14 +221,19 @@ E264_DEV void dk_params(const uint8_t *prm, const uint8_t *tc0tab, const DkRole 
 }
 // The four edge slots of a line pair held in v[0..19] (positions -4..15): slot e works on v[4e .. 4e+7]; in chroma lanes
 // only p1 p0 q0 q1 = v[4e+2 .. 4e+5] matter.
+template <int K>
 E264_DEV void dk_filter(s16x2 *v, const DkPrm &P, const DkRole &R)
 {
 #pragma unroll
 	for (int e = 0; e < 4; e++) {
 		const s16x2 bl = as_s2(as_u(P.be[e]) & R.luma_mask);
-		if (e == 0) dk_edge<1>(v, P.al[0], P.be[0], bl, P.tc[0], P.thr, P.strong0);
-		else if (e == 2) dk_edge<2>(v + 8, P.al[2], P.be[2], bl, P.tc[2], P.thr, P.strong2);
-		else dk_edge<0>(v + 4 * e, P.al[e], P.be[e], bl, P.tc[e], P.thr, P.thr);
+		if (K == 1) { // chroma lanes only: slots 0 and 2 are the macroblock edges of Cb and Cr
+			if (e == 0) dk_edge<2, false>(v, P.al[0], P.be[0], bl, P.tc[0], P.thr, P.strong0);
+			else if (e == 2) dk_edge<2, false>(v + 8, P.al[2], P.be[2], bl, P.tc[2], P.thr, P.strong2);
+			else dk_edge<0, false>(v + 4 * e, P.al[e], P.be[e], bl, P.tc[e], P.thr, P.thr);
+		} else if (e == 0) dk_edge<1, true>(v, P.al[0], P.be[0], bl, P.tc[0], P.thr, P.strong0);
+		else if (e == 2 && K == 2) dk_edge<2, true>(v + 8, P.al[2], P.be[2], bl, P.tc[2], P.thr, P.strong2); // (mixed waves: the Cr macroblock edge of the chroma lanes)
+		else dk_edge<0, true>(v + 4 * e, P.al[e], P.be[e], bl, P.tc[e], P.thr, P.thr);
 	}
 }
 
@@ -229,18 +253,20 @@ E264_DEV void dk_filter(s16x2 *v, const DkPrm &P, const DkRole &R)
 //     luma lane:    e1 = 32: pieces k & 3 = macroblock k & 3 of row (k >> 2);          chroma lane: e1 = distance Cb -> Cr:
 //                   piece k & 1 = macroblocks (2 (k & 1), 2 (k & 1) + 1) of plane (k >> 1 & 1), row (k >> 2)
 struct DkSrc { const gu8 *base; int e1, d2; }; // row y of the lane's wave: address of macroblock 0, see above
-E264_DEV DkSrc dk_src(const FrameCtx &f, const DkRole &R, int y)
+template <int K> E264_DEV DkSrc dk_src(const FrameCtx &f, const DkRole &R, int y)
 {
 	DkSrc s;
-	if (!R.chroma) { s.base = f.cur + (size_t)(y * 16 + 2 * R.pi) * f.sY; s.e1 = 32; s.d2 = f.sY; }
+	if (!dk_chroma<K>(R)) { s.base = f.cur + (size_t)(y * 16 + 2 * R.pi) * f.sY; s.e1 = 32; s.d2 = f.sY; }
 	else { s.base = plane_base(f, f.cur, 1) + (size_t)(y * 8 + 2 * R.pi) * f.sC; s.e1 = f.sC >> 1; s.d2 = f.sC; }
 	return s;
 }
 // macroblocks x0 .. x0 + 3 of the lane's row -> N[0..7].  LOADS ONLY.  A chroma piece may start one macroblock before the row
 // (x0 = -1: its second half is macroblock 0) or end one after it: 8 bytes before / after the row, which are the previous /
 // next row, the end of the luma plane, or the slack every frame allocation ends with (e264hip_frame_alloc).
-E264_DEV void dk_fetch4(const DkSrc &S, const DkRole &R, int x0, int wm, v4u N[8])
+template <int K> E264_DEV void dk_fetch4(const DkSrc &S, const DkRole &R0, int x0, int wm, v4u N[8])
 {
+	DkRole R = R0;
+	R.chroma = dk_chroma<K>(R0);
 #ifdef E264_ABL_DBK_NOLOAD // timing ablation
 	if (R.slot_mul) { for (int k = 0; k < 8; k++) N[k] = (v4u){(uint32_t)x0, 1, 2, 3}; return; }
 #endif
@@ -254,8 +280,10 @@ E264_DEV void dk_fetch4(const DkSrc &S, const DkRole &R, int x0, int wm, v4u N[8
 }
 // the registers of macroblock x0 + k out of a fetched group: a = the lane's first row (luma: 16 bytes; chroma: Cb 8 bytes, Cr 8
 // bytes), b = its second row
-E264_DEV void dk_pick(const v4u N[8], const DkRole &R, int k, v4u &a, v4u &b)
+template <int K> E264_DEV void dk_pick(const v4u N[8], const DkRole &R0, int k, v4u &a, v4u &b)
 {
+	DkRole R = R0;
+	R.chroma = dk_chroma<K>(R0);
 #pragma unroll
 	for (int row = 0; row < 2; row++) {
 		const v4u *L = N + 4 * row;
@@ -274,7 +302,7 @@ E264_DEV void dk_fetch_prm(const FrameCtx &f, const DkRole &R, int x, int y, v4u
 	if (R.r < 4)
 		p = *(const gv4u *)(f.dbk + (size_t)(y * f.wm + x) * E264_DBK_BYTES + R.r * 16);
 }
-E264_DEV void dk_commit_prm(DkWave &W, const DkRole &R, int x, const v4u &p)
+template <class DkWave> E264_DEV void dk_commit_prm(DkWave &W, const DkRole &R, int x, const v4u &p)
 {
 	if (R.r < 4)
 		*(v4u *)&W.prm[R.g][x & 1][R.r * 4] = p;
@@ -283,9 +311,10 @@ E264_DEV void dk_commit_prm(DkWave &W, const DkRole &R, int x, const v4u &p)
 // ---------------------------------------------------------------------------------------------------------------------
 // V phase: the vertical edges of macroblock x of the lane's row (a, b: dk_fetch's registers)
 // ---------------------------------------------------------------------------------------------------------------------
-E264_DEV void dk_vpass(DkWave &W, const DkPrm &P, const DkRole &R, const v4u &ra, const v4u &rb, int x)
+template <int K> E264_DEV void dk_vpass(DkWaveT<K> &W, const DkPrm &P, const DkRole &R, const v4u &ra, const v4u &rb, int x)
 {
 	uint8_t *W8 = (uint8_t *)&W;
+	const bool chroma = dk_chroma<K>(R);
 	const int own = R.rowa + (x & 7) * R.slot_mul;
 	const int prev = R.rowa + ((x - 1) & 7) * R.slot_mul + R.slot_mul - 4; // the left neighbour's last 4 bytes (garbage at x = 0: its bS is 0)
 	const uint32_t La = *(const uint32_t *)(W8 + prev), Lb = *(const uint32_t *)(W8 + prev + DK_STRIDE);
@@ -297,7 +326,7 @@ E264_DEV void dk_vpass(DkWave &W, const DkPrm &P, const DkRole &R, const v4u &ra
 #pragma unroll
 	for (int k = 0; k < 20; k++)
 		v[k] = as_s2(v_perm(B[k >> 2], A[k >> 2], 0x0c040c00u + (uint32_t)(k & 3) * 0x00010001u)); // (a_k, b_k) as two 16-bit lanes
-	dk_filter(v, P, R);
+	dk_filter<K>(v, P, R);
 #pragma unroll
 	for (int d = 0; d < 5; d++) {
 		const uint32_t t01 = v_perm(as_u(v[4 * d + 1]), as_u(v[4 * d]), 0x06020400u), t23 = v_perm(as_u(v[4 * d + 3]), as_u(v[4 * d + 2]), 0x06020400u);
@@ -306,7 +335,7 @@ E264_DEV void dk_vpass(DkWave &W, const DkPrm &P, const DkRole &R, const v4u &ra
 	}
 	*(uint32_t *)(W8 + prev) = A[0];
 	*(uint32_t *)(W8 + prev + DK_STRIDE) = B[0];
-	if (!R.chroma) {
+	if (!chroma) {
 		*(v4u *)(W8 + own) = (v4u){A[1], A[2], A[3], A[4]};
 		*(v4u *)(W8 + own + DK_STRIDE) = (v4u){B[1], B[2], B[3], B[4]};
 	} else {
@@ -326,7 +355,7 @@ E264_DEV int dk_haddr(int bT, int bO, int bT2, int bO2, int k)
 {
 	return (k < 4 ? bT + k * DK_STRIDE : k < 10 ? bO + (k - 4) * DK_STRIDE : k < 12 ? bT2 + (k - 4) * DK_STRIDE : bO2 + (k - 4) * DK_STRIDE);
 }
-E264_DEV void dk_hpass(DkWave &W, const DkPrm &P, const DkRole &R, int x)
+template <int K> E264_DEV void dk_hpass(DkWaveT<K> &W, const DkPrm &P, const DkRole &R, int x)
 {
 	uint8_t *W8 = (uint8_t *)&W;
 	const int sl = (x & 7) * R.slot_mul;
@@ -335,7 +364,7 @@ E264_DEV void dk_hpass(DkWave &W, const DkPrm &P, const DkRole &R, int x)
 #pragma unroll
 	for (int k = 0; k < 20; k++)
 		v[k] = as_s2(v_perm(0, *(const uint16_t *)(W8 + dk_haddr(bT, bO, bT2, bO2, k)), 0x0c010c00u));
-	dk_filter(v, P, R);
+	dk_filter<K>(v, P, R);
 #pragma unroll
 	for (int k = 1; k < 19; k++)
 		*(uint16_t *)(W8 + dk_haddr(bT, bO, bT2, bO2, k)) = (uint16_t)v_perm(0, as_u(v[k]), 0x0c0c0200u);
@@ -344,71 +373,79 @@ E264_DEV void dk_hpass(DkWave &W, const DkPrm &P, const DkRole &R, int x)
 // ---------------------------------------------------------------------------------------------------------------------
 // output: group q (macroblocks 4q .. 4q+3) of row y, all 16 rows, as 64-byte row pieces (32 for a chroma plane)
 // ---------------------------------------------------------------------------------------------------------------------
-E264_DEV void dk_flush(const DkWave &W, const FrameCtx &f, const DkRole &R, int q, int y)
+template <int K> E264_DEV void dk_flush(const DkWaveT<K> &W, const FrameCtx &f, const DkRole &R, int q, int y)
 {
+	typedef DkGeom<K> G;
 	const int s0 = (q * 4) & 7, x0 = q * 4;
 #ifdef E264_ABL_DBK_NOSTORE // timing ablation
 	if (f.wm > 0) return;
 #endif
+	if (G::LUMA) {
 #pragma unroll
-	for (int it = 0; it < 6; it++) { // luma: 16 rows x 4 pieces of 16 bytes
-		const int idx = it * DK_LANES + R.r, row = min(idx >> 2, 15), m = idx & 3;
-		const v4u val = *(const v4u *)&W.y[R.g][row][(s0 + m) * 16];
-		if (idx < 64 && x0 + m < f.wm)
-			DK_STORE4((gv4u *)(f.cur + (size_t)(y * 16 + row) * f.sY + (x0 + m) * 16), val);
+		for (int it = 0; it < (64 + G::LANES - 1) / G::LANES; it++) { // luma: 16 rows x 4 pieces of 16 bytes, dealt to the row's lanes
+			const int idx = it * G::LANES + R.r, row = min(idx >> 2, 15), m = idx & 3;
+			const v4u val = *(const v4u *)&W.y[G::LUMA ? R.g : 0][row][(s0 + m) * 16];
+			if (idx < 64 && x0 + m < f.wm)
+				DK_STORE4((gv4u *)(f.cur + (size_t)(y * 16 + row) * f.sY + (x0 + m) * 16), val);
+		}
 	}
+	if (G::CHROMA) {
 #pragma unroll
-	for (int it = 0; it < 3; it++) { // chroma: 2 planes x 8 rows x 2 pieces of 16 bytes (two macroblocks each)
-		const int idx = it * DK_LANES + R.r, pl = min(idx >> 4, 1), row = idx >> 1 & 7, h = idx & 1;
-		const v4u val = *(const v4u *)&W.c[R.g][row][pl * DK_CR + (s0 + 2 * h) * 8];
-		const int n = f.wm - (x0 + 2 * h);
-		gu8 *dst = plane_base(f, f.cur, 1 + pl) + (size_t)(y * 8 + row) * f.sC + (x0 + 2 * h) * 8;
-		if (idx < 32 && n >= 2) DK_STORE4((gv4u *)dst, val);
-		else if (idx < 32 && n == 1) *(gv2u *)dst = (v2u){val.x, val.y};
+		for (int it = 0; it < (32 + G::LANES - 1) / G::LANES; it++) { // chroma: 2 planes x 8 rows x 2 pieces of 16 bytes (two macroblocks each)
+			const int idx = it * G::LANES + R.r, pl = min(idx >> 4, 1), row = idx >> 1 & 7, h = idx & 1;
+			const v4u val = *(const v4u *)&W.c[G::CHROMA ? R.g : 0][row][pl * DK_CR + (s0 + 2 * h) * 8];
+			const int n = f.wm - (x0 + 2 * h);
+			gu8 *dst = plane_base(f, f.cur, 1 + pl) + (size_t)(y * 8 + row) * f.sC + (x0 + 2 * h) * 8;
+			if (idx < 32 && n >= 2) DK_STORE4((gv4u *)dst, val);
+			else if (idx < 32 && n == 1) *(gv2u *)dst = (v2u){val.x, val.y};
+		}
 	}
 }
 
 // The top strip of the wave's first row y0 (> 0): group q, lanes 0..23 of the wave: 16 luma pieces (rows -4..-1) and
 // 8 chroma pieces (2 planes x rows -2, -1 x 2).  fetch: memory -> register; commit: register -> LDS; flush: LDS -> memory.
 struct DkTopAddr { int lds; gu8 *mem; int n; }; // n: 16-byte piece (2), 8-byte piece (1), nothing (0)
-E264_DEV DkTopAddr dk_top_addr(const FrameCtx &f, int lane, int q, int y0)
+// lanes of the wave that carry the top strip: mixed 0..15 luma + 16..23 chroma, luma-only 0..15, chroma-only 0..7
+template <int K> E264_DEV DkTopAddr dk_top_addr(const FrameCtx &f, int lane, int q, int y0)
 {
+	typedef DkWaveT<K> DkWave;
 	DkTopAddr t;
 	const int s0 = (q * 4) & 7, x0 = q * 4;
-	if (lane < 16) {
+	const int nl = K == 1 ? 0 : 16; // luma pieces come first
+	if (lane < nl) {
 		const int row = lane >> 2, m = lane & 3;
 		t.lds = (int)offsetof(DkWave, ty) + row * DK_STRIDE + (s0 + m) * 16;
 		t.mem = f.cur + (size_t)(y0 * 16 - 4 + row) * f.sY + (x0 + m) * 16;
 		t.n = x0 + m < f.wm ? 2 : 0;
 	} else {
-		const int i = lane - 16, pl = i >> 2 & 1, row = i >> 1 & 1, h = i & 1;
+		const int i = lane - nl, pl = i >> 2 & 1, row = i >> 1 & 1, h = i & 1;
 		t.lds = (int)offsetof(DkWave, tc) + row * DK_STRIDE + pl * DK_CR + (s0 + 2 * h) * 8;
 		t.mem = plane_base(f, f.cur, 1 + pl) + (size_t)(y0 * 8 - 2 + row) * f.sC + (x0 + 2 * h) * 8;
-		t.n = lane < 24 ? min(max(f.wm - (x0 + 2 * h), 0), 2) : 0;
+		t.n = (K != 0 && i < 8) ? min(max(f.wm - (x0 + 2 * h), 0), 2) : 0;
 	}
 	return t;
 }
-E264_DEV void dk_top_fetch(const FrameCtx &f, int lane, int q, int y0, v4u &tt)
+template <int K> E264_DEV void dk_top_fetch(const FrameCtx &f, int lane, int q, int y0, v4u &tt)
 {
-	const DkTopAddr t = dk_top_addr(f, lane, q, y0);
+	const DkTopAddr t = dk_top_addr<K>(f, lane, q, y0);
 	if (t.n == 2) tt = *(const gv4u *)t.mem;
 	else if (t.n == 1) { const v2u h = *(const gv2u *)t.mem; tt.x = h.x; tt.y = h.y; }
 }
-E264_DEV void dk_top_commit(DkWave &W, const FrameCtx &f, int lane, int q, int y0, const v4u &tt)
+template <int K> E264_DEV void dk_top_commit(DkWaveT<K> &W, const FrameCtx &f, int lane, int q, int y0, const v4u &tt)
 {
-	const DkTopAddr t = dk_top_addr(f, lane, q, y0);
+	const DkTopAddr t = dk_top_addr<K>(f, lane, q, y0);
 	if (t.n) *(v4u *)((uint8_t *)&W + t.lds) = tt;
 }
-E264_DEV void dk_top_flush(const DkWave &W, const FrameCtx &f, int lane, int q, int y0)
+template <int K> E264_DEV void dk_top_flush(const DkWaveT<K> &W, const FrameCtx &f, int lane, int q, int y0)
 {
-	const DkTopAddr t = dk_top_addr(f, lane, q, y0);
+	const DkTopAddr t = dk_top_addr<K>(f, lane, q, y0);
 	const v4u val = *(const v4u *)((const uint8_t *)&W + t.lds);
 	if (t.n == 2) *(gv4u *)t.mem = val;
 	else if (t.n == 1) *(gv2u *)t.mem = (v2u){val.x, val.y};
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// What a lane does at step t of its wave's walk over rows y0 .. y0+4 (t runs from DK_FIRST_STEP: the pipeline fills first).
+// What a lane does at step t of its wave's walk over rows y0 .. y0+ROWS-1 (t runs from DK_FIRST_STEP: the pipeline fills first).
 #define DK_FIRST_STEP (-4)
 // ---------------------------------------------------------------------------------------------------------------------
 struct DkPlan {
@@ -421,7 +458,8 @@ struct DkPlan {
 	bool publish;                         // (wave-uniform) the groups written at the top of this step are announced at its end
 };
 E264_DEV int dk_groups(int wm) { return (wm + 3) >> 2; }
-E264_DEV int dk_last_step(int wm) { return 4 * (dk_groups(wm) + 1) + 1; }
+// the last row of the wave (g = ROWS - 1) writes its last group at the top of step t0 + 1, t0 the first multiple of 4 with t0 - g >= 4 * groups
+template <int K> E264_DEV int dk_last_step(int wm) { return 4 * dk_groups(wm) + ((DkGeom<K>::ROWS - 1 + 3) & ~3) + 1; }
 E264_DEV DkPlan dk_plan(int t, const DkRole &R, bool row_ok, bool top, int wm)
 {
 	DkPlan p;
@@ -435,18 +473,18 @@ E264_DEV DkPlan dk_plan(int t, const DkRole &R, bool row_ok, bool top, int wm)
 	p.top_fetch = (top && ((t + 2) & 3) == 0 && (t + 2) >> 2 < nq) ? (t + 2) >> 2 : -1;
 	p.top_commit = (top && ((t + 1) & 3) == 0 && (t + 1) >> 2 < nq) ? (t + 1) >> 2 : -1;
 	// after step t0 (a multiple of 4) macroblocks 0 .. t0-g-1 of row g are final, rows 13..15 included (the row below has
-	// passed them); whole groups: t0/4 - 1 for the first row, t0/4 - 2 for the others.  They are written at the TOP of step
-	// t0 + 1 (their strip slots are reused in that step's V phase at the earliest) and announced at its END: the stores
-	// then had a whole step to drain and the release fence does not wait for them.
+	// passed them); whole groups: up to ((t0 - g) >> 2) - 1 (t0/4 - 1 for the first row, t0/4 - 2 for rows 1..4, ...).  They are
+	// written at the TOP of step t0 + 1 (their strip slots are reused in that step's V phase at the earliest) and announced at its
+	// END: the stores then had a whole step to drain and the release fence does not wait for them.
 	const int t0 = t - 1;
 	p.publish = (t0 & 3) == 0 && t0 >= 4;
-	const int qf = (t0 >> 2) - (R.g ? 2 : 1);
+	const int qf = ((t0 - R.g) >> 2) - 1;
 	p.flush = (p.publish && row_ok && qf >= 0 && qf < nq) ? qf : -1;
 	p.top_flush = (p.publish && top && (t0 >> 2) - 1 < nq) ? (t0 >> 2) - 1 : -1;
 	return p;
 }
 // macroblocks of row g that have left for memory with the flush of step t (a publishing step)
-E264_DEV int dk_progress(int t, int g, int wm) { return min(max((((t - 1) >> 2) - (g ? 1 : 0)) * 4, 0), wm); }
+E264_DEV int dk_progress(int t, int g, int wm) { return min(max(((t - 1 - g) >> 2) * 4, 0), wm); }
 
 } // namespace
 #endif

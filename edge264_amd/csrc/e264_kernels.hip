@@ -170,113 +170,155 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 }
 
 
-// In-loop deblocking: one workgroup per picture, NW waves, each walking five macroblock rows at a time (e264_dbk.h; the
-// phases run on the host in tests/emu).  Waves take the groups of five rows round-robin; a wave waits for the wave that
-// owns the rows above through progress[] (macroblocks of that group's last row that have reached memory).
+// In-loop deblocking: one workgroup per picture (e264_dbk.h; the phases run on the host in tests/emu).  A wave walks a GROUP of
+// macroblock rows of kind K (DkGeom: mixed 5 rows luma + chroma, luma-only 8 rows, chroma-only 16 rows) from left to right; it waits for
+// the wave that walks the group above through progress[] (macroblocks of that group's last row that have reached memory).
+// dk_walk_group: one group q of kind K, by the calling wave.  progress: the counters of this kind's chain of groups.
+template <int K>
+static __device__ __forceinline__ void dk_walk_group(DkWaveT<K> &W, const FrameCtx &f, const uint8_t *tc0tab, int *progress, const int q, const int lane, const int tl_slot)
+{
+	typedef DkGeom<K> G;
+	const DkRole R = dk_role<K>(lane);
+	const int wm = f.wm, last_step = dk_last_step<K>(wm);
+	const int y0 = q * G::ROWS, y = y0 + R.g;
+	const bool row_ok = !R.idle && y < f.hm, top = q > 0;
+	const int lastg = min(G::ROWS, f.hm - y0) - 1; // the row the wave below waits for
+	const DkSrc src = dk_src<K>(f, R, y);
+#if defined(E264_PHASE_TIMING) || defined(E264_DBK_TIMELINE)
+	if (blockIdx.x == 0 && lane == 0 && tl_slot < 64) g_timeline[2 * tl_slot] = __builtin_amdgcn_s_memtime();
+#endif
+	v4u p0 = {0, 0, 0, 0}, p1 = p0, tt = p0;
+	v4u N[8];               // samples of four macroblocks of the lane's two rows (dk_fetch4), requested at steps t = 0 mod 4
+	v4u K2a = p0, K2b = p0, K3a = p0, K3b = p0; // the last two of them, kept while the next group is on its way
+	PH_DECL;
+	// one step; k = (t + 2) & 3: which macroblock of its group the step filters (k = 2, 3: of the group before, out of K2 / K3);
+	// sp: the parameter register set of this step's parity (parameters of x+1, requested two steps ago)
+	auto step = [&](const int t, const int k, v4u &sp) __attribute__((always_inline)) {
+		const DkPlan p = dk_plan(t, R, row_ok, top, wm);
+		// what earlier steps requested is picked up BEFORE this step's stores are issued: the compiler cannot count
+		// conditional stores, any use of a loaded register after them is an s_waitcnt vmcnt(0) = a full drain
+		if (p.top_commit >= 0) dk_top_commit<K>(W, f, lane, p.top_commit, y0, tt);
+		if (p.prm_commit) dk_commit_prm(W, R, p.x + 1, sp);
+		v4u ra, rb;
+		if (k < 2) dk_pick<K>(N, R, k, ra, rb);
+		else { ra = k == 2 ? K2a : K3a; rb = k == 2 ? K2b : K3b; }
+		if (k == 1) { dk_pick<K>(N, R, 2, K2a, K2b); dk_pick<K>(N, R, 3, K3a, K3b); } // N is overwritten in the next step
+		asm volatile("" :: "v"(ra), "v"(rb), "v"(K2a), "v"(K2b), "v"(K3a), "v"(K3b)); // the copies happen here
+		if (p.flush >= 0) dk_flush<K>(W, f, R, p.flush, y);
+		if (p.top_flush >= 0) dk_top_flush<K>(W, f, lane, p.top_flush, y0);
+		PH(0);
+		if (p.top_fetch >= 0) { // (wave-uniform) the rows above this group of 4 must have reached memory
+			const int need = min(p.top_fetch * 4 + 4, wm);
+			while (lds_load_relaxed(&progress[q - 1]) < need)
+				__builtin_amdgcn_s_sleep(1);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			dk_top_fetch<K>(f, lane, p.top_fetch, y0, tt);
+		}
+		PH(1);
+		if (p.prm_fetch) dk_fetch_prm(f, R, p.x + 3, y, sp);
+		if (k == 2 && p.grp_fetch) dk_fetch4<K>(src, R, p.x + 2, wm, N);
+		wave_sync();
+		PH(2);
+		DkPrm P[2];
+		if (p.act) {
+			dk_params<K>((const uint8_t *)W.prm[R.g][p.x & 1], tc0tab, R, P);
+			PH(3);
+			dk_vpass<K>(W, P[0], R, ra, rb, p.x);
+		}
+		wave_sync();
+		PH(4);
+		if (p.act) dk_hpass<K>(W, P[1], R, p.x);
+		wave_sync();
+		PH(5);
+		if (p.publish) {
+			// the stores at the top of this step must be visible to the wave below before the counter moves
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			if (lane == lastg * G::LANES)
+				__hip_atomic_store(&progress[q], dk_progress(t, lastg, wm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+		PH(6);
+	};
+#pragma unroll 1
+	for (int t = DK_FIRST_STEP; t <= last_step; t += 4) { // unrolled by four: a group of four macroblocks per fetch, registers by name
+		step(t, 2, p0);
+		step(t + 1, 3, p1);
+		step(t + 2, 0, p0);
+		step(t + 3, 1, p1);
+	}
+#if defined(E264_PHASE_TIMING) || defined(E264_DBK_TIMELINE)
+	if (blockIdx.x == 0 && lane == 0 && tl_slot < 64) g_timeline[2 * tl_slot + 1] = __builtin_amdgcn_s_memtime();
+#endif
+#ifndef E264_PHASE_INTRA
+	PH_FLUSH_DBK(lane);
+#endif
+}
+
+// (a) mixed waves (rounds 2 and 3): NW waves take the groups of five rows round-robin
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jobs)
 {
-	__shared__ DkWave lds[NW];
-	__shared__ int progress[(E264_MAX_ROWS + DK_ROWS - 1) / DK_ROWS];
+	__shared__ DkWaveT<2> lds[NW];
+	__shared__ int progress[(E264_MAX_ROWS + DK_ROWS_OF(2) - 1) / DK_ROWS_OF(2)];
 	__shared__ uint8_t tc0tab[4 * 52]; // row (bS & 3): row 0 is all zero (bS 0 and 4 have no tC0)
 	const int lane = lane_id();
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	FrameCtx f;
 	if (!open_frame(f, jobs[blockIdx.x]) || !f.dbk)
 		return;
-	const int nquint = (f.hm + DK_ROWS - 1) / DK_ROWS, wm = f.wm;
+	const int nquint = (f.hm + DK_ROWS_OF(2) - 1) / DK_ROWS_OF(2);
 	for (int i = threadIdx.x; i < nquint; i += NW * 64)
 		progress[i] = 0;
 	for (int i = threadIdx.x; i < 4 * 52; i += NW * 64)
 		tc0tab[i] = i < 52 ? 0 : c_tc0[i / 52 - 1][i % 52];
 	__syncthreads();
-	DkWave &W = lds[wave];
-	const DkRole R = dk_role(lane);
-	const int last_step = dk_last_step(wm);
-#ifdef E264_DBK_WAVE_PERM // groups 0, 1 on the waves of one SIMD (waves w and w + NW / 2 share one), 2, 3 on the next, ...
-	const int wslot = NW >= 4 && NW % 2 == 0 ? ((wave % (NW / 2)) * 2 + wave / (NW / 2)) : wave;
-#else
-	const int wslot = wave;
-#endif
 #pragma unroll 1
-	for (int q = wslot; q < nquint; q += NW) {
+	for (int q = wave; q < nquint; q += NW) {
 #ifndef E264_DBK_NO_PRIO // (1.045 - 1.059 -> 1.039 ms: profiles/r04_ablations.txt item 5)
 		// Groups of rows form ONE dependency chain (a wave waits for the group above), and two waves share a SIMD: with equal priority the
 		// OLDER wave wins the issue slots -- in its second pass (group w + NW) that is the wave whose work depends on its partner's
 		// first-pass group (w + NW / 2).  Earlier passes get the higher priority, whatever the wave's age.
 		{ const int pass = q / NW; if (pass == 0) __builtin_amdgcn_s_setprio(3); else if (pass == 1) __builtin_amdgcn_s_setprio(2); else if (pass == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #endif
-		const int y0 = q * DK_ROWS, y = y0 + R.g;
-		const bool row_ok = !R.idle && y < f.hm, top = q > 0;
-		const int lastg = min(DK_ROWS, f.hm - y0) - 1; // the row the wave below waits for
-		const DkSrc src = dk_src(f, R, y);
-#if defined(E264_PHASE_TIMING) || defined(E264_DBK_TIMELINE)
-		if (blockIdx.x == 0 && lane == 0 && q < 64) g_timeline[2 * q] = __builtin_amdgcn_s_memtime();
-#endif
-		v4u p0 = {0, 0, 0, 0}, p1 = p0, tt = p0;
-		v4u N[8];               // samples of four macroblocks of the lane's two rows (dk_fetch4), requested at steps t = 0 mod 4
-		v4u K2a = p0, K2b = p0, K3a = p0, K3b = p0; // the last two of them, kept while the next group is on its way
-		PH_DECL;
-		// one step; k = (t + 2) & 3: which macroblock of its group the step filters (k = 2, 3: of the group before, out of K2 / K3);
-		// sp: the parameter register set of this step's parity (parameters of x+1, requested two steps ago)
-		auto step = [&](const int t, const int k, v4u &sp) __attribute__((always_inline)) {
-			const DkPlan p = dk_plan(t, R, row_ok, top, wm);
-			// what earlier steps requested is picked up BEFORE this step's stores are issued: the compiler cannot count
-			// conditional stores, any use of a loaded register after them is an s_waitcnt vmcnt(0) = a full drain
-			if (p.top_commit >= 0) dk_top_commit(W, f, lane, p.top_commit, y0, tt);
-			if (p.prm_commit) dk_commit_prm(W, R, p.x + 1, sp);
-			v4u ra, rb;
-			if (k < 2) dk_pick(N, R, k, ra, rb);
-			else { ra = k == 2 ? K2a : K3a; rb = k == 2 ? K2b : K3b; }
-			if (k == 1) { dk_pick(N, R, 2, K2a, K2b); dk_pick(N, R, 3, K3a, K3b); } // N is overwritten in the next step
-			asm volatile("" :: "v"(ra), "v"(rb), "v"(K2a), "v"(K2b), "v"(K3a), "v"(K3b)); // the copies happen here
-			if (p.flush >= 0) dk_flush(W, f, R, p.flush, y);
-			if (p.top_flush >= 0) dk_top_flush(W, f, lane, p.top_flush, y0);
-			PH(0);
-			if (p.top_fetch >= 0) { // (wave-uniform) the rows above this group of 4 must have reached memory
-				const int need = min(p.top_fetch * 4 + 4, wm);
-				while (lds_load_relaxed(&progress[q - 1]) < need)
-					__builtin_amdgcn_s_sleep(1);
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-				dk_top_fetch(f, lane, p.top_fetch, y0, tt);
-			}
-			PH(1);
-			if (p.prm_fetch) dk_fetch_prm(f, R, p.x + 3, y, sp);
-			if (k == 2 && p.grp_fetch) dk_fetch4(src, R, p.x + 2, wm, N);
-			wave_sync();
-			PH(2);
-			DkPrm P[2];
-			if (p.act) {
-				dk_params((const uint8_t *)W.prm[R.g][p.x & 1], tc0tab, R, P);
-				PH(3);
-				dk_vpass(W, P[0], R, ra, rb, p.x);
-			}
-			wave_sync();
-			PH(4);
-			if (p.act) dk_hpass(W, P[1], R, p.x);
-			wave_sync();
-			PH(5);
-			if (p.publish) {
-				// the stores at the top of this step must be visible to the wave below before the counter moves
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-				if (lane == lastg * DK_LANES)
-					__hip_atomic_store(&progress[q], dk_progress(t, lastg, wm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			}
-			PH(6);
-		};
+		dk_walk_group<2>(lds[wave], f, tc0tab, progress, q, lane, q);
+	}
+}
+
+// (b) luma waves and chroma waves (round 4).  Luma and chroma are two independent chains of groups (8 / 16 rows each); the NW waves
+// take the groups of BOTH chains from one list, luma and chroma interleaved in proportion, through a counter in LDS: a wave that
+// finishes takes the next group of the list, whatever its kind, so the SIMDs stay evenly loaded (the mixed kernel's 14 groups of a
+// 1080p picture fall 4 / 4 / 3 / 3 on the four SIMDs).  A group's predecessor is always earlier in the list: it has been taken.
+union DkWaveAny { DkWaveT<0> l; DkWaveT<1> c; };
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void e264_deblock_split_kernel(const E264Job *jobs)
+{
+	__shared__ DkWaveAny lds[NW];
+	__shared__ int progress_l[(E264_MAX_ROWS + DK_ROWS_OF(0) - 1) / DK_ROWS_OF(0)];
+	__shared__ int progress_c[(E264_MAX_ROWS + DK_ROWS_OF(1) - 1) / DK_ROWS_OF(1)];
+	__shared__ int next_task;
+	__shared__ uint8_t tc0tab[4 * 52];
+	const int lane = lane_id();
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	FrameCtx f;
+	if (!open_frame(f, jobs[blockIdx.x]) || !f.dbk)
+		return;
+	const int nl = (f.hm + DK_ROWS_OF(0) - 1) / DK_ROWS_OF(0), nc = (f.hm + DK_ROWS_OF(1) - 1) / DK_ROWS_OF(1), total = nl + nc;
+	for (int i = threadIdx.x; i < nl; i += NW * 64) progress_l[i] = 0;
+	for (int i = threadIdx.x; i < nc; i += NW * 64) progress_c[i] = 0;
+	for (int i = threadIdx.x; i < 4 * 52; i += NW * 64)
+		tc0tab[i] = i < 52 ? 0 : c_tc0[i / 52 - 1][i % 52];
+	if (threadIdx.x == 0) next_task = 0;
+	__syncthreads();
 #pragma unroll 1
-		for (int t = DK_FIRST_STEP; t <= last_step; t += 4) { // unrolled by four: a group of four macroblocks per fetch, registers by name
-			step(t, 2, p0);
-			step(t + 1, 3, p1);
-			step(t + 2, 0, p0);
-			step(t + 3, 1, p1);
-		}
-#if defined(E264_PHASE_TIMING) || defined(E264_DBK_TIMELINE)
-		if (blockIdx.x == 0 && lane == 0 && q < 64) g_timeline[2 * q + 1] = __builtin_amdgcn_s_memtime();
-#endif
-#ifndef E264_PHASE_INTRA
-		PH_FLUSH_DBK(lane);
-#endif
+	for (;;) {
+		int task = 0;
+		if (lane == 0) task = atomicAdd(&next_task, 1);
+		task = __builtin_amdgcn_readfirstlane(task);
+		if (task >= total)
+			break;
+		// luma groups among the first i tasks of the list: (i * nl) / total; task i is a luma group iff that count grows at i + 1
+		const int lb = task * nl / total, la = (task + 1) * nl / total;
+		if (la > lb) dk_walk_group<0>(lds[wave].l, f, tc0tab, progress_l, lb, lane, lb);
+		else dk_walk_group<1>(lds[wave].c, f, tc0tab, progress_c, task - lb, lane, 32 + task - lb);
 	}
 }
 
@@ -377,7 +419,10 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 	if (marks) hipEventRecord(marks[3], stream);
 	if (side) hipStreamWaitEvent(stream, fork->joined, 0);
 	if (mode & 2) {
-		switch (waves) { // waves per picture, five macroblock rows each (default 8, set by the back end)
+		switch (waves) { // waves per picture (default 8, set by the back end); 100 + n: luma / chroma waves (e264_deblock_split_kernel)
+		case 108: hipLaunchKernelGGL(e264_deblock_split_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs); break;
+		case 107: hipLaunchKernelGGL(e264_deblock_split_kernel<7>, dim3(n_jobs), dim3(448), 0, stream, jobs); break;
+		case 106: hipLaunchKernelGGL(e264_deblock_split_kernel<6>, dim3(n_jobs), dim3(384), 0, stream, jobs); break;
 		case 2: hipLaunchKernelGGL(e264_deblock_kernel<2>, dim3(n_jobs), dim3(128), 0, stream, jobs); break;
 		case 4: hipLaunchKernelGGL(e264_deblock_kernel<4>, dim3(n_jobs), dim3(256), 0, stream, jobs); break;
 		case 8: hipLaunchKernelGGL(e264_deblock_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs); break;

@@ -58,58 +58,71 @@ extern "C" __attribute__((visibility("default"))) int e264emu_dbkparam_frame(con
 	return 0;
 }
 
-// e264_deblock_kernel: dbk = the parameter records (e264emu_dbkparam_frame's output); the picture in dpb[dst_slot] is
-// filtered in place.  Waves are run one after the other (a wave only ever waits for the wave above it), the lanes of a
-// wave phase by phase.
+// e264_deblock_kernel / e264_deblock_split_kernel: dbk = the parameter records (e264emu_dbkparam_frame's output); the picture in
+// dpb[dst_slot] is filtered in place.  Groups of rows are run one after the other (a group only ever waits for the group above it
+// of its own kind), the lanes of a wave phase by phase.  K: the kind of wave (DkGeom): 2 mixed, 0 luma only, 1 chroma only.
 #include "../../edge264_amd/csrc/e264_dbk.h"
-extern "C" __attribute__((visibility("default"))) int e264emu_deblock_frame(const uint8_t *pkt, uint8_t *const *dpb, uint8_t *dbk)
+template <int K>
+static void emu_walk_group(const FrameCtx &f, const uint8_t *tc0tab, int q)
+{
+	typedef DkGeom<K> G;
+	static DkWaveT<K> W;
+	DkRole R[64];
+	for (int lane = 0; lane < 64; lane++) R[lane] = dk_role<K>(lane);
+	memset(&W, 0xA5, sizeof(W));
+	const int y0 = q * G::ROWS;
+	const bool top = q > 0;
+	static v4u N[64][8], K2a[64], K2b[64], K3a[64], K3b[64], np[2][64], tt[64], ra[64], rb[64];
+	memset(N, 0x5A, sizeof(N)); memset(K2a, 0x5A, sizeof(K2a)); memset(K2b, 0x5A, sizeof(K2b)); memset(K3a, 0x5A, sizeof(K3a)); memset(K3b, 0x5A, sizeof(K3b));
+	memset(np, 0x5A, sizeof(np)); memset(tt, 0x5A, sizeof(tt));
+	for (int t4 = DK_FIRST_STEP; t4 <= dk_last_step<K>(f.wm); t4 += 4) // (the kernel's loop: whole groups of four steps)
+	for (int t = t4; t < t4 + 4; t++) {
+		const int par = t & 1, k = (t + 2) & 3; // the parameter register set of this step; which macroblock of its group it filters
+		DkPlan p[64];
+		for (int lane = 0; lane < 64; lane++) {
+			const int y = y0 + R[lane].g;
+			p[lane] = dk_plan(t, R[lane], !R[lane].idle && y < f.hm, top, f.wm);
+			if (p[lane].top_commit >= 0) dk_top_commit<K>(W, f, lane, p[lane].top_commit, y0, tt[lane]);
+			if (p[lane].prm_commit) dk_commit_prm(W, R[lane], p[lane].x + 1, np[par][lane]);
+			if (k < 2) dk_pick<K>(N[lane], R[lane], k, ra[lane], rb[lane]);
+			else { ra[lane] = k == 2 ? K2a[lane] : K3a[lane]; rb[lane] = k == 2 ? K2b[lane] : K3b[lane]; }
+			if (k == 1) { dk_pick<K>(N[lane], R[lane], 2, K2a[lane], K2b[lane]); dk_pick<K>(N[lane], R[lane], 3, K3a[lane], K3b[lane]); }
+			if (p[lane].flush >= 0) dk_flush<K>(W, f, R[lane], p[lane].flush, y);
+			if (p[lane].top_flush >= 0) dk_top_flush<K>(W, f, lane, p[lane].top_flush, y0);
+			if (p[lane].top_fetch >= 0) dk_top_fetch<K>(f, lane, p[lane].top_fetch, y0, tt[lane]);
+			if (p[lane].prm_fetch) dk_fetch_prm(f, R[lane], p[lane].x + 3, y, np[par][lane]);
+			if (k == 2 && p[lane].grp_fetch) dk_fetch4<K>(dk_src<K>(f, R[lane], y), R[lane], p[lane].x + 2, f.wm, N[lane]);
+		}
+		static DkPrm P[64][2];
+		for (int lane = 0; lane < 64; lane++)
+			if (p[lane].act) {
+				dk_params<K>((const uint8_t *)W.prm[R[lane].g][p[lane].x & 1], tc0tab, R[lane], P[lane]);
+				dk_vpass<K>(W, P[lane][0], R[lane], ra[lane], rb[lane], p[lane].x);
+			}
+		for (int lane = 0; lane < 64; lane++)
+			if (p[lane].act) dk_hpass<K>(W, P[lane][1], R[lane], p[lane].x);
+	}
+}
+// split: 0 = mixed waves (e264_deblock_kernel), 1 = luma waves + chroma waves (e264_deblock_split_kernel)
+extern "C" __attribute__((visibility("default"))) int e264emu_deblock_frame2(const uint8_t *pkt, uint8_t *const *dpb, uint8_t *dbk, int split)
 {
 	E264Job job = {pkt, dpb, dbk};
 	FrameCtx f;
 	if (!open_frame(f, job) || !f.dbk)
 		return -1;
-	static DkWave W;
 	uint8_t tc0tab[4 * 52];
 	for (int i = 0; i < 4 * 52; i++) tc0tab[i] = i < 52 ? 0 : c_tc0[i / 52 - 1][i % 52];
-	DkRole R[64];
-	for (int lane = 0; lane < 64; lane++) R[lane] = dk_role(lane);
-	const int nquint = (f.hm + DK_ROWS - 1) / DK_ROWS;
-	for (int q = 0; q < nquint; q++) {
-		memset(&W, 0xA5, sizeof(W));
-		const int y0 = q * DK_ROWS;
-		const bool top = q > 0;
-		static v4u N[64][8], K2a[64], K2b[64], K3a[64], K3b[64], np[2][64], tt[64], ra[64], rb[64];
-		memset(N, 0x5A, sizeof(N)); memset(K2a, 0x5A, sizeof(K2a)); memset(K2b, 0x5A, sizeof(K2b)); memset(K3a, 0x5A, sizeof(K3a)); memset(K3b, 0x5A, sizeof(K3b));
-		memset(np, 0x5A, sizeof(np)); memset(tt, 0x5A, sizeof(tt));
-		for (int t4 = DK_FIRST_STEP; t4 <= dk_last_step(f.wm); t4 += 4) // (the kernel's loop: whole groups of four steps)
-		for (int t = t4; t < t4 + 4; t++) {
-			const int par = t & 1, k = (t + 2) & 3; // the parameter register set of this step; which macroblock of its group it filters
-			DkPlan p[64];
-			for (int lane = 0; lane < 64; lane++) {
-				const int y = y0 + R[lane].g;
-				p[lane] = dk_plan(t, R[lane], !R[lane].idle && y < f.hm, top, f.wm);
-				if (p[lane].top_commit >= 0) dk_top_commit(W, f, lane, p[lane].top_commit, y0, tt[lane]);
-				if (p[lane].prm_commit) dk_commit_prm(W, R[lane], p[lane].x + 1, np[par][lane]);
-				if (k < 2) dk_pick(N[lane], R[lane], k, ra[lane], rb[lane]);
-				else { ra[lane] = k == 2 ? K2a[lane] : K3a[lane]; rb[lane] = k == 2 ? K2b[lane] : K3b[lane]; }
-				if (k == 1) { dk_pick(N[lane], R[lane], 2, K2a[lane], K2b[lane]); dk_pick(N[lane], R[lane], 3, K3a[lane], K3b[lane]); }
-				if (p[lane].flush >= 0) dk_flush(W, f, R[lane], p[lane].flush, y);
-				if (p[lane].top_flush >= 0) dk_top_flush(W, f, lane, p[lane].top_flush, y0);
-				if (p[lane].top_fetch >= 0) dk_top_fetch(f, lane, p[lane].top_fetch, y0, tt[lane]);
-				if (p[lane].prm_fetch) dk_fetch_prm(f, R[lane], p[lane].x + 3, y, np[par][lane]);
-				if (k == 2 && p[lane].grp_fetch) dk_fetch4(dk_src(f, R[lane], y), R[lane], p[lane].x + 2, f.wm, N[lane]);
-			}
-			static DkPrm P[64][2];
-			for (int lane = 0; lane < 64; lane++)
-				if (p[lane].act) {
-					dk_params((const uint8_t *)W.prm[R[lane].g][p[lane].x & 1], tc0tab, R[lane], P[lane]);
-					dk_vpass(W, P[lane][0], R[lane], ra[lane], rb[lane], p[lane].x);
-				}
-			for (int lane = 0; lane < 64; lane++)
-				if (p[lane].act) dk_hpass(W, P[lane][1], R[lane], p[lane].x);
-		}
+	if (!split) {
+		for (int q = 0; q < (f.hm + DK_ROWS_OF(2) - 1) / DK_ROWS_OF(2); q++) emu_walk_group<2>(f, tc0tab, q);
+	} else {
+		for (int q = 0; q < (f.hm + DK_ROWS_OF(1) - 1) / DK_ROWS_OF(1); q++) emu_walk_group<1>(f, tc0tab, q); // (the two chains are independent: any order)
+		for (int q = 0; q < (f.hm + DK_ROWS_OF(0) - 1) / DK_ROWS_OF(0); q++) emu_walk_group<0>(f, tc0tab, q);
 	}
 	return 0;
+}
+extern "C" __attribute__((visibility("default"))) int e264emu_deblock_frame(const uint8_t *pkt, uint8_t *const *dpb, uint8_t *dbk)
+{
+	return e264emu_deblock_frame2(pkt, dpb, dbk, 0);
 }
 
 // the four edge slots of one lane: lines[2][20] (positions -4..15 of the lane's two lines) filtered in place
@@ -117,11 +130,11 @@ extern "C" __attribute__((visibility("default"))) void e264emu_dk_filter(uint8_t
 {
 	uint8_t tc0tab[4 * 52];
 	for (int i = 0; i < 4 * 52; i++) tc0tab[i] = i < 52 ? 0 : c_tc0[i / 52 - 1][i % 52];
-	const DkRole R = dk_role(lane);
+	const DkRole R = dk_role<2>(lane);
 	s16x2 v[20];
 	for (int k = 0; k < 20; k++) v[k] = (s16x2){(short)lines[k], (short)lines[20 + k]};
 	DkPrm P[2];
-	dk_params(prm, tc0tab, R, P);
-	dk_filter(v, P[dir], R);
+	dk_params<2>(prm, tc0tab, R, P);
+	dk_filter<2>(v, P[dir], R);
 	for (int k = 0; k < 20; k++) { lines[k] = (uint8_t)v[k].x; lines[20 + k] = (uint8_t)v[k].y; }
 }

@@ -22,8 +22,8 @@ def emu():
     lib = C.CDLL(os.path.join(d, "libe264_pred_emu.so"))
     lib.e264emu_dbkparam_frame.argtypes = [C.c_char_p, C.c_void_p]
     lib.e264emu_dbkparam_frame.restype = C.c_int
-    lib.e264emu_deblock_frame.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p]
-    lib.e264emu_deblock_frame.restype = C.c_int
+    lib.e264emu_deblock_frame2.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.e264emu_deblock_frame2.restype = C.c_int
     return lib
 
 
@@ -39,11 +39,14 @@ CASES = [
     ("two_wide", "IPB", 2, 6, dict()),                          # one chroma piece (two macroblocks) is the whole row
     ("five_wide", "IPP", 5, 3, dict(residual_prob=0.8)),        # a group of four + one: the chroma piece of the last macroblock hangs over the row
     ("six_wide", "IPB", 6, 4, dict(num_refs=2)),
+    ("tall", "IPP", 5, 35, dict(residual_prob=0.6)),            # 7 mixed groups / 5 luma groups / 3 chroma groups: every hand-off between waves
+    ("h17", "IPB", 4, 17, dict(intra_in_inter=0.3)),            # one row into the second chroma group, the third luma group
 ]
 
 
+@pytest.mark.parametrize("split", [0, 1], ids=["mixed_waves", "luma_and_chroma_waves"])
 @pytest.mark.parametrize("name,gop,w,h,kw", CASES, ids=[c[0] for c in CASES])
-def test_deblock_emu(emu, name, gop, w, h, kw):
+def test_deblock_emu(emu, name, gop, w, h, kw, split):
     g = synth.StreamSynth(w, h, seed=len(name) * 7 + 1, **kw)
     nb = P.frame_bytes(w, h)
     rng = np.random.default_rng(5)
@@ -56,7 +59,7 @@ def test_deblock_emu(emu, name, gop, w, h, kw):
         orc.decode_frame(pkt, mine, 1)          # reconstruction only
         prm = np.zeros((w * h, 64), np.uint8)
         assert emu.e264emu_dbkparam_frame(pkt, prm.ctypes.data) == 0
-        assert emu.e264emu_deblock_frame(pkt, _dpb_array(mine), prm.ctypes.data) == 0
+        assert emu.e264emu_deblock_frame2(pkt, _dpb_array(mine), prm.ctypes.data, split) == 0
         orc.decode_frame(pkt, dpb, 3)           # reconstruction + deblocking: the reference for this frame and the next
         sY = w * 16
         got_y = mine[d][:sY * h * 16].reshape(h * 16, sY)

@@ -209,14 +209,15 @@ def test_max_frame_size(device, oracle):
     run_stream(device, oracle, 31, "IPB", dict(t8x8=True, i_kinds=ALL_I), 256, 144, passes_split=False)
 
 
-@pytest.mark.parametrize("waves", [2, 4, 7, 8])
+@pytest.mark.parametrize("waves", [2, 4, 7, 8, 106, 108])
 def test_deblock_waves_per_frame(device, oracle, waves):
     """Frames wider than the LDS strips and taller than one round of the deblocking kernel (5 x waves rows): strip wrap,
-    the hand-off between waves and between rounds through memory, a last group of fewer than five rows."""
+    the hand-off between waves and between rounds through memory, a last group of fewer than five rows.  100 + n: the kernel with
+    luma waves (8 rows) and chroma waves (16 rows), n waves per picture."""
     prev = device.set_option("waves", waves)
     try:
         run_stream(device, oracle, 3, "IPB", dict(t8x8=True, i_kinds=ALL_I), 5, 21)
-        run_stream(device, oracle, 4, "IPP", dict(), 26, 5 * waves * 2 + 3)
+        run_stream(device, oracle, 4, "IPP", dict(), 26, 5 * (waves % 100) * 2 + 3)
     finally:
         device.set_option("waves", prev)
 
