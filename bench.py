@@ -581,6 +581,7 @@ def main() -> int:
             "pcie_inclusive": pcie,
             "same_input": same,
             "gpu_event_ms_per_step": round(ev_ms / args.steps, 3),
+            "build_flags": backend.build_flags() if hasattr(backend, "build_flags") else None,
             "per_rank": {"frames_per_s": [round(r, 1) for r in rates], "min": round(min(rates), 1), "max": round(max(rates), 1),
                          "numa": numa},
         }

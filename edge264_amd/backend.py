@@ -71,6 +71,7 @@ def load_library():
         "e264hip_kernel_time_ms": (i, [vp, C.POINTER(C.c_double), C.POINTER(i)]),
         "e264hip_set_option": (i, [vp, C.c_char_p, i]),
         "e264hip_build_flags": (C.c_char_p, []),
+        "e264hip_frame_device_ptr": (vp, [vp, i]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if the library does not export the header's symbol
@@ -94,7 +95,7 @@ EXPORTED_SYMBOLS = [
     "e264hip_frame_free", "e264hip_frame_fill", "e264hip_frame_upload", "e264hip_frame_submit",
     "e264hip_packet_buffer", "e264hip_frame_wait", "e264hip_frame_download", "e264hip_packet_upload",
     "e264hip_packet_free", "e264hip_packet_check", "e264hip_submit_batch", "e264hip_submit_batch_host", "e264hip_submit_batch_pinned", "e264hip_host_alloc", "e264hip_host_free", "e264hip_batch_create", "e264hip_batch_submit", "e264hip_batch_free", "e264hip_event_record", "e264hip_event_elapsed_ms", "e264hip_event_query",
-    "e264hip_kernel_timing", "e264hip_kernel_time_ms", "e264hip_set_option", "e264hip_build_flags",
+    "e264hip_kernel_timing", "e264hip_kernel_time_ms", "e264hip_set_option", "e264hip_build_flags", "e264hip_frame_device_ptr",
 ]
 
 

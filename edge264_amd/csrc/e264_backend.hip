@@ -531,6 +531,12 @@ API void e264hip_frame_free(E264Stream *s, int slot)
 	push_table(s);
 }
 
+API void *e264hip_frame_device_ptr(E264Stream *s, int slot)
+{
+	if (!s || slot < 0 || slot >= E264_MAX_SLOTS) return nullptr;
+	return s->h_table[slot];
+}
+
 API int e264hip_frame_fill(E264Stream *s, int slot, int value)
 {
 	if (!s || slot < 0 || slot >= E264_MAX_SLOTS || !s->h_table[slot]) return fail(EINVAL, "frame_fill slot");

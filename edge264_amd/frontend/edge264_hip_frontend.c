@@ -64,6 +64,7 @@ static struct {
 	int (*stream_flush)(E264Stream *);
 	void *(*host_alloc)(E264Device *, size_t);
 	void (*host_free)(E264Device *, void *);
+	void *(*frame_device_ptr)(E264Stream *, int);
 	int (*packet_check)(const void *, size_t);
 	const char *(*build_flags)(void);
 	E264Device *devs[E264_FRONT_MAX_DEVICES]; /* one device object per GPU ordinal, shared by every decoder bound to that GPU */
@@ -164,7 +165,7 @@ static int hip_load(void)
 #define BIND(n) if (!(*(void **)&hip.n = dlsym(hip.lib, "e264hip_" #n))) return ENODEV
 	BIND(device_open); BIND(stream_open); BIND(stream_close); BIND(frame_alloc); BIND(frame_free); BIND(frame_fill);
 	BIND(frame_submit); BIND(packet_buffer); BIND(frame_wait); BIND(frame_download); BIND(stream_flush);
-	BIND(host_alloc); BIND(host_free); BIND(packet_check); BIND(build_flags);
+	BIND(host_alloc); BIND(host_free); BIND(packet_check); BIND(build_flags); BIND(frame_device_ptr);
 #undef BIND
 	{ /* a timing-ablation build of the back end (wrong samples by design) is not a decoder: refused unless asked for by name */
 		const char *f = hip.build_flags(), *a = getenv("E264_ALLOW_ABLATION");
@@ -647,6 +648,20 @@ PUBLIC void *e264front_device_of(Edge264Decoder *dec)
 {
 	E264Emitter *e = emitter_of(dec);
 	return e && ON_DEVICE(e) ? e->hip_dev : NULL;
+}
+
+/* Decode-to-device (e264front_set_download(0)): the HBM address that corresponds to a plane pointer of an Edge264Frame
+ * (samples[i] / samples_mvc[i] as edge264_get_frame filled them in: same offsets, same strides, device memory), after waiting for
+ * the kernels that write the picture.  NULL for a pointer that belongs to no frame of this decoder or a decoder without device. */
+PUBLIC void *e264front_device_samples(Edge264Decoder *dec, const void *samples)
+{
+	E264Emitter *e = emitter_of(dec);
+	size_t off;
+	if (!e || !samples || !ON_DEVICE(e)) return NULL;
+	const int slot = e264_locate(e, (const uint8_t *)samples, &off);
+	if (slot < 0 || hip.frame_wait(e->hip_stream, slot)) return NULL;
+	uint8_t *base = hip.frame_device_ptr(e->hip_stream, slot);
+	return base ? base + off : NULL;
 }
 
 /* DPB slot a sample pointer of Edge264Frame belongs to (samples[] = base view, samples_mvc[] = second view):

@@ -74,6 +74,11 @@ void *e264hip_packet_buffer(E264Stream *s, size_t max_bytes);
 int  e264hip_frame_wait(E264Stream *s, int slot);
 /* Copy the finished frame to its host mirror (what get_frame hands out). */
 int  e264hip_frame_download(E264Stream *s, int slot, void *dst, size_t bytes);
+/* Decode-to-device use (the consumer of the pictures is another GPU stage -- scaler, encoder, inference): the
+ * HBM address of slot `slot` in the reference's frame layout (Edge264Frame: Y plane, then rows of Cb | Cr, strides as in the
+ * packet header), valid until e264hip_frame_free; call e264hip_frame_wait first.  NULL when the slot is not allocated.  Nothing
+ * crosses PCIe.  The reference has no counterpart (its frames are host memory, edge264.h:45-62). */
+void *e264hip_frame_device_ptr(E264Stream *s, int slot);
 /* edge264_flush (src/edge264.c:261-270): wait for what THIS stream has submitted, keep allocations.  (frame_alloc,
  * frame_free, stream_close and frame_download likewise never wait for other decoders' work: freed memory is parked and
  * recycled by the device object instead of hipFree'd, which would drain every queue.) */

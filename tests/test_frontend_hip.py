@@ -125,3 +125,58 @@ def test_concealment_on_the_gpu(front):
         want = sums[f"{name}-{which}-{keep}"]
         assert codes == want["nal_codes"], (name, which, keep)
         assert md5s(frames) == want["md5"], (name, which, keep)
+
+
+def test_decode_to_device_without_readback(front):
+    """Decode-to-device: with e264front_set_download(0) edge264_get_frame copies nothing back; the picture is
+    read where it lies in HBM through e264front_device_samples (the device address behind an Edge264Frame plane pointer, same
+    strides) -- here with a plain hipMemcpy -- and equals the reference's."""
+    import ctypes as C
+    import errno
+    import numpy as np
+    from oracle.pyoracle import Edge264Frame
+    with open(os.path.join(STREAMS, "reference_md5.json")) as f:
+        sums = json.load(f)
+    L = front.lib
+    L.e264front_device_samples.restype = C.c_void_p
+    L.e264front_device_samples.argtypes = [C.c_void_p, C.c_void_p]
+    hipl = C.CDLL("libamdhip64.so")
+    hipl.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    name = "ipb_spatial"
+    data = open(os.path.join(STREAMS, name + ".264"), "rb").read()
+    buf = np.frombuffer(data + b"\0" * 64, np.uint8).copy()
+    base, end = buf.ctypes.data, buf.ctypes.data + len(data)
+    L.e264front_set_download(0)
+    try:
+        dec = C.c_void_p(L.edge264_alloc(0, None, None, 0, None, None, None))
+        assert dec
+        out = Edge264Frame()
+        frames = []
+
+        def drain():
+            while L.edge264_get_frame(dec, C.byref(out), 0) == 0:
+                planes = []
+                for i, (w, h, stride) in enumerate(((out.width_Y, out.height_Y, out.stride_Y), (out.width_C, out.height_C, out.stride_C), (out.width_C, out.height_C, out.stride_C))):
+                    dptr = L.e264front_device_samples(dec, out.samples[i])
+                    assert dptr, "no device address for a frame the decoder handed out"
+                    host = np.zeros((h, stride), np.uint8)
+                    assert hipl.hipMemcpy(host.ctypes.data, dptr, host.nbytes - (stride - w), 2) == 0  # device -> host (the last row ends at its last sample)
+                    planes.append(host[:, :w].copy())
+                frames.append(tuple(planes))
+        nal = L.edge264_find_start_code(base, end, 0) + 3
+        while True:
+            nxt = L.edge264_find_start_code(nal, end, 0) if nal < end else end
+            res = L.edge264_decode_NAL(dec, nal, nxt, None, None)
+            n0 = len(frames)
+            drain()
+            if res == errno.ENOBUFS:
+                assert len(frames) > n0
+                continue
+            if res == errno.ENODATA or nal >= end:
+                break
+            nal = min(nxt + 3, end)
+        drain()
+        L.edge264_free(C.byref(dec))
+    finally:
+        L.e264front_set_download(1)
+    assert md5s(frames) == sums[name]["md5"]

@@ -146,8 +146,8 @@ def test_1080p_ipb(device, oracle):
 
 def test_1080p_config3(device, oracle):
     """BASELINE configs[3] at its own size: IBBP, 8x8 transform, scaling lists, explicit weighted bi-prediction, two
-    references, deblocking -- two seeds, every frame compared."""
-    for seed in (31, 32):
+    references, deblocking -- four seeds, every frame compared."""
+    for seed in (31, 32, 33, 34):
         run_stream(device, oracle, seed, "IPBBP", dict(t8x8=True, scaling=True, weighted=1, num_refs=2, i_kinds=ALL_I), 120, 68, passes_split=False)
 
 

@@ -20,6 +20,7 @@ ap.add_argument("--streams", type=int)
 ap.add_argument("--gop")
 ap.add_argument("--width-mbs", type=int, default=120)
 ap.add_argument("--height-mbs", type=int, default=68)
+ap.add_argument("--bench-json", help="a bench.py line of the SAME build: its live kernel times are recorded in the traffic file (bench.py flags the file as stale when they drift)")
 args = ap.parse_args()
 
 q = """select s.kernel_name, p.name, e.value, d.id
@@ -60,6 +61,11 @@ if args.traffic:
     out["note"] = ("HBM bytes per launch from the L2 memory-side request counters, sized individually: reads 32*RDREQ_32B + 64*RDREQ_64B + "
                    "128*RDREQ_128B, writes 64*WRREQ_64B + 32*(WRREQ - WRREQ_64B); calibrated on tools/calib/pmc_calib.hip "
                    "(profiles/r01_pmc_calibration.txt); averaged over all launches of the GOP")
+    if args.bench_json:
+        with open(args.bench_json) as f:
+            bj = json.load(f)
+        out["kernel_ms_per_launch"] = {k: v["ms_per_launch"] for k, v in bj["roofline"]["kernels"].items()}
+        out["taken_with"] = {"value": bj["value"], "build_flags": bj.get("build_flags")}
     with open(args.traffic, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", args.traffic)
