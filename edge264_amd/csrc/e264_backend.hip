@@ -320,7 +320,8 @@ API int e264hip_device_open(int ordinal, E264Device **out)
 	E264Device *d = new (std::nothrow) E264Device();
 	if (!d) return fail(ENOMEM, "device object");
 	d->ordinal = ordinal;
-	d->waves = 8; // 40 macroblock rows in flight (all the LDS takes: 154 KB); since the samples are fetched four macroblocks at a time 8 waves beat
+	d->waves = 108; // round 4: e264_deblock2_kernel, 8 waves that take luma groups (8 rows) and chroma groups (15 rows) from one list: 0.99 - 1.02 ms against
+	// 1.02 - 1.03 for the mixed waves below (profiles/r04_ablations.txt item 7).  Before (waves = 8, e264_deblock_kernel): 40 macroblock rows in flight (all the LDS takes: 154 KB); since the samples are fetched four macroblocks at a time 8 waves beat
 	              // 7 (1.081 -> 1.051 ms per 256 x 1080p; round 2, one macroblock per fetch: 7 was the optimum)
 	d->intra_waves = 16; // 16 rows in flight: 1.6 -> 1.1 ms per 256-frame launch (the intra kernel fits 128 VGPRs)
 	d->ktiming = false; d->kev_used = 0;
@@ -406,7 +407,7 @@ API int e264hip_set_option(E264Device *dev, const char *name, int value)
 	}
 	if (!strcmp(name, "waves")) {
 		int prev = dev->waves;
-		if (value == 2 || value == 4 || value == 7 || value == 8 || value == 106 || value == 107 || value == 108) dev->waves = value; // 100 + n: n luma / chroma waves (e264_deblock_split_kernel) // anything else keeps the setting
+		if (value == 2 || value == 4 || value == 7 || value == 8 || value == 106 || value == 107 || value == 108) dev->waves = value; // 100 + n: n luma / chroma waves (e264_deblock2_kernel) // anything else keeps the setting
 		return prev;
 	}
 	return -1;

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 // 1080p picture fall 4 / 4 / 3 / 3 on the four SIMDs).  A group's predecessor is always earlier in the list: it has been taken.
 union DkWaveAny { DkWaveT<0> l; DkWaveT<1> c; };
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void e264_deblock_split_kernel(const E264Job *jobs)
+__global__ __launch_bounds__(NW * 64) void e264_deblock2_kernel(const E264Job *jobs)
 {
 	__shared__ DkWaveAny lds[NW];
 	__shared__ int progress_l[(E264_MAX_ROWS + DK_ROWS_OF(0) - 1) / DK_ROWS_OF(0)];
@@ -419,10 +419,10 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 	if (marks) hipEventRecord(marks[3], stream);
 	if (side) hipStreamWaitEvent(stream, fork->joined, 0);
 	if (mode & 2) {
-		switch (waves) { // waves per picture (default 8, set by the back end); 100 + n: luma / chroma waves (e264_deblock_split_kernel)
-		case 108: hipLaunchKernelGGL(e264_deblock_split_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs); break;
-		case 107: hipLaunchKernelGGL(e264_deblock_split_kernel<7>, dim3(n_jobs), dim3(448), 0, stream, jobs); break;
-		case 106: hipLaunchKernelGGL(e264_deblock_split_kernel<6>, dim3(n_jobs), dim3(384), 0, stream, jobs); break;
+		switch (waves) { // waves per picture (default 8, set by the back end); 100 + n: luma / chroma waves (e264_deblock2_kernel)
+		case 108: hipLaunchKernelGGL(e264_deblock2_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs); break;
+		case 107: hipLaunchKernelGGL(e264_deblock2_kernel<7>, dim3(n_jobs), dim3(448), 0, stream, jobs); break;
+		case 106: hipLaunchKernelGGL(e264_deblock2_kernel<6>, dim3(n_jobs), dim3(384), 0, stream, jobs); break;
 		case 2: hipLaunchKernelGGL(e264_deblock_kernel<2>, dim3(n_jobs), dim3(128), 0, stream, jobs); break;
 		case 4: hipLaunchKernelGGL(e264_deblock_kernel<4>, dim3(n_jobs), dim3(256), 0, stream, jobs); break;
 		case 8: hipLaunchKernelGGL(e264_deblock_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs); break;

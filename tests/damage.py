@@ -37,6 +37,17 @@ def truncated_only(name: str, which: int, keep: float) -> bytes:
     return b"".join(nals[:k] + [nals[k][:max(8, int(len(nals[k]) * keep))]] + nals[k + 1:])
 
 
+def two_truncated_then_resent(name: str, which: int, keep_a: float, keep_b: float) -> bytes:
+    """TWO failures inside one picture before anything is sent again: slice NALs `which` and `which + 1` (of the same picture) both
+    cut short, then both sent again intact (/root/reference/src/edge264_headers.c:295-430, 486-529)."""
+    nals = nal_units(open(os.path.join(STREAMS, name + ".264"), "rb").read())
+    si = slice_indices(nals)
+    a, b = si[which], si[which + 1]
+    bad_a = nals[a][:max(8, int(len(nals[a]) * keep_a))]
+    bad_b = nals[b][:max(8, int(len(nals[b]) * keep_b))]
+    return b"".join(nals[:a] + [bad_a, bad_b, nals[a], nals[b]] + nals[b + 1:])
+
+
 # (fixture, slice NAL, fraction kept): I / P / B slices, CAVLC and CABAC, one and several slices per picture, slice-boundary
 # deblocking on and off, arbitrary slice order, 8x8 transform, I_PCM, MVC, weighted prediction
 RESENT = [
@@ -51,3 +62,12 @@ RESENT = [
     ("mvc_ipp", 3, 0.5), ("cabac_weighted_b", 4, 0.4), ("reorder_weighted", 5, 0.6),
 ]
 LOST = [("ipp_partitions", 3, 0.5), ("cabac_ipp", 3, 0.4), ("slices_deblock_idc", 11, 0.5), ("cabac_t8x8_slices", 11, 0.5)]
+# two failed slices in ONE picture, then both sent again: (fixture, first of the two slice NALs -- both in the same picture --, fractions kept).
+# I and P / B pictures, CAVLC and CABAC, three and four slices per picture, arbitrary slice order, 8x8 transform.  (Pairs that span two
+# pictures are left out: the unmodified reference aborts on them -- assertion in its own worker_loop, src/edge264_headers.c:465.)
+RESENT2 = [
+    ("slices_deblock_idc", 0, 0.3, 0.7), ("slices_deblock_idc", 1, 0.6, 0.4), ("slices_deblock_idc", 3, 0.3, 0.7), ("slices_deblock_idc", 7, 0.6, 0.4),
+    ("cabac_slices_deblock_idc", 0, 0.6, 0.4), ("cabac_slices_deblock_idc", 4, 0.3, 0.7), ("cabac_slices_deblock_idc", 9, 0.6, 0.4),
+    ("aso_slices", 1, 0.3, 0.7), ("aso_slices", 5, 0.6, 0.4), ("aso_slices", 10, 0.3, 0.7), ("aso_slices", 17, 0.6, 0.4),
+    ("cabac_t8x8_slices", 0, 0.3, 0.7), ("cabac_t8x8_slices", 4, 0.6, 0.4), ("cabac_t8x8_slices", 10, 0.3, 0.7),
+]

@@ -58,7 +58,7 @@ extern "C" __attribute__((visibility("default"))) int e264emu_dbkparam_frame(con
 	return 0;
 }
 
-// e264_deblock_kernel / e264_deblock_split_kernel: dbk = the parameter records (e264emu_dbkparam_frame's output); the picture in
+// e264_deblock_kernel / e264_deblock2_kernel: dbk = the parameter records (e264emu_dbkparam_frame's output); the picture in
 // dpb[dst_slot] is filtered in place.  Groups of rows are run one after the other (a group only ever waits for the group above it
 // of its own kind), the lanes of a wave phase by phase.  K: the kind of wave (DkGeom): 2 mixed, 0 luma only, 1 chroma only.
 #include "../../edge264_amd/csrc/e264_dbk.h"
@@ -103,7 +103,7 @@ static void emu_walk_group(const FrameCtx &f, const uint8_t *tc0tab, int q)
 			if (p[lane].act) dk_hpass<K>(W, P[lane][1], R[lane], p[lane].x);
 	}
 }
-// split: 0 = mixed waves (e264_deblock_kernel), 1 = luma waves + chroma waves (e264_deblock_split_kernel)
+// split: 0 = mixed waves (e264_deblock_kernel), 1 = luma waves + chroma waves (e264_deblock2_kernel)
 extern "C" __attribute__((visibility("default"))) int e264emu_deblock_frame2(const uint8_t *pkt, uint8_t *const *dpb, uint8_t *dbk, int split)
 {
 	E264Job job = {pkt, dpb, dbk};

@@ -37,6 +37,19 @@ def test_failed_slice_resent(name, which, keep, oracle, refdecoder):
     assert len(f0) > 0
 
 
+@pytest.mark.parametrize("name,which,ka,kb", damage.RESENT2, ids=[f"{n}-{w}+{w + 1}-{a}-{b}" for n, w, a, b in damage.RESENT2])
+def test_two_failed_slices_in_one_picture_resent(name, which, ka, kb, oracle, refdecoder):
+    """Two failures inside one picture before either slice arrives again (DESIGN.md section 7.1 listed it as not reproduced and untested
+    in round 3): every frame equals the unmodified reference decoder's."""
+    from oracle.pyoracle import HipFront
+    data = damage.two_truncated_then_resent(name, which, ka, kb)
+    f0, c0 = refdecoder.decode(data)
+    f1, c1, _ = HipFront().decode_capture(data, oracle)
+    assert c0 == c1
+    assert md5s(f0) == md5s(f1)
+    assert len(f0) > 0
+
+
 @pytest.mark.parametrize("name,which,keep", damage.LOST, ids=[f"{n}-{w}-{k}" for n, w, k in damage.LOST])
 def test_failed_slice_never_resent(name, which, keep, oracle, refdecoder):
     """The damaged picture is the last one: the reference never hands it out, neither does the shim; everything else is equal."""

@@ -125,6 +125,12 @@ def test_concealment_on_the_gpu(front):
         want = sums[f"{name}-{which}-{keep}"]
         assert codes == want["nal_codes"], (name, which, keep)
         assert md5s(frames) == want["md5"], (name, which, keep)
+    # two failed slices inside one picture before either arrives again
+    for name, which, ka, kb in damage.RESENT2:
+        frames, codes = front.decode(damage.two_truncated_then_resent(name, which, ka, kb))
+        want = sums[f"{name}-{which}+{which + 1}-{ka}-{kb}"]
+        assert codes == want["nal_codes"], (name, which, ka, kb)
+        assert md5s(frames) == want["md5"], (name, which, ka, kb)
 
 
 def test_decode_to_device_without_readback(front):
