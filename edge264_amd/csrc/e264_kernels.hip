@@ -209,8 +209,10 @@ static __device__ __forceinline__ void dk_walk_group(DkWaveT<K> &W, const FrameC
 		PH(0);
 		if (p.top_fetch >= 0) { // (wave-uniform) the rows above this group of 4 must have reached memory
 			const int need = min(p.top_fetch * 4 + 4, wm);
+#ifndef E264_ABL_DBK_NOWAIT // timing ablation: the group above is not waited for (wrong samples along the seams): what the hand-off lag costs
 			while (lds_load_relaxed(&progress[q - 1]) < need)
 				__builtin_amdgcn_s_sleep(1);
+#endif
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 			dk_top_fetch<K>(f, lane, p.top_fetch, y0, tt);
 		}
@@ -351,6 +353,9 @@ extern "C" const char *e264_kernel_build_flags(void)
 #endif
 #ifdef E264_ABL_DBK_NOSTORE
 		" E264_ABL_DBK_NOSTORE"
+#endif
+#ifdef E264_ABL_DBK_NOWAIT
+		" E264_ABL_DBK_NOWAIT"
 #endif
 #ifdef E264_PHASE_TIMING
 		" E264_PHASE_TIMING"
