@@ -174,6 +174,38 @@ def test_committed_bench_line_obeys_the_contract():
     assert abs(d["value"] - d["config"]["frames_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
 
 
+def test_round4_bench_line_says_what_it_measures():
+    """profiles/r04_bench_default.json = stdout of `python bench.py` on the MI355X, round 4: the line says in
+    `config.workload` that the packets are resident and the H2D copy excluded, carries the PCIe-inclusive rates, a SAME-INPUT leg
+    (the two 1080p bitstream fixtures on the GPU, resident and with the copy inside, next to the CPU reference on the same files,
+    bit-exact) and names the file its PMC traffic figure comes from."""
+    import json
+    lines = [l for l in open(os.path.join(ROOT, "profiles", "r04_bench_default.json")).read().splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "pcie_inclusive", "same_input", "build_flags"):
+        assert k in d, k
+    w = d["config"]["workload"]
+    assert "RESIDENT IN HBM" in w and "H2D" in w and "excluded" in w and "pcie_inclusive" in w
+    assert d["bit_exact"] is True and d["build_flags"] == ""
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    k = r["kernels"][r["kernel"]]
+    assert abs(r["achieved"] - (k["sample_bytes"] + k["command_bytes"]) / (k["ms_per_launch"] * 1e-3) / 1e9) < 1.0
+    assert r["traffic"] > 0 and r["traffic_source"]["file"].startswith("profiles/r")
+    p = d["pcie_inclusive"]
+    assert p["value"] > 30000 and p["pinned_in_place"]["value"] > 30000   # 1000 x 1080p30 with the copy inside
+    si = d["same_input"]
+    assert si["bit_exact"] is True and si["files"] == ["hd1080_ipp30.264", "cabac_hd1080_ibbp30.264"]
+    for key in ("gpu_resident_frames_per_s", "gpu_pcie_inclusive_frames_per_s", "host_parse_emit_frames_per_s_one_core", "cpu_reference_frames_per_s", "cpu_cores"):
+        assert si[key] > 0, key
+    c = d["cpu_baseline"]
+    assert c["kind"] == "reference" and c["same_input"] is True and c["cores"] >= 1 and c["value"] == si["cpu_reference_frames_per_s"]
+    assert d["per_rank"]["numa"]["numa_node"] >= 0   # the rank found its GPU's NUMA node (also at N = 1)
+    assert abs(d["value"] - d["config"]["frames_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+
+
 def test_bench_gpus_flag_spawns_ranks(tmp_path):
     """`python bench.py --gpus 2` outside torchrun launches 2 ranks itself (torch.distributed.run, here gloo + a stub device):
     rank 0 prints ONE line with n_gpus 2 and the frames of BOTH ranks' stream shards; a mismatch between --gpus and an
