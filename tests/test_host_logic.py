@@ -258,3 +258,30 @@ def test_numa_helpers():
     before = os.sched_getaffinity(0)
     info = bind_rank_to_gpu_socket(0)   # no GPU here: node unknown, affinity untouched
     assert info["bound"] is False and os.sched_getaffinity(0) == before
+
+
+def test_product_library_reports_no_build_switches_and_ablation_builds_are_refused(monkeypatch):
+    """e264hip_build_flags() is "" for the product build; a library that reports a timing-ablation switch (wrong
+    samples by design) is refused by the loader unless E264_ALLOW_ABLATION=1."""
+    from edge264_amd import backend
+    assert backend.build_flags() == ""
+    lib = backend.load_library()
+
+    class Fake:
+        def __init__(self, real, flags):
+            self._real, self._flags = real, flags
+
+        def __getattr__(self, name):
+            if name == "e264hip_build_flags":
+                f = lambda: self._flags  # noqa: E731
+                return f
+            return getattr(self._real, name)
+
+    monkeypatch.setattr(backend, "_lib", None)
+    monkeypatch.setattr(backend.C, "CDLL", lambda path: Fake(lib, b" E264_ABL_NOLOAD"))
+    monkeypatch.delenv("E264_ALLOW_ABLATION", raising=False)
+    with pytest.raises(backend.BackendError, match="ablation"):
+        backend.load_library()
+    monkeypatch.setenv("E264_ALLOW_ABLATION", "1")
+    assert backend.load_library() is not None
+    monkeypatch.setattr(backend, "_lib", lib)
