@@ -67,6 +67,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs[1] and configs[3] (N=1)")
     ap.add_argument("--no-host-packets", action="store_true", help="skip the PCIe-inclusive run (N=1)")
+    ap.add_argument("--variants", type=int, default=int(os.environ.get("E264_VARIANTS", 4)), help="distinct synthetic GOPs (seeds 1234, 1235, ...): stream k decodes GOP k mod V, "
+                    "so that the timed pictures and the verification are not copies of one GOP")
     ap.add_argument("--no-same-input", action="store_true", help="skip the same-input leg (the 1080p bitstream fixtures on the GPU next to the CPU reference, N=1)")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("E264_LANES", 1)), help="compute lanes (HIP queues): the streams are split into this many "
                     "groups whose submissions overlap on the GPU")
@@ -295,12 +297,18 @@ def main() -> int:
         args.no_other_configs = True
     else:
         # ---- synthetic input (same bytes on every rank: seeded) -------------------------------
-        gen = synth.StreamSynth(W, H, seed=1234, t8x8=True, i_kinds=ALL_I, num_refs=2, residual_prob=0.3)
-        packets = gen.gop(args.gop)
+        vpk = [synth.StreamSynth(W, H, seed=1234 + v, t8x8=True, i_kinds=ALL_I, num_refs=2, residual_prob=0.3).gop(args.gop) for v in range(max(1, args.variants))]
+        packets = vpk[0]
         parsed = [P.Packet(p) for p in packets]
-    models = [pk.traffic_model() for pk in parsed]
+    if args.capture:
+        vpk = [packets]
+    V = len(vpk)
+    vparsed = [[P.Packet(p) for p in pk] for pk in vpk]
+    for vp in vparsed:  # the variants differ in content only: same slots, same geometry
+        assert [int(q.hdr["dst_slot"]) for q in vp] == [int(q.hdr["dst_slot"]) for q in parsed]
+    models = [pk.traffic_model() for vp in vparsed for pk in vp]
     used = 0
-    for pk in parsed:
+    for pk in (q for vp in vparsed for q in vp):
         used |= 1 << int(pk.hdr["dst_slot"]) | int(pk.hdr["ref_slots"])
     n_slots = max(used.bit_length(), 3)
     frame_nb = int(parsed[0].hdr["plane_size_Y"]) + int(parsed[0].hdr["plane_size_C"])
@@ -326,7 +334,7 @@ def main() -> int:
             st.alloc(i)
             st.fill(i, fill_value)
         streams.append(st)
-        dpk.append([dev.upload_packet(p) for p in packets])  # per-stream copy of the command bytes
+        dpk.append([dev.upload_packet(p) for p in vpk[s % V]])  # per-stream copy of the command bytes (stream s decodes GOP s mod V)
     # compute lanes: group g = streams g, g + L, g + 2L, ...; one batch per (frame, group)
     lanes = max(1, min(args.lanes, getattr(backend, "MAX_LANES", 1), my_streams))
     groups = [list(range(g, my_streams, lanes)) for g in range(lanes)]
@@ -385,22 +393,23 @@ def main() -> int:
     verify, bit_exact = None, None
     if rank == 0 and not args.no_verify and not stub:
         from oracle.pyoracle import Oracle
-        orc = Oracle()
         nb = frame_nb
-        dpb = [np.full(nb + 64, fill_value, np.uint8) for _ in range(n_slots)] + [None] * (32 - n_slots)
+        orcs = [Oracle() for _ in range(V)]
+        dpbs = [[np.full(nb + 64, fill_value, np.uint8) for _ in range(n_slots)] + [None] * (32 - n_slots) for _ in range(V)]
         for st in streams:
             for i in range(n_slots):
                 st.fill(i, fill_value)
         bad = 0
-        for f, p in enumerate(packets):
-            orc.decode_frame(p, dpb, 3)
+        for f in range(len(packets)):
+            for v in range(V):
+                orcs[v].decode_frame(vpk[v][f], dpbs[v], 3)
             submit_frame(batches[f], backend.RUN_ALL)
             dev.sync()
             d = int(parsed[f].hdr["dst_slot"])
-            want = dpb[d][:nb]
-            for st in streams:
-                bad += 0 if np.array_equal(st.download(d), want) else 1
-        verify = {"streams": len(streams), "frames_per_stream": len(packets), "frames_compared": len(streams) * len(packets), "mismatching_frames": bad}
+            for k, st in enumerate(streams):
+                bad += 0 if np.array_equal(st.download(d), dpbs[k % V][d][:nb]) else 1
+        verify = {"streams": len(streams), "frames_per_stream": len(packets), "frames_compared": len(streams) * len(packets), "distinct_pictures": V * len(packets),
+                  "mismatching_frames": bad}
         bit_exact = bad == 0
 
     # ---- CPU baseline (N=1 only, the contract) -----------------------------------------------------------------------
@@ -503,7 +512,7 @@ def main() -> int:
     # ---- PCIe-inclusive rate (informational, never `value`): the same GOP submitted from host memory -------------------
     pcie = None
     if rank == 0 and world == 1 and not args.no_host_packets and not stub:
-        hbs = [dev.prepare_host_batch([streams[k] for k in idx], [packets[f]] * len(idx)) for f in range(len(packets)) for idx in groups]
+        hbs = [dev.prepare_host_batch([streams[k] for k in idx], [vpk[k % V][f] for k in idx]) for f in range(len(packets)) for idx in groups]
         for hb in hbs:
             dev.submit_host_prepared(hb, backend.RUN_ALL)
         dev.sync()
@@ -514,15 +523,17 @@ def main() -> int:
         dev.sync()
         dt2 = time.perf_counter() - t2
         pcie = {"value": round(2 * len(packets) * len(streams) / dt2, 1), "unit": "frames/s",
-                "packet_MB_per_frame": round(float(np.mean([len(p) for p in packets])) / 1e6, 3),
+                "packet_MB_per_frame": round(float(np.mean([len(p) for pk in vpk for p in pk])) / 1e6, 3),
                 "what": "pageable host packets -> per-macroblock validation + copy into the batch's page-locked staging buffer by the back end's host "
                         "threads (E264_HOST_THREADS, default min(15, cores / 2)) -> ONE H2D per batch on the upload queue beside the kernels of the batch "
                         "before -> 4 kernels, asynchronous, one batch per frame index and lane"}
         # the front end's own path: packets assembled in place in page-locked memory and validated where they are produced
-        for p in packets:
-            assert backend.packet_check(p) == 0
-        pins = [dev.pinned_copy(p) for p in packets]
-        pbs = [dev.prepare_pinned_batch([streams[k] for k in idx], [pins[f]] * len(idx), [len(packets[f])] * len(idx)) for f in range(len(packets)) for idx in groups]
+        for pk in vpk:
+            for p in pk:
+                assert backend.packet_check(p) == 0
+        vpins = [[dev.pinned_copy(p) for p in pk] for pk in vpk]
+        pins = [pp for row in vpins for pp in row]
+        pbs = [dev.prepare_pinned_batch([streams[k] for k in idx], [vpins[k % V][f] for k in idx], [len(vpk[k % V][f]) for k in idx]) for f in range(len(packets)) for idx in groups]
         for pb in pbs:
             dev.submit_pinned_prepared(pb, backend.RUN_ALL)
         dev.sync()
@@ -567,6 +578,7 @@ def main() -> int:
             "config": {"workload": (f"{W * 16}x{H * 16} captured packets of a real bitstream ({args.gop}), one copy per stream, resident in HBM (H2D excluded, see pcie_inclusive)" if args.capture else
                                     f"{W * 16}x{H * 16} High-profile {args.gop} GOP (synthetic command packets: intra 4x4 / 8x8 / 16x16 I frame + "
                                     "P frames with 6-tap luma / bilinear chroma MC, 2 references, 4x4 and 8x8 transforms, 30% coded residual, "
+                                    f"{V} distinct GOPs dealt to the streams round-robin, "
                                     "in-loop deblocking), BASELINE configs[2]; command packets and DPBs RESIDENT IN HBM before the timed region: the H2D copy of the "
                                     "packets is excluded from `value` -- see `pcie_inclusive` (host packets, copy included) and `same_input` (packets of real "
                                     "bitstreams through the reference's parser)") + (f"; configs[4]: {args.total_streams} streams sharded over {world} GPU(s)" if strong else ""),

@@ -189,6 +189,8 @@ def test_round4_bench_line_says_what_it_measures():
     w = d["config"]["workload"]
     assert "RESIDENT IN HBM" in w and "H2D" in w and "excluded" in w and "pcie_inclusive" in w
     assert d["bit_exact"] is True and d["build_flags"] == ""
+    v = d["verify"]   # breadth of the check: 4 distinct GOPs dealt to the streams, not 256 copies of one
+    assert v["mismatching_frames"] == 0 and v["frames_compared"] == 2048 and v["distinct_pictures"] == 32 and "4 distinct GOPs" in w
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     k = r["kernels"][r["kernel"]]
