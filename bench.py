@@ -284,6 +284,7 @@ def main() -> int:
 
     W, H = args.width_mbs, args.height_mbs
     ALL_I = (P.MB_I4x4, P.MB_I8x8, P.MB_I16x16)
+    head_i = tuple(k for k, n in zip(ALL_I, ("4", "8", "16")) if n in os.environ.get("E264_I_KINDS", "4,8,16").split(","))  # measuring aid: intra kinds of the synthetic GOP
     fill_value = 128
     if args.capture:
         # ---- captured packets of a real bitstream (reference front end -> our emitters), first stream of the file ----
@@ -297,7 +298,7 @@ def main() -> int:
         args.no_other_configs = True
     else:
         # ---- synthetic input (same bytes on every rank: seeded) -------------------------------
-        vpk = [synth.StreamSynth(W, H, seed=1234 + v, t8x8=True, i_kinds=ALL_I, num_refs=2, residual_prob=0.3).gop(args.gop) for v in range(max(1, args.variants))]
+        vpk = [synth.StreamSynth(W, H, seed=1234 + v, t8x8=True, i_kinds=head_i, num_refs=2, residual_prob=float(os.environ.get("E264_RESIDUAL_PROB", 0.3))).gop(args.gop) for v in range(max(1, args.variants))]
         packets = vpk[0]
         parsed = [P.Packet(p) for p in packets]
     if args.capture:

@@ -45,8 +45,8 @@ struct __attribute__((aligned(16))) WaveLds { // reconstruction scratch of one w
 	int32_t dc[24];            // 16 luma DC (zig order), 4 Cb, 4 Cr
 	uint8_t ytile[17 * YT_STRIDE];
 	uint8_t ctile[2][9 * CT_STRIDE];
-	uint8_t ftop[32];          // intra 8x8 filtered top  ft[-1..15] at [i+1]
-	uint8_t fleft[8];          // intra 8x8 filtered left
+	__attribute__((aligned(4))) uint8_t fz[32]; // intra 8x8: the filtered edge, FL(j) at j, the corner at 8, FT(i) at 12 + i
+	uint8_t pad_[8];
 	// residual inputs, staged so that the transforms never wait for memory (see coef_dma / slice_cache; the payload buffers live
 	// in IntraLds.coef)
 	__attribute__((aligned(4))) uint8_t ws[224];   // scaling lists of the cached slice: weightScale4x4[6][16], weightScale8x8[0..1][64]
@@ -459,101 +459,56 @@ E264_DEV int intra4x4_px(const WaveLds &L, int X0, int Y0, int mode, int x, int 
 #undef TR
 }
 
-__constant__ int8_t c_i8spec[32] = {0, 0, 0, 0, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 5, 5, 6, 7, 7, 7, 7, 8, 8};
-__constant__ int8_t c_i8unav[32] = {0, 4, 8, 12, 0, 8, 0, 1, 5, 9, 13, 2, 10, 4, 8, 12, 3, 0, 4, 8, 12, 0, 4, 0, 4, 0, 0, 4, 8, 12, 0, 8};
+// shape (0..8, c_i8tab) and unavailability bits (1 left, 2 top, 4 top right, 8 corner) of the 32 internal Intra8x8 modes, one nibble each
+// (immediates: the tables used to be two scalar memory reads at the head of every block)
+E264_DEV int i8_nibble(unsigned long long lo, unsigned long long hi, int mode) { return (int)(((mode & 16) ? hi : lo) >> (4 * (mode & 15)) & 15); }
+#define I8_SPEC_LO 0x2222222222110000ull
+#define I8_SPEC_HI 0x8877776554433332ull
+#define I8_UNAV_LO 0xc84a2d951080c840ull
+#define I8_UNAV_HI 0x80c84004040c8403ull
+#define I8_FZ 1 // the wave's filtered edge: FL(j) at fz[j], the corner at fz[8], FT(i) at fz[12 + i] (c_i8tab's tap offsets)
 
-// one 8x8 block: all 64 lanes = (y = lane>>3, x = lane&7).  8.3.2.2.1 filtering into L.ftop/L.fleft first.
-E264_DEV void intra8x8_block(WaveLds &L, int X0, int Y0, int mode, int lane)
+// one 8x8 block by the whole wave.  Round 4: two branch-free phases (the first version walked three lane ranges with their special
+// cases, then a nine-way switch of per-lane conditions: 3.3 x the time of an Intra4x4 macroblock, profiles/r04_ablations.txt item 16).
+//   filter   8.3.2.2.1 on the 25 edge samples L7..L0, corner, T0..T15 as ONE line: lane k < 25 filters sample k from its two
+//            neighbours on the line; ends, missing corner / top right and the corner's own rules are index replacements.
+//            The line's address in the luma tile is piecewise linear in k (up the left column, then along the top row).
+//   predict  lane = sample (y = lane >> 3, x = lane & 7): table word e (c_i8tab, fetched by the caller's previous step) = three taps on
+//            the filtered edge + filter type, the same instructions for all eight directional shapes; DC from four v_sad_u8.
+E264_DEV void intra8x8_block(WaveLds &L, uint32_t e, int X0, int Y0, int mode, int lane)
 {
-	const int sm = c_i8spec[mode], un = c_i8unav[mode];
+	const int sm = i8_nibble(I8_SPEC_LO, I8_SPEC_HI, mode), un = i8_nibble(I8_UNAV_LO, I8_UNAV_HI, mode);
 	const bool useA = !(un & 1) && (sm == 1 || sm == 2 || sm == 4 || sm == 5 || sm == 6 || sm == 8);
 	const bool useB = !(un & 2) && (sm == 0 || sm == 2 || sm == 3 || sm == 4 || sm == 5 || sm == 6 || sm == 7);
 	const bool useC = useB && !(un & 4) && sm != 6;
 	const bool cornerAvail = !(un & 8) && (useA || useB);
-#define T(i) ((int)L.YT(Y0 - 1, X0 + (i)))
-#define TC(i) ((i) < 8 || useC ? T(i) : T(7))
-#define Lf(i) ((int)L.YT(Y0 + (i), X0 - 1))
-	if (lane < 16) { // filtered top ft[0..15]
-		int i = lane, v = 0;
-		if (useB) {
-			if (i == 0) v = cornerAvail ? LP(T(-1), T(0), T(1)) : (3 * T(0) + T(1) + 2) >> 2;
-			else if (i == 15) v = (TC(14) + 3 * TC(15) + 2) >> 2;
-			else v = LP(TC(i - 1), TC(i), TC(i + 1));
-		}
-		L.ftop[i + 1] = (uint8_t)v;
-	} else if (lane < 24) { // filtered left
-		int i = lane - 16, v = 0;
-		if (useA) {
-			if (i == 0) v = cornerAvail ? LP(T(-1), Lf(0), Lf(1)) : (3 * Lf(0) + Lf(1) + 2) >> 2;
-			else if (i == 7) v = (Lf(6) + 3 * Lf(7) + 2) >> 2;
-			else v = LP(Lf(i - 1), Lf(i), Lf(i + 1));
-		}
-		L.fleft[i] = (uint8_t)v;
-	} else if (lane == 24) {
-		int v = 0;
-		if (cornerAvail) {
-			if (!useB) v = (3 * T(-1) + Lf(0) + 2) >> 2;
-			else if (!useA) v = (3 * T(-1) + T(0) + 2) >> 2;
-			else v = LP(T(0), T(-1), Lf(0));
-		}
-		L.ftop[0] = (uint8_t)v;
-	}
-#undef T
-#undef TC
-#undef Lf
-	wave_sync();
 	const int x = lane & 7, y = lane >> 3;
-#define FT(i) ((int)L.ftop[(i) + 1])
-#define FL(i) ((i) < 0 ? (int)L.ftop[0] : (int)L.fleft[i])
-	int v;
-	if (mode == 16) v = 128;
-	else switch (sm) {
-	default:
-	case 0: v = FT(x); break;
-	case 1: v = FL(y); break;
-	case 2: {
-		int st = 0, sl = 0;
-#pragma unroll
-		for (int i = 0; i < 8; i++) { st += FT(i); sl += FL(i); }
-		v = useA && useB ? (st + sl + 8) >> 4 : useB ? (st + 4) >> 3 : useA ? (sl + 4) >> 3 : 128;
-		} break;
-	case 3: v = (x == 7 && y == 7) ? (FT(14) + 3 * FT(15) + 2) >> 2 : LP(FT(x + y), FT(x + y + 1), FT(x + y + 2)); break;
-	case 4:
-		if (x > y) v = LP(FT(x - y - 2), FT(x - y - 1), FT(x - y));
-		else if (x < y) v = LP(FL(y - x - 2), FL(y - x - 1), FL(y - x));
-		else v = LP(FT(0), FT(-1), FL(0));
-		break;
-	case 5: {
-		int z = 2 * x - y, i = x - (y >> 1);
-		if (z >= 0 && !(z & 1)) v = (FT(i - 1) + FT(i) + 1) >> 1;
-		else if (z >= 0) v = LP(FT(i - 2), FT(i - 1), FT(i));
-		else if (z == -1) v = LP(FL(0), FT(-1), FT(0));
-		else v = LP(FL(y - 2 * x - 1), FL(y - 2 * x - 2), FL(y - 2 * x - 3));
-		} break;
-	case 6: {
-		int z = 2 * y - x, i = y - (x >> 1);
-		if (z >= 0 && !(z & 1)) v = (FL(i - 1) + FL(i) + 1) >> 1;
-		else if (z >= 0) v = LP(FL(i - 2), FL(i - 1), FL(i));
-		else if (z == -1) v = LP(FL(0), FT(-1), FT(0));
-		else v = LP(FT(x - 2 * y - 1), FT(x - 2 * y - 2), FT(x - 2 * y - 3));
-		} break;
-	case 7: {
-		int i = x + (y >> 1);
-		v = (y & 1) ? LP(FT(i), FT(i + 1), FT(i + 2)) : (FT(i) + FT(i + 1) + 1) >> 1;
-		} break;
-	case 8: {
-		int z = x + 2 * y, i = y + (x >> 1);
-		if (z > 13) v = FL(7);
-		else if (z == 13) v = (FL(6) + 3 * FL(7) + 2) >> 2;
-		else if (z & 1) v = LP(FL(i), FL(i + 1), FL(i + 2));
-		else v = (FL(i) + FL(i + 1) + 1) >> 1;
-		} break;
+	const int rres = L.res[(Y0 + y) * 16 + X0 + x]; // requested in front of everything else
+	{
+		const int k = min(lane, 24), hi = useC ? 24 : 16; // without a top right, T8..T15 read as T7
+		int ia = max(k - 1, 0), ib = k, ic = k + 1;
+		if (k == 7 && !cornerAvail) ic = 7;           // L0 without a corner: (3 L0 + L1 + 2) >> 2
+		if (k == 9 && !cornerAvail) ia = 9;           // T0 likewise
+		if (k == 8) { if (!useB) ic = 8; if (!useA) ia = 8; } // the corner with one side only: (3 corner + side + 2) >> 2
+		ia = min(ia, hi); ib = min(ib, hi); ic = min(ic, hi);
+		const uint8_t *A0 = &L.YT(Y0 + 7, X0 - 1);    // sample 0 of the line (L7); sample i: 32 bytes up per step until the corner (8), then to the right
+		const int a = A0[max(ia - 8, 0) - 32 * min(ia, 8)], b = A0[max(ib - 8, 0) - 32 * min(ib, 8)], c = A0[max(ic - 8, 0) - 32 * min(ic, 8)];
+		if (lane < 25)
+			L.fz[lane < 8 ? 7 - lane : lane == 8 ? 8 : lane + 3] = (uint8_t)LP(a, b, c);
 	}
-#undef FT
-#undef FL
-	// add residual (add_idct8x8 tail, residual.c:318-342) and write the tile
-	int rres = L.res[(Y0 + y) * 16 + X0 + x];
 	wave_sync();
+	int v;
+	if (sm == 2 || mode == 16) { // (uniform) DC from the filtered edge, or nothing available
+		const uint32_t *w = (const uint32_t *)L.fz;
+		const int sl = (int)v_sad_u8(w[0], 0, v_sad_u8(w[1], 0, 0)), st = (int)v_sad_u8(w[3], 0, v_sad_u8(w[4], 0, 0));
+		v = mode == 16 ? 128 : useA && useB ? (st + sl + 8) >> 4 : useB ? (st + 4) >> 3 : useA ? (sl + 4) >> 3 : 128;
+	} else {
+		const int a = L.fz[e & 255], b = L.fz[e >> 8 & 255], c = L.fz[e >> 16 & 255];
+		const int ty = (int)(e >> 24), sh = ty >> 3;
+		v = (a + (ty & 3) * b + ((ty & 4) ? c : 0) + ((1 << sh) >> 1)) >> sh;
+	}
+	// add residual (add_idct8x8 tail, residual.c:318-342) and write the tile: every read of the tile by this block happened before the
+	// wave_sync above
 	L.YT(Y0 + y, X0 + x) = (uint8_t)clip255(w16(v + rres));
 	wave_sync();
 }
@@ -724,9 +679,16 @@ E264_DEV void recon_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, int mbx, 
 			}
 		} else { // I8x8, edge264_slice.c:645-668
 			tile_luma = true;
+			const uint32_t *i8tab = i4tab + 14 * 16;
+			const int l8 = (E264_INTRA_LAUNDER & 1) ? relane(lane) : lane;
+			uint32_t e_n = i8tab[i8_nibble(I8_SPEC_LO, I8_SPEC_HI, (int)(modes_lo & 255)) * 64 + l8];
 #pragma unroll 1
-			for (int b = 0; b < 4; b++)
-				intra8x8_block(L, BXf(b * 4), BYf(b * 4), (int)(modes_lo >> (8 * b) & 255), (E264_INTRA_LAUNDER & 1) ? relane(lane) : lane);
+			for (int b = 0; b < 4; b++) {
+				const uint32_t e = e_n;
+				if (b < 3) // the next block's table word depends on its mode only: in flight during this block
+					e_n = i8tab[i8_nibble(I8_SPEC_LO, I8_SPEC_HI, (int)(modes_lo >> (8 * b + 8) & 255)) * 64 + l8];
+				intra8x8_block(L, e, BXf(b * 4), BYf(b * 4), (int)(modes_lo >> (8 * b) & 255), l8);
+			}
 		}
 		PH(6);
 		pC[0] = intra_chroma_px(L, cpl, m.chroma_mode, cx, cy);
@@ -765,7 +727,7 @@ struct __attribute__((aligned(16))) IntraLds {
 	uint32_t hdrs[NW][64 * 8];           // E264Mb records of the 64 macroblocks being scanned, per wave
 	WaveLds w[NW];
 	int progress[E264_MAX_ROWS];         // macroblocks finished per row
-	uint32_t i4tab[14 * 16];             // c_i4tab: read with a per-lane index
+	uint32_t i4tab[14 * 16 + 9 * 64];    // c_i4tab, then c_i8tab: read with a per-lane index
 };
 
 // what thread tid of the picture's workgroup does
@@ -785,8 +747,8 @@ E264_DEV void intra_kernel_body(IntraLds<NW> &S, const E264Job &job, const int t
 		return; // nothing intra in this frame (PCM is handled by the parallel kernel but counted as coded: rare)
 	for (int i = tid; i < f.hm; i += NW * 64)
 		progress[i] = 0;
-	for (int i = tid; i < 14 * 16; i += NW * 64)
-		i4tab[i] = c_i4tab[i];
+	for (int i = tid; i < 14 * 16 + 9 * 64; i += NW * 64)
+		i4tab[i] = i < 14 * 16 ? c_i4tab[i] : c_i8tab[i - 14 * 16];
 	E264_WG_SYNC();
 	WaveLds &L = lds[wave];
 	if (lane == 0) L.ws_slice = -1;

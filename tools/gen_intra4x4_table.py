@@ -119,6 +119,118 @@ def entry(mode, x, y):
     return off(a) | off(b) << 8 | off(c) << 16 | ty << 24
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Intra8x8: the same trick on the FILTERED edge (8.3.2.2.1), which the kernel lays out in a 32-byte array per wave:
+#   FL(j) (left, j = 0..7) at j, the corner FT(-1) = FL(-1) at 8, FT(i) (top and top right, i = 0..15) at 12 + i.
+# Nine shapes (c_i8spec of the kernel: the 32 internal modes differ in which neighbours exist, not in the shape):
+#   0 vertical, 1 horizontal, 2 DC (no table), 3 diagonal down left, 4 diagonal down right, 5 vertical right, 6 horizontal down,
+#   7 vertical left, 8 horizontal up.
+FT = lambda i: ("FT", i)
+FL = lambda j: ("FT", -1) if j < 0 else ("FL", j)
+LP3 = 3 | 2 << 3  # (a + 3 b + 2) >> 2
+
+
+def taps8(sm, x, y):
+    if sm == 0: return FT(x), FT(x), FT(x), COPY
+    if sm == 1: return FL(y), FL(y), FL(y), COPY
+    if sm == 2: return None
+    if sm == 3:
+        if x == 7 and y == 7: return FT(14), FT(15), FT(15), LP3
+        return FT(x + y), FT(x + y + 1), FT(x + y + 2), LP
+    if sm == 4:
+        if x > y: return FT(x - y - 2), FT(x - y - 1), FT(x - y), LP
+        if x < y: return FL(y - x - 2), FL(y - x - 1), FL(y - x), LP
+        return FT(0), FT(-1), FL(0), LP
+    if sm == 5:
+        z, i = 2 * x - y, x - (y >> 1)
+        if z >= 0 and not z & 1: return FT(i - 1), FT(i), FT(i), AVG
+        if z >= 0: return FT(i - 2), FT(i - 1), FT(i), LP
+        if z == -1: return FL(0), FT(-1), FT(0), LP
+        return FL(y - 2 * x - 1), FL(y - 2 * x - 2), FL(y - 2 * x - 3), LP
+    if sm == 6:
+        z, i = 2 * y - x, y - (x >> 1)
+        if z >= 0 and not z & 1: return FL(i - 1), FL(i), FL(i), AVG
+        if z >= 0: return FL(i - 2), FL(i - 1), FL(i), LP
+        if z == -1: return FL(0), FT(-1), FT(0), LP
+        return FT(x - 2 * y - 1), FT(x - 2 * y - 2), FT(x - 2 * y - 3), LP
+    if sm == 7:
+        i = x + (y >> 1)
+        if y & 1: return FT(i), FT(i + 1), FT(i + 2), LP
+        return FT(i), FT(i + 1), FT(i + 1), AVG
+    if sm == 8:
+        z, i = x + 2 * y, y + (x >> 1)
+        if z > 13: return FL(7), FL(7), FL(7), COPY
+        if z == 13: return FL(6), FL(7), FL(7), LP3
+        if z & 1: return FL(i), FL(i + 1), FL(i + 2), LP
+        return FL(i), FL(i + 1), FL(i + 1), AVG
+    raise ValueError(sm)
+
+
+def direct8(sm, x, y, ft, fl):
+    """8.3.2.2.2-9 on the filtered edge (ft: FT(-1..15) at index i + 1, fl: FL(0..7)), written out independently of taps8"""
+    T_ = lambda i: ft[i + 1]
+    L_ = lambda j: ft[0] if j < 0 else fl[j]
+    lp = lambda a, b, c: (a + 2 * b + c + 2) >> 2
+    if sm == 0: return T_(x)
+    if sm == 1: return fl[y]
+    if sm == 3: return (T_(14) + 3 * T_(15) + 2) >> 2 if (x == 7 and y == 7) else lp(T_(x + y), T_(x + y + 1), T_(x + y + 2))
+    if sm == 4:
+        if x > y: return lp(T_(x - y - 2), T_(x - y - 1), T_(x - y))
+        if x < y: return lp(L_(y - x - 2), L_(y - x - 1), L_(y - x))
+        return lp(T_(0), T_(-1), fl[0])
+    if sm == 5:
+        z, i = 2 * x - y, x - (y >> 1)
+        if z >= 0 and z % 2 == 0: return (T_(i - 1) + T_(i) + 1) >> 1
+        if z >= 0: return lp(T_(i - 2), T_(i - 1), T_(i))
+        if z == -1: return lp(fl[0], T_(-1), T_(0))
+        return lp(L_(y - 2 * x - 1), L_(y - 2 * x - 2), L_(y - 2 * x - 3))
+    if sm == 6:
+        z, i = 2 * y - x, y - (x >> 1)
+        if z >= 0 and z % 2 == 0: return (L_(i - 1) + L_(i) + 1) >> 1
+        if z >= 0: return lp(L_(i - 2), L_(i - 1), L_(i))
+        if z == -1: return lp(fl[0], T_(-1), T_(0))
+        return lp(T_(x - 2 * y - 1), T_(x - 2 * y - 2), T_(x - 2 * y - 3))
+    if sm == 7:
+        i = x + (y >> 1)
+        return lp(T_(i), T_(i + 1), T_(i + 2)) if y & 1 else (T_(i) + T_(i + 1) + 1) >> 1
+    if sm == 8:
+        z, i = x + 2 * y, y + (x >> 1)
+        if z > 13: return fl[7]
+        if z == 13: return (fl[6] + 3 * fl[7] + 2) >> 2
+        return lp(fl[i], fl[i + 1], fl[i + 2]) if z & 1 else (fl[i] + fl[i + 1] + 1) >> 1
+
+
+def off8(tap):
+    kind, i = tap
+    return i if kind == "FL" else (8 if i < 0 else 12 + i)
+
+
+def table8(rnd):
+    rows = []
+    for sm in range(9):
+        row = []
+        for p in range(64):
+            x, y = p & 7, p >> 3
+            r = taps8(sm, x, y)
+            if r is None:
+                row.append(0)
+                continue
+            a, b, c, ty = r
+            e = off8(a) | off8(b) << 8 | off8(c) << 16 | ty << 24
+            row.append(e)
+            for _ in range(20):
+                ft = [rnd.randrange(256) for _ in range(17)]
+                fl = [rnd.randrange(256) for _ in range(8)]
+                fz = {j: fl[j] for j in range(8)}
+                fz[8] = ft[0]
+                for i in range(16): fz[12 + i] = ft[i + 1]
+                va, vb, vc, sh = fz[e & 255], fz[e >> 8 & 255], fz[e >> 16 & 255], ty >> 3
+                v = (va + (ty & 3) * vb + (vc if ty & 4 else 0) + ((1 << sh) >> 1)) >> sh
+                assert v == direct8(sm, x, y, ft, fl), (sm, x, y)
+        rows.append(row)
+    return rows
+
+
 def main():
     rnd = random.Random(1)
     rows = []
@@ -145,6 +257,12 @@ def main():
     print("__constant__ uint32_t c_i4tab[14 * 16] = {")
     for mode, row in enumerate(rows):
         print("\t" + ", ".join(f"0x{e:08x}u" for e in row) + f", // mode {mode}")
+    print("};")
+    print("// Intra8x8 shapes (c_i8spec) as taps on the filtered edge array of the wave: FL(j) at j, the corner at 8, FT(i) at 12 + i.")
+    print("__constant__ uint32_t c_i8tab[9 * 64] = {")
+    for sm, row in enumerate(table8(rnd)):
+        for y in range(8):
+            print("\t" + ", ".join(f"0x{e:08x}u" for e in row[8 * y:8 * y + 8]) + "," + (f" // shape {sm}" if y == 0 else ""))
     print("};")
 
 
