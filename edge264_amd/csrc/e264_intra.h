@@ -102,7 +102,7 @@ E264_DEV void idct4x4_blocks(WaveLds &L, int nblk, uint32_t codedmask, bool use_
 		for (int x = 0; x < 4; x++) {
 			int pos = x * 4 + y;
 			int LS = wS[pos] * norm4(m, pos);
-			d[x] = (int)(((uint32_t)(level_at(coef_base, cb + pos, l8) * LS) << sh) + 8u) >> 4;
+			d[x] = (int)(((uint32_t)mul24(level_at(coef_base, cb + pos, l8), LS) << sh) + 8u) >> 4; // (|level| < 2^15, LS < 2^13: full-rate multiply)
 		}
 		if (use_dc && y == 0)
 			d[0] = L.dc[dc_off + k];
@@ -178,15 +178,15 @@ E264_DEV void idct8x8_blocks(WaveLds &L, uint32_t coded, const uint8_t *coef_bas
 			int LS = wS[pos] * norm8(m, pos);
 			const int lev = level_at(coef_base, nb * 64 + pos, l8);
 			if (div < 6)
-				d[i] = (int16_t)sat16((lev * LS + (1 << (5 - div))) >> (6 - div));
+				d[i] = (int16_t)sat16((mul24(lev, LS) + (1 << (5 - div))) >> (6 - div));
 			else
-				d[i] = (int16_t)(lev * (int)(int16_t)(LS << (div - 6)));
+				d[i] = (int16_t)mul24(lev, (int)(int16_t)(LS << (div - 6)));
 		}
 		idct8_1d(d);
-		// transposed read in pass 2: element [i][j]; +32 lands on the new vector 0 = all elements with j == 0
+		// transposed read in pass 2: element [i][j]
 #pragma unroll
 		for (int i = 0; i < 8; i++)
-			t16[b * 64 + i * 8 + j] = (int16_t)(d[i] + (j == 0 ? 32 : 0));
+			t16[b * 64 + i * 8 + j] = d[i];
 	}
 	wave_sync();
 	if (on) {
@@ -195,6 +195,7 @@ E264_DEV void idct8x8_blocks(WaveLds &L, uint32_t coded, const uint8_t *coef_bas
 #pragma unroll
 		for (int jj = 0; jj < 8; jj++)
 			d[jj] = t16[b * 64 + i * 8 + jj];
+		d[0] = (int16_t)(d[0] + 32); // the rounding term of the >> 6 below, on the new vector 0 (residual.c:288: int16 wrap-around as there)
 		idct8_1d(d);
 		int16_t *r = L.res + BYf(b * 4) * 16 + BXf(b * 4) + i;
 #pragma unroll

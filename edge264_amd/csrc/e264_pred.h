@@ -192,8 +192,8 @@ E264_DEV uint32_t ref_dword(const gu8 *row, int x, int Wb)
 { // Wb: width of the plane in bytes; x: dword-aligned column, possibly outside
 	const int xc = min(max(x, 0), Wb - 4);
 	uint32_t v = *(const gu32 *)(row + xc);
-	if (x < 0) v = (v & 255u) * 0x01010101u;
-	if (x > Wb - 4) v = (v >> 24) * 0x01010101u;
+	if (x < 0) v = v_perm(v, v, 0x00000000u);       // byte 0 four times (v_perm_b32; `(v & 255) * 0x01010101` is a quarter-rate multiply)
+	if (x > Wb - 4) v = v_perm(v, v, 0x03030303u);  // byte 3 four times
 	return v;
 }
 struct Row4 { uint32_t a0, a1, a2, a3; };
@@ -236,7 +236,7 @@ E264_DEV void load_window(const gu8 *plane, int sY, int W, int H, int X, int Y, 
 		for (int r = 0; r < NR; r++) {
 			if (r >= NR - 4 && !all)
 				continue;
-			const gu8 *row = plane + (size_t)min(max(Y + r, 0), H - 1) * sY;
+			const gu8 *row = plane + (uint32_t)mul24(min(max(Y + r, 0), H - 1), sY);
 			A[r].a0 = ref_dword(row, XA, W); A[r].a1 = ref_dword(row, XA + 4, W); A[r].a2 = ref_dword(row, XA + 8, W); A[r].a3 = ref_dword(row, XA + 12, W);
 		}
 	}
@@ -262,7 +262,7 @@ E264_DEV void load_window_rows(const gu8 *plane, int sY, int W, int H, int X, in
 		for (int r = 0; r < 13; r++) {
 			if (r < lo || r >= hi)
 				continue;
-			const gu8 *row = plane + (size_t)min(max(Y + r, 0), H - 1) * sY;
+			const gu8 *row = plane + (uint32_t)mul24(min(max(Y + r, 0), H - 1), sY);
 			A[r].a0 = ref_dword(row, XA, W); A[r].a1 = ref_dword(row, XA + 4, W); A[r].a2 = ref_dword(row, XA + 8, W); A[r].a3 = ref_dword(row, XA + 12, W);
 		}
 	}
@@ -564,7 +564,7 @@ E264_DEV void chroma_load(const gu8 *plane, int sC, int Wc, int Hc, int XC, int 
 		for (int r = 0; r < 5; r++) {
 			if (!need[r])
 				continue;
-			const v2u v = *(const gv2u *)(plane + (size_t)min(max(YC + r, 0), Hc - 1) * sC + XA);
+			const v2u v = *(const gv2u *)(plane + (uint32_t)mul24(min(max(YC + r, 0), Hc - 1), sC) + XA);
 			w[r][0] = v.x; w[r][1] = v.y;
 		}
 	} else {
@@ -572,7 +572,7 @@ E264_DEV void chroma_load(const gu8 *plane, int sC, int Wc, int Hc, int XC, int 
 		for (int r = 0; r < 5; r++) {
 			if (!need[r])
 				continue;
-			const gu8 *row = plane + (size_t)min(max(YC + r, 0), Hc - 1) * sC;
+			const gu8 *row = plane + (uint32_t)mul24(min(max(YC + r, 0), Hc - 1), sC);
 			w[r][0] = ref_dword(row, XA, Wc); w[r][1] = ref_dword(row, XA + 4, Wc);
 		}
 	}
@@ -587,14 +587,14 @@ E264_DEV void chroma_load12(const gu8 *plane, int sC, int Wc, int Hc, int XC, in
 #pragma unroll
 		for (int r = 0; r < 5; r++) {
 			if (r == 4 && !frac) { w[r][0] = any_u32(); w[r][1] = any_u32(); w[r][2] = any_u32(); continue; }
-			const v3u v = *(const gv3u *)(plane + (size_t)min(max(YC + r, 0), Hc - 1) * sC + XA);
+			const v3u v = *(const gv3u *)(plane + (uint32_t)mul24(min(max(YC + r, 0), Hc - 1), sC) + XA);
 			w[r][0] = v.x; w[r][1] = v.y; w[r][2] = v.z;
 		}
 	} else {
 #pragma unroll
 		for (int r = 0; r < 5; r++) {
 			if (r == 4 && !frac) { w[r][0] = any_u32(); w[r][1] = any_u32(); w[r][2] = any_u32(); continue; }
-			const gu8 *row = plane + (size_t)min(max(YC + r, 0), Hc - 1) * sC;
+			const gu8 *row = plane + (uint32_t)mul24(min(max(YC + r, 0), Hc - 1), sC);
 			w[r][0] = ref_dword(row, XA, Wc); w[r][1] = ref_dword(row, XA + 4, Wc); w[r][2] = ref_dword(row, XA + 8, Wc);
 		}
 	}
@@ -1055,7 +1055,7 @@ E264_DEV void res_item8(PredLds &L, const FrameCtx &f, int item)
 				const int j = jp * 2 + h, pos = i * 8 + j;
 				const int lev = (int)(int16_t)(cw[jp] >> (h * 16));
 				const int LS = (int)(ww[j >> 2] >> ((j & 3) * 8) & 255u) * norm8(m, pos);
-				dq[h] = div < 6 ? sat16((lev * LS + (1 << (5 - div))) >> (6 - div)) : (int)(int16_t)(lev * (int)(int16_t)(LS << (div - 6)));
+				dq[h] = div < 6 ? sat16((mul24(lev, LS) + (1 << (5 - div))) >> (6 - div)) : (int)(int16_t)mul24(lev, (int)(int16_t)(LS << (div - 6))); // (|lev| < 2^15, LS < 2^14)
 			}
 			const s16x2 v = {(short)dq[0], (short)dq[1]};
 			t[i][jp] = v;

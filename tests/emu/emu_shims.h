@@ -10,6 +10,7 @@
 #define E264_AS_CONST
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
+static inline int mul24(int a, int b) { return (int)((uint32_t)(a << 8 >> 8) * (uint32_t)(b << 8 >> 8)); } // v_mul_i32_i24: operands truncated to 24 bits signed, as the instruction does
 static inline uint32_t v_perm(uint32_t hi, uint32_t lo, uint32_t sel)
 { // v_perm_b32: selector byte 0..3 -> lo, 4..7 -> hi, 0x0c -> 0x00, >= 0x0d -> 0xff (8..11: sign replication, unused here)
 	uint64_t src = (uint64_t)hi << 32 | lo;

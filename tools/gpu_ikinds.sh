@@ -1,6 +1,6 @@
 # what one I picture of each intra kind costs (intra kernel, 256 pictures per launch); E264_I_KINDS / E264_RESIDUAL_PROB are measuring aids of bench.py
 mkdir -p gpurun_out/ik
-timeout 600 python -m pytest tests/test_hip_parity.py tests/test_hip_golden.py -m gpu -x -q 2>&1 | tail -2
+[ -n "$KINDS" ] || timeout 600 python -m pytest tests/test_hip_parity.py tests/test_hip_golden.py -m gpu -x -q 2>&1 | tail -2
 B="python bench.py --no-cpu-baseline --no-other-configs --no-host-packets --no-same-input --variants 1 --gop I --steps 10 --warmup 2"
 for K in ${KINDS:-4 8 16 4,8,16}; do
   E264_I_KINDS=$K timeout 300 $B > gpurun_out/ik/b_$K.json 2> gpurun_out/ik/b_$K.err
