@@ -298,7 +298,9 @@ def main() -> int:
         args.no_other_configs = True
     else:
         # ---- synthetic input (same bytes on every rank: seeded) -------------------------------
-        vpk = [synth.StreamSynth(W, H, seed=1234 + v, t8x8=True, i_kinds=head_i, num_refs=2, residual_prob=float(os.environ.get("E264_RESIDUAL_PROB", 0.3))).gop(args.gop) for v in range(max(1, args.variants))]
+        skw = dict(t8x8=True, i_kinds=head_i, num_refs=2, residual_prob=float(os.environ.get("E264_RESIDUAL_PROB", 0.3)))
+        skw.update(json.loads(os.environ.get("E264_SYNTH_KW", "{}")))  # measuring aid (tools/gpu_sweep.sh): what each kernel's time depends on
+        vpk = [synth.StreamSynth(W, H, seed=1234 + v, **skw).gop(args.gop) for v in range(max(1, args.variants))]
         packets = vpk[0]
         parsed = [P.Packet(p) for p in packets]
     if args.capture:

@@ -720,6 +720,13 @@ E264_DEV int lds_load_relaxed(const int *p)
 
 
 #define E264_MAX_ROWS 1056
+// A row may reconstruct macroblock x once the row above has finished x + 1: rows that start the moment they may run exactly two
+// macroblocks behind each other, with no slack -- whenever any row of the wavefront is late (a slower kind of macroblock, a lost
+// arbitration) every row below it waits, and the picture advances at the pace of the slowest row of each step.  A row's FIRST
+// dependent macroblock therefore waits for this many macroblocks more: distance that later absorbs the jitter.
+#ifndef E264_INTRA_SLACK
+#define E264_INTRA_SLACK 0
+#endif
 
 // the workgroup's LDS: one object, the LDS-DMA targets first (lowest LDS addresses)
 template <int NW>
@@ -758,6 +765,7 @@ E264_DEV void intra_kernel_body(IntraLds<NW> &S, const E264Job &job, const int t
 	PH_DECL;
 #pragma unroll 1
 	for (int y = wave; y < f.hm; y += NW) {
+		bool row_start = true; // (uniform) the row's first dependent macroblock has not started yet: see E264_INTRA_SLACK
 		// the row is scanned 64 macroblocks at a time (one vector load + ballot) instead of one scalar load per
 		// macroblock: in P/B frames, where few macroblocks are intra, the scan WAS the kernel's run time
 #pragma unroll 1
@@ -805,8 +813,13 @@ E264_DEV void intra_kernel_body(IntraLds<NW> &S, const E264Job &job, const int t
 				PH(0);
 				const int rx = x - x0; // the neighbours above: x-1 (corner), x, x+1 (top right); outside the chunk: assume intra
 				const bool dep = (upi >> rx & 1) || (rx > 0 ? (int)(upi >> (rx - 1) & 1) : x0 > 0) || (rx < 63 ? (int)(upi >> (rx + 1) & 1) : x + 1 < f.wm);
+#ifdef E264_ABL_INTRA_NOWAIT // timing ablation: nobody waits for the row above (wrong samples): what the wavefront order itself costs
+				if (false) {
+#else
 				if (y > 0 && dep) {
-					int want = min(x + 2, f.wm);
+#endif
+					int want = min(x + 2 + (row_start ? E264_INTRA_SLACK : 0), f.wm);
+					row_start = false;
 					while (lds_load_relaxed(&progress[y - 1]) < want)
 						E264_SLEEP();
 					E264_FENCE_ACQUIRE();
@@ -815,7 +828,9 @@ E264_DEV void intra_kernel_body(IntraLds<NW> &S, const E264Job &job, const int t
 				coef_dma_wait();
 				recon_mb<2>(L, f, mi, x, y, lane, i4tab, S.coef[wave][buf], S.coef[wave][buf ^ 1], next_rec, mn PH_ARGS);
 				PH(8);
+#ifndef E264_ABL_INTRA_NOFENCE // timing ablation: progress published without waiting for the stores
 				E264_FENCE_RELEASE();
+#endif
 				PH(9);
 				// finished: everything up to the next intra macroblock of the chunk (or the chunk's end)
 				const int upto = todo ? x0 + (int)__builtin_ctzll(todo) : xe;

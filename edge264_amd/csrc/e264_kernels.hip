@@ -354,6 +354,12 @@ extern "C" const char *e264_kernel_build_flags(void)
 #ifdef E264_ABL_DBK_NOSTORE
 		" E264_ABL_DBK_NOSTORE"
 #endif
+#ifdef E264_ABL_INTRA_NOWAIT
+		" E264_ABL_INTRA_NOWAIT"
+#endif
+#ifdef E264_ABL_INTRA_NOFENCE
+		" E264_ABL_INTRA_NOFENCE"
+#endif
 #ifdef E264_ABL_DBK_NOWAIT
 		" E264_ABL_DBK_NOWAIT"
 #endif
