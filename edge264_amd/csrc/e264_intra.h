@@ -338,7 +338,7 @@ E264_DEV void compute_residual(WaveLds &L, const int16_t *coefs, const FrameCtx 
 // ---------------------------------------------------------------------------------
 #define LP(l, m, r) (((l) + 2 * (m) + (r) + 2) >> 2)
 #ifndef E264_I4_UNROLL
-#define E264_I4_UNROLL 10 // steps of the Intra4x4 anti-diagonal loop unrolled together: all ten (what a lane does in a step is then a handful of
+#define E264_I4_UNROLL 10 // (history: the Intra4x4 anti-diagonal loop is always fully unrolled now) all ten (what a lane does in a step is then a handful of
                           // loop-invariant registers; affordable since E264_INTRA_LAUNDER freed the registers: round 2 spilled with it)
 #endif
 #include "e264_intra_tab.h"
@@ -644,38 +644,33 @@ E264_DEV void recon_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, int mbx, 
 			// neighbours, all of which belong to earlier anti-diagonals x + 2y.  Lanes 0..15 take the first block of a
 			// diagonal, lanes 16..31 the second one; the modes are already resolved against availability by the parser.
 			// zig-zag indices per step: (0,-)(1,-)(4,2)(5,3)(6,8)(7,9)(12,10)(13,11)(14,-)(15,-)
-			const uint64_t firsts = 0xfedc765410ull, seconds = 0xffba9832ffull; // one nibble per step
-			const int half = lane >> 4, hl16 = lane & 15;
-			const uint64_t order = half ? seconds : firsts;
-			// the lane's block and mode at step t (lanes that idle take block 0: valid addresses, nothing stored)
-			auto step_mode = [&](int t, int &bb) {
-				const bool on_ = lane < 32 && !(half == 1 && (t < 2 || t > 7));
-				bb = on_ ? (int)(order >> (4 * t) & 15) : 0;
-				return (int)(((bb < 8 ? modes_lo : modes_hi) >> (4 * (bb & 7))) & 15);
-			};
-			int bb_n;
-			int mode_n = step_mode(0, bb_n);
+			// Which block a half takes at step t is a CONSTANT of the unrolled loop, so its mode is a scalar field extract of the header and
+			// the lane only selects between the two halves' values (round 4; the per-lane 64-bit shifts of an order word cost ~8 VALU per step).
+			static constexpr int F4[10] = {0, 1, 4, 5, 6, 7, 12, 13, 14, 15}, S4[10] = {0, 0, 2, 3, 8, 9, 10, 11, 0, 0}; // (second half idle: block 0, valid addresses, nothing stored)
+			const bool second = lane >= 16;
+			const int hl16 = lane & 15, px = hl16 & 3, py = hl16 >> 2;
+			auto mode_of = [&](int blk) { return (int)(((blk < 8 ? modes_lo : modes_hi) >> (4 * (blk & 7))) & 15); };
+			int mode_n = second ? mode_of(S4[0]) : mode_of(F4[0]);
 			uint32_t e_n = i4tab[mode_n * 16 + hl16];
-#pragma unroll E264_I4_UNROLL
+#pragma unroll
 			for (int t = 0; t < 10; t++) {
-				const bool on = lane < 32 && !(half == 1 && (t < 2 || t > 7));
-				const int bb = bb_n, mode = mode_n;
+				const bool on = (t >= 2 && t <= 7) ? lane < 32 : lane < 16;
+				const int mode = mode_n;
 				const uint32_t e = e_n;
 				if (t < 9) { // next step's table word: in flight during this step's sample reads
-					mode_n = step_mode(t + 1, bb_n);
+					mode_n = second ? mode_of(S4[t + 1]) : mode_of(F4[t + 1]);
 					e_n = i4tab[mode_n * 16 + hl16];
 				}
-				int X0 = BXf(bb), Y0 = BYf(bb);
+				const int X0 = second ? BXf(S4[t]) : BXf(F4[t]), Y0 = second ? BYf(S4[t]) : BYf(F4[t]);
 				int v = 0;
 				if (on) {
-					int x = hl16 & 3, y = hl16 >> 2;
-					const int rres = L.res[(Y0 + y) * 16 + X0 + x]; // requested in front of the prediction's reads, not behind its branches
+					const int rres = L.res[(Y0 + py) * 16 + X0 + px]; // requested in front of the prediction's reads, not behind its branches
 					v = intra4x4_tab(L, e, X0, Y0, mode);
 					v = clip255(w16(v + rres));
 				}
 				wave_sync();
 				if (on)
-					L.YT(Y0 + (hl16 >> 2), X0 + (hl16 & 3)) = (uint8_t)v;
+					L.YT(Y0 + py, X0 + px) = (uint8_t)v;
 				wave_sync();
 			}
 		} else { // I8x8, edge264_slice.c:645-668
