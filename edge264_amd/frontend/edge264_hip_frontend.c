@@ -394,12 +394,17 @@ static int e264_finish_frame_(E264Emitter *e, int slot, int partial)
 	h.dst_slot = slot; h.frame_id = b->frame_id;
 	h.n_coded_mbs = (uint32_t)n_coded; h.n_inter_mbs = (uint32_t)n_inter;
 	h.ref_slots = ref_slots;
-	memset(pkt, 0, payload_off);
-	memcpy(pkt, &h, sizeof(h));
-	memcpy(pkt + slices_off, b->slices, sizeof(E264SliceParams) * (size_t)b->n_slices);
-	memcpy(pkt + mbs_off, b->mbs, sizeof(E264Mb) * (size_t)b->n_mbs);
+	/* the sections, and zeros in the (at most 15-byte) gaps between them: the packet's bytes are a function of the picture alone.
+	 * (Until round 4 the whole 0.4 MB in front of the payload was cleared first and then overwritten.) */
+	uint32_t at = 0;
+#define E264_SECTION(off, src, n) do { memset(pkt + at, 0, (off) - at); memcpy(pkt + (off), (src), (n)); at = (uint32_t)((off) + (n)); } while (0)
+	E264_SECTION(0, &h, sizeof(h));
+	E264_SECTION(slices_off, b->slices, sizeof(E264SliceParams) * (size_t)b->n_slices);
+	E264_SECTION(mbs_off, b->mbs, sizeof(E264Mb) * (size_t)b->n_mbs);
 	if (motion_bytes)
-		memcpy(pkt + motion_off, b->mot, motion_bytes);
+		E264_SECTION(motion_off, b->mot, motion_bytes);
+	memset(pkt + at, 0, payload_off - at);
+#undef E264_SECTION
 	memcpy(pkt + payload_off, b->payload, b->payload_len);
 	memset(pkt + payload_off + b->payload_len, 0, payload_bytes - b->payload_len);
 	if (partial || b->multi) {
