@@ -460,13 +460,11 @@ E264_DEV int intra4x4_px(const WaveLds &L, int X0, int Y0, int mode, int x, int 
 #undef TR
 }
 
-// shape (0..8, c_i8tab) and unavailability bits (1 left, 2 top, 4 top right, 8 corner) of the 32 internal Intra8x8 modes, one nibble each
+// shape (0..8, c_i8tab) of the 32 internal Intra8x8 modes, one nibble each
 // (immediates: the tables used to be two scalar memory reads at the head of every block)
 E264_DEV int i8_nibble(unsigned long long lo, unsigned long long hi, int mode) { return (int)(((mode & 16) ? hi : lo) >> (4 * (mode & 15)) & 15); }
 #define I8_SPEC_LO 0x2222222222110000ull
 #define I8_SPEC_HI 0x8877776554433332ull
-#define I8_UNAV_LO 0xc84a2d951080c840ull
-#define I8_UNAV_HI 0x80c84004040c8403ull
 #define I8_FZ 1 // the wave's filtered edge: FL(j) at fz[j], the corner at fz[8], FT(i) at fz[12 + i] (c_i8tab's tap offsets)
 
 // one 8x8 block by the whole wave.  Round 4: two branch-free phases (the first version walked three lane ranges with their special
@@ -478,11 +476,11 @@ E264_DEV int i8_nibble(unsigned long long lo, unsigned long long hi, int mode) {
 //            the filtered edge + filter type, the same instructions for all eight directional shapes; DC from four v_sad_u8.
 E264_DEV void intra8x8_block(WaveLds &L, uint32_t e, int X0, int Y0, int mode, int lane)
 {
-	const int sm = i8_nibble(I8_SPEC_LO, I8_SPEC_HI, mode), un = i8_nibble(I8_UNAV_LO, I8_UNAV_HI, mode);
-	const bool useA = !(un & 1) && (sm == 1 || sm == 2 || sm == 4 || sm == 5 || sm == 6 || sm == 8);
-	const bool useB = !(un & 2) && (sm == 0 || sm == 2 || sm == 3 || sm == 4 || sm == 5 || sm == 6 || sm == 7);
-	const bool useC = useB && !(un & 4) && sm != 6;
-	const bool cornerAvail = !(un & 8) && (useA || useB);
+	// which neighbours the mode reads, one bit per internal mode (from the shape and the unavailability bits: left = shape in {1, 2, 4, 5, 6, 8}
+	// and available; top = shape in {0, 2, 3, 4, 5, 6, 7} and available; top right = top, available, shape != 6; corner = available and
+	// left or top): five scalar bit tests instead of thirty compares per block
+	const bool useA = 0xc3e0f870u >> mode & 1, useB = 0x3ffee7cfu >> mode & 1, useC = 0x14aa42c5u >> mode & 1, cornerAvail = 0x4fe629d3u >> mode & 1;
+	const bool isDC = 0x0001ffc0u >> mode & 1; // shape 2 (mode 16: nothing available, 128)
 	const int x = lane & 7, y = lane >> 3;
 	const int rres = L.res[(Y0 + y) * 16 + X0 + x]; // requested in front of everything else
 	{
@@ -499,10 +497,10 @@ E264_DEV void intra8x8_block(WaveLds &L, uint32_t e, int X0, int Y0, int mode, i
 	}
 	wave_sync();
 	int v;
-	if (sm == 2 || mode == 16) { // (uniform) DC from the filtered edge, or nothing available
+	if (isDC) { // (uniform) DC from the filtered edge (mode 16: nothing available)
 		const uint32_t *w = (const uint32_t *)L.fz;
 		const int sl = (int)v_sad_u8(w[0], 0, v_sad_u8(w[1], 0, 0)), st = (int)v_sad_u8(w[3], 0, v_sad_u8(w[4], 0, 0));
-		v = mode == 16 ? 128 : useA && useB ? (st + sl + 8) >> 4 : useB ? (st + 4) >> 3 : useA ? (sl + 4) >> 3 : 128;
+		v = useA && useB ? (st + sl + 8) >> 4 : useB ? (st + 4) >> 3 : useA ? (sl + 4) >> 3 : 128;
 	} else {
 		const int a = L.fz[e & 255], b = L.fz[e >> 8 & 255], c = L.fz[e >> 16 & 255];
 		const int ty = (int)(e >> 24), sh = ty >> 3;
