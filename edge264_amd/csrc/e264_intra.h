@@ -39,9 +39,12 @@ E264_DEV int relane(int lane) { asm volatile("" : "+v"(lane)); return lane; } //
 #define CT_STRIDE 16
 #define CT(p, y, x) ctile[p][((y) + 1) * CT_STRIDE + (x) + 4]
 
+// 4x4 transform: block k's 16 intermediate values at tmp[k * T4_STRIDE]: 20 dwords apart, the 64 lanes of a pass (16 blocks x 4 lanes on consecutive
+// dwords) fall on the 32 banks twice each; 16 apart they fell on 8 banks, eight times each
+#define T4_STRIDE 20
 struct __attribute__((aligned(16))) WaveLds { // reconstruction scratch of one wave
 	int16_t res[384];          // residual: luma [y*16+x], Cb at 256 [y*8+x], Cr at 320
-	int32_t tmp[256];          // IDCT intermediate (4x4: 16 blocks x 16 int32; 8x8: int16 view)
+	int32_t tmp[16 * T4_STRIDE]; // IDCT intermediate (4x4: 16 blocks x 16 int32, T4_STRIDE apart; 8x8: int16 view of the first 512 bytes)
 	int32_t dc[24];            // 16 luma DC (zig order), 4 Cb, 4 Cr
 	uint8_t ytile[17 * YT_STRIDE];
 	uint8_t ctile[2][9 * CT_STRIDE];
@@ -107,7 +110,7 @@ E264_DEV void idct4x4_blocks(WaveLds &L, int nblk, uint32_t codedmask, bool use_
 		if (use_dc && y == 0)
 			d[0] = L.dc[dc_off + k];
 		int e0 = d[0] + d[2], e1 = d[0] - d[2], e2 = (d[1] >> 1) - d[3], e3 = (d[3] >> 1) + d[1];
-		int32_t *t = L.tmp + k * 16;
+		int32_t *t = L.tmp + k * T4_STRIDE;
 		int add = (y == 0) ? 32 : 0;
 		t[0 * 4 + y] = e0 + e3 + add;
 		t[1 * 4 + y] = e1 + e2 + add;
@@ -123,7 +126,7 @@ E264_DEV void idct4x4_blocks(WaveLds &L, int nblk, uint32_t codedmask, bool use_
 		else            // chroma: plane k>>2 (64 samples each), 2x2 blocks of an 8x8 tile
 			r = L.res + res_off + (k >> 2) * 64 + ((k >> 1) & 1) * 4 * res_stride + (k & 1) * 4 + x;
 		if (coded) {
-			const int32_t *t = L.tmp + k * 16 + x * 4;
+			const int32_t *t = L.tmp + k * T4_STRIDE + x * 4;
 			int f0 = t[0], f1 = t[1], f2 = t[2], f3 = t[3];
 			int g0 = f0 + f2, g1 = f0 - f2, g2 = (f1 >> 1) - f3, g3 = (f3 >> 1) + f1;
 			r[0 * res_stride] = (int16_t)sat16((g0 + g3) >> 6);
@@ -168,19 +171,20 @@ E264_DEV void idct8x8_blocks(WaveLds &L, uint32_t coded, const uint8_t *coef_bas
 	bool on = lane < 32 && (coded >> (b * 4) & 1);
 	int16_t *t16 = (int16_t *)L.tmp;
 	if (on) {
-		int nb = 0;
-		for (int i = 0; i < b; i++) nb += coded >> (i * 4) & 1;
+		const int nb = __builtin_popcount(coded & 0x1111u & ((1u << (b * 4)) - 1)); // coded 8x8 blocks before this one
 		int div = qP / 6, m = qP - div * 6;
+		// residual.c:214-247 has two forms: qP < 36: saturate((level * LS + 2^(5 - div)) >> (6 - div)) to int16; else (level * int16(LS << (div - 6)))
+		// wrapped to int16.  One flow for both (all scalars): the shifts and the rounding term are 0 on the side that has none, the
+		// clamp bounds are int16's for the first form and int32's (no clamp; the store wraps) for the second.
+		const int shl = max(div - 6, 0), shr = max(6 - div, 0), rnd = div < 6 ? 1 << (5 - div) : 0;
+		const int lo = div < 6 ? -32768 : (int)0x80000000, hi = div < 6 ? 32767 : 0x7fffffff;
 		int16_t d[8];
 #pragma unroll
 		for (int i = 0; i < 8; i++) {
 			int pos = i * 8 + j;
 			int LS = wS[pos] * norm8(m, pos);
 			const int lev = level_at(coef_base, nb * 64 + pos, l8);
-			if (div < 6)
-				d[i] = (int16_t)sat16((mul24(lev, LS) + (1 << (5 - div))) >> (6 - div));
-			else
-				d[i] = (int16_t)mul24(lev, (int)(int16_t)(LS << (div - 6)));
+			d[i] = (int16_t)min(max((mul24(lev, (int)(int16_t)(LS << shl)) + rnd) >> shr, lo), hi);
 		}
 		idct8_1d(d);
 		// transposed read in pass 2: element [i][j]
@@ -264,13 +268,13 @@ E264_DEV void slice_cache(WaveLds &L, const FrameCtx &f, int slice, int lane)
 }
 
 // coefs holds the macroblock's payload (coef_dma + coef_dma_wait), the slice cache is valid (slice_cache)
-E264_DEV void compute_residual(WaveLds &L, const int16_t *coefs, const FrameCtx &f, const MbInfo &m, int lane)
+// inter: the macroblock is an inter one (its own scaling lists); the intra kernel never sees one and passes a constant
+E264_DEV void compute_residual(WaveLds &L, const int16_t *coefs, const FrameCtx &f, const MbInfo &m, bool inter, int lane)
 {
 	// zero the residual tile (384 int16 = 192 dwords)
 	uint32_t *rz = (uint32_t *)L.res;
 	rz[lane] = 0; rz[lane + 64] = 0; rz[lane + 128] = 0;
 	const uint32_t coded = m.coded;
-	const bool inter = m.kind == E264_MB_INTER;
 	const int16_t *pl = coefs;
 	const int16_t *ldc = nullptr, *cdc = nullptr;
 	if (coded & E264_CODED_LUMA_DC) { ldc = pl; pl += 16; }
@@ -625,7 +629,7 @@ E264_DEV void recon_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, int mbx, 
 	}
 	slice_cache(L, f, m.slice, lane);
 	PH(3);
-	compute_residual(L, coefs, f, m, (E264_INTRA_LAUNDER & 4) ? relane(lane) : lane);
+	compute_residual(L, coefs, f, m, WHICH == 2 ? false : m.kind == E264_MB_INTER, (E264_INTRA_LAUNDER & 4) ? relane(lane) : lane);
 	PH(4);
 
 	int pY[4], pC[2];
