@@ -117,7 +117,7 @@ E264_DEV uint32_t v_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __buil
 E264_DEV uint32_t v_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); } // ({hi,lo} >> 8*(sh&3))
 E264_DEV uint32_t v_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }   // ({hi,lo} >> (sh&31))
 E264_DEV uint32_t v_lerp_u8(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_lerp(a, b, c); }              // per byte (a + b + (c & 1)) >> 1
-E264_DEV int mul24(int a, int b) { int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; } // v_mul_i32_i24: the low 32 bits of a * b for operands within 24 bits signed -- full rate, where v_mul_lo_u32 / v_mad_u64_u32 (what `a * b` compiles to when the compiler cannot see the ranges) take four passes
+E264_DEV int mul24(int a, int b) { return a * b; } // operands within 24 bits signed.  (As inline asm v_mul_i32_i24 it bought nothing -- v_mul_lo_u32 issues at the VOP3 rate on gfx950, profiles/r02_valu_rate.txt -- and cost s_nops the compiler puts around asm it cannot see into.)
 E264_DEV uint32_t v_sat_pk_u8_i16(uint32_t v) // two int16 -> two bytes with unsigned saturation in bits 15:0; no builtin
 {
 	uint32_t r;

@@ -330,11 +330,13 @@ struct LumaSink {
 };
 E264_DEV void sink_row(const LumaSink &k, int j, uint32_t v0, uint32_t v1)
 {
-	if (j >= k.nr)
+	if (j >= 4 && j >= k.nr) // (a partition has 4 or 8 rows: no test at all for the first four)
 		return;
 	uint32_t *d = k.ty + j * PT_W * 4;
-	if (k.mode == 1) { v0 = v_lerp_u8(d[0], v0, ONES8); v1 = v_lerp_u8(d[1], v1, ONES8); }
-	else if (k.mode == 2) { v0 = wpred4(d[0], v0, k.w); v1 = wpred4(d[1], v1, k.w); }
+	if (k.mode) { // one test where no lane of the wave combines with list 0 (every P picture without explicit weights)
+		if (k.mode == 1) { v0 = v_lerp_u8(d[0], v0, ONES8); v1 = v_lerp_u8(d[1], v1, ONES8); }
+		else { v0 = wpred4(d[0], v0, k.w); v1 = wpred4(d[1], v1, k.w); }
+	}
 	d[0] = v0;
 	if (k.w8) d[1] = v1;
 }
@@ -1039,6 +1041,10 @@ E264_DEV void res_item8(PredLds &L, const FrameCtx &f, int item)
 	const gu8 *co = pl + ((__builtin_popcount(coded & 0x1111 & ((1u << (bq * 4)) - 1)) * 128) >> l8);
 	const gu8 *wsp = (const gu8 *)s + offsetof(E264SliceParams, weightScale8x8) + 64; // list 1: inter Y
 	const int qP = (int)(d0 >> 16 & 255), div = qP / 6, m = qP - div * 6;
+	// residual.c:214-247 has two forms (qP < 36: saturate((level * LS + 2^(5 - div)) >> (6 - div)); else level * int16(LS << (div - 6)), wrapped): one
+	// flow for both -- qP is per lane here, a two-way form is a divergent branch around every one of the 64 coefficients
+	const int shl = max(div - 6, 0), shr = max(6 - div, 0), rnd = div < 6 ? 1 << (5 - div) : 0;
+	const int lo = div < 6 ? -32768 : (int)0x80000000, hi = div < 6 ? 32767 : 0x7fffffff;
 	// pass 1 (residual.c:250-296): for every j, the 1-D transform over i of d[i][j] = level c[i*8+j] dequantised; packed pairs (j, j+1)
 	s16x2 t[8][4]; // [i][pair of j]
 #pragma unroll
@@ -1055,7 +1061,7 @@ E264_DEV void res_item8(PredLds &L, const FrameCtx &f, int item)
 				const int j = jp * 2 + h, pos = i * 8 + j;
 				const int lev = (int)(int16_t)(cw[jp] >> (h * 16));
 				const int LS = (int)(ww[j >> 2] >> ((j & 3) * 8) & 255u) * norm8(m, pos);
-				dq[h] = div < 6 ? sat16((mul24(lev, LS) + (1 << (5 - div))) >> (6 - div)) : (int)(int16_t)mul24(lev, (int)(int16_t)(LS << (div - 6))); // (|lev| < 2^15, LS < 2^14)
+				dq[h] = min(max((lev * (int)(int16_t)(LS << shl) + rnd) >> shr, lo), hi); // (stored as int16: wraps where the second form wraps)
 			}
 			const s16x2 v = {(short)dq[0], (short)dq[1]};
 			t[i][jp] = v;
