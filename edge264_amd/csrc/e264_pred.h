@@ -763,23 +763,37 @@ E264_DEV void pred_item(PredLds &L, const FrameCtx &f, const PredTile &t, int li
 		uint32_t oc[2][4];
 		chroma4x4(cw[0], XC, mx & 7, my & 7, oc[0]);
 		chroma4x4(cw[1], XC, mx & 7, my & 7, oc[1]);
-		const int ncr = h8 ? 4 : 2;
+		// Every test once per item, not once per row and plane (round 4: each `if` of a lane-dependent condition is three scalar
+		// instructions of execution-mask bookkeeping, and there were twenty-four of them here): the combination with list 0, then the
+		// stores by width, the lower two rows of a partition 8 high under one test.
+		uint32_t *tc0 = &L.c[0][py0 >> 1][px0 >> 3];
+		uint16_t *hc0 = (uint16_t *)&L.c[0][py0 >> 1][0] + (px0 >> 2);
+		constexpr int PL = (int)(sizeof(L.c[0]) / 4); // dwords per chroma plane of the tile
+		if (mode != 0) {
 #pragma unroll
-		for (int pc = 0; pc < 2; pc++) {
-			uint32_t *tc = &L.c[pc][py0 >> 1][px0 >> 3];
-			uint16_t *hc = (uint16_t *)&L.c[pc][py0 >> 1][0] + (px0 >> 2);
-			const Wod &w = pc ? wCr : wCb;
+			for (int pc = 0; pc < 2; pc++) {
+				const Wod &w = pc ? wCr : wCb;
 #pragma unroll
-			for (int j = 0; j < 4; j++)
-				if (j < ncr) {
-					uint32_t v = oc[pc][j];
-					if (mode != 0) {
-						const uint32_t qv = w8 ? tc[j * PT_W * 2] : hc[j * PT_W * 4];
-						v = mode == 1 ? v_lerp_u8(qv, v, ONES8) : wpred4(qv, v, w);
-					}
-					if (w8) tc[j * PT_W * 2] = v;
-					else hc[j * PT_W * 4] = (uint16_t)v;
+				for (int j = 0; j < 4; j++) { // (rows 2, 3 of a partition 4 high: read and combined for nothing, never stored)
+					const uint32_t qv = w8 ? tc0[pc * PL + j * PT_W * 2] : hc0[pc * PL * 2 + j * PT_W * 4];
+					oc[pc][j] = mode == 1 ? v_lerp_u8(qv, oc[pc][j], ONES8) : wpred4(qv, oc[pc][j], w);
 				}
+			}
+		}
+		if (w8) {
+#pragma unroll
+			for (int pc = 0; pc < 2; pc++) { tc0[pc * PL] = oc[pc][0]; tc0[pc * PL + PT_W * 2] = oc[pc][1]; }
+			if (h8) {
+#pragma unroll
+				for (int pc = 0; pc < 2; pc++) { tc0[pc * PL + 2 * PT_W * 2] = oc[pc][2]; tc0[pc * PL + 3 * PT_W * 2] = oc[pc][3]; }
+			}
+		} else {
+#pragma unroll
+			for (int pc = 0; pc < 2; pc++) { hc0[pc * PL * 2] = (uint16_t)oc[pc][0]; hc0[pc * PL * 2 + PT_W * 4] = (uint16_t)oc[pc][1]; }
+			if (h8) {
+#pragma unroll
+				for (int pc = 0; pc < 2; pc++) { hc0[pc * PL * 2 + 2 * PT_W * 4] = (uint16_t)oc[pc][2]; hc0[pc * PL * 2 + 3 * PT_W * 4] = (uint16_t)oc[pc][3]; }
+			}
 		}
 	}
 	LumaSink sink;
