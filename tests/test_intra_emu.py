@@ -83,3 +83,23 @@ def test_intra_emu_vs_oracle(emu, name):
             badc = got_c != exp_c
             assert not badc.any(), f"{name} seed {seed} frame {ft}: chroma differs at (y, x) {np.argwhere(badc)[:5].tolist()}"
             dpb[d][:] = mine[d]  # (identical) keep going from the emulated picture
+
+
+def test_check_vectors_through_the_emulated_kernels(emu):
+    """The reference's published vectors (src/edge264_check.c:185-357, tests/golden_packets.py: all 14 + 32 + 7 + 7 intra modes, the 48
+    luma quarter-sample positions, chroma) through the kernels' SOURCE on the host: what tests/test_hip_golden.py does on the GPU,
+    here without one -- a change to e264_intra.h / e264_pred.h that breaks a mode shows in the CPU suite, no oracle in between."""
+    from tests import golden_packets as GP
+    nb = P.frame_bytes(GP.W, GP.H)
+    n = 0
+    for name, pkt, init, checks in GP.cases():
+        dpb = [None] * 32
+        for s in (GP.DST, GP.REF):
+            dpb[s] = np.zeros(nb + 16, np.uint8)
+        for s, buf in init.items():
+            dpb[s][:nb] = buf[:nb]
+        assert emu.e264emu_pred_frame(pkt, _dpb_array(dpb)) == 0, name
+        assert emu.e264emu_intra_frame(pkt, _dpb_array(dpb)) == 0, name
+        GP.check(name, dpb[GP.DST][:nb], checks)
+        n += 1
+    assert n == 110
