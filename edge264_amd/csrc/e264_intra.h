@@ -100,12 +100,20 @@ E264_DEV void idct4x4_blocks(WaveLds &L, int nblk, uint32_t codedmask, bool use_
 		// coefficient blocks are packed in increasing k: offset = popcount of lower coded bits
 		const int cb = __builtin_popcount(codedmask & ((1u << k) - 1)) * 16; // levels before this block
 		int sh = qP / 6, m = qP - sh * 6;
-		int d[4];
+		int lev[4], d[4];
+		// ONE test of the level size around the four reads (the compiler left `l8 ? int8 read : int16 read` as a scalar branch around each)
+		if (l8) {
+#pragma unroll
+			for (int x = 0; x < 4; x++) lev[x] = ((const int8_t *)coef_base)[cb + x * 4 + y];
+		} else {
+#pragma unroll
+			for (int x = 0; x < 4; x++) lev[x] = ((const int16_t *)coef_base)[cb + x * 4 + y];
+		}
 #pragma unroll
 		for (int x = 0; x < 4; x++) {
 			int pos = x * 4 + y;
 			int LS = wS[pos] * norm4(m, pos);
-			d[x] = (int)(((uint32_t)mul24(level_at(coef_base, cb + pos, l8), LS) << sh) + 8u) >> 4; // (|level| < 2^15, LS < 2^13: full-rate multiply)
+			d[x] = (int)(((uint32_t)mul24(lev[x], LS) << sh) + 8u) >> 4; // (|level| < 2^15, LS < 2^13)
 		}
 		if (use_dc && y == 0)
 			d[0] = L.dc[dc_off + k];
@@ -179,12 +187,19 @@ E264_DEV void idct8x8_blocks(WaveLds &L, uint32_t coded, const uint8_t *coef_bas
 		const int shl = max(div - 6, 0), shr = max(6 - div, 0), rnd = div < 6 ? 1 << (5 - div) : 0;
 		const int lo = div < 6 ? -32768 : (int)0x80000000, hi = div < 6 ? 32767 : 0x7fffffff;
 		int16_t d[8];
+		int lev[8];
+		if (l8) { // (one test of the level size around the eight reads)
+#pragma unroll
+			for (int i = 0; i < 8; i++) lev[i] = ((const int8_t *)coef_base)[nb * 64 + i * 8 + j];
+		} else {
+#pragma unroll
+			for (int i = 0; i < 8; i++) lev[i] = ((const int16_t *)coef_base)[nb * 64 + i * 8 + j];
+		}
 #pragma unroll
 		for (int i = 0; i < 8; i++) {
 			int pos = i * 8 + j;
 			int LS = wS[pos] * norm8(m, pos);
-			const int lev = level_at(coef_base, nb * 64 + pos, l8);
-			d[i] = (int16_t)min(max((mul24(lev, (int)(int16_t)(LS << shl)) + rnd) >> shr, lo), hi);
+			d[i] = (int16_t)min(max((mul24(lev[i], (int)(int16_t)(LS << shl)) + rnd) >> shr, lo), hi);
 		}
 		idct8_1d(d);
 		// transposed read in pass 2: element [i][j]
@@ -789,6 +804,8 @@ E264_DEV void intra_kernel_body(IntraLds<NW> &S, const E264Job &job, const int t
 			// macroblock starts at once instead of queueing behind every intra macroblock up and to the left of it).
 			const unsigned long long upi = E264_BALLOT(kup == E264_MB_I4x4 || kup == E264_MB_I8x8 || kup == E264_MB_I16x16);
 			const int xe = min(x0 + 64, f.wm);
+			// bit rx: one of the three macroblocks above macroblock x0 + rx -- x-1 (corner), x, x+1 (top right) -- is intra; outside the chunk: assume so
+			const unsigned long long depmask = upi | upi << 1 | upi >> 1 | (x0 > 0 ? 1ull : 0ull) | (x0 + 64 < f.wm ? 1ull << 63 : 0ull);
 			if (todo == 0 || (int)__builtin_ctzll(todo) > 0) { // macroblocks before the first intra one need nothing from this kernel
 				const int upto = todo ? x0 + (int)__builtin_ctzll(todo) : xe;
 				if (lane == 0)
@@ -808,8 +825,7 @@ E264_DEV void intra_kernel_body(IntraLds<NW> &S, const E264Job &job, const int t
 				todo &= todo - 1;
 				const uint32_t *next_rec = todo ? &hdrs[wave][__builtin_ctzll(todo) * 8] : nullptr;
 				PH(0);
-				const int rx = x - x0; // the neighbours above: x-1 (corner), x, x+1 (top right); outside the chunk: assume intra
-				const bool dep = (upi >> rx & 1) || (rx > 0 ? (int)(upi >> (rx - 1) & 1) : x0 > 0) || (rx < 63 ? (int)(upi >> (rx + 1) & 1) : x + 1 < f.wm);
+				const bool dep = depmask >> (x - x0) & 1;
 #ifdef E264_ABL_INTRA_NOWAIT // timing ablation: nobody waits for the row above (wrong samples): what the wavefront order itself costs
 				if (false) {
 #else
