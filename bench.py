@@ -300,6 +300,9 @@ def main() -> int:
         # ---- synthetic input (same bytes on every rank: seeded) -------------------------------
         skw = dict(t8x8=True, i_kinds=head_i, num_refs=2, residual_prob=float(os.environ.get("E264_RESIDUAL_PROB", 0.3)))
         skw.update(json.loads(os.environ.get("E264_SYNTH_KW", "{}")))  # measuring aid (tools/gpu_sweep.sh): what each kernel's time depends on
+    # a run with any of the measuring aids set does not measure BASELINE configs[2] any more: the line says so (config.synth_overrides, workload)
+    synth_overrides = {k: os.environ[k] for k in ("E264_I_KINDS", "E264_RESIDUAL_PROB", "E264_SYNTH_KW") if os.environ.get(k) and not args.capture}
+    if not args.capture:
         vpk = [synth.StreamSynth(W, H, seed=1234 + v, **skw).gop(args.gop) for v in range(max(1, args.variants))]
         packets = vpk[0]
         parsed = [P.Packet(p) for p in packets]
@@ -584,9 +587,11 @@ def main() -> int:
                                     f"{V} distinct GOPs dealt to the streams round-robin, "
                                     "in-loop deblocking), BASELINE configs[2]; command packets and DPBs RESIDENT IN HBM before the timed region: the H2D copy of the "
                                     "packets is excluded from `value` -- see `pcie_inclusive` (host packets, copy included) and `same_input` (packets of real "
-                                    "bitstreams through the reference's parser)") + (f"; configs[4]: {args.total_streams} streams sharded over {world} GPU(s)" if strong else ""),
+                                    "bitstreams through the reference's parser)") + (f"; configs[4]: {args.total_streams} streams sharded over {world} GPU(s)" if strong else "")
+                                   + (f"; NOT the BASELINE workload: synthetic content overridden by {synth_overrides} (a measuring run)" if synth_overrides else ""),
                        "streams_per_gpu": my_streams, "total_streams": frames_per_step // len(packets), "frames_per_step": frames_per_step,
-                       "waves_per_frame": args.waves, "compute_lanes": lanes, "parallelism": f"stream-parallel x{world}, no collectives"},
+                       "waves_per_frame": args.waves, "compute_lanes": lanes, "parallelism": f"stream-parallel x{world}, no collectives",
+                       "synth_overrides": synth_overrides or None},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kern[dom]["frac"], "traffic": traffic, "traffic_source": traffic_src,
                          "launches": launches, "kernels": kern,

@@ -254,6 +254,27 @@ def test_bench_config5_shards_a_fixed_job(tmp_path):
     assert few.returncode != 0
 
 
+def test_bench_says_when_the_synthetic_content_is_overridden():
+    """bench.py's measuring aids (E264_I_KINDS, E264_RESIDUAL_PROB, E264_SYNTH_KW: tools/gpu_ikinds.sh, gpu_sweep.sh) change the synthetic
+    content: a line produced with one of them set says that it is NOT the BASELINE workload and which override was in force; without
+    them `config.synth_overrides` is null."""
+    import json
+    env = dict(os.environ, E264_BENCH_BACKEND="tests.stub_backend", OMP_NUM_THREADS="1", PYTHONPATH=ROOT)
+    for k in ("WORLD_SIZE", "E264_I_KINDS", "E264_RESIDUAL_PROB", "E264_SYNTH_KW"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--streams", "2", "--gop", "IP", "--width-mbs", "4", "--height-mbs", "3",
+           "--variants", "2"]
+    for over in ({}, {"E264_I_KINDS": "8", "E264_SYNTH_KW": '{"mv_range": 0}'}):
+        out = subprocess.run(cmd, env=dict(env, **over), capture_output=True, text=True, timeout=300, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-3000:]
+        d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        if over:
+            assert d["config"]["synth_overrides"] == over and "NOT the BASELINE workload" in d["config"]["workload"]
+        else:
+            assert d["config"]["synth_overrides"] is None and "NOT the BASELINE" not in d["config"]["workload"]
+            assert "2 distinct GOPs" in d["config"]["workload"]
+
+
 def test_numa_helpers():
     from edge264_amd.sharding import bind_rank_to_gpu_socket, parse_cpulist
     assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and parse_cpulist("") == []
