@@ -36,6 +36,7 @@ CASES = {
     "i_big_levels": dict(gop="I", w=6, h=4, kw=dict(big_levels=True)),
     "p_with_intra": dict(gop="IPB", w=9, h=7, kw=dict(intra_in_inter=0.4, pcm_prob=0.1, slices_per_frame=3)),
     "i_slices_qp": dict(gop="II", w=8, h=6, kw=dict(slices_per_frame=4, scaling=True)),
+    "i_8x8_qp_around_36": dict(gop="II", w=8, h=5, kw=dict(i_kinds=(P.MB_I8x8,), t8x8=True, scaling=True, qp_base=37)),  # both forms of the 8x8 dequantisation
 }
 
 

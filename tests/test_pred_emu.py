@@ -43,6 +43,8 @@ CASES = {
     "stress_far_mvs": dict(gop="IPBP", w=4, h=3, kw=dict(stress=True, mv_range=400, residual_prob=0.8)),
     "pcm_slices": dict(gop="IPB", w=6, h=5, kw=dict(pcm_prob=0.3, intra_in_inter=0.3, slices_per_frame=3)),
     "all_residual": dict(gop="IPP", w=6, h=4, kw=dict(residual_prob=1.0, p_skip=0.0)),
+    # QP walks around 36: lanes of one wave on both sides of the 8x8 dequantisation's two forms (residual.c:214-247; one flow since round 4)
+    "t8x8_qp_around_36": dict(gop="IPB", w=9, h=6, kw=dict(t8x8=True, scaling=True, residual_prob=1.0, qp_base=37)),
 }
 
 
