@@ -1,0 +1,66 @@
+"""The multi-stream driver's host side WITHOUT a GPU (edge264_amd/driver/e264_multi.cpp --parse-only: decoders advanced by a pool of
+threads, any thread any decoder, packets collected per round but submitted nowhere): the packets it produces describe the same pictures as
+the packets the capture sink produces for the same streams one decoder at a time (same sizes, macroblock counts, payloads; the DPB slot a
+picture lands in depends on when the caller takes frames out, so the bytes may differ in the slot fields), every one passes the back end's
+host-only validation, and nothing depends on the number of threads.  (On the GPU: tests/test_multi_stream.py.)"""
+import collections
+import json
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+STREAMS = os.path.join(HERE, "golden", "streams")
+EXE = os.path.join(ROOT, "edge264_amd", "e264_multi")
+FRONT = os.path.join(ROOT, "edge264_amd", "libedge264_hipfront.so")
+HIP = os.path.join(ROOT, "edge264_amd", "libedge264_hip.so")
+NAMES = ["ipb_spatial", "cabac_ipp", "mvc_ipp", "slices_deblock_idc", "cabac_t8x8_scaling", "i_4x4_16x16_pcm"]
+
+
+def shape(p):
+    """what a packet says about its picture, without the DPB slots"""
+    from edge264_amd import packet as P
+    h = P.Packet(p).hdr
+    return tuple(int(h[k]) for k in ("total_bytes", "width_mbs", "height_mbs", "n_slices", "n_coded_mbs", "n_inter_mbs", "payload_bytes"))
+
+
+def split_packets(data):
+    out, off = [], 0
+    while off < len(data):
+        n = int.from_bytes(data[off + 8:off + 12], "little")  # E264FrameHdr.total_bytes
+        out.append(data[off:off + n])
+        off += n
+    assert off == len(data)
+    return out
+
+
+@pytest.mark.skipif(not (os.path.exists(EXE) and os.path.exists(FRONT) and os.path.exists(HIP)), reason="libraries not built")
+def test_parse_only_driver_produces_the_capture_sinks_packets(tmp_path):
+    from edge264_amd import backend, front
+    files = [os.path.join(STREAMS, n + ".264") for n in NAMES]
+    want = collections.Counter()
+    frames = 0
+    for f in files:
+        pk, nf, _ = front.capture_packets(open(f, "rb").read())
+        frames += nf
+        for p in pk:
+            assert backend.packet_check(p) == 0
+            want[shape(p)] += 1
+    repeat = 3
+    stats = {}
+    for threads in (1, 4):
+        dump = tmp_path / f"p{threads}.e264"
+        out = subprocess.run([EXE, "--front", FRONT, "--hip", HIP, "--threads", str(threads), "--repeat", str(repeat), "--parse-only", "--dump-packets", str(dump)] + files,
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        st = stats[threads] = json.loads(out.stdout.strip().splitlines()[-1])
+        assert st["streams"] == len(NAMES) * repeat and st["frames"] == repeat * frames
+        pkts = split_packets(dump.read_bytes())
+        for p in pkts:
+            assert backend.packet_check(p) == 0
+        got = collections.Counter(shape(p) for p in pkts)
+        assert sum(got.values()) == st["packets"] == repeat * sum(want.values())
+        assert got == collections.Counter({k: v * repeat for k, v in want.items()}), "the driver's packets do not describe the capture sink's pictures"
+    assert stats[1]["packets"] == stats[4]["packets"]
