@@ -407,7 +407,7 @@ API int e264hip_set_option(E264Device *dev, const char *name, int value)
 	}
 	if (!strcmp(name, "waves")) {
 		int prev = dev->waves;
-		if (value == 2 || value == 4 || value == 7 || value == 8 || value == 106 || value == 107 || value == 108) dev->waves = value; // 100 + n: n luma / chroma waves (e264_deblock2_kernel) // anything else keeps the setting
+		if (value == 2 || value == 4 || value == 7 || value == 8 || value == 106 || value == 107 || value == 108 || value == 110 || value == 112) dev->waves = value; // (110, 112: builds with strips of four macroblocks, E264_DBK_GS = 2; else they mean 108) // 100 + n: n luma / chroma waves (e264_deblock2_kernel) // anything else keeps the setting
 		return prev;
 	}
 	return -1;

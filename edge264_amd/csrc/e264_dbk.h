@@ -40,16 +40,27 @@ namespace {
 // Luma and chroma deblocking never read each other's samples (edge264_deblock.c filters the three planes in turn): with waves of
 // their own the luma instruction stream -- which every lane of a mixed wave executes, chroma lanes included -- serves 8 macroblocks per
 // step instead of 5, and the chroma waves run a third of it (no p1 / q1 updates, no bS 4 luma filter) for 16.
+// Macroblocks per fetch / flush group, a build-time choice (round 5):
+//   4  strips of 8 macroblocks, 64-byte row pieces in and out, 20 KB of LDS per wave: 8 waves per picture (2 per SIMD)
+//   2  strips of 4 macroblocks, 32-byte row pieces, 12.6 KB per wave: 12 waves per picture (3 per SIMD) -- VERDICT r4 item 1: at two
+//      waves per SIMD the VALU pipe is ~57 % busy and a step's time is the latency of its dependent chain
+#ifndef E264_DBK_GS
+#define E264_DBK_GS 4
+#endif
+#define DK_GS E264_DBK_GS
+#define DK_LG (DK_GS == 4 ? 2 : 1)
+#define DK_SLOTS (2 * DK_GS)    // macroblocks a strip row holds: the group being filtered and the one waiting for the row below
+static_assert(DK_GS == 4 || DK_GS == 2, "E264_DBK_GS: 4 or 2");
 template <int K> struct DkGeom {
-	static constexpr int ROWS = K == 0 ? 8 : K == 1 ? 15 : 5;     // macroblock rows per wave (chroma: 15, not 16 -- 60 lanes -- so that EIGHT waves' strips fit the CU's 160 KB; a 1080p picture is 5 chroma groups either way)
+	static constexpr int ROWS = K == 0 ? 8 : K == 1 ? (DK_GS == 4 ? 15 : 16) : 5; // macroblock rows per wave (chroma with groups of 4: 15, not 16 -- 60 lanes -- so that EIGHT waves' strips fit the CU's 160 KB; a 1080p picture is 5 chroma groups either way)
 	static constexpr int LANES = K == 0 ? 8 : K == 1 ? 4 : 12;    // lanes per row
 	static constexpr int NLUMA = K == 1 ? 0 : 8;                  // of which luma line pairs (the others: chroma line pairs, Cb and Cr)
 	static constexpr bool LUMA = K != 1, CHROMA = K != 0;
 	static constexpr int YROWS = LUMA ? ROWS : 1, CROWS = CHROMA ? ROWS : 1; // strips that exist
 };
 #define DK_ROWS_OF(K) (DkGeom<K>::ROWS)
-#define DK_STRIDE 144  // bytes per strip row: 8 macroblocks x 16 + 16 (keeps the row pairs of a V phase on different banks)
-#define DK_CR 64       // chroma strip row: Cb at +0, Cr at +64
+#define DK_STRIDE (DK_SLOTS * 16 + 16) // bytes per strip row: 8 (4) macroblocks x 16 + 16 (keeps the row pairs of a V phase on different banks)
+#define DK_CR (DK_SLOTS * 8)           // chroma strip row: Cb at +0, Cr at +64 (+32)
 
 template <int K> struct __attribute__((aligned(16))) DkWaveT { // (the members a kind does not use shrink to 16 bytes)
 	uint8_t y[DkGeom<K>::YROWS][DkGeom<K>::LUMA ? 16 : 1][DkGeom<K>::LUMA ? DK_STRIDE : 16];   // luma strips: macroblock x at columns (x & 7) * 16
@@ -103,7 +114,7 @@ template <int K> E264_DEV DkRole dk_role(int lane)
 	R.g = lane / G::LANES; R.r = lane - R.g * G::LANES;
 	R.idle = R.g >= G::ROWS;
 	if (R.idle) R.g = G::ROWS - 1; // addresses stay valid; the lane never acts
-	R.chroma = R.r >= G::NLUMA;
+	R.chroma = K == 2 ? R.r >= G::NLUMA : K == 1; // (a constant for the one-plane kinds: everything derived from it below folds)
 	R.pi = R.chroma ? R.r - G::NLUMA : R.r;
 	R.seg = R.chroma ? R.pi : R.pi >> 1;
 	const int g = R.g, col = 2 * R.pi;
@@ -263,32 +274,34 @@ template <int K> E264_DEV DkSrc dk_src(const FrameCtx &f, const DkRole &R, int y
 // macroblocks x0 .. x0 + 3 of the lane's row -> N[0..7].  LOADS ONLY.  A chroma piece may start one macroblock before the row
 // (x0 = -1: its second half is macroblock 0) or end one after it: 8 bytes before / after the row, which are the previous /
 // next row, the end of the luma plane, or the slack every frame allocation ends with (e264hip_frame_alloc).
-template <int K> E264_DEV void dk_fetch4(const DkSrc &S, const DkRole &R0, int x0, int wm, v4u N[8])
+// (groups of 2, DK_GS == 2: FOUR loads, pieces k & 1 of row k >> 1; a chroma lane: piece = plane k & 1, both macroblocks)
+template <int K> E264_DEV void dk_fetch4(const DkSrc &S, const DkRole &R0, int x0, int wm, v4u N[2 * DK_GS])
 {
 	DkRole R = R0;
 	R.chroma = dk_chroma<K>(R0);
 #ifdef E264_ABL_DBK_NOLOAD // timing ablation
-	if (R.slot_mul) { for (int k = 0; k < 8; k++) N[k] = (v4u){(uint32_t)x0, 1, 2, 3}; return; }
+	if (R.slot_mul) { for (int k = 0; k < 2 * DK_GS; k++) N[k] = (v4u){(uint32_t)x0, 1, 2, 3}; return; }
 #endif
 #pragma unroll
-	for (int k = 0; k < 8; k++) {
-		// first macroblock of the piece: luma piece k & 3; chroma piece (k & 1) = two macroblocks
-		const int mb = R.chroma ? min(max(x0 + 2 * (k & 1), -1), wm - 1) : min(max(x0 + (k & 3), 0), wm - 1);
-		const int plane_off = R.chroma ? (k >> 1 & 1) * S.e1 : 0;
-		N[k] = *(const gv4u *)(S.base + mb * R.slot_mul + plane_off + (k >> 2) * S.d2);
+	for (int k = 0; k < 2 * DK_GS; k++) {
+		// first macroblock of the piece: luma piece i = k % GS; chroma piece i % (GS / 2) = two macroblocks of plane i / (GS / 2)
+		const int i = k & (DK_GS - 1);
+		const int mb = R.chroma ? min(max(x0 + 2 * (i & (DK_GS / 2 - 1)), -1), wm - 1) : min(max(x0 + i, 0), wm - 1);
+		const int plane_off = R.chroma ? (i / (DK_GS / 2)) * S.e1 : 0;
+		N[k] = *(const gv4u *)(S.base + mb * R.slot_mul + plane_off + (k >> DK_LG) * S.d2);
 	}
 }
 // the registers of macroblock x0 + k out of a fetched group: a = the lane's first row (luma: 16 bytes; chroma: Cb 8 bytes, Cr 8
 // bytes), b = its second row
-template <int K> E264_DEV void dk_pick(const v4u N[8], const DkRole &R0, int k, v4u &a, v4u &b)
+template <int K> E264_DEV void dk_pick(const v4u N[2 * DK_GS], const DkRole &R0, int k, v4u &a, v4u &b)
 {
 	DkRole R = R0;
 	R.chroma = dk_chroma<K>(R0);
 #pragma unroll
 	for (int row = 0; row < 2; row++) {
-		const v4u *L = N + 4 * row;
+		const v4u *L = N + DK_GS * row;
 		const v4u lu = L[k];                        // luma: piece k
-		const v4u cb = L[k >> 1], cr = L[2 + (k >> 1)]; // chroma: half (k & 1) of the plane's piece k >> 1
+		const v4u cb = L[k >> 1], cr = L[DK_GS / 2 + (k >> 1)]; // chroma: half (k & 1) of the plane's piece k >> 1
 		v4u ch;
 		if (k & 1) { ch.x = cb.z; ch.y = cb.w; ch.z = cr.z; ch.w = cr.w; }
 		else { ch.x = cb.x; ch.y = cb.y; ch.z = cr.x; ch.w = cr.y; }
@@ -315,8 +328,8 @@ template <int K> E264_DEV void dk_vpass(DkWaveT<K> &W, const DkPrm &P, const DkR
 {
 	uint8_t *W8 = (uint8_t *)&W;
 	const bool chroma = dk_chroma<K>(R);
-	const int own = R.rowa + (x & 7) * R.slot_mul;
-	const int prev = R.rowa + ((x - 1) & 7) * R.slot_mul + R.slot_mul - 4; // the left neighbour's last 4 bytes (garbage at x = 0: its bS is 0)
+	const int own = R.rowa + (x & (DK_SLOTS - 1)) * R.slot_mul;
+	const int prev = R.rowa + ((x - 1) & (DK_SLOTS - 1)) * R.slot_mul + R.slot_mul - 4; // the left neighbour's last 4 bytes (garbage at x = 0: its bS is 0)
 	const uint32_t La = *(const uint32_t *)(W8 + prev), Lb = *(const uint32_t *)(W8 + prev + DK_STRIDE);
 	const uint32_t Ca = *(const uint32_t *)(W8 + prev + R.cr_off), Cb = *(const uint32_t *)(W8 + prev + R.cr_off + DK_STRIDE);
 	// the line as 5 dwords.  Chroma: {Cb left, Cb 0..3, Cb 4,5 | Cr left 6,7, Cr 0..3, Cr 4..7}
@@ -358,7 +371,7 @@ E264_DEV int dk_haddr(int bT, int bO, int bT2, int bO2, int k)
 template <int K> E264_DEV void dk_hpass(DkWaveT<K> &W, const DkPrm &P, const DkRole &R, int x)
 {
 	uint8_t *W8 = (uint8_t *)&W;
-	const int sl = (x & 7) * R.slot_mul;
+	const int sl = (x & (DK_SLOTS - 1)) * R.slot_mul;
 	const int bT = R.hT + sl, bO = R.hO + sl, bT2 = R.hT2 + sl, bO2 = R.hO2 + sl;
 	s16x2 v[20];
 #pragma unroll
@@ -376,28 +389,28 @@ template <int K> E264_DEV void dk_hpass(DkWaveT<K> &W, const DkPrm &P, const DkR
 template <int K> E264_DEV void dk_flush(const DkWaveT<K> &W, const FrameCtx &f, const DkRole &R, int q, int y)
 {
 	typedef DkGeom<K> G;
-	const int s0 = (q * 4) & 7, x0 = q * 4;
+	const int s0 = (q * DK_GS) & (DK_SLOTS - 1), x0 = q * DK_GS;
 #ifdef E264_ABL_DBK_NOSTORE // timing ablation
 	if (f.wm > 0) return;
 #endif
 	if (G::LUMA) {
 #pragma unroll
-		for (int it = 0; it < (64 + G::LANES - 1) / G::LANES; it++) { // luma: 16 rows x 4 pieces of 16 bytes, dealt to the row's lanes
-			const int idx = it * G::LANES + R.r, row = min(idx >> 2, 15), m = idx & 3;
+		for (int it = 0; it < (16 * DK_GS + G::LANES - 1) / G::LANES; it++) { // luma: 16 rows x 4 (2) pieces of 16 bytes, dealt to the row's lanes
+			const int idx = it * G::LANES + R.r, row = min(idx >> DK_LG, 15), m = idx & (DK_GS - 1);
 			const v4u val = *(const v4u *)&W.y[G::LUMA ? R.g : 0][row][(s0 + m) * 16];
-			if (idx < 64 && x0 + m < f.wm)
+			if (idx < 16 * DK_GS && x0 + m < f.wm)
 				DK_STORE4((gv4u *)(f.cur + (size_t)(y * 16 + row) * f.sY + (x0 + m) * 16), val);
 		}
 	}
 	if (G::CHROMA) {
 #pragma unroll
-		for (int it = 0; it < (32 + G::LANES - 1) / G::LANES; it++) { // chroma: 2 planes x 8 rows x 2 pieces of 16 bytes (two macroblocks each)
-			const int idx = it * G::LANES + R.r, pl = min(idx >> 4, 1), row = idx >> 1 & 7, h = idx & 1;
+		for (int it = 0; it < (8 * DK_GS + G::LANES - 1) / G::LANES; it++) { // chroma: 2 planes x 8 rows x 2 (1) pieces of 16 bytes (two macroblocks each)
+			const int idx = it * G::LANES + R.r, pl = min(idx / (4 * DK_GS), 1), row = idx / (DK_GS / 2) & 7, h = idx & (DK_GS / 2 - 1);
 			const v4u val = *(const v4u *)&W.c[G::CHROMA ? R.g : 0][row][pl * DK_CR + (s0 + 2 * h) * 8];
 			const int n = f.wm - (x0 + 2 * h);
 			gu8 *dst = plane_base(f, f.cur, 1 + pl) + (size_t)(y * 8 + row) * f.sC + (x0 + 2 * h) * 8;
-			if (idx < 32 && n >= 2) DK_STORE4((gv4u *)dst, val);
-			else if (idx < 32 && n == 1) *(gv2u *)dst = (v2u){val.x, val.y};
+			if (idx < 8 * DK_GS && n >= 2) DK_STORE4((gv4u *)dst, val);
+			else if (idx < 8 * DK_GS && n == 1) *(gv2u *)dst = (v2u){val.x, val.y};
 		}
 	}
 }
@@ -410,18 +423,18 @@ template <int K> E264_DEV DkTopAddr dk_top_addr(const FrameCtx &f, int lane, int
 {
 	typedef DkWaveT<K> DkWave;
 	DkTopAddr t;
-	const int s0 = (q * 4) & 7, x0 = q * 4;
-	const int nl = K == 1 ? 0 : 16; // luma pieces come first
+	const int s0 = (q * DK_GS) & (DK_SLOTS - 1), x0 = q * DK_GS;
+	const int nl = K == 1 ? 0 : 4 * DK_GS; // luma pieces come first: 4 rows x the group's macroblocks
 	if (lane < nl) {
-		const int row = lane >> 2, m = lane & 3;
+		const int row = lane >> DK_LG, m = lane & (DK_GS - 1);
 		t.lds = (int)offsetof(DkWave, ty) + row * DK_STRIDE + (s0 + m) * 16;
 		t.mem = f.cur + (size_t)(y0 * 16 - 4 + row) * f.sY + (x0 + m) * 16;
 		t.n = x0 + m < f.wm ? 2 : 0;
 	} else {
-		const int i = lane - nl, pl = i >> 2 & 1, row = i >> 1 & 1, h = i & 1;
+		const int i = lane - nl, pl = i / DK_GS & 1, row = i / (DK_GS / 2) & 1, h = i & (DK_GS / 2 - 1); // 2 planes x 2 rows x pieces of two macroblocks
 		t.lds = (int)offsetof(DkWave, tc) + row * DK_STRIDE + pl * DK_CR + (s0 + 2 * h) * 8;
 		t.mem = plane_base(f, f.cur, 1 + pl) + (size_t)(y0 * 8 - 2 + row) * f.sC + (x0 + 2 * h) * 8;
-		t.n = (K != 0 && i < 8) ? min(max(f.wm - (x0 + 2 * h), 0), 2) : 0;
+		t.n = (K != 0 && i < 2 * DK_GS) ? min(max(f.wm - (x0 + 2 * h), 0), 2) : 0;
 	}
 	return t;
 }
@@ -457,9 +470,9 @@ struct DkPlan {
 	int flush, top_flush;                 // group to write out before the V phase, -1: none
 	bool publish;                         // (wave-uniform) the groups written at the top of this step are announced at its end
 };
-E264_DEV int dk_groups(int wm) { return (wm + 3) >> 2; }
+E264_DEV int dk_groups(int wm) { return (wm + DK_GS - 1) >> DK_LG; }
 // the last row of the wave (g = ROWS - 1) writes its last group at the top of step t0 + 1, t0 the first multiple of 4 with t0 - g >= 4 * groups
-template <int K> E264_DEV int dk_last_step(int wm) { return 4 * dk_groups(wm) + ((DkGeom<K>::ROWS - 1 + 3) & ~3) + 1; }
+template <int K> E264_DEV int dk_last_step(int wm) { return DK_GS * dk_groups(wm) + ((DkGeom<K>::ROWS - 1 + DK_GS - 1) & ~(DK_GS - 1)) + 1; }
 E264_DEV DkPlan dk_plan(int t, const DkRole &R, bool row_ok, bool top, int wm)
 {
 	DkPlan p;
@@ -468,23 +481,25 @@ E264_DEV DkPlan dk_plan(int t, const DkRole &R, bool row_ok, bool top, int wm)
 	p.act = row_ok && p.x >= 0 && p.x < wm;
 	p.prm_commit = row_ok && p.x + 1 >= 0 && p.x + 1 < wm;
 	p.prm_fetch = row_ok && p.x + 3 >= 0 && p.x + 3 < wm;
-	p.grp_fetch = (t & 3) == 0 && row_ok && p.x + 5 >= 0 && p.x + 2 < wm;
-	// the wave's first row filters group Q's first macroblock at t = 4Q: fetched at t = 4Q - 2, committed at t = 4Q - 1
-	p.top_fetch = (top && ((t + 2) & 3) == 0 && (t + 2) >> 2 < nq) ? (t + 2) >> 2 : -1;
-	p.top_commit = (top && ((t + 1) & 3) == 0 && (t + 1) >> 2 < nq) ? (t + 1) >> 2 : -1;
+	p.grp_fetch = (t & (DK_GS - 1)) == 0 && row_ok && p.x + 1 + DK_GS >= 0 && p.x + 2 < wm;
+	// the wave's first row filters group Q's first macroblock at t = 4Q: fetched at t = 4Q - 2, committed at t = 4Q - 1 (groups of 2: 2Q ...)
+	p.top_fetch = (top && ((t + 2) & (DK_GS - 1)) == 0 && (t + 2) >> DK_LG < nq) ? (t + 2) >> DK_LG : -1;
+	// (groups of 2: committed at the top of step 2Q itself -- the top strip has four slots, group Q - 2 leaves them at the top of step 2Q - 1)
+	const int tc = t + (DK_GS == 4 ? 1 : 0);
+	p.top_commit = (top && (tc & (DK_GS - 1)) == 0 && tc >> DK_LG < nq) ? tc >> DK_LG : -1;
 	// after step t0 (a multiple of 4) macroblocks 0 .. t0-g-1 of row g are final, rows 13..15 included (the row below has
 	// passed them); whole groups: up to ((t0 - g) >> 2) - 1 (t0/4 - 1 for the first row, t0/4 - 2 for rows 1..4, ...).  They are
 	// written at the TOP of step t0 + 1 (their strip slots are reused in that step's V phase at the earliest) and announced at its
 	// END: the stores then had a whole step to drain and the release fence does not wait for them.
 	const int t0 = t - 1;
-	p.publish = (t0 & 3) == 0 && t0 >= 4;
-	const int qf = ((t0 - R.g) >> 2) - 1;
+	p.publish = (t0 & (DK_GS - 1)) == 0 && t0 >= DK_GS;
+	const int qf = ((t0 - R.g) >> DK_LG) - 1;
 	p.flush = (p.publish && row_ok && qf >= 0 && qf < nq) ? qf : -1;
-	p.top_flush = (p.publish && top && (t0 >> 2) - 1 < nq) ? (t0 >> 2) - 1 : -1;
+	p.top_flush = (p.publish && top && (t0 >> DK_LG) - 1 < nq) ? (t0 >> DK_LG) - 1 : -1;
 	return p;
 }
 // macroblocks of row g that have left for memory with the flush of step t (a publishing step)
-E264_DEV int dk_progress(int t, int g, int wm) { return min(max(((t - 1 - g) >> 2) * 4, 0), wm); }
+E264_DEV int dk_progress(int t, int g, int wm) { return min(max(((t - 1 - g) >> DK_LG) * DK_GS, 0), wm); }
 
 } // namespace
 #endif

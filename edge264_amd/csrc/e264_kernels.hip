@@ -188,10 +188,11 @@ static __device__ __forceinline__ void dk_walk_group(DkWaveT<K> &W, const FrameC
 	if (blockIdx.x == 0 && lane == 0 && tl_slot < 64) g_timeline[2 * tl_slot] = __builtin_amdgcn_s_memtime();
 #endif
 	v4u p0 = {0, 0, 0, 0}, p1 = p0, tt = p0;
-	v4u N[8];               // samples of four macroblocks of the lane's two rows (dk_fetch4), requested at steps t = 0 mod 4
-	v4u K2a = p0, K2b = p0, K3a = p0, K3b = p0; // the last two of them, kept while the next group is on its way
+	v4u N[2 * DK_GS];       // samples of four (two) macroblocks of the lane's two rows (dk_fetch4), requested at steps t = 0 mod 4 (2)
+	v4u K2a = p0, K2b = p0, K3a = p0, K3b = p0; // the last two (groups of 2: K3, the last one) of them, kept while the next group is on its way
 	PH_DECL;
 	// one step; k = (t + 2) & 3: which macroblock of its group the step filters (k = 2, 3: of the group before, out of K2 / K3);
+	// groups of 2: k = t & 1, k = 1 out of K3, the step with k = 0 requests the next group;
 	// sp: the parameter register set of this step's parity (parameters of x+1, requested two steps ago)
 	auto step = [&](const int t, const int k, v4u &sp) __attribute__((always_inline)) {
 		const DkPlan p = dk_plan(t, R, row_ok, top, wm);
@@ -200,15 +201,21 @@ static __device__ __forceinline__ void dk_walk_group(DkWaveT<K> &W, const FrameC
 		if (p.top_commit >= 0) dk_top_commit<K>(W, f, lane, p.top_commit, y0, tt);
 		if (p.prm_commit) dk_commit_prm(W, R, p.x + 1, sp);
 		v4u ra, rb;
-		if (k < 2) dk_pick<K>(N, R, k, ra, rb);
-		else { ra = k == 2 ? K2a : K3a; rb = k == 2 ? K2b : K3b; }
-		if (k == 1) { dk_pick<K>(N, R, 2, K2a, K2b); dk_pick<K>(N, R, 3, K3a, K3b); } // N is overwritten in the next step
-		asm volatile("" :: "v"(ra), "v"(rb), "v"(K2a), "v"(K2b), "v"(K3a), "v"(K3b)); // the copies happen here
+		if (DK_GS == 4) {
+			if (k < 2) dk_pick<K>(N, R, k, ra, rb);
+			else { ra = k == 2 ? K2a : K3a; rb = k == 2 ? K2b : K3b; }
+			if (k == 1) { dk_pick<K>(N, R, 2, K2a, K2b); dk_pick<K>(N, R, 3, K3a, K3b); } // N is overwritten in the next step
+			asm volatile("" :: "v"(ra), "v"(rb), "v"(K2a), "v"(K2b), "v"(K3a), "v"(K3b)); // the copies happen here
+		} else {
+			if (k == 0) { dk_pick<K>(N, R, 0, ra, rb); dk_pick<K>(N, R, 1, K3a, K3b); } // N is overwritten further down in this step
+			else { ra = K3a; rb = K3b; }
+			asm volatile("" :: "v"(ra), "v"(rb), "v"(K3a), "v"(K3b));
+		}
 		if (p.flush >= 0) dk_flush<K>(W, f, R, p.flush, y);
 		if (p.top_flush >= 0) dk_top_flush<K>(W, f, lane, p.top_flush, y0);
 		PH(0);
 		if (p.top_fetch >= 0) { // (wave-uniform) the rows above this group of 4 must have reached memory
-			const int need = min(p.top_fetch * 4 + 4, wm);
+			const int need = min(p.top_fetch * DK_GS + DK_GS, wm);
 #ifndef E264_ABL_DBK_NOWAIT // timing ablation: the group above is not waited for (wrong samples along the seams): what the hand-off lag costs
 			while (lds_load_relaxed(&progress[q - 1]) < need)
 				__builtin_amdgcn_s_sleep(1);
@@ -218,7 +225,7 @@ static __device__ __forceinline__ void dk_walk_group(DkWaveT<K> &W, const FrameC
 		}
 		PH(1);
 		if (p.prm_fetch) dk_fetch_prm(f, R, p.x + 3, y, sp);
-		if (k == 2 && p.grp_fetch) dk_fetch4<K>(src, R, p.x + 2, wm, N);
+		if (k == (DK_GS == 4 ? 2 : 0) && p.grp_fetch) dk_fetch4<K>(src, R, p.x + 2, wm, N);
 		wave_sync();
 		PH(2);
 		DkPrm P[2];
@@ -241,11 +248,16 @@ static __device__ __forceinline__ void dk_walk_group(DkWaveT<K> &W, const FrameC
 		PH(6);
 	};
 #pragma unroll 1
-	for (int t = DK_FIRST_STEP; t <= last_step; t += 4) { // unrolled by four: a group of four macroblocks per fetch, registers by name
-		step(t, 2, p0);
-		step(t + 1, 3, p1);
-		step(t + 2, 0, p0);
-		step(t + 3, 1, p1);
+	for (int t = DK_FIRST_STEP; t <= last_step; t += DK_GS) { // unrolled by four (two): a group of macroblocks per fetch, registers by name
+		if (DK_GS == 4) {
+			step(t, 2, p0);
+			step(t + 1, 3, p1);
+			step(t + 2, 0, p0);
+			step(t + 3, 1, p1);
+		} else {
+			step(t, 0, p0);
+			step(t + 1, 1, p1);
+		}
 	}
 #if defined(E264_PHASE_TIMING) || defined(E264_DBK_TIMELINE)
 	if (blockIdx.x == 0 && lane == 0 && tl_slot < 64) g_timeline[2 * tl_slot + 1] = __builtin_amdgcn_s_memtime();
@@ -431,6 +443,12 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 	if (side) hipStreamWaitEvent(stream, fork->joined, 0);
 	if (mode & 2) {
 		switch (waves) { // waves per picture (default 8, set by the back end); 100 + n: luma / chroma waves (e264_deblock2_kernel)
+#if E264_DBK_GS == 2 // strips of four macroblocks: 12.6 KB of LDS per wave, twelve waves (three per SIMD) fit the CU
+		case 112: hipLaunchKernelGGL(e264_deblock2_kernel<12>, dim3(n_jobs), dim3(768), 0, stream, jobs); break;
+		case 110: hipLaunchKernelGGL(e264_deblock2_kernel<10>, dim3(n_jobs), dim3(640), 0, stream, jobs); break;
+#else
+		case 112: case 110:
+#endif
 		case 108: hipLaunchKernelGGL(e264_deblock2_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs); break;
 		case 107: hipLaunchKernelGGL(e264_deblock2_kernel<7>, dim3(n_jobs), dim3(448), 0, stream, jobs); break;
 		case 106: hipLaunchKernelGGL(e264_deblock2_kernel<6>, dim3(n_jobs), dim3(384), 0, stream, jobs); break;

@@ -72,26 +72,29 @@ static void emu_walk_group(const FrameCtx &f, const uint8_t *tc0tab, int q)
 	memset(&W, 0xA5, sizeof(W));
 	const int y0 = q * G::ROWS;
 	const bool top = q > 0;
-	static v4u N[64][8], K2a[64], K2b[64], K3a[64], K3b[64], np[2][64], tt[64], ra[64], rb[64];
+	static v4u N[64][2 * DK_GS], K2a[64], K2b[64], K3a[64], K3b[64], np[2][64], tt[64], ra[64], rb[64];
 	memset(N, 0x5A, sizeof(N)); memset(K2a, 0x5A, sizeof(K2a)); memset(K2b, 0x5A, sizeof(K2b)); memset(K3a, 0x5A, sizeof(K3a)); memset(K3b, 0x5A, sizeof(K3b));
 	memset(np, 0x5A, sizeof(np)); memset(tt, 0x5A, sizeof(tt));
-	for (int t4 = DK_FIRST_STEP; t4 <= dk_last_step<K>(f.wm); t4 += 4) // (the kernel's loop: whole groups of four steps)
-	for (int t = t4; t < t4 + 4; t++) {
-		const int par = t & 1, k = (t + 2) & 3; // the parameter register set of this step; which macroblock of its group it filters
+	for (int t4 = DK_FIRST_STEP; t4 <= dk_last_step<K>(f.wm); t4 += DK_GS) // (the kernel's loop: whole groups of four (two) steps)
+	for (int t = t4; t < t4 + DK_GS; t++) {
+		const int par = t & 1, k = (t + 2) & (DK_GS - 1); // the parameter register set of this step; which macroblock of its group it filters
 		DkPlan p[64];
 		for (int lane = 0; lane < 64; lane++) {
 			const int y = y0 + R[lane].g;
 			p[lane] = dk_plan(t, R[lane], !R[lane].idle && y < f.hm, top, f.wm);
 			if (p[lane].top_commit >= 0) dk_top_commit<K>(W, f, lane, p[lane].top_commit, y0, tt[lane]);
 			if (p[lane].prm_commit) dk_commit_prm(W, R[lane], p[lane].x + 1, np[par][lane]);
-			if (k < 2) dk_pick<K>(N[lane], R[lane], k, ra[lane], rb[lane]);
-			else { ra[lane] = k == 2 ? K2a[lane] : K3a[lane]; rb[lane] = k == 2 ? K2b[lane] : K3b[lane]; }
-			if (k == 1) { dk_pick<K>(N[lane], R[lane], 2, K2a[lane], K2b[lane]); dk_pick<K>(N[lane], R[lane], 3, K3a[lane], K3b[lane]); }
+			if (DK_GS == 4) {
+				if (k < 2) dk_pick<K>(N[lane], R[lane], k, ra[lane], rb[lane]);
+				else { ra[lane] = k == 2 ? K2a[lane] : K3a[lane]; rb[lane] = k == 2 ? K2b[lane] : K3b[lane]; }
+				if (k == 1) { dk_pick<K>(N[lane], R[lane], 2, K2a[lane], K2b[lane]); dk_pick<K>(N[lane], R[lane], 3, K3a[lane], K3b[lane]); }
+			} else if (k == 0) { dk_pick<K>(N[lane], R[lane], 0, ra[lane], rb[lane]); dk_pick<K>(N[lane], R[lane], 1, K3a[lane], K3b[lane]); }
+			else { ra[lane] = K3a[lane]; rb[lane] = K3b[lane]; }
 			if (p[lane].flush >= 0) dk_flush<K>(W, f, R[lane], p[lane].flush, y);
 			if (p[lane].top_flush >= 0) dk_top_flush<K>(W, f, lane, p[lane].top_flush, y0);
 			if (p[lane].top_fetch >= 0) dk_top_fetch<K>(f, lane, p[lane].top_fetch, y0, tt[lane]);
 			if (p[lane].prm_fetch) dk_fetch_prm(f, R[lane], p[lane].x + 3, y, np[par][lane]);
-			if (k == 2 && p[lane].grp_fetch) dk_fetch4<K>(dk_src<K>(f, R[lane], y), R[lane], p[lane].x + 2, f.wm, N[lane]);
+			if (k == (DK_GS == 4 ? 2 : 0) && p[lane].grp_fetch) dk_fetch4<K>(dk_src<K>(f, R[lane], y), R[lane], p[lane].x + 2, f.wm, N[lane]);
 		}
 		static DkPrm P[64][2];
 		for (int lane = 0; lane < 64; lane++)

@@ -15,16 +15,22 @@ from oracle.pyoracle import Oracle, _dpb_array
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.fixture(scope="module")
-def emu():
+def _load(name):
     d = os.path.join(HERE, "emu")
     subprocess.run(["make", "-C", d], check=True, stdout=subprocess.DEVNULL)
-    lib = C.CDLL(os.path.join(d, "libe264_pred_emu.so"))
+    lib = C.CDLL(os.path.join(d, name))
     lib.e264emu_dbkparam_frame.argtypes = [C.c_char_p, C.c_void_p]
     lib.e264emu_dbkparam_frame.restype = C.c_int
     lib.e264emu_deblock_frame2.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.e264emu_deblock_frame2.restype = C.c_int
     return lib
+
+
+@pytest.fixture(scope="module", params=["groups_of_4", "groups_of_2"])
+def emu(request):
+    """the product build (strips of eight macroblocks, fetch / flush groups of four) and -DE264_DBK_GS=2 (strips of four: the
+    twelve-wave variant measured in round 5, profiles/r05_ablations.txt item 1)"""
+    return _load("libe264_pred_emu.so" if request.param == "groups_of_4" else "libe264_pred_emu_gs2.so")
 
 
 CASES = [
