@@ -85,6 +85,13 @@ template <int K> struct __attribute__((aligned(16))) DkWaveT { // (the members a
 #define DK_ANY(x) __any((x) != 0)
 #endif
 
+// Where p0 + delta / q0 - delta are clipped to 0..255 (round 5): 1 = in the pack back to bytes (v_sat_pk_u8_i16 on the eight p0 / q0 registers of a
+// line pair; no later edge reads them before: the next edge's p3 is only looked at by the bS 4 luma filter, which exists on edge 0 alone), 0 = in
+// dk_edge with a packed max + min per value (rounds 2 - 4).
+#ifndef E264_DBK_SATPACK
+#define E264_DBK_SATPACK 1
+#endif
+E264_DEV bool dk_is_p0q0(int k) { return k >= 3 && k <= 16 && ((k & 3) == 3 || (k & 3) == 0); } // v[4e + 3], v[4e + 4]
 E264_DEV uint32_t dk_bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); } // v_bfi_b32
 E264_DEV s16x2 dk_dup(uint32_t x) { return as_s2(x | x << 16); }
 E264_DEV s16x2 dk_sel(s16x2 mask, s16x2 a, s16x2 b) { return as_s2(dk_bfi(as_u(mask), as_u(a), as_u(b))); }
@@ -167,7 +174,11 @@ E264_DEV void dk_edge(s16x2 *v, s16x2 alphaE, s16x2 beta, s16x2 betal, s16x2 tc0
 	const s16x2 z = {0, 0}, m255 = {255, 255};
 	const s16x2 dp1 = LUMA ? dk_clip((p2 + avg - p1 * (short)2) >> 1, -tc0, tc0) & ap : zero2; // tc0 is 0 on bS 4 lines: p1 stays
 	const s16x2 dq1 = LUMA ? dk_clip((q2 + avg - q1 * (short)2) >> 1, -tc0, tc0) & aq : zero2;
+#if E264_DBK_SATPACK // p0 / q0 leave the edge unclipped (-27 .. 282): the pack back to bytes saturates them (dk_vpass / dk_hpass), 4 instructions per edge fewer
+	s16x2 np0 = p0 + delta, nq0 = q0 - delta;
+#else
 	s16x2 np0 = dk_clip(p0 + delta, z, m255), nq0 = dk_clip(q0 - delta, z, m255);
+#endif
 	s16x2 np1 = p1 + dp1, nq1 = q1 + dq1;
 	if (STRONG) {
 		const s16x2 S = strong & go;
@@ -342,7 +353,12 @@ template <int K> E264_DEV void dk_vpass(DkWaveT<K> &W, const DkPrm &P, const DkR
 	dk_filter<K>(v, P, R);
 #pragma unroll
 	for (int d = 0; d < 5; d++) {
+#if E264_DBK_SATPACK // v[4d] (d >= 1) and v[4d + 3] (d <= 3) are a q0 / p0: saturated to two bytes first, picked up from bytes 0, 1
+		const uint32_t t01 = d >= 1 ? v_perm(as_u(v[4 * d + 1]), v_sat_pk_u8_i16(as_u(v[4 * d])), 0x06010400u) : v_perm(as_u(v[4 * d + 1]), as_u(v[4 * d]), 0x06020400u);
+		const uint32_t t23 = d <= 3 ? v_perm(v_sat_pk_u8_i16(as_u(v[4 * d + 3])), as_u(v[4 * d + 2]), 0x05020400u) : v_perm(as_u(v[4 * d + 3]), as_u(v[4 * d + 2]), 0x06020400u);
+#else
 		const uint32_t t01 = v_perm(as_u(v[4 * d + 1]), as_u(v[4 * d]), 0x06020400u), t23 = v_perm(as_u(v[4 * d + 3]), as_u(v[4 * d + 2]), 0x06020400u);
+#endif
 		A[d] = v_perm(t23, t01, 0x05040100u);
 		B[d] = v_perm(t23, t01, 0x07060302u);
 	}
@@ -380,7 +396,7 @@ template <int K> E264_DEV void dk_hpass(DkWaveT<K> &W, const DkPrm &P, const DkR
 	dk_filter<K>(v, P, R);
 #pragma unroll
 	for (int k = 1; k < 19; k++)
-		*(uint16_t *)(W8 + dk_haddr(bT, bO, bT2, bO2, k)) = (uint16_t)v_perm(0, as_u(v[k]), 0x0c0c0200u);
+		*(uint16_t *)(W8 + dk_haddr(bT, bO, bT2, bO2, k)) = (uint16_t)((E264_DBK_SATPACK && dk_is_p0q0(k)) ? v_sat_pk_u8_i16(as_u(v[k])) : v_perm(0, as_u(v[k]), 0x0c0c0200u));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -139,5 +139,8 @@ extern "C" __attribute__((visibility("default"))) void e264emu_dk_filter(uint8_t
 	DkPrm P[2];
 	dk_params<2>(prm, tc0tab, R, P);
 	dk_filter<2>(v, P[dir], R);
-	for (int k = 0; k < 20; k++) { lines[k] = (uint8_t)v[k].x; lines[20 + k] = (uint8_t)v[k].y; }
+	for (int k = 0; k < 20; k++) { // (the pack back to bytes, as dk_vpass / dk_hpass do it: p0 / q0 may arrive unclipped, E264_DBK_SATPACK)
+		const uint32_t b = (E264_DBK_SATPACK && dk_is_p0q0(k)) ? v_sat_pk_u8_i16(as_u(v[k])) : v_perm(0, as_u(v[k]), 0x0c0c0200u);
+		lines[k] = (uint8_t)b; lines[20 + k] = (uint8_t)(b >> 8);
+	}
 }

@@ -17,5 +17,5 @@ for vw in $2; do
   v=${vw%%:*}; w=${vw##*:}
   lib=$REPO/edge264_amd/variants/libedge264_hip_$v.so
   [ $v = main ] && lib=$REPO/edge264_amd/libedge264_hip.so
-  E264_ALLOW_ABLATION=1 E264_HIP_LIB=$lib E264_WAVES=$w timeout 300 python bench.py --no-cpu-baseline --no-host-packets $BENCH_ARGS > $OUT/bench_${v}_$w.json 2> $OUT/bench_${v}_$w.err; summ $OUT/bench_${v}_$w.json ${v}_$w
+  E264_ALLOW_ABLATION=1 E264_HIP_LIB=$lib E264_WAVES=$w timeout ${BENCH_TIMEOUT:-120} python bench.py --no-cpu-baseline --no-host-packets $BENCH_ARGS > $OUT/bench_${v}_$w.json 2> $OUT/bench_${v}_$w.err; summ $OUT/bench_${v}_$w.json ${v}_$w
 done
