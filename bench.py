@@ -69,6 +69,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-host-packets", action="store_true", help="skip the PCIe-inclusive run (N=1)")
     ap.add_argument("--variants", type=int, default=int(os.environ.get("E264_VARIANTS", 4)), help="distinct synthetic GOPs (seeds 1234, 1235, ...): stream k decodes GOP k mod V, "
                     "so that the timed pictures and the verification are not copies of one GOP")
+    ap.add_argument("--no-system", action="store_true", help="skip the system leg (e264_multi: parser + emitters + GPU on the container's cores, N=1)")
     ap.add_argument("--no-same-input", action="store_true", help="skip the same-input leg (the 1080p bitstream fixtures on the GPU next to the CPU reference, N=1)")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("E264_LANES", 1)), help="compute lanes (HIP queues): the streams are split into this many "
                     "groups whose submissions overlap on the GPU")
@@ -161,7 +162,7 @@ def same_input_leg(dev, backend, n_streams, cpu):
     sdir = os.path.join(ROOT, "tests", "golden", "streams")
     files = ["hd1080_ipp30.264", "cabac_hd1080_ibbp30.264"]
     res = {"files": files, "streams": n_streams, "per_file": {}}
-    tot_frames = tot_res = tot_host = tot_parse = 0.0
+    tot_frames = tot_res = tot_host = tot_parse = tot_pictures = 0.0
     all_ok = True
     for name in files:
         with open(os.path.join(sdir, name), "rb") as f:
@@ -223,7 +224,7 @@ def same_input_leg(dev, backend, n_streams, cpu):
                                  "gpu_resident_frames_per_s": round(n / t_res, 1), "gpu_pcie_inclusive_frames_per_s": round(n / t_host, 1),
                                  "host_parse_emit_frames_per_s_one_core": round(len(packets) / parse_s, 1),
                                  "pictures_compared": len(packets) * len(probe), "mismatching": bad}
-        tot_frames += n; tot_res += t_res; tot_host += t_host; tot_parse += parse_s
+        tot_frames += n; tot_res += t_res; tot_host += t_host; tot_parse += parse_s; tot_pictures += len(packets)
         for b in bs:
             dev.free_batch(b)
         for row in dpk:
@@ -232,7 +233,7 @@ def same_input_leg(dev, backend, n_streams, cpu):
         for st in sts:
             st.close()
     res.update({"gpu_resident_frames_per_s": round(tot_frames / tot_res, 1), "gpu_pcie_inclusive_frames_per_s": round(tot_frames / tot_host, 1),
-                "host_parse_emit_frames_per_s_one_core": round(60 / tot_parse, 1) if tot_parse else None, "bit_exact": bool(all_ok),
+                "host_parse_emit_frames_per_s_one_core": round(tot_pictures / tot_parse, 1) if tot_parse else None, "bit_exact": bool(all_ok),
                 "what": "both sides decode the SAME two files: GPU = their command packets (reference parser + emitters, parsed in this process) decoded by "
                         f"{n_streams} concurrent decoders, packets resident in HBM / pageable host packets with validation + H2D inside the timed region; "
                         "CPU = the unmodified reference decoder on these files (cpu_baseline, same run).  The parser itself is host work on both sides: "
@@ -242,6 +243,53 @@ def same_input_leg(dev, backend, n_streams, cpu):
         res["cpu_cores"] = cpu["cores"]
         res["gpu_resident_vs_cpu_all_cores"] = round(res["gpu_resident_frames_per_s"] / cpu["value"], 2)
         res["gpu_pcie_inclusive_vs_cpu_all_cores"] = round(res["gpu_pcie_inclusive_frames_per_s"] / cpu["value"], 2)
+    return res
+
+
+def system_leg(cpu, seconds=6.0):
+    """SYSTEM level (the shape of the reference's own whole-decoder clock, /root/reference/src/edge264_test.c:482-542): Annex-B bytes in, decoded
+    pictures in HBM out, with the reference's parser + our emitters on the host cores INSIDE the clock: edge264_amd/e264_multi, 128 decoders
+    (64 x the two 1080p fixtures `cpu_baseline` decodes), threads = the container's cores - 1 (one is left to the submitter and the back
+    end's threads), packets assembled in page-locked memory and submitted in place, no read-back.  Two runs: parser + emitters alone
+    (packets dropped: what the host delivers) and end to end (the same with the GPU behind it)."""
+    from oracle.cpu_baseline import FIXTURES_1080P, STREAMS, cpu_quota, physical_cores  # (host-side helpers only: which cores, which files)
+    exe = os.path.join(ROOT, "edge264_amd", "e264_multi")
+    front = os.path.join(ROOT, "edge264_amd", "libedge264_hipfront.so")
+    hip = os.path.join(ROOT, "edge264_amd", "libedge264_hip.so")
+    for f in (exe, front, hip):
+        if not os.path.exists(f):
+            return {"unavailable": f"{os.path.relpath(f, ROOT)} is not built"}
+    quota = cpu_quota()
+    cores = len(physical_cores()) if quota is None else max(1, min(len(physical_cores()), int(quota)))
+    threads = max(1, cores - 1)
+    files = [os.path.join(STREAMS, n) for n in FIXTURES_1080P]
+    res = {"streams": 128, "threads": threads, "cores": cores, "files": list(FIXTURES_1080P)}
+    for key, flag in (("parse_only", "--parse-only"), ("end_to_end", "--no-download")):
+        loops = 2
+        out = None
+        for _ in range(3):  # a short run sizes the long one: ~`seconds` of wall clock each
+            cmd = [exe, "--front", front, "--hip", hip, flag, "--threads", str(threads), "--repeat", "64", "--loops", str(loops)] + files
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
+            if r.returncode != 0 or line is None:
+                return {**res, "unavailable": f"e264_multi {flag}: rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+            out = json.loads(line)
+            if out["seconds"] >= 0.6 * seconds:
+                break
+            loops = max(loops + 1, int(loops * seconds / max(out["seconds"], 0.05)))
+        res[key] = {"frames_per_s": out["frames_per_s"], "frames": out["frames"], "seconds": out["seconds"], "loops": loops,
+                    "decode_ms_per_picture": out.get("decode_ms_per_picture"), "avg_batch": out.get("avg_batch"),
+                    "thread_seconds": out.get("thread_seconds")}
+    po, ee = res["parse_only"], res["end_to_end"]
+    res["end_to_end_vs_parse_only"] = round(ee["frames_per_s"] / po["frames_per_s"], 3)
+    if ee.get("decode_ms_per_picture"):
+        res["host_cores_for_1000_streams_1080p30"] = round(30000.0 * ee["decode_ms_per_picture"] / 1e3, 1)
+    if cpu and cpu.get("value"):
+        res["cpu_reference_frames_per_s"] = cpu["value"]
+        res["vs_cpu_reference_same_cores"] = round(ee["frames_per_s"] / cpu["value"], 2)
+    res["what"] = ("whole decoder, host included: Annex-B bytes -> reference parser + emitters on `threads` host threads -> page-locked packets submitted in place "
+                   "-> 4 kernels per batch -> pictures in HBM (no read-back); `parse_only` = the same host work with the packets dropped.  The device rates of "
+                   "`value` / `same_input` need ~30000 x decode_ms_per_picture / 1000 parsing cores per GPU at 1000 x 1080p30")
     return res
 
 
@@ -278,7 +326,23 @@ def main() -> int:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=tdev)
 
     # host side of this rank next to its GPU: before the back end creates its threads
+    launcher_affinity = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     numa = {"numa_node": -1, "bound": False, "cpus": 0} if (stub or args.no_numa_bind) else bind_rank_to_gpu_socket(local_rank)
+
+    class launcher_cpus:
+        """The CPU legs (cpu_baseline, system) run on the cores the LAUNCHER granted, not on the GPU's NUMA node this rank bound itself to:
+        'all cores' must mean the host's (on a two-socket box the baseline was taken on half the machine and the GPU / CPU ratio
+        was inflated).  The binding comes back afterwards."""
+        def __enter__(self):
+            self.bound = os.sched_getaffinity(0) if launcher_affinity is not None else None
+            if launcher_affinity is not None and self.bound != launcher_affinity:
+                os.sched_setaffinity(0, launcher_affinity)
+            return self
+
+        def __exit__(self, *exc):
+            if self.bound is not None and self.bound != launcher_affinity:
+                os.sched_setaffinity(0, self.bound)
+            return False
 
     from edge264_amd import packet as P, synth
 
@@ -423,7 +487,9 @@ def main() -> int:
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not stub:
         try:
             from oracle.cpu_baseline import reference_decoder_baseline
-            cpu = reference_decoder_baseline(min(args.cpu_seconds, 6.0), args.cpu_seconds)
+            with launcher_cpus():
+                cpu = reference_decoder_baseline(min(args.cpu_seconds, 6.0), args.cpu_seconds)
+            cpu["affinity"] = "the launcher's (not the GPU's NUMA node the rank is bound to)"
         except (OSError, FileNotFoundError) as e:
             cpu = {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference", "sample": f"unavailable: {e}"}
         try:  # second figure (synthetic GOP only): the reference's own sample kernels (no entropy decoding) replaying the bench packets, one core
@@ -453,8 +519,10 @@ def main() -> int:
                  ("configs[3] IBBP, 8x8 transform, explicit weighted bi-prediction, scaling lists, deblocking", "IPBBPBBP", backend.RUN_ALL,
                   dict(t8x8=True, scaling=True, weighted=1, num_refs=2, residual_prob=0.3, i_kinds=ALL_I))]
         for label, gop2, mode2, kw in specs:
-            g2 = synth.StreamSynth(W, H, seed=4321, **kw)
-            pk2 = g2.gop(gop2)
+            vpk2 = [synth.StreamSynth(W, H, seed=4321 + v, **kw).gop(gop2) for v in range(V)]  # the same number of distinct GOPs as the headline
+            pk2 = vpk2[0]
+            for q2 in vpk2:
+                assert [int(P.Packet(q).hdr["dst_slot"]) for q in q2] == [int(P.Packet(q).hdr["dst_slot"]) for q in pk2]
             need = max(int(P.Packet(q).hdr["dst_slot"]) for q in pk2) + 1
             for st in streams:
                 for i in range(n_slots, need):
@@ -462,7 +530,7 @@ def main() -> int:
                 for i in range(need):
                     st.fill(i, 128)
             n_slots = max(n_slots, need)
-            d2 = [[dev.upload_packet(q) for q in pk2] for _ in streams]
+            d2 = [[dev.upload_packet(q) for q in vpk2[k % V]] for k in range(len(streams))]
             b2 = make_batches(d2)
 
             def step2():
@@ -480,24 +548,25 @@ def main() -> int:
             dev.kernel_timing(False)
             ok2, cmp2 = None, 0
             if not args.no_verify:  # one more GOP, untimed: EVERY stream, EVERY frame against the oracle (as the headline)
-                orc = Oracle()
+                orcs2 = [Oracle() for _ in range(V)]
                 nb = P.frame_bytes(W, H)
-                dpb = [np.full(nb + 16, 128, np.uint8) for _ in range(n_slots)] + [None] * (32 - n_slots)
+                dpbs2 = [[np.full(nb + 16, 128, np.uint8) for _ in range(n_slots)] + [None] * (32 - n_slots) for _ in range(V)]
                 for st in streams:
                     for i in range(need):
                         st.fill(i, 128)
                 bad2 = 0
                 for f, q in enumerate(pk2):
-                    orc.decode_frame(q, dpb, mode2)
+                    for v in range(V):
+                        orcs2[v].decode_frame(vpk2[v][f], dpbs2[v], mode2)
                     submit_frame(b2[f], mode2)
                     dev.sync()
                     d = int(P.Packet(q).hdr["dst_slot"])
-                    for st in streams:
-                        bad2 += 0 if np.array_equal(st.download(d), dpb[d][:nb]) else 1
+                    for k, st in enumerate(streams):
+                        bad2 += 0 if np.array_equal(st.download(d), dpbs2[k % V][d][:nb]) else 1
                         cmp2 += 1
                 ok2 = bad2 == 0
             other[label] = {"value": round(2 * len(pk2) * len(streams) / dt2, 1), "unit": "frames/s", "gop": gop2, "steps": 2, "bit_exact": ok2,
-                            "frames_compared": cmp2,
+                            "frames_compared": cmp2, "distinct_pictures": V * len(pk2),
                             "kernel_ms_per_launch": {n: round(t / max(l4, 1), 4) for n, t in zip(KERNELS, k4)}}
             for b in sum(b2, []):
                 dev.free_batch(b)
@@ -514,6 +583,15 @@ def main() -> int:
                 cpu["same_input"] = True  # the files of `same_input` are the files this baseline decodes
         except Exception as e:  # noqa: BLE001 -- the front-end library is built from the reference tree; without it the leg says so
             same = {"unavailable": f"{type(e).__name__}: {e}"}
+
+    # ---- system level (N=1 only): parser + emitters + GPU on this container's cores, next to cpu_baseline (same files, same cores) ------
+    system = None
+    if rank == 0 and world == 1 and not args.no_system and not stub and not args.capture:
+        try:
+            with launcher_cpus():
+                system = system_leg(cpu)
+        except Exception as e:  # noqa: BLE001 -- a missing binary or a failed run is reported, never fatal for the headline
+            system = {"unavailable": f"{type(e).__name__}: {e}"}
 
     # ---- PCIe-inclusive rate (informational, never `value`): the same GOP submitted from host memory -------------------
     pcie = None
@@ -537,9 +615,9 @@ def main() -> int:
         for pk in vpk:
             for p in pk:
                 assert backend.packet_check(p) == 0
-        vpins = [[dev.pinned_copy(p) for p in pk] for pk in vpk]
-        pins = [pp for row in vpins for pp in row]
-        pbs = [dev.prepare_pinned_batch([streams[k] for k in idx], [vpins[k % V][f] for k in idx], [len(vpk[k % V][f]) for k in idx]) for f in range(len(packets)) for idx in groups]
+        spins = [[dev.pinned_copy(p) for p in vpk[k % V]] for k in range(len(streams))]  # ONE page-locked buffer per stream and frame, as a front end per decoder leaves them
+        pins = [pp for row in spins for pp in row]
+        pbs = [dev.prepare_pinned_batch([streams[k] for k in idx], [spins[k][f] for k in idx], [len(vpk[k % V][f]) for k in idx]) for f in range(len(packets)) for idx in groups]
         for pb in pbs:
             dev.submit_pinned_prepared(pb, backend.RUN_ALL)
         dev.sync()
@@ -550,8 +628,9 @@ def main() -> int:
         dev.sync()
         dt2 = time.perf_counter() - t2
         pcie["pinned_in_place"] = {"value": round(2 * len(packets) * len(streams) / dt2, 1), "unit": "frames/s",
-                                   "what": "packets already in page-locked memory (as the emitters leave them) and validated by their producer -> "
-                                           "one H2D per stream and frame -> 4 kernels"}
+                                   "pinned_buffers": len(pins),
+                                   "what": "packets already in page-locked memory (as the emitters leave them: one buffer per stream and frame) and validated by "
+                                           "their producer -> gathered into the batch's staging buffer -> one H2D per batch -> 4 kernels"}
         for pp in pins:
             dev.pinned_free(pp)
 
@@ -602,6 +681,7 @@ def main() -> int:
             "other_configs": other,
             "pcie_inclusive": pcie,
             "same_input": same,
+            "system": system,
             "gpu_event_ms_per_step": round(ev_ms / args.steps, 3),
             "build_flags": backend.build_flags() if hasattr(backend, "build_flags") else None,
             "per_rank": {"frames_per_s": [round(r, 1) for r in rates], "min": round(min(rates), 1), "max": round(max(rates), 1),

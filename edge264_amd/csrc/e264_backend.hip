@@ -153,10 +153,11 @@ struct E264Device {
 	// Which submission wrote a slot last, and when it has retired: edge264_get_frame of ONE decoder must not wait for the
 	// whole device (every later batch of every other decoder), only for the submission that produced its frame.
 	uint64_t serial = 0;       // submissions so far (guarded by `lock`)
-	enum { NEV = 64 };
+	enum { NEV = 1024 };       // (round 5: 64 wrapped at once when hundreds of decoders filled their slots -- every fill takes a serial -- and every wait fell back to the whole lane)
 	hipEvent_t sub_ev[NEV] = {};
 	uint64_t sub_serial[NEV] = {};
 	int sub_lane[NEV] = {};
+	std::atomic<uint64_t> lane_retired[NQ] = {}; // per lane: the highest serial anybody has SEEN retired (a lane runs in order: everything below has too)
 	// Memory recycler.  hipFree / hipHostFree drain EVERY queue of the device, so what a decoder gives back (frame slots and
 	// their host mirrors at an SPS change or edge264_free, parameter and staging buffers) is parked with the submission that
 	// may still read it and handed to the next request of the same size once that submission has retired.  Parked memory is
@@ -224,15 +225,25 @@ static hipEvent_t serial_event(E264Device *dev, uint64_t serial)
 static bool serial_retired(E264Device *dev, uint64_t serial, int lane)
 {
 	if (!serial) return true;
+	std::atomic<uint64_t> &seen = dev->lane_retired[lane];
+	if (serial <= seen.load(std::memory_order_relaxed)) return true; // no lock, no driver call: somebody saw this lane get past it
 	hipEvent_t ev = serial_event(dev, serial);
-	if (ev) return hipEventQuery(ev) == hipSuccess;
-	// the event ring has wrapped past this serial.  A lane runs its work in order: any NEWER entry of the same lane that has retired
-	// proves this one has (a continuously busy lane is never idle, hipStreamQuery alone would keep old blocks parked for good)
+	if (ev) {
+		if (hipEventQuery(ev) != hipSuccess) { (void)hipGetLastError(); return false; }
+		raise_serial(seen, serial);
+		return true;
+	}
+	// the event ring has wrapped past this serial.  A lane runs its work in order: a NEWER entry of the same lane that has retired proves
+	// this one has (a continuously busy lane is never idle, hipStreamQuery alone would keep old blocks parked for good).  ONE query: the
+	// oldest such entry still in the ring, picked under the lock, asked outside it (round 4 asked up to 64 under the lock, per parked block).
+	hipEvent_t probe = nullptr;
+	uint64_t probe_serial = 0;
 	{
 		std::lock_guard<std::mutex> g(dev->lock);
 		for (int i = 0; i < E264Device::NEV; i++)
-			if (dev->sub_serial[i] > serial && dev->sub_lane[i] == lane && dev->sub_ev[i] && hipEventQuery(dev->sub_ev[i]) == hipSuccess) return true;
+			if (dev->sub_serial[i] > serial && dev->sub_lane[i] == lane && dev->sub_ev[i] && (!probe || dev->sub_serial[i] < probe_serial)) { probe = dev->sub_ev[i]; probe_serial = dev->sub_serial[i]; }
 	}
+	if (probe && hipEventQuery(probe) == hipSuccess) { raise_serial(seen, probe_serial); return true; }
 	(void)hipGetLastError(); // (hipErrorNotReady is not an error to keep)
 	return hipStreamQuery(dev->q[lane]) == hipSuccess;
 }
@@ -526,7 +537,9 @@ API void e264hip_frame_free(E264Stream *s, int slot)
 	if (!s || slot < 0 || slot >= E264_MAX_SLOTS || !s->h_table[slot]) return;
 	set_device(s->dev);
 	// kernels and fills already queued may still read or write the slot: it is parked until the stream's latest work has retired
-	mem_release(s->dev, s->h_table[slot], s->slot_bytes[slot] + 64, false, s->last_serial, s->lane);
+	// behind the lane's CURRENT tail (a marker of its own), not s->last_serial: a batch the submitter thread has just launched may not have
+	// published its serial to the stream yet (the block could be recycled while that batch still used it)
+	mem_release(s->dev, s->h_table[slot], s->slot_bytes[slot] + 64, false, mark_lane(s->dev, s->lane), s->lane);
 	mem_release(s->dev, s->mirror[slot], s->slot_bytes[slot], true, 0, 0); // downloads are synchronous: nothing in flight
 	s->h_table[slot] = nullptr; s->mirror[slot] = nullptr; s->slot_bytes[slot] = 0; s->slot_serial[slot] = 0;
 	push_table(s);
@@ -678,7 +691,7 @@ static int check_slots_of(const E264Stream *s, const E264FrameHdr *h)
 static int ensure_dbk(E264Stream *s, int n_mbs)
 {
 	if (s->dbk_mbs >= (size_t)n_mbs) return 0;
-	mem_release(s->dev, s->d_dbk, s->dbk_mbs * E264_DBK_BYTES, false, s->last_serial, s->lane); // queued kernels may still use it
+	mem_release(s->dev, s->d_dbk, s->dbk_mbs * E264_DBK_BYTES, false, mark_lane(s->dev, s->lane), s->lane); // queued kernels may still use it (behind the lane's tail, as frame_free)
 	s->d_dbk = (uint8_t *)mem_acquire(s->dev, (size_t)n_mbs * E264_DBK_BYTES, false);
 	s->dbk_mbs = s->d_dbk ? (size_t)n_mbs : 0;
 	return s->d_dbk ? 0 : fail(ENOMEM, "hipMalloc deblock parameters");

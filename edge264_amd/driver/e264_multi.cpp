@@ -92,7 +92,7 @@ struct Stream {
 	FILE *out = nullptr;
 	struct Pkt { void *data; size_t bytes; };
 	std::deque<Pkt> q;     // parsed, not yet submitted (guarded by the queue mutex)
-	bool finished = false; // its worker will queue nothing more
+	std::atomic<bool> finished{false}; // its worker will queue nothing more (read outside `mu` by the other workers)
 	std::atomic<bool> held{false}; // a parser thread is inside this decoder right now
 	int dev_index = 0;     // which of --devices holds its frames
 };

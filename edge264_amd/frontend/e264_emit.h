@@ -175,6 +175,8 @@ static int e264_slice_index(E264Emitter *e, E264FrameBuilder *b)
 	for (int i = b->n_slices - 1; i >= 0; i--)
 		if (b->slice_serial[i] == e->serial)
 			return i;
+	if (b->oom) /* the tables stopped growing (below): the picture is dropped anyway, every later slice of it shares the last entry */
+		return b->n_slices > 0 ? b->n_slices - 1 : 0;
 	if (b->n_slices == b->cap_slices) {
 		const int cap = b->cap_slices ? b->cap_slices * 2 : 8;
 		E264SliceParams *ns = malloc(sizeof(E264SliceParams) * (size_t)cap);
@@ -184,7 +186,7 @@ static int e264_slice_index(E264Emitter *e, E264FrameBuilder *b)
 			free(ns); free(nser); free(nf);
 			b->oom = 1;
 			if (b->n_slices > 0) return b->n_slices - 1;
-			static E264SliceParams spare_slice; static int spare_serial; static uint8_t spare_filled;
+			static _Thread_local E264SliceParams spare_slice; static _Thread_local int spare_serial; static _Thread_local uint8_t spare_filled; /* one element each: n_slices stays 1 (b->oom above) */
 			b->slices = &spare_slice; b->slice_serial = &spare_serial; b->slice_filled = &spare_filled; /* never freed through these (cap_slices stays 0: see edge264_free) */
 			b->slice_filled[0] = 1; b->n_slices = 1;
 			return 0;
