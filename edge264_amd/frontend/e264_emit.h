@@ -186,7 +186,9 @@ static int e264_slice_index(E264Emitter *e, E264FrameBuilder *b)
 			free(ns); free(nser); free(nf);
 			b->oom = 1;
 			if (b->n_slices > 0) return b->n_slices - 1;
-			static _Thread_local E264SliceParams spare_slice; static _Thread_local int spare_serial; static _Thread_local uint8_t spare_filled; /* one element each: n_slices stays 1 (b->oom above) */
+			static E264SliceParams spare_slice; static int spare_serial; static uint8_t spare_filled; /* one element each: n_slices stays 1 (b->oom above).  Shared by
+			   all decoders, and never written after this point: slice_filled[0] = 1 keeps e264_fill_slice out, nothing else stores through them (they cannot be
+			   thread-local: 2 KB more of initial-exec TLS and the library no longer loads with dlopen) */
 			b->slices = &spare_slice; b->slice_serial = &spare_serial; b->slice_filled = &spare_filled; /* never freed through these (cap_slices stays 0: see edge264_free) */
 			b->slice_filled[0] = 1; b->n_slices = 1;
 			return 0;
