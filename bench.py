@@ -160,7 +160,8 @@ def same_input_leg(dev, backend, n_streams, cpu):
     from edge264_amd import front, packet as P
     from oracle.pyoracle import Oracle  # checker only: the comparison below
     sdir = os.path.join(ROOT, "tests", "golden", "streams")
-    files = ["hd1080_ipp30.264", "cabac_hd1080_ibbp30.264"]
+    from oracle.cpu_baseline import FIXTURES_1080P  # (the list only: the files the CPU baseline decodes)
+    files = [n for n in FIXTURES_1080P if os.path.exists(os.path.join(sdir, n))]
     res = {"files": files, "streams": n_streams, "per_file": {}}
     tot_frames = tot_res = tot_host = tot_parse = tot_pictures = 0.0
     all_ok = True
@@ -189,11 +190,14 @@ def same_input_leg(dev, backend, n_streams, cpu):
         for b in bs:  # warm-up pass
             dev.submit_prepared(b, backend.RUN_ALL)
         dev.sync()
+        dev.kernel_timing(True)
         t0 = time.perf_counter()
         for b in bs:
             dev.submit_prepared(b, backend.RUN_ALL)
         dev.sync()
         t_res = time.perf_counter() - t0
+        k4, l4 = dev.kernel_time_ms()
+        dev.kernel_timing(False)
         hbs = [dev.prepare_host_batch(sts, [packets[f]] * n_streams) for f in range(len(packets))]
         for hb in hbs[:2]:
             dev.submit_host_prepared(hb, backend.RUN_ALL)
@@ -223,6 +227,7 @@ def same_input_leg(dev, backend, n_streams, cpu):
         res["per_file"][name] = {"pictures": len(packets), "packet_MB_per_picture": round(float(np.mean([len(p) for p in packets])) / 1e6, 3),
                                  "gpu_resident_frames_per_s": round(n / t_res, 1), "gpu_pcie_inclusive_frames_per_s": round(n / t_host, 1),
                                  "host_parse_emit_frames_per_s_one_core": round(len(packets) / parse_s, 1),
+                                 "kernel_ms_per_launch": {n: round(t / max(l4, 1), 4) for n, t in zip(KERNELS, k4)},
                                  "pictures_compared": len(packets) * len(probe), "mismatching": bad}
         tot_frames += n; tot_res += t_res; tot_host += t_host; tot_parse += parse_s; tot_pictures += len(packets)
         for b in bs:
@@ -234,7 +239,7 @@ def same_input_leg(dev, backend, n_streams, cpu):
             st.close()
     res.update({"gpu_resident_frames_per_s": round(tot_frames / tot_res, 1), "gpu_pcie_inclusive_frames_per_s": round(tot_frames / tot_host, 1),
                 "host_parse_emit_frames_per_s_one_core": round(tot_pictures / tot_parse, 1) if tot_parse else None, "bit_exact": bool(all_ok),
-                "what": "both sides decode the SAME two files: GPU = their command packets (reference parser + emitters, parsed in this process) decoded by "
+                "what": "both sides decode the SAME files (two of random syntax, two from the procedural-video encoder tests/golden/nat_encoder.py): GPU = their command packets (reference parser + emitters, parsed in this process) decoded by "
                         f"{n_streams} concurrent decoders, packets resident in HBM / pageable host packets with validation + H2D inside the timed region; "
                         "CPU = the unmodified reference decoder on these files (cpu_baseline, same run).  The parser itself is host work on both sides: "
                         "host_parse_emit is what ONE core delivers, the GPU figures are what the device sustains behind enough parsing cores"})
@@ -249,7 +254,7 @@ def same_input_leg(dev, backend, n_streams, cpu):
 def system_leg(cpu, seconds=6.0):
     """SYSTEM level (the shape of the reference's own whole-decoder clock, /root/reference/src/edge264_test.c:482-542): Annex-B bytes in, decoded
     pictures in HBM out, with the reference's parser + our emitters on the host cores INSIDE the clock: edge264_amd/e264_multi, 128 decoders
-    (64 x the two 1080p fixtures `cpu_baseline` decodes), threads = the container's cores - 1 (one is left to the submitter and the back
+    (32 x the four 1080p fixtures `cpu_baseline` decodes), threads = the container's cores - 1 (one is left to the submitter and the back
     end's threads), packets assembled in page-locked memory and submitted in place, no read-back.  Two runs: parser + emitters alone
     (packets dropped: what the host delivers) and end to end (the same with the GPU behind it)."""
     from oracle.cpu_baseline import FIXTURES_1080P, STREAMS, cpu_quota, physical_cores  # (host-side helpers only: which cores, which files)
@@ -262,13 +267,15 @@ def system_leg(cpu, seconds=6.0):
     quota = cpu_quota()
     cores = len(physical_cores()) if quota is None else max(1, min(len(physical_cores()), int(quota)))
     threads = max(1, cores - 1)
-    files = [os.path.join(STREAMS, n) for n in FIXTURES_1080P]
-    res = {"streams": 128, "threads": threads, "cores": cores, "files": list(FIXTURES_1080P)}
+    names = [n for n in FIXTURES_1080P if os.path.exists(os.path.join(STREAMS, n))]
+    files = [os.path.join(STREAMS, n) for n in names]
+    repeat = max(1, 128 // len(names))
+    res = {"streams": repeat * len(names), "threads": threads, "cores": cores, "files": names}
     for key, flag in (("parse_only", "--parse-only"), ("end_to_end", "--no-download")):
         loops = 2
         out = None
         for _ in range(3):  # a short run sizes the long one: ~`seconds` of wall clock each
-            cmd = [exe, "--front", front, "--hip", hip, flag, "--threads", str(threads), "--repeat", "64", "--loops", str(loops)] + files
+            cmd = [exe, "--front", front, "--hip", hip, flag, "--threads", str(threads), "--repeat", str(repeat), "--stay", "--loops", str(loops)] + files
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
             if r.returncode != 0 or line is None:

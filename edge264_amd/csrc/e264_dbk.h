@@ -377,6 +377,30 @@ template <int K> E264_DEV void dk_vpass(DkWaveT<K> &W, const DkPrm &P, const DkR
 	}
 }
 
+// The V phase of a step in which NO macroblock of the wave has an edge to filter (every bS of every row's record is 0): the samples
+// only move from the fetch registers into the strip, exactly where dk_vpass would have left them (its stores with nothing changed: the left
+// neighbour's columns stay as they are).  Round 5: on encoder-made streams 53 % of the macroblocks have every bS 0 and they come in
+// runs (skipped background), tools/stream_stats.py; the synthetic bench GOP never takes this path.
+template <int K> E264_DEV void dk_vcopy(DkWaveT<K> &W, const DkRole &R, const v4u &ra, const v4u &rb, int x)
+{
+	uint8_t *W8 = (uint8_t *)&W;
+	const int own = R.rowa + (x & (DK_SLOTS - 1)) * R.slot_mul;
+	if (!dk_chroma<K>(R)) {
+		*(v4u *)(W8 + own) = ra;
+		*(v4u *)(W8 + own + DK_STRIDE) = rb;
+	} else {
+		*(v2u *)(W8 + own) = (v2u){ra.x, ra.y};
+		*(v2u *)(W8 + own + DK_STRIDE) = (v2u){rb.x, rb.y};
+		*(v2u *)(W8 + own + DK_CR) = (v2u){ra.z, ra.w};
+		*(v2u *)(W8 + own + DK_CR + DK_STRIDE) = (v2u){rb.z, rb.w};
+	}
+}
+// does the macroblock's parameter record name any edge at all?  (bytes 0..31: bS[direction][edge][segment])
+E264_DEV uint32_t dk_any_bs(const uint32_t *prm) { return prm[0] | prm[1] | prm[2] | prm[3] | prm[4] | prm[5] | prm[6] | prm[7]; }
+#ifndef E264_DBK_ZEROSKIP
+#define E264_DBK_ZEROSKIP 1
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------------
 // H phase: the horizontal edges; the lane owns columns 2pi, 2pi+1 (chroma: of Cb and of Cr)
 // ---------------------------------------------------------------------------------------------------------------------

@@ -229,15 +229,23 @@ static __device__ __forceinline__ void dk_walk_group(DkWaveT<K> &W, const FrameC
 		wave_sync();
 		PH(2);
 		DkPrm P[2];
-		if (p.act) {
-			dk_params<K>((const uint8_t *)W.prm[R.g][p.x & 1], tc0tab, R, P);
-			PH(3);
-			dk_vpass<K>(W, P[0], R, ra, rb, p.x);
+#if E264_DBK_ZEROSKIP // (wave-uniform) a step in which no macroblock of the wave has an edge to filter only moves its samples into the strips
+		if (!__any(p.act && dk_any_bs(W.prm[R.g][p.x & 1]) != 0)) {
+			if (p.act) dk_vcopy<K>(W, R, ra, rb, p.x);
+			wave_sync();
+		} else
+#endif
+		{
+			if (p.act) {
+				dk_params<K>((const uint8_t *)W.prm[R.g][p.x & 1], tc0tab, R, P);
+				PH(3);
+				dk_vpass<K>(W, P[0], R, ra, rb, p.x);
+			}
+			wave_sync();
+			PH(4);
+			if (p.act) dk_hpass<K>(W, P[1], R, p.x);
+			wave_sync();
 		}
-		wave_sync();
-		PH(4);
-		if (p.act) dk_hpass<K>(W, P[1], R, p.x);
-		wave_sync();
 		PH(5);
 		if (p.publish) {
 			// the stores at the top of this step must be visible to the wave below before the counter moves

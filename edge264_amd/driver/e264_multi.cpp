@@ -132,6 +132,7 @@ int main(int argc, char **argv)
 	                    // (e264hip_submit_batch_pinned, E264_SUBMIT_TRUSTED: the producer is the emitter) instead of being validated
 	                    // again and copied into staging memory by the back end
 	bool pin = false; // --pin: parser thread k runs on the k-th CPU this process may use (the submitters float): no migration, warm caches
+	bool stay = false; // --stay: a thread parses up to `ahead` pictures of one decoder in a row (round 5: cache locality against rotation, profiles/r05_host.txt)
 	bool parse_only = false; // --parse-only: sink 1, no GPU: packets are produced and dropped (front-end speed / debugging)
 	std::vector<std::string> files;
 	for (int i = 1; i < argc; i++) {
@@ -149,6 +150,7 @@ int main(int argc, char **argv)
 		else if (a == "--loops") loops = atoi(next().c_str());
 		else if (a == "--ahead") ahead = std::max(1, atoi(next().c_str()));
 		else if (a == "--pin") pin = true;
+		else if (a == "--stay") stay = true;
 		else if (a == "--out") out_dir = next();
 		else if (a == "--dump-packets") dump_path = next();
 		else files.push_back(a);
@@ -296,7 +298,9 @@ int main(int argc, char **argv)
 						std::lock_guard<std::mutex> lk(mu);
 						s.finished = true; unfinished_count--; cv_ready.notify_all();
 					}
-					if (a == GOT) { progressed = true; at = (at + n + 1) % S.size(); s.held = false; break; }
+					// --stay: the thread comes back to THIS decoder first (its state is in the core's caches) until it is `ahead` pictures ahead;
+					// default: on to the next decoder after every picture
+					if (a == GOT) { progressed = true; at = (at + n + (stay ? 0 : 1)) % S.size(); s.held = false; break; }
 				}
 				s.held = false;
 			}

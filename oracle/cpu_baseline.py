@@ -15,7 +15,9 @@ import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 STREAMS = os.path.join(os.path.dirname(HERE), "tests", "golden", "streams")
-FIXTURES_1080P = ("hd1080_ipp30.264", "cabac_hd1080_ibbp30.264")  # 30 pictures each: CAVLC IPPP, CABAC IBBP with 8x8 transform + scaling lists
+# 30 pictures each.  Random syntax (tests/golden/make_streams.py): CAVLC IPPP; CABAC IBBP with 8x8 transform + scaling lists.  Encoder-shaped
+# (tests/golden/nat_encoder.py, round 5: procedural video through a real motion search / mode decision / quantiser): CAVLC IPPP, CABAC IBBP.
+FIXTURES_1080P = ("hd1080_ipp30.264", "cabac_hd1080_ibbp30.264", "nat1080_ipp30.264", "cabac_nat1080_ibbp30.264")
 
 
 def cpu_model() -> str:
@@ -112,7 +114,8 @@ def reference_decoder_baseline(seconds_single: float = 6.0, seconds_all: float =
     lib = os.path.join(HERE, "_ref", "libedge264_ref.so")
     if not os.path.exists(lib):
         raise FileNotFoundError(lib)
-    blobs = [open(os.path.join(STREAMS, n), "rb").read() for n in FIXTURES_1080P]
+    names = [n for n in FIXTURES_1080P if os.path.exists(os.path.join(STREAMS, n))]
+    blobs = [open(os.path.join(STREAMS, n), "rb").read() for n in names]
     host_cores = physical_cores()
     quota = cpu_quota()
     # one process per core the container can actually run at once: more processes than that only share the quota
@@ -133,6 +136,6 @@ def reference_decoder_baseline(seconds_single: float = 6.0, seconds_all: float =
             "cpu_model": cpu_model(), "host_physical_cores": len(host_cores), "cpu_quota_cores": quota,
             "cpu_seconds_total": round(sum(r[2] for r in res) + c1, 1),
             "sample": f"the unmodified reference decoder (edge264_alloc(0, ...), CAVLC/CABAC parsing + reconstruction + deblocking) on the "
-                      f"1080p fixtures {', '.join(FIXTURES_1080P)} decoded in a loop: 1 process for {w1:.1f} s ({f1} frames), then "
+                      f"1080p fixtures {', '.join(names)} decoded in a loop: 1 process for {w1:.1f} s ({f1} frames), then "
                       f"{len(cores)} processes pinned to distinct physical cores for {wa:.1f} s ({fa} frames)"
                       + (f"; the container's CPU quota is {quota:g} cores of the host's {len(host_cores)}" if quota is not None else "")}

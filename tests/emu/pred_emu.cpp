@@ -62,6 +62,12 @@ extern "C" __attribute__((visibility("default"))) int e264emu_dbkparam_frame(con
 // dpb[dst_slot] is filtered in place.  Groups of rows are run one after the other (a group only ever waits for the group above it
 // of its own kind), the lanes of a wave phase by phase.  K: the kind of wave (DkGeom): 2 mixed, 0 luma only, 1 chroma only.
 #include "../../edge264_amd/csrc/e264_dbk.h"
+static long g_zero_steps, g_filter_steps; // steps that took the copy-only path / the filter path (tests check that both are exercised)
+extern "C" __attribute__((visibility("default"))) void e264emu_deblock_step_counts(long *zero, long *filt, int reset)
+{
+	*zero = g_zero_steps; *filt = g_filter_steps;
+	if (reset) g_zero_steps = g_filter_steps = 0;
+}
 template <int K>
 static void emu_walk_group(const FrameCtx &f, const uint8_t *tc0tab, int q)
 {
@@ -97,6 +103,16 @@ static void emu_walk_group(const FrameCtx &f, const uint8_t *tc0tab, int q)
 			if (k == (DK_GS == 4 ? 2 : 0) && p[lane].grp_fetch) dk_fetch4<K>(dk_src<K>(f, R[lane], y), R[lane], p[lane].x + 2, f.wm, N[lane]);
 		}
 		static DkPrm P[64][2];
+		bool any_edge = !E264_DBK_ZEROSKIP; // (the kernel's wave-uniform test: no macroblock of the wave has an edge to filter -> samples only move into the strips)
+		for (int lane = 0; lane < 64; lane++)
+			if (p[lane].act && dk_any_bs(W.prm[R[lane].g][p[lane].x & 1]) != 0) any_edge = true;
+		if (!any_edge) {
+			for (int lane = 0; lane < 64; lane++)
+				if (p[lane].act) dk_vcopy<K>(W, R[lane], ra[lane], rb[lane], p[lane].x);
+			g_zero_steps++;
+			continue;
+		}
+		g_filter_steps++;
 		for (int lane = 0; lane < 64; lane++)
 			if (p[lane].act) {
 				dk_params<K>((const uint8_t *)W.prm[R[lane].g][p[lane].x & 1], tc0tab, R[lane], P[lane]);

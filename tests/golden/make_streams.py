@@ -397,13 +397,15 @@ class Synth:
         return self.finish_inter(fc, mx, my, sl, mb, can_t8)
 
     # ---- slices -----------------------------------------------------------------------------------
-    def slice_nal(self, fc, ftype, first, last, sl, hdr):
-        """hdr: dict(frame_num, poc, is_ref, idr, nref0, nref1, idr_pic_id)."""
+    def slice_nal(self, fc, ftype, first, last, sl, hdr, mbs=None):
+        """hdr: dict(frame_num, poc, is_ref, idr, nref0, nref1, idr_pic_id).  mbs: the macroblocks of the slice already described (an encoder's
+        decisions, nat_encoder.py) instead of the seeded random description drawn here."""
         g, r = self.g, self.rng
         st = {"I": 2, "P": 0, "B": 1}[ftype]
-        mbs, pending = [], None  # pending: entry that carries mb_skip_run
+        given = mbs is not None
+        mbs, pending = (mbs if given else []), None  # pending: entry that carries mb_skip_run
         run = 0
-        for addr in range(first, last):
+        for addr in (() if given else range(first, last)):
             mx, my = addr % self.W, addr // self.W
             fc.slice_of[my][mx] = sl
             if st != 2 and r.random() < self.skip:

@@ -1,0 +1,885 @@
+#!/usr/bin/env python3
+"""tests/golden/nat_encoder.py -- ENCODER-SHAPED fixtures: nat1080_ipp30.264 (CAVLC) and cabac_nat1080_ibbp30.264 (CABAC).
+
+Every other fixture of tests/golden/streams is a RANDOM description (modes, vectors, levels drawn from a seeded generator).  The
+reference's own correctness claim rests on encoder output (the 109 JVT conformance clips, /root/reference/README.md:103,
+src/edge264_test.c:276-286), which cannot be fetched here.  This script is the part of that gap that can be closed offline: a
+procedural 1080p video (a panning textured background, textured rectangles moving over it at fractional velocities, a flat region,
+a noisy region, sensor noise) goes through a small but real encoder --
+
+  * motion search on the RECONSTRUCTED (deblocked) references as the decoder will see them: full search on integer positions, then half- and
+    quarter-sample refinement on the 16 interpolated planes of 8.4.2.2.1; 16x16 or four 8x8 partitions by cost; one reference per list;
+  * vector prediction (8.4.1.3), P_Skip (8.4.1.1) and spatial direct prediction for B_Skip / B_Direct_16x16 (8.4.1.2.2, colZeroFlag
+    from the co-located picture's motion) so that a macroblock whose best choice is the predicted motion and whose residual quantises
+    to zero is SKIPPED: long skip runs, coherent vectors, bS = 0 on most edges -- the statistics real decoders see;
+  * B pictures: direct, L0, L1 or bi-predicted 16x16 by cost; default weighting;
+  * residual = source - prediction through the forward 4x4 integer transform, the Intra16x16 / chroma DC Hadamard transforms and a
+    dead-zone quantiser at a fixed QP;
+  * intra: Intra16x16 (4 modes) or Intra4x4 (7 of the 9 modes) by SAD on its own in-loop reconstruction;
+
+and is written out by the same syntax writers as the other fixtures (the reference's tests/gen_avc.py for CAVLC, cabac_writer.py for
+CABAC).  The UNMODIFIED reference decoder closes the loop: after every picture the stream so far is decoded by it and ITS pictures are
+the references of the next one.  The encoder's own arithmetic therefore only has to be good enough to make sensible decisions: what
+the pictures ARE is whatever the reference decodes (tests/golden/streams/reference_md5.json), as for every other fixture.
+
+It only runs in the build container (where /root/reference exists).  Re-run:  python tests/golden/nat_encoder.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import make_streams as ms  # noqa: E402
+
+W_MBS, H_MBS = 120, 68
+ZZ = [0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15]  # raster index of scan position i (frame zig-zag)
+QPC = list(range(30)) + [29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39]
+MF = [(13107, 5243, 8066), (11916, 4660, 7490), (10082, 4194, 6554), (9362, 3647, 5825), (8192, 3355, 5243), (7282, 2893, 4559)]
+VQ = [(10, 16, 13), (11, 18, 14), (13, 20, 16), (14, 23, 18), (16, 25, 20), (18, 29, 23)]
+POSCLASS = np.array([[0, 2, 0, 2], [2, 1, 2, 1], [0, 2, 0, 2], [2, 1, 2, 1]])  # 0: both even, 1: both odd, 2: mixed
+CF = np.array([[1, 1, 1, 1], [2, 1, -1, -2], [1, -1, -1, 1], [1, -2, 2, -1]])
+ZIDX = [[0, 1, 4, 5], [2, 3, 6, 7], [8, 9, 12, 13], [10, 11, 14, 15]]  # decoding order of the 4x4 block at [y][x]
+PAD = 40  # samples of edge replication around a reference plane (search range + taps)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the video
+# ---------------------------------------------------------------------------------------------------------------------
+class Layer:
+    """A texture that can be sampled at any sub-sample position: a sum of sinusoids (band-limited by construction)."""
+
+    def __init__(self, rng, base, amp, n=18, fmax=0.45, chroma=(128, 128)):
+        self.base, self.n = base, n
+        self.f = rng.uniform(-fmax, fmax, (n, 2)) * rng.choice([0.15, 0.4, 1.0], (n, 1))
+        self.ph = rng.uniform(0, 2 * np.pi, n)
+        self.a = amp * rng.uniform(0.3, 1.0, n) / np.sqrt(n) * 2.2
+        self.cf = rng.uniform(-0.02, 0.02, (2, 3, 2))
+        self.cph = rng.uniform(0, 2 * np.pi, (2, 3))
+        self.cbase = chroma
+
+    def luma(self, xs, ys):
+        v = np.full((len(ys), len(xs)), float(self.base))
+        for k in range(self.n):
+            v += self.a[k] * np.sin(self.f[k, 0] * xs[None, :] + self.f[k, 1] * ys[:, None] + self.ph[k])
+        return v
+
+    def chroma(self, p, xs, ys):
+        v = np.full((len(ys), len(xs)), float(self.cbase[p]))
+        for k in range(3):
+            v += 9.0 * np.sin(self.cf[p, k, 0] * xs[None, :] + self.cf[p, k, 1] * ys[:, None] + self.cph[p, k])
+        return v
+
+
+class Scene:
+    """frame(n) -> (Y, Cb, Cr) uint8 of W x H (4:2:0)."""
+
+    def __init__(self, W, H, seed):
+        self.W, self.H = W, H
+        r = self.rng = np.random.default_rng(seed)
+        self.bg = Layer(r, 120, 38, chroma=(118, 136))
+        self.bg_v = (1.25, 0.5)  # quarter-sample pan per picture
+        # rectangles: x, y, w, h, vx, vy, layer, sensor-noise sigma inside
+        self.objs = [
+            (200, 150, 420, 300, -3.0, 1.75, Layer(r, 150, 45, chroma=(100, 160)), 0.0),
+            (900, 500, 360, 260, 2.5, 0.0, Layer(r, 90, 30, chroma=(150, 110)), 0.0),
+            (1400, 120, 300, 420, 0.75, -0.25, Layer(r, 170, 25, chroma=(128, 128)), 0.0),
+            (600, 760, 520, 220, 6.25, 2.0, Layer(r, 110, 55, fmax=0.7, chroma=(140, 120)), 0.0),
+            (60, 820, 340, 200, 0.0, 0.0, Layer(r, 60, 12, chroma=(128, 128)), 0.0),           # a static overlay
+            (1100, 40, 640, 90, 0.0, 0.0, Layer(r, 200, 1.5, n=4, chroma=(120, 132)), 0.0),     # flat: skips, bS 0
+            (1500, 700, 320, 300, -1.5, -0.75, Layer(r, 128, 30, chroma=(128, 128)), 5.0),     # noisy: coded everywhere
+        ]
+
+    def frame(self, n):
+        W, H = self.W, self.H
+        xs, ys = np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64)
+        cx, cy = np.arange(W // 2, dtype=np.float64) * 2 + 0.5, np.arange(H // 2, dtype=np.float64) * 2 + 0.5
+        ox, oy = self.bg_v[0] * n, self.bg_v[1] * n
+        Y = self.bg.luma(xs - ox, ys - oy)
+        C = [self.bg.chroma(p, cx - ox, cy - oy) for p in range(2)]
+        noise = np.full((H, W), 1.0)
+        for (x, y, w, h, vx, vy, lay, sig) in self.objs:
+            px, py = x + vx * n, y + vy * n
+            x0, x1 = int(np.ceil(max(px, 0))), int(np.floor(min(px + w, W)))
+            y0, y1 = int(np.ceil(max(py, 0))), int(np.floor(min(py + h, H)))
+            if x1 <= x0 or y1 <= y0:
+                continue
+            Y[y0:y1, x0:x1] = lay.luma(xs[x0:x1] - px, ys[y0:y1] - py)
+            if sig:
+                noise[y0:y1, x0:x1] = sig
+            c0x, c1x, c0y, c1y = (x0 + 1) // 2, x1 // 2, (y0 + 1) // 2, y1 // 2
+            for p in range(2):
+                C[p][c0y:c1y, c0x:c1x] = lay.chroma(p, cx[c0x:c1x] - px, cy[c0y:c1y] - py)
+        g = np.random.default_rng(1000 + n)
+        Y = Y + g.normal(0, 1, (H, W)) * noise
+        C = [c + g.normal(0, 0.5, c.shape) for c in C]
+        q = lambda a: np.clip(np.rint(a), 0, 255).astype(np.uint8)  # noqa: E731
+        return q(Y), q(C[0]), q(C[1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# reference planes: padding, the 16 quarter-sample planes (8.4.2.2.1), chroma bilinear (8.4.2.2.2)
+# ---------------------------------------------------------------------------------------------------------------------
+def pad(a, p=PAD):
+    return np.pad(a, p, mode="edge")
+
+
+def tap6(a, axis):
+    s = [np.roll(a, -k, axis=axis) for k in range(-2, 4)]
+    return s[0] - 5 * s[1] + 20 * s[2] + 20 * s[3] - 5 * s[4] + s[5]
+
+
+def qpel_planes(Y):
+    """Y: padded luma (uint8).  Returns planes[yFrac][xFrac] (uint8, same shape; the outermost 3 samples are garbage from the rolls)."""
+    G = Y.astype(np.int32)
+    b1, h1 = tap6(G, 1), tap6(G, 0)
+    clip = lambda a: np.clip(a, 0, 255)  # noqa: E731
+    b, h = clip((b1 + 16) >> 5), clip((h1 + 16) >> 5)
+    j = clip((tap6(b1, 0) + 512) >> 10)
+    Gr, Gd = np.roll(G, -1, 1), np.roll(G, -1, 0)
+    m, s = np.roll(h, -1, 1), np.roll(b, -1, 0)
+    avg = lambda p, q: (p + q + 1) >> 1  # noqa: E731
+    P = [[G, avg(G, b), b, avg(Gr, b)],
+         [avg(G, h), avg(b, h), avg(b, j), avg(b, m)],
+         [h, avg(h, j), j, avg(j, m)],
+         [avg(Gd, h), avg(h, s), avg(j, s), avg(m, s)]]
+    return np.array([[p.astype(np.uint8) for p in row] for row in P])
+
+
+def luma_pred(planes, x, y, mv, w, h):
+    """w x h block at (x, y) (unpadded coordinates) displaced by the quarter-sample vector mv."""
+    ix, iy = x + (mv[0] >> 2) + PAD, y + (mv[1] >> 2) + PAD
+    H, W = planes.shape[2:]
+    ix, iy = min(max(ix, 3), W - w - 4), min(max(iy, 3), H - h - 4)  # (far outside: the padding's flat edge is what the clamp of 8.4.2.2 gives)
+    return planes[mv[1] & 3, mv[0] & 3, iy:iy + h, ix:ix + w].astype(np.int32)
+
+
+def chroma_pred(C, x, y, mv, w, h):
+    """C: padded chroma plane; (x, y), w, h in chroma samples; mv in quarter luma = eighth chroma samples."""
+    ix, iy = x + (mv[0] >> 3) + PAD, y + (mv[1] >> 3) + PAD
+    H, W = C.shape
+    ix, iy = min(max(ix, 0), W - w - 1), min(max(iy, 0), H - h - 1)
+    xf, yf = mv[0] & 7, mv[1] & 7
+    a = C[iy:iy + h + 1, ix:ix + w + 1].astype(np.int32)
+    return ((8 - xf) * (8 - yf) * a[:-1, :-1] + xf * (8 - yf) * a[:-1, 1:] + (8 - xf) * yf * a[1:, :-1] + xf * yf * a[1:, 1:] + 32) >> 6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# transform and quantisation (8.5; the forward side as in the JM)
+# ---------------------------------------------------------------------------------------------------------------------
+def fwd4x4(blocks):
+    """blocks: (..., 4, 4) residual -> transform coefficients"""
+    return np.einsum("ij,...jk,lk->...il", CF, blocks, CF)
+
+
+def quant(Wc, qp, intra):
+    qb = 15 + qp // 6
+    mfv = np.array(MF[qp % 6])[POSCLASS]
+    f = (1 << qb) // (3 if intra else 6)
+    return np.sign(Wc) * ((np.abs(Wc) * mfv + f) >> qb)
+
+
+def quant_dc(D, qp, intra):
+    qb = 15 + qp // 6
+    f = (1 << qb) // (3 if intra else 6)
+    return np.sign(D) * ((np.abs(D) * MF[qp % 6][0] + 2 * f) >> (qb + 1))
+
+
+def dequant(L, qp):
+    v = np.array(VQ[qp % 6])[POSCLASS] * 16
+    return (((L * v) << (qp // 6)) + 8) >> 4
+
+
+def inv4x4(d):
+    """d: (..., 4, 4) dequantised coefficients -> residual ((x + 32) >> 6)"""
+    def one(x):  # along the last axis
+        e0, e1 = x[..., 0] + x[..., 2], x[..., 0] - x[..., 2]
+        e2, e3 = (x[..., 1] >> 1) - x[..., 3], x[..., 1] + (x[..., 3] >> 1)
+        return np.stack([e0 + e3, e1 + e2, e1 - e2, e0 - e3], -1)
+    t = one(d)                       # rows
+    t = one(t.swapaxes(-1, -2)).swapaxes(-1, -2)  # columns
+    return (t + 32) >> 6
+
+
+H4 = np.array([[1, 1, 1, 1], [1, 1, -1, -1], [1, -1, -1, 1], [1, -1, 1, -1]])
+H2 = np.array([[1, 1], [1, -1]])
+
+
+def scan(block):  # (4, 4) -> 16 levels in zig-zag order
+    f = block.reshape(16)
+    return [int(f[i]) for i in ZZ]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# motion state of a picture: per 4x4 block, both lists
+# ---------------------------------------------------------------------------------------------------------------------
+class Motion:
+    UNAVAIL = -2
+
+    def __init__(self, W, H):
+        self.W4, self.H4 = 4 * W, 4 * H
+        self.ref = np.full((2, self.H4, self.W4), self.UNAVAIL, np.int8)
+        self.mv = np.zeros((2, self.H4, self.W4, 2), np.int32)
+
+    def get(self, lst, bx, by):
+        if bx < 0 or by < 0 or bx >= self.W4 or by >= self.H4:
+            return self.UNAVAIL, (0, 0)
+        r = int(self.ref[lst, by, bx])
+        if r < 0:
+            return r, (0, 0)
+        return r, (int(self.mv[lst, by, bx, 0]), int(self.mv[lst, by, bx, 1]))
+
+    def set(self, lst, bx, by, w4, h4, ref, mv=(0, 0)):
+        self.ref[lst, by:by + h4, bx:bx + w4] = ref
+        self.mv[lst, by:by + h4, bx:bx + w4] = mv
+
+    def neighbours(self, lst, bx, by, w4):
+        A = self.get(lst, bx - 1, by)
+        B = self.get(lst, bx, by - 1)
+        Cn = self.get(lst, bx + w4, by - 1)
+        if Cn[0] == self.UNAVAIL:
+            Cn = self.get(lst, bx - 1, by - 1)
+        return A, B, Cn
+
+    def mvp(self, lst, bx, by, w4, ref):
+        """8.4.1.3 (median prediction; no 16x8 / 8x16 partitions are ever written)"""
+        A, B, Cn = self.neighbours(lst, bx, by, w4)
+        if B[0] == self.UNAVAIL and Cn[0] == self.UNAVAIL and A[0] != self.UNAVAIL:
+            B = Cn = A
+        same = [n for n in (A, B, Cn) if n[0] == ref]
+        if len(same) == 1:
+            return same[0][1]
+        med = lambda a, b, c: a + b + c - min(a, b, c) - max(a, b, c)  # noqa: E731
+        return (med(A[1][0], B[1][0], Cn[1][0]), med(A[1][1], B[1][1], Cn[1][1]))
+
+    def p_skip_mv(self, bx, by):
+        A, B = self.get(0, bx - 1, by), self.get(0, bx, by - 1)
+        if A[0] == self.UNAVAIL or B[0] == self.UNAVAIL or (A[0] == 0 and A[1] == (0, 0)) or (B[0] == 0 and B[1] == (0, 0)):
+            return (0, 0)
+        return self.mvp(0, bx, by, 4, 0)
+
+
+def se_bits(v):
+    k = 2 * abs(v) + (0 if v > 0 else 1) if v else 1
+    return 2 * int(k).bit_length() - 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the encoder
+# ---------------------------------------------------------------------------------------------------------------------
+class NatEncoder(ms.Synth):
+    def __init__(self, g, name, frames, *, cabac, qp, seed, tables=None, search=8):
+        super().__init__(g, name, W_MBS, H_MBS, frames, seed, num_refs=2 if "B" in frames else 1, cabac=cabac, tables=tables, qp=qp, level=4.0,
+                         pcm=0.0)
+        self.scene = Scene(16 * W_MBS, 16 * H_MBS, seed)
+        self.search = search
+        self.qpc = QPC[qp]
+        self.lam = max(2, int(0.85 * 2 ** ((qp - 12) / 6)))  # SAD units per bit
+        self.stats = {}
+
+    # ---- motion search of a whole picture against one reference (vectorised) ----------------------------------------------
+    def search_picture(self, src, refpad, planes):
+        """-> best quarter-sample vectors and SADs: mv16 (H, W, 2), sad16 (H, W), mv8 (2H, 2W, 2), sad8 (2H, 2W)"""
+        Wm, Hm, R = self.W, self.H, self.search
+        S = src.astype(np.int16)
+        best8 = np.full((2 * Hm, 2 * Wm), 1 << 30, np.int64)
+        best16 = np.full((Hm, Wm), 1 << 30, np.int64)
+        mv8 = np.zeros((2 * Hm, 2 * Wm, 2), np.int32)
+        mv16 = np.zeros((Hm, Wm, 2), np.int32)
+        Hs, Ws = S.shape
+        for dy in range(-R, R + 1):
+            for dx in range(-R, R + 1):
+                ref = refpad[PAD + dy:PAD + dy + Hs, PAD + dx:PAD + dx + Ws].astype(np.int16)
+                ad = np.abs(S - ref).astype(np.int32)
+                s8 = ad.reshape(2 * Hm, 8, 2 * Wm, 8).sum((1, 3))
+                s16 = s8.reshape(Hm, 2, Wm, 2).sum((1, 3))
+                bias = (abs(dx) + abs(dy)) * 2  # ties go to the shorter vector: coherent fields
+                m = s8 + bias < best8
+                best8[m] = (s8 + bias)[m]
+                mv8[m] = (4 * dx, 4 * dy)
+                m = s16 + bias < best16
+                best16[m] = (s16 + bias)[m]
+                mv16[m] = (4 * dx, 4 * dy)
+        # sub-sample refinement: 8 neighbours at half, then at quarter sample distance
+        for (mv, best, bs) in ((mv16, best16, 16), (mv8, best8, 8)):
+            nby, nbx = mv.shape[:2]
+            yy = (np.arange(nby) * bs)[:, None, None, None] + np.arange(bs)[None, None, :, None]
+            xx = (np.arange(nbx) * bs)[None, :, None, None] + np.arange(bs)[None, None, None, :]
+            Sb = S.reshape(nby, bs, nbx, bs).transpose(0, 2, 1, 3).astype(np.int32)
+            Hp, Wp = planes.shape[2:]
+
+            def sad_of(v):
+                iy = np.clip(yy + (v[..., 1] >> 2)[:, :, None, None] + PAD, 3, Hp - 4)
+                ix = np.clip(xx + (v[..., 0] >> 2)[:, :, None, None] + PAD, 3, Wp - 4)
+                pr = planes[(v[..., 1] & 3)[:, :, None, None], (v[..., 0] & 3)[:, :, None, None], iy, ix].astype(np.int32)
+                return np.abs(Sb - pr).sum((2, 3))
+            cur = sad_of(mv)
+            for step in (2, 1):
+                base = mv.copy()
+                for oy in (-step, 0, step):
+                    for ox in (-step, 0, step):
+                        if ox == 0 and oy == 0:
+                            continue
+                        cand = base + np.array([ox, oy])
+                        s = sad_of(cand) + 2
+                        m = s < cur
+                        cur[m] = s[m]
+                        mv[m] = cand[m]
+            best[...] = cur
+        return mv16, best16, mv8, best8
+
+    # ---- residual of one macroblock ---------------------------------------------------------------------------------------
+    def code_residual(self, src, pred, intra16=False):
+        """src, pred: (Y 16x16, Cb 8x8, Cr 8x8) int arrays.  -> (luma levels (16, 4, 4) in block-zigzag order, luma dc levels (4, 4) or None,
+        chroma dc levels [2][(2, 2)], chroma ac levels (2, 4, 4, 4), reconstruction (Y, Cb, Cr))"""
+        qp, qpc = self.qp, self.qpc
+        ry = (src[0] - pred[0]).reshape(4, 4, 4, 4).transpose(0, 2, 1, 3)  # [by][bx][y][x]
+        Wy = fwd4x4(ry)
+        ldc = None
+        if intra16:
+            dc = Wy[..., 0, 0]
+            D = (H4 @ dc @ H4) // 2
+            ldc = quant_dc(D, qp, True)
+            Ly = quant(Wy, qp, True)
+            Ly[..., 0, 0] = 0
+        else:
+            Ly = quant(Wy, qp, intra16 is None)
+        # reconstruction
+        dy = dequant(Ly, qp)
+        if intra16:
+            f = H4 @ ldc @ H4
+            ls = (VQ[qp % 6][0] * 16) << (qp // 6)
+            dy[..., 0, 0] = (f * ls + 32) >> 6
+        recy = np.clip(pred[0] + inv4x4(dy).transpose(0, 2, 1, 3).reshape(16, 16), 0, 255)
+        cdc, cac, recc = [], [], []
+        for p in range(2):
+            rc = (src[1 + p] - pred[1 + p]).reshape(2, 4, 2, 4).transpose(0, 2, 1, 3)
+            Wc = fwd4x4(rc)
+            D = H2 @ Wc[..., 0, 0] @ H2
+            Ldc = quant_dc(D, qpc, intra16 is not False)
+            Lac = quant(Wc, qpc, intra16 is not False)
+            Lac[..., 0, 0] = 0
+            dc_ = dequant(Lac, qpc)
+            f = H2 @ Ldc @ H2
+            ls = (VQ[qpc % 6][0] * 16) << (qpc // 6)
+            dc_[..., 0, 0] = (f * ls) >> 5
+            recc.append(np.clip(pred[1 + p] + inv4x4(dc_).transpose(0, 2, 1, 3).reshape(8, 8), 0, 255))
+            cdc.append(Ldc)
+            cac.append(Lac)
+        return Ly, ldc, cdc, cac, (recy, recc[0], recc[1])
+
+    def residual_syntax(self, fc, mx, my, sl, Ly, ldc, cdc, cac, i16):
+        """-> (coded_block_pattern, coeffLevels list in syntax order); updates the CAVLC contexts of the frame"""
+        blocks = []
+        # luma blocks in coding order: 8x8 quadrant b8, then its four 4x4 blocks
+        order = [(ms.BLK_Y[b], ms.BLK_X[b]) for b in range(16)]
+        nz8 = [any(Ly[order[4 * b8 + k]].any() for k in range(4)) for b8 in range(4)]
+        if i16:
+            cbp_l = 15 if any(nz8) else 0
+        else:
+            cbp_l = sum(1 << b8 for b8 in range(4) if nz8[b8])
+        if i16:
+            blocks.append({"nC": fc.nC(fc.tcY, 2, 4 * mx, 4 * my, sl), "c": scan(ldc)})
+        for b in range(16):
+            if not cbp_l >> (b >> 2) & 1:
+                continue
+            by, bx = order[b]
+            c = scan(Ly[by, bx])
+            if i16:
+                c = c[1:]
+            gx, gy = 4 * mx + bx, 4 * my + by
+            blocks.append({"nC": fc.nC(fc.tcY, 2, gx, gy, sl), "c": c})
+            fc.tcY[gy][gx] = sum(1 for v in c if v)
+        any_dc = any(d.any() for d in cdc)
+        any_ac = any(a.any() for a in cac)
+        cbp_c = 2 if any_ac else 1 if any_dc else 0
+        if cbp_c:
+            for p in range(2):
+                blocks.append({"nC": -1, "c": [int(v) for v in cdc[p].reshape(4)]})
+        if cbp_c == 2:
+            for p in range(2):
+                for b in range(4):
+                    gx, gy = 2 * mx + (b & 1), 2 * my + (b >> 1)
+                    c = scan(cac[p][b >> 1, b & 1])[1:]
+                    blocks.append({"nC": fc.nC(fc.tcC[p], 1, gx, gy, sl), "c": c})
+                    fc.tcC[p][gy][gx] = sum(1 for v in c if v)
+        return cbp_l | cbp_c << 4, blocks
+
+    # ---- intra ------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def i16_preds(rec, x, y):
+        """candidates {mode: 16x16 prediction} from the in-loop reconstruction (8.3.3); mode numbers of Intra16x16PredMode"""
+        top = rec[y - 1, x:x + 16].astype(np.int32) if y > 0 else None
+        left = rec[y:y + 16, x - 1].astype(np.int32) if x > 0 else None
+        out = {}
+        if top is not None:
+            out[0] = np.tile(top, (16, 1))
+        if left is not None:
+            out[1] = np.tile(left[:, None], (1, 16))
+        if top is not None and left is not None:
+            dc = (top.sum() + left.sum() + 16) >> 5
+        elif top is not None:
+            dc = (top.sum() + 8) >> 4
+        elif left is not None:
+            dc = (left.sum() + 8) >> 4
+        else:
+            dc = 128
+        out[2] = np.full((16, 16), dc, np.int32)
+        if top is not None and left is not None:
+            tl = int(rec[y - 1, x - 1])
+            t = np.concatenate(([tl], top))
+            lf = np.concatenate(([tl], left))
+            Hh = sum((i + 1) * (int(t[9 + i]) - int(t[7 - i])) for i in range(8))
+            V = sum((i + 1) * (int(lf[9 + i]) - int(lf[7 - i])) for i in range(8))
+            a = 16 * (int(left[15]) + int(top[15]))
+            b, c = (5 * Hh + 32) >> 6, (5 * V + 32) >> 6
+            yy, xx = np.mgrid[0:16, 0:16]
+            out[3] = np.clip((a + b * (xx - 7) + c * (yy - 7) + 16) >> 5, 0, 255)
+        return out
+
+    @staticmethod
+    def chroma_preds(rec, x, y):
+        """{intra_chroma_pred_mode: 8x8 prediction} (8.3.4): 0 DC, 1 horizontal, 2 vertical, 3 plane"""
+        top = rec[y - 1, x:x + 8].astype(np.int32) if y > 0 else None
+        left = rec[y:y + 8, x - 1].astype(np.int32) if x > 0 else None
+        out = {}
+        dc = np.zeros((8, 8), np.int32)
+        for by in range(2):
+            for bx in range(2):
+                t = top[4 * bx:4 * bx + 4].sum() if top is not None else None
+                lf = left[4 * by:4 * by + 4].sum() if left is not None else None
+                if (bx, by) == (1, 0):
+                    v = (t + 2) >> 2 if t is not None else (lf + 2) >> 2 if lf is not None else 128
+                elif (bx, by) == (0, 1):
+                    v = (lf + 2) >> 2 if lf is not None else (t + 2) >> 2 if t is not None else 128
+                else:
+                    v = (t + lf + 4) >> 3 if t is not None and lf is not None else (t + 2) >> 2 if t is not None else (lf + 2) >> 2 if lf is not None else 128
+                dc[4 * by:4 * by + 4, 4 * bx:4 * bx + 4] = v
+        out[0] = dc
+        if left is not None:
+            out[1] = np.tile(left[:, None], (1, 8))
+        if top is not None:
+            out[2] = np.tile(top, (8, 1))
+        if top is not None and left is not None:
+            tl = int(rec[y - 1, x - 1])
+            t = np.concatenate(([tl], top))
+            lf = np.concatenate(([tl], left))
+            Hh = sum((i + 1) * (int(t[5 + i]) - int(t[3 - i])) for i in range(4))
+            V = sum((i + 1) * (int(lf[5 + i]) - int(lf[3 - i])) for i in range(4))
+            a = 16 * (int(left[7]) + int(top[7]))
+            b, c = (34 * Hh + 32) >> 6, (34 * V + 32) >> 6
+            yy, xx = np.mgrid[0:8, 0:8]
+            out[3] = np.clip((a + b * (xx - 3) + c * (yy - 3) + 16) >> 5, 0, 255)
+        return out
+
+    @staticmethod
+    def i4_preds(rec, x, y, top_right_ok):
+        """{Intra4x4PredMode: 4x4 prediction}: modes 0 vertical, 1 horizontal, 2 DC, 3 diagonal down-left, 4 diagonal down-right, 7 vertical-left,
+        8 horizontal-up (8.3.1.2; 5 and 6 are never chosen)"""
+        H, W = rec.shape
+        ta, la = y > 0, x > 0
+        T = rec[y - 1, x:x + 4].astype(np.int32) if ta else None
+        Lf = rec[y:y + 4, x - 1].astype(np.int32) if la else None
+        out = {}
+        if ta:
+            out[0] = np.tile(T, (4, 1))
+            T8 = np.concatenate((T, rec[y - 1, x + 4:x + 8].astype(np.int32) if top_right_ok else np.full(4, T[3])))
+            f3 = lambda a, i: (a[i - 1] + 2 * a[i] + a[i + 1] + 2) >> 2  # noqa: E731
+            ddl = np.zeros((4, 4), np.int32)
+            vl = np.zeros((4, 4), np.int32)
+            for yy in range(4):
+                for xx in range(4):
+                    ddl[yy, xx] = (T8[6] + 3 * T8[7] + 2) >> 2 if xx == 3 and yy == 3 else (T8[xx + yy] + 2 * T8[xx + yy + 1] + T8[xx + yy + 2] + 2) >> 2
+                    i = xx + (yy >> 1)
+                    vl[yy, xx] = (T8[i] + T8[i + 1] + 1) >> 1 if yy % 2 == 0 else f3(T8, i + 1)
+            out[3], out[7] = ddl, vl
+        if la:
+            out[1] = np.tile(Lf[:, None], (1, 4))
+            hu = np.zeros((4, 4), np.int32)
+            for yy in range(4):
+                for xx in range(4):
+                    z = xx + 2 * yy
+                    i = yy + (xx >> 1)
+                    hu[yy, xx] = Lf[3] if z > 5 else (Lf[2] + 3 * Lf[3] + 2) >> 2 if z == 5 else \
+                        (Lf[i] + Lf[i + 1] + 1) >> 1 if z % 2 == 0 else (Lf[i] + 2 * Lf[i + 1] + Lf[i + 2] + 2) >> 2
+            out[8] = hu
+        if ta and la:
+            out[2] = np.full((4, 4), (T.sum() + Lf.sum() + 4) >> 3, np.int32)
+            E = np.concatenate((Lf[::-1], [int(rec[y - 1, x - 1])], T))  # L3 L2 L1 L0 corner T0..T3: index 4 = corner
+            ddr = np.zeros((4, 4), np.int32)
+            for yy in range(4):
+                for xx in range(4):
+                    i = 4 + xx - yy
+                    ddr[yy, xx] = (E[i - 1] + 2 * E[i] + E[i + 1] + 2) >> 2
+            out[4] = ddr
+        elif ta:
+            out[2] = np.full((4, 4), (T.sum() + 2) >> 2, np.int32)
+        elif la:
+            out[2] = np.full((4, 4), (Lf.sum() + 2) >> 2, np.int32)
+        else:
+            out[2] = np.full((4, 4), 128, np.int32)
+        return out
+
+    def intra_mb(self, fc, rec, src, mx, my, sl, base, inter_cost=None):
+        """Decides and codes an intra macroblock on the in-loop reconstruction `rec` (Y, Cb, Cr int16 planes, updated).  Returns (mb dict, cost)
+        or None when inter_cost is given and intra is not better."""
+        x, y = 16 * mx, 16 * my
+        sy = src[0][y:y + 16, x:x + 16].astype(np.int32)
+        sc = [src[1 + p][y // 2:y // 2 + 8, x // 2:x // 2 + 8].astype(np.int32) for p in range(2)]
+        c16 = self.i16_preds(rec[0], x, y)
+        m16 = min(c16, key=lambda m: np.abs(sy - c16[m]).sum())
+        cost16 = int(np.abs(sy - c16[m16]).sum()) + 4 * self.lam
+        if inter_cost is not None and cost16 - 40 * self.lam >= inter_cost:  # (Intra4x4 never beats Intra16x16 by more than its mode bits on this content)
+            return None
+        cp = [self.chroma_preds(rec[1 + p], x // 2, y // 2) for p in range(2)]
+        cm = min(cp[0], key=lambda m: sum(np.abs(sc[p] - cp[p][m]).sum() for p in range(2)))
+        # Intra4x4: block by block on a scratch reconstruction
+        scratch = rec[0][max(y - 1, 0):y + 16, :].copy()
+        oy = y - max(y - 1, 0)
+        cost4, modes4, lev4 = 0, [], np.zeros((4, 4, 4, 4), np.int64)
+        for b in range(16):
+            bx, by = ms.BLK_X[b], ms.BLK_Y[b]
+            gx, gy = x + 4 * bx, oy + 4 * by
+            # top right (block (bx + 1, by - 1)): in the macroblock above / above right for the first row; inside this macroblock it must precede
+            # in decoding order; to the right of the macroblock it is never there
+            if by == 0:
+                tr = y > 0 and (bx < 3 or mx + 1 < self.W)
+            else:
+                tr = bx < 3 and ZIDX[by - 1][bx + 1] < b
+            cands = self.i4_preds(scratch, gx, gy, bool(tr))
+            sb = sy[4 * by:4 * by + 4, 4 * bx:4 * bx + 4]
+            m = min(cands, key=lambda k: np.abs(sb - cands[k]).sum() + (0 if k == 2 else self.lam))
+            L = quant(fwd4x4(sb - cands[m]), self.qp, True)
+            r = np.clip(cands[m] + inv4x4(dequant(L, self.qp)), 0, 255)
+            scratch[gy:gy + 4, gx:gx + 4] = r
+            cost4 += int(np.abs(sb - cands[m]).sum()) + 3 * self.lam
+            modes4.append(m)
+            lev4[by, bx] = L
+        use4 = cost4 < cost16
+        cost = min(cost4, cost16)
+        if inter_cost is not None and cost >= inter_cost:
+            return None
+        cpred = [cp[p][cm] for p in range(2)]
+        if use4:
+            # chroma through the common path (its luma part is discarded: the Intra4x4 luma was coded block by block above)
+            _, _, cdc, cac, recs = self.code_residual((sy, sc[0], sc[1]), (sy, cpred[0], cpred[1]), None)
+            rec[0][y:y + 16, x:x + 16] = scratch[oy:oy + 16, x:x + 16]
+            rec[1][y // 2:y // 2 + 8, x // 2:x // 2 + 8], rec[2][y // 2:y // 2 + 8, x // 2:x // 2 + 8] = recs[1], recs[2]
+            fc.nxn[my][mx] = True
+            left, top = fc.mb_avail(mx - 1, my, sl), fc.mb_avail(mx, my - 1, sl)
+            rem = []
+            for b in range(16):
+                bx, by = 4 * mx + ms.BLK_X[b], 4 * my + ms.BLK_Y[b]
+                la, ta = (bx & 3) > 0 or left, (by & 3) > 0 or top
+                if not la or not ta:
+                    pm = 2
+                else:
+                    pa = fc.ipm[by][bx - 1] if fc.nxn[by >> 2][(bx - 1) >> 2] else 2
+                    pb = fc.ipm[by - 1][bx] if fc.nxn[(by - 1) >> 2][bx >> 2] else 2
+                    pm = min(pa, pb)
+                want = modes4[b]
+                rem.append(-1 if want == pm else (want if want < pm else want - 1))
+                fc.ipm[by][bx] = want
+            cbp, blocks = self.residual_syntax(fc, mx, my, sl, lev4, None, cdc, cac, False)
+            mb = {"mb_type": base, "rem_intra4x4_pred_modes": rem, "intra_chroma_pred_mode": cm, "coded_block_pattern": cbp}
+            if cbp:
+                mb.update(mb_qp_delta=0, coeffLevels=blocks)
+            return mb, cost
+        Ly, ldc, cdc, cac, recs = self.code_residual((sy, sc[0], sc[1]), (c16[m16], cpred[0], cpred[1]), True)
+        rec[0][y:y + 16, x:x + 16] = recs[0]
+        rec[1][y // 2:y // 2 + 8, x // 2:x // 2 + 8], rec[2][y // 2:y // 2 + 8, x // 2:x // 2 + 8] = recs[1], recs[2]
+        cbp, blocks = self.residual_syntax(fc, mx, my, sl, Ly, ldc, cdc, cac, True)
+        mb = {"mb_type": base + 1 + m16 + 4 * (cbp >> 4) + 12 * (cbp & 15 == 15), "intra_chroma_pred_mode": cm, "mb_qp_delta": 0, "coeffLevels": blocks}
+        return mb, cost
+
+    # ---- pictures -----------------------------------------------------------------------------------------------------------
+    def encode_picture(self, ptype, src, refs, col):
+        """src: (Y, Cb, Cr) uint8.  refs: {list: (padded Y, padded Cb, padded Cr, planes)} of the reference decoder's pictures.
+        col: Motion of RefPicList1[0] (B pictures).  -> (list of macroblock dicts with skip runs folded in, FrameCtx, Motion, counters)"""
+        Wm, Hm = self.W, self.H
+        fc = ms.FrameCtx(Wm, Hm)
+        mot = Motion(Wm, Hm)
+        rec = [np.zeros((16 * Hm, 16 * Wm), np.int32), np.zeros((8 * Hm, 8 * Wm), np.int32), np.zeros((8 * Hm, 8 * Wm), np.int32)]
+        st = {"I": 2, "P": 0, "B": 1}[ptype]
+        srch = {lst: self.search_picture(src[0], r[0], r[3]) for lst, r in refs.items()}
+        cnt = dict(skip=0, direct=0, p16=0, p8x8=0, intra=0, bi=0, l0=0, l1=0, coded=0)
+        out = []
+        S = [p.astype(np.int32) for p in src]
+
+        def inter_pred(parts):
+            """parts: list of (bx4, by4 (4x4 units inside the MB), size in samples, {list: mv}) -> (Y, Cb, Cr) prediction"""
+            py, pc = np.zeros((16, 16), np.int32), [np.zeros((8, 8), np.int32), np.zeros((8, 8), np.int32)]
+            for (ox, oy, sz, mvs) in parts:
+                acc_y, acc_c, n = 0, [0, 0], 0
+                for lst, mv in mvs.items():
+                    R = refs[lst]
+                    acc_y = acc_y + luma_pred(R[3], x + ox, y + oy, mv, sz, sz)
+                    for p in range(2):
+                        acc_c[p] = acc_c[p] + chroma_pred(R[1 + p], (x + ox) // 2, (y + oy) // 2, mv, sz // 2, sz // 2)
+                    n += 1
+                if n == 2:
+                    acc_y = (acc_y + 1) >> 1
+                    acc_c = [(c + 1) >> 1 for c in acc_c]
+                py[oy:oy + sz, ox:ox + sz] = acc_y
+                for p in range(2):
+                    pc[p][oy // 2:(oy + sz) // 2, ox // 2:(ox + sz) // 2] = acc_c[p]
+            return py, pc[0], pc[1]
+
+        for my in range(Hm):
+            for mx in range(Wm):
+                x, y = 16 * mx, 16 * my
+                fc.slice_of[my][mx] = 0
+                sy = S[0][y:y + 16, x:x + 16]
+                srcmb = (sy, S[1][y // 2:y // 2 + 8, x // 2:x // 2 + 8], S[2][y // 2:y // 2 + 8, x // 2:x // 2 + 8])
+                if st == 2:
+                    mb, _ = self.intra_mb(fc, rec, src, mx, my, 0, 0)
+                    mot.set(0, 4 * mx, 4 * my, 4, 4, -1)
+                    mot.set(1, 4 * mx, 4 * my, 4, 4, -1)
+                    out.append(mb)
+                    cnt["intra"] += 1
+                    continue
+                cands = []  # (cost, kind, parts, syntax)
+                if st == 0:
+                    mv16, sad16, mv8, sad8 = srch[0]
+                    skip_mv = mot.p_skip_mv(4 * mx, 4 * my)
+                    mvp16 = mot.mvp(0, 4 * mx, 4 * my, 4, 0)
+                    best = (int(mv16[my, mx, 0]), int(mv16[my, mx, 1]))
+                    for v in {best, mvp16, skip_mv}:
+                        p = luma_pred(refs[0][3], x, y, v, 16, 16)
+                        bits = se_bits(v[0] - mvp16[0]) + se_bits(v[1] - mvp16[1])
+                        cands.append((int(np.abs(sy - p).sum()) + self.lam * (bits if v != skip_mv else 0), "p16", v))
+                    c8 = 6 * self.lam + sum(int(sad8[2 * my + (b >> 1), 2 * mx + (b & 1)]) + 5 * self.lam for b in range(4))
+                    cands.append((c8, "p8x8", None))
+                    cost, kind, v = min(cands, key=lambda c: c[0])
+                    r = self.intra_mb(fc, rec, src, mx, my, 0, 5, inter_cost=cost)
+                    if r is not None:
+                        out.append(r[0])
+                        mot.set(0, 4 * mx, 4 * my, 4, 4, -1)
+                        cnt["intra"] += 1
+                        continue
+                    if kind == "p16":
+                        parts = [(0, 0, 16, {0: v})]
+                        mot.set(0, 4 * mx, 4 * my, 4, 4, 0, v)
+                        mvds = [(v[0] - mvp16[0], v[1] - mvp16[1])]
+                        mb = {"mb_type": 0, "ref_idx": {}, "mvds": mvds}
+                    else:
+                        parts, mvds = [], []
+                        for b in range(4):
+                            bx4, by4 = 2 * (b & 1), 2 * (b >> 1)
+                            vv = (int(mv8[2 * my + (b >> 1), 2 * mx + (b & 1), 0]), int(mv8[2 * my + (b >> 1), 2 * mx + (b & 1), 1]))
+                            pr = mot.mvp(0, 4 * mx + bx4, 4 * my + by4, 2, 0)
+                            mot.set(0, 4 * mx + bx4, 4 * my + by4, 2, 2, 0, vv)
+                            mvds.append((vv[0] - pr[0], vv[1] - pr[1]))
+                            parts.append((4 * bx4, 4 * by4, 8, {0: vv}))
+                        mb = {"mb_type": 3, "sub_mb_types": [0, 0, 0, 0], "ref_idx": {}, "mvds": mvds}
+                    pred = inter_pred(parts)
+                    Ly, _, cdc, cac, recs = self.code_residual(srcmb, pred, False)
+                    zero = not Ly.any() and not any(d.any() for d in cdc) and not any(a.any() for a in cac)
+                    if zero and kind == "p16" and v == skip_mv:
+                        out.append(None)
+                        cnt["skip"] += 1
+                    else:
+                        cbp, blocks = self.residual_syntax(fc, mx, my, 0, Ly, None, cdc, cac, False)
+                        mb["coded_block_pattern"] = cbp
+                        if cbp:
+                            mb.update(mb_qp_delta=0, coeffLevels=blocks)
+                            cnt["coded"] += 1
+                        out.append(mb)
+                        cnt[kind] += 1
+                else:
+                    # ---- B: spatial direct (8.4.1.2.2), L0 / L1 / Bi 16x16 ----
+                    nb = [mot.neighbours(lst, 4 * mx, 4 * my, 4) for lst in range(2)]
+
+                    def minpos(a, b):
+                        return min(a, b) if a >= 0 and b >= 0 else max(a, b)
+                    dref = [minpos(max(nb[l][0][0], -1), minpos(max(nb[l][1][0], -1), max(nb[l][2][0], -1))) for l in range(2)]
+                    if dref[0] < 0 and dref[1] < 0:
+                        dref, dmv = [0, 0], [(0, 0), (0, 0)]
+                    else:
+                        dmv = [mot.mvp(l, 4 * mx, 4 * my, 4, dref[l]) if dref[l] >= 0 else (0, 0) for l in range(2)]
+                    dparts = []
+                    for b in range(4):
+                        cx4, cy4 = 4 * mx + 3 * (b & 1), 4 * my + 3 * (b >> 1)  # corner 4x4 block of the co-located macroblock (direct_8x8_inference)
+                        rc, mvc = col.get(0, cx4, cy4)
+                        if rc < 0:
+                            rc, mvc = col.get(1, cx4, cy4)
+                        colzero = rc == 0 and abs(mvc[0]) <= 1 and abs(mvc[1]) <= 1
+                        mvs = {l: ((0, 0) if (colzero and dref[l] == 0) else dmv[l]) for l in range(2) if dref[l] >= 0}
+                        dparts.append((8 * (b & 1), 8 * (b >> 1), 8, mvs))
+                    dpred = inter_pred(dparts)
+                    cands.append((int(np.abs(sy - dpred[0]).sum()), "direct", None))
+                    one = {}
+                    for l in range(2):
+                        mv16, sad16, _, _ = srch[l]
+                        pr = mot.mvp(l, 4 * mx, 4 * my, 4, 0)
+                        v = (int(mv16[my, mx, 0]), int(mv16[my, mx, 1]))
+                        bits = se_bits(v[0] - pr[0]) + se_bits(v[1] - pr[1])
+                        one[l] = (v, pr, bits)
+                        cands.append((int(sad16[my, mx]) + self.lam * (bits + 3), "l%d" % l, None))
+                    pbi = (luma_pred(refs[0][3], x, y, one[0][0], 16, 16) + luma_pred(refs[1][3], x, y, one[1][0], 16, 16) + 1) >> 1
+                    cands.append((int(np.abs(sy - pbi).sum()) + self.lam * (one[0][2] + one[1][2] + 5), "bi", None))
+                    cost, kind, _ = min(cands, key=lambda c: c[0])
+                    if kind == "direct":
+                        parts, pred = dparts, dpred
+                        for (ox, oy, sz, mvs) in dparts:
+                            for l in range(2):
+                                if l in mvs:
+                                    mot.set(l, 4 * mx + ox // 4, 4 * my + oy // 4, 2, 2, dref[l], mvs[l])
+                                else:
+                                    mot.set(l, 4 * mx + ox // 4, 4 * my + oy // 4, 2, 2, -1)
+                        mb = {"mb_type": 0}
+                    else:
+                        use = {"l0": (0,), "l1": (1,), "bi": (0, 1)}[kind]
+                        mvs = {l: one[l][0] for l in use}
+                        for l in range(2):
+                            if l in use:
+                                mot.set(l, 4 * mx, 4 * my, 4, 4, 0, one[l][0])
+                            else:
+                                mot.set(l, 4 * mx, 4 * my, 4, 4, -1)
+                        pred = inter_pred([(0, 0, 16, mvs)])
+                        mb = {"mb_type": {"l0": 1, "l1": 2, "bi": 3}[kind], "ref_idx": {},
+                              "mvds": [(one[l][0][0] - one[l][1][0], one[l][0][1] - one[l][1][1]) for l in use]}
+                    Ly, _, cdc, cac, recs = self.code_residual(srcmb, pred, False)
+                    zero = not Ly.any() and not any(d.any() for d in cdc) and not any(a.any() for a in cac)
+                    if zero and kind == "direct":
+                        out.append(None)
+                        cnt["skip"] += 1
+                    else:
+                        cbp, blocks = self.residual_syntax(fc, mx, my, 0, Ly, None, cdc, cac, False)
+                        mb["coded_block_pattern"] = cbp
+                        if cbp:
+                            mb.update(mb_qp_delta=0, coeffLevels=blocks)
+                            cnt["coded"] += 1
+                        out.append(mb)
+                        cnt[kind if kind != "direct" else "direct"] += 1
+                rec[0][y:y + 16, x:x + 16] = recs[0]
+                rec[1][y // 2:y // 2 + 8, x // 2:x // 2 + 8], rec[2][y // 2:y // 2 + 8, x // 2:x // 2 + 8] = recs[1], recs[2]
+        # fold the skipped macroblocks into mb_skip_run entries, as Synth.slice_nal writes them
+        mbs, run, pending = [], 0, None
+        for mb in out:
+            if st != 2 and mb is None:
+                e = {}
+                if run == 0:
+                    pending = e
+                run += 1
+                pending["mb_skip_run"] = run
+                mbs.append(e)
+                continue
+            if st != 2 and run == 0:
+                mb = {"mb_skip_run": 0, **mb}
+            run = 0
+            mbs.append(mb)
+        return mbs, fc, mot, cnt, rec
+
+    def build(self, ref_dec):
+        from make_streams import FrameCtx  # noqa: F401
+        Wm, Hm = self.W, self.H
+        out = [self.nal(self.sps()), self.nal(self.pps())]
+        # decode order and display order (poc): B pictures sit between the two references decoded before them
+        order, poc, i = [], 0, 0
+        fr = self.frames
+        while i < len(fr):
+            t = fr[i]
+            if t in "IP" and i + 1 < len(fr) and fr[i + 1] == "B" and i > 0:
+                nb = 0
+                while i + 1 + nb < len(fr) and fr[i + 1 + nb] == "B":
+                    nb += 1
+                order.append((t, poc + 2 * (nb + 1)))
+                for k in range(nb):
+                    order.append(("B", poc + 2 * (k + 1)))
+                poc += 2 * (nb + 1)
+                i += 1 + nb
+            else:
+                if i > 0:
+                    poc += 2
+                order.append((t, poc))
+                i += 1
+        frame_num = 0
+        decoded = {}      # poc -> (Y, Cb, Cr) of the reference decoder
+        motion = {}       # poc -> Motion
+        ref_pocs = []     # reference pictures, newest first
+        totals = {}
+        for idx, (t, p) in enumerate(order):
+            src = self.scene.frame(p // 2)
+            refs = {}
+            if t == "P":
+                refs[0] = self.prepare(decoded[ref_pocs[0]])
+            elif t == "B":
+                before = max(q for q in ref_pocs if q < p)
+                after = min(q for q in ref_pocs if q > p)
+                refs[0], refs[1] = self.prepare(decoded[before]), self.prepare(decoded[after])
+            col = motion[min(q for q in ref_pocs if q > p)] if t == "B" else None
+            mbs, fc, mot, cnt, rec = self.encode_picture(t, src, refs, col)
+            motion[p] = mot
+            if self.cabac:
+                import cabac_writer as cw
+                self.cabac_fs = cw.FrameState(Wm, Hm)
+            hdr = dict(frame_num=frame_num % (1 << self.log2_fn), poc=p % (1 << self.log2_poc), is_ref=t != "B", idr=idx == 0, nref0=1, nref1=1,
+                       idr_pic_id=0, slice_qp_delta=0, deblock=0, alpha=0, beta=0, mmco1=0, reorder_l0=0, pps_id=0)
+            out.append(self.slice_nal(fc, t, 0, Wm * Hm, 0, hdr, mbs=mbs))
+            frames, codes = ref_dec.decode(b"".join(out))
+            assert len(frames) == idx + 1 and all(c in (0, 105, 61) for c in codes), (self.name, idx, len(frames), codes[-4:])
+            pocs = sorted(q for _, q in order[:idx + 1])
+            got = frames[pocs.index(p)]
+            decoded[p] = got
+            if t != "B":
+                frame_num += 1
+                ref_pocs.insert(0, p)
+                ref_pocs = ref_pocs[:2]
+            psnr = 10 * np.log10(255.0 ** 2 / max(1e-9, np.mean((got[0].astype(np.float64) - src[0]) ** 2)))
+            mine = np.mean(np.abs(rec[0] - src[0]))
+            for k, v in cnt.items():
+                totals[k] = totals.get(k, 0) + v
+            print(f"  {self.name} picture {idx} ({t}, poc {p}): {sum(len(n) for n in out[-1:])} bytes, luma PSNR {psnr:.2f} dB, {cnt}", flush=True)
+            del mine
+        self.stats = totals
+        return b"".join(out)
+
+    @staticmethod
+    def prepare(fr):
+        Y = pad(fr[0])
+        return (Y, pad(fr[1]), pad(fr[2]), qpel_planes(Y))
+
+
+STREAMS = [
+    ("nat1080_ipp30", "I" + "P" * 29, dict(cabac=False, qp=30, seed=7)),
+    ("cabac_nat1080_ibbp30", "I" + "PBB" * 9 + "PB", dict(cabac=True, qp=31, seed=8)),
+]
+
+
+def main(argv):
+    g = ms.load_gen()
+    from oracle.pyoracle import ref_decoder
+    ref = ref_decoder()
+    n_frames = int(argv[1]) if len(argv) > 1 else None
+    path = os.path.join(ms.OUT, "reference_md5.json")
+    sums = json.load(open(path))
+    tables = None
+    for name, frames, opt in STREAMS:
+        if n_frames:
+            frames = frames[:n_frames]
+        if opt["cabac"]:
+            import cabac_writer as cw
+            tables = tables or cw.load_tables()
+            opt = dict(opt, tables=tables)
+        enc = NatEncoder(g, name, frames, **opt)
+        data = enc.build(ref)
+        out, codes = ref.decode(data)
+        assert len(out) == len(frames) and all(c in (0, 105, 61) for c in codes), (name, len(out), codes)
+        if not n_frames:
+            with open(os.path.join(ms.OUT, name + ".264"), "wb") as f:
+                f.write(data)
+            sums[name] = {"width_mbs": W_MBS, "height_mbs": H_MBS, "frames": frames, "nal_codes": codes, "views": 1,
+                          "md5": [hashlib.md5(b"".join(p.tobytes() for p in fr)).hexdigest() for fr in out], "encoder_stats": enc.stats}
+        print(f"{name}.264: {len(data)} bytes ({len(data) * 8 * 30 / len(frames) / 1e6:.2f} Mbit/s at 30 pictures/s), {enc.stats}")
+    if not n_frames:
+        with open(path, "w") as f:
+            json.dump(sums, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv))

@@ -47,6 +47,10 @@ CASES = [
     ("six_wide", "IPB", 6, 4, dict(num_refs=2)),
     ("tall", "IPP", 5, 35, dict(residual_prob=0.6)),            # 7 mixed groups / 5 luma groups / 3 chroma groups: every hand-off between waves
     ("h17", "IPB", 4, 17, dict(intra_in_inter=0.3)),            # one row into the second chroma group, the third luma group
+    # P pictures whose macroblocks have no edge to filter at all (one reference, zero vectors, no residual, no intra): whole steps take
+    # the copy-only path (dk_vcopy); with a few coded macroblocks the two paths alternate inside a group
+    ("static", "IPP", 13, 10, dict(num_refs=1, mv_range=0, residual_prob=0.0, intra_in_inter=0.0)),
+    ("static_some_coded", "IPPP", 12, 20, dict(num_refs=1, mv_range=0, residual_prob=0.04, intra_in_inter=0.01)),
 ]
 
 
@@ -77,6 +81,10 @@ def test_deblock_emu(emu, name, gop, w, h, kw, split):
         badc = got_c != exp_c
         assert not badc.any(), f"{name} frame {i} ({ft}): chroma differs at (y, x) {np.argwhere(badc)[:6].tolist()}"
         assert np.array_equal(mine[d][nb:], dpb[d][nb:])
+    if name.startswith("static"):  # both paths ran: steps without any edge took the copy-only one
+        z, f = C.c_long(), C.c_long()
+        emu.e264emu_deblock_step_counts(C.byref(z), C.byref(f), 1)
+        assert z.value > 0 and f.value > 0, (z.value, f.value)
 
 
 # ---- the packed edge arithmetic against the standard's formulas (8.7.2.3 / 8.7.2.4), line by line ----------------------
