@@ -163,8 +163,10 @@ E264_DEV void dk_edge(s16x2 *v, s16x2 alphaE, s16x2 beta, s16x2 betal, s16x2 tc0
 #ifdef E264_ABL_DBK_NOFILTER // timing ablation
 	if (as_u(go) != 0x12345) return;
 #endif
+#ifndef E264_DBK_NOEARLY // (measuring aid: what the wave-wide "no lane filters this edge" test is worth)
 	if (!DK_ANY(as_u(go)))
 		return;
+#endif
 	const s16x2 zero2 = {0, 0};
 	const s16x2 ap = LUMA ? ((dk_abs(p2 - p0) - betal) >> 15) & go : zero2, aq = LUMA ? ((dk_abs(q2 - q0) - betal) >> 15) & go : zero2;
 	// ---- bS < 4
@@ -398,7 +400,8 @@ template <int K> E264_DEV void dk_vcopy(DkWaveT<K> &W, const DkRole &R, const v4
 // does the macroblock's parameter record name any edge at all?  (bytes 0..31: bS[direction][edge][segment])
 E264_DEV uint32_t dk_any_bs(const uint32_t *prm) { return prm[0] | prm[1] | prm[2] | prm[3] | prm[4] | prm[5] | prm[6] | prm[7]; }
 #ifndef E264_DBK_ZEROSKIP
-#define E264_DBK_ZEROSKIP 1
+#define E264_DBK_ZEROSKIP 0 // measured (profiles/r05_ablations.txt item 5): the eight macroblocks of a step lie on a diagonal through eight rows; on the
+                            // encoder-made fixtures 58 % of the macroblocks have no edge but only 6.6 % of the steps: no gain there, -1.4 % on the bench GOP
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------------
