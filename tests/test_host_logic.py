@@ -208,6 +208,43 @@ def test_round4_bench_line_says_what_it_measures():
     assert abs(d["value"] - d["config"]["frames_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
 
 
+def test_round5_bench_line_carries_the_system_figure():
+    """profiles/r05_bench_default.json = stdout of `python bench.py` on the MI355X, round 5: a `system` leg (the whole
+    decoder with the host inside the clock: e264_multi, parser + emitters alone and end to end, next to cpu_baseline on the same files and cores),
+    the encoder-shaped fixtures in `same_input` with per-kernel times, the CPU legs taken under the launcher's affinity, one page-locked buffer
+    per stream and frame in the pinned leg, configs[3] on the same number of distinct GOPs as the headline."""
+    import json
+    lines = [l for l in open(os.path.join(ROOT, "profiles", "r05_bench_default.json")).read().splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == base["metric"] and d["unit"] == "frames/s" and d["dtype"] == "u8" and d["vs_baseline"] is None
+    assert d["bit_exact"] is True and d["build_flags"] == ""
+    assert abs(d["value"] - d["config"]["frames_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+    r = d["roofline"]
+    k = r["kernels"][r["kernel"]]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - (k["sample_bytes"] + k["command_bytes"]) / (k["ms_per_launch"] * 1e-3) / 1e9) < 1.0
+    assert r["traffic"] > 0 and r["traffic_source"]["file"].startswith("profiles/r05")
+    sy = d["system"]
+    assert sy["threads"] >= 1 and sy["cores"] >= sy["threads"] and len(sy["files"]) == 4
+    for leg in ("parse_only", "end_to_end"):
+        assert sy[leg]["frames_per_s"] > 0 and sy[leg]["decode_ms_per_picture"] > 0 and sy[leg]["frames"] > 1000
+    assert abs(sy["end_to_end_vs_parse_only"] - sy["end_to_end"]["frames_per_s"] / sy["parse_only"]["frames_per_s"]) < 0.01
+    assert sy["host_cores_for_1000_streams_1080p30"] > 0 and sy["cpu_reference_frames_per_s"] == d["cpu_baseline"]["value"]
+    si = d["same_input"]
+    assert si["bit_exact"] is True and si["files"] == ["hd1080_ipp30.264", "cabac_hd1080_ibbp30.264", "nat1080_ipp30.264", "cabac_nat1080_ibbp30.264"]
+    for f in si["files"]:
+        pf = si["per_file"][f]
+        assert pf["mismatching"] == 0 and pf["pictures"] == 30 and all(v >= 0 for v in pf["kernel_ms_per_launch"].values())
+    assert "launcher" in d["cpu_baseline"]["affinity"] and d["cpu_baseline"]["same_input"] is True
+    p = d["pcie_inclusive"]
+    assert p["value"] > 30000 and p["pinned_in_place"]["value"] > 30000
+    assert p["pinned_in_place"]["pinned_buffers"] == d["config"]["streams_per_gpu"] * 8   # one per stream and frame of the GOP
+    for v in d["other_configs"].values():
+        assert v["bit_exact"] is True and v["distinct_pictures"] == 4 * len(v["gop"])
+
+
 def test_bench_gpus_flag_spawns_ranks(tmp_path):
     """`python bench.py --gpus 2` outside torchrun launches 2 ranks itself (torch.distributed.run, here gloo + a stub device):
     rank 0 prints ONE line with n_gpus 2 and the frames of BOTH ranks' stream shards; a mismatch between --gpus and an
