@@ -207,6 +207,9 @@ E264_DEV void dk_edge(s16x2 *v, s16x2 alphaE, s16x2 beta, s16x2 betal, s16x2 tc0
 // directions in one batch at the top of a step (two LDS round trips in all: the record's bytes, then the tC0 table) --
 // fetched where they are used, slot by slot behind the branches that skip idle edges, they cost a dozen exposed LDS
 // latencies per step with only two waves per SIMD to hide them.
+#ifndef E264_DBK_PIN_PARAMS
+#define E264_DBK_PIN_PARAMS 1
+#endif
 struct DkPrm { s16x2 al[4], be[4], tc[4]; uint32_t bS[4]; s16x2 thr, strong0, strong2; }; // al: alpha, or 0 where bS is 0
 // Luma lanes: slot e = edge e of the macroblock.  Chroma lanes: slot 0 = Cb macroblock edge, 1 = Cb inner edge, 2 = Cr
 // macroblock edge, 3 = Cr inner edge.  prm: the macroblock's 64-byte parameter record in LDS.
@@ -242,6 +245,24 @@ template <int K> E264_DEV void dk_params(const uint8_t *prm, const uint8_t *tc0t
 		P[dir].strong0 = dk_dup(P[dir].bS[0] == 4 ? 0xffffu : 0u);
 		P[dir].strong2 = dk_dup(P[dir].bS[2] == 4 ? 0xffffu : 0u);
 	}
+#if E264_DBK_PIN_PARAMS && !defined(E264_HOST_INTRINSICS)
+	// Round 5: the batch above is the point of this function -- and the compiler undid it: every value that is only used behind an edge's
+	// `no lane filters it` branch was SUNK into that branch, LDS reads included (the indexA byte, then the tC0 table look-up that depends on it:
+	// two exposed LDS round trips per edge, sixteen per step, with two waves per SIMD to hide them).  An opaque use here keeps them where they
+	// are computed.
+#pragma unroll
+	for (int dir = 0; dir < 2; dir++) {
+#pragma unroll
+		for (int e = 0; e < 4; e++) {
+			uint32_t a = as_u(P[dir].al[e]), b = as_u(P[dir].be[e]), c = as_u(P[dir].tc[e]);
+			asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
+			P[dir].al[e] = as_s2(a); P[dir].be[e] = as_s2(b); P[dir].tc[e] = as_s2(c);
+		}
+		uint32_t t = as_u(P[dir].thr), s0 = as_u(P[dir].strong0), s2 = as_u(P[dir].strong2);
+		asm volatile("" : "+v"(t), "+v"(s0), "+v"(s2));
+		P[dir].thr = as_s2(t); P[dir].strong0 = as_s2(s0); P[dir].strong2 = as_s2(s2);
+	}
+#endif
 }
 // The four edge slots of a line pair held in v[0..19] (positions -4..15): slot e works on v[4e .. 4e+7]; in chroma lanes
 // only p1 p0 q0 q1 = v[4e+2 .. 4e+5] matter.
