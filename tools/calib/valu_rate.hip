@@ -47,18 +47,25 @@ __global__ __launch_bounds__(256) void name(uint32_t *out, unsigned long long *c
 #define A_DOT4(n) "v_dot4_i32_i8 %" #n ", %4, %5, %" #n "\n"
 #define A_SAD(n) "v_sad_u8 %" #n ", %4, %5, %" #n "\n"
 #define A_BFE(n) "v_bfe_u32 %" #n ", %" #n ", 8, 8\n"
+// round 5: which of v_cndmask_b32's forms is the slow one (0.105 G/s above), and what a compare + select pair or a bit-field insert costs instead
+#define A_CND64V(n) "v_cndmask_b32_e64 %" #n ", %" #n ", %4, vcc\n"
+#define A_CMPCND(n) "v_cmp_lt_u32_e32 vcc, %" #n ", %5\n v_cndmask_b32_e32 %" #n ", %" #n ", %4, vcc\n"
+#define A_CMPCND64(n) "v_cmp_lt_u32_e64 s[10:11], %" #n ", %5\n v_cndmask_b32_e64 %" #n ", %" #n ", %4, s[10:11]\n"
+#define A_BFI(n) "v_bfi_b32 %" #n ", %5, %" #n ", %4\n"
 KERNEL(k_add, A_ADD) KERNEL(k_pkadd, A_PKADD) KERNEL(k_pkmad, A_PKMAD) KERNEL(k_pkmul, A_PKMUL) KERNEL(k_pkashr, A_PKASHR)
 KERNEL(k_pkmax, A_PKMAX) KERNEL(k_perm, A_PERM) KERNEL(k_alignb, A_ALIGNB) KERNEL(k_lerp, A_LERP) KERNEL(k_cndmask, A_CNDMASK)
 KERNEL(k_mad24, A_MAD24) KERNEL(k_mullo, A_MULLO) KERNEL(k_fma, A_FMA) KERNEL(k_med3, A_MED3) KERNEL(k_add3, A_ADD3)
 KERNEL(k_cnd64, A_CNDMASK64) KERNEL(k_max32, A_MAX32) KERNEL(k_lshr, A_LSHR) KERNEL(k_and, A_AND) KERNEL(k_mul24, A_MUL24) KERNEL(k_addu16, A_ADDU16) KERNEL(k_mov, A_MOV)
 KERNEL(k_lshladd, A_LSHLADD) KERNEL(k_sdwa, A_SDWA) KERNEL(k_dot4, A_DOT4) KERNEL(k_sad, A_SAD) KERNEL(k_bfe, A_BFE)
+KERNEL(k_cnd64v, A_CND64V) KERNEL(k_cmpcnd, A_CMPCND) KERNEL(k_cmpcnd64, A_CMPCND64) KERNEL(k_bfi, A_BFI)
 typedef void (*kern_t)(uint32_t *, unsigned long long *);
 int main()
 {
 	struct { const char *name; kern_t k; } ks[] = {{"v_add_u32", k_add}, {"v_pk_add_u16", k_pkadd}, {"v_pk_mad_u16", k_pkmad}, {"v_pk_mul_lo_u16", k_pkmul},
 		{"v_pk_ashrrev_i16", k_pkashr}, {"v_pk_max_i16", k_pkmax}, {"v_perm_b32", k_perm}, {"v_alignbyte_b32", k_alignb}, {"v_lerp_u8", k_lerp},
 		{"v_cndmask_b32", k_cndmask}, {"v_cndmask_b32_e64 sgpr", k_cnd64}, {"v_max_i32", k_max32}, {"v_lshrrev_b32", k_lshr}, {"v_and_b32", k_and}, {"v_mul_u32_u24", k_mul24}, {"v_add_u16", k_addu16}, {"v_mov_b32", k_mov}, {"v_mad_i32_i24", k_mad24}, {"v_mul_lo_u32", k_mullo}, {"v_fma_f32", k_fma}, {"v_med3_i32", k_med3},
-		{"v_add3_u32", k_add3}, {"v_lshl_add_u32", k_lshladd}, {"v_add_u32_sdwa", k_sdwa}, {"v_dot4_i32_i8", k_dot4}, {"v_sad_u8", k_sad}, {"v_bfe_u32", k_bfe}};
+		{"v_add3_u32", k_add3}, {"v_lshl_add_u32", k_lshladd}, {"v_add_u32_sdwa", k_sdwa}, {"v_dot4_i32_i8", k_dot4}, {"v_sad_u8", k_sad}, {"v_bfe_u32", k_bfe},
+		{"v_cndmask_b32_e64 vcc", k_cnd64v}, {"v_cmp_e32 + v_cndmask_e32 (vcc), PAIRS", k_cmpcnd}, {"v_cmp_e64 + v_cndmask_e64 (sgpr), PAIRS", k_cmpcnd64}, {"v_bfi_b32", k_bfi}};
 	const int blocks = 256 * 4; // 4 workgroups of 4 waves per CU = 4 waves per SIMD
 	uint32_t *out; unsigned long long *cyc;
 	hipMalloc((void **)&out, blocks * 256 * 4); hipMalloc((void **)&cyc, 8);
