@@ -29,8 +29,14 @@ struct __attribute__((aligned(16))) DbkpLds {
 	uint32_t out[DP_MBS][16];
 	int8_t fo[DP_MBS][2];              // FilterOffsetA / B of each macroblock's slice
 	uint8_t alpha[52], beta[52];
+	uint32_t any_l1;                   // some record of the workgroup (own, left, top) predicts from list 1
 };
 
+#ifndef E264_HOST_INTRINSICS
+E264_DEV void dbkp_note_l1(uint32_t *p) { atomicOr(p, 1u); }
+#else
+E264_DEV void dbkp_note_l1(uint32_t *p) { *p |= 1u; }
+#endif
 // macroblock address of record j
 E264_DEV int dbkp_addr(const FrameCtx &f, int a0, int j)
 {
@@ -47,6 +53,7 @@ E264_DEV void dbkp_phase_load(DbkpLds &L, const FrameCtx &f, int a0, int tid)
 		*(v4u *)&L.hdr[j][part * 4] = *(const gv4u *)(mbs_g + (size_t)dbkp_addr(f, a0, j) * 32 + part * 16);
 	}
 	if (tid < 52) { L.alpha[tid] = c_alpha[tid]; L.beta[tid] = c_beta[tid]; }
+	if (tid == 0) L.any_l1 = 0;
 }
 
 // One list of a macroblock's compact motion record (edge264_cmd.h E264_MOT_*) -> the per-4x4 form the comparisons index:
@@ -99,8 +106,11 @@ E264_DEV void dbkp_phase_slices(DbkpLds &L, const FrameCtx &f, int tid)
 	if (f.motion)
 		for (int i = tid; i < (2 * DP_MBS + 1) * 2; i += DP_NT) {
 			const int j = i >> 1, l = i & 1;
-			if ((L.hdr[j][0] & 255) == E264_MB_INTER)
+			if ((L.hdr[j][0] & 255) == E264_MB_INTER) {
 				dbkp_expand_list(f.motion, L.hdr[j][5], L.hdr[j][6], l, L.mo[j]);
+				const uint32_t h = L.hdr[j][6];
+				if (l && (E264_MOT_UNI(h, 1) || (h >> 4 & 15u))) dbkp_note_l1(&L.any_l1); // (E264_MOT_USED(h, 4..7): the quadrants of list 1)
+			}
 		}
 	if (tid < DP_MBS) {
 		cslice_t s = f.slices + (L.hdr[1 + tid][7] & 0xffff); // E264Mb.dbk_slice
@@ -125,6 +135,10 @@ E264_DEV uint32_t dbkp_absdiff2(uint32_t A, uint32_t B)
 // Round 2 computed one bS per task (32 tasks per macroblock): neighbour selection, flags and the block numbering were
 // worked out 32 times, every vector difference in 32-bit arithmetic -- the kernel ran at the VALU issue limit (170 M
 // wave-instructions per 256 pictures, profiles/r03_pmc_sq_instruction_mix.txt).
+// L1 = false (round 5): no record of the workgroup predicts from list 1 (every workgroup of a P picture): the list-1 halves of the comparison are
+// constants -- references 0xff on both sides, vectors 0 -- so "same lists" reduces to the list-0 reference and vector, and "crossed lists" is always a
+// difference (a used list-0 slot against 0xff).  A quarter of the vector arithmetic of the general form.
+template <bool L1>
 E264_DEV uint32_t dbkp_bs4(const uint32_t *hm, const uint32_t *mm, const uint32_t *hL, const uint32_t *mL, const uint32_t *hT, const uint32_t *mT,
 	bool has_motion, bool on, int dir, int e)
 {
@@ -153,12 +167,18 @@ E264_DEV uint32_t dbkp_bs4(const uint32_t *hm, const uint32_t *mm, const uint32_
 		uint32_t bs = ((nzp >> kp | nzq >> kq) & 1u) ? 2u : 0u;
 		if (has_motion) { // (uniform) references as bytes (unused list: 0xff), vectors biased for dbkp_absdiff2 (unused list: 0)
 			const int sq = (kq >> 2) * 8, sp = (kp >> 2) * 8;
-			const uint32_t q0 = mm[0] >> sq & 255u, q1 = mm[1] >> sq & 255u, p0 = mn[0] >> sp & 255u, p1 = mn[1] >> sp & 255u;
-			const uint32_t vq0 = mm[4 + kq] ^ DBKP_BIAS, vq1 = mm[20 + kq] ^ DBKP_BIAS, vp0 = mn[4 + kp] ^ DBKP_BIAS, vp1 = mn[20 + kp] ^ DBKP_BIAS;
-			// same lists, or crossed (deblock.c:913-925): a difference either way
-			const uint32_t par = (p0 ^ q0) | (p1 ^ q1) | ((dbkp_absdiff2(vp0, vq0) | dbkp_absdiff2(vp1, vq1)) & DBKP_FAR);
-			const uint32_t crs = (p0 ^ q1) | (p1 ^ q0) | ((dbkp_absdiff2(vp0, vq1) | dbkp_absdiff2(vp1, vq0)) & DBKP_FAR);
-			if (bs == 0) bs = (par != 0 && crs != 0) ? 1u : 0u;
+			if (L1) {
+				const uint32_t q0 = mm[0] >> sq & 255u, q1 = mm[1] >> sq & 255u, p0 = mn[0] >> sp & 255u, p1 = mn[1] >> sp & 255u;
+				const uint32_t vq0 = mm[4 + kq] ^ DBKP_BIAS, vq1 = mm[20 + kq] ^ DBKP_BIAS, vp0 = mn[4 + kp] ^ DBKP_BIAS, vp1 = mn[20 + kp] ^ DBKP_BIAS;
+				// same lists, or crossed (deblock.c:913-925): a difference either way
+				const uint32_t par = (p0 ^ q0) | (p1 ^ q1) | ((dbkp_absdiff2(vp0, vq0) | dbkp_absdiff2(vp1, vq1)) & DBKP_FAR);
+				const uint32_t crs = (p0 ^ q1) | (p1 ^ q0) | ((dbkp_absdiff2(vp0, vq1) | dbkp_absdiff2(vp1, vq0)) & DBKP_FAR);
+				if (bs == 0) bs = (par != 0 && crs != 0) ? 1u : 0u;
+			} else { // list 0 only on both sides (the bias cancels in the difference)
+				const uint32_t q0 = mm[0] >> sq & 255u, p0 = mn[0] >> sp & 255u;
+				const uint32_t par = (p0 ^ q0) | (dbkp_absdiff2(mn[4 + kp] ^ DBKP_BIAS, mm[4 + kq] ^ DBKP_BIAS) & DBKP_FAR);
+				if (bs == 0) bs = par != 0 ? 1u : 0u;
+			}
 		}
 		out |= bs << (8 * sg);
 	}
@@ -192,8 +212,13 @@ E264_DEV void dbkp_phase_compute(DbkpLds &L, const FrameCtx &f, int a0, int tid)
 	const bool on = a0 + i < n_mbs && (h0 >> 8 & E264_MBF_DEBLOCK) && (h0 & 255) != E264_MB_ABSENT;
 	const int dir = r >> 1, e0 = (r & 1) * 2;
 	v2u bs;
-	bs.x = dbkp_bs4(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], L.mo[rt], has_motion, on, dir, e0);
-	bs.y = dbkp_bs4(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], L.mo[rt], has_motion, on, dir, e0 + 1);
+	if (L.any_l1) { // (uniform over the workgroup)
+		bs.x = dbkp_bs4<true>(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], L.mo[rt], has_motion, on, dir, e0);
+		bs.y = dbkp_bs4<true>(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], L.mo[rt], has_motion, on, dir, e0 + 1);
+	} else {
+		bs.x = dbkp_bs4<false>(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], L.mo[rt], has_motion, on, dir, e0);
+		bs.y = dbkp_bs4<false>(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], L.mo[rt], has_motion, on, dir, e0 + 1);
+	}
 	*(v2u *)&L.out[i][2 * r] = bs;
 	uint8_t *o8 = (uint8_t *)&L.out[i][0];
 	if (r < 3) {
