@@ -284,9 +284,14 @@ def system_leg(cpu, seconds=12.0):
             if out["seconds"] >= 0.6 * seconds:  # (long enough that the first loop's page-locking of ~400 packet buffers and first touches do not set the figure)
                 break
             loops = max(loops + 1, int(loops * seconds / max(out["seconds"], 0.05)))
-        res[key] = {"frames_per_s": out["frames_per_s"], "frames": out["frames"], "seconds": out["seconds"], "loops": loops,
-                    "decode_ms_per_picture": out.get("decode_ms_per_picture"), "avg_batch": out.get("avg_batch"),
-                    "thread_seconds": out.get("thread_seconds")}
+        st = out.get("steady") or {}
+        steady = st.get("frames_per_s", 0) > 0
+        res[key] = {"frames_per_s": st["frames_per_s"] if steady else out["frames_per_s"],
+                    "decode_ms_per_picture": st["decode_ms_per_picture"] if steady else out.get("decode_ms_per_picture"),
+                    "steady_state": steady, "after_seconds": st.get("after_seconds"),
+                    "whole_run": {"frames_per_s": out["frames_per_s"], "frames": out["frames"], "seconds": out["seconds"], "loops": loops,
+                                  "decode_ms_per_picture": out.get("decode_ms_per_picture")},
+                    "frames": out["frames"], "avg_batch": out.get("avg_batch"), "thread_seconds": out.get("thread_seconds")}
     po, ee = res["parse_only"], res["end_to_end"]
     res["end_to_end_vs_parse_only"] = round(ee["frames_per_s"] / po["frames_per_s"], 3)
     if ee.get("decode_ms_per_picture"):
@@ -294,6 +299,9 @@ def system_leg(cpu, seconds=12.0):
     if cpu and cpu.get("value"):
         res["cpu_reference_frames_per_s"] = cpu["value"]
         res["vs_cpu_reference_same_cores"] = round(ee["frames_per_s"] / cpu["value"], 2)
+    res["steady_state_note"] = ("frames_per_s / decode_ms_per_picture are STEADY-STATE figures: everything after the first loop's worth of pictures.  The first loop "
+                                "allocates every decoder's device frames, page-locked mirrors and packet buffers inside the clock (~1.5 s for 128 decoders: "
+                                "profiles/r05_host.txt item 4); `whole_run` includes it")
     res["what"] = ("whole decoder, host included: Annex-B bytes -> reference parser + emitters on `threads` host threads -> page-locked packets submitted in place "
                    "-> 4 kernels per batch -> pictures in HBM (no read-back); `parse_only` = the same host work with the packets dropped.  The device rates of "
                    "`value` / `same_input` need ~30000 x decode_ms_per_picture / 1000 parsing cores per GPU at 1000 x 1080p30")

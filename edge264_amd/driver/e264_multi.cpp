@@ -317,6 +317,10 @@ int main(int argc, char **argv)
 		cv_ready.notify_all();
 	};
 	auto t0 = std::chrono::steady_clock::now();
+	// (time, packets taken by device 0's submitter, ns inside decode_NAL) after every round: the STEADY rate is what comes after the first loop's worth of
+	// pictures -- the first loop allocates every decoder's device frames, page-locked mirrors and packet buffers inside the clock (1.5 s for 128 decoders)
+	struct Trail { double t; long packets; long long ns_decode; };
+	std::vector<Trail> trail;
 	std::vector<std::thread> pool;
 	for (int k = 0; k < n_threads; k++) pool.emplace_back(worker, k);
 	if (pin) {
@@ -395,6 +399,7 @@ int main(int argc, char **argv)
 		}
 		my_packets += (long)owner.size();
 		my_rounds++;
+		if (di == 0) trail.push_back({std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), my_packets, ns_decode.load()}); // (round: ~400 per second)
 		const long long t_sub = now_ns();
 		if (!parse_only) {
 			release_round(pend_next, true);
@@ -431,9 +436,23 @@ int main(int argc, char **argv)
 		F.free_dec(&s.dec);
 	}
 	if (dump) fclose(dump);
+	// steady state: everything after the first loop's worth of packets (one device only; with fewer than two loops there is none)
+	double st_fps = 0, st_ms = 0, st_after = 0;
+	if (devices.size() == 1 && loops >= 2 && !trail.empty()) {
+		const long warm = trail.back().packets / loops; // (--loops K: every stream is played K times)
+		for (const Trail &w : trail)
+			if (w.packets >= warm && warm > 0 && trail.back().packets > w.packets && trail.back().t > w.t) {
+				st_after = w.t;
+				st_fps = (double)(trail.back().packets - w.packets) / (trail.back().t - w.t);
+				st_ms = (double)(ns_decode.load() - w.ns_decode) * 1e-6 / (double)(trail.back().packets - w.packets);
+				break;
+			}
+	}
 	printf("{\"streams\": %zu, \"devices\": %zu, \"threads\": %d, \"frames\": %ld, \"packets\": %ld, \"rounds\": %ld, \"avg_batch\": %.2f, \"seconds\": %.4f, \"frames_per_s\": %.1f, "
-		"\"thread_seconds\": {\"decode_NAL\": %.2f, \"get_frame\": %.2f, \"idle\": %.2f, \"submit_calls\": %.2f}, \"decode_ms_per_picture\": %.3f}\n",
+		"\"thread_seconds\": {\"decode_NAL\": %.2f, \"get_frame\": %.2f, \"idle\": %.2f, \"submit_calls\": %.2f}, \"decode_ms_per_picture\": %.3f, "
+		"\"steady\": {\"after_seconds\": %.3f, \"frames_per_s\": %.1f, \"decode_ms_per_picture\": %.3f}}\n",
 		S.size(), devices.size(), n_threads, total_frames, packets, rounds, rounds ? (double)packets / rounds : 0.0, sec, sec > 0 ? total_frames / sec : 0.0,
-		ns_decode.load() * 1e-9, ns_drain.load() * 1e-9, ns_idle.load() * 1e-9, ns_submit.load() * 1e-9, packets ? ns_decode.load() * 1e-6 / (double)packets : 0.0);
+		ns_decode.load() * 1e-9, ns_drain.load() * 1e-9, ns_idle.load() * 1e-9, ns_submit.load() * 1e-9, packets ? ns_decode.load() * 1e-6 / (double)packets : 0.0,
+		st_after, st_fps, st_ms);
 	return 0;
 }

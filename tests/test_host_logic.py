@@ -230,6 +230,7 @@ def test_round5_bench_line_carries_the_system_figure():
     assert sy["threads"] >= 1 and sy["cores"] >= sy["threads"] and len(sy["files"]) == 4
     for leg in ("parse_only", "end_to_end"):
         assert sy[leg]["frames_per_s"] > 0 and sy[leg]["decode_ms_per_picture"] > 0 and sy[leg]["frames"] > 1000
+        assert sy[leg]["steady_state"] is True and sy[leg]["whole_run"]["frames_per_s"] <= sy[leg]["frames_per_s"] * 1.02  # the start-up is inside `whole_run` only
     assert abs(sy["end_to_end_vs_parse_only"] - sy["end_to_end"]["frames_per_s"] / sy["parse_only"]["frames_per_s"]) < 0.01
     assert sy["host_cores_for_1000_streams_1080p30"] > 0 and sy["cpu_reference_frames_per_s"] == d["cpu_baseline"]["value"]
     si = d["same_input"]
