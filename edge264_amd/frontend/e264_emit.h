@@ -25,6 +25,7 @@ typedef struct {
 	void *mbs;         /* what the reference sees as mb_buffers[slot] */
 	void *mbs_base;    /* start of the allocation (guard bands on both sides of mbs) */
 	void *user_mbs;    /* caller allocators: the mbs block the caller's alloc_cb returned (held, handed back to its free_cb) */
+	int plain_mirror;  /* the mirror is ordinary memory of this library (decode-to-device: nothing is read back), not the back end's page-locked one */
 } E264Slot;
 
 typedef struct {

@@ -197,14 +197,20 @@ static void e264_alloc_cb(void **samples, unsigned samples_size, void **mbs, uns
 			return;
 		}
 	}
+	/* Decode-to-device (e264front_set_download(0)): no picture is ever read back, the mirror only serves what the parser itself writes into sample
+	 * memory (I_PCM, the concealment's blend): ordinary memory, not 3 MB of page-locked memory per slot -- 768 hipHostMalloc calls at the start of a
+	 * 128-decoder run, each of which stalls every parsing thread of the process (profiles/r05_host.txt item 4).  A later set_download(1) still works:
+	 * the download then lands in pageable memory. */
+	const int plain_mirror = ON_DEVICE(e) && !g_download && !e->user_alloc;
 	if (ON_DEVICE(e)) {
-		if (hip.frame_alloc(e->hip_stream, slot, samples_size, e->user_alloc ? NULL : &mirror)) { /* no pinned mirror beside caller memory */
+		if (hip.frame_alloc(e->hip_stream, slot, samples_size, (e->user_alloc || plain_mirror) ? NULL : &mirror)) { /* no pinned mirror beside caller memory */
 			if (e->user_alloc && e->user_free) e->user_free(user_samples, user_mbs, e->user_arg);
 			return;
 		}
 		/* "non-existing" frames are never written (headers.c:1122-1144): the reference leaves their memory as its allocator
 		 * returned it; the device slot is cleared so that what a damaged stream predicts from them is at least deterministic */
 		hip.frame_fill(e->hip_stream, slot, 0);
+		if (plain_mirror) mirror = aligned_alloc(64, ((size_t)samples_size + 63) & ~(size_t)63);
 	} else if (!e->user_alloc) {
 		mirror = aligned_alloc(64, ((size_t)samples_size + 63) & ~(size_t)63);
 	}
@@ -223,7 +229,7 @@ static void e264_alloc_cb(void **samples, unsigned samples_size, void **mbs, uns
 		free(base);
 		if (ON_DEVICE(e)) hip.frame_free(e->hip_stream, slot);
 		if (e->user_alloc) { if (e->user_free) e->user_free(user_samples, user_mbs, e->user_arg); }
-		else if (!ON_DEVICE(e)) free(mirror);
+		else if (!ON_DEVICE(e) || plain_mirror) free(mirror);
 		return;
 	}
 	memset(base, 0, guard);
@@ -233,6 +239,7 @@ static void e264_alloc_cb(void **samples, unsigned samples_size, void **mbs, uns
 	e->slot[slot].samples_size = samples_size;
 	e->slot[slot].mbs = m;
 	e->slot[slot].user_mbs = user_mbs;
+	e->slot[slot].plain_mirror = plain_mirror;
 	*samples = mirror;
 	*mbs = m;
 }
@@ -247,7 +254,7 @@ static void e264_free_cb(void *samples, void *mbs, void *arg)
 			e->fb[s].active = 0;
 			if (ON_DEVICE(e)) hip.frame_free(e->hip_stream, s);
 			if (e->user_alloc) { if (e->user_free) e->user_free(samples, e->slot[s].user_mbs, e->user_arg); }
-			else if (!ON_DEVICE(e)) free(samples);
+			else if (!ON_DEVICE(e) || e->slot[s].plain_mirror) free(samples);
 			free(e->slot[s].mbs_base);
 			memset(&e->slot[s], 0, sizeof(e->slot[s]));
 			return;
