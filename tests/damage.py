@@ -60,6 +60,10 @@ RESENT = [
     ("ipb_spatial", 2, 0.3), ("ipb_spatial", 3, 0.7), ("cabac_ipb_spatial", 2, 0.5),
     ("t8x8_plain", 1, 0.3), ("cabac_t8x8_slices", 5, 0.3), ("cabac_t8x8_slices", 8, 0.7),
     ("mvc_ipp", 3, 0.5), ("cabac_weighted_b", 4, 0.4), ("reorder_weighted", 5, 0.6),
+    # round 5: encoder-shaped pictures (tests/golden/nat_encoder.py on 320 x 192): the concealment's P_Skip / B_Skip macroblocks take their vectors from
+    # coherent neighbourhoods and skip runs, not from random syntax
+    ("nat_small_ipp8", 0, 0.5), ("nat_small_ipp8", 2, 0.3), ("nat_small_ipp8", 5, 0.6),
+    ("cabac_nat_small_ibbp10", 2, 0.4), ("cabac_nat_small_ibbp10", 4, 0.5), ("cabac_nat_small_ibbp10", 6, 0.7),
 ]
 LOST = [("ipp_partitions", 3, 0.5), ("cabac_ipp", 3, 0.4), ("slices_deblock_idc", 11, 0.5), ("cabac_t8x8_slices", 11, 0.5)]
 # two failed slices in ONE picture, then both sent again: (fixture, first of the two slice NALs -- both in the same picture --, fractions kept).

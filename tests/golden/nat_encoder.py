@@ -81,6 +81,7 @@ class Scene:
     def __init__(self, W, H, seed):
         self.W, self.H = W, H
         r = self.rng = np.random.default_rng(seed)
+        k = W / 1920.0  # the rectangles below are laid out for 1920 x 1088; smaller pictures get the same scene, scaled (velocities halved at most)
         self.bg = Layer(r, 120, 38, chroma=(118, 136))
         self.bg_v = (1.25, 0.5)  # quarter-sample pan per picture
         # rectangles: x, y, w, h, vx, vy, layer, sensor-noise sigma inside
@@ -93,6 +94,9 @@ class Scene:
             (1100, 40, 640, 90, 0.0, 0.0, Layer(r, 200, 1.5, n=4, chroma=(120, 132)), 0.0),     # flat: skips, bS 0
             (1500, 700, 320, 300, -1.5, -0.75, Layer(r, 128, 30, chroma=(128, 128)), 5.0),     # noisy: coded everywhere
         ]
+        if k != 1.0:
+            v = max(k, 0.5)
+            self.objs = [(x * k, y * k, w * k, h * k, vx * v, vy * v, lay, sig) for (x, y, w, h, vx, vy, lay, sig) in self.objs]
 
     def frame(self, n):
         W, H = self.W, self.H
@@ -272,10 +276,10 @@ def se_bits(v):
 # the encoder
 # ---------------------------------------------------------------------------------------------------------------------
 class NatEncoder(ms.Synth):
-    def __init__(self, g, name, frames, *, cabac, qp, seed, tables=None, search=8):
-        super().__init__(g, name, W_MBS, H_MBS, frames, seed, num_refs=2 if "B" in frames else 1, cabac=cabac, tables=tables, qp=qp, level=4.0,
+    def __init__(self, g, name, frames, *, cabac, qp, seed, tables=None, search=8, W=W_MBS, H=H_MBS):
+        super().__init__(g, name, W, H, frames, seed, num_refs=2 if "B" in frames else 1, cabac=cabac, tables=tables, qp=qp, level=4.0,
                          pcm=0.0)
-        self.scene = Scene(16 * W_MBS, 16 * H_MBS, seed)
+        self.scene = Scene(16 * W, 16 * H, seed)
         self.search = search
         self.qpc = QPC[qp]
         self.lam = max(2, int(0.85 * 2 ** ((qp - 12) / 6)))  # SAD units per bit
@@ -848,6 +852,10 @@ class NatEncoder(ms.Synth):
 STREAMS = [
     ("nat1080_ipp30", "I" + "P" * 29, dict(cabac=False, qp=30, seed=7)),
     ("cabac_nat1080_ibbp30", "I" + "PBB" * 9 + "PB", dict(cabac=True, qp=31, seed=8)),
+    # the same encoder on a 320 x 192 picture: small enough for the damaged-stream scenarios (tests/damage.py), whose concealment (erroneous
+    # macroblocks decoded again as P_Skip / B_Skip, src/edge264_headers.c:295-430) meets coherent vector fields and skip runs here
+    ("nat_small_ipp8", "I" + "P" * 7, dict(cabac=False, qp=28, seed=9, W=20, H=12)),
+    ("cabac_nat_small_ibbp10", "IPBBPBBPBB", dict(cabac=True, qp=29, seed=10, W=20, H=12)),
 ]
 
 
@@ -855,11 +863,14 @@ def main(argv):
     g = ms.load_gen()
     from oracle.pyoracle import ref_decoder
     ref = ref_decoder()
-    n_frames = int(argv[1]) if len(argv) > 1 else None
+    n_frames = int(argv[1]) if len(argv) > 1 and argv[1].isdigit() else None
+    only = [a for a in argv[1:] if not a.isdigit()]  # stream names: regenerate just these
     path = os.path.join(ms.OUT, "reference_md5.json")
     sums = json.load(open(path))
     tables = None
     for name, frames, opt in STREAMS:
+        if only and name not in only:
+            continue
         if n_frames:
             frames = frames[:n_frames]
         if opt["cabac"]:
@@ -873,7 +884,7 @@ def main(argv):
         if not n_frames:
             with open(os.path.join(ms.OUT, name + ".264"), "wb") as f:
                 f.write(data)
-            sums[name] = {"width_mbs": W_MBS, "height_mbs": H_MBS, "frames": frames, "nal_codes": codes, "views": 1,
+            sums[name] = {"width_mbs": enc.W, "height_mbs": enc.H, "frames": frames, "nal_codes": codes, "views": 1,
                           "md5": [hashlib.md5(b"".join(p.tobytes() for p in fr)).hexdigest() for fr in out], "encoder_stats": enc.stats}
         print(f"{name}.264: {len(data)} bytes ({len(data) * 8 * 30 / len(frames) / 1e6:.2f} Mbit/s at 30 pictures/s), {enc.stats}")
     if not n_frames:
