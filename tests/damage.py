@@ -64,6 +64,8 @@ RESENT = [
     # coherent neighbourhoods and skip runs, not from random syntax
     ("nat_small_ipp8", 0, 0.5), ("nat_small_ipp8", 2, 0.3), ("nat_small_ipp8", 5, 0.6),
     ("cabac_nat_small_ibbp10", 2, 0.4), ("cabac_nat_small_ibbp10", 4, 0.5), ("cabac_nat_small_ibbp10", 6, 0.7),
+    # ... and with the High-profile tools (8x8 transform by choice, two references in P macroblocks, implicit weighted bi-prediction)
+    ("cabac_nat_small_high_ibbp10", 1, 0.5), ("cabac_nat_small_high_ibbp10", 3, 0.3), ("cabac_nat_small_high_ibbp10", 7, 0.6),
 ]
 LOST = [("ipp_partitions", 3, 0.5), ("cabac_ipp", 3, 0.4), ("slices_deblock_idc", 11, 0.5), ("cabac_t8x8_slices", 11, 0.5)]
 # two failed slices in ONE picture, then both sent again: (fixture, first of the two slice NALs -- both in the same picture --, fractions kept).

@@ -16,6 +16,8 @@ a noisy region, sensor noise) goes through a small but real encoder --
   * residual = source - prediction through the forward 4x4 integer transform, the Intra16x16 / chroma DC Hadamard transforms and a
     dead-zone quantiser at a fixed QP;
   * intra: Intra16x16 (4 modes) or Intra4x4 (7 of the 9 modes) by SAD on its own in-loop reconstruction;
+  * `high=True` (cabac_nat*_high_*): the 8x8 transform chosen per inter macroblock where it describes the residual more cheaply, two reference
+    pictures for P macroblocks (per 16x16 / per 8x8 quadrant), implicit weighted bi-prediction (8.4.2.3.1) in B pictures;
 
 and is written out by the same syntax writers as the other fixtures (the reference's tests/gen_avc.py for CAVLC, cabac_writer.py for
 CABAC).  The UNMODIFIED reference decoder closes the loop: after every picture the stream so far is decoded by it and ITS pictures are
@@ -209,6 +211,80 @@ def inv4x4(d):
     return (t + 32) >> 6
 
 
+# 8x8 transform (High profile): forward butterfly as in the JM, quantiser / dequantiser tables by position class (8.5.13; the classes of
+# normAdjust8x8, /root/reference/src/edge264_residual.c:77-98)
+Q8 = [(13107, 11428, 20972, 12222, 16777, 15481), (11916, 10826, 19174, 11058, 14980, 14290), (10082, 8943, 15978, 9675, 12710, 11985),
+      (9362, 8228, 14913, 8931, 11984, 11259), (8192, 7346, 13159, 7740, 10486, 9777), (7282, 6428, 11570, 6830, 9118, 8640)]
+V8 = [(20, 18, 32, 19, 25, 24), (22, 19, 35, 21, 28, 26), (26, 23, 42, 24, 33, 31), (28, 25, 45, 26, 35, 33), (32, 28, 51, 30, 40, 38), (36, 32, 58, 34, 46, 43)]
+
+
+def _cls8(i, j):
+    if i % 4 == 0 and j % 4 == 0:
+        return 0
+    if i % 2 == 1 and j % 2 == 1:
+        return 1
+    if i % 4 == 2 and j % 4 == 2:
+        return 2
+    if (i % 4 == 0 and j % 2 == 1) or (i % 2 == 1 and j % 4 == 0):
+        return 3
+    if (i % 4 == 0 and j % 4 == 2) or (i % 4 == 2 and j % 4 == 0):
+        return 4
+    return 5
+
+
+CLS8 = np.array([[_cls8(i, j) for j in range(8)] for i in range(8)])
+ZZ8 = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50,
+       43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+
+
+def _fwd8_1d(x):  # along the last axis
+    a0, a1, a2, a3 = x[..., 0] + x[..., 7], x[..., 1] + x[..., 6], x[..., 2] + x[..., 5], x[..., 3] + x[..., 4]
+    b0, b1, b2, b3 = a0 + a3, a1 + a2, a0 - a3, a1 - a2
+    a4, a5, a6, a7 = x[..., 0] - x[..., 7], x[..., 1] - x[..., 6], x[..., 2] - x[..., 5], x[..., 3] - x[..., 4]
+    b4 = a5 + a6 + ((a4 >> 1) + a4)
+    b5 = a4 - a7 - ((a6 >> 1) + a6)
+    b6 = a4 + a7 - ((a5 >> 1) + a5)
+    b7 = a5 - a6 + ((a7 >> 1) + a7)
+    return np.stack([b0 + b1, b4 + (b7 >> 2), b2 + (b3 >> 1), b5 + (b6 >> 2), b0 - b1, b6 - (b5 >> 2), (b2 >> 1) - b3, -b7 + (b4 >> 2)], -1)
+
+
+def _inv8_1d(d):  # along the last axis (8.5.13; the butterfly of edge264_residual.c:250-316)
+    d0, d1, d2, d3, d4, d5, d6, d7 = (d[..., k] for k in range(8))
+    e0, e2 = d0 + d4, d0 - d4
+    e1 = d5 - d3 - ((d7 >> 1) + d7)
+    e3 = d1 + d7 - ((d3 >> 1) + d3)
+    e4, e6 = (d2 >> 1) - d6, (d6 >> 1) + d2
+    e5 = d7 - d1 + ((d5 >> 1) + d5)
+    e7 = d3 + d5 + ((d1 >> 1) + d1)
+    f0, f1, f2, f3 = e0 + e6, (e7 >> 2) + e1, e2 + e4, (e5 >> 2) + e3
+    f4, f5, f6, f7 = e2 - e4, (e3 >> 2) - e5, e0 - e6, e7 - (e1 >> 2)
+    return np.stack([f0 + f7, f2 + f5, f4 + f3, f6 + f1, f6 - f1, f4 - f3, f2 - f5, f0 - f7], -1)
+
+
+def fwd8x8(blocks):  # (..., 8, 8)
+    t = _fwd8_1d(blocks)
+    return _fwd8_1d(t.swapaxes(-1, -2)).swapaxes(-1, -2)
+
+
+def quant8(Wc, qp, intra):
+    qb = 16 + qp // 6
+    f = (1 << qb) // (3 if intra else 6)
+    return np.sign(Wc) * ((np.abs(Wc) * np.array(Q8[qp % 6])[CLS8] + f) >> qb)
+
+
+def dequant8(L, qp):
+    v = np.array(V8[qp % 6])[CLS8] * 16
+    if qp >= 36:
+        return (L * v) << (qp // 6 - 6)
+    return (L * v + (1 << (5 - qp // 6))) >> (6 - qp // 6)
+
+
+def inv8x8(d):
+    t = _inv8_1d(d)
+    t = _inv8_1d(t.swapaxes(-1, -2)).swapaxes(-1, -2)
+    return (t + 32) >> 6
+
+
 H4 = np.array([[1, 1, 1, 1], [1, 1, -1, -1], [1, -1, -1, 1], [1, -1, 1, -1]])
 H2 = np.array([[1, 1], [1, -1]])
 
@@ -276,9 +352,12 @@ def se_bits(v):
 # the encoder
 # ---------------------------------------------------------------------------------------------------------------------
 class NatEncoder(ms.Synth):
-    def __init__(self, g, name, frames, *, cabac, qp, seed, tables=None, search=8, W=W_MBS, H=H_MBS):
-        super().__init__(g, name, W, H, frames, seed, num_refs=2 if "B" in frames else 1, cabac=cabac, tables=tables, qp=qp, level=4.0,
-                         pcm=0.0)
+    def __init__(self, g, name, frames, *, cabac, qp, seed, tables=None, search=8, W=W_MBS, H=H_MBS, high=False):
+        """high: the High-profile tools on top -- 8x8 transform chosen per inter macroblock, two reference pictures for P macroblocks (per 16x16 /
+        per 8x8), implicit weighted bi-prediction (weighted_bipred_idc 2, 8.4.2.3.1) in B pictures"""
+        super().__init__(g, name, W, H, frames, seed, num_refs=2 if ("B" in frames or high) else 1, cabac=cabac, tables=tables, qp=qp, level=4.0,
+                         pcm=0.0, t8x8=high, weighted_bipred=2 if high else 0)
+        self.high = high
         self.scene = Scene(16 * W, 16 * H, seed)
         self.search = search
         self.qpc = QPC[qp]
@@ -337,12 +416,21 @@ class NatEncoder(ms.Synth):
         return mv16, best16, mv8, best8
 
     # ---- residual of one macroblock ---------------------------------------------------------------------------------------
-    def code_residual(self, src, pred, intra16=False):
-        """src, pred: (Y 16x16, Cb 8x8, Cr 8x8) int arrays.  -> (luma levels (16, 4, 4) in block-zigzag order, luma dc levels (4, 4) or None,
+    def code_residual(self, src, pred, intra16=False, allow_t8=False):
+        """src, pred: (Y 16x16, Cb 8x8, Cr 8x8) int arrays.  -> (luma levels (4, 4, 4, 4) [by][bx][y][x] -- or (2, 2, 8, 8) when the 8x8 transform was chosen
+        (allow_t8: an inter macroblock without partitions below 8x8 in a High-profile stream; self.last_t8 says which) --, luma dc levels (4, 4) or None,
         chroma dc levels [2][(2, 2)], chroma ac levels (2, 4, 4, 4), reconstruction (Y, Cb, Cr))"""
         qp, qpc = self.qp, self.qpc
         ry = (src[0] - pred[0]).reshape(4, 4, 4, 4).transpose(0, 2, 1, 3)  # [by][bx][y][x]
         Wy = fwd4x4(ry)
+        self.last_t8 = False
+        L8 = None
+        if allow_t8:
+            r8 = (src[0] - pred[0]).reshape(2, 8, 2, 8).transpose(0, 2, 1, 3)
+            L8 = quant8(fwd8x8(r8), qp, False)
+            L4 = quant(Wy, qp, False)
+            # the cheaper description wins (levels and their magnitudes as a proxy for bits; ties to 8x8: fewer blocks to signal)
+            self.last_t8 = bool((np.abs(L8).sum() + (L8 != 0).sum()) <= (np.abs(L4).sum() + (L4 != 0).sum()))
         ldc = None
         if intra16:
             dc = Wy[..., 0, 0]
@@ -359,6 +447,9 @@ class NatEncoder(ms.Synth):
             ls = (VQ[qp % 6][0] * 16) << (qp // 6)
             dy[..., 0, 0] = (f * ls + 32) >> 6
         recy = np.clip(pred[0] + inv4x4(dy).transpose(0, 2, 1, 3).reshape(16, 16), 0, 255)
+        if self.last_t8:
+            Ly = L8
+            recy = np.clip(pred[0] + inv8x8(dequant8(L8, qp)).transpose(0, 2, 1, 3).reshape(16, 16), 0, 255)
         cdc, cac, recc = [], [], []
         for p in range(2):
             rc = (src[1 + p] - pred[1 + p]).reshape(2, 4, 2, 4).transpose(0, 2, 1, 3)
@@ -376,19 +467,35 @@ class NatEncoder(ms.Synth):
             cac.append(Lac)
         return Ly, ldc, cdc, cac, (recy, recc[0], recc[1])
 
-    def residual_syntax(self, fc, mx, my, sl, Ly, ldc, cdc, cac, i16):
+    def residual_syntax(self, fc, mx, my, sl, Ly, ldc, cdc, cac, i16, t8=False):
         """-> (coded_block_pattern, coeffLevels list in syntax order); updates the CAVLC contexts of the frame"""
         blocks = []
         # luma blocks in coding order: 8x8 quadrant b8, then its four 4x4 blocks
         order = [(ms.BLK_Y[b], ms.BLK_X[b]) for b in range(16)]
-        nz8 = [any(Ly[order[4 * b8 + k]].any() for k in range(4)) for b8 in range(4)]
+        if t8:  # Ly: (2, 2, 8, 8).  An 8x8 block is written as four 4x4 blocks holding every fourth coefficient of its zig-zag scan (7.3.5.3.2)
+            cbp_l = sum(1 << b8 for b8 in range(4) if Ly[b8 >> 1, b8 & 1].any())
+            for b8 in range(4):
+                if not cbp_l >> b8 & 1:
+                    continue
+                f = Ly[b8 >> 1, b8 & 1].reshape(64)
+                c64 = [int(f[i]) for i in ZZ8]
+                for k in range(4):
+                    c = c64[k::4]
+                    by, bx = order[4 * b8 + k]
+                    gx, gy = 4 * mx + bx, 4 * my + by
+                    blocks.append({"nC": fc.nC(fc.tcY, 2, gx, gy, sl), "c": c})
+                    fc.tcY[gy][gx] = sum(1 for v in c if v)
+            Ly = np.zeros((4, 4, 4, 4), np.int64)  # (nothing below adds luma blocks)
+            nz8 = [False] * 4
+        else:
+            nz8 = [any(Ly[order[4 * b8 + k]].any() for k in range(4)) for b8 in range(4)]
         if i16:
             cbp_l = 15 if any(nz8) else 0
-        else:
+        elif not t8:
             cbp_l = sum(1 << b8 for b8 in range(4) if nz8[b8])
         if i16:
             blocks.append({"nC": fc.nC(fc.tcY, 2, 4 * mx, 4 * my, sl), "c": scan(ldc)})
-        for b in range(16):
+        for b in range(16 if not t8 else 0):
             if not cbp_l >> (b >> 2) & 1:
                 continue
             by, bx = order[b]
@@ -590,6 +697,8 @@ class NatEncoder(ms.Synth):
                 fc.ipm[by][bx] = want
             cbp, blocks = self.residual_syntax(fc, mx, my, sl, lev4, None, cdc, cac, False)
             mb = {"mb_type": base, "rem_intra4x4_pred_modes": rem, "intra_chroma_pred_mode": cm, "coded_block_pattern": cbp}
+            if self.t8x8:
+                mb = {"mb_type": base, "transform_size_8x8_flag": 0, **{k: v for k, v in mb.items() if k != "mb_type"}}
             if cbp:
                 mb.update(mb_qp_delta=0, coeffLevels=blocks)
             return mb, cost
@@ -609,25 +718,30 @@ class NatEncoder(ms.Synth):
         mot = Motion(Wm, Hm)
         rec = [np.zeros((16 * Hm, 16 * Wm), np.int32), np.zeros((8 * Hm, 8 * Wm), np.int32), np.zeros((8 * Hm, 8 * Wm), np.int32)]
         st = {"I": 2, "P": 0, "B": 1}[ptype]
-        srch = {lst: self.search_picture(src[0], r[0], r[3]) for lst, r in refs.items()}
+        # refs: {list: [prepared reference pictures, index = refIdx]}; one motion search per (list, refIdx)
+        srch = {(lst, ri): self.search_picture(src[0], r[0], r[3]) for lst, rl in refs.items() for ri, r in enumerate(rl)}
+        wbi = getattr(self, "bi_weights", None)  # implicit weights (w0, w1) of the (L0[0], L1[0]) pair of this B picture, or None: (p0 + p1 + 1) >> 1
         cnt = dict(skip=0, direct=0, p16=0, p8x8=0, intra=0, bi=0, l0=0, l1=0, coded=0)
         out = []
         S = [p.astype(np.int32) for p in src]
 
+        def bipred(p0, p1):
+            if wbi is None:
+                return (p0 + p1 + 1) >> 1
+            return np.clip((p0 * wbi[0] + p1 * wbi[1] + 32) >> 6, 0, 255)  # 8.4.2.3.2 with logWD 5, no offsets
+
         def inter_pred(parts):
-            """parts: list of (bx4, by4 (4x4 units inside the MB), size in samples, {list: mv}) -> (Y, Cb, Cr) prediction"""
+            """parts: list of (bx4, by4 (4x4 units inside the MB), size in samples, {list: mv or (mv, refIdx)}) -> (Y, Cb, Cr) prediction"""
             py, pc = np.zeros((16, 16), np.int32), [np.zeros((8, 8), np.int32), np.zeros((8, 8), np.int32)]
             for (ox, oy, sz, mvs) in parts:
-                acc_y, acc_c, n = 0, [0, 0], 0
-                for lst, mv in mvs.items():
-                    R = refs[lst]
-                    acc_y = acc_y + luma_pred(R[3], x + ox, y + oy, mv, sz, sz)
-                    for p in range(2):
-                        acc_c[p] = acc_c[p] + chroma_pred(R[1 + p], (x + ox) // 2, (y + oy) // 2, mv, sz // 2, sz // 2)
-                    n += 1
-                if n == 2:
-                    acc_y = (acc_y + 1) >> 1
-                    acc_c = [(c + 1) >> 1 for c in acc_c]
+                ys, cs = [], []
+                for lst in sorted(mvs):
+                    mv, ri = mvs[lst] if isinstance(mvs[lst][0], tuple) else (mvs[lst], 0)
+                    R = refs[lst][ri]
+                    ys.append(luma_pred(R[3], x + ox, y + oy, mv, sz, sz))
+                    cs.append([chroma_pred(R[1 + p], (x + ox) // 2, (y + oy) // 2, mv, sz // 2, sz // 2) for p in range(2)])
+                acc_y = ys[0] if len(ys) == 1 else bipred(ys[0], ys[1])
+                acc_c = cs[0] if len(cs) == 1 else [bipred(cs[0][p], cs[1][p]) for p in range(2)]
                 py[oy:oy + sz, ox:ox + sz] = acc_y
                 for p in range(2):
                     pc[p][oy // 2:(oy + sz) // 2, ox // 2:(ox + sz) // 2] = acc_c[p]
@@ -648,47 +762,63 @@ class NatEncoder(ms.Synth):
                     continue
                 cands = []  # (cost, kind, parts, syntax)
                 if st == 0:
-                    mv16, sad16, mv8, sad8 = srch[0]
+                    nref = len(refs[0])
+                    refbits = 1 if nref > 1 else 0
                     skip_mv = mot.p_skip_mv(4 * mx, 4 * my)
-                    mvp16 = mot.mvp(0, 4 * mx, 4 * my, 4, 0)
-                    best = (int(mv16[my, mx, 0]), int(mv16[my, mx, 1]))
-                    for v in {best, mvp16, skip_mv}:
-                        p = luma_pred(refs[0][3], x, y, v, 16, 16)
-                        bits = se_bits(v[0] - mvp16[0]) + se_bits(v[1] - mvp16[1])
-                        cands.append((int(np.abs(sy - p).sum()) + self.lam * (bits if v != skip_mv else 0), "p16", v))
-                    c8 = 6 * self.lam + sum(int(sad8[2 * my + (b >> 1), 2 * mx + (b & 1)]) + 5 * self.lam for b in range(4))
-                    cands.append((c8, "p8x8", None))
-                    cost, kind, v = min(cands, key=lambda c: c[0])
+                    for ri in range(nref):
+                        mv16, sad16, mv8, sad8 = srch[(0, ri)]
+                        mvp16 = mot.mvp(0, 4 * mx, 4 * my, 4, ri)
+                        best = (int(mv16[my, mx, 0]), int(mv16[my, mx, 1]))
+                        for v in ({best, mvp16, skip_mv} if ri == 0 else {best, mvp16}):
+                            p = luma_pred(refs[0][ri][3], x, y, v, 16, 16)
+                            bits = se_bits(v[0] - mvp16[0]) + se_bits(v[1] - mvp16[1]) + refbits
+                            cands.append((int(np.abs(sy - p).sum()) + self.lam * (bits if (v != skip_mv or ri) else 0), "p16", (v, ri, mvp16)))
+                    # 8x8: every quadrant takes the better of its references
+                    q8 = []
+                    for b in range(4):
+                        q8.append(min((int(srch[(0, ri)][3][2 * my + (b >> 1), 2 * mx + (b & 1)]) + self.lam * refbits, ri) for ri in range(nref)))
+                    cands.append((6 * self.lam + sum(c + 5 * self.lam for c, _ in q8), "p8x8", None))
+                    cost, kind, sel = min(cands, key=lambda c: c[0])
                     r = self.intra_mb(fc, rec, src, mx, my, 0, 5, inter_cost=cost)
                     if r is not None:
                         out.append(r[0])
                         mot.set(0, 4 * mx, 4 * my, 4, 4, -1)
                         cnt["intra"] += 1
                         continue
+                    v = None
                     if kind == "p16":
-                        parts = [(0, 0, 16, {0: v})]
-                        mot.set(0, 4 * mx, 4 * my, 4, 4, 0, v)
-                        mvds = [(v[0] - mvp16[0], v[1] - mvp16[1])]
-                        mb = {"mb_type": 0, "ref_idx": {}, "mvds": mvds}
+                        v, ri, mvp16 = sel
+                        parts = [(0, 0, 16, {0: (v, ri)})]
+                        mot.set(0, 4 * mx, 4 * my, 4, 4, ri, v)
+                        mb = {"mb_type": 0, "ref_idx": ({"0": ri} if nref > 1 else {}), "mvds": [(v[0] - mvp16[0], v[1] - mvp16[1])]}
+                        if ri:
+                            v = None  # (not the skip candidate: P_Skip predicts from reference 0)
                     else:
-                        parts, mvds = [], []
+                        parts, mvds, ridx = [], [], {}
                         for b in range(4):
                             bx4, by4 = 2 * (b & 1), 2 * (b >> 1)
+                            ri = q8[b][1]
+                            mv8 = srch[(0, ri)][2]
                             vv = (int(mv8[2 * my + (b >> 1), 2 * mx + (b & 1), 0]), int(mv8[2 * my + (b >> 1), 2 * mx + (b & 1), 1]))
-                            pr = mot.mvp(0, 4 * mx + bx4, 4 * my + by4, 2, 0)
-                            mot.set(0, 4 * mx + bx4, 4 * my + by4, 2, 2, 0, vv)
+                            pr = mot.mvp(0, 4 * mx + bx4, 4 * my + by4, 2, ri)
+                            mot.set(0, 4 * mx + bx4, 4 * my + by4, 2, 2, ri, vv)
                             mvds.append((vv[0] - pr[0], vv[1] - pr[1]))
-                            parts.append((4 * bx4, 4 * by4, 8, {0: vv}))
-                        mb = {"mb_type": 3, "sub_mb_types": [0, 0, 0, 0], "ref_idx": {}, "mvds": mvds}
+                            parts.append((4 * bx4, 4 * by4, 8, {0: (vv, ri)}))
+                            ridx[str(b)] = ri
+                        mb = {"mb_type": 3, "sub_mb_types": [0, 0, 0, 0], "ref_idx": (ridx if nref > 1 else {}), "mvds": mvds}
                     pred = inter_pred(parts)
-                    Ly, _, cdc, cac, recs = self.code_residual(srcmb, pred, False)
+                    Ly, _, cdc, cac, recs = self.code_residual(srcmb, pred, False, allow_t8=self.high)
+                    t8 = self.last_t8
                     zero = not Ly.any() and not any(d.any() for d in cdc) and not any(a.any() for a in cac)
                     if zero and kind == "p16" and v == skip_mv:
                         out.append(None)
                         cnt["skip"] += 1
                     else:
-                        cbp, blocks = self.residual_syntax(fc, mx, my, 0, Ly, None, cdc, cac, False)
+                        cbp, blocks = self.residual_syntax(fc, mx, my, 0, Ly, None, cdc, cac, False, t8=t8)
                         mb["coded_block_pattern"] = cbp
+                        if self.high and cbp & 15:
+                            mb["transform_size_8x8_flag"] = int(t8)
+                            cnt["t8"] = cnt.get("t8", 0) + int(t8)
                         if cbp:
                             mb.update(mb_qp_delta=0, coeffLevels=blocks)
                             cnt["coded"] += 1
@@ -718,13 +848,13 @@ class NatEncoder(ms.Synth):
                     cands.append((int(np.abs(sy - dpred[0]).sum()), "direct", None))
                     one = {}
                     for l in range(2):
-                        mv16, sad16, _, _ = srch[l]
+                        mv16, sad16, _, _ = srch[(l, 0)]
                         pr = mot.mvp(l, 4 * mx, 4 * my, 4, 0)
                         v = (int(mv16[my, mx, 0]), int(mv16[my, mx, 1]))
                         bits = se_bits(v[0] - pr[0]) + se_bits(v[1] - pr[1])
                         one[l] = (v, pr, bits)
                         cands.append((int(sad16[my, mx]) + self.lam * (bits + 3), "l%d" % l, None))
-                    pbi = (luma_pred(refs[0][3], x, y, one[0][0], 16, 16) + luma_pred(refs[1][3], x, y, one[1][0], 16, 16) + 1) >> 1
+                    pbi = bipred(luma_pred(refs[0][0][3], x, y, one[0][0], 16, 16), luma_pred(refs[1][0][3], x, y, one[1][0], 16, 16))
                     cands.append((int(np.abs(sy - pbi).sum()) + self.lam * (one[0][2] + one[1][2] + 5), "bi", None))
                     cost, kind, _ = min(cands, key=lambda c: c[0])
                     if kind == "direct":
@@ -747,14 +877,18 @@ class NatEncoder(ms.Synth):
                         pred = inter_pred([(0, 0, 16, mvs)])
                         mb = {"mb_type": {"l0": 1, "l1": 2, "bi": 3}[kind], "ref_idx": {},
                               "mvds": [(one[l][0][0] - one[l][1][0], one[l][0][1] - one[l][1][1]) for l in use]}
-                    Ly, _, cdc, cac, recs = self.code_residual(srcmb, pred, False)
+                    Ly, _, cdc, cac, recs = self.code_residual(srcmb, pred, False, allow_t8=self.high)
+                    t8 = self.last_t8
                     zero = not Ly.any() and not any(d.any() for d in cdc) and not any(a.any() for a in cac)
                     if zero and kind == "direct":
                         out.append(None)
                         cnt["skip"] += 1
                     else:
-                        cbp, blocks = self.residual_syntax(fc, mx, my, 0, Ly, None, cdc, cac, False)
+                        cbp, blocks = self.residual_syntax(fc, mx, my, 0, Ly, None, cdc, cac, False, t8=t8)
                         mb["coded_block_pattern"] = cbp
+                        if self.high and cbp & 15:  # (B_Direct_16x16 too: direct_8x8_inference_flag is 1)
+                            mb["transform_size_8x8_flag"] = int(t8)
+                            cnt["t8"] = cnt.get("t8", 0) + int(t8)
                         if cbp:
                             mb.update(mb_qp_delta=0, coeffLevels=blocks)
                             cnt["coded"] += 1
@@ -810,19 +944,28 @@ class NatEncoder(ms.Synth):
         for idx, (t, p) in enumerate(order):
             src = self.scene.frame(p // 2)
             refs = {}
+            self.bi_weights = None
             if t == "P":
-                refs[0] = self.prepare(decoded[ref_pocs[0]])
+                refs[0] = [self.prepare(decoded[q]) for q in ref_pocs[:2 if self.high else 1]]
             elif t == "B":
                 before = max(q for q in ref_pocs if q < p)
                 after = min(q for q in ref_pocs if q > p)
-                refs[0], refs[1] = self.prepare(decoded[before]), self.prepare(decoded[after])
+                refs[0], refs[1] = [self.prepare(decoded[before])], [self.prepare(decoded[after])]
+                if self.wbp == 2:  # implicit weights, 8.4.2.3.1 (both references short-term)
+                    c3 = lambda v: max(-128, min(127, v))  # noqa: E731
+                    tb, td = c3(p - before), c3(after - before)
+                    tx = int((16384 + abs(td // 2)) / td)
+                    dsf = max(-1024, min(1023, (tb * tx + 32) >> 6))
+                    w1 = dsf >> 2
+                    self.bi_weights = (32, 32) if (w1 < -64 or w1 > 128) else (64 - w1, w1)
             col = motion[min(q for q in ref_pocs if q > p)] if t == "B" else None
             mbs, fc, mot, cnt, rec = self.encode_picture(t, src, refs, col)
             motion[p] = mot
             if self.cabac:
                 import cabac_writer as cw
                 self.cabac_fs = cw.FrameState(Wm, Hm)
-            hdr = dict(frame_num=frame_num % (1 << self.log2_fn), poc=p % (1 << self.log2_poc), is_ref=t != "B", idr=idx == 0, nref0=1, nref1=1,
+            hdr = dict(frame_num=frame_num % (1 << self.log2_fn), poc=p % (1 << self.log2_poc), is_ref=t != "B", idr=idx == 0,
+                       nref0=len(refs[0]) if t == "P" else 1, nref1=1,
                        idr_pic_id=0, slice_qp_delta=0, deblock=0, alpha=0, beta=0, mmco1=0, reorder_l0=0, pps_id=0)
             out.append(self.slice_nal(fc, t, 0, Wm * Hm, 0, hdr, mbs=mbs))
             frames, codes = ref_dec.decode(b"".join(out))
@@ -856,6 +999,9 @@ STREAMS = [
     # macroblocks decoded again as P_Skip / B_Skip, src/edge264_headers.c:295-430) meets coherent vector fields and skip runs here
     ("nat_small_ipp8", "I" + "P" * 7, dict(cabac=False, qp=28, seed=9, W=20, H=12)),
     ("cabac_nat_small_ibbp10", "IPBBPBBPBB", dict(cabac=True, qp=29, seed=10, W=20, H=12)),
+    # High-profile tools on the same scene: 8x8 transform by choice, two references for P macroblocks, implicit weighted bi-prediction
+    ("cabac_nat_small_high_ibbp10", "IPBBPBBPBB", dict(cabac=True, qp=29, seed=11, W=20, H=12, high=True)),
+    ("cabac_nat1080_high_ibbp30", "I" + "PBB" * 9 + "PB", dict(cabac=True, qp=31, seed=12, high=True)),
 ]
 
 

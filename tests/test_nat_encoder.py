@@ -65,6 +65,21 @@ def test_transform_pair_reconstructs_within_the_quantiser_step():
     assert not ne.quant(ne.fwd4x4(np.zeros((4, 4), np.int64)), 28, False).any()
 
 
+def test_8x8_transform_pair_reconstructs_within_the_quantiser_step():
+    """the High-profile variant's forward 8x8 transform + quantiser against the standard's dequantiser + inverse (as the decoder runs them)"""
+    rng = np.random.default_rng(6)
+    for qp in (20, 28, 31, 36, 40):
+        res = rng.integers(-60, 61, (40, 8, 8))
+        rec = ne.inv8x8(ne.dequant8(ne.quant8(ne.fwd8x8(res), qp, False), qp))
+        step = 0.625 * 2 ** (qp / 6)
+        assert np.abs(rec - res).mean() < step / 2, qp
+    ramp = np.add.outer(np.arange(8), np.arange(8)) * 3          # a smooth block: two or three low-frequency levels describe it
+    lev = ne.quant8(ne.fwd8x8(ramp), 28, False)
+    assert (lev != 0).sum() <= 4 and np.abs(ne.inv8x8(ne.dequant8(lev, 28)) - ramp).max() <= 6
+    # the zig-zag of an 8x8 block is a permutation and starts along the first anti-diagonals
+    assert sorted(ne.ZZ8) == list(range(64)) and ne.ZZ8[:6] == [0, 1, 8, 16, 9, 2]
+
+
 def test_vector_prediction_rules():
     m = ne.Motion(4, 3)
     # nothing decoded yet: everything unavailable -> (0, 0); P_Skip without a left / top neighbour -> (0, 0)
