@@ -50,6 +50,10 @@ struct __attribute__((aligned(16))) WaveLds { // reconstruction scratch of one w
 	uint8_t ctile[2][9 * CT_STRIDE];
 	__attribute__((aligned(4))) uint8_t fz[32]; // intra 8x8: the filtered edge, FL(j) at j, the corner at 8, FT(i) at 12 + i
 	uint8_t pad_[8];
+	// the LEFT neighbour columns once more, contiguous (round 5): luma 16 samples, Cb 8, Cr 8.  In the tiles a column is 32 / 16 bytes apart per sample: the
+	// DC and plane modes of Intra16x16 / chroma read it with 16 (8) byte accesses per lane, each batch behind a full LDS drain (the ISA showed 14 + 8 + 6 + 6
+	// `s_waitcnt lgkmcnt(0)` in those four places); as dwords it is 4 (2) reads and the sums are v_sad_u8
+	__attribute__((aligned(4))) uint8_t lcol[3][16];
 	// residual inputs, staged so that the transforms never wait for memory (see coef_dma / slice_cache; the payload buffers live
 	// in IntraLds.coef)
 	__attribute__((aligned(4))) uint8_t ws[224];   // scaling lists of the cached slice: weightScale4x4[6][16], weightScale8x8[0..1][64]
@@ -396,9 +400,9 @@ E264_DEV void commit_intra_neighbours(WaveLds &L, const IntraNb &n, int lane)
 	const bool left = lane >= 32 && lane < 48;
 	const uint8_t vy = n.oky ? (uint8_t)n.y : 0, vc = n.okc ? (uint8_t)n.c : 0;
 	if (lane < 25) L.YT(-1, lane - 1) = vy;
-	else if (left) L.YT(lane - 32, -1) = vy;
+	else if (left) { L.YT(lane - 32, -1) = vy; L.lcol[0][lane - 32] = vy; }
 	if (lane < 18) L.CT(lane / 9, -1, lane % 9 - 1) = vc;
-	else if (left) L.CT((lane - 32) >> 3, lane & 7, -1) = vc;
+	else if (left) { L.CT((lane - 32) >> 3, lane & 7, -1) = vc; L.lcol[1 + ((lane - 32) >> 3)][lane & 7] = vc; }
 	wave_sync();
 }
 
@@ -532,6 +536,7 @@ E264_DEV void intra8x8_block(WaveLds &L, uint32_t e, int X0, int Y0, int mode, i
 }
 
 // Intra 16x16 in the pixel layout: returns 4 predicted samples for (row Yr, cols X..X+3)
+E264_DEV int byte_of(const uint32_t *w, int j) { return (int)(w[j >> 2] >> (8 * (j & 3)) & 255u); } // sample j of a row / column held as dwords (j: a constant of an unrolled loop)
 E264_DEV void intra16x16_pred(const WaveLds &L, int mode, int X, int Yr, int out[4])
 {
 #define T(i) ((int)L.YT(-1, (i)))
@@ -543,17 +548,21 @@ E264_DEV void intra16x16_pred(const WaveLds &L, int mode, int X, int Yr, int out
 	case 2: case 3: case 4: case 5: {
 		int st = 0, sl = 0;
 		if (mode == 2 || mode == 3) for (int i = 0; i < 4; i++) st = (int)v_sad_u8(*(const uint32_t *)&L.YT(-1, 4 * i), 0, (uint32_t)st); // the row above, four samples per instruction
-		if (mode == 2 || mode == 4) for (int i = 0; i < 16; i++) sl += Lf(i);
+		if (mode == 2 || mode == 4) for (int i = 0; i < 4; i++) sl = (int)v_sad_u8(((const uint32_t *)L.lcol[0])[i], 0, (uint32_t)sl); // the left column out of its contiguous copy
 		int v = mode == 2 ? (st + sl + 16) >> 5 : mode == 3 ? (st + 8) >> 4 : mode == 4 ? (sl + 8) >> 4 : 128;
 		for (int i = 0; i < 4; i++) out[i] = v;
 		return; }
 	case 6: {
+		// the row above and the left column as four dwords each, the corner as one byte: 9 LDS reads, the 32 samples extracted in registers
+		uint32_t tw[4], lw[4];
+		for (int i = 0; i < 4; i++) { tw[i] = *(const uint32_t *)&L.YT(-1, 4 * i); lw[i] = ((const uint32_t *)L.lcol[0])[i]; }
+		const int corner = T(-1);
 		int Hh = 0, V = 0;
 		for (int i = 0; i < 8; i++) {
-			Hh += (i + 1) * (T(8 + i) - (i == 7 ? T(-1) : T(6 - i)));
-			V += (i + 1) * (Lf(8 + i) - (i == 7 ? T(-1) : Lf(6 - i)));
+			Hh += (i + 1) * (byte_of(tw, 8 + i) - (i == 7 ? corner : byte_of(tw, 6 - i)));
+			V += (i + 1) * (byte_of(lw, 8 + i) - (i == 7 ? corner : byte_of(lw, 6 - i)));
 		}
-		int a = 16 * (Lf(15) + T(15)), b = (5 * Hh + 32) >> 6, c = (5 * V + 32) >> 6;
+		int a = 16 * (byte_of(lw, 15) + byte_of(tw, 15)), b = (5 * Hh + 32) >> 6, c = (5 * V + 32) >> 6;
 		for (int i = 0; i < 4; i++) out[i] = clip255((a + b * (X + i - 7) + c * (Yr - 7) + 16) >> 5);
 		return; }
 	}
@@ -573,7 +582,7 @@ E264_DEV int intra_chroma_px(const WaveLds &L, int p, int mode, int x, int y)
 		int bx = x >> 2, by = y >> 2;
 		int t = 0, l = 0;
 		t = (int)v_sad_u8(*(const uint32_t *)&L.CT(p, -1, bx * 4), 0, 0);
-		for (int i = 0; i < 4; i++) l += Lf(by * 4 + i);
+		l = (int)v_sad_u8(((const uint32_t *)L.lcol[1 + p])[by], 0, 0); // four samples of the left column out of its contiguous copy
 		if (mode == 1) return (t + 2) >> 2;
 		if (mode == 2) return (l + 2) >> 2;
 		if (bx == by) return (t + l + 4) >> 3;
@@ -581,12 +590,15 @@ E264_DEV int intra_chroma_px(const WaveLds &L, int p, int mode, int x, int y)
 	case 4: return Lf(y);
 	case 5: return T(x);
 	case 6: {
+		const uint32_t tw[2] = {*(const uint32_t *)&L.CT(p, -1, 0), *(const uint32_t *)&L.CT(p, -1, 4)};
+		const uint32_t lw[2] = {((const uint32_t *)L.lcol[1 + p])[0], ((const uint32_t *)L.lcol[1 + p])[1]};
+		const int corner = T(-1);
 		int Hh = 0, V = 0;
 		for (int i = 0; i < 4; i++) {
-			Hh += (i + 1) * (T(4 + i) - (i == 3 ? T(-1) : T(2 - i)));
-			V += (i + 1) * (Lf(4 + i) - (i == 3 ? T(-1) : Lf(2 - i)));
+			Hh += (i + 1) * (byte_of(tw, 4 + i) - (i == 3 ? corner : byte_of(tw, 2 - i)));
+			V += (i + 1) * (byte_of(lw, 4 + i) - (i == 3 ? corner : byte_of(lw, 2 - i)));
 		}
-		int a = 16 * (Lf(7) + T(7)), b = (34 * Hh + 32) >> 6, c = (34 * V + 32) >> 6;
+		int a = 16 * (byte_of(lw, 7) + byte_of(tw, 7)), b = (34 * Hh + 32) >> 6, c = (34 * V + 32) >> 6;
 		return clip255((a + b * (x - 3) + c * (y - 3) + 16) >> 5); }
 	}
 #undef T
