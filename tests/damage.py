@@ -66,6 +66,11 @@ RESENT = [
     ("cabac_nat_small_ibbp10", 2, 0.4), ("cabac_nat_small_ibbp10", 4, 0.5), ("cabac_nat_small_ibbp10", 6, 0.7),
     # ... and with the High-profile tools (8x8 transform by choice, two references in P macroblocks, implicit weighted bi-prediction)
     ("cabac_nat_small_high_ibbp10", 1, 0.5), ("cabac_nat_small_high_ibbp10", 3, 0.3), ("cabac_nat_small_high_ibbp10", 7, 0.6),
+    # ... and rate-control-shaped: adaptive QP and three slices per picture (the failed slice's neighbours above and below belong to other slices
+    # of the same picture: concealment next to macroblocks that stay)
+    ("nat_small_aq_slices_ipp8", 1, 0.5), ("nat_small_aq_slices_ipp8", 4, 0.4), ("nat_small_aq_slices_ipp8", 8, 0.6), ("nat_small_aq_slices_ipp8", 12, 0.3),
+    ("cabac_nat_small_aq_slices_ibbp10", 1, 0.5), ("cabac_nat_small_aq_slices_ibbp10", 4, 0.3), ("cabac_nat_small_aq_slices_ibbp10", 7, 0.5),
+    ("cabac_nat_small_aq_slices_ibbp10", 11, 0.6), ("cabac_nat_small_aq_slices_ibbp10", 14, 0.4),
 ]
 LOST = [("ipp_partitions", 3, 0.5), ("cabac_ipp", 3, 0.4), ("slices_deblock_idc", 11, 0.5), ("cabac_t8x8_slices", 11, 0.5)]
 # two failed slices in ONE picture, then both sent again: (fixture, first of the two slice NALs -- both in the same picture --, fractions kept).
@@ -76,4 +81,7 @@ RESENT2 = [
     ("cabac_slices_deblock_idc", 0, 0.6, 0.4), ("cabac_slices_deblock_idc", 4, 0.3, 0.7), ("cabac_slices_deblock_idc", 9, 0.6, 0.4),
     ("aso_slices", 1, 0.3, 0.7), ("aso_slices", 5, 0.6, 0.4), ("aso_slices", 10, 0.3, 0.7), ("aso_slices", 17, 0.6, 0.4),
     ("cabac_t8x8_slices", 0, 0.3, 0.7), ("cabac_t8x8_slices", 4, 0.6, 0.4), ("cabac_t8x8_slices", 10, 0.3, 0.7),
+    # round 5: encoder-shaped pictures of three slices
+    ("nat_small_aq_slices_ipp8", 0, 0.3, 0.7), ("nat_small_aq_slices_ipp8", 4, 0.6, 0.4), ("nat_small_aq_slices_ipp8", 10, 0.3, 0.7),
+    ("cabac_nat_small_aq_slices_ibbp10", 3, 0.6, 0.4), ("cabac_nat_small_aq_slices_ibbp10", 7, 0.3, 0.7), ("cabac_nat_small_aq_slices_ibbp10", 12, 0.6, 0.4),
 ]

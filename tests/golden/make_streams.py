@@ -459,7 +459,21 @@ class Synth:
                 bits = u(bits, 1, 0)  # ref_pic_list_modification_flag_l0
             if st == 1:
                 bits = u(bits, 1, 0)
-            if (st == 0 and self.wp) or (st == 1 and self.wbp == 1):
+            if st == 0 and self.wp and hdr.get("wp_table"):  # pred_weight_table (7.3.3.2) as an encoder decided it (nat_encoder.py): P slices only
+                t = hdr["wp_table"]
+                bits = ue(bits, t["luma_log2_denom"])
+                bits = ue(bits, t["chroma_log2_denom"])
+                for e in t["l0"]:
+                    bits = u(bits, 1, int(e["luma"] is not None))
+                    if e["luma"] is not None:
+                        bits = se(bits, e["luma"][0])
+                        bits = se(bits, e["luma"][1])
+                    bits = u(bits, 1, int(e["chroma"] is not None))
+                    if e["chroma"] is not None:
+                        for (w_, o_) in e["chroma"]:
+                            bits = se(bits, w_)
+                            bits = se(bits, o_)
+            elif (st == 0 and self.wp) or (st == 1 and self.wbp == 1):
                 ld, cd = r.randint(0, 6), r.randint(0, 6)
                 bits = ue(bits, ld)
                 bits = ue(bits, cd)

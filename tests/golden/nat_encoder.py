@@ -123,6 +123,11 @@ class Scene:
         g = np.random.default_rng(1000 + n)
         Y = Y + g.normal(0, 1, (H, W)) * noise
         C = [c + g.normal(0, 0.5, c.shape) for c in C]
+        fade = getattr(self, "fade", None)  # (first picture, last picture, gain at the end): a fade towards black between the two
+        if fade:
+            gain = 1.0 + (fade[2] - 1.0) * min(1.0, max(0.0, (n - fade[0]) / float(fade[1] - fade[0])))
+            Y = (Y - 16.0) * gain + 16.0
+            C = [(c - 128.0) * gain + 128.0 for c in C]
         q = lambda a: np.clip(np.rint(a), 0, 255).astype(np.uint8)  # noqa: E731
         return q(Y), q(C[0]), q(C[1])
 
@@ -302,11 +307,12 @@ class Motion:
 
     def __init__(self, W, H):
         self.W4, self.H4 = 4 * W, 4 * H
+        self.row0_4 = 0  # first row (in 4x4 blocks) of the slice being coded: rows above it belong to another slice
         self.ref = np.full((2, self.H4, self.W4), self.UNAVAIL, np.int8)
         self.mv = np.zeros((2, self.H4, self.W4, 2), np.int32)
 
     def get(self, lst, bx, by):
-        if bx < 0 or by < 0 or bx >= self.W4 or by >= self.H4:
+        if bx < 0 or by < self.row0_4 or bx >= self.W4 or by >= self.H4:
             return self.UNAVAIL, (0, 0)
         r = int(self.ref[lst, by, bx])
         if r < 0:
@@ -325,9 +331,14 @@ class Motion:
             Cn = self.get(lst, bx - 1, by - 1)
         return A, B, Cn
 
-    def mvp(self, lst, bx, by, w4, ref):
-        """8.4.1.3 (median prediction; no 16x8 / 8x16 partitions are ever written)"""
+    def mvp(self, lst, bx, by, w4, ref, rule=None):
+        """8.4.1.3: median prediction; rule "A" / "B" / "C": the directional prediction of a 16x8 (upper: B, lower: A) or 8x16 (left: A, right: C)
+        partition -- that neighbour's vector if it uses the same reference, the median otherwise"""
         A, B, Cn = self.neighbours(lst, bx, by, w4)
+        if rule is not None:
+            n = {"A": A, "B": B, "C": Cn}[rule]
+            if n[0] == ref:
+                return n[1]
         if B[0] == self.UNAVAIL and Cn[0] == self.UNAVAIL and A[0] != self.UNAVAIL:
             B = Cn = A
         same = [n for n in (A, B, Cn) if n[0] == ref]
@@ -352,17 +363,37 @@ def se_bits(v):
 # the encoder
 # ---------------------------------------------------------------------------------------------------------------------
 class NatEncoder(ms.Synth):
-    def __init__(self, g, name, frames, *, cabac, qp, seed, tables=None, search=8, W=W_MBS, H=H_MBS, high=False):
+    def __init__(self, g, name, frames, *, cabac, qp, seed, tables=None, search=8, W=W_MBS, H=H_MBS, high=False, aq=0, slice_rows=0, deblock_idc=0, fade=None, rect=False):
         """high: the High-profile tools on top -- 8x8 transform chosen per inter macroblock, two reference pictures for P macroblocks (per 16x16 /
-        per 8x8), implicit weighted bi-prediction (weighted_bipred_idc 2, 8.4.2.3.1) in B pictures"""
+        per 8x8), implicit weighted bi-prediction (weighted_bipred_idc 2, 8.4.2.3.1) in B pictures.
+        aq: adaptive quantisation -- every macroblock's QP is the stream's plus an offset of up to +-aq from the activity of its source samples
+        (flat regions finer, busy regions coarser, as rate control does): mb_qp_delta chains, edges between macroblocks of different QP.
+        slice_rows: a slice every so many macroblock rows (0: one slice per picture): neighbours across the boundary are not available for
+        vector / mode / context prediction, the skip runs and the QP chain start again.  deblock_idc: disable_deblocking_filter_idc of every slice.
+        fade: (first, last, gain) -- the scene fades towards black; P slices then carry an explicit prediction weight table (8.4.2.3.2) estimated per
+        reference from the means and spreads of the source and of the reference picture, as encoders do for fades.
+        rect: P macroblocks may also split into two 16x8 or two 8x16 partitions (own search, directional vector prediction of 8.4.1.3)."""
         super().__init__(g, name, W, H, frames, seed, num_refs=2 if ("B" in frames or high) else 1, cabac=cabac, tables=tables, qp=qp, level=4.0,
-                         pcm=0.0, t8x8=high, weighted_bipred=2 if high else 0)
-        self.high = high
+                         pcm=0.0, t8x8=high, weighted_bipred=2 if high else 0, slices=(-(-H // slice_rows) if slice_rows else 1), weighted_pred=1 if fade else 0)
+        self.high, self.aq, self.slice_rows, self.deblock_idc, self.rect = high, aq, slice_rows, deblock_idc, rect
         self.scene = Scene(16 * W, 16 * H, seed)
+        self.scene.fade = fade
         self.search = search
-        self.qpc = QPC[qp]
-        self.lam = max(2, int(0.85 * 2 ** ((qp - 12) / 6)))  # SAD units per bit
+        self.set_mb_qp(qp)
+        self.qp_prev = qp
         self.stats = {}
+
+    def set_mb_qp(self, q):
+        """the QP the macroblock under decision is quantised with"""
+        self.q = q
+        self.qpc = QPC[q]
+        self.lam = max(2, int(0.85 * 2 ** ((q - 12) / 6)))  # SAD units per bit
+
+    def take_qp(self):
+        """mb_qp_delta of a macroblock that carries one (7.4.5: relative to the previous macroblock of the slice in decoding order)"""
+        d = self.q - self.qp_prev
+        self.qp_prev = self.q
+        return d
 
     # ---- motion search of a whole picture against one reference (vectorised) ----------------------------------------------
     def search_picture(self, src, refpad, planes):
@@ -373,6 +404,10 @@ class NatEncoder(ms.Synth):
         best16 = np.full((Hm, Wm), 1 << 30, np.int64)
         mv8 = np.zeros((2 * Hm, 2 * Wm, 2), np.int32)
         mv16 = np.zeros((Hm, Wm, 2), np.int32)
+        rect = getattr(self, "rect", False)
+        if rect:  # 16x8 blocks (2H x W of them) and 8x16 blocks (H x 2W)
+            best168, best816 = np.full((2 * Hm, Wm), 1 << 30, np.int64), np.full((Hm, 2 * Wm), 1 << 30, np.int64)
+            mv168, mv816 = np.zeros((2 * Hm, Wm, 2), np.int32), np.zeros((Hm, 2 * Wm, 2), np.int32)
         Hs, Ws = S.shape
         for dy in range(-R, R + 1):
             for dx in range(-R, R + 1):
@@ -387,12 +422,20 @@ class NatEncoder(ms.Synth):
                 m = s16 + bias < best16
                 best16[m] = (s16 + bias)[m]
                 mv16[m] = (4 * dx, 4 * dy)
+                if rect:
+                    s168, s816 = s8.reshape(2 * Hm, Wm, 2).sum(2), s8.reshape(Hm, 2, 2 * Wm).sum(1)
+                    m = s168 + bias < best168
+                    best168[m] = (s168 + bias)[m]
+                    mv168[m] = (4 * dx, 4 * dy)
+                    m = s816 + bias < best816
+                    best816[m] = (s816 + bias)[m]
+                    mv816[m] = (4 * dx, 4 * dy)
         # sub-sample refinement: 8 neighbours at half, then at quarter sample distance
-        for (mv, best, bs) in ((mv16, best16, 16), (mv8, best8, 8)):
+        for (mv, best, bw, bh) in ((mv16, best16, 16, 16), (mv8, best8, 8, 8)) + (((mv168, best168, 16, 8), (mv816, best816, 8, 16)) if rect else ()):
             nby, nbx = mv.shape[:2]
-            yy = (np.arange(nby) * bs)[:, None, None, None] + np.arange(bs)[None, None, :, None]
-            xx = (np.arange(nbx) * bs)[None, :, None, None] + np.arange(bs)[None, None, None, :]
-            Sb = S.reshape(nby, bs, nbx, bs).transpose(0, 2, 1, 3).astype(np.int32)
+            yy = (np.arange(nby) * bh)[:, None, None, None] + np.arange(bh)[None, None, :, None]
+            xx = (np.arange(nbx) * bw)[None, :, None, None] + np.arange(bw)[None, None, None, :]
+            Sb = S.reshape(nby, bh, nbx, bw).transpose(0, 2, 1, 3).astype(np.int32)
             Hp, Wp = planes.shape[2:]
 
             def sad_of(v):
@@ -413,6 +456,8 @@ class NatEncoder(ms.Synth):
                         cur[m] = s[m]
                         mv[m] = cand[m]
             best[...] = cur
+        if rect:
+            return mv16, best16, mv8, best8, mv168, best168, mv816, best816
         return mv16, best16, mv8, best8
 
     # ---- residual of one macroblock ---------------------------------------------------------------------------------------
@@ -420,7 +465,7 @@ class NatEncoder(ms.Synth):
         """src, pred: (Y 16x16, Cb 8x8, Cr 8x8) int arrays.  -> (luma levels (4, 4, 4, 4) [by][bx][y][x] -- or (2, 2, 8, 8) when the 8x8 transform was chosen
         (allow_t8: an inter macroblock without partitions below 8x8 in a High-profile stream; self.last_t8 says which) --, luma dc levels (4, 4) or None,
         chroma dc levels [2][(2, 2)], chroma ac levels (2, 4, 4, 4), reconstruction (Y, Cb, Cr))"""
-        qp, qpc = self.qp, self.qpc
+        qp, qpc = self.q, self.qpc
         ry = (src[0] - pred[0]).reshape(4, 4, 4, 4).transpose(0, 2, 1, 3)  # [by][bx][y][x]
         Wy = fwd4x4(ry)
         self.last_t8 = False
@@ -635,12 +680,14 @@ class NatEncoder(ms.Synth):
             out[2] = np.full((4, 4), 128, np.int32)
         return out
 
-    def intra_mb(self, fc, rec, src, mx, my, sl, base, inter_cost=None):
+    def intra_mb(self, fc, rec, src, mx, my, sl, base, inter_cost=None, row0=0):
         """Decides and codes an intra macroblock on the in-loop reconstruction `rec` (Y, Cb, Cr int16 planes, updated).  Returns (mb dict, cost)
-        or None when inter_cost is given and intra is not better."""
+        or None when inter_cost is given and intra is not better.  row0: first macroblock row of the slice (nothing above it is a neighbour)."""
         x, y = 16 * mx, 16 * my
         sy = src[0][y:y + 16, x:x + 16].astype(np.int32)
         sc = [src[1 + p][y // 2:y // 2 + 8, x // 2:x // 2 + 8].astype(np.int32) for p in range(2)]
+        rec = [rec[0][16 * row0:], rec[1][8 * row0:], rec[2][8 * row0:]]  # views: the slice's own rows, y counted from its top from here on
+        y -= 16 * row0
         c16 = self.i16_preds(rec[0], x, y)
         m16 = min(c16, key=lambda m: np.abs(sy - c16[m]).sum())
         cost16 = int(np.abs(sy - c16[m16]).sum()) + 4 * self.lam
@@ -664,8 +711,8 @@ class NatEncoder(ms.Synth):
             cands = self.i4_preds(scratch, gx, gy, bool(tr))
             sb = sy[4 * by:4 * by + 4, 4 * bx:4 * bx + 4]
             m = min(cands, key=lambda k: np.abs(sb - cands[k]).sum() + (0 if k == 2 else self.lam))
-            L = quant(fwd4x4(sb - cands[m]), self.qp, True)
-            r = np.clip(cands[m] + inv4x4(dequant(L, self.qp)), 0, 255)
+            L = quant(fwd4x4(sb - cands[m]), self.q, True)
+            r = np.clip(cands[m] + inv4x4(dequant(L, self.q)), 0, 255)
             scratch[gy:gy + 4, gx:gx + 4] = r
             cost4 += int(np.abs(sb - cands[m]).sum()) + 3 * self.lam
             modes4.append(m)
@@ -700,13 +747,13 @@ class NatEncoder(ms.Synth):
             if self.t8x8:
                 mb = {"mb_type": base, "transform_size_8x8_flag": 0, **{k: v for k, v in mb.items() if k != "mb_type"}}
             if cbp:
-                mb.update(mb_qp_delta=0, coeffLevels=blocks)
+                mb.update(mb_qp_delta=self.take_qp(), coeffLevels=blocks)
             return mb, cost
         Ly, ldc, cdc, cac, recs = self.code_residual((sy, sc[0], sc[1]), (c16[m16], cpred[0], cpred[1]), True)
         rec[0][y:y + 16, x:x + 16] = recs[0]
         rec[1][y // 2:y // 2 + 8, x // 2:x // 2 + 8], rec[2][y // 2:y // 2 + 8, x // 2:x // 2 + 8] = recs[1], recs[2]
         cbp, blocks = self.residual_syntax(fc, mx, my, sl, Ly, ldc, cdc, cac, True)
-        mb = {"mb_type": base + 1 + m16 + 4 * (cbp >> 4) + 12 * (cbp & 15 == 15), "intra_chroma_pred_mode": cm, "mb_qp_delta": 0, "coeffLevels": blocks}
+        mb = {"mb_type": base + 1 + m16 + 4 * (cbp >> 4) + 12 * (cbp & 15 == 15), "intra_chroma_pred_mode": cm, "mb_qp_delta": self.take_qp(), "coeffLevels": blocks}
         return mb, cost
 
     # ---- pictures -----------------------------------------------------------------------------------------------------------
@@ -722,6 +769,8 @@ class NatEncoder(ms.Synth):
         srch = {(lst, ri): self.search_picture(src[0], r[0], r[3]) for lst, rl in refs.items() for ri, r in enumerate(rl)}
         wbi = getattr(self, "bi_weights", None)  # implicit weights (w0, w1) of the (L0[0], L1[0]) pair of this B picture, or None: (p0 + p1 + 1) >> 1
         cnt = dict(skip=0, direct=0, p16=0, p8x8=0, intra=0, bi=0, l0=0, l1=0, coded=0)
+        if self.rect:
+            cnt.update(p16x8=0, p8x16=0)
         out = []
         S = [p.astype(np.int32) for p in src]
 
@@ -735,26 +784,40 @@ class NatEncoder(ms.Synth):
             py, pc = np.zeros((16, 16), np.int32), [np.zeros((8, 8), np.int32), np.zeros((8, 8), np.int32)]
             for (ox, oy, sz, mvs) in parts:
                 ys, cs = [], []
+                sw, sh = sz if isinstance(sz, tuple) else (sz, sz)
                 for lst in sorted(mvs):
                     mv, ri = mvs[lst] if isinstance(mvs[lst][0], tuple) else (mvs[lst], 0)
                     R = refs[lst][ri]
-                    ys.append(luma_pred(R[3], x + ox, y + oy, mv, sz, sz))
-                    cs.append([chroma_pred(R[1 + p], (x + ox) // 2, (y + oy) // 2, mv, sz // 2, sz // 2) for p in range(2)])
+                    ys.append(luma_pred(R[3], x + ox, y + oy, mv, sw, sh))
+                    cs.append([chroma_pred(R[1 + p], (x + ox) // 2, (y + oy) // 2, mv, sw // 2, sh // 2) for p in range(2)])
+                    if len(R) > 4:  # explicit weights: the luma planes carry theirs already, chroma after the interpolation
+                        cs[-1] = [self.weigh(cs[-1][p], *R[4][p]) for p in range(2)]
                 acc_y = ys[0] if len(ys) == 1 else bipred(ys[0], ys[1])
                 acc_c = cs[0] if len(cs) == 1 else [bipred(cs[0][p], cs[1][p]) for p in range(2)]
-                py[oy:oy + sz, ox:ox + sz] = acc_y
+                py[oy:oy + sh, ox:ox + sw] = acc_y
                 for p in range(2):
-                    pc[p][oy // 2:(oy + sz) // 2, ox // 2:(ox + sz) // 2] = acc_c[p]
+                    pc[p][oy // 2:(oy + sh) // 2, ox // 2:(ox + sw) // 2] = acc_c[p]
             return py, pc[0], pc[1]
 
+        # adaptive quantisation: offset from the macroblock's activity (log2 of the luma variance) against the picture's mean
+        if self.aq:
+            var = S[0].reshape(Hm, 16, Wm, 16).transpose(0, 2, 1, 3).reshape(Hm, Wm, 256).var(axis=2)
+            act = np.log2(var + 1.0)
+            aq_off = np.clip(np.rint(0.9 * (act - act.mean())), -self.aq, self.aq).astype(int)
+        rows = self.slice_rows or Hm
         for my in range(Hm):
             for mx in range(Wm):
                 x, y = 16 * mx, 16 * my
-                fc.slice_of[my][mx] = 0
+                sl, row0 = my // rows, my // rows * rows
+                if mx == 0 and my == row0:  # a slice starts: nothing above is a neighbour, the QP chain starts from the slice's QP
+                    mot.row0_4 = 4 * row0
+                    self.qp_prev = self.qp
+                fc.slice_of[my][mx] = sl
+                self.set_mb_qp(max(10, min(51, self.qp + int(aq_off[my, mx]))) if self.aq else self.qp)
                 sy = S[0][y:y + 16, x:x + 16]
                 srcmb = (sy, S[1][y // 2:y // 2 + 8, x // 2:x // 2 + 8], S[2][y // 2:y // 2 + 8, x // 2:x // 2 + 8])
                 if st == 2:
-                    mb, _ = self.intra_mb(fc, rec, src, mx, my, 0, 0)
+                    mb, _ = self.intra_mb(fc, rec, src, mx, my, sl, 0, row0=row0)
                     mot.set(0, 4 * mx, 4 * my, 4, 4, -1)
                     mot.set(1, 4 * mx, 4 * my, 4, 4, -1)
                     out.append(mb)
@@ -766,7 +829,7 @@ class NatEncoder(ms.Synth):
                     refbits = 1 if nref > 1 else 0
                     skip_mv = mot.p_skip_mv(4 * mx, 4 * my)
                     for ri in range(nref):
-                        mv16, sad16, mv8, sad8 = srch[(0, ri)]
+                        mv16, sad16, mv8, sad8 = srch[(0, ri)][:4]
                         mvp16 = mot.mvp(0, 4 * mx, 4 * my, 4, ri)
                         best = (int(mv16[my, mx, 0]), int(mv16[my, mx, 1]))
                         for v in ({best, mvp16, skip_mv} if ri == 0 else {best, mvp16}):
@@ -778,8 +841,13 @@ class NatEncoder(ms.Synth):
                     for b in range(4):
                         q8.append(min((int(srch[(0, ri)][3][2 * my + (b >> 1), 2 * mx + (b & 1)]) + self.lam * refbits, ri) for ri in range(nref)))
                     cands.append((6 * self.lam + sum(c + 5 * self.lam for c, _ in q8), "p8x8", None))
+                    if self.rect:  # two 16x8 or two 8x16 partitions, each with the better of its references
+                        h168 = [min((int(srch[(0, ri)][5][2 * my + k, mx]) + self.lam * refbits, ri) for ri in range(nref)) for k in range(2)]
+                        h816 = [min((int(srch[(0, ri)][7][my, 2 * mx + k]) + self.lam * refbits, ri) for ri in range(nref)) for k in range(2)]
+                        cands.append((3 * self.lam + sum(c + 5 * self.lam for c, _ in h168), "p16x8", h168))
+                        cands.append((3 * self.lam + sum(c + 5 * self.lam for c, _ in h816), "p8x16", h816))
                     cost, kind, sel = min(cands, key=lambda c: c[0])
-                    r = self.intra_mb(fc, rec, src, mx, my, 0, 5, inter_cost=cost)
+                    r = self.intra_mb(fc, rec, src, mx, my, sl, 5, inter_cost=cost, row0=row0)
                     if r is not None:
                         out.append(r[0])
                         mot.set(0, 4 * mx, 4 * my, 4, 4, -1)
@@ -793,6 +861,23 @@ class NatEncoder(ms.Synth):
                         mb = {"mb_type": 0, "ref_idx": ({"0": ri} if nref > 1 else {}), "mvds": [(v[0] - mvp16[0], v[1] - mvp16[1])]}
                         if ri:
                             v = None  # (not the skip candidate: P_Skip predicts from reference 0)
+                    elif kind in ("p16x8", "p8x16"):
+                        parts, mvds, ridx = [], [], {}
+                        for k in range(2):
+                            ri = sel[k][1]
+                            if kind == "p16x8":
+                                bx4, by4, w4, h4, rule = 0, 2 * k, 4, 2, "BA"[k]
+                                vv = srch[(0, ri)][4][2 * my + k, mx]
+                            else:
+                                bx4, by4, w4, h4, rule = 2 * k, 0, 2, 4, "AC"[k]
+                                vv = srch[(0, ri)][6][my, 2 * mx + k]
+                            vv = (int(vv[0]), int(vv[1]))
+                            pr = mot.mvp(0, 4 * mx + bx4, 4 * my + by4, w4, ri, rule)
+                            mot.set(0, 4 * mx + bx4, 4 * my + by4, w4, h4, ri, vv)
+                            mvds.append((vv[0] - pr[0], vv[1] - pr[1]))
+                            parts.append((4 * bx4, 4 * by4, (4 * w4, 4 * h4), {0: (vv, ri)}))
+                            ridx[str((by4 >> 1) * 2 + (bx4 >> 1))] = ri
+                        mb = {"mb_type": 1 if kind == "p16x8" else 2, "ref_idx": (ridx if nref > 1 else {}), "mvds": mvds}
                     else:
                         parts, mvds, ridx = [], [], {}
                         for b in range(4):
@@ -814,13 +899,13 @@ class NatEncoder(ms.Synth):
                         out.append(None)
                         cnt["skip"] += 1
                     else:
-                        cbp, blocks = self.residual_syntax(fc, mx, my, 0, Ly, None, cdc, cac, False, t8=t8)
+                        cbp, blocks = self.residual_syntax(fc, mx, my, sl, Ly, None, cdc, cac, False, t8=t8)
                         mb["coded_block_pattern"] = cbp
                         if self.high and cbp & 15:
                             mb["transform_size_8x8_flag"] = int(t8)
                             cnt["t8"] = cnt.get("t8", 0) + int(t8)
                         if cbp:
-                            mb.update(mb_qp_delta=0, coeffLevels=blocks)
+                            mb.update(mb_qp_delta=self.take_qp(), coeffLevels=blocks)
                             cnt["coded"] += 1
                         out.append(mb)
                         cnt[kind] += 1
@@ -848,7 +933,7 @@ class NatEncoder(ms.Synth):
                     cands.append((int(np.abs(sy - dpred[0]).sum()), "direct", None))
                     one = {}
                     for l in range(2):
-                        mv16, sad16, _, _ = srch[(l, 0)]
+                        mv16, sad16, _, _ = srch[(l, 0)][:4]
                         pr = mot.mvp(l, 4 * mx, 4 * my, 4, 0)
                         v = (int(mv16[my, mx, 0]), int(mv16[my, mx, 1]))
                         bits = se_bits(v[0] - pr[0]) + se_bits(v[1] - pr[1])
@@ -884,21 +969,25 @@ class NatEncoder(ms.Synth):
                         out.append(None)
                         cnt["skip"] += 1
                     else:
-                        cbp, blocks = self.residual_syntax(fc, mx, my, 0, Ly, None, cdc, cac, False, t8=t8)
+                        cbp, blocks = self.residual_syntax(fc, mx, my, sl, Ly, None, cdc, cac, False, t8=t8)
                         mb["coded_block_pattern"] = cbp
                         if self.high and cbp & 15:  # (B_Direct_16x16 too: direct_8x8_inference_flag is 1)
                             mb["transform_size_8x8_flag"] = int(t8)
                             cnt["t8"] = cnt.get("t8", 0) + int(t8)
                         if cbp:
-                            mb.update(mb_qp_delta=0, coeffLevels=blocks)
+                            mb.update(mb_qp_delta=self.take_qp(), coeffLevels=blocks)
                             cnt["coded"] += 1
                         out.append(mb)
                         cnt[kind if kind != "direct" else "direct"] += 1
                 rec[0][y:y + 16, x:x + 16] = recs[0]
                 rec[1][y // 2:y // 2 + 8, x // 2:x // 2 + 8], rec[2][y // 2:y // 2 + 8, x // 2:x // 2 + 8] = recs[1], recs[2]
-        # fold the skipped macroblocks into mb_skip_run entries, as Synth.slice_nal writes them
+        mot.row0_4 = 0  # (as the co-located picture of a later B picture it is read everywhere)
+        self.set_mb_qp(self.qp)
+        # fold the skipped macroblocks into mb_skip_run entries, as Synth.slice_nal writes them; a run ends with its slice
         mbs, run, pending = [], 0, None
-        for mb in out:
+        for k, mb in enumerate(out):
+            if k % (rows * Wm) == 0:
+                run, pending = 0, None
             if st != 2 and mb is None:
                 e = {}
                 if run == 0:
@@ -945,7 +1034,12 @@ class NatEncoder(ms.Synth):
             src = self.scene.frame(p // 2)
             refs = {}
             self.bi_weights = None
-            if t == "P":
+            wp_table = None
+            if t == "P" and self.wp:
+                both = [self.fade_weights(src, decoded[q]) for q in ref_pocs[:2 if self.high else 1]]
+                refs[0] = [b[0] for b in both]
+                wp_table = dict(luma_log2_denom=5, chroma_log2_denom=5, l0=[b[1] for b in both])
+            elif t == "P":
                 refs[0] = [self.prepare(decoded[q]) for q in ref_pocs[:2 if self.high else 1]]
             elif t == "B":
                 before = max(q for q in ref_pocs if q < p)
@@ -966,8 +1060,14 @@ class NatEncoder(ms.Synth):
                 self.cabac_fs = cw.FrameState(Wm, Hm)
             hdr = dict(frame_num=frame_num % (1 << self.log2_fn), poc=p % (1 << self.log2_poc), is_ref=t != "B", idr=idx == 0,
                        nref0=len(refs[0]) if t == "P" else 1, nref1=1,
-                       idr_pic_id=0, slice_qp_delta=0, deblock=0, alpha=0, beta=0, mmco1=0, reorder_l0=0, pps_id=0)
-            out.append(self.slice_nal(fc, t, 0, Wm * Hm, 0, hdr, mbs=mbs))
+                       idr_pic_id=0, slice_qp_delta=0, deblock=self.deblock_idc, alpha=0, beta=0, mmco1=0, reorder_l0=0, pps_id=0)
+            if wp_table:
+                hdr["wp_table"] = wp_table
+            per = (self.slice_rows or Hm) * Wm
+            n_before = len(out)
+            for sl, first in enumerate(range(0, Wm * Hm, per)):
+                last = min(first + per, Wm * Hm)
+                out.append(self.slice_nal(fc, t, first, last, sl, hdr, mbs=mbs[first:last]))
             frames, codes = ref_dec.decode(b"".join(out))
             assert len(frames) == idx + 1 and all(c in (0, 105, 61) for c in codes), (self.name, idx, len(frames), codes[-4:])
             pocs = sorted(q for _, q in order[:idx + 1])
@@ -981,7 +1081,7 @@ class NatEncoder(ms.Synth):
             mine = np.mean(np.abs(rec[0] - src[0]))
             for k, v in cnt.items():
                 totals[k] = totals.get(k, 0) + v
-            print(f"  {self.name} picture {idx} ({t}, poc {p}): {sum(len(n) for n in out[-1:])} bytes, luma PSNR {psnr:.2f} dB, {cnt}", flush=True)
+            print(f"  {self.name} picture {idx} ({t}, poc {p}): {sum(len(n) for n in out[n_before:])} bytes, luma PSNR {psnr:.2f} dB, {cnt}", flush=True)
             del mine
         self.stats = totals
         return b"".join(out)
@@ -990,6 +1090,30 @@ class NatEncoder(ms.Synth):
     def prepare(fr):
         Y = pad(fr[0])
         return (Y, pad(fr[1]), pad(fr[2]), qpel_planes(Y))
+
+    @staticmethod
+    def weigh(a, w, o, ld):
+        """8.4.2.3.2, one list: Clip1(((pred * w + 2^(logWD - 1)) >> logWD) + o)"""
+        a = a.astype(np.int32) * w
+        return np.clip((((a + (1 << (ld - 1))) >> ld) if ld else a) + o, 0, 255)
+
+    def fade_weights(self, src, ref, ld=5, cd=5):
+        """(prepared reference with its luma planes weighted + the chroma weights for inter_pred, entry of the slice header's table) for one reference
+        picture `ref` (Y, Cb, Cr of the reference decoder) of the source picture `src`"""
+        sy, ry = src[0].astype(np.float64), ref[0].astype(np.float64)
+        w = int(np.clip(np.rint((1 << ld) * sy.std() / max(ry.std(), 1e-3)), 1, 127))
+        o = int(np.clip(np.rint(sy.mean() - w / float(1 << ld) * ry.mean()), -128, 127))
+        cw = []
+        for p in range(2):
+            sc, rc = src[1 + p].astype(np.float64), ref[1 + p].astype(np.float64)
+            wc = int(np.clip(np.rint((1 << cd) * sc.std() / max(rc.std(), 1e-3)), 1, 127))
+            oc = int(np.clip(np.rint(sc.mean() - wc / float(1 << cd) * rc.mean()), -128, 127))
+            cw.append((wc, oc, cd))
+        R = self.prepare(ref)
+        Rw = (self.weigh(R[0], w, o, ld).astype(np.uint8), R[1], R[2], self.weigh(R[3], w, o, ld).astype(np.uint8), cw)
+        luma_flag = (w, o) != (1 << ld, 0)
+        chroma_flag = any((wc, oc) != (1 << cd, 0) for wc, oc, _ in cw)
+        return Rw, dict(luma=(w, o) if luma_flag else None, chroma=[(wc, oc) for wc, oc, _ in cw] if chroma_flag else None)
 
 
 STREAMS = [
@@ -1002,6 +1126,18 @@ STREAMS = [
     # High-profile tools on the same scene: 8x8 transform by choice, two references for P macroblocks, implicit weighted bi-prediction
     ("cabac_nat_small_high_ibbp10", "IPBBPBBPBB", dict(cabac=True, qp=29, seed=11, W=20, H=12, high=True)),
     ("cabac_nat1080_high_ibbp30", "I" + "PBB" * 9 + "PB", dict(cabac=True, qp=31, seed=12, high=True)),
+    # rate-control-shaped: adaptive quantisation (QP 24..32 by activity: mb_qp_delta chains, deblocking edges between different QPs) and several
+    # slices per picture (every 4 / 5 macroblock rows; the CABAC one with disable_deblocking_filter_idc 2: slice edges left unfiltered)
+    ("nat_small_aq_slices_ipp8", "I" + "P" * 7, dict(cabac=False, qp=28, seed=13, W=20, H=12, aq=4, slice_rows=4)),
+    ("cabac_nat_small_aq_slices_ibbp10", "IPBBPBBPBB", dict(cabac=True, qp=29, seed=14, W=20, H=12, high=True, aq=4, slice_rows=5, deblock_idc=2)),
+    # a fade towards black: P slices with an explicit prediction weight table estimated per reference (the CABAC one with two references, each with
+    # its own weights and offsets)
+    ("nat_small_fade_wp_ipp8", "I" + "P" * 7, dict(cabac=False, qp=28, seed=16, W=20, H=12, fade=(0, 8, 0.25))),
+    ("cabac_nat_small_fade_wp_ipp8", "I" + "P" * 7, dict(cabac=True, qp=28, seed=17, W=20, H=12, high=True, fade=(0, 8, 0.3))),
+    # rectangular partitions in P pictures
+    ("nat_small_rect_ipp8", "I" + "P" * 7, dict(cabac=False, qp=27, seed=18, W=20, H=12, rect=True)),
+    ("cabac_nat_small_rect_ipp8", "I" + "P" * 7, dict(cabac=True, qp=27, seed=19, W=20, H=12, high=True, rect=True, aq=3)),
+    ("cabac_nat1080_aq_slices_ibbp12", "IPBBPBBPBBPB", dict(cabac=True, qp=31, seed=15, high=True, aq=4, slice_rows=17)),  # four slices of 17 rows
 ]
 
 

@@ -114,3 +114,67 @@ def test_the_committed_streams_are_encoder_shaped():
         size = os.path.getsize(os.path.join(HERE, "golden", "streams", name + ".264"))
         assert 4e6 < size * 8 * 30 / len(sums[name]["frames"]) < 6e6, (name, size)  # 4 - 6 Mbit/s at 30 pictures/s
     assert sums["cabac_nat1080_ibbp30"]["encoder_stats"]["direct"] > 20000   # B_Direct_16x16 beside B_Skip
+
+
+def test_the_rate_control_shaped_streams_vary_qp_and_cut_slices():
+    """nat_small_aq_slices_* (adaptive quantisation + a slice every few macroblock rows): what reaches the kernels really has several QPs inside a
+    picture, edges between macroblocks of different QP, several slice entries per picture and -- in the CABAC one -- disable_deblocking_filter_idc 2."""
+    from edge264_amd import front, packet as P
+    for name, rows, idc in (("nat_small_aq_slices_ipp8", 4, 0), ("cabac_nat_small_aq_slices_ibbp10", 5, 2)):
+        data = open(os.path.join(HERE, "golden", "streams", name + ".264"), "rb").read()
+        packets, _, _ = front.capture_packets(data)
+        assert len(packets) == (8 if idc == 0 else 10)
+        for pkt in packets:
+            pk = P.Packet(pkt)
+            W, H = pk.width_mbs, pk.height_mbs
+            qp = pk.mbs["qp"][:, 0].reshape(H, W).astype(int)
+            assert qp.max() - qp.min() >= 4, (name, qp.min(), qp.max())
+            assert (np.diff(qp, axis=1) != 0).mean() > 0.15, name             # neighbouring macroblocks of different QP: qPav, not QP, on the edge
+            sl = pk.mbs["slice"].reshape(H, W).astype(int)
+            assert (sl[:, 0] == sl[:, -1]).all() and len(np.unique(sl)) == -(-H // rows), (name, np.unique(sl))
+            assert all(int(s["disable_deblocking_filter_idc"]) == idc for s in pk.slices[:len(np.unique(sl))])
+
+
+def test_the_fade_streams_carry_explicit_weights_that_follow_the_fade():
+    """nat_small_fade_wp_* (a fade towards black): every P slice reaches the kernels with explicit luma weights below 1.0 (denominator 2^5) for
+    reference 0 -- the picture is darker than what it predicts from -- and most macroblocks still skip or predict without residual."""
+    from edge264_amd import front, packet as P
+    with open(os.path.join(HERE, "golden", "streams", "reference_md5.json")) as f:
+        sums = json.load(f)
+    for name in ("nat_small_fade_wp_ipp8", "cabac_nat_small_fade_wp_ipp8"):
+        data = open(os.path.join(HERE, "golden", "streams", name + ".264"), "rb").read()
+        packets, _, _ = front.capture_packets(data)
+        assert len(packets) == 8
+        for pkt in packets[1:]:
+            s = P.Packet(pkt).slices[0]
+            assert int(s["slice_type"]) == 0 and int(s["luma_log2_weight_denom"]) == 5
+            w = int(s["explicit_weights"][0][0])
+            assert 16 <= w < 32, (name, w)
+        assert sums[name]["encoder_stats"]["skip"] > 0.2 * 240 * 7, sums[name]["encoder_stats"]
+
+
+def test_directional_vector_prediction_of_rectangular_partitions():
+    """8.4.1.3: the upper 16x8 partition predicts from B, the lower from A, the left 8x16 from A, the right from C -- when that neighbour uses the
+    same reference; the median otherwise."""
+    m = ne.Motion(3, 2)
+    m.set(0, 0, 0, 4, 4, 0, (8, 0))       # macroblock (0, 0)
+    m.set(0, 4, 0, 4, 4, 1, (0, 12))      # (1, 0): another reference
+    m.set(0, 8, 0, 4, 4, 0, (-4, -4))     # (2, 0)
+    m.set(0, 0, 4, 4, 4, 0, (2, 6))       # (0, 1)
+    # macroblock (1, 1): A = (2, 6) ref 0, B = (0, 12) ref 1, C = (-4, -4) ref 0
+    assert m.mvp(0, 4, 4, 4, 1, "B") == (0, 12)           # upper 16x8 with reference 1: B's vector
+    assert m.mvp(0, 4, 4, 4, 0, "B") == m.mvp(0, 4, 4, 4, 0) == (0, 6)  # B has another reference: median of (2,6) (0,12) (-4,-4)
+    assert m.mvp(0, 4, 6, 4, 0, "A") == (2, 6)            # lower 16x8: A's vector
+    assert m.mvp(0, 4, 4, 2, 0, "A") == (2, 6)            # left 8x16
+    assert m.mvp(0, 6, 4, 2, 0, "C") == (-4, -4)          # right 8x16: C = macroblock (2, 0)
+    # lower 16x8 whose A has another reference: the median, with C replaced by D (the block up-left, C lies in a macroblock not decoded yet)
+    m.set(0, 4, 4, 4, 2, 1, (10, 10))                     # the upper partition is set first
+    assert m.mvp(0, 4, 6, 4, 1, "A") == (10, 10)          # A (2,6) ref 0, B = upper partition ref 1, D = (0,1) ref 0: only B has reference 1
+
+
+def test_the_rectangular_partition_streams_use_them():
+    with open(os.path.join(HERE, "golden", "streams", "reference_md5.json")) as f:
+        sums = json.load(f)
+    for name in ("nat_small_rect_ipp8", "cabac_nat_small_rect_ipp8"):
+        st = sums[name]["encoder_stats"]
+        assert st["p16x8"] > 150 and st["p8x16"] > 150 and st["p16"] > st["p16x8"] + st["p8x16"], (name, st)  # a minority, as encoders choose them
