@@ -72,7 +72,8 @@ RESENT = [
     ("cabac_nat_small_aq_slices_ibbp10", 1, 0.5), ("cabac_nat_small_aq_slices_ibbp10", 4, 0.3), ("cabac_nat_small_aq_slices_ibbp10", 7, 0.5),
     ("cabac_nat_small_aq_slices_ibbp10", 11, 0.6), ("cabac_nat_small_aq_slices_ibbp10", 14, 0.4),
 ]
-LOST = [("ipp_partitions", 3, 0.5), ("cabac_ipp", 3, 0.4), ("slices_deblock_idc", 11, 0.5), ("cabac_t8x8_slices", 11, 0.5)]
+LOST = [("ipp_partitions", 3, 0.5), ("cabac_ipp", 3, 0.4), ("slices_deblock_idc", 11, 0.5), ("cabac_t8x8_slices", 11, 0.5),
+        ("nat_small_aq_slices_ipp8", 22, 0.5), ("cabac_nat_small_aq_slices_ibbp10", 28, 0.4), ("nat_small_rect_ipp8", 7, 0.5)]
 # two failed slices in ONE picture, then both sent again: (fixture, first of the two slice NALs -- both in the same picture --, fractions kept).
 # I and P / B pictures, CAVLC and CABAC, three and four slices per picture, arbitrary slice order, 8x8 transform.  (Pairs that span two
 # pictures are left out: the unmodified reference aborts on them -- assertion in its own worker_loop, src/edge264_headers.c:465.)

@@ -363,7 +363,7 @@ def se_bits(v):
 # the encoder
 # ---------------------------------------------------------------------------------------------------------------------
 class NatEncoder(ms.Synth):
-    def __init__(self, g, name, frames, *, cabac, qp, seed, tables=None, search=8, W=W_MBS, H=H_MBS, high=False, aq=0, slice_rows=0, deblock_idc=0, fade=None, rect=False):
+    def __init__(self, g, name, frames, *, cabac, qp, seed, tables=None, search=8, W=W_MBS, H=H_MBS, high=False, aq=0, slice_rows=0, deblock_idc=0, fade=None, rect=False, sub=False):
         """high: the High-profile tools on top -- 8x8 transform chosen per inter macroblock, two reference pictures for P macroblocks (per 16x16 /
         per 8x8), implicit weighted bi-prediction (weighted_bipred_idc 2, 8.4.2.3.1) in B pictures.
         aq: adaptive quantisation -- every macroblock's QP is the stream's plus an offset of up to +-aq from the activity of its source samples
@@ -372,10 +372,11 @@ class NatEncoder(ms.Synth):
         vector / mode / context prediction, the skip runs and the QP chain start again.  deblock_idc: disable_deblocking_filter_idc of every slice.
         fade: (first, last, gain) -- the scene fades towards black; P slices then carry an explicit prediction weight table (8.4.2.3.2) estimated per
         reference from the means and spreads of the source and of the reference picture, as encoders do for fades.
-        rect: P macroblocks may also split into two 16x8 or two 8x16 partitions (own search, directional vector prediction of 8.4.1.3)."""
+        rect: P macroblocks may also split into two 16x8 or two 8x16 partitions (own search, directional vector prediction of 8.4.1.3).
+        sub: the quadrants of a P_8x8 macroblock may split further into 8x4, 4x8 or 4x4 partitions (searched on their own)."""
         super().__init__(g, name, W, H, frames, seed, num_refs=2 if ("B" in frames or high) else 1, cabac=cabac, tables=tables, qp=qp, level=4.0,
                          pcm=0.0, t8x8=high, weighted_bipred=2 if high else 0, slices=(-(-H // slice_rows) if slice_rows else 1), weighted_pred=1 if fade else 0)
-        self.high, self.aq, self.slice_rows, self.deblock_idc, self.rect = high, aq, slice_rows, deblock_idc, rect
+        self.high, self.aq, self.slice_rows, self.deblock_idc, self.rect, self.sub = high, aq, slice_rows, deblock_idc, rect, sub
         self.scene = Scene(16 * W, 16 * H, seed)
         self.scene.fade = fade
         self.search = search
@@ -404,7 +405,11 @@ class NatEncoder(ms.Synth):
         best16 = np.full((Hm, Wm), 1 << 30, np.int64)
         mv8 = np.zeros((2 * Hm, 2 * Wm, 2), np.int32)
         mv16 = np.zeros((Hm, Wm, 2), np.int32)
-        rect = getattr(self, "rect", False)
+        sub = getattr(self, "sub", False)
+        rect = getattr(self, "rect", False) or sub
+        if sub:  # 8x4 (4H x 2W blocks), 4x8 (2H x 4W), 4x4 (4H x 4W)
+            best84, best48, best44 = (np.full(sh, 1 << 30, np.int64) for sh in ((4 * Hm, 2 * Wm), (2 * Hm, 4 * Wm), (4 * Hm, 4 * Wm)))
+            mv84, mv48, mv44 = (np.zeros(sh + (2,), np.int32) for sh in ((4 * Hm, 2 * Wm), (2 * Hm, 4 * Wm), (4 * Hm, 4 * Wm)))
         if rect:  # 16x8 blocks (2H x W of them) and 8x16 blocks (H x 2W)
             best168, best816 = np.full((2 * Hm, Wm), 1 << 30, np.int64), np.full((Hm, 2 * Wm), 1 << 30, np.int64)
             mv168, mv816 = np.zeros((2 * Hm, Wm, 2), np.int32), np.zeros((Hm, 2 * Wm, 2), np.int32)
@@ -430,8 +435,16 @@ class NatEncoder(ms.Synth):
                     m = s816 + bias < best816
                     best816[m] = (s816 + bias)[m]
                     mv816[m] = (4 * dx, 4 * dy)
+                if sub:
+                    s44 = ad.reshape(4 * Hm, 4, 4 * Wm, 4).sum((1, 3))
+                    s84, s48 = s44.reshape(4 * Hm, 2 * Wm, 2).sum(2), s44.reshape(2 * Hm, 2, 4 * Wm).sum(1)
+                    for (sx, bestx, mvx) in ((s44, best44, mv44), (s84, best84, mv84), (s48, best48, mv48)):
+                        m = sx + bias < bestx
+                        bestx[m] = (sx + bias)[m]
+                        mvx[m] = (4 * dx, 4 * dy)
         # sub-sample refinement: 8 neighbours at half, then at quarter sample distance
-        for (mv, best, bw, bh) in ((mv16, best16, 16, 16), (mv8, best8, 8, 8)) + (((mv168, best168, 16, 8), (mv816, best816, 8, 16)) if rect else ()):
+        for (mv, best, bw, bh) in ((mv16, best16, 16, 16), (mv8, best8, 8, 8)) + (((mv168, best168, 16, 8), (mv816, best816, 8, 16)) if rect else ()) + (
+                ((mv84, best84, 8, 4), (mv48, best48, 4, 8), (mv44, best44, 4, 4)) if sub else ()):
             nby, nbx = mv.shape[:2]
             yy = (np.arange(nby) * bh)[:, None, None, None] + np.arange(bh)[None, None, :, None]
             xx = (np.arange(nbx) * bw)[None, :, None, None] + np.arange(bw)[None, None, None, :]
@@ -456,6 +469,8 @@ class NatEncoder(ms.Synth):
                         cur[m] = s[m]
                         mv[m] = cand[m]
             best[...] = cur
+        if sub:
+            return mv16, best16, mv8, best8, mv168, best168, mv816, best816, mv84, best84, mv48, best48, mv44, best44
         if rect:
             return mv16, best16, mv8, best8, mv168, best168, mv816, best816
         return mv16, best16, mv8, best8
@@ -840,7 +855,17 @@ class NatEncoder(ms.Synth):
                     q8 = []
                     for b in range(4):
                         q8.append(min((int(srch[(0, ri)][3][2 * my + (b >> 1), 2 * mx + (b & 1)]) + self.lam * refbits, ri) for ri in range(nref)))
-                    cands.append((6 * self.lam + sum(c + 5 * self.lam for c, _ in q8), "p8x8", None))
+                    if self.sub:  # every quadrant as 8x8, two 8x4, two 4x8 or four 4x4 (one reference per quadrant): (cost, refIdx, sub_mb_type)
+                        def sub_cost(b, ri, t):
+                            gy, gx = 2 * my + (b >> 1), 2 * mx + (b & 1)
+                            r_ = srch[(0, ri)]
+                            if t == 1:
+                                return int(r_[9][2 * gy, gx]) + int(r_[9][2 * gy + 1, gx]) + 11 * self.lam
+                            if t == 2:
+                                return int(r_[11][gy, 2 * gx]) + int(r_[11][gy, 2 * gx + 1]) + 11 * self.lam
+                            return int(r_[13][2 * gy:2 * gy + 2, 2 * gx:2 * gx + 2].sum()) + 21 * self.lam
+                        q8 = [min(q8[b] + (0,), *((sub_cost(b, ri, t) + self.lam * refbits, ri, t) for ri in range(nref) for t in (1, 2, 3))) for b in range(4)]
+                    cands.append((6 * self.lam + sum(q[0] + 5 * self.lam for q in q8), "p8x8", None))
                     if self.rect:  # two 16x8 or two 8x16 partitions, each with the better of its references
                         h168 = [min((int(srch[(0, ri)][5][2 * my + k, mx]) + self.lam * refbits, ri) for ri in range(nref)) for k in range(2)]
                         h816 = [min((int(srch[(0, ri)][7][my, 2 * mx + k]) + self.lam * refbits, ri) for ri in range(nref)) for k in range(2)]
@@ -879,20 +904,30 @@ class NatEncoder(ms.Synth):
                             ridx[str((by4 >> 1) * 2 + (bx4 >> 1))] = ri
                         mb = {"mb_type": 1 if kind == "p16x8" else 2, "ref_idx": (ridx if nref > 1 else {}), "mvds": mvds}
                     else:
-                        parts, mvds, ridx = [], [], {}
+                        parts, mvds, ridx, subs = [], [], {}, []
                         for b in range(4):
                             bx4, by4 = 2 * (b & 1), 2 * (b >> 1)
                             ri = q8[b][1]
-                            mv8 = srch[(0, ri)][2]
-                            vv = (int(mv8[2 * my + (b >> 1), 2 * mx + (b & 1), 0]), int(mv8[2 * my + (b >> 1), 2 * mx + (b & 1), 1]))
-                            pr = mot.mvp(0, 4 * mx + bx4, 4 * my + by4, 2, ri)
-                            mot.set(0, 4 * mx + bx4, 4 * my + by4, 2, 2, ri, vv)
-                            mvds.append((vv[0] - pr[0], vv[1] - pr[1]))
-                            parts.append((4 * bx4, 4 * by4, 8, {0: (vv, ri)}))
+                            t = q8[b][2] if self.sub else 0
+                            subs.append(t)
+                            # the sub-macroblock partitions of the quadrant in decoding order: (x, y in 4x4 units inside the quadrant, w, h, result arrays)
+                            shape = [[(0, 0, 2, 2, 2)], [(0, 0, 2, 1, 8), (0, 1, 2, 1, 8)], [(0, 0, 1, 2, 10), (1, 0, 1, 2, 10)],
+                                     [(0, 0, 1, 1, 12), (1, 0, 1, 1, 12), (0, 1, 1, 1, 12), (1, 1, 1, 1, 12)]][t]
+                            for (sx4, sy4, w4, h4, k) in shape:
+                                gx4, gy4 = 4 * mx + bx4 + sx4, 4 * my + by4 + sy4
+                                a = srch[(0, ri)][k][gy4 // h4, gx4 // w4]
+                                vv = (int(a[0]), int(a[1]))
+                                pr = mot.mvp(0, gx4, gy4, w4, ri)
+                                mot.set(0, gx4, gy4, w4, h4, ri, vv)
+                                mvds.append((vv[0] - pr[0], vv[1] - pr[1]))
+                                parts.append((4 * (bx4 + sx4), 4 * (by4 + sy4), (4 * w4, 4 * h4), {0: (vv, ri)}))
                             ridx[str(b)] = ri
-                        mb = {"mb_type": 3, "sub_mb_types": [0, 0, 0, 0], "ref_idx": (ridx if nref > 1 else {}), "mvds": mvds}
+                        mb = {"mb_type": 3, "sub_mb_types": subs, "ref_idx": (ridx if nref > 1 else {}), "mvds": mvds}
+                        if any(subs):
+                            cnt["subparts"] = cnt.get("subparts", 0) + 1
                     pred = inter_pred(parts)
-                    Ly, _, cdc, cac, recs = self.code_residual(srcmb, pred, False, allow_t8=self.high)
+                    can_t8 = self.high and not (kind == "p8x8" and any(mb["sub_mb_types"]))  # (7.3.5: no 8x8 transform over partitions below 8x8)
+                    Ly, _, cdc, cac, recs = self.code_residual(srcmb, pred, False, allow_t8=can_t8)
                     t8 = self.last_t8
                     zero = not Ly.any() and not any(d.any() for d in cdc) and not any(a.any() for a in cac)
                     if zero and kind == "p16" and v == skip_mv:
@@ -901,7 +936,7 @@ class NatEncoder(ms.Synth):
                     else:
                         cbp, blocks = self.residual_syntax(fc, mx, my, sl, Ly, None, cdc, cac, False, t8=t8)
                         mb["coded_block_pattern"] = cbp
-                        if self.high and cbp & 15:
+                        if can_t8 and cbp & 15:
                             mb["transform_size_8x8_flag"] = int(t8)
                             cnt["t8"] = cnt.get("t8", 0) + int(t8)
                         if cbp:
@@ -1137,6 +1172,9 @@ STREAMS = [
     # rectangular partitions in P pictures
     ("nat_small_rect_ipp8", "I" + "P" * 7, dict(cabac=False, qp=27, seed=18, W=20, H=12, rect=True)),
     ("cabac_nat_small_rect_ipp8", "I" + "P" * 7, dict(cabac=True, qp=27, seed=19, W=20, H=12, high=True, rect=True, aq=3)),
+    # ... and partitions below 8x8 (textured objects over a moving background: the small blocks sit on their borders)
+    ("nat_small_sub_ipp8", "I" + "P" * 7, dict(cabac=False, qp=24, seed=20, W=20, H=12, rect=True, sub=True)),
+    ("cabac_nat_small_sub_ipp8", "I" + "P" * 7, dict(cabac=True, qp=24, seed=21, W=20, H=12, high=True, rect=True, sub=True)),
     ("cabac_nat1080_aq_slices_ibbp12", "IPBBPBBPBBPB", dict(cabac=True, qp=31, seed=15, high=True, aq=4, slice_rows=17)),  # four slices of 17 rows
 ]
 

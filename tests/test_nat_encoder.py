@@ -178,3 +178,11 @@ def test_the_rectangular_partition_streams_use_them():
     for name in ("nat_small_rect_ipp8", "cabac_nat_small_rect_ipp8"):
         st = sums[name]["encoder_stats"]
         assert st["p16x8"] > 150 and st["p8x16"] > 150 and st["p16"] > st["p16x8"] + st["p8x16"], (name, st)  # a minority, as encoders choose them
+
+
+def test_the_sub_partition_streams_use_them():
+    with open(os.path.join(HERE, "golden", "streams", "reference_md5.json")) as f:
+        sums = json.load(f)
+    for name in ("nat_small_sub_ipp8", "cabac_nat_small_sub_ipp8"):
+        st = sums[name]["encoder_stats"]
+        assert 250 < st["subparts"] <= st["p8x8"], (name, st)   # P_8x8 macroblocks with a quadrant split below 8x8
