@@ -125,8 +125,12 @@ def test_two_rank_sharded_run_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    import socket
+    with socket.socket() as sk:  # a port that is free NOW (a fixed one collides with whatever else rendezvouses on this host)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     import json
