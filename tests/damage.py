@@ -71,6 +71,9 @@ RESENT = [
     ("nat_small_aq_slices_ipp8", 1, 0.5), ("nat_small_aq_slices_ipp8", 4, 0.4), ("nat_small_aq_slices_ipp8", 8, 0.6), ("nat_small_aq_slices_ipp8", 12, 0.3),
     ("cabac_nat_small_aq_slices_ibbp10", 1, 0.5), ("cabac_nat_small_aq_slices_ibbp10", 4, 0.3), ("cabac_nat_small_aq_slices_ibbp10", 7, 0.5),
     ("cabac_nat_small_aq_slices_ibbp10", 11, 0.6), ("cabac_nat_small_aq_slices_ibbp10", 14, 0.4),
+    # ... an I picture in the middle of the stream cut short (the I-slice concealment blends with the neighbours' DC before the copy arrives), Intra8x8 inside
+    ("nat_small_i8x8_iipp6", 1, 0.5), ("cabac_nat_small_i8x8_iipp6", 1, 0.4), ("cabac_nat_small_i8x8_iipp6", 3, 0.5),
+    ("nat_small_sub_ipp8", 3, 0.5), ("cabac_nat_small_fade_wp_ipp8", 4, 0.6),
 ]
 LOST = [("ipp_partitions", 3, 0.5), ("cabac_ipp", 3, 0.4), ("slices_deblock_idc", 11, 0.5), ("cabac_t8x8_slices", 11, 0.5),
         ("nat_small_aq_slices_ipp8", 22, 0.5), ("cabac_nat_small_aq_slices_ibbp10", 28, 0.4), ("nat_small_rect_ipp8", 7, 0.5)]

@@ -363,7 +363,7 @@ def se_bits(v):
 # the encoder
 # ---------------------------------------------------------------------------------------------------------------------
 class NatEncoder(ms.Synth):
-    def __init__(self, g, name, frames, *, cabac, qp, seed, tables=None, search=8, W=W_MBS, H=H_MBS, high=False, aq=0, slice_rows=0, deblock_idc=0, fade=None, rect=False, sub=False):
+    def __init__(self, g, name, frames, *, cabac, qp, seed, tables=None, search=8, W=W_MBS, H=H_MBS, high=False, aq=0, slice_rows=0, deblock_idc=0, fade=None, rect=False, sub=False, i8x8=False):
         """high: the High-profile tools on top -- 8x8 transform chosen per inter macroblock, two reference pictures for P macroblocks (per 16x16 /
         per 8x8), implicit weighted bi-prediction (weighted_bipred_idc 2, 8.4.2.3.1) in B pictures.
         aq: adaptive quantisation -- every macroblock's QP is the stream's plus an offset of up to +-aq from the activity of its source samples
@@ -373,10 +373,11 @@ class NatEncoder(ms.Synth):
         fade: (first, last, gain) -- the scene fades towards black; P slices then carry an explicit prediction weight table (8.4.2.3.2) estimated per
         reference from the means and spreads of the source and of the reference picture, as encoders do for fades.
         rect: P macroblocks may also split into two 16x8 or two 8x16 partitions (own search, directional vector prediction of 8.4.1.3).
-        sub: the quadrants of a P_8x8 macroblock may split further into 8x4, 4x8 or 4x4 partitions (searched on their own)."""
+        sub: the quadrants of a P_8x8 macroblock may split further into 8x4, 4x8 or 4x4 partitions (searched on their own).
+        i8x8 (with high): Intra8x8 beside Intra16x16 and Intra4x4 (5 of the 9 modes, on the filtered neighbours of 8.3.2.2.1)."""
         super().__init__(g, name, W, H, frames, seed, num_refs=2 if ("B" in frames or high) else 1, cabac=cabac, tables=tables, qp=qp, level=4.0,
                          pcm=0.0, t8x8=high, weighted_bipred=2 if high else 0, slices=(-(-H // slice_rows) if slice_rows else 1), weighted_pred=1 if fade else 0)
-        self.high, self.aq, self.slice_rows, self.deblock_idc, self.rect, self.sub = high, aq, slice_rows, deblock_idc, rect, sub
+        self.high, self.aq, self.slice_rows, self.deblock_idc, self.rect, self.sub, self.i8x8 = high, aq, slice_rows, deblock_idc, rect, sub, i8x8 and high
         self.scene = Scene(16 * W, 16 * H, seed)
         self.scene.fade = fade
         self.search = search
@@ -695,6 +696,56 @@ class NatEncoder(ms.Synth):
             out[2] = np.full((4, 4), 128, np.int32)
         return out
 
+    @staticmethod
+    def i8_preds(rec, x, y, top_right_ok, top_left_ok):
+        """{Intra8x8PredMode: 8x8 prediction} from the FILTERED neighbours (8.3.2.2.1, 8.3.2.2.2-6): 0 vertical, 1 horizontal, 2 DC, 3 diagonal
+        down-left, 4 diagonal down-right (5-8 are never chosen).  rec: the in-loop reconstruction, (x, y) the block in it; what is above row 0
+        or left of column 0 is not there."""
+        ta, la = y > 0, x > 0
+        tl = int(rec[y - 1, x - 1]) if (ta and la and top_left_ok) else None
+        T = L = None
+        if ta:
+            t = rec[y - 1, x:x + 8].astype(np.int64)
+            t = np.concatenate((t, rec[y - 1, x + 8:x + 16].astype(np.int64) if top_right_ok else np.full(8, t[7])))
+            T = np.empty(16, np.int64)
+            T[0] = (tl + 2 * t[0] + t[1] + 2) >> 2 if tl is not None else (3 * t[0] + t[1] + 2) >> 2
+            T[1:15] = (t[0:14] + 2 * t[1:15] + t[2:16] + 2) >> 2
+            T[15] = (t[14] + 3 * t[15] + 2) >> 2
+        if la:
+            l_ = rec[y:y + 8, x - 1].astype(np.int64)
+            L = np.empty(8, np.int64)
+            L[0] = (tl + 2 * l_[0] + l_[1] + 2) >> 2 if tl is not None else (3 * l_[0] + l_[1] + 2) >> 2
+            L[1:7] = (l_[0:6] + 2 * l_[1:7] + l_[2:8] + 2) >> 2
+            L[7] = (l_[6] + 3 * l_[7] + 2) >> 2
+        out = {}
+        if ta:
+            out[0] = np.tile(T[:8], (8, 1))
+            yy, xx = np.mgrid[0:8, 0:8]
+            k = xx + yy
+            ddl = (T[np.minimum(k, 15)] + 2 * T[np.minimum(k + 1, 15)] + T[np.minimum(k + 2, 15)] + 2) >> 2
+            ddl[7, 7] = (T[14] + 3 * T[15] + 2) >> 2
+            out[3] = ddl
+        if la:
+            out[1] = np.tile(L[:, None], (1, 8))
+        if ta and la:
+            out[2] = np.full((8, 8), (T[:8].sum() + L.sum() + 8) >> 4)
+        elif ta:
+            out[2] = np.full((8, 8), (T[:8].sum() + 4) >> 3)
+        elif la:
+            out[2] = np.full((8, 8), (L.sum() + 4) >> 3)
+        else:
+            out[2] = np.full((8, 8), 128)
+        if tl is not None:
+            TL = (int(rec[y - 1, x]) + 2 * tl + int(rec[y, x - 1]) + 2) >> 2
+            e = np.concatenate((L[::-1], [TL], T[:8]))  # e[8 + d]: d = x - y; -1 -> the corner, below it the left column, above it the top row
+            ddr = np.empty((8, 8), np.int64)
+            for j in range(8):
+                for i in range(8):
+                    d = 8 + i - j
+                    ddr[j, i] = (e[d - 1] + 2 * e[d] + e[d + 1] + 2) >> 2
+            out[4] = ddr
+        return out
+
     def intra_mb(self, fc, rec, src, mx, my, sl, base, inter_cost=None, row0=0):
         """Decides and codes an intra macroblock on the in-loop reconstruction `rec` (Y, Cb, Cr int16 planes, updated).  Returns (mb dict, cost)
         or None when inter_cost is given and intra is not better.  row0: first macroblock row of the slice (nothing above it is a neighbour)."""
@@ -732,11 +783,57 @@ class NatEncoder(ms.Synth):
             cost4 += int(np.abs(sb - cands[m]).sum()) + 3 * self.lam
             modes4.append(m)
             lev4[by, bx] = L
-        use4 = cost4 < cost16
-        cost = min(cost4, cost16)
+        cost8 = 1 << 60
+        if self.i8x8:  # Intra8x8: four blocks on a scratch reconstruction of their own
+            scr8 = rec[0][max(y - 1, 0):y + 16, :].copy()
+            cost8, modes8, lev8 = 0, [], np.zeros((2, 2, 8, 8), np.int64)
+            for b in range(4):
+                gx, gy = x + 8 * (b & 1), oy + 8 * (b >> 1)
+                tr = [y > 0, y > 0 and mx + 1 < self.W, True, False][b]
+                tlk = [x > 0 and y > 0, y > 0, x > 0, True][b]
+                cands = self.i8_preds(scr8, gx, gy, tr, tlk)
+                sb = sy[8 * (b >> 1):8 * (b >> 1) + 8, 8 * (b & 1):8 * (b & 1) + 8]
+                m = min(cands, key=lambda k: np.abs(sb - cands[k]).sum() + (0 if k == 2 else self.lam))
+                L = quant8(fwd8x8(sb - cands[m]), self.q, True)
+                scr8[gy:gy + 8, gx:gx + 8] = np.clip(cands[m] + inv8x8(dequant8(L, self.q)), 0, 255)
+                cost8 += int(np.abs(sb - cands[m]).sum()) + 3 * self.lam
+                modes8.append(m)
+                lev8[b >> 1, b & 1] = L
+        # (SAD favours the finer Intra4x4 prediction; what the 8x8 transform saves in bits is not in these costs: Intra8x8 is taken when its
+        # prediction error is within 60 % of Intra4x4's, as encoders that weigh the rate do)
+        use8 = cost8 < cost16 and (cost8 - 12 * self.lam) <= 1.6 * (cost4 - 48 * self.lam) + 48 * self.lam
+        use4 = not use8 and cost4 < cost16
+        cost = min(cost4, cost16, cost8)
         if inter_cost is not None and cost >= inter_cost:
             return None
         cpred = [cp[p][cm] for p in range(2)]
+        if use8:
+            _, _, cdc, cac, recs = self.code_residual((sy, sc[0], sc[1]), (sy, cpred[0], cpred[1]), None)
+            rec[0][y:y + 16, x:x + 16] = scr8[oy:oy + 16, x:x + 16]
+            rec[1][y // 2:y // 2 + 8, x // 2:x // 2 + 8], rec[2][y // 2:y // 2 + 8, x // 2:x // 2 + 8] = recs[1], recs[2]
+            fc.nxn[my][mx] = True
+            left, top = fc.mb_avail(mx - 1, my, sl), fc.mb_avail(mx, my - 1, sl)
+            rem = []
+            for b in range(4):
+                bx, by = 4 * mx + 2 * (b & 1), 4 * my + 2 * (b >> 1)
+                la, ta = (bx & 3) > 0 or left, (by & 3) > 0 or top
+                if not la or not ta:
+                    pm = 2
+                else:  # (8.3.2.1: of a neighbour coded as Intra4x4 the block beside this one's first row / above its first column counts)
+                    pa = fc.ipm[by][bx - 1] if fc.nxn[by >> 2][(bx - 1) >> 2] else 2
+                    pb = fc.ipm[by - 1][bx] if fc.nxn[(by - 1) >> 2][bx >> 2] else 2
+                    pm = min(pa, pb)
+                want = modes8[b]
+                rem.append(-1 if want == pm else (want if want < pm else want - 1))
+                for cy in range(2):
+                    for cx in range(2):
+                        fc.ipm[by + cy][bx + cx] = want
+            cbp, blocks = self.residual_syntax(fc, mx, my, sl, lev8, None, cdc, cac, False, t8=True)
+            mb = {"mb_type": base, "transform_size_8x8_flag": 1, "rem_intra8x8_pred_modes": rem, "intra_chroma_pred_mode": cm, "coded_block_pattern": cbp}
+            if cbp:
+                mb.update(mb_qp_delta=self.take_qp(), coeffLevels=blocks)
+            self.n_i8x8 = getattr(self, "n_i8x8", 0) + 1
+            return mb, cost
         if use4:
             # chroma through the common path (its luma part is discarded: the Intra4x4 luma was coded block by block above)
             _, _, cdc, cac, recs = self.code_residual((sy, sc[0], sc[1]), (sy, cpred[0], cpred[1]), None)
@@ -1118,6 +1215,8 @@ class NatEncoder(ms.Synth):
                 totals[k] = totals.get(k, 0) + v
             print(f"  {self.name} picture {idx} ({t}, poc {p}): {sum(len(n) for n in out[n_before:])} bytes, luma PSNR {psnr:.2f} dB, {cnt}", flush=True)
             del mine
+        if self.i8x8:
+            totals["i8x8"] = getattr(self, "n_i8x8", 0)
         self.stats = totals
         return b"".join(out)
 
@@ -1175,6 +1274,9 @@ STREAMS = [
     # ... and partitions below 8x8 (textured objects over a moving background: the small blocks sit on their borders)
     ("nat_small_sub_ipp8", "I" + "P" * 7, dict(cabac=False, qp=24, seed=20, W=20, H=12, rect=True, sub=True)),
     ("cabac_nat_small_sub_ipp8", "I" + "P" * 7, dict(cabac=True, qp=24, seed=21, W=20, H=12, high=True, rect=True, sub=True)),
+    # Intra8x8 by choice (smooth textures take it): two I pictures and the intra macroblocks of the P pictures
+    ("nat_small_i8x8_iipp6", "IIPPPP", dict(cabac=False, qp=26, seed=22, W=20, H=12, high=True, i8x8=True)),
+    ("cabac_nat_small_i8x8_iipp6", "IIPPPP", dict(cabac=True, qp=30, seed=23, W=20, H=12, high=True, i8x8=True, aq=3)),
     ("cabac_nat1080_aq_slices_ibbp12", "IPBBPBBPBBPB", dict(cabac=True, qp=31, seed=15, high=True, aq=4, slice_rows=17)),  # four slices of 17 rows
 ]
 

@@ -186,3 +186,16 @@ def test_the_sub_partition_streams_use_them():
     for name in ("nat_small_sub_ipp8", "cabac_nat_small_sub_ipp8"):
         st = sums[name]["encoder_stats"]
         assert 250 < st["subparts"] <= st["p8x8"], (name, st)   # P_8x8 macroblocks with a quadrant split below 8x8
+
+
+def test_the_intra8x8_streams_use_it():
+    """nat_small_i8x8_*: Intra8x8 macroblocks chosen by the encoder (transform_size_8x8_flag on an I_NxN macroblock) reach the kernels as such."""
+    from edge264_amd import front, packet as P
+    with open(os.path.join(HERE, "golden", "streams", "reference_md5.json")) as f:
+        sums = json.load(f)
+    for name in ("nat_small_i8x8_iipp6", "cabac_nat_small_i8x8_iipp6"):
+        assert sums[name]["encoder_stats"]["i8x8"] > 80, sums[name]["encoder_stats"]
+        data = open(os.path.join(HERE, "golden", "streams", name + ".264"), "rb").read()
+        packets, _, _ = front.capture_packets(data)
+        n8 = sum(int((P.Packet(p).mbs["kind"] == P.MB_I8x8).sum()) for p in packets)
+        assert n8 == sums[name]["encoder_stats"]["i8x8"], (name, n8)
