@@ -412,7 +412,8 @@ static int e264_finish_frame_(E264Emitter *e, int slot, int partial)
 		E264_SECTION(motion_off, b->mot, motion_bytes);
 	memset(pkt + at, 0, payload_off - at);
 #undef E264_SECTION
-	memcpy(pkt + payload_off, b->payload, b->payload_len);
+	if (b->payload_len) /* (a picture without a coded block has no payload buffer at all) */
+		memcpy(pkt + payload_off, b->payload, b->payload_len);
 	memset(pkt + payload_off + b->payload_len, 0, payload_bytes - b->payload_len);
 	if (partial || b->multi) {
 		/* a picture in several packets: what THIS packet reconstructs and deblocks, record by record (in the packet's copy) */

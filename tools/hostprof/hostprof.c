@@ -80,5 +80,7 @@ int main(int argc, char **argv)
 	const double w = now() - t0, c = cpu() - c0;
 	printf("{\"lib\": \"%s\", \"frames\": %ld, \"wall_s\": %.3f, \"cpu_s\": %.3f, \"frames_per_s\": %.1f, \"core_ms_per_picture\": %.3f, \"packets\": %ld, \"mean_packet_bytes\": %.0f}\n",
 		argv[1], frames, w, c, frames / w, frames ? c * 1e3 / frames : 0.0, packets, packets ? pkt_bytes / packets : 0.0);
+	for (int i = 0; i < nf; i++) free(buf[i]);
+	free(buf); free(len); /* (tools/sanitize runs this driver under the leak checker) */
 	return 0;
 }
