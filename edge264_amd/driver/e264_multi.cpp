@@ -55,6 +55,7 @@ struct Front {
 	int (*decode_NAL)(void *, const uint8_t *, const uint8_t *, void *, void *);
 	int (*get_frame)(void *, Edge264Frame *, int);
 	void (*free_dec)(void **);
+	void (*flush)(void *);
 	const uint8_t *(*find_start_code)(const uint8_t *, const uint8_t *, int);
 	void (*set_sink)(int);
 	void (*set_device)(int);
@@ -95,6 +96,7 @@ struct Stream {
 	std::atomic<bool> finished{false}; // its worker will queue nothing more (read outside `mu` by the other workers)
 	std::atomic<bool> held{false}; // a parser thread is inside this decoder right now
 	int dev_index = 0;     // which of --devices holds its frames
+	bool just_flushed = false; // the last thing done to it was edge264_flush, to get it out of ENOBUFS with nothing to fetch
 };
 
 static void write_frame(FILE *f, const Edge264Frame &fr)
@@ -166,7 +168,7 @@ int main(int argc, char **argv)
 	if (!fl) { fprintf(stderr, "e264_multi: %s\n", dlerror()); return 2; }
 	Front F; Hip H;
 	bind(fl, "edge264_alloc", F.alloc); bind(fl, "edge264_decode_NAL", F.decode_NAL); bind(fl, "edge264_get_frame", F.get_frame);
-	bind(fl, "edge264_free", F.free_dec); bind(fl, "edge264_find_start_code", F.find_start_code);
+	bind(fl, "edge264_free", F.free_dec); bind(fl, "edge264_flush", F.flush); bind(fl, "edge264_find_start_code", F.find_start_code);
 	bind(fl, "e264front_set_sink", F.set_sink); bind(fl, "e264front_set_device", F.set_device); bind(fl, "e264front_set_download", F.set_download);
 	bind(fl, "e264front_set_pinned", F.set_pinned);
 	bind(fl, "e264front_take_packet", F.take_packet); bind(fl, "e264front_free_packet", F.free_packet);
@@ -217,11 +219,14 @@ int main(int argc, char **argv)
 
 	auto drain = [&](Stream &s) {
 		Edge264Frame fr;
+		long n = 0;
 		while (F.get_frame(s.dec, &fr, 0) == 0) {
-			s.frames++;
+			s.frames++; n++;
 			if (s.out) write_frame(s.out, fr);
 		}
+		return n;
 	};
+	std::atomic<long> stuck_flushes{0}, stuck_given_up{0};
 	long rounds = 0, packets = 0, total_frames = 0;
 	// where the parser threads' time goes (summed over threads, seconds): inside edge264_decode_NAL, fetching frames, asleep with nothing to do
 	std::atomic<long long> ns_decode{0}, ns_drain{0}, ns_idle{0}, ns_submit{0};
@@ -257,10 +262,23 @@ int main(int argc, char **argv)
 					if (!s.q.empty()) return BLOCKED;
 				}
 				const long long t_dr = now_ns();
-				drain(s);
+				const long n_out = drain(s);
 				ns_drain += now_ns() - t_dr;
+				if (n_out == 0) {
+					// ENOBUFS and nothing to hand out: a picture that will never complete (one of its slices failed and never came again) holds the
+					// frame buffers, and the same NAL would return ENOBUFS for ever (until round 5 this loop did exactly that).  edge264_flush is
+					// the API's way out (edge264.h:66: drop the delayed frames, clear the decoder state); decoding resumes at the next IDR picture.
+					// A decoder that is still stuck right after a flush is given up.
+					if (s.just_flushed) { s.done = true; stuck_given_up++; break; }
+					F.flush(s.dec);
+					s.just_flushed = true;
+					stuck_flushes++;
+					drain(s);
+					continue;
+				}
 				continue;
 			}
+			s.just_flushed = false;
 			void *pkt = nullptr; size_t bytes = 0;
 			bool got = F.take_packet(s.dec, &pkt, &bytes) == 0;
 			if (res == ENODATA || s.nal >= s.end) s.done = true;
@@ -450,9 +468,9 @@ int main(int argc, char **argv)
 	}
 	printf("{\"streams\": %zu, \"devices\": %zu, \"threads\": %d, \"frames\": %ld, \"packets\": %ld, \"rounds\": %ld, \"avg_batch\": %.2f, \"seconds\": %.4f, \"frames_per_s\": %.1f, "
 		"\"thread_seconds\": {\"decode_NAL\": %.2f, \"get_frame\": %.2f, \"idle\": %.2f, \"submit_calls\": %.2f}, \"decode_ms_per_picture\": %.3f, "
-		"\"steady\": {\"after_seconds\": %.3f, \"frames_per_s\": %.1f, \"decode_ms_per_picture\": %.3f}}\n",
+		"\"steady\": {\"after_seconds\": %.3f, \"frames_per_s\": %.1f, \"decode_ms_per_picture\": %.3f}, \"stuck_decoders_flushed\": %ld, \"stuck_decoders_given_up\": %ld}\n",
 		S.size(), devices.size(), n_threads, total_frames, packets, rounds, rounds ? (double)packets / rounds : 0.0, sec, sec > 0 ? total_frames / sec : 0.0,
 		ns_decode.load() * 1e-9, ns_drain.load() * 1e-9, ns_idle.load() * 1e-9, ns_submit.load() * 1e-9, packets ? ns_decode.load() * 1e-6 / (double)packets : 0.0,
-		st_after, st_fps, st_ms);
+		st_after, st_fps, st_ms, stuck_flushes.load(), stuck_given_up.load());
 	return 0;
 }

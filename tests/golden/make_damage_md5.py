@@ -20,6 +20,9 @@ for name, which, keep in damage.RESENT:
 for name, which, ka, kb in damage.RESENT2:
     frames, codes = ref.decode(damage.two_truncated_then_resent(name, which, ka, kb))
     out[f"{name}-{which}+{which + 1}-{ka}-{kb}"] = {"nal_codes": codes, "md5": [hashlib.md5(b"".join(p.tobytes() for p in fr)).hexdigest() for fr in frames]}
+for name, which, keep in damage.LOST:  # the slice never comes again: what the reference hands out before the stream is stuck
+    frames, codes = ref.decode(damage.truncated_only(name, which, keep))
+    out[f"lost-{name}-{which}-{keep}"] = {"nal_codes": codes, "md5": [hashlib.md5(b"".join(p.tobytes() for p in fr)).hexdigest() for fr in frames]}
 with open(os.path.join(damage.STREAMS, "damage_md5.json"), "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)
 print(len(out), "scenarios")

@@ -131,6 +131,12 @@ def test_concealment_on_the_gpu(front):
         want = sums[f"{name}-{which}+{which + 1}-{ka}-{kb}"]
         assert codes == want["nal_codes"], (name, which, ka, kb)
         assert md5s(frames) == want["md5"], (name, which, ka, kb)
+    # a slice lost for good: the stream ends stuck (ENOBUFS with nothing to hand out), everything before is the reference's
+    for name, which, keep in damage.LOST:
+        frames, codes = front.decode(damage.truncated_only(name, which, keep))
+        want = sums[f"lost-{name}-{which}-{keep}"]
+        assert codes == want["nal_codes"], (name, which, keep)
+        assert md5s(frames) == want["md5"], (name, which, keep)
 
 
 def test_decode_to_device_without_readback(front):

@@ -88,3 +88,36 @@ def test_multi_stream_driver_devices(tmp_path):
         for n in names:
             assert frame_md5s(tmp_path / f"s{k}.yuv", sums[n]["width_mbs"], sums[n]["height_mbs"], sums[n]["views"]) == sums[n]["md5"], f"stream {k} ({n})"
             k += 1
+
+
+def test_multi_stream_driver_survives_a_lost_slice(tmp_path):
+    """Decoders whose last picture never completes (a slice failed and never came again: edge264_decode_NAL answers ENOBUFS, nothing can be handed
+    out) beside intact ones, on the device: the driver gets them out with edge264_flush instead of offering the same NAL for ever, every frame
+    handed out equals the reference's (tests/golden/make_damage_md5.py), the intact decoders of the same batches are untouched."""
+    from tests import damage
+    with open(os.path.join(STREAMS, "damage_md5.json")) as f:
+        dsums = json.load(f)
+    with open(os.path.join(STREAMS, "reference_md5.json")) as f:
+        sums = json.load(f)
+    lost = [("ipp_partitions", 3, 0.5), ("cabac_t8x8_slices", 11, 0.5), ("nat_small_aq_slices_ipp8", 22, 0.5), ("cabac_nat_small_aq_slices_ibbp10", 28, 0.4)]
+    intact = ["cabac_ipp", "nat_small_rect_ipp8", "slices_deblock_idc"]
+    files = []
+    for (n, w, k) in lost:
+        p = tmp_path / f"lost-{n}.264"
+        p.write_bytes(damage.truncated_only(n, w, k))
+        files.append(str(p))
+    files += [os.path.join(STREAMS, n + ".264") for n in intact]
+    repeat = 2
+    out = subprocess.run([EXE, "--front", FRONT, "--hip", HIP, "--repeat", str(repeat), "--threads", "3", "--out", str(tmp_path)] + files,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    st = json.loads(out.stdout.strip().splitlines()[-1])
+    assert st["stuck_decoders_flushed"] == repeat * len(lost) and st["stuck_decoders_given_up"] == 0, st
+    k = 0
+    for _ in range(repeat):
+        for (n, w, kp) in lost:
+            assert frame_md5s(tmp_path / f"s{k}.yuv", sums[n]["width_mbs"], sums[n]["height_mbs"]) == dsums[f"lost-{n}-{w}-{kp}"]["md5"], f"stream {k} (lost {n})"
+            k += 1
+        for n in intact:
+            assert frame_md5s(tmp_path / f"s{k}.yuv", sums[n]["width_mbs"], sums[n]["height_mbs"]) == sums[n]["md5"], f"stream {k} ({n})"
+            k += 1

@@ -65,3 +65,28 @@ def test_parse_only_driver_produces_the_capture_sinks_packets(tmp_path):
         assert sum(got.values()) == st["packets"] == repeat * sum(want.values())
         assert got == collections.Counter({k: v * repeat for k, v in want.items()}), "the driver's packets do not describe the capture sink's pictures"
     assert stats[1]["packets"] == stats[4]["packets"]
+
+
+@pytest.mark.skipif(not (os.path.exists(EXE) and os.path.exists(FRONT)), reason="libraries not built")
+def test_a_decoder_whose_picture_never_completes_does_not_hold_the_driver(tmp_path):
+    """A slice that fails and never comes again leaves its picture incomplete: edge264_decode_NAL answers ENOBUFS and edge264_get_frame has nothing
+    to hand out (the unmodified reference behaves the same: tests/test_frontend_concealment.py::test_failed_slice_never_resent).  Until round 5 the
+    driver offered the same NAL again for ever.  Now it takes the API's way out (edge264_flush), every decoder ends, the other decoders of the run
+    are not disturbed and each play of a damaged stream hands out what the reference hands out for it."""
+    from tests import damage
+    from edge264_amd import front
+    want = {("ipp_partitions", 3, 0.5): 3, ("cabac_t8x8_slices", 11, 0.5): 3, ("nat_small_aq_slices_ipp8", 22, 0.5): 7, ("cabac_nat_small_aq_slices_ibbp10", 28, 0.4): 8}
+    files = []
+    for (n, w, k) in want:
+        p = tmp_path / f"lost-{n}.264"
+        p.write_bytes(damage.truncated_only(n, w, k))
+        files.append(str(p))
+    intact = [os.path.join(STREAMS, n + ".264") for n in ("cabac_ipp", "nat_small_rect_ipp8")]
+    n_intact = sum(front.capture_packets(open(f, "rb").read())[1] for f in intact)
+    for threads in (1, 3):
+        out = subprocess.run([EXE, "--front", FRONT, "--hip", "/nonexistent/libedge264_hip.so", "--threads", str(threads), "--repeat", "2", "--parse-only", "--stay", "--ahead", "5"]
+                             + files + intact, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-2000:]
+        st = json.loads(out.stdout.strip().splitlines()[-1])
+        assert st["frames"] == 2 * (sum(want.values()) + n_intact), st
+        assert st["stuck_decoders_flushed"] == 2 * len(want) and st["stuck_decoders_given_up"] == 0, st

@@ -7,6 +7,7 @@ reference's parser with our emitters, capture sink: no device involved) over
 and sorts what the sanitizers say by WHERE it happened: in the emitters / wrappers of edge264_amd/frontend (ours: must be none), or inside
 the reference's own parser sources (reported, not ours to change).  A corrupted stream may also stop at one of the reference's own
 assertions (src/edge264_headers.c:465): counted, not an error of the binding.
+A second leg runs the many-decoder driver (edge264_amd/driver/e264_multi.cpp, --parse-only: no device) and the front end under ThreadSanitizer.
 
     python tools/sanitize/run.py [--flips N] [--out profiles/r05_sanitizers.txt]
 """
@@ -61,6 +62,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--flips", type=int, default=3, help="corrupted variants per fixture")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--no-tsan", action="store_true", help="skip the ThreadSanitizer leg (e264_multi --parse-only)")
     args = ap.parse_args()
     subprocess.run(["make", "-C", HERE], check=True, stdout=subprocess.DEVNULL)
     exe, lib = os.path.join(HERE, "hostprof_san"), os.path.join(HERE, "libedge264_hipfront_san.so")
@@ -137,6 +139,27 @@ def main():
     lines.append(f"distinct reports located in the reference's own sources (its parser, compiled where it lies), or other exits: {len(theirs)}")
     for (head, where), runs in theirs.items():
         lines.append(f"  {head}\n      at {where}\n      in {len(runs)} runs, e.g. {runs[0]}")
+    # ---- ThreadSanitizer: the many-decoder driver, parse-only (no device), any thread advances any decoder ----
+    if not args.no_tsan:
+        subprocess.run(["make", "-C", HERE, "tsan"], check=True, stdout=subprocess.DEVNULL)
+        multi, tlib = os.path.join(HERE, "e264_multi_tsan"), os.path.join(HERE, "libedge264_hipfront_tsan.so")
+        small = [f for f in fixtures if os.path.getsize(f) < 60_000]
+        damaged = [c[2] for c in cases if c[0] in ("resent", "resent2", "lost")]
+        lines += ["", "ThreadSanitizer over e264_multi --parse-only (driver and front end built with it; threads x decoders, --stay --ahead 5, every stream played twice):"]
+        tsan_bad = 0
+        for label, files, threads in (("intact small fixtures", small, 2), ("intact small fixtures", small, 5), ("intact small fixtures", small, 16),
+                                      ("damaged streams", damaged, 4), ("both, no --stay", small + damaged, 7)):
+            cmd = [multi, "--front", tlib, "--hip", "/nonexistent", "--parse-only", "--threads", str(threads), "--repeat", "2"]
+            cmd += [] if "no --stay" in label else ["--stay", "--ahead", "5"]
+            p = subprocess.run(cmd + files, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0"), capture_output=True, text=True, timeout=900)
+            n = p.stderr.count("WARNING: ThreadSanitizer")
+            tsan_bad += n + (p.returncode != 0)
+            m = re.search(r'"frames": (\d+)', p.stdout)
+            lines.append(f"  {label:24s} {len(files):3d} decoders x2  {threads:2d} threads   frames {m.group(1) if m else '?':>5s}   warnings {n}   exit {p.returncode}")
+            for w in re.findall(r"SUMMARY: ThreadSanitizer: [^\n]*", p.stderr)[:5]:
+                lines.append(f"      {w}")
+        if tsan_bad:
+            ours["tsan"] = ["tsan"]
     text = "\n".join(lines) + "\n"
     print(text)
     if args.out:
