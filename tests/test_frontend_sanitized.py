@@ -23,3 +23,14 @@ def test_no_sanitizer_report_in_the_emitters(tmp_path):
     first = {ln.split()[0]: ln for ln in text.splitlines() if ln.startswith(("fixture", "resent", "lost", "truncated", "flips_last"))}
     assert " clean 55 " in first["fixture"] or "reports_ours 0" in first["fixture"]
     assert all("reports_ours 0" in ln and "other_exit 0" in ln for ln in first.values()), first
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++") or not os.path.exists(os.path.join(ROOT, "edge264_amd", "libedge264_hip.so")),
+                    reason="needs the ROCm clang (ASan runtime) and the built back end (its host-side packet validation)")
+def test_validated_packets_keep_the_kernels_in_bounds():
+    """tools/sanitize/kernel_fuzz.py, quick form: damaged command packets that the product's validation still accepts run through the kernels' source
+    (host build, AddressSanitizer) on buffers of exactly the back end's sizes; a report is an access the device would make outside its allocations."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sanitize", "kernel_fuzz.py"), "--per-packet", "2", "--stride", "9", "--seed", "7"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "no sanitizer report" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+    assert "AddressSanitizer" not in p.stderr.replace("ASan doesn't fully support", "")
