@@ -445,8 +445,15 @@ static E264MbStage *e264_touch_ctx(Edge264Context *ctx)
 {
 	E264Emitter *e = e264_tls_emitter;
 	E264MbStage *c = &e->cur;
-	if (c->valid && c->mbptr == ctx->_mb && c->serial == e->serial)
-		return c; /* the macroblock under assembly (most calls: one per coded block) */
+	if (c->valid && c->mbptr == ctx->_mb && c->serial == e->serial) { /* the macroblock under assembly (most calls: one per coded block) */
+		/* ... which an intra leaf may have opened from a bare sample pointer: this is then the first call of the slice that sees its constants.
+		 * (Round 5, found by tools/stream_sweep.py: an I slice with disable_deblocking_filter_idc 1 -- deblock_mb returns before it looks at the
+		 * slice -- kept the default flat scaling lists whatever the parameter sets said.) */
+		E264FrameBuilder *b = &e->fb[c->slot];
+		if (__builtin_expect(!b->slice_filled[c->slice], 0))
+			e264_fill_slice(e, b, c->slice, ctx);
+		return c;
+	}
 	size_t off;
 	int slot = e264_locate(e, ctx->samples_mb[0], &off);
 	if (slot < 0)

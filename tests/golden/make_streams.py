@@ -658,6 +658,10 @@ STREAMS = [
     ("cabac_reorder_longterm", 5, 4, "IPPPPBP", 62, dict(cabac=True, pcm=0.0, num_refs=3, longterm=True, reorder=0.8, t8x8=True)),
     ("reorder_weighted", 5, 4, "IPPPBPP", 63, dict(num_refs=4, reorder=0.9, weighted_pred=1, weighted_bipred=2)),
     ("aso_slices", 6, 5, "IPPBP", 64, dict(slices=4, aso=True, num_refs=2, deblock=(0, 2))),
+    # round 5 (found by tools/stream_sweep.py): scaling lists from the parameter sets in slices whose deblocking is switched off -- an I slice with
+    # disable_deblocking_filter_idc 1 issues no leaf call that sees the slice before its first residual block (with and without the 8x8 transform)
+    ("scaling_idc1", 5, 4, "IIPP", 81, dict(scaling=True, deblock=(1,), slices=2, num_refs=2, pcm=0.0)),
+    ("cabac_scaling_idc1_t8x8", 5, 4, "IPIP", 82, dict(cabac=True, pcm=0.0, scaling=True, t8x8=True, deblock=(1, 0), slices=2, num_refs=2)),
     ("pps_switch_scaling", 5, 4, "IPPBPP", 65, dict(pps_switch=True, t8x8=True, scaling=True, num_refs=2, cqp=(1, -2))),
     ("cabac_pps_switch", 5, 4, "IPPPP", 66, dict(cabac=True, pcm=0.0, pps_switch=True, num_refs=2, slices=2)),
     # frame_num gaps: "non-existing" frames enter the DPB (edge264_headers.c:1122-1144) and push real ones out of the window
@@ -681,7 +685,13 @@ def main():
     ref = ref_decoder()
     sums = {}
     tables = None
+    only = set(sys.argv[1:])  # names: generate just these and merge them into the existing reference_md5.json (the file also holds nat_encoder.py's streams)
+    if only:
+        with open(os.path.join(OUT, "reference_md5.json")) as f:
+            sums = json.load(f)
     for name, W, H, frames, seed, opt in STREAMS:
+        if only and name not in only:
+            continue
         twin = None
         if opt.get("cabac"):
             import cabac_writer as cw
