@@ -215,27 +215,32 @@ static int e264_slice_index(E264Emitter *e, E264FrameBuilder *b)
 
 /* what the leaf functions read from the slice: captured at the first
  * context-bearing leaf call of the slice */
+/* ... from the slice's task (src/edge264_internal.h Edge264Task: everything but the implicit weights, which initialize_context derives per worker) */
+static void e264_fill_slice_task(E264Emitter *e, E264FrameBuilder *b, int idx, const Edge264Task *t)
+{
+	E264SliceParams *s = &b->slices[idx];
+	s->slice_type = t->slice_type;
+	s->weighted_bipred_idc = t->pps.weighted_bipred_idc;
+	s->luma_log2_weight_denom = t->luma_log2_weight_denom;
+	s->chroma_log2_weight_denom = t->chroma_log2_weight_denom;
+	s->FilterOffsetA = t->FilterOffsetA;
+	s->FilterOffsetB = t->FilterOffsetB;
+	s->disable_deblocking_filter_idc = t->disable_deblocking_filter_idc;
+	s->cabac = t->pps.entropy_coding_mode_flag;
+	s->first_mb = t->first_mb_in_slice;
+	memcpy(s->weightScale4x4, t->pps.weightScale4x4, sizeof(s->weightScale4x4));
+	memcpy(s->weightScale8x8, t->pps.weightScale8x8, sizeof(s->weightScale8x8));
+	memcpy(s->explicit_weights, t->explicit_weights, sizeof(s->explicit_weights));
+	memcpy(s->explicit_offsets, t->explicit_offsets, sizeof(s->explicit_offsets));
+	b->slice_filled[idx] = 1;
+	e->cabac_of_serial = s->cabac;
+}
 static void e264_fill_slice(E264Emitter *e, E264FrameBuilder *b, int idx, const Edge264Context *ctx)
 {
 	if (b->slice_filled[idx])
 		return;
-	E264SliceParams *s = &b->slices[idx];
-	s->slice_type = ctx->t.slice_type;
-	s->weighted_bipred_idc = ctx->t.pps.weighted_bipred_idc;
-	s->luma_log2_weight_denom = ctx->t.luma_log2_weight_denom;
-	s->chroma_log2_weight_denom = ctx->t.chroma_log2_weight_denom;
-	s->FilterOffsetA = ctx->t.FilterOffsetA;
-	s->FilterOffsetB = ctx->t.FilterOffsetB;
-	s->disable_deblocking_filter_idc = ctx->t.disable_deblocking_filter_idc;
-	s->cabac = ctx->t.pps.entropy_coding_mode_flag;
-	s->first_mb = ctx->t.first_mb_in_slice;
-	memcpy(s->weightScale4x4, ctx->t.pps.weightScale4x4, sizeof(s->weightScale4x4));
-	memcpy(s->weightScale8x8, ctx->t.pps.weightScale8x8, sizeof(s->weightScale8x8));
-	memcpy(s->explicit_weights, ctx->t.explicit_weights, sizeof(s->explicit_weights));
-	memcpy(s->explicit_offsets, ctx->t.explicit_offsets, sizeof(s->explicit_offsets));
-	memcpy(s->implicit_weights, ctx->implicit_weights, sizeof(s->implicit_weights));
-	b->slice_filled[idx] = 1;
-	e->cabac_of_serial = s->cabac;
+	e264_fill_slice_task(e, b, idx, &ctx->t);
+	memcpy(b->slices[idx].implicit_weights, ctx->implicit_weights, sizeof(b->slices[idx].implicit_weights));
 }
 
 static void e264_payload_append(E264FrameBuilder *b, const void *src, size_t n)

@@ -519,6 +519,19 @@ static void e264_unref_cb(int ret, void *arg)
 	struct E264Unref *u = arg;
 	E264Emitter *e = u->e;
 	const int slot = e->trk_serial == e->serial ? e->trk_slot : e->dec->currPic; /* a slice may fail before its first leaf call */
+	/* (the reference also calls unref_cb for every NAL that is not a slice, at once: src/edge264.c:356-357; a slice's call comes from its task,
+	 * src/edge264_headers.c:497, which is still marked busy then: :596) */
+	if ((0x100022u >> e->dec->nal_unit_type & 1) && e->dec->busy_tasks && slot >= 0 && slot < E264_MAX_SLOTS && e->slot[slot].samples) {
+		/* A slice may also END without a single leaf call that sees its context: all of its macroblocks I_PCM (no leaf call at all), or intra without
+		 * residual, with its deblocking switched off (deblock_mb then returns before it looks at the slice).  The picture still has to go out -- a
+		 * picture made of such slices only had no builder and never reached the device (round 5, tools/stream_sweep.py --wide) -- and the slice
+		 * needs its entry (first_mb_in_slice tells e264_lift_pcm whose the I_PCM macroblocks are): taken from the task, which is still marked busy
+		 * while this callback runs (src/edge264_headers.c:495-497 comes before :596; one task at a time in the synchronous mode). */
+		E264FrameBuilder *b = e264_builder(e, slot);
+		const int idx = e264_slice_index(e, b);
+		if (!b->slice_filled[idx])
+			e264_fill_slice_task(e, b, idx, &e->dec->tasks[__builtin_ctz(e->dec->busy_tasks)]);
+	}
 	if (ret && slot >= 0 && slot < E264_MAX_SLOTS && e->slot[slot].samples) {
 		e->failed_serial = e->serial;
 		e->failed_slot = slot;

@@ -662,6 +662,10 @@ STREAMS = [
     # disable_deblocking_filter_idc 1 issues no leaf call that sees the slice before its first residual block (with and without the 8x8 transform)
     ("scaling_idc1", 5, 4, "IIPP", 81, dict(scaling=True, deblock=(1,), slices=2, num_refs=2, pcm=0.0)),
     ("cabac_scaling_idc1_t8x8", 5, 4, "IPIP", 82, dict(cabac=True, pcm=0.0, scaling=True, t8x8=True, deblock=(1, 0), slices=2, num_refs=2)),
+    # ... and pictures / slices that issue no leaf call at all: every macroblock I_PCM, deblocking off (the picture had no packet); I_PCM slices between
+    # slices of other parameter sets (whose slice are they?)
+    ("pcm_only_idc1", 3, 2, "IPP", 83, dict(pcm=1.0, intra_in_inter=1.0, skip=0.0, deblock=(1,), slices=2, num_refs=2)),
+    ("cabac_pcm_slices_pps_switch", 3, 2, "IPBBPB", 84, dict(cabac=True, pcm=0.5, deblock=(1, 2, 0), slices=6, num_refs=2, pps_switch=True, scaling=True, t8x8=True)),
     ("pps_switch_scaling", 5, 4, "IPPBPP", 65, dict(pps_switch=True, t8x8=True, scaling=True, num_refs=2, cqp=(1, -2))),
     ("cabac_pps_switch", 5, 4, "IPPPP", 66, dict(cabac=True, pcm=0.0, pps_switch=True, num_refs=2, slices=2)),
     # frame_num gaps: "non-existing" frames enter the DPB (edge264_headers.c:1122-1144) and push real ones out of the window

@@ -23,6 +23,7 @@ from oracle.pyoracle import HipFront, Oracle, ref_decoder  # noqa: E402
 
 
 DEGENERATE = False
+WIDE = False
 
 
 def options(seed):
@@ -60,6 +61,25 @@ def options(seed):
         o.update(gap_at=tuple(sorted(r.sample(range(2, 5), r.randint(1, 2)))), num_refs=max(o["num_refs"], 2))
     if o["cabac"]:
         o["pcm"] = o["pcm"] if r.random() < 0.5 else 0.0
+    if WIDE:  # --wide: the corners of the option space and combinations of the decoder-state features (some the writer refuses: counted)
+        W, H = r.choice([2, 3, 5, 8, 12]), r.choice([2, 3, 6, 8])
+        n = W * H
+        frames = r.choice([frames, "IPPPPPPPPP", "IPBBPBBPBB", "IIII", "IPIPIP", "IPBPBPBPB"])
+        o.update(slices=min(n, r.choice([1, 2, 5, 9, n])), intra_in_inter=r.choice([0.0, 0.12, 1.0]), pcm=r.choice([0.0, 0.05, 0.5]),
+                 skip=r.choice([0.0, 0.5, 0.95]), cbp_zero=r.choice([0.0, 0.5, 1.0]), qp=r.choice([4, 12, 26, 40, 51]), coef_density=r.choice([0.02, 0.35, 1.0]),
+                 big_levels=r.choice([0.0, 0.03, 0.5]))
+        if "B" in frames:
+            o["num_refs"] = max(o["num_refs"], 2)
+            o.pop("gap_at", None)  # (the writer keeps P pictures away from the non-existing frames of a gap, not B pictures: such a stream predicts from them)
+        for k, v in (("longterm", True), ("reorder", 0.7), ("pps_switch", True), ("crop", (2, 2, 2, 2))):
+            if r.random() < 0.25 and not o.get("mvc"):
+                o[k] = v
+        if o.get("gap_at"):
+            o.pop("reorder", None)  # (a drawn list modification may put the gap's non-existing frame in front: the stream would predict from it)
+        if o.get("longterm") or o.get("reorder"):
+            o["num_refs"] = max(o["num_refs"], 3)
+        if o["slices"] > 1 and r.random() < 0.3:
+            o["aso"] = True
     return W, H, frames, o
 
 
@@ -71,9 +91,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", default="0:100")
     ap.add_argument("--degenerate", action="store_true", help="also pictures one macroblock wide or high (a known defect of the reference shows)")
+    ap.add_argument("--wide", action="store_true", help="corners of the option space, larger pictures, combinations of the decoder-state features")
     args = ap.parse_args()
-    global DEGENERATE
-    DEGENERATE = args.degenerate
+    global DEGENERATE, WIDE
+    DEGENERATE, WIDE = args.degenerate, args.wide
     a, b = (int(x) for x in args.seeds.split(":"))
     g = ms.load_gen()
     ref, orc = ref_decoder(), Oracle()
