@@ -519,9 +519,15 @@ static void e264_unref_cb(int ret, void *arg)
 	struct E264Unref *u = arg;
 	E264Emitter *e = u->e;
 	const int slot = e->trk_serial == e->serial ? e->trk_slot : e->dec->currPic; /* a slice may fail before its first leaf call */
+	/* A slice that made no leaf call, for a picture that was complete before it came and has gone out (the reference marks completion after this
+	 * callback, src/edge264_headers.c:538-567: INT_MAX here is an EARLIER slice's doing): a stray copy of a slice the picture already has.  It changes
+	 * nothing in the picture and must not bring the picture's builder back -- round 5, tools/damage_sweep.py: a slice NAL cut behind its last
+	 * macroblock decodes completely; its intact copy then fails before its first macroblock, the failure path below opened an empty builder for the
+	 * finished picture, and the intra macroblocks of that picture went out once more as "I_PCM" lifted from a host mirror that never held them. */
+	const int stray = slot >= 0 && slot < E264_MAX_SLOTS && e->trk_serial != e->serial && !e->fb[slot].active && e->dec->next_deblock_addr[slot] == INT_MAX;
 	/* (the reference also calls unref_cb for every NAL that is not a slice, at once: src/edge264.c:356-357; a slice's call comes from its task,
 	 * src/edge264_headers.c:497, which is still marked busy then: :596) */
-	if ((0x100022u >> e->dec->nal_unit_type & 1) && e->dec->busy_tasks && slot >= 0 && slot < E264_MAX_SLOTS && e->slot[slot].samples) {
+	if (!stray && (0x100022u >> e->dec->nal_unit_type & 1) && e->dec->busy_tasks && slot >= 0 && slot < E264_MAX_SLOTS && e->slot[slot].samples) {
 		/* A slice may also END without a single leaf call that sees its context: all of its macroblocks I_PCM (no leaf call at all), or intra without
 		 * residual, with its deblocking switched off (deblock_mb then returns before it looks at the slice).  The picture still has to go out -- a
 		 * picture made of such slices only had no builder and never reached the device (round 5, tools/stream_sweep.py --wide) -- and the slice
@@ -532,7 +538,7 @@ static void e264_unref_cb(int ret, void *arg)
 		if (!b->slice_filled[idx])
 			e264_fill_slice_task(e, b, idx, &e->dec->tasks[__builtin_ctz(e->dec->busy_tasks)]);
 	}
-	if (ret && slot >= 0 && slot < E264_MAX_SLOTS && e->slot[slot].samples) {
+	if (ret && !stray && slot >= 0 && slot < E264_MAX_SLOTS && e->slot[slot].samples) {
 		e->failed_serial = e->serial;
 		e->failed_slot = slot;
 		if (e->cur.valid && e->cur.slot == slot)

@@ -89,3 +89,10 @@ RESENT2 = [
     ("nat_small_aq_slices_ipp8", 0, 0.3, 0.7), ("nat_small_aq_slices_ipp8", 4, 0.6, 0.4), ("nat_small_aq_slices_ipp8", 10, 0.3, 0.7),
     ("cabac_nat_small_aq_slices_ibbp10", 3, 0.6, 0.4), ("cabac_nat_small_aq_slices_ibbp10", 7, 0.3, 0.7), ("cabac_nat_small_aq_slices_ibbp10", 12, 0.6, 0.4),
 ]
+
+
+# Damaged streams kept as files: cases of tools/damage_sweep.py (round 5) in which the front end and the unmodified reference disagreed.  All five:
+# a slice NAL cut BEHIND its last macroblock (it still decodes completely and completes the picture), followed by its intact copy, which then fails
+# before its first macroblock -- a stray slice for a picture that has already gone out.
+DAMAGED_FILES = ["sweep_1998", "sweep_6872", "sweep_11707", "sweep_11790", "sweep_16906"]
+DAMAGED_DIR = os.path.join(HERE, "golden", "damaged")

@@ -23,6 +23,9 @@ for name, which, ka, kb in damage.RESENT2:
 for name, which, keep in damage.LOST:  # the slice never comes again: what the reference hands out before the stream is stuck
     frames, codes = ref.decode(damage.truncated_only(name, which, keep))
     out[f"lost-{name}-{which}-{keep}"] = {"nal_codes": codes, "md5": [hashlib.md5(b"".join(p.tobytes() for p in fr)).hexdigest() for fr in frames]}
+for name in damage.DAMAGED_FILES:  # damaged streams kept as files (cases found by tools/damage_sweep.py)
+    frames, codes = ref.decode(open(os.path.join(damage.DAMAGED_DIR, name + ".264"), "rb").read())
+    out[f"file-{name}"] = {"nal_codes": codes, "md5": [hashlib.md5(b"".join(p.tobytes() for p in fr)).hexdigest() for fr in frames]}
 with open(os.path.join(damage.STREAMS, "damage_md5.json"), "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)
 print(len(out), "scenarios")

@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""tools/damage_sweep.py -- CHECKING TOOL (CPU, build container only): the concealment path of the emitters against the unmodified reference, randomised.
+Every seed: a small random stream (tools/stream_sweep.py's generator, several slices per picture more often than not), one of its slice NALs cut short
+at a random place and -- two times out of three -- sent again intact behind the damaged copy (tests/damage.py holds 75 fixed scenarios of this kind).
+Both decoders see the same bytes; every NAL's return code and every frame handed out must agree.  Cases run in child processes, 40 at a time: a damaged
+stream may stop at one of the reference's own assertions (src/edge264_headers.c:465), which ends the child, not the run.
+
+    python tools/damage_sweep.py [--seeds A:B]
+"""
+import argparse
+import hashlib
+import json
+import os
+import random
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def nal_units(data):
+    pos, i = [], 0
+    while True:
+        j = data.find(b"\0\0\1", i)
+        if j < 0:
+            break
+        pos.append(j)
+        i = j + 3
+    return [data[a:b] for a, b in zip(pos, pos[1:] + [len(data)])]
+
+
+def child(a, b):
+    import make_streams as ms
+    import stream_sweep as ss
+    from oracle.pyoracle import HipFront, Oracle, ref_decoder
+    g = ms.load_gen()
+    ref, orc = ref_decoder(), Oracle()
+    tables = None
+    md5 = lambda fr: [hashlib.md5(b"".join(p.tobytes() for p in f)).hexdigest() for f in fr]  # noqa: E731
+    for seed in range(a, b):
+        W, H, frames, o = ss.options(seed)
+        r = random.Random(seed ^ 0x5eed)
+        o["slices"] = min(W * H, r.choice([1, 2, 3, 3, 4]))
+        o.pop("aso", None) if o["slices"] == 1 else None
+        o.pop("mvc", None)  # (a failed slice of the second view: the reference's own territory of assertions)
+        if o["cabac"]:
+            import cabac_writer as cw
+            tables = tables or cw.load_tables()
+            o = dict(o, tables=tables)
+        try:
+            data = ms.Synth(g, f"d{seed}", W, H, frames, seed, **o).build()
+        except Exception:
+            print(json.dumps({"seed": seed, "status": "refused"}), flush=True)
+            continue
+        nals = nal_units(data)
+        sl = [i for i, n in enumerate(nals) if (n[3] & 31) in (1, 5)]
+        resend = r.random() < 0.67
+        # (a slice that never comes again leaves its picture incomplete: only in the LAST picture, or the reference stops at its assertion about
+        # incomplete reference frames as soon as a later picture predicts from it)
+        k = r.choice(sl) if resend else r.choice(sl[-o["slices"]:])
+        bad = nals[k][:max(6, int(len(nals[k]) * r.uniform(0.15, 0.95)))]
+        dmg = b"".join(nals[:k] + [bad] + (nals[k:] if resend else nals[k + 1:]))
+        print(json.dumps({"seed": seed, "status": "start"}), flush=True)
+        f0, c0 = ref.decode(dmg)
+        f1, c1, _ = HipFront().decode_capture(dmg, orc)
+        same = c0 == c1 and md5(f0) == md5(f1)
+        print(json.dumps({"seed": seed, "status": "same" if same else "MISMATCH", "frames": len(f0), "resend": resend, "slice": k, "slices": o["slices"],
+                          "size": f"{W}x{H}", "gop": frames, "codes_equal": c0 == c1, "n": (len(f0), len(f1))}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", default="0:400")
+    ap.add_argument("--child", default=None)
+    args = ap.parse_args()
+    if args.child:
+        a, b = (int(x) for x in args.child.split(":"))
+        child(a, b)
+        return 0
+    a, b = (int(x) for x in args.seeds.split(":"))
+    t0 = time.time()
+    tally = dict(same=0, MISMATCH=0, refused=0, reference_stopped=0)
+    bad, stopped = [], []
+    s = a
+    while s < b:
+        e = min(b, s + 40)
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", f"{s}:{e}"], capture_output=True, text=True, timeout=1200)
+        last_started = None
+        for ln in p.stdout.splitlines():
+            if not ln.startswith("{"):
+                continue
+            d = json.loads(ln)
+            if d["status"] == "start":
+                last_started = d["seed"]
+                continue
+            last_started = None
+            tally[d["status"]] += 1
+            if d["status"] == "MISMATCH":
+                bad.append(d)
+                print(d, flush=True)
+        if p.returncode != 0 and last_started is not None:  # the child died inside a case: the reference's assertion (or a crash: stderr says which)
+            tally["reference_stopped"] += 1
+            stopped.append((last_started, p.stderr.strip().splitlines()[-1][:160] if p.stderr.strip() else f"exit {p.returncode}"))
+            s = last_started + 1
+            continue
+        s = e
+    print(f"damage_sweep seeds {a}:{b}: {tally}, {time.time() - t0:.0f} s")
+    for st in stopped[:12]:
+        print("  stopped:", st)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
