@@ -90,6 +90,9 @@ class RefKernels:
             raise RuntimeError(f"reference harness rejected packet ({r})")
 
 
+LAZY_DRAIN = False  # tools/*_sweep.py --lazy: frames are only fetched when edge264_decode_NAL answers ENOBUFS, and at the end of the stream
+
+
 class Edge264Frame(C.Structure):
     # edge264.h:45-62
     _fields_ = [("samples", C.c_void_p * 3), ("samples_mvc", C.c_void_p * 3), ("mb_errors", C.c_void_p),
@@ -148,7 +151,8 @@ class Edge264Lib:
                 if len(frames) == n0:  # nothing can be output: the stream is stuck (reference behaviour), give up
                     break
                 continue
-            drain()
+            if not LAZY_DRAIN:  # (LAZY_DRAIN: an application that only fetches frames when the decoder asks for room, edge264.h ENOBUFS)
+                drain()
             if res == errno.ENODATA or nal >= end:
                 break
             nal = min(nxt + 3, end)
@@ -268,7 +272,7 @@ class HipFront(Edge264Lib):
         out = Edge264Frame()
         geom = {}
 
-        def pump():
+        def pump(want_frames=True):
             data, n = C.c_void_p(), C.c_size_t()
             while L.e264front_take_packet(dec, C.byref(data), C.byref(n)) == 0:
                 pkt = C.string_at(data, n.value)
@@ -282,7 +286,7 @@ class HipFront(Edge264Lib):
                     if dpb[s] is None and (s == int(h["dst_slot"]) or int(h["ref_slots"]) >> s & 1):
                         dpb[s] = np.zeros(nb + 64, np.uint8)  # like the HIP sink (frame_fill 0) and a fresh mmap in the reference
                 oracle.decode_frame(pkt, dpb, 3)
-            while L.edge264_get_frame(dec, C.byref(out), 0) == 0:
+            while want_frames and L.edge264_get_frame(dec, C.byref(out), 0) == 0:
                 planes = []
                 for view in ([out.samples] + ([out.samples_mvc] if out.samples_mvc[0] else [])):   # MVC: second view
                     slot = L.e264front_slot_of(dec, view[0])
@@ -302,7 +306,7 @@ class HipFront(Edge264Lib):
             res = L.edge264_decode_NAL(dec, nal, nxt, None, None)
             codes.append(res)
             n0 = len(frames)
-            pump()
+            pump(want_frames=not LAZY_DRAIN or res == errno.ENOBUFS)
             if res == errno.ENOBUFS:
                 if len(frames) == n0:
                     break

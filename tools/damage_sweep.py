@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """tools/damage_sweep.py -- CHECKING TOOL (CPU, build container only): the concealment path of the emitters against the unmodified reference, randomised.
 Every seed: a small random stream (tools/stream_sweep.py's generator, several slices per picture more often than not), one of its slice NALs cut short
-at a random place and -- two times out of three -- sent again intact behind the damaged copy (tests/damage.py holds 75 fixed scenarios of this kind).
+at a random place and -- two times out of three -- sent again intact behind the damaged copy, sometimes with the next slice of the same picture cut too
+before both are sent again (tests/damage.py holds 75 fixed scenarios of these kinds).
 Both decoders see the same bytes; every NAL's return code and every frame handed out must agree.  Cases run in child processes, 40 at a time: a damaged
 stream may stop at one of the reference's own assertions (src/edge264_headers.c:465), which ends the child, not the run.
 
@@ -64,11 +65,20 @@ def child(a, b):
         k = r.choice(sl) if resend else r.choice(sl[-o["slices"]:])
         bad = nals[k][:max(6, int(len(nals[k]) * r.uniform(0.15, 0.95)))]
         dmg = b"".join(nals[:k] + [bad] + (nals[k:] if resend else nals[k + 1:]))
+        two = False
+        if resend and o["slices"] >= 2 and not o.get("aso") and r.random() < 0.3:
+            # two failures inside ONE picture before anything is sent again (pairs that span two pictures stop the reference at its assertion)
+            j = sl.index(k)
+            if j + 1 < len(sl) and j // o["slices"] == (j + 1) // o["slices"]:
+                k2 = sl[j + 1]
+                bad2 = nals[k2][:max(6, int(len(nals[k2]) * r.uniform(0.15, 0.95)))]
+                dmg = b"".join(nals[:k] + [bad, bad2, nals[k], nals[k2]] + nals[k2 + 1:])
+                two = True
         print(json.dumps({"seed": seed, "status": "start"}), flush=True)
         f0, c0 = ref.decode(dmg)
         f1, c1, _ = HipFront().decode_capture(dmg, orc)
         same = c0 == c1 and md5(f0) == md5(f1)
-        print(json.dumps({"seed": seed, "status": "same" if same else "MISMATCH", "frames": len(f0), "resend": resend, "slice": k, "slices": o["slices"],
+        print(json.dumps({"seed": seed, "status": "same" if same else "MISMATCH", "frames": len(f0), "resend": resend, "two": two, "slice": k, "slices": o["slices"],
                           "size": f"{W}x{H}", "gop": frames, "codes_equal": c0 == c1, "n": (len(f0), len(f1))}), flush=True)
 
 
@@ -76,7 +86,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", default="0:400")
     ap.add_argument("--child", default=None)
+    ap.add_argument("--lazy", action="store_true", help="fetch frames only when the decoder answers ENOBUFS (and at the end), on both sides")
     args = ap.parse_args()
+    import oracle.pyoracle as po
+    po.LAZY_DRAIN = args.lazy
     if args.child:
         a, b = (int(x) for x in args.child.split(":"))
         child(a, b)
@@ -88,7 +101,7 @@ def main():
     s = a
     while s < b:
         e = min(b, s + 40)
-        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", f"{s}:{e}"], capture_output=True, text=True, timeout=1200)
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", f"{s}:{e}"] + (["--lazy"] if args.lazy else []), capture_output=True, text=True, timeout=1200)
         last_started = None
         for ln in p.stdout.splitlines():
             if not ln.startswith("{"):

@@ -50,7 +50,10 @@ def options(seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", default="0:50")
+    ap.add_argument("--lazy", action="store_true", help="fetch frames only when the decoder answers ENOBUFS (and at the end), on both sides")
     args = ap.parse_args()
+    import oracle.pyoracle as po
+    po.LAZY_DRAIN = args.lazy
     a, b = (int(x) for x in args.seeds.split(":"))
     g = ms.load_gen()
     ref, orc = ref_decoder(), Oracle()

@@ -92,7 +92,10 @@ def main():
     ap.add_argument("--seeds", default="0:100")
     ap.add_argument("--degenerate", action="store_true", help="also pictures one macroblock wide or high (a known defect of the reference shows)")
     ap.add_argument("--wide", action="store_true", help="corners of the option space, larger pictures, combinations of the decoder-state features")
+    ap.add_argument("--lazy", action="store_true", help="fetch frames only when the decoder answers ENOBUFS (and at the end), on both sides")
     args = ap.parse_args()
+    import oracle.pyoracle as po
+    po.LAZY_DRAIN = args.lazy
     global DEGENERATE, WIDE
     DEGENERATE, WIDE = args.degenerate, args.wide
     a, b = (int(x) for x in args.seeds.split(":"))
