@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--seeds", default="0:100")
     ap.add_argument("--degenerate", action="store_true", help="also pictures one macroblock wide or high (a known defect of the reference shows)")
     ap.add_argument("--wide", action="store_true", help="corners of the option space, larger pictures, combinations of the decoder-state features")
+    ap.add_argument("--allocators", action="store_true", help="our side decodes with caller allocators (alloc_cb / free_cb of edge264_alloc)")
     ap.add_argument("--lazy", action="store_true", help="fetch frames only when the decoder answers ENOBUFS (and at the end), on both sides")
     args = ap.parse_args()
     import oracle.pyoracle as po
@@ -118,7 +119,15 @@ def main():
         if len(f0) != len(frames) or not all(c in (0, 105, 61) for c in c0):
             rejected += 1  # the reference itself does not take the stream as meant (a writer limitation): not a case
             continue
-        f1, c1, _ = HipFront().decode_capture(data, orc)
+        al = None
+        if args.allocators:  # the application's own alloc_cb / free_cb (edge264.h:42-43) on our side: every block given back, same frames
+            from oracle.pyoracle import CallerAllocator
+            al = CallerAllocator()
+        f1, c1, _ = HipFront().decode_capture(data, orc, allocator=al)
+        if al is not None and (al.allocs != al.frees or al.live):
+            bad.append(seed)
+            print(f"ALLOCATOR seed {seed}: {al.allocs} allocations, {al.frees} given back", flush=True)
+            continue
         n_pics += len(f0)
         if c0 != c1 or md5s(f0) != md5s(f1):
             shown = {k: v for k, v in o.items() if k != "tables"}
