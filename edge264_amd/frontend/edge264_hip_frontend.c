@@ -297,8 +297,11 @@ static void e264_lift_pcm(E264Emitter *e, int slot)
 			m->flags = (uint8_t)((fe & 1 ? E264_MBF_EDGE_LEFT : 0) | (fe & 2 ? E264_MBF_EDGE_TOP : 0) | (fe ? E264_MBF_DEBLOCK : 0));
 			m->nz_mask = 0xffff;
 			m->slice = 0;
-			for (int i = b->n_slices - 1; i >= 0; i--)
-				if (b->slices[i].first_mb <= (uint32_t)a && b->slice_filled[i]) { m->slice = (uint16_t)i; break; }
+			/* whose it is: the slice that starts closest below it; of two entries with the same start (a slice that failed and its copy) the later one.
+			 * (Slices may arrive in any order, 7.4.1.2.5 arbitrary slice order: the entries are in arrival order, not in address order.) */
+			uint32_t best = 0;
+			for (int i = 0; i < b->n_slices; i++)
+				if (b->slice_filled[i] && b->slices[i].first_mb <= (uint32_t)a && b->slices[i].first_mb >= best) { best = b->slices[i].first_mb; m->slice = (uint16_t)i; }
 			m->dbk_slice = b->side[a].dbk_slice != 0xffff ? b->side[a].dbk_slice : m->slice;
 			while (b->payload_len & 7)
 				e264_payload_append(b, "\0", 1);
