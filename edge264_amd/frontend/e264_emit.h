@@ -349,10 +349,8 @@ static void e264_flush_mb_(E264Emitter *e)
 	for (int k = 0; k < 16; k++)
 		nz |= (unsigned)(M->nC[k] != 0) << k;
 #endif
-	if (t8 && fe && nz && !b->slices[c->slice].cabac)
-		for (int q = 0; q < 4; q++)
-			if (nz >> (q * 4) & 15)
-				nz |= 15u << (q * 4);
+	/* (the broadcast itself happens where the reference does it: in deblock_mb, emit_deblock.c -- a macroblock that is decoded again after a failed slice
+	 * and NOT deblocked again keeps the raw flags, and its neighbours' bS is computed from those) */
 	m->nz_mask = (uint16_t)nz;
 	if (c->kind == E264_MB_I4x4)
 		for (int k = 0; k < 16; k++)

@@ -36,6 +36,18 @@ static noinline void deblock_mb(Edge264Context *ctx)
 				b->side[a].dbk_slice = 0xffff;
 			}
 			b->side[a].fedges = mb->filter_edges;
+			/* CAVLC + 8x8 transform: the reference replaces the sixteen per-4x4 flags of an inter macroblock by one flag per 8x8 block the moment it
+			 * deblocks it (src/edge264_deblock.c:1092-1096, in place in mb->nC) and the bS = 2 tests of this macroblock and of its later neighbours read
+			 * that.  Mirrored here, on the record, at the same moment (round 5, tools/damage_sweep.py: until then e264_flush_mb did it for every
+			 * macroblock with filter_edges set, which is the same thing unless the macroblock is decoded again and never deblocked again). */
+			E264Mb *m = &b->mbs[a];
+			if (m->kind == E264_MB_INTER && (m->flags & E264_MBF_T8x8) && !ctx->t.pps.entropy_coding_mode_flag && m->nz_mask) {
+				unsigned nz = m->nz_mask;
+				for (int q = 0; q < 4; q++)
+					if (nz >> (q * 4) & 15)
+						nz |= 15u << (q * 4);
+				m->nz_mask = (uint16_t)nz;
+			}
 			/* the first call is the one that filters (the picture-completing pass runs over macroblocks that were deblocked
 			 * earlier without touching them) */
 			if (b->side[a].dbk_slice == 0xffff) {

@@ -34,52 +34,63 @@ def nal_units(data):
     return [data[a:b] for a, b in zip(pos, pos[1:] + [len(data)])]
 
 
-def child(a, b):
+def make_case(seed, g, tables_box):
+    """-> (damaged stream, info) of one seed, or (None, info) when the writer refuses the drawn options"""
     import make_streams as ms
     import stream_sweep as ss
+    W, H, frames, o = ss.options(seed)
+    r = random.Random(seed ^ 0x5eed)
+    o["slices"] = min(W * H, r.choice([1, 2, 3, 3, 4]))
+    o.pop("aso", None) if o["slices"] == 1 else None
+    o.pop("mvc", None)  # (a failed slice of the second view: the reference's own territory of assertions)
+    if o["cabac"]:
+        import cabac_writer as cw
+        tables_box[0] = tables_box[0] or cw.load_tables()
+        o = dict(o, tables=tables_box[0])
+    info = dict(size=f"{W}x{H}", gop=frames, slices=o["slices"], options={k: v for k, v in o.items() if k != "tables"})
+    try:
+        data = ms.Synth(g, f"d{seed}", W, H, frames, seed, **o).build()
+    except Exception:
+        return None, info
+    nals = nal_units(data)
+    sl = [i for i, n in enumerate(nals) if (n[3] & 31) in (1, 5)]
+    resend = r.random() < 0.67
+    # (a slice that never comes again leaves its picture incomplete: only in the LAST picture, or the reference stops at its assertion about
+    # incomplete reference frames as soon as a later picture predicts from it)
+    k = r.choice(sl) if resend else r.choice(sl[-o["slices"]:])
+    bad = nals[k][:max(6, int(len(nals[k]) * r.uniform(0.15, 0.95)))]
+    dmg = b"".join(nals[:k] + [bad] + (nals[k:] if resend else nals[k + 1:]))
+    two = False
+    if resend and o["slices"] >= 2 and not o.get("aso") and r.random() < 0.3:
+        # two failures inside ONE picture before anything is sent again (pairs that span two pictures stop the reference at its assertion)
+        j = sl.index(k)
+        if j + 1 < len(sl) and j // o["slices"] == (j + 1) // o["slices"]:
+            k2 = sl[j + 1]
+            bad2 = nals[k2][:max(6, int(len(nals[k2]) * r.uniform(0.15, 0.95)))]
+            dmg = b"".join(nals[:k] + [bad, bad2, nals[k], nals[k2]] + nals[k2 + 1:])
+            two = True
+    info.update(resend=resend, two=two, slice=k, cut_to=len(bad), of=len(nals[k]))
+    return dmg, info
+
+
+def child(a, b):
+    import make_streams as ms
     from oracle.pyoracle import HipFront, Oracle, ref_decoder
     g = ms.load_gen()
     ref, orc = ref_decoder(), Oracle()
-    tables = None
+    box = [None]
     md5 = lambda fr: [hashlib.md5(b"".join(p.tobytes() for p in f)).hexdigest() for f in fr]  # noqa: E731
     for seed in range(a, b):
-        W, H, frames, o = ss.options(seed)
-        r = random.Random(seed ^ 0x5eed)
-        o["slices"] = min(W * H, r.choice([1, 2, 3, 3, 4]))
-        o.pop("aso", None) if o["slices"] == 1 else None
-        o.pop("mvc", None)  # (a failed slice of the second view: the reference's own territory of assertions)
-        if o["cabac"]:
-            import cabac_writer as cw
-            tables = tables or cw.load_tables()
-            o = dict(o, tables=tables)
-        try:
-            data = ms.Synth(g, f"d{seed}", W, H, frames, seed, **o).build()
-        except Exception:
+        dmg, info = make_case(seed, g, box)
+        if dmg is None:
             print(json.dumps({"seed": seed, "status": "refused"}), flush=True)
             continue
-        nals = nal_units(data)
-        sl = [i for i, n in enumerate(nals) if (n[3] & 31) in (1, 5)]
-        resend = r.random() < 0.67
-        # (a slice that never comes again leaves its picture incomplete: only in the LAST picture, or the reference stops at its assertion about
-        # incomplete reference frames as soon as a later picture predicts from it)
-        k = r.choice(sl) if resend else r.choice(sl[-o["slices"]:])
-        bad = nals[k][:max(6, int(len(nals[k]) * r.uniform(0.15, 0.95)))]
-        dmg = b"".join(nals[:k] + [bad] + (nals[k:] if resend else nals[k + 1:]))
-        two = False
-        if resend and o["slices"] >= 2 and not o.get("aso") and r.random() < 0.3:
-            # two failures inside ONE picture before anything is sent again (pairs that span two pictures stop the reference at its assertion)
-            j = sl.index(k)
-            if j + 1 < len(sl) and j // o["slices"] == (j + 1) // o["slices"]:
-                k2 = sl[j + 1]
-                bad2 = nals[k2][:max(6, int(len(nals[k2]) * r.uniform(0.15, 0.95)))]
-                dmg = b"".join(nals[:k] + [bad, bad2, nals[k], nals[k2]] + nals[k2 + 1:])
-                two = True
         print(json.dumps({"seed": seed, "status": "start"}), flush=True)
         f0, c0 = ref.decode(dmg)
         f1, c1, _ = HipFront().decode_capture(dmg, orc)
         same = c0 == c1 and md5(f0) == md5(f1)
-        print(json.dumps({"seed": seed, "status": "same" if same else "MISMATCH", "frames": len(f0), "resend": resend, "two": two, "slice": k, "slices": o["slices"],
-                          "size": f"{W}x{H}", "gop": frames, "codes_equal": c0 == c1, "n": (len(f0), len(f1))}), flush=True)
+        print(json.dumps({"seed": seed, "status": "same" if same else "MISMATCH", "frames": len(f0), "resend": info["resend"], "two": info["two"], "slice": info["slice"],
+                          "slices": info["slices"], "size": info["size"], "gop": info["gop"], "codes_equal": c0 == c1, "n": (len(f0), len(f1))}), flush=True)
 
 
 def main():
