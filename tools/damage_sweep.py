@@ -34,13 +34,18 @@ def nal_units(data):
     return [data[a:b] for a, b in zip(pos, pos[1:] + [len(data)])]
 
 
+MORE = False
+
+
 def make_case(seed, g, tables_box):
     """-> (damaged stream, info) of one seed, or (None, info) when the writer refuses the drawn options"""
     import make_streams as ms
     import stream_sweep as ss
     W, H, frames, o = ss.options(seed)
     r = random.Random(seed ^ 0x5eed)
-    o["slices"] = min(W * H, r.choice([1, 2, 3, 3, 4]))
+    _pick = r.choice([1, 2, 3, 3, 4])  # (drawn in both modes: the same seed stays the same case)
+    if not ss.WIDE:
+        o["slices"] = min(W * H, _pick)
     o.pop("aso", None) if o["slices"] == 1 else None
     o.pop("mvc", None)  # (a failed slice of the second view: the reference's own territory of assertions)
     if o["cabac"]:
@@ -69,6 +74,17 @@ def make_case(seed, g, tables_box):
             bad2 = nals[k2][:max(6, int(len(nals[k2]) * r.uniform(0.15, 0.95)))]
             dmg = b"".join(nals[:k] + [bad, bad2, nals[k], nals[k2]] + nals[k2 + 1:])
             two = True
+    if MORE and resend and not two and r.random() < 0.5:
+        # --more: further slices of the stream cut and sent again, each inside its own picture (every failure is repaired before the next one)
+        out, n_cut = [], 0
+        for i, n in enumerate(nals):
+            if i in sl and (i == k or r.random() < 0.25):
+                frac = r.choice([0.0, 0.02, 0.999]) if r.random() < 0.3 else r.uniform(0.1, 0.97)  # also: the header alone, nearly nothing, nearly everything
+                out.append(n[:max(5, int(len(n) * frac))])
+                n_cut += 1
+            out.append(n)
+        dmg = b"".join(out)
+        info["cuts"] = n_cut
     info.update(resend=resend, two=two, slice=k, cut_to=len(bad), of=len(nals[k]))
     return dmg, info
 
@@ -97,10 +113,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", default="0:400")
     ap.add_argument("--child", default=None)
+    ap.add_argument("--wide", action="store_true", help="stream_sweep.py --wide's option space (larger pictures, one slice per macroblock, all-intra / all-PCM ...)")
+    ap.add_argument("--more", action="store_true", help="several slices of a stream cut and sent again, cuts at the extremes too")
     ap.add_argument("--lazy", action="store_true", help="fetch frames only when the decoder answers ENOBUFS (and at the end), on both sides")
     args = ap.parse_args()
     import oracle.pyoracle as po
     po.LAZY_DRAIN = args.lazy
+    import stream_sweep as ss
+    global MORE
+    ss.WIDE, MORE = args.wide, args.more
     if args.child:
         a, b = (int(x) for x in args.child.split(":"))
         child(a, b)
@@ -112,7 +133,7 @@ def main():
     s = a
     while s < b:
         e = min(b, s + 40)
-        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", f"{s}:{e}"] + (["--lazy"] if args.lazy else []), capture_output=True, text=True, timeout=1200)
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", f"{s}:{e}"] + (["--lazy"] if args.lazy else []) + (["--wide"] if args.wide else []) + (["--more"] if args.more else []), capture_output=True, text=True, timeout=1200)
         last_started = None
         for ln in p.stdout.splitlines():
             if not ln.startswith("{"):
