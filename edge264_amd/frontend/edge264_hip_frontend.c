@@ -287,7 +287,11 @@ static void e264_lift_pcm(E264Emitter *e, int slot)
 			 * clears the mark): it came back as I_PCM.  Reconstructed again from the new samples; not deblocked again unless
 			 * deblock_mb saw it (emit_deblock.c then has already reset the record). */
 			memset(m, 0, sizeof(*m));
-			b->side[a].state &= E264_ST_DBK;
+			/* a new version of the macroblock: what an earlier packet did to the old one no longer counts.  It is deblocked again when -- and only when --
+			 * the reference calls deblock_mb on it from here on (round 5, tools/damage_sweep.py --wide: the state kept "deblocked by an earlier packet" and
+			 * the slice that had done it, so the deblocking the reference does to the new samples at the end of the picture was left out) */
+			b->side[a].state = 0;
+			b->side[a].dbk_slice = 0xffff;
 		}
 		if (m->kind == E264_MB_ABSENT && !(b->side[a].state & E264_ST_RECON) && M->recovery_bits == flip && !M->mbIsInterFlag) {
 			m->kind = E264_MB_PCM;

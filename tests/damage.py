@@ -97,5 +97,8 @@ RESENT2 = [
 DAMAGED_FILES = ["sweep_1998", "sweep_6872", "sweep_11707", "sweep_11790", "sweep_16906",
                  # CAVLC + 8x8 transform, several slices, a B picture: a macroblock of the failed slice is decoded again by the copy and NOT deblocked again (the
                  # reference had deblocked its first version): its per-4x4 coefficient flags stay as parsed, the bS of its neighbours follows them
-                 "sweep_134724", "sweep_147736", "sweep_151776"]
+                 "sweep_134724", "sweep_147736", "sweep_151776",
+                 # an I_PCM macroblock that a failed slice ran over is decoded again by its own slice, lifted into a packet, and deblocked by the reference only
+                 # at the end of the picture: the earlier deblocking of its old version must not count (pictures of 9 - 15 slices, several cuts per stream)
+                 "sweep_207375", "sweep_6677", "sweep_6298"]
 DAMAGED_DIR = os.path.join(HERE, "golden", "damaged")
