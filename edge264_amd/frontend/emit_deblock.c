@@ -28,6 +28,12 @@ static noinline void deblock_mb(Edge264Context *ctx)
 		const size_t mby = (size_t)(((uint64_t)i * b->recip_w1) >> 40), mbx = i - mby * (size_t)(b->width_mbs + 1);
 		if (mbx < (size_t)b->width_mbs && mby < (size_t)b->height_mbs) {
 			size_t a = mby * (size_t)b->width_mbs + mbx;
+			/* how far the NAL has got counts macroblocks it DEBLOCKS too: a slice's last macroblocks may be I_PCM (no leaf call), and the reference deblocks
+			 * the rest of a slice AFTER the unref callback (src/edge264_headers.c:497-525).  When recover_slice then walks back over them, e264_touch_ must
+			 * see that it goes back, or the failed attempt's own deblocking shares a packet with the concealment that overwrites it and is lost
+			 * (round 5, tools/damage_sweep.py --wide, one sample). */
+			if (e->trk_serial != e->serial) { e->trk_serial = e->serial; e->trk_slot = slot; e->trk_addr = (int)a; }
+			else if (e->trk_slot == slot && (int)a > e->trk_addr) e->trk_addr = (int)a;
 			if ((b->side[a].state & E264_ST_ERR) && mb->recovery_bits == ctx->t.frame_flip_bit) {
 				/* marked erroneous, then decoded again without a single leaf call: as I_PCM (src/edge264_slice.c:914-935).
 				 * Its record starts over; e264_lift_pcm picks the samples up when the packet is closed. */
