@@ -35,12 +35,48 @@ def nal_units(data):
 
 
 MORE = False
+NAT = False
+_REF = [None]
+
+
+def make_nat_case(seed, g, tables_box):
+    """--nat: an encoder-shaped clip (tools/nat_sweep.py's options; the reference closes the encoder's loop) with one slice NAL cut and sent again"""
+    import contextlib
+    import io
+    import nat_encoder as ne
+    import nat_sweep as ns
+    from oracle.pyoracle import ref_decoder
+    frames, o = ns.options(seed)
+    r = random.Random(seed ^ 0x5eed)
+    if r.random() < 0.7 and "slice_rows" not in o:
+        o["slice_rows"] = r.randint(1, max(1, o["H"] - 1))  # several slices per picture more often than not
+    if o["cabac"]:
+        import cabac_writer as cw
+        tables_box[0] = tables_box[0] or cw.load_tables()
+        o = dict(o, tables=tables_box[0])
+    _REF[0] = _REF[0] or ref_decoder()
+    info = dict(size=f"{o['W']}x{o['H']}", gop=frames, slices=-(-o["H"] // o["slice_rows"]) if o.get("slice_rows") else 1, options={k: v for k, v in o.items() if k != "tables"})
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            data = ne.NatEncoder(g, f"n{seed}", frames, **o).build(_REF[0])
+    except Exception:
+        return None, info
+    nals = nal_units(data)
+    sl = [i for i, n in enumerate(nals) if (n[3] & 31) in (1, 5)]
+    resend = r.random() < 0.75
+    k = r.choice(sl) if resend else r.choice(sl[-info["slices"]:])
+    bad = nals[k][:max(6, int(len(nals[k]) * r.uniform(0.15, 0.95)))]
+    dmg = b"".join(nals[:k] + [bad] + (nals[k:] if resend else nals[k + 1:]))
+    info.update(resend=resend, two=False, slice=k, cut_to=len(bad), of=len(nals[k]))
+    return dmg, info
 
 
 def make_case(seed, g, tables_box):
     """-> (damaged stream, info) of one seed, or (None, info) when the writer refuses the drawn options"""
     import make_streams as ms
     import stream_sweep as ss
+    if NAT:
+        return make_nat_case(seed, g, tables_box)
     W, H, frames, o = ss.options(seed)
     r = random.Random(seed ^ 0x5eed)
     _pick = r.choice([1, 2, 3, 3, 4])  # (drawn in both modes: the same seed stays the same case)
@@ -123,14 +159,15 @@ def main():
     ap.add_argument("--seeds", default="0:400")
     ap.add_argument("--child", default=None)
     ap.add_argument("--wide", action="store_true", help="stream_sweep.py --wide's option space (larger pictures, one slice per macroblock, all-intra / all-PCM ...)")
+    ap.add_argument("--nat", action="store_true", help="encoder-shaped clips (tools/nat_sweep.py's generator) instead of random syntax")
     ap.add_argument("--more", action="store_true", help="several slices of a stream cut and sent again, cuts at the extremes too")
     ap.add_argument("--lazy", action="store_true", help="fetch frames only when the decoder answers ENOBUFS (and at the end), on both sides")
     args = ap.parse_args()
     import oracle.pyoracle as po
     po.LAZY_DRAIN = args.lazy
     import stream_sweep as ss
-    global MORE
-    ss.WIDE, MORE = args.wide, args.more
+    global MORE, NAT
+    ss.WIDE, MORE, NAT = args.wide, args.more, args.nat
     if args.child:
         a, b = (int(x) for x in args.child.split(":"))
         child(a, b)
@@ -142,7 +179,7 @@ def main():
     s = a
     while s < b:
         e = min(b, s + 40)
-        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", f"{s}:{e}"] + (["--lazy"] if args.lazy else []) + (["--wide"] if args.wide else []) + (["--more"] if args.more else []), capture_output=True, text=True, timeout=1200)
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", f"{s}:{e}"] + (["--lazy"] if args.lazy else []) + (["--wide"] if args.wide else []) + (["--more"] if args.more else []) + (["--nat"] if args.nat else []), capture_output=True, text=True, timeout=1200)
         last_started = None
         for ln in p.stdout.splitlines():
             if not ln.startswith("{"):
