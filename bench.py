@@ -115,7 +115,7 @@ def kernel_own_bytes(models, n_streams):
 
 def newest_traffic(dom, streams, gop, W, H, lanes, live_ms):
     """HBM-side bytes per launch of the dominant kernel from the NEWEST profiles/r*_hbm_traffic.json taken on this configuration
-    (PMC passes cannot run inside a timed bench: separate rocprofv3 --pmc runs, tools/gpu_profile_r4.sh).  Returns (bytes or None,
+    (PMC passes cannot run inside a timed bench: separate rocprofv3 --pmc runs, tools/visits/gpu_profile_r4.sh).  Returns (bytes or None,
     a description that names the file, the kernel times it was taken at when it records them, and says so when the live
     times have moved more than 10 % away from them)."""
     import glob
@@ -378,7 +378,7 @@ def main() -> int:
     else:
         # ---- synthetic input (same bytes on every rank: seeded) -------------------------------
         skw = dict(t8x8=True, i_kinds=head_i, num_refs=2, residual_prob=float(os.environ.get("E264_RESIDUAL_PROB", 0.3)))
-        skw.update(json.loads(os.environ.get("E264_SYNTH_KW", "{}")))  # measuring aid (tools/gpu_sweep.sh): what each kernel's time depends on
+        skw.update(json.loads(os.environ.get("E264_SYNTH_KW", "{}")))  # measuring aid (tools/visits/gpu_sweep.sh): what each kernel's time depends on
     # a run with any of the measuring aids set does not measure BASELINE configs[2] any more: the line says so (config.synth_overrides, workload)
     synth_overrides = {k: os.environ[k] for k in ("E264_I_KINDS", "E264_RESIDUAL_PROB", "E264_SYNTH_KW") if os.environ.get(k) and not args.capture}
     if not args.capture:

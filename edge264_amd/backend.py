@@ -79,7 +79,7 @@ def load_library():
     flags = (L.e264hip_build_flags() or b"").decode()
     if ("E264_ABL_" in flags or "E264_PHASE_" in flags) and os.environ.get("E264_ALLOW_ABLATION") != "1":
         raise BackendError(f"{LIB_PATH} is a timing-ablation build ({flags.strip()}): its samples are wrong by design; "
-                           "set E264_ALLOW_ABLATION=1 to load it (tools/gpu_ab.sh does)")
+                           "set E264_ALLOW_ABLATION=1 to load it (tools/visits/gpu_ab.sh does)")
     _lib = L
     return L
 

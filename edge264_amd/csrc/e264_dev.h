@@ -30,7 +30,7 @@ E264_DEV int clip3i(int lo, int hi, int v) { return min(max(v, lo), hi); }
 E264_DEV int clip255(int v) { return min(max(v, 0), 255); }
 E264_DEV int sat16(int v) { return min(max(v, -32768), 32767); }
 E264_DEV int w16(int v) { return (int)(int16_t)v; }
-// build-time experiment switches (`make variant NAME=.. DEFS=-D..` builds one library per setting, tools/gpu_ab.sh compares them)
+// build-time experiment switches (`make variant NAME=.. DEFS=-D..` builds one library per setting, tools/visits/gpu_ab.sh compares them)
 #ifdef E264_ABL_NOBH
 #define E264_ABL_BH && false
 #else

@@ -21,7 +21,7 @@
 // comes from many independent streams (one frame of each per launch), the north-star workload
 // (>=1000 concurrent streams).  Integer / byte work throughout, no MFMA.
 //
-// Pipeline rule (learnt with the phase profiler, -DE264_PHASE_TIMING / tools/gpu_phase.sh): a stage that ISSUES loads for
+// Pipeline rule (learnt with the phase profiler, -DE264_PHASE_TIMING / tools/visits/gpu_phase.sh): a stage that ISSUES loads for
 // a later stage must not read, clear or copy any register that may still have a load in flight -- each of those is an
 // s_waitcnt vmcnt(0), i.e. a wait for the loads it has just issued.  Hence: prefetch helpers contain loads only, nothing
 // is zero-initialised in front of a conditional load, one code path fills the pipeline registers, and the place where
@@ -36,7 +36,7 @@
 #include "e264_dbk.h"
 
 namespace {
-// -DE264_PHASE_TIMING: wall cycles of the mbpar kernel's phases, summed over all waves (tools/gpu_phase.sh reads them back
+// -DE264_PHASE_TIMING: wall cycles of the mbpar kernel's phases, summed over all waves (tools/visits/gpu_phase.sh reads them back
 // through e264_debug_phase_cycles).  s_memtime at the phase boundaries drains the LGKM counter, so the numbers are a
 // profile, not a benchmark.
 #if defined(E264_DBK_TIMELINE) && !defined(E264_PHASE_TIMING) // only the start / end stamps of the deblocking kernel's groups of rows (workgroup 0): two s_memtime per 130 steps

@@ -297,7 +297,7 @@ def test_bench_config5_shards_a_fixed_job(tmp_path):
 
 
 def test_bench_says_when_the_synthetic_content_is_overridden():
-    """bench.py's measuring aids (E264_I_KINDS, E264_RESIDUAL_PROB, E264_SYNTH_KW: tools/gpu_ikinds.sh, gpu_sweep.sh) change the synthetic
+    """bench.py's measuring aids (E264_I_KINDS, E264_RESIDUAL_PROB, E264_SYNTH_KW: tools/visits/gpu_ikinds.sh, gpu_sweep.sh) change the synthetic
     content: a line produced with one of them set says that it is NOT the BASELINE workload and which override was in force; without
     them `config.synth_overrides` is null."""
     import json

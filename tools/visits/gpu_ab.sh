@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of library variants: parity tests on the default build, then bench per variant (edge264_amd/variants/*.so)
-# usage: tools/gpu_ab.sh TAG [pmc] ; extra bench arguments through $BENCH_ARGS
+# usage: tools/visits/gpu_ab.sh TAG [pmc] ; extra bench arguments through $BENCH_ARGS
 TAG=${1:-ab}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG

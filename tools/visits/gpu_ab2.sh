@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library variants (edge264_amd/variants/*.so) + environment settings on the bench GOP; every frame verified.  usage: tools/gpu_ab2.sh TAG
+# A/B of library variants (edge264_amd/variants/*.so) + environment settings on the bench GOP; every frame verified.  usage: tools/visits/gpu_ab2.sh TAG
 TAG=${1:-ab}
 REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp E264_ALLOW_ABLATION=1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # end-to-end multi-stream driver: host parsing threads vs throughput (bit-exactness is covered by tests/test_multi_stream.py)
-# bash tools/gpu_multi.sh TAG
+# bash tools/visits/gpu_multi.sh TAG
 TAG=${1:-multi}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 nproc

@@ -1,7 +1,7 @@
 #!/bin/bash
 # e264_multi end to end on the GPU box (reference parser + emitters + back end), 128 streams of the two 1080p fixtures:
 # packets assembled in page-locked buffers and submitted in place (default) against pageable packets validated + copied
-# by the back end (--pageable), and the parser alone.   bash tools/gpu_multi_r3.sh TAG
+# by the back end (--pageable), and the parser alone.   bash tools/visits/gpu_multi_r3.sh TAG
 TAG=${1:-multi}
 REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ counters of e264_intra_kernel on all-intra pictures (bench --gop II: the I frame mix of the bench GOP), for the default
 # library and every variant in edge264_amd/variants: instruction mix, issue and wait cycles, LDS conflicts.
-# usage: bash tools/gpu_pmc_intra.sh TAG
+# usage: bash tools/visits/gpu_pmc_intra.sh TAG
 TAG=${1:-pmci}
 REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp

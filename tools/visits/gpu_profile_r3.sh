@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box visit that produces everything profiles/r03_* is made of: the GPU tests, the default bench line, the rocprofv3
 # kernel trace of the same command, the HBM-side PMC passes (reads / writes in separate passes, no trace domain beside
-# them), the SQ instruction mix, the capture bench, the staging microbenchmark.   bash tools/gpu_profile_r3.sh TAG
+# them), the SQ instruction mix, the capture bench, the staging microbenchmark.   bash tools/visits/gpu_profile_r3.sh TAG
 TAG=${1:-r03}
 REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box visit that produces what profiles/r04_* is made of: the GPU tests, the default bench line, the rocprofv3 kernel
 # trace of the same command, the HBM-side PMC passes (reads / writes in separate passes, no trace domain beside them), the SQ
-# instruction mix, stream-count variants, e264_multi end to end, the host cost per picture.   bash tools/gpu_profile_r4.sh TAG
+# instruction mix, stream-count variants, e264_multi end to end, the host cost per picture.   bash tools/visits/gpu_profile_r4.sh TAG
 TAG=${1:-r04}
 REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box visit that produces what profiles/r05_* is made of: the default bench line (every leg), the rocprofv3 kernel trace of the timed command,
 # the HBM-side PMC passes (reads / writes in separate passes, no trace domain beside them), the SQ instruction mix, 512 / 1024 streams per launch.
-#   bash tools/gpu_profile_r5.sh TAG
+#   bash tools/visits/gpu_profile_r5.sh TAG
 TAG=${1:-r05}
 REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5 A/B runner: bench of the default library, then of every variant in edge264_amd/variants with the wave counts given
-# usage: tools/gpu_r5b.sh TAG "variant:waves variant:waves ..."   (variant "main" = the default library)
+# usage: tools/visits/gpu_r5b.sh TAG "variant:waves variant:waves ..."   (variant "main" = the default library)
 TAG=${1:-r5b}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG

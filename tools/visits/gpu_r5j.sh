@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5: per-kernel times on the bitstream fixtures (same_input leg), default library against variants
-# usage: tools/gpu_r5j.sh TAG "main nozero ..."
+# usage: tools/visits/gpu_r5j.sh TAG "main nozero ..."
 TAG=${1:-r5j}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$(pwd)
