@@ -227,11 +227,19 @@ static bool serial_retired(E264Device *dev, uint64_t serial, int lane)
 	if (!serial) return true;
 	std::atomic<uint64_t> &seen = dev->lane_retired[lane];
 	if (serial <= seen.load(std::memory_order_relaxed)) return true; // no lock, no driver call: somebody saw this lane get past it
+	// An event handle read under dev->lock is queried OUTSIDE it, and ring entry serial % NEV is the next one launch() / mark_lane() record
+	// again -- possibly for ANOTHER lane: a "done" answer only counts if the entry still belongs to the serial it was read for once the query
+	// has returned (checked under the lock again); otherwise the answer is about somebody else's marker and nothing may be cached from it.
+	auto still = [&](uint64_t want) {
+		std::lock_guard<std::mutex> g(dev->lock);
+		const int idx = (int)(want % E264Device::NEV);
+		return dev->sub_serial[idx] == want && dev->sub_lane[idx] == lane;
+	};
 	hipEvent_t ev = serial_event(dev, serial);
 	if (ev) {
 		if (hipEventQuery(ev) != hipSuccess) { (void)hipGetLastError(); return false; }
-		raise_serial(seen, serial);
-		return true;
+		if (still(serial)) { raise_serial(seen, serial); return true; }
+		// re-recorded while we asked: the ring has wrapped past this serial, fall through to the wrapped path
 	}
 	// the event ring has wrapped past this serial.  A lane runs its work in order: a NEWER entry of the same lane that has retired proves
 	// this one has (a continuously busy lane is never idle, hipStreamQuery alone would keep old blocks parked for good).  ONE query: the
@@ -243,7 +251,7 @@ static bool serial_retired(E264Device *dev, uint64_t serial, int lane)
 		for (int i = 0; i < E264Device::NEV; i++)
 			if (dev->sub_serial[i] > serial && dev->sub_lane[i] == lane && dev->sub_ev[i] && (!probe || dev->sub_serial[i] < probe_serial)) { probe = dev->sub_ev[i]; probe_serial = dev->sub_serial[i]; }
 	}
-	if (probe && hipEventQuery(probe) == hipSuccess) { raise_serial(seen, probe_serial); return true; }
+	if (probe && hipEventQuery(probe) == hipSuccess && still(probe_serial)) { raise_serial(seen, probe_serial); return true; }
 	(void)hipGetLastError(); // (hipErrorNotReady is not an error to keep)
 	return hipStreamQuery(dev->q[lane]) == hipSuccess;
 }
@@ -252,7 +260,12 @@ static int serial_wait(E264Device *dev, uint64_t serial, int lane)
 {
 	if (!serial) return 0;
 	hipEvent_t ev = serial_event(dev, serial);
-	if (ev) { HIPCHK(hipEventSynchronize(ev), EIO); return 0; }
+	if (ev) {
+		HIPCHK(hipEventSynchronize(ev), EIO);
+		std::lock_guard<std::mutex> g(dev->lock); // (as in serial_retired: the entry may have been recorded again, for another lane, while we waited)
+		const int idx = (int)(serial % E264Device::NEV);
+		if (dev->sub_serial[idx] == serial && dev->sub_lane[idx] == lane) return 0;
+	}
 	HIPCHK(hipStreamSynchronize(dev->q[lane]), EIO);
 	return 0;
 }
@@ -403,7 +416,7 @@ API int e264hip_set_option(E264Device *dev, const char *name, int value)
 	if (!dev || !name) return -1;
 	if (!strcmp(name, "side_queue")) {
 		int prev = dev->side_queue;
-		dev->side_queue = value && dev->q2;
+		dev->side_queue = dev->q2 ? (value == 1 || value == 2 ? value : 0) : 0; // 1: beside the prediction kernel, 2: beside the intra kernel
 		return prev;
 	}
 	if (!strcmp(name, "upload_queue")) {
@@ -418,7 +431,11 @@ API int e264hip_set_option(E264Device *dev, const char *name, int value)
 	}
 	if (!strcmp(name, "waves")) {
 		int prev = dev->waves;
-		if (value == 2 || value == 4 || value == 7 || value == 8 || value == 106 || value == 107 || value == 108 || value == 110 || value == 112) dev->waves = value; // (110, 112: builds with strips of four macroblocks, E264_DBK_GS = 2; else they mean 108) // 100 + n: n luma / chroma waves (e264_deblock2_kernel) // anything else keeps the setting
+		// 100 + n: n luma / chroma waves (e264_deblock2_kernel); 110, 112 exist only in builds with strips of four macroblocks (E264_DBK_GS = 2):
+		// elsewhere they are refused (-1, setting kept) instead of silently running as 108
+		const bool gs2 = strstr(e264_kernel_build_flags(), "E264_DBK_GS=2") != nullptr;
+		if ((value == 110 || value == 112) && !gs2) return -1;
+		if (value == 2 || value == 4 || value == 7 || value == 8 || value == 106 || value == 107 || value == 108 || value == 110 || value == 112) dev->waves = value; // anything else keeps the setting
 		return prev;
 	}
 	return -1;
@@ -702,7 +719,7 @@ static int launch(E264Device *dev, int lane, const E264Job *d_jobs, int n, int m
 {
 	std::lock_guard<std::mutex> g(dev->lock);
 	hipEvent_t *marks = nullptr;
-	E264Fork fork = {dev->side_queue ? dev->q2 : nullptr, dev->forked, dev->joined, nullptr};
+	E264Fork fork = {dev->side_queue ? dev->q2 : nullptr, dev->forked, dev->joined, nullptr, dev->side_queue};
 	if (dev->ktiming) {
 		if (dev->kev_used == dev->kev.size()) {
 			E264Device::Marks m;

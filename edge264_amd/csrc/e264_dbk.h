@@ -68,8 +68,9 @@ template <int K> struct __attribute__((aligned(16))) DkWaveT { // (the members a
 	uint8_t ty[DkGeom<K>::LUMA ? 4 : 1][DkGeom<K>::LUMA ? DK_STRIDE : 16];          // rows -4..-1 above the wave's first row (luma)
 	uint8_t tcp[DkGeom<K>::CHROMA ? 2 : 1][DkGeom<K>::CHROMA ? DK_STRIDE : 16];     // never holds samples: the unused taps of chroma lanes land here
 	uint8_t tc[DkGeom<K>::CHROMA ? 2 : 1][DkGeom<K>::CHROMA ? DK_STRIDE : 16];      // chroma rows -2, -1 above the wave's first row (right behind tcp)
-	uint32_t prm[DkGeom<K>::ROWS][2][16];      // parameter records of macroblock x (slot x & 1) of each row
 };
+// (until round 5 the strips were followed by the raw parameter records of two macroblocks per row; the parameters now arrive in the
+// lanes' own layout and never touch LDS: DkRaw below)
 
 // Final samples leave with a streaming hint: nothing in this kernel reads them again, and every line they would occupy in
 // the L2 pushes out a line of samples still waiting for its neighbours (a line is visited over 8 steps, the L2 of an XCD
@@ -210,59 +211,32 @@ E264_DEV void dk_edge(s16x2 *v, s16x2 alphaE, s16x2 beta, s16x2 betal, s16x2 tc0
 #ifndef E264_DBK_PIN_PARAMS
 #define E264_DBK_PIN_PARAMS 1
 #endif
-struct DkPrm { s16x2 al[4], be[4], tc[4]; uint32_t bS[4]; s16x2 thr, strong0, strong2; }; // al: alpha, or 0 where bS is 0
+struct DkPrm { s16x2 al[4], be[4], tc[4]; s16x2 thr, strong0, strong2; }; // al: alpha, or 0 where bS is 0
 // Luma lanes: slot e = edge e of the macroblock.  Chroma lanes: slot 0 = Cb macroblock edge, 1 = Cb inner edge, 2 = Cr
-// macroblock edge, 3 = Cr inner edge.  prm: the macroblock's 64-byte parameter record in LDS.
-template <int K> E264_DEV void dk_params(const uint8_t *prm, const uint8_t *tc0tab, const DkRole &R0, DkPrm P[2])
+// macroblock edge, 3 = Cr inner edge.
+// Round 6: the parameter kernel delivers them per lane (e264_dbkp.h: one 16-byte piece per plane kind, direction and segment): a lane
+// fetches the two pieces of its segment (V and H direction) straight into registers one step ahead and spreads each byte into a packed
+// pair with one v_perm -- 26 byte permutes and 4 bit-field extracts where rounds 2 - 5 spent ~26 LDS reads, a dependent table look-up and
+// ~160 VALU instructions per step.
+struct DkRaw { v4u v, h; }; // the lane's pieces of one macroblock: vertical edges (direction 0), horizontal edges (direction 1)
+E264_DEV s16x2 dk_dupb(uint32_t w, int k) { return as_s2(v_perm(0, w, 0x0c000c00u | (uint32_t)k * 0x00010001u)); } // byte k of w in both halves
+E264_DEV uint32_t dk_bit_mask(uint32_t w, int bit) { return (uint32_t)((int32_t)(w << (31 - bit)) >> 31); } // all ones where the bit is set (v_bfe_i32)
+E264_DEV void dk_params1(const v4u &piece, DkPrm &P)
 {
-	DkRole R = R0;
-	R.chroma = dk_chroma<K>(R0);
-	uint32_t alpha[2][4], beta[2][4], ia[2][4], tc0[2][4];
 #pragma unroll
-	for (int dir = 0; dir < 2; dir++)
-#pragma unroll
-		for (int e = 0; e < 4; e++) {
-			const bool mbe = R.chroma ? !(e & 1) : e == 0;                                   // a macroblock edge: its own alpha / beta / indexA
-			const int bso = (R.chroma ? (e & 1) * 8 : e * 4) + R.seg;                        // chroma inner edge = luma edge 2
-			const int abi = (R.chroma ? (1 + (e >> 1)) * 3 : 0) + (mbe ? 1 + dir : 0);       // [plane * 3 + {inner, left, top}]
-			P[dir].bS[e] = prm[dir * 16 + bso];
-			alpha[dir][e] = prm[32 + abi]; beta[dir][e] = prm[41 + abi]; ia[dir][e] = prm[50 + abi];
-		}
-#pragma unroll
-	for (int dir = 0; dir < 2; dir++)
-#pragma unroll
-		for (int e = 0; e < 4; e++)
-			tc0[dir][e] = tc0tab[(P[dir].bS[e] & 3) * 52 + ia[dir][e]]; // row 0 of the table (bS 0 and 4) is zero
-#pragma unroll
-	for (int dir = 0; dir < 2; dir++) {
-#pragma unroll
-		for (int e = 0; e < 4; e++) {
-			P[dir].al[e] = dk_dup(P[dir].bS[e] ? alpha[dir][e] : 0u);
-			P[dir].be[e] = dk_dup(beta[dir][e]);
-			P[dir].tc[e] = dk_dup(tc0[dir][e] + R.tc_add);
-		}
-		P[dir].thr = dk_dup((alpha[dir][0] >> 2) + 2);
-		P[dir].strong0 = dk_dup(P[dir].bS[0] == 4 ? 0xffffu : 0u);
-		P[dir].strong2 = dk_dup(P[dir].bS[2] == 4 ? 0xffffu : 0u);
+	for (int e = 0; e < 4; e++) {
+		P.al[e] = dk_dupb(piece.x, e);
+		P.tc[e] = dk_dupb(piece.y, e);
+		P.be[e] = dk_dupb(piece.z, e);
 	}
-#if E264_DBK_PIN_PARAMS && !defined(E264_HOST_INTRINSICS)
-	// Round 5: the batch above is the point of this function -- and the compiler undid it: every value that is only used behind an edge's
-	// `no lane filters it` branch was SUNK into that branch, LDS reads included (the indexA byte, then the tC0 table look-up that depends on it:
-	// two exposed LDS round trips per edge, sixteen per step, with two waves per SIMD to hide them).  An opaque use here keeps them where they
-	// are computed.
-#pragma unroll
-	for (int dir = 0; dir < 2; dir++) {
-#pragma unroll
-		for (int e = 0; e < 4; e++) {
-			uint32_t a = as_u(P[dir].al[e]), b = as_u(P[dir].be[e]), c = as_u(P[dir].tc[e]);
-			asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
-			P[dir].al[e] = as_s2(a); P[dir].be[e] = as_s2(b); P[dir].tc[e] = as_s2(c);
-		}
-		uint32_t t = as_u(P[dir].thr), s0 = as_u(P[dir].strong0), s2 = as_u(P[dir].strong2);
-		asm volatile("" : "+v"(t), "+v"(s0), "+v"(s2));
-		P[dir].thr = as_s2(t); P[dir].strong0 = as_s2(s0); P[dir].strong2 = as_s2(s2);
-	}
-#endif
+	P.thr = dk_dupb(piece.w, 0);
+	P.strong0 = as_s2(dk_bit_mask(piece.w, 8));
+	P.strong2 = as_s2(dk_bit_mask(piece.w, 9));
+}
+E264_DEV void dk_params(const DkRaw &raw, DkPrm P[2])
+{
+	dk_params1(raw.v, P[0]);
+	dk_params1(raw.h, P[1]);
 }
 // The four edge slots of a line pair held in v[0..19] (positions -4..15): slot e works on v[4e .. 4e+7]; in chroma lanes
 // only p1 p0 q0 q1 = v[4e+2 .. 4e+5] matter.
@@ -343,16 +317,12 @@ template <int K> E264_DEV void dk_pick(const v4u N[2 * DK_GS], const DkRole &R0,
 		o.x = R.chroma ? ch.x : lu.x; o.y = R.chroma ? ch.y : lu.y; o.z = R.chroma ? ch.z : lu.z; o.w = R.chroma ? ch.w : lu.w;
 	}
 }
-// the parameter record of macroblock (x, y): 4 pieces of 16 bytes, luma lanes 0..3
-E264_DEV void dk_fetch_prm(const FrameCtx &f, const DkRole &R, int x, int y, v4u &p)
+// the lane's two parameter pieces of macroblock (x, y).  LOADS ONLY.
+template <int K> E264_DEV void dk_fetch_prm(const FrameCtx &f, const DkRole &R, int x, int y, DkRaw &p)
 {
-	if (R.r < 4)
-		p = *(const gv4u *)(f.dbk + (size_t)(y * f.wm + x) * E264_DBK_BYTES + R.r * 16);
-}
-template <class DkWave> E264_DEV void dk_commit_prm(DkWave &W, const DkRole &R, int x, const v4u &p)
-{
-	if (R.r < 4)
-		*(v4u *)&W.prm[R.g][x & 1][R.r * 4] = p;
+	const gu8 *rec = f.dbk + (size_t)(y * f.wm + x) * E264_DBK_BYTES + (dk_chroma<K>(R) ? 128 : 0) + R.seg * 16;
+	p.v = *(const gv4u *)rec;
+	p.h = *(const gv4u *)(rec + 64);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -418,8 +388,8 @@ template <int K> E264_DEV void dk_vcopy(DkWaveT<K> &W, const DkRole &R, const v4
 		*(v2u *)(W8 + own + DK_CR + DK_STRIDE) = (v2u){rb.z, rb.w};
 	}
 }
-// does the macroblock's parameter record name any edge at all?  (bytes 0..31: bS[direction][edge][segment])
-E264_DEV uint32_t dk_any_bs(const uint32_t *prm) { return prm[0] | prm[1] | prm[2] | prm[3] | prm[4] | prm[5] | prm[6] | prm[7]; }
+// can any of the lane's eight edge slots filter at all?  (alpha is 0 where bS is 0, and for the low indexA no edge passes)
+E264_DEV uint32_t dk_any_bs(const DkRaw &raw) { return raw.v.x | raw.h.x; }
 #ifndef E264_DBK_ZEROSKIP
 #define E264_DBK_ZEROSKIP 0 // measured (profiles/r05_ablations.txt item 5): the eight macroblocks of a step lie on a diagonal through eight rows; on the
                             // encoder-made fixtures 58 % of the macroblocks have no edge but only 6.6 % of the steps: no gain there, -1.4 % on the bench GOP
@@ -528,7 +498,7 @@ template <int K> E264_DEV void dk_top_flush(const DkWaveT<K> &W, const FrameCtx 
 struct DkPlan {
 	int x;             // the row's macroblock at this step
 	bool act;          // V and H phases
-	bool prm_commit, prm_fetch;           // parameters of x+1 -> LDS, of x+3 -> register (two register sets alternating with the parity of t)
+	bool prm_fetch;                       // parameters of x+1 -> the register set of the other parity (used by the next step)
 	bool grp_fetch;                       // (t % 4 == 0) samples of x+2 .. x+5 -> registers: consumed at steps t+2 .. t+5
 	int top_fetch, top_commit;            // group of the top strip to fetch / commit, -1: none (wave lanes 0..23, when the wave has rows above)
 	int flush, top_flush;                 // group to write out before the V phase, -1: none
@@ -543,8 +513,7 @@ E264_DEV DkPlan dk_plan(int t, const DkRole &R, bool row_ok, bool top, int wm)
 	const int nq = dk_groups(wm);
 	p.x = t - R.g;
 	p.act = row_ok && p.x >= 0 && p.x < wm;
-	p.prm_commit = row_ok && p.x + 1 >= 0 && p.x + 1 < wm;
-	p.prm_fetch = row_ok && p.x + 3 >= 0 && p.x + 3 < wm;
+	p.prm_fetch = row_ok && p.x + 1 >= 0 && p.x + 1 < wm;
 	p.grp_fetch = (t & (DK_GS - 1)) == 0 && row_ok && p.x + 1 + DK_GS >= 0 && p.x + 2 < wm;
 	// the wave's first row filters group Q's first macroblock at t = 4Q: fetched at t = 4Q - 2, committed at t = 4Q - 1 (groups of 2: 2Q ...)
 	p.top_fetch = (top && ((t + 2) & (DK_GS - 1)) == 0 && (t + 2) >> DK_LG < nq) ? (t + 2) >> DK_LG : -1;

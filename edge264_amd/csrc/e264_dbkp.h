@@ -11,9 +11,21 @@
 // their 64 top neighbours and of the left neighbour of the first one into LDS with CONTIGUOUS 16-byte loads (11 per
 // macroblock), computes from LDS, and writes the 64-byte parameter records back as contiguous 16-byte stores.
 //
-// Output record (E264_DBK_BYTES = 64 per macroblock), unchanged:
+// Raw record (DP_RAW = 64 bytes per macroblock, in LDS only since round 6):
 //   [0..31]  bS[dir][edge][segment]      [32..40] alpha[plane*3 + t], t = 0 internal edges, 1 left MB edge, 2 top MB edge
 //   [41..49] beta                        [50..58] indexA (tC0 lookup)                       [59..63] zero
+// What leaves for memory (round 6, E264_DBK_BYTES = 256 per macroblock) is the same information IN THE LAYOUT OF THE DEBLOCKING KERNEL'S
+// LANES: sixteen 16-byte pieces, one per (plane kind, direction, line-pair segment) -- exactly what one lane of e264_dbk.h needs for its
+// four edge slots of one direction, ready to be spread into packed 16-bit pairs with one byte permute per value:
+//   piece (luma: byte offset (dir * 4 + seg) * 16; chroma: 128 + (dir * 4 + line pair) * 16):
+//     dword 0  alphaE[slot 0..3]   alpha of the slot's edge, or 0 where its bS is 0 (nothing is below 0: the edge is left alone)
+//     dword 1  tC[slot 0..3]       tC0 of (bS, indexA); chroma: + 1 (its tC); 0 for bS 0 and 4
+//     dword 2  beta[slot 0..3]
+//     dword 3  byte 0: (alpha of slot 0 >> 2) + 2 (the bS 4 luma test); byte 1 bit 0: slot 0 has bS 4, bit 1: slot 2 has bS 4
+//   (luma slot e = edge e of the macroblock; chroma slot 0 = Cb macroblock edge, 1 = Cb inner edge, 2 / 3 = the same of Cr)
+// Until round 5 every lane of the deblocking kernel derived these from the raw record in every step: ~26 LDS reads, a dependent tC0
+// table look-up and ~160 VALU instructions per step and wave, i.e. once per line-pair segment of each of the 8 (15) macroblocks of a step
+// AND per lane pair that shares it; here it is done once per macroblock by four threads.
 // The phases are plain functions of (LDS, frame, first macroblock, thread id): tests/emu runs them on the host.
 #ifndef E264_DBKP_H
 #define E264_DBKP_H
@@ -23,14 +35,20 @@ namespace {
 
 #define DP_MBS 64
 #define DP_NT 256
+#define DP_RAW 64
 struct __attribute__((aligned(16))) DbkpLds {
 	uint32_t hdr[2 * DP_MBS + 1][8];   // E264Mb: [0] left neighbour of the first macroblock, [1..64] own, [65..128] top neighbours
-	uint32_t mo[2 * DP_MBS + 1][36];   // motion in expanded (E264Motion) form, same order; filled from the compact records
-	uint32_t out[DP_MBS][16];
+	union {
+		uint32_t mo[2 * DP_MBS + 1][36];               // motion in expanded (E264Motion) form, same order; filled from the compact records
+		uint32_t pieces[DP_MBS][E264_DBK_BYTES / 4];   // (once the comparisons are done) the records in the lanes' layout, on their way out
+	};
+	uint32_t out[DP_MBS][DP_RAW / 4];  // raw records
 	int8_t fo[DP_MBS][2];              // FilterOffsetA / B of each macroblock's slice
 	uint8_t alpha[52], beta[52];
+	uint32_t tc3[52];                  // per indexA: bytes {0, tC0 of bS 1, of bS 2, of bS 3} (bS 0 and 4 have no tC0: entry bS & 3 = 0)
 	uint32_t any_l1;                   // some record of the workgroup (own, left, top) predicts from list 1
 };
+static_assert(sizeof(((DbkpLds *)0)->pieces) <= sizeof(((DbkpLds *)0)->mo), "the pieces reuse the motion area");
 
 #ifndef E264_HOST_INTRINSICS
 E264_DEV void dbkp_note_l1(uint32_t *p) { atomicOr(p, 1u); }
@@ -53,6 +71,7 @@ E264_DEV void dbkp_phase_load(DbkpLds &L, const FrameCtx &f, int a0, int tid)
 		*(v4u *)&L.hdr[j][part * 4] = *(const gv4u *)(mbs_g + (size_t)dbkp_addr(f, a0, j) * 32 + part * 16);
 	}
 	if (tid < 52) { L.alpha[tid] = c_alpha[tid]; L.beta[tid] = c_beta[tid]; }
+	if (tid < 52) L.tc3[tid] = (uint32_t)c_tc0[0][tid] << 8 | (uint32_t)c_tc0[1][tid] << 16 | (uint32_t)c_tc0[2][tid] << 24;
 	if (tid == 0) L.any_l1 = 0;
 }
 
@@ -234,12 +253,81 @@ E264_DEV void dbkp_phase_compute(DbkpLds &L, const FrameCtx &f, int a0, int tid)
 	}
 }
 
+// One piece of the lanes' layout out of a raw record (see the head of this file; the selection of bS / alpha / beta / indexA per slot is
+// what e264_dbk.h's dk_params did per lane and step until round 5).  s: luma segment / chroma line pair, 0..3.
+E264_DEV uint32_t dk_bfi_u(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); } // v_bfi_b32
+E264_DEV v4u dbkp_piece(const uint8_t *rec, const uint8_t *tc0tab, bool chroma, int dir, int s)
+{
+	uint32_t al = 0, tc = 0, be = 0, last = 0;
+#pragma unroll
+	for (int e = 0; e < 4; e++) {
+		const bool mbe = chroma ? !(e & 1) : e == 0;                              // a macroblock edge: its own alpha / beta / indexA
+		const int bso = (chroma ? (e & 1) * 8 : e * 4) + s;                       // chroma inner edge = luma edge 2
+		const int abi = (chroma ? (1 + (e >> 1)) * 3 : 0) + (mbe ? 1 + dir : 0);  // [plane * 3 + {inner, left, top}]
+		const uint32_t bS = rec[dir * 16 + bso], alpha = rec[32 + abi], beta = rec[41 + abi], ia = rec[50 + abi];
+		al |= (bS ? alpha : 0u) << (8 * e);
+		tc |= ((uint32_t)tc0tab[(bS & 3) * 52 + ia] + (chroma ? 1u : 0u)) << (8 * e);
+		be |= beta << (8 * e);
+		if (e == 0) last |= ((alpha >> 2) + 2) | (bS == 4 ? 0x100u : 0u);
+		if (e == 2) last |= bS == 4 ? 0x200u : 0u;
+	}
+	return (v4u){al, tc, be, last};
+}
+// after the raw records: thread r of a macroblock builds the four pieces of direction r >> 1, segments / line pairs 2 (r & 1), 2 (r & 1) + 1.
+// dbkp_piece above is the definition (and what the host tests compare with); this is the same on four slots at a time: the bS of a piece's
+// four slots gathered into one dword, "bS != 0" as a byte mask, and the tC0 of all four out of ONE byte permute whose selector is bS itself
+// (L.tc3[indexA] = {0, tC0 of bS 1, 2, 3}: the macroblock-edge entry in the low source, the inner-edge entry in the high one).
+E264_DEV uint32_t dbkp_byte(const uint32_t *w, int k) { return w[k >> 2] >> (8 * (k & 3)) & 255u; } // byte k of the raw record's dwords 8..15 (k - 32)
+E264_DEV void dbkp_phase_pieces(DbkpLds &L, int tid)
+{
+	const int i = tid >> 2, r = tid & 3, dir = r >> 1, s0 = (r & 1) * 2;
+	const v4u B = *(const v4u *)&L.out[i][dir * 4]; // bS of edges 0..3, one segment per byte
+	const v4u w0 = *(const v4u *)&L.out[i][8], w1 = *(const v4u *)&L.out[i][12];
+	const uint32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+	uint32_t alv[3], bev[3], t_mb[3], t_in[3], thr0 = 0;
+#pragma unroll
+	for (int pl = 0; pl < 3; pl++) { // [plane * 3 + {inner, left, top}] at bytes 32 (alpha), 41 (beta), 50 (indexA) of the record
+		const uint32_t a_in = dbkp_byte(w, 3 * pl), a_mb = dir ? dbkp_byte(w, 3 * pl + 2) : dbkp_byte(w, 3 * pl + 1);
+		const uint32_t b_in = dbkp_byte(w, 9 + 3 * pl), b_mb = dir ? dbkp_byte(w, 9 + 3 * pl + 2) : dbkp_byte(w, 9 + 3 * pl + 1);
+		const uint32_t i_in = dbkp_byte(w, 18 + 3 * pl), i_mb = dir ? dbkp_byte(w, 18 + 3 * pl + 2) : dbkp_byte(w, 18 + 3 * pl + 1);
+		alv[pl] = a_mb | a_in << 8; bev[pl] = b_mb | b_in << 8; // (macroblock edge, inner edges)
+		t_mb[pl] = L.tc3[i_mb]; t_in[pl] = L.tc3[i_in];
+		if (pl == 0) thr0 = (a_mb >> 2) + 2;
+	}
+	const uint32_t al_l = v_perm(0, alv[0], 0x01010100u), be_l = v_perm(0, bev[0], 0x01010100u);  // luma slots: mb, inner, inner, inner
+	const uint32_t al_c = v_perm(alv[2], alv[1], 0x05040100u), be_c = v_perm(bev[2], bev[1], 0x05040100u); // chroma slots: Cb mb, Cb inner, Cr mb, Cr inner
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const uint32_t sg = (uint32_t)(s0 + k);
+		{ // luma: slot e = edge e
+			const uint32_t sel = sg * 0x0101u + 0x0400u; // bytes (sg of the low source, sg of the high source)
+			const uint32_t bsv = v_perm(v_perm(B.w, B.z, sel), v_perm(B.y, B.x, sel), 0x05040100u);
+			const uint32_t nz7 = (bsv + 0x7f7f7f7fu) & 0x80808080u, full = (nz7 << 1) - (nz7 >> 7); // 0xff where bS != 0 (bS <= 4: no carry between bytes)
+			const uint32_t tc = v_perm(t_in[0], t_mb[0], (bsv & 0x03030303u) + 0x04040400u);
+			const uint32_t x4 = bsv & 0x00040004u; // bS == 4 <=> bit 2 (bS is 0..4)
+			*(v4u *)&L.pieces[i][(dir * 4 + s0 + k) * 4] = (v4u){al_l & full, tc, be_l, thr0 | (x4 << 6 & 0x100u) | (x4 >> 9 & 0x200u)};
+		}
+		{ // chroma: slots (Cb edge 0, Cb edge 2, Cr edge 0, Cr edge 2)
+			const uint32_t sel = sg * 0x01010101u + 0x04000400u;
+			const uint32_t bsv = v_perm(B.z, B.x, sel);
+			const uint32_t nz7 = (bsv + 0x7f7f7f7fu) & 0x80808080u, full = (nz7 << 1) - (nz7 >> 7);
+			const uint32_t tsel = (bsv & 0x03030303u) + 0x04000400u;
+			const uint32_t tc = dk_bfi_u(0x0000ffffu, v_perm(t_in[1], t_mb[1], tsel), v_perm(t_in[2], t_mb[2], tsel)) + 0x01010101u;
+			const uint32_t x4 = bsv & 0x00040004u;
+			*(v4u *)&L.pieces[i][32 + (dir * 4 + s0 + k) * 4] = (v4u){al_c & full, tc, be_c, ((alv[1] & 255u) >> 2) + 2 | (x4 << 6 & 0x100u) | (x4 >> 9 & 0x200u)};
+		}
+	}
+}
+
 E264_DEV void dbkp_phase_store(const DbkpLds &L, const FrameCtx &f, int a0, int tid)
 {
 	const int n_mbs = f.wm * f.hm;
-	const int i = tid >> 2, part = tid & 3; // 64 records x 4 pieces of 16 bytes
-	if (a0 + i < n_mbs)
-		*(gv4u *)(f.dbk + (size_t)(a0 + i) * E264_DBK_BYTES + part * 16) = *(const v4u *)&L.out[i][part * 4];
+#pragma unroll
+	for (int k = 0; k < E264_DBK_BYTES / 64; k++) { // 64 records x 16 pieces of 16 bytes, consecutive threads consecutive pieces
+		const int idx = k * DP_NT + tid, i = idx >> 4, part = idx & 15;
+		if (a0 + i < n_mbs)
+			*(gv4u *)(f.dbk + (size_t)(a0 + i) * E264_DBK_BYTES + part * 16) = *(const v4u *)&L.pieces[i][part * 4];
+	}
 }
 
 } // namespace

@@ -11,13 +11,13 @@ struct E264Job {
 	uint8_t *const *dpb;
 	uint8_t *dbk; // per-stream scratch: E264_DBK_BYTES per macroblock (bS, alpha, beta, indexA), NULL = no deblocking
 };
-#define E264_DBK_BYTES 64
+#define E264_DBK_BYTES 256 // sixteen 16-byte pieces in the layout of the deblocking kernel's lanes (e264_dbkp.h)
 
 // mode: bit0 reconstruction, bit1 deblocking.  waves: 4, 8 or 16 macroblock rows in flight per frame.
 // max_mbs: largest macroblock count among the jobs; max_tiles: largest e264_pred_tiles() among the jobs.  marks: NULL or 5 events (boundaries of the 4 kernels).
 // fork: NULL, or a second queue + events on which the parameter kernel runs beside the macroblock-parallel kernel
 // (amarks: 2 events bracketing it there, recorded when marks != NULL).
-struct E264Fork { hipStream_t aux; hipEvent_t forked, joined; hipEvent_t *amarks; };
+struct E264Fork { hipStream_t aux; hipEvent_t forked, joined; hipEvent_t *amarks; int where; }; // where: 1 = beside the prediction kernel, 2 = beside the intra kernel
 // workgroups e264_pred_kernel needs for a picture of this size (its tile geometry is a build-time choice of the kernels)
 extern "C" int e264_pred_tiles(int width_mbs, int height_mbs);
 // build-time switches of the kernels ("" = product build; e264hip_build_flags hands it out)

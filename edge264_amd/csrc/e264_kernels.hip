@@ -159,6 +159,8 @@ __global__ __launch_bounds__(DP_NT) void e264_dbkparam2_kernel(const E264Job *jo
 	__syncthreads();
 	dbkp_phase_compute(L, f, a0, tid);
 	__syncthreads();
+	dbkp_phase_pieces(L, tid);
+	__syncthreads();
 	dbkp_phase_store(L, f, a0, tid);
 }
 
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 // the wave that walks the group above through progress[] (macroblocks of that group's last row that have reached memory).
 // dk_walk_group: one group q of kind K, by the calling wave.  progress: the counters of this kind's chain of groups.
 template <int K>
-static __device__ __forceinline__ void dk_walk_group(DkWaveT<K> &W, const FrameCtx &f, const uint8_t *tc0tab, int *progress, const int q, const int lane, const int tl_slot)
+static __device__ __forceinline__ void dk_walk_group(DkWaveT<K> &W, const FrameCtx &f, int *progress, const int q, const int lane, const int tl_slot)
 {
 	typedef DkGeom<K> G;
 	const DkRole R = dk_role<K>(lane);
@@ -187,20 +189,21 @@ static __device__ __forceinline__ void dk_walk_group(DkWaveT<K> &W, const FrameC
 #if defined(E264_PHASE_TIMING) || defined(E264_DBK_TIMELINE)
 	if (blockIdx.x == 0 && lane == 0 && tl_slot < 64) g_timeline[2 * tl_slot] = __builtin_amdgcn_s_memtime();
 #endif
-	v4u p0 = {0, 0, 0, 0}, p1 = p0, tt = p0;
+	v4u tt = {0, 0, 0, 0};
+	DkRaw p0 = {tt, tt}, p1 = p0; // the lane's parameter pieces: the set this step uses and the set it requests for the next one
 	v4u N[2 * DK_GS];       // samples of four (two) macroblocks of the lane's two rows (dk_fetch4), requested at steps t = 0 mod 4 (2)
-	v4u K2a = p0, K2b = p0, K3a = p0, K3b = p0; // the last two (groups of 2: K3, the last one) of them, kept while the next group is on its way
+	v4u K2a = tt, K2b = tt, K3a = tt, K3b = tt; // the last two (groups of 2: K3, the last one) of them, kept while the next group is on its way
 	PH_DECL;
 	// one step; k = (t + 2) & 3: which macroblock of its group the step filters (k = 2, 3: of the group before, out of K2 / K3);
 	// groups of 2: k = t & 1, k = 1 out of K3, the step with k = 0 requests the next group;
-	// sp: the parameter register set of this step's parity (parameters of x+1, requested two steps ago)
-	auto step = [&](const int t, const int k, v4u &sp) __attribute__((always_inline)) {
+	// sp: the parameter pieces of x, requested by the step before; sn: where this step requests those of x + 1
+	auto step = [&](const int t, const int k, DkRaw &sp, DkRaw &sn) __attribute__((always_inline)) {
 		const DkPlan p = dk_plan(t, R, row_ok, top, wm);
 		// what earlier steps requested is picked up BEFORE this step's stores are issued: the compiler cannot count
 		// conditional stores, any use of a loaded register after them is an s_waitcnt vmcnt(0) = a full drain
 		if (p.top_commit >= 0) dk_top_commit<K>(W, f, lane, p.top_commit, y0, tt);
-		if (p.prm_commit) dk_commit_prm(W, R, p.x + 1, sp);
 		v4u ra, rb;
+		asm volatile("" :: "v"(sp.v), "v"(sp.h)); // (the parameters of this step have landed)
 		if (DK_GS == 4) {
 			if (k < 2) dk_pick<K>(N, R, k, ra, rb);
 			else { ra = k == 2 ? K2a : K3a; rb = k == 2 ? K2b : K3b; }
@@ -224,20 +227,20 @@ static __device__ __forceinline__ void dk_walk_group(DkWaveT<K> &W, const FrameC
 			dk_top_fetch<K>(f, lane, p.top_fetch, y0, tt);
 		}
 		PH(1);
-		if (p.prm_fetch) dk_fetch_prm(f, R, p.x + 3, y, sp);
+		if (p.prm_fetch) dk_fetch_prm<K>(f, R, p.x + 1, y, sn);
 		if (k == (DK_GS == 4 ? 2 : 0) && p.grp_fetch) dk_fetch4<K>(src, R, p.x + 2, wm, N);
 		wave_sync();
 		PH(2);
 		DkPrm P[2];
 #if E264_DBK_ZEROSKIP // (wave-uniform) a step in which no macroblock of the wave has an edge to filter only moves its samples into the strips
-		if (!__any(p.act && dk_any_bs(W.prm[R.g][p.x & 1]) != 0)) {
+		if (!__any(p.act && dk_any_bs(sp) != 0)) {
 			if (p.act) dk_vcopy<K>(W, R, ra, rb, p.x);
 			wave_sync();
 		} else
 #endif
 		{
 			if (p.act) {
-				dk_params<K>((const uint8_t *)W.prm[R.g][p.x & 1], tc0tab, R, P);
+				dk_params(sp, P);
 				PH(3);
 				dk_vpass<K>(W, P[0], R, ra, rb, p.x);
 			}
@@ -258,13 +261,13 @@ static __device__ __forceinline__ void dk_walk_group(DkWaveT<K> &W, const FrameC
 #pragma unroll 1
 	for (int t = DK_FIRST_STEP; t <= last_step; t += DK_GS) { // unrolled by four (two): a group of macroblocks per fetch, registers by name
 		if (DK_GS == 4) {
-			step(t, 2, p0);
-			step(t + 1, 3, p1);
-			step(t + 2, 0, p0);
-			step(t + 3, 1, p1);
+			step(t, 2, p0, p1);
+			step(t + 1, 3, p1, p0);
+			step(t + 2, 0, p0, p1);
+			step(t + 3, 1, p1, p0);
 		} else {
-			step(t, 0, p0);
-			step(t + 1, 1, p1);
+			step(t, 0, p0, p1);
+			step(t + 1, 1, p1, p0);
 		}
 	}
 #if defined(E264_PHASE_TIMING) || defined(E264_DBK_TIMELINE)
@@ -281,7 +284,6 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 {
 	__shared__ DkWaveT<2> lds[NW];
 	__shared__ int progress[(E264_MAX_ROWS + DK_ROWS_OF(2) - 1) / DK_ROWS_OF(2)];
-	__shared__ uint8_t tc0tab[4 * 52]; // row (bS & 3): row 0 is all zero (bS 0 and 4 have no tC0)
 	const int lane = lane_id();
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	FrameCtx f;
@@ -290,8 +292,6 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 	const int nquint = (f.hm + DK_ROWS_OF(2) - 1) / DK_ROWS_OF(2);
 	for (int i = threadIdx.x; i < nquint; i += NW * 64)
 		progress[i] = 0;
-	for (int i = threadIdx.x; i < 4 * 52; i += NW * 64)
-		tc0tab[i] = i < 52 ? 0 : c_tc0[i / 52 - 1][i % 52];
 	__syncthreads();
 #pragma unroll 1
 	for (int q = wave; q < nquint; q += NW) {
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock_kernel(const E264Job *jo
 		// first-pass group (w + NW / 2).  Earlier passes get the higher priority, whatever the wave's age.
 		{ const int pass = q / NW; if (pass == 0) __builtin_amdgcn_s_setprio(3); else if (pass == 1) __builtin_amdgcn_s_setprio(2); else if (pass == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #endif
-		dk_walk_group<2>(lds[wave], f, tc0tab, progress, q, lane, q);
+		dk_walk_group<2>(lds[wave], f, progress, q, lane, q);
 	}
 }
 
@@ -317,7 +317,6 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock2_kernel(const E264Job *j
 	__shared__ int progress_l[(E264_MAX_ROWS + DK_ROWS_OF(0) - 1) / DK_ROWS_OF(0)];
 	__shared__ int progress_c[(E264_MAX_ROWS + DK_ROWS_OF(1) - 1) / DK_ROWS_OF(1)];
 	__shared__ int next_task;
-	__shared__ uint8_t tc0tab[4 * 52];
 	const int lane = lane_id();
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	FrameCtx f;
@@ -326,8 +325,6 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock2_kernel(const E264Job *j
 	const int nl = (f.hm + DK_ROWS_OF(0) - 1) / DK_ROWS_OF(0), nc = (f.hm + DK_ROWS_OF(1) - 1) / DK_ROWS_OF(1), total = nl + nc;
 	for (int i = threadIdx.x; i < nl; i += NW * 64) progress_l[i] = 0;
 	for (int i = threadIdx.x; i < nc; i += NW * 64) progress_c[i] = 0;
-	for (int i = threadIdx.x; i < 4 * 52; i += NW * 64)
-		tc0tab[i] = i < 52 ? 0 : c_tc0[i / 52 - 1][i % 52];
 	if (threadIdx.x == 0) next_task = 0;
 	__syncthreads();
 #pragma unroll 1
@@ -339,8 +336,8 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock2_kernel(const E264Job *j
 			break;
 		// luma groups among the first i tasks of the list: (i * nl) / total; task i is a luma group iff that count grows at i + 1
 		const int lb = task * nl / total, la = (task + 1) * nl / total;
-		if (la > lb) dk_walk_group<0>(lds[wave].l, f, tc0tab, progress_l, lb, lane, lb);
-		else dk_walk_group<1>(lds[wave].c, f, tc0tab, progress_c, task - lb, lane, 32 + task - lb);
+		if (la > lb) dk_walk_group<0>(lds[wave].l, f, progress_l, lb, lane, lb);
+		else dk_walk_group<1>(lds[wave].c, f, progress_c, task - lb, lane, 32 + task - lb);
 	}
 }
 
@@ -350,6 +347,9 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock2_kernel(const E264Job *j
 extern "C" const char *e264_kernel_build_flags(void)
 {
 	return ""
+#if E264_DBK_GS == 2 // (not an ablation: a bit-exact variant; named so that the back end knows which wave counts exist)
+		" E264_DBK_GS=2"
+#endif
 #ifdef E264_ABL_NOBH
 		" E264_ABL_NOBH"
 #endif
@@ -421,7 +421,11 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 	// runs on a second queue NEXT TO the macroblock-parallel kernel -- 28 VGPRs per wave, its waves fit beside the two
 	// 215-VGPR waves per SIMD and use issue slots those leave idle.  Ordered after everything enqueued before (the packet
 	// copies, the previous batch's deblocking that still reads the parameter buffer) by `forked`, before deblocking by `joined`.
+	// fork->where: 1 = beside the macroblock-parallel kernel (rounds 1 - 4: no gain, that kernel fills every CU), 2 = beside the intra
+	// kernel (round 6): one 125-KB workgroup per CU leaves 38 KB of LDS and, on P / B pictures, most issue slots -- the 27-KB / 40-VGPR
+	// parameter workgroups fit beside it, and deblocking (the only consumer) starts when both are done.
 	const bool side = dbkp && fork && fork->aux;
+	const int where = side ? (fork->where == 2 ? 2 : 1) : 0;
 	auto launch_side = [&]() {
 		hipEventRecord(fork->forked, stream);
 		hipStreamWaitEvent(fork->aux, fork->forked, 0);
@@ -430,14 +434,16 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 		if (marks) hipEventRecord(fork->amarks[1], fork->aux);
 		hipEventRecord(fork->joined, fork->aux);
 	};
-	if (side)
+	if (where == 1)
 		launch_side();
-	else if (dbkp)
+	else if (dbkp && !side)
 		hipLaunchKernelGGL(e264_dbkparam2_kernel, dim3((max_mbs + DP_MBS - 1) / DP_MBS, n_jobs), dim3(DP_NT), 0, stream, jobs);
 	if (marks) hipEventRecord(marks[1], stream);
 	if (mode & 1)
 		hipLaunchKernelGGL(e264_pred_kernel, dim3(max_tiles, n_jobs), dim3(PT_NT), 0, stream, jobs, mode);
 	if (marks) hipEventRecord(marks[2], stream);
+	if (where == 2)
+		launch_side();
 	const int intra_waves = waves >> 8 ? waves >> 8 : waves & 255;
 	waves &= 255;
 	if (mode & 1) {
@@ -447,8 +453,8 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 		default: hipLaunchKernelGGL(e264_intra_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs); break;
 		}
 	}
+	if (side) hipStreamWaitEvent(stream, fork->joined, 0); // (before the mark: with the parameter kernel beside it, "intra" is the phase both share)
 	if (marks) hipEventRecord(marks[3], stream);
-	if (side) hipStreamWaitEvent(stream, fork->joined, 0);
 	if (mode & 2) {
 		switch (waves) { // waves per picture (default 8, set by the back end); 100 + n: luma / chroma waves (e264_deblock2_kernel)
 #if E264_DBK_GS == 2 // strips of four macroblocks: 12.6 KB of LDS per wave, twelve waves (three per SIMD) fit the CU

@@ -64,6 +64,9 @@ struct __attribute__((aligned(16))) PredLds {
 	uint32_t staged[PT_MBS / 32];       // macroblocks this kernel writes (inter, PCM)
 	int any_l1;                         // some quadrant of the tile uses list 1
 	generic_u8p dpb[E264_MAX_SLOTS];
+#ifdef E264_PRED_LDS_PAD // measuring aid: what the kernel does at a lower occupancy (bytes of LDS nobody uses)
+	uint8_t pad[E264_PRED_LDS_PAD];
+#endif
 };
 
 struct PredTile { int tx0, ty0; };     // first macroblock of the tile

@@ -2,6 +2,7 @@
 // the host and runs e264_pred_kernel's phases thread by thread, tile by tile: the same arithmetic, the same LDS layout,
 // the same work lists, with the four VALU byte instructions the source names restated below.  tests/test_pred_emu.py
 // compares the result with the CPU oracle, so that a logic error is found here and not on the GPU box.
+#include <stdlib.h>
 #include "emu_shims.h"
 #include "../../edge264_amd/csrc/e264_pred.h"
 #include "../../edge264_amd/csrc/e264_dbkp.h"
@@ -37,8 +38,9 @@ extern "C" __attribute__((visibility("default"))) int e264emu_pred_frame(const u
 	return e264emu_pred_frame2(pkt, dpb, nullptr);
 }
 
-// e264_dbkparam2_kernel: out = 64 bytes per macroblock
-extern "C" __attribute__((visibility("default"))) int e264emu_dbkparam_frame(const uint8_t *pkt, uint8_t *out)
+// e264_dbkparam2_kernel: out = E264_DBK_BYTES (256) per macroblock, the pieces of the deblocking lanes' layout; raw (may be NULL) = the 64-byte
+// raw records (bS, alpha, beta, indexA) the pieces are made of, as they stand in LDS between the kernel's phases
+extern "C" __attribute__((visibility("default"))) int e264emu_dbkparam_frame2(const uint8_t *pkt, uint8_t *out, uint8_t *raw)
 {
 	uint8_t dummy = 0;
 	uint8_t *dpb[E264_MAX_SLOTS];
@@ -48,14 +50,50 @@ extern "C" __attribute__((visibility("default"))) int e264emu_dbkparam_frame(con
 	if (!open_frame(f, job))
 		return -1;
 	static DbkpLds L;
-	for (int a0 = 0; a0 < f.wm * f.hm; a0 += DP_MBS) {
+	const int n = f.wm * f.hm;
+	for (int a0 = 0; a0 < n; a0 += DP_MBS) {
 		memset(&L, 0xA5, sizeof(L));
 		for (int tid = 0; tid < DP_NT; tid++) dbkp_phase_load(L, f, a0, tid);
 		for (int tid = 0; tid < DP_NT; tid++) dbkp_phase_slices(L, f, tid);
 		for (int tid = 0; tid < DP_NT; tid++) dbkp_phase_compute(L, f, a0, tid);
+		if (raw) for (int i = 0; i < DP_MBS && a0 + i < n; i++) memcpy(raw + (size_t)(a0 + i) * DP_RAW, L.out[i], DP_RAW);
+		memset(L.mo, 0xA5, sizeof(L.mo)); // (the pieces reuse the motion area: nothing of it may be read any more)
+		for (int tid = 0; tid < DP_NT; tid++) dbkp_phase_pieces(L, tid);
 		for (int tid = 0; tid < DP_NT; tid++) dbkp_phase_store(L, f, a0, tid);
 	}
 	return 0;
+}
+// the pieces alone: what e264emu_deblock_frame2 consumes
+extern "C" __attribute__((visibility("default"))) int e264emu_dbkparam_frame(const uint8_t *pkt, uint8_t *out)
+{
+	return e264emu_dbkparam_frame2(pkt, out, nullptr);
+}
+// the raw records alone (64 bytes per macroblock)
+extern "C" __attribute__((visibility("default"))) int e264emu_dbkparam_raw(const uint8_t *pkt, uint8_t *raw)
+{
+	FrameCtx f;
+	uint8_t dummy = 0;
+	uint8_t *dpb[E264_MAX_SLOTS];
+	for (int i = 0; i < E264_MAX_SLOTS; i++) dpb[i] = &dummy;
+	E264Job job = {pkt, dpb, &dummy};
+	if (!open_frame(f, job))
+		return -1;
+	uint8_t *out = (uint8_t *)malloc((size_t)f.wm * f.hm * E264_DBK_BYTES);
+	const int r = e264emu_dbkparam_frame2(pkt, out, raw);
+	free(out);
+	return r;
+}
+// a raw record -> its sixteen pieces (what the kernel's piece phase does)
+extern "C" __attribute__((visibility("default"))) void e264emu_dbk_pieces(const uint8_t *raw, uint8_t *out256)
+{
+	uint8_t tc0tab[4 * 52];
+	for (int i = 0; i < 4 * 52; i++) tc0tab[i] = i < 52 ? 0 : c_tc0[i / 52 - 1][i % 52];
+	for (int c = 0; c < 2; c++)
+		for (int dir = 0; dir < 2; dir++)
+			for (int sgm = 0; sgm < 4; sgm++) {
+				const v4u p = dbkp_piece(raw, tc0tab, c != 0, dir, sgm);
+				memcpy(out256 + c * 128 + (dir * 4 + sgm) * 16, &p, 16);
+			}
 }
 
 // e264_deblock_kernel / e264_deblock2_kernel: dbk = the parameter records (e264emu_dbkparam_frame's output); the picture in
@@ -69,7 +107,7 @@ extern "C" __attribute__((visibility("default"))) void e264emu_deblock_step_coun
 	if (reset) g_zero_steps = g_filter_steps = 0;
 }
 template <int K>
-static void emu_walk_group(const FrameCtx &f, const uint8_t *tc0tab, int q)
+static void emu_walk_group(const FrameCtx &f, int q)
 {
 	typedef DkGeom<K> G;
 	static DkWaveT<K> W;
@@ -78,7 +116,8 @@ static void emu_walk_group(const FrameCtx &f, const uint8_t *tc0tab, int q)
 	memset(&W, 0xA5, sizeof(W));
 	const int y0 = q * G::ROWS;
 	const bool top = q > 0;
-	static v4u N[64][2 * DK_GS], K2a[64], K2b[64], K3a[64], K3b[64], np[2][64], tt[64], ra[64], rb[64];
+	static v4u N[64][2 * DK_GS], K2a[64], K2b[64], K3a[64], K3b[64], tt[64], ra[64], rb[64];
+	static DkRaw np[2][64];
 	memset(N, 0x5A, sizeof(N)); memset(K2a, 0x5A, sizeof(K2a)); memset(K2b, 0x5A, sizeof(K2b)); memset(K3a, 0x5A, sizeof(K3a)); memset(K3b, 0x5A, sizeof(K3b));
 	memset(np, 0x5A, sizeof(np)); memset(tt, 0x5A, sizeof(tt));
 	for (int t4 = DK_FIRST_STEP; t4 <= dk_last_step<K>(f.wm); t4 += DK_GS) // (the kernel's loop: whole groups of four (two) steps)
@@ -89,7 +128,6 @@ static void emu_walk_group(const FrameCtx &f, const uint8_t *tc0tab, int q)
 			const int y = y0 + R[lane].g;
 			p[lane] = dk_plan(t, R[lane], !R[lane].idle && y < f.hm, top, f.wm);
 			if (p[lane].top_commit >= 0) dk_top_commit<K>(W, f, lane, p[lane].top_commit, y0, tt[lane]);
-			if (p[lane].prm_commit) dk_commit_prm(W, R[lane], p[lane].x + 1, np[par][lane]);
 			if (DK_GS == 4) {
 				if (k < 2) dk_pick<K>(N[lane], R[lane], k, ra[lane], rb[lane]);
 				else { ra[lane] = k == 2 ? K2a[lane] : K3a[lane]; rb[lane] = k == 2 ? K2b[lane] : K3b[lane]; }
@@ -99,13 +137,13 @@ static void emu_walk_group(const FrameCtx &f, const uint8_t *tc0tab, int q)
 			if (p[lane].flush >= 0) dk_flush<K>(W, f, R[lane], p[lane].flush, y);
 			if (p[lane].top_flush >= 0) dk_top_flush<K>(W, f, lane, p[lane].top_flush, y0);
 			if (p[lane].top_fetch >= 0) dk_top_fetch<K>(f, lane, p[lane].top_fetch, y0, tt[lane]);
-			if (p[lane].prm_fetch) dk_fetch_prm(f, R[lane], p[lane].x + 3, y, np[par][lane]);
+			if (p[lane].prm_fetch) dk_fetch_prm<K>(f, R[lane], p[lane].x + 1, y, np[par ^ 1][lane]);
 			if (k == (DK_GS == 4 ? 2 : 0) && p[lane].grp_fetch) dk_fetch4<K>(dk_src<K>(f, R[lane], y), R[lane], p[lane].x + 2, f.wm, N[lane]);
 		}
 		static DkPrm P[64][2];
 		bool any_edge = !E264_DBK_ZEROSKIP; // (the kernel's wave-uniform test: no macroblock of the wave has an edge to filter -> samples only move into the strips)
 		for (int lane = 0; lane < 64; lane++)
-			if (p[lane].act && dk_any_bs(W.prm[R[lane].g][p[lane].x & 1]) != 0) any_edge = true;
+			if (p[lane].act && dk_any_bs(np[par][lane]) != 0) any_edge = true;
 		if (!any_edge) {
 			for (int lane = 0; lane < 64; lane++)
 				if (p[lane].act) dk_vcopy<K>(W, R[lane], ra[lane], rb[lane], p[lane].x);
@@ -115,7 +153,7 @@ static void emu_walk_group(const FrameCtx &f, const uint8_t *tc0tab, int q)
 		g_filter_steps++;
 		for (int lane = 0; lane < 64; lane++)
 			if (p[lane].act) {
-				dk_params<K>((const uint8_t *)W.prm[R[lane].g][p[lane].x & 1], tc0tab, R[lane], P[lane]);
+				dk_params(np[par][lane], P[lane]);
 				dk_vpass<K>(W, P[lane][0], R[lane], ra[lane], rb[lane], p[lane].x);
 			}
 		for (int lane = 0; lane < 64; lane++)
@@ -129,13 +167,11 @@ extern "C" __attribute__((visibility("default"))) int e264emu_deblock_frame2(con
 	FrameCtx f;
 	if (!open_frame(f, job) || !f.dbk)
 		return -1;
-	uint8_t tc0tab[4 * 52];
-	for (int i = 0; i < 4 * 52; i++) tc0tab[i] = i < 52 ? 0 : c_tc0[i / 52 - 1][i % 52];
 	if (!split) {
-		for (int q = 0; q < (f.hm + DK_ROWS_OF(2) - 1) / DK_ROWS_OF(2); q++) emu_walk_group<2>(f, tc0tab, q);
+		for (int q = 0; q < (f.hm + DK_ROWS_OF(2) - 1) / DK_ROWS_OF(2); q++) emu_walk_group<2>(f, q);
 	} else {
-		for (int q = 0; q < (f.hm + DK_ROWS_OF(1) - 1) / DK_ROWS_OF(1); q++) emu_walk_group<1>(f, tc0tab, q); // (the two chains are independent: any order)
-		for (int q = 0; q < (f.hm + DK_ROWS_OF(0) - 1) / DK_ROWS_OF(0); q++) emu_walk_group<0>(f, tc0tab, q);
+		for (int q = 0; q < (f.hm + DK_ROWS_OF(1) - 1) / DK_ROWS_OF(1); q++) emu_walk_group<1>(f, q); // (the two chains are independent: any order)
+		for (int q = 0; q < (f.hm + DK_ROWS_OF(0) - 1) / DK_ROWS_OF(0); q++) emu_walk_group<0>(f, q);
 	}
 	return 0;
 }
@@ -144,16 +180,19 @@ extern "C" __attribute__((visibility("default"))) int e264emu_deblock_frame(cons
 	return e264emu_deblock_frame2(pkt, dpb, dbk, 0);
 }
 
-// the four edge slots of one lane: lines[2][20] (positions -4..15 of the lane's two lines) filtered in place
+// the four edge slots of one lane: lines[2][20] (positions -4..15 of the lane's two lines) filtered in place; prm: a RAW 64-byte record
 extern "C" __attribute__((visibility("default"))) void e264emu_dk_filter(uint8_t *lines, const uint8_t *prm, int lane, int dir)
 {
-	uint8_t tc0tab[4 * 52];
-	for (int i = 0; i < 4 * 52; i++) tc0tab[i] = i < 52 ? 0 : c_tc0[i / 52 - 1][i % 52];
 	const DkRole R = dk_role<2>(lane);
 	s16x2 v[20];
 	for (int k = 0; k < 20; k++) v[k] = (s16x2){(short)lines[k], (short)lines[20 + k]};
+	uint8_t pieces[E264_DBK_BYTES];
+	e264emu_dbk_pieces(prm, pieces);
+	DkRaw raw;
+	memcpy(&raw.v, pieces + (R.chroma ? 128 : 0) + R.seg * 16, 16);
+	memcpy(&raw.h, pieces + (R.chroma ? 128 : 0) + 64 + R.seg * 16, 16);
 	DkPrm P[2];
-	dk_params<2>(prm, tc0tab, R, P);
+	dk_params(raw, P);
 	dk_filter<2>(v, P[dir], R);
 	for (int k = 0; k < 20; k++) { // (the pack back to bytes, as dk_vpass / dk_hpass do it: p0 / q0 may arrive unclipped, E264_DBK_SATPACK)
 		const uint32_t b = (E264_DBK_SATPACK && dk_is_p0q0(k)) ? v_sat_pk_u8_i16(as_u(v[k])) : v_perm(0, as_u(v[k]), 0x0c0c0200u);
