@@ -177,7 +177,7 @@ struct E264Stream {
 	uint8_t *h_table[E264_MAX_SLOTS];     // same, host copy
 	void *mirror[E264_MAX_SLOTS];         // pinned host mirrors
 	size_t slot_bytes[E264_MAX_SLOTS];
-	uint8_t *d_dbk;                       // deblocking parameters, E264_DBK_BYTES per macroblock
+	uint8_t *d_dbk;                       // per-stream scratch of the kernels: E264_SCRATCH_BYTES(dbk_mbs) (deblocking parameters + the intra bitmap)
 	size_t dbk_mbs;
 	// the slot table reaches the device from a small pinned ring (asynchronous: a pageable source would make hipMemcpyAsync
 	// wait for the queue)
@@ -502,7 +502,7 @@ API void e264hip_stream_close(E264Stream *s)
 		mem_release(dev, st.d_job, sizeof(E264Job), false, 0, 0);
 		if (st.done) hipEventDestroy(st.done);
 	}
-	mem_release(dev, s->d_dbk, s->dbk_mbs * E264_DBK_BYTES, false, 0, 0);
+	mem_release(dev, s->d_dbk, E264_SCRATCH_BYTES(s->dbk_mbs), false, 0, 0);
 	if (s->dl_done) hipEventDestroy(s->dl_done);
 	for (int i = 0; i < E264Stream::NTAB; i++)
 		if (s->tab_ev[i]) hipEventDestroy(s->tab_ev[i]);
@@ -708,8 +708,8 @@ static int check_slots_of(const E264Stream *s, const E264FrameHdr *h)
 static int ensure_dbk(E264Stream *s, int n_mbs)
 {
 	if (s->dbk_mbs >= (size_t)n_mbs) return 0;
-	mem_release(s->dev, s->d_dbk, s->dbk_mbs * E264_DBK_BYTES, false, mark_lane(s->dev, s->lane), s->lane); // queued kernels may still use it (behind the lane's tail, as frame_free)
-	s->d_dbk = (uint8_t *)mem_acquire(s->dev, (size_t)n_mbs * E264_DBK_BYTES, false);
+	mem_release(s->dev, s->d_dbk, E264_SCRATCH_BYTES(s->dbk_mbs), false, mark_lane(s->dev, s->lane), s->lane); // queued kernels may still use it (behind the lane's tail, as frame_free)
+	s->d_dbk = (uint8_t *)mem_acquire(s->dev, E264_SCRATCH_BYTES(n_mbs), false);
 	s->dbk_mbs = s->d_dbk ? (size_t)n_mbs : 0;
 	return s->d_dbk ? 0 : fail(ENOMEM, "hipMalloc deblock parameters");
 }

@@ -92,6 +92,9 @@ template <int K> struct __attribute__((aligned(16))) DkWaveT { // (the members a
 #ifndef E264_DBK_SATPACK
 #define E264_DBK_SATPACK 1
 #endif
+#ifndef E264_DBK_ALSKIP
+#define E264_DBK_ALSKIP 0
+#endif
 E264_DEV bool dk_is_p0q0(int k) { return k >= 3 && k <= 16 && ((k & 3) == 3 || (k & 3) == 0); } // v[4e + 3], v[4e + 4]
 E264_DEV uint32_t dk_bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); } // v_bfi_b32
 E264_DEV s16x2 dk_dup(uint32_t x) { return as_s2(x | x << 16); }
@@ -158,6 +161,10 @@ template <int STRONG, bool LUMA>
 E264_DEV void dk_edge(s16x2 *v, s16x2 alphaE, s16x2 beta, s16x2 betal, s16x2 tc0, s16x2 small_thr, s16x2 strong)
 {
 	s16x2 &p3 = v[0], &p2 = v[1], &p1 = v[2], &p0 = v[3], &q0 = v[4], &q1 = v[5], &q2 = v[6], &q3 = v[7];
+#if E264_DBK_ALSKIP // (wave-uniform) no lane has a boundary strength here: not even the three differences are needed (encoder-made content: 89 % of all bS are 0)
+	if (!DK_ANY(as_u(alphaE)))
+		return;
+#endif
 	const s16x2 d = p0 - q0, dpq = dk_abs(d);
 	// filterSamplesFlag: all three differences below their thresholds <=> all three (difference - threshold) negative
 	const s16x2 go = ((dpq - alphaE) & (dk_abs(p1 - p0) - beta) & (dk_abs(q1 - q0) - beta)) >> 15;

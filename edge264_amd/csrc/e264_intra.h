@@ -777,15 +777,23 @@ E264_DEV void intra_kernel_body(IntraLds<NW> &S, const E264Job &job, const int t
 		return;
 	if (f.h->n_coded_mbs == f.h->n_inter_mbs)
 		return; // nothing intra in this frame (PCM is handled by the parallel kernel but counted as coded: rare)
+#if defined(E264_ABL_INTRA_STOP) && E264_ABL_INTRA_STOP == 1 // timing ablation: what the launch alone costs
+	if (f.wm > 0) return;
+#endif
 	for (int i = tid; i < f.hm; i += NW * 64)
 		progress[i] = 0;
 	for (int i = tid; i < 14 * 16 + 9 * 64; i += NW * 64)
 		i4tab[i] = i < 14 * 16 ? c_i4tab[i] : c_i8tab[i - 14 * 16];
 	E264_WG_SYNC();
+#if defined(E264_ABL_INTRA_STOP) && E264_ABL_INTRA_STOP == 2 // timing ablation: launch + tables + barrier
+	if (f.wm > 0) return;
+#endif
 	WaveLds &L = lds[wave];
 	if (lane == 0) L.ws_slice = -1;
 	wave_sync();
 	const gu8 *mbs_g = f.payload - f.h->payload_off + f.h->mbs_off; // the E264Mb array through a per-lane (global) pointer
+	const gu16 *bitmap = f.dbk ? (const gu16 *)(f.dbk + E264_BITMAP_OFF(f.wm * f.hm)) : nullptr;
+	const int ntx16 = (f.wm + 15) >> 4;
 	PH_DECL;
 #pragma unroll 1
 	for (int y = wave; y < f.hm; y += NW) {
@@ -795,6 +803,18 @@ E264_DEV void intra_kernel_body(IntraLds<NW> &S, const E264Job &job, const int t
 #pragma unroll 1
 		for (int x0 = 0; x0 < f.wm; x0 += 64) {
 			const int xl = x0 + lane;
+			// Round 6: the prediction kernel of this submission has left one bit per macroblock "intra, and this packet's" in the stream's
+			// scratch (e264_kernels.h E264_BITMAP_OFF; it reads every record anyway).  A chunk without any is left alone after one 2-byte load
+			// per lane -- on P / B pictures of encoder-made streams (1 - 4 intra macroblocks per picture) the scan of 8 160 records per picture,
+			// two 16-byte loads per lane and chunk, WAS this kernel: 0.11 ms per launch for nothing.  No scratch (host tests): every chunk is scanned.
+			if (bitmap) {
+				const bool mine = xl < f.wm && (bitmap[(size_t)y * ntx16 + (xl >> 4)] >> (xl & 15) & 1);
+				if (E264_BALLOT(mine) == 0) {
+					if (lane == 0)
+						E264_PROGRESS_STORE(&progress[y], min(x0 + 64, f.wm));
+					continue;
+				}
+			}
 			// whole records of the chunk -> LDS (2 x 16 bytes per lane); `kind` for the ballot comes out of the first dword
 			v4u h0v = {0, 0, 0, 0}, h1v = {0, 0, 0, 0};
 			uint32_t kup = E264_MB_ABSENT; // kind of the macroblock above

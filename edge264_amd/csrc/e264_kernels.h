@@ -9,9 +9,15 @@
 struct E264Job {
 	const uint8_t *packet;
 	uint8_t *const *dpb;
-	uint8_t *dbk; // per-stream scratch: E264_DBK_BYTES per macroblock (bS, alpha, beta, indexA), NULL = no deblocking
+	uint8_t *dbk; // per-stream scratch, E264_SCRATCH_BYTES(macroblocks) (NULL: no deblocking, no intra bitmap -- host tests only, the back end always has one)
 };
 #define E264_DBK_BYTES 256 // sixteen 16-byte pieces in the layout of the deblocking kernel's lanes (e264_dbkp.h)
+// The scratch of a stream: the parameter records of n_mbs macroblocks, then the INTRA BITMAP of the picture being decoded: one uint16_t per
+// (macroblock row, group of 16 macroblocks) = per row of a prediction tile, bit i = macroblock 16 g + i is Intra4x4 / 8x8 / 16x16 and this
+// packet's to reconstruct.  Written by e264_pred_kernel (which reads every record anyway), read by e264_intra_kernel in the same submission
+// to leave rows and 64-macroblock chunks without intra macroblocks alone (P / B pictures).  2 bytes per macroblock cover the worst shape (one column).
+#define E264_SCRATCH_BYTES(n_mbs) ((size_t)(n_mbs) * (E264_DBK_BYTES + 2) + 64)
+#define E264_BITMAP_OFF(n_mbs) ((size_t)(n_mbs) * E264_DBK_BYTES)
 
 // mode: bit0 reconstruction, bit1 deblocking.  waves: 4, 8 or 16 macroblock rows in flight per frame.
 // max_mbs: largest macroblock count among the jobs; max_tiles: largest e264_pred_tiles() among the jobs.  marks: NULL or 5 events (boundaries of the 4 kernels).

@@ -103,6 +103,7 @@ __attribute__((amdgpu_waves_per_eu(E264_PRED_WAVES_PER_EU, E264_PRED_WAVES_PER_E
 	pred_phase_setup(L, f, t, tid);
 	PH(0);
 	__syncthreads();
+	pred_phase_bitmap(L, f, t, tid);
 	{ // nothing more for this kernel in the tile (every tile of an I frame)? leave at once
 		const int kind = tid < PT_MBS ? (int)(L.hdr[tid][0] & 255) : 0;
 		if (!__syncthreads_or(kind == E264_MB_INTER || kind == E264_MB_PCM))
@@ -376,6 +377,9 @@ extern "C" const char *e264_kernel_build_flags(void)
 #endif
 #ifdef E264_ABL_INTRA_NOWAIT
 		" E264_ABL_INTRA_NOWAIT"
+#endif
+#ifdef E264_ABL_INTRA_STOP
+		" E264_ABL_INTRA_STOP"
 #endif
 #ifdef E264_ABL_INTRA_NOFENCE
 		" E264_ABL_INTRA_NOFENCE"

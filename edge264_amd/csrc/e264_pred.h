@@ -97,6 +97,26 @@ E264_DEV void pred_phase_setup(PredLds &L, const FrameCtx &f, const PredTile &t,
 	}
 }
 
+// The intra bitmap of the tile's rows (e264_kernels.h E264_BITMAP_OFF): one uint16_t per macroblock row of the tile, bit i = macroblock tx0 + i is
+// Intra4x4 / 8x8 / 16x16 and this packet's to reconstruct -- the very test e264_intra_kernel's scan makes on the records (e264_intra.h), made here
+// where the records already are in LDS, so that the intra kernel of this submission can leave rows and chunks without intra macroblocks alone.
+// Every tile of the picture writes its entries, the tiles of an I picture before they leave.
+static_assert(PT_W == 16, "the bitmap has one 16-bit entry per tile row");
+E264_DEV void pred_phase_bitmap(const PredLds &L, const FrameCtx &f, const PredTile &t, int tid)
+{
+	if (tid >= PT_H || !f.dbk || t.ty0 + tid >= f.hm)
+		return;
+	uint32_t bits = 0;
+#pragma unroll
+	for (int i = 0; i < PT_W; i++) {
+		const uint32_t d0 = L.hdr[tid * PT_W + i][0];
+		const int kind = (d0 >> 8 & E264_MBF_DONE) ? E264_MB_ABSENT : (int)(d0 & 255);
+		if (kind == E264_MB_I4x4 || kind == E264_MB_I8x8 || kind == E264_MB_I16x16) bits |= 1u << i;
+	}
+	gu16 *bitmap = (gu16 *)(f.dbk + E264_BITMAP_OFF(f.wm * f.hm));
+	bitmap[(size_t)(t.ty0 + tid) * ((f.wm + 15) >> 4) + (t.tx0 >> 4)] = (uint16_t)bits;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // phase 1: one thread per quadrant: partition shape of list `list`, items into the class lists; PCM samples
 // ---------------------------------------------------------------------------------------------------------------------

@@ -113,7 +113,9 @@ typedef struct E264Emitter {
 	struct E264Captured { uint8_t *data; size_t bytes; struct E264Captured *next; } *cap_head, *cap_tail;
 } E264Emitter;
 
-static __thread E264Emitter *e264_tls_emitter; /* set by the API wrappers around the reference's decode_NAL */
+/* set by the API wrappers around the reference's decode_NAL.  ONE variable for the library: the logging variant of the reference's parser is a
+ * second translation unit (front_logs.c, as in the reference's own build) whose copies of the leaf emitters must find the same decoder */
+extern __thread E264Emitter *e264_tls_emitter __attribute__((visibility("hidden")));
 
 static inline int16_t e264_sat16(int32_t v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : (int16_t)v; }
 

@@ -44,6 +44,8 @@
 #include "e264_emit.h"
 #include "edge264_hip.h"
 
+__thread E264Emitter *e264_tls_emitter __attribute__((visibility("hidden"))); /* (declared in e264_emit.h) */
+
 #define PUBLIC __attribute__((visibility("default")))
 #define ON_DEVICE(e) ((e)->sink_kind != 1) /* sinks 0 and 2 keep the frames in HBM */
 #define E264_FRONT_MAX_DEVICES 16
@@ -502,9 +504,21 @@ PUBLIC Edge264Decoder *edge264_alloc(int n_threads, Edge264LogCb log_cb, void *l
 	e->sink_kind = g_sink_kind;
 	e->user_alloc = alloc_cb; e->user_free = free_cb; e->user_arg = alloc_arg;
 	e->flush_partial = e264_flush_partial;
-	if (ON_DEVICE(e) && (hip_bind_ordinal(g_device_ordinal, (E264Device **)&e->hip_dev) || hip.stream_open(e->hip_dev, (E264Stream **)&e->hip_stream))) {
-		free(e);
-		return NULL;
+	if (ON_DEVICE(e)) {
+		/* why a decoder cannot be had is said through the caller's log callback (and on stderr with E264_FRONT_VERBOSE set): "NULL" alone
+		 * does not tell an integrator whether the back-end library, the GPU or memory is missing */
+		int r = hip_bind_ordinal(g_device_ordinal, (E264Device **)&e->hip_dev);
+		const char *what = "the HIP back end (libedge264_hip.so beside this library, or $E264_HIP_LIB) could not be loaded or no gfx950 device opened";
+		if (!r) { r = hip.stream_open(e->hip_dev, (E264Stream **)&e->hip_stream); what = "e264hip_stream_open failed"; }
+		if (r) {
+			char msg[256];
+			snprintf(msg, sizeof(msg), "edge264_alloc: %s (error %d: %s)\n", what, r, strerror(r));
+			if (log_cb) log_cb(msg, log_arg);
+			if (getenv("E264_FRONT_VERBOSE")) fputs(msg, stderr);
+			free(e);
+			errno = r;
+			return NULL;
+		}
 	}
 	Edge264Decoder *dec = e264ref_alloc(0, log_cb, log_arg, 0, e264_alloc_cb, e264_free_cb, e);
 	if (!dec) {

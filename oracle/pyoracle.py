@@ -121,7 +121,17 @@ class Edge264Lib:
         L.edge264_get_frame.argtypes = [C.c_void_p, C.POINTER(Edge264Frame), C.c_int]
         L.edge264_return_frame.argtypes = [C.c_void_p, C.c_void_p]
 
-    def decode(self, stream: bytes, max_frames: int = 1 << 30, crop: bool = True, n_threads: int = 0, allocator=None):
+    LOG_CB = C.CFUNCTYPE(C.c_int, C.c_char_p, C.c_void_p)  # edge264.h:36 Edge264LogCb
+
+    @staticmethod
+    def _log_args(log):
+        """log: None, or a list that receives every string the decoder hands to its log callback (edge264.h:36-41, 65)"""
+        if log is None:
+            return None, None
+        cb = Edge264Lib.LOG_CB(lambda s, _arg: (log.append(s.decode("latin-1")), 0)[1])
+        return cb, C.cast(cb, C.c_void_p)
+
+    def decode(self, stream: bytes, max_frames: int = 1 << 30, crop: bool = True, n_threads: int = 0, allocator=None, log=None):
         """Decodes an Annex-B byte stream; returns (list of (Y,Cb,Cr) arrays, list of NAL return codes).
         allocator: a CallerAllocator (edge264.h:42-43 alloc_cb / free_cb pair)."""
         import errno
@@ -130,7 +140,8 @@ class Edge264Lib:
         base = buf.ctypes.data
         end = base + len(stream)
         a = allocator.args() if allocator else (None, None, None)
-        dec = C.c_void_p(L.edge264_alloc(n_threads, None, None, 0, *a))
+        keep, log_cb = self._log_args(log)
+        dec = C.c_void_p(L.edge264_alloc(n_threads, log_cb, None, 0, *a))
         if not dec:
             raise MemoryError("edge264_alloc")
         frames, codes = [], []
@@ -253,7 +264,7 @@ class HipFront(Edge264Lib):
         L.e264front_slot_of.argtypes = [C.c_void_p, C.c_void_p]
         L.e264front_slot_of.restype = C.c_int
 
-    def decode_capture(self, stream: bytes, oracle: "Oracle", n_threads: int = 0, allocator=None):
+    def decode_capture(self, stream: bytes, oracle: "Oracle", n_threads: int = 0, allocator=None, log=None):
         """Returns (frames, codes, packets): frames as the HIP sink would return them, with the
         oracle standing in for the GPU (same slot bookkeeping as edge264_get_frame in the shim)."""
         import errno
@@ -264,7 +275,8 @@ class HipFront(Edge264Lib):
         base = buf.ctypes.data
         end = base + len(stream)
         a = allocator.args() if allocator else (None, None, None)
-        dec = C.c_void_p(L.edge264_alloc(n_threads, None, None, 0, *a))
+        keep, log_cb = self._log_args(log)
+        dec = C.c_void_p(L.edge264_alloc(n_threads, log_cb, None, 0, *a))
         if not dec:
             raise MemoryError("edge264_alloc")
         frames, codes, packets = [], [], []

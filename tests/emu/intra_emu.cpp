@@ -96,9 +96,16 @@ void fibre_main(int lane)
 } // namespace
 
 // e264_intra_kernel<1> on one picture: every intra macroblock of the packet is reconstructed into dpb[dst_slot]
+// scratch: NULL (every chunk of every row is scanned), or the stream's scratch with the intra bitmap e264_pred_kernel has left there
+// (tests/emu/pred_emu.cpp e264emu_pred_frame2 on the same packet): rows and chunks without a bit are left alone
+extern "C" __attribute__((visibility("default"))) int e264emu_intra_frame2(const uint8_t *pkt, uint8_t *const *dpb, uint8_t *scratch);
 extern "C" __attribute__((visibility("default"))) int e264emu_intra_frame(const uint8_t *pkt, uint8_t *const *dpb)
 {
-	const E264Job job = {pkt, dpb, nullptr};
+	return e264emu_intra_frame2(pkt, dpb, nullptr);
+}
+extern "C" __attribute__((visibility("default"))) int e264emu_intra_frame2(const uint8_t *pkt, uint8_t *const *dpb, uint8_t *scratch)
+{
+	const E264Job job = {pkt, dpb, scratch};
 	FrameCtx f;
 	if (!open_frame(f, job))
 		return -1;

@@ -7,7 +7,7 @@
 #include "../../edge264_amd/csrc/e264_pred.h"
 #include "../../edge264_amd/csrc/e264_dbkp.h"
 
-// dbk: NULL, or room for 64 bytes per macroblock: the kernel then also computes the deblocking parameters of its tiles
+// dbk: NULL, or the stream's scratch (E264_SCRATCH_BYTES(macroblocks)): the kernel then also writes the intra bitmap of its tiles
 extern "C" __attribute__((visibility("default"))) int e264emu_pred_frame2(const uint8_t *pkt, uint8_t *const *dpb, uint8_t *dbk)
 {
 	E264Job job = {pkt, dpb, dbk};
@@ -20,6 +20,7 @@ extern "C" __attribute__((visibility("default"))) int e264emu_pred_frame2(const 
 		PredTile t = {(ti % ntx) * PT_W, (ti / ntx) * PT_H};
 		memset(&L, 0xA5, sizeof(L)); // LDS is not zeroed on the device either
 		for (int tid = 0; tid < PT_NT; tid++) pred_phase_setup(L, f, t, tid);
+		for (int tid = 0; tid < PT_NT; tid++) pred_phase_bitmap(L, f, t, tid);
 		for (int list = 0; list < 2; list++) {
 			if (list == 1 && !L.any_l1) break;
 			if (list == 1) for (int tid = 0; tid < PT_NT; tid++) pred_phase_reset(L, tid);

@@ -41,6 +41,23 @@ def test_hip_sink_matches_reference(name, front):
     assert md5s(frames) == sums[name]["md5"]
 
 
+API = os.path.join(HERE, "golden", "api")
+API_NAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(API, "*.264")))
+
+
+@pytest.mark.parametrize("name", API_NAMES)
+def test_reference_api_fixtures_on_the_hip_sink(name, front):
+    """The reference's own API-behaviour fixtures (/root/reference/tests/*.264, copied as data into tests/golden/api: parameter sets missing or
+    changing, frame finishing, POC order, nal_ref_idc 0, supported / unsupported NAL types, zero cropping) through the product on the GPU: the same
+    return code for every edge264_decode_NAL call and the same frames as the unmodified reference (tests/golden/make_api_md5.py)."""
+    with open(os.path.join(API, "api_md5.json")) as f:
+        sums = json.load(f)
+    data = open(os.path.join(API, name + ".264"), "rb").read()
+    frames, codes = front.decode(data)
+    assert codes == sums[name]["nal_codes"]
+    assert md5s(frames) == sums[name]["md5"]
+
+
 def test_two_decoders_interleaved(front):
     """Two decoder instances share the device object (one E264Stream each)."""
     import ctypes as C

@@ -20,11 +20,20 @@ def emu():
     d = os.path.join(HERE, "emu")
     subprocess.run(["make", "-C", d], check=True, stdout=subprocess.DEVNULL)
     lib = C.CDLL(os.path.join(d, "libe264_pred_emu.so"))
-    lib.e264emu_intra_frame = C.CDLL(os.path.join(d, "libe264_intra_emu.so")).e264emu_intra_frame
+    ilib = C.CDLL(os.path.join(d, "libe264_intra_emu.so"))
+    lib.e264emu_intra_frame = ilib.e264emu_intra_frame
+    lib.e264emu_intra_frame2 = ilib.e264emu_intra_frame2
     for fn in (lib.e264emu_pred_frame, lib.e264emu_intra_frame):
         fn.argtypes = [C.c_char_p, C.c_void_p]
         fn.restype = C.c_int
+    for fn in (lib.e264emu_pred_frame2, lib.e264emu_intra_frame2):
+        fn.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p]
+        fn.restype = C.c_int
     return lib
+
+
+def scratch_bytes(n_mbs):
+    return n_mbs * 258 + 64  # edge264_amd/csrc/e264_kernels.h E264_SCRATCH_BYTES
 
 
 CASES = {
@@ -36,6 +45,7 @@ CASES = {
     "i_big_levels": dict(gop="I", w=6, h=4, kw=dict(big_levels=True)),
     "p_with_intra": dict(gop="IPB", w=9, h=7, kw=dict(intra_in_inter=0.4, pcm_prob=0.1, slices_per_frame=3)),
     "i_slices_qp": dict(gop="II", w=8, h=6, kw=dict(slices_per_frame=4, scaling=True)),
+    "p_sparse_intra_wide": dict(gop="IPP", w=70, h=5, kw=dict(intra_in_inter=0.01)),  # rows and 64-macroblock chunks without any intra macroblock
     "i_8x8_qp_around_36": dict(gop="II", w=8, h=5, kw=dict(i_kinds=(P.MB_I8x8,), t8x8=True, scaling=True, qp_base=37)),  # both forms of the 8x8 dequantisation
 }
 
@@ -57,10 +67,14 @@ def _synth(w, h, seed, kw):
     return g
 
 
+@pytest.mark.parametrize("bitmap", [False, True], ids=["scan", "bitmap"])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_intra_emu_vs_oracle(emu, name):
+def test_intra_emu_vs_oracle(emu, name, bitmap):
+    """bitmap: the prediction kernel leaves the intra bitmap in the stream's scratch and the intra kernel skips by it (what a submission does on
+    the device); scan: no scratch, every chunk of every row is scanned (the fallback)"""
     c = CASES[name]
     w, h = c["w"], c["h"]
+    scratch = np.full(scratch_bytes(w * h), 0xFF if bitmap else 0, np.uint8)  # (stale ones: the kernel must overwrite every entry it reads)
     for seed in (1, 2, 3):
         g = _synth(w, h, seed * 131 + len(name), c["kw"])
         nb = P.frame_bytes(w, h)
@@ -72,8 +86,19 @@ def test_intra_emu_vs_oracle(emu, name):
             d = int(P.Packet(pkt).hdr["dst_slot"])
             mine = [None if b is None else b.copy() for b in dpb]
             orc.decode_frame(pkt, dpb, 1)  # reconstruction only: prediction kernel + intra kernel
-            assert emu.e264emu_pred_frame(pkt, _dpb_array(mine)) == 0
-            assert emu.e264emu_intra_frame(pkt, _dpb_array(mine)) == 0
+            if bitmap:
+                scratch[w * h * 256:] = 0x00 if ft == "I" else 0xFF  # stale entries of the picture before, both ways
+                assert emu.e264emu_pred_frame2(pkt, _dpb_array(mine), scratch.ctypes.data) == 0
+                assert emu.e264emu_intra_frame2(pkt, _dpb_array(mine), scratch.ctypes.data) == 0
+                ntx = (w + 15) // 16
+                bm = scratch[w * h * 256:w * h * 256 + 2 * ntx * h].view("<u2").reshape(h, ntx)
+                kinds = P.Packet(pkt).mbs["kind"].reshape(h, w)
+                want = np.isin(kinds, (P.MB_I4x4, P.MB_I8x8, P.MB_I16x16))
+                got_bits = np.array([[bm[y, x >> 4] >> (x & 15) & 1 for x in range(w)] for y in range(h)], bool)
+                assert np.array_equal(got_bits, want), f"{name} frame {ft}: intra bitmap differs"
+            else:
+                assert emu.e264emu_pred_frame(pkt, _dpb_array(mine)) == 0
+                assert emu.e264emu_intra_frame(pkt, _dpb_array(mine)) == 0
             sY = w * 16
             got_y = mine[d][:sY * h * 16].reshape(h * 16, sY)
             exp_y = dpb[d][:sY * h * 16].reshape(h * 16, sY)

@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--wide", type=int, default=400)
     ap.add_argument("--damage", type=int, default=300)
     ap.add_argument("--nat", type=int, default=100)
+    ap.add_argument("--zip", default=None, help="write the corpus as a zip archive instead (index.json + NNNNN.264, deflated): the committed sample "
+                                                "tests/golden/corpus/gpu_corpus_sample.zip that tests/test_gpu_corpus.py runs on the device")
+    ap.add_argument("--seed-shift", type=int, default=0, help="added to every seed range: a sample the sweeps and earlier corpora have not seen")
     args = ap.parse_args()
     g = ms.load_gen()
     ref = ref_decoder()
@@ -69,7 +72,7 @@ def main():
         return True
     for wide, n in ((False, args.narrow), (True, args.wide)):
         ss.WIDE = wide
-        for seed in range(700000, 700000 + n):
+        for seed in range(700000 + args.seed_shift, 700000 + args.seed_shift + n):
             W, H, frames, o = ss.options(seed)
             if o["cabac"]:
                 o = dict(o, tables=tables)
@@ -81,7 +84,7 @@ def main():
     ss.WIDE = False
     # damaged streams: only cases the reference survives (each in a child process in the sweep; here: the ones the sweep has already run, seeds 0:..)
     done = 0
-    for seed in range(0, 10 * args.damage):
+    for seed in range(args.seed_shift, args.seed_shift + 10 * args.damage):
         if done >= args.damage:
             break
         W, H, frames, o = ss.options(seed)
@@ -103,7 +106,7 @@ def main():
         dmg = b"".join(nals[:k] + [bad] + nals[k:])
         if add("damaged", seed, dmg, guarded=True):
             done += 1
-    for seed in range(900000, 900000 + args.nat):
+    for seed in range(900000 + args.seed_shift, 900000 + args.seed_shift + args.nat):
         frames, o = ns.options(seed)
         if o["cabac"]:
             o = dict(o, tables=tables)
@@ -111,8 +114,17 @@ def main():
             data = ne.NatEncoder(g, "n", frames, **o).build(ref)
         add("nat", seed, data)
     out = os.path.join(ROOT, "tools", "_gpu_corpus.bin")
-    with open(out, "wb") as f:
-        pickle.dump(corpus, f)
+    if args.zip:
+        import zipfile
+        out = args.zip
+        os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
+        with zipfile.ZipFile(out, "w", zipfile.ZIP_DEFLATED, compresslevel=9) as z:
+            z.writestr("index.json", json.dumps([dict(kind=c["kind"], seed=c["seed"], codes=c["codes"], md5=c["md5"], file=f"{i:05d}.264") for i, c in enumerate(corpus)]))
+            for i, c in enumerate(corpus):
+                z.writestr(f"{i:05d}.264", c["data"])
+    else:
+        with open(out, "wb") as f:
+            pickle.dump(corpus, f)
     kinds = {}
     for c in corpus:
         kinds[c["kind"]] = kinds.get(c["kind"], 0) + 1
