@@ -71,6 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--variants", type=int, default=int(os.environ.get("E264_VARIANTS", 4)), help="distinct synthetic GOPs (seeds 1234, 1235, ...): stream k decodes GOP k mod V, "
                     "so that the timed pictures and the verification are not copies of one GOP")
     ap.add_argument("--no-system", action="store_true", help="skip the system leg (e264_multi: parser + emitters + GPU on the container's cores, N=1)")
+    ap.add_argument("--no-single-stream", action="store_true", help="skip the single-stream latency leg (N=1)")
     ap.add_argument("--no-same-input", action="store_true", help="skip the same-input leg (the 1080p bitstream fixtures on the GPU next to the CPU reference, N=1)")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("E264_LANES", 1)), help="compute lanes (HIP queues): the streams are split into this many "
                     "groups whose submissions overlap on the GPU")
@@ -150,6 +151,126 @@ def newest_traffic(dom, streams, gop, W, H, lanes, live_ms):
     else:
         src["stale"] = None  # the file does not say which build it was taken on
     return int(best[2]["kernels"][dom]["hbm_bytes_per_launch"]), src
+
+
+VALU_RATE_G = 0.54   # G wave-instructions/s per SIMD of the packed / VOP3 / byte-permute instructions the kernels are made of (tools/calib/valu_rate, profiles/r05_valu_rate.txt: 0.50 - 0.57; plain VOP2 adds / ands / shifts: 0.9)
+N_SIMDS = 1024       # 256 CUs x 4
+
+
+def newest_sq_mix(streams, gop, W, H):
+    """per-kernel SQ counters per launch from the NEWEST profiles/r*_sq_mix.json of this configuration (tools/pmc_summary.py --sq-json; counters
+    cannot be collected inside a timed run)"""
+    import glob
+    import re
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_sq_mix.json")):
+        m = re.match(r"r(\d+)([a-z]?)_", os.path.basename(path))
+        try:
+            with open(path) as f:
+                tj = json.load(f)
+        except (OSError, ValueError):
+            continue
+        cfg = tj.get("config", {})
+        if (cfg.get("streams"), cfg.get("gop"), cfg.get("width_mbs"), cfg.get("height_mbs")) != (streams, gop, W, H):
+            continue
+        key = (int(m.group(1)) if m else -1, m.group(2) if m else "", os.path.getmtime(path))
+        if best is None or key > best[0]:
+            best = (key, path, tj)
+    return (None, None) if best is None else (os.path.relpath(best[1], ROOT), best[2])
+
+
+def issue_roofline(kern, sq_path, sq, samples_per_launch):
+    """The roof the kernels are under: none of them is bound by bytes.  Per kernel, from the SQ counters of the newest
+    canned PMC pass: VALU wave-instructions per launch, the share of the chip's VALU issue slots they take at the LIVE kernel time when
+    priced at the packed / VOP3 rate (an upper bound: VOP2 instructions issue 1.7 x faster), and lane-level VALU instructions per picture sample."""
+    if sq is None:
+        return None
+    out = {"source": sq_path, "rate_G_wave_instr_per_s_per_simd": VALU_RATE_G, "simds": N_SIMDS,
+           "how": "valu_issue_frac = SQ_INSTS_VALU per launch / (simds x live seconds per launch x rate); counters canned (separate rocprofv3 --pmc pass), time live",
+           "kernels": {}}
+    for name, k in kern.items():
+        c = sq["kernels"].get(name) or (sq["kernels"].get("e264_deblock2_kernel") if name == "e264_deblock_kernel" else None)
+        if not c or "SQ_INSTS_VALU" not in c or k["ms_per_launch"] <= 0:
+            continue
+        valu = c["SQ_INSTS_VALU"]
+        at = (sq.get("kernel_ms_per_launch") or {}).get(name)
+        out["kernels"][name] = {"valu_wave_instr_per_launch": int(valu), "salu_wave_instr_per_launch": int(c.get("SQ_INSTS_SALU", 0)),
+                                "lds_wave_instr_per_launch": int(c.get("SQ_INSTS_LDS", 0)), "vmem_wave_instr_per_launch": int(c.get("SQ_INSTS_VMEM", 0)),
+                                "valu_issue_frac": round(valu / (N_SIMDS * k["ms_per_launch"] * 1e-3 * VALU_RATE_G * 1e9), 3),
+                                "lane_instr_per_sample": round(valu * 64 / samples_per_launch, 2),
+                                "counters_taken_at_ms": at, "stale": (abs(k["ms_per_launch"] / at - 1.0) > 0.10) if at else None}
+    return out
+
+
+def link_rate_gbs():
+    """H2D rate of this box's link from page-locked memory (one 256-MiB copy, best of 4): what pcie_inclusive is a fraction of"""
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return None
+        n = 256 << 20
+        h = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+        d = torch.empty(n, dtype=torch.uint8, device="cuda")
+        best = 0.0
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            d.copy_(h, non_blocking=True)
+            b.record()
+            torch.cuda.synchronize()
+            best = max(best, n / (a.elapsed_time(b) * 1e-3) / 1e9)
+        del h, d
+        return round(best, 2)
+    except Exception:  # noqa: BLE001 -- informational
+        return None
+
+
+def single_stream_leg(dev, backend, gop_packets, W, H, n_slots, frame_nb, fill_value):
+    """ONE 1080p stream (VERDICT r5 item 7 of "missing": what an integrator asks first).  (a) resident: the bench GOP's packets in HBM, one picture per
+    submission, the host waits for every picture; (b) the edge264.h API: nat1080_ipp30.264 through edge264_decode_NAL / edge264_get_frame of
+    libedge264_hipfront.so (parser + emitters + H2D + 4 kernels + download to the host mirror), the second of two runs."""
+    out = {}
+    st = backend.Stream(dev, W, H)
+    st.frame_bytes = frame_nb
+    for i in range(n_slots):
+        st.alloc(i)
+        st.fill(i, fill_value)
+    dp = [dev.upload_packet(p) for p in gop_packets]
+    bs = [dev.make_batch([st], [q]) for q in dp]
+    for b in bs:
+        dev.submit_prepared(b, backend.RUN_ALL)
+    dev.sync()
+    per = []
+    for _ in range(3):
+        for b in bs:
+            t0 = time.perf_counter()
+            dev.submit_prepared(b, backend.RUN_ALL)
+            dev.sync()
+            per.append(time.perf_counter() - t0)
+    n = len(bs)
+    ms = [1e3 * float(np.mean(per[f::n])) for f in range(n)]
+    out["resident"] = {"ms_per_picture": round(float(np.mean(ms)), 3), "ms_first_picture_of_gop": round(ms[0], 3), "ms_other_pictures": round(float(np.mean(ms[1:])), 3) if n > 1 else None,
+                       "pictures_per_s": round(1e3 / float(np.mean(ms)), 1),
+                       "what": "one stream, packets resident, one submission (4 launches) per picture, host synchronises after each: two of the four kernels run ONE workgroup per picture"}
+    for b in bs:
+        dev.free_batch(b)
+    for q in dp:
+        q.free()
+    st.close()
+    try:
+        from edge264_amd import front
+        path = os.path.join(ROOT, "tests", "golden", "streams", "nat1080_ipp30.264")
+        data = open(path, "rb").read()
+        front.decode_timed(data)
+        r = front.decode_timed(data)
+        out["api"] = {"file": os.path.basename(path), "pictures": r["pictures"], "ms_per_picture": round(1e3 * r["seconds"] / max(r["pictures"], 1), 3),
+                      "pictures_per_s": round(r["pictures"] / r["seconds"], 1), "first_picture_ms": round(1e3 * r["first_picture_seconds"], 3) if r["first_picture_seconds"] else None,
+                      "edge264_alloc_ms": round(1e3 * r["alloc_seconds"], 3),
+                      "what": "edge264_alloc / edge264_decode_NAL / edge264_get_frame on the HIP sink, one decoder, one thread: parser + emitters + validation + H2D + 4 kernels + "
+                              "download of every output frame to the host; second run of the file in this process"}
+    except Exception as e:  # noqa: BLE001
+        out["api"] = {"unavailable": f"{type(e).__name__}: {e}"}
+    return out
 
 
 def same_input_leg(dev, backend, n_streams, cpu):
@@ -650,6 +771,21 @@ def main() -> int:
                                            "their producer -> gathered into the batch's staging buffer -> one H2D per batch -> 4 kernels"}
         for pp in pins:
             dev.pinned_free(pp)
+        link = link_rate_gbs()
+        pcie["link_h2d_GBps_measured"] = link
+        if link:
+            for e in (pcie, pcie["pinned_in_place"]):
+                gbs = e["value"] * pcie["packet_MB_per_frame"] * 1e6 / 1e9
+                e["packet_GBps"] = round(gbs, 2)
+                e["link_frac"] = round(gbs / link, 3)
+            pcie["link_note"] = "link_frac = packet bytes per second / the H2D rate of one 256-MiB copy from page-locked memory on this box: near 1 = this leg is bound by the link, not by the GPU"
+
+    single = None
+    if rank == 0 and world == 1 and not args.no_single_stream and not stub and not args.capture:
+        try:
+            single = single_stream_leg(dev, backend, vpk[0], W, H, n_slots, frame_nb, fill_value)
+        except Exception as e:  # noqa: BLE001
+            single = {"unavailable": f"{type(e).__name__}: {e}"}
 
     rc = 0
     if rank == 0:
@@ -671,6 +807,9 @@ def main() -> int:
         tot_ms = sum(kms) if lanes == 1 and not side_queue else elapsed * 1e3 / (args.steps * len(packets))
         e2e_g = (e2e_samples + e2e_cmds) / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
         traffic, traffic_src = newest_traffic(dom, args.streams, args.gop, W, H, lanes, kms)
+        sq_path, sq = newest_sq_mix(args.streams, args.gop, W, H)
+        issue = issue_roofline(kern, sq_path, sq, float(np.mean([m["F"] for m in models])) * my_streams / lanes)
+        dom_issue = (issue or {}).get("kernels", {}).get(dom, {}).get("valu_issue_frac")
         out = {
             "metric": "1080p frames/s/GPU (bit-exact YUV) + achieved HBM GB/s vs 8 TB/s peak",
             "value": round(value, 1), "unit": "frames/s",
@@ -689,8 +828,11 @@ def main() -> int:
                        "streams_per_gpu": my_streams, "total_streams": frames_per_step // len(packets), "frames_per_step": frames_per_step,
                        "waves_per_frame": args.waves, "compute_lanes": lanes, "parallelism": f"stream-parallel x{world}, no collectives",
                        "synth_overrides": synth_overrides or None},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["gbps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `bound`: what the numbers say.  The contract's achieved / peak / frac stay the HBM figures (algorithmic bytes over the live kernel time
+            # against 8 TB/s); the roof the kernels ARE under is VALU issue: `valu_issue` prices every kernel against it
+            "roofline": {"bound": "valu-issue" if (dom_issue or 0) > kern[dom]["frac"] else "hbm", "kernel": dom, "achieved": kern[dom]["gbps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kern[dom]["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                         "valu_issue_frac": dom_issue, "valu_issue": issue,
                          "launches": launches, "kernels": kern,
                          "end_to_end": {"ms_per_submission": round(tot_ms, 4), "sample_bytes": int(e2e_samples), "command_bytes": int(e2e_cmds),
                                         "gbps": round(e2e_g, 1), "frac": round(e2e_g / HBM_PEAK_GBS, 4)}},
@@ -700,6 +842,7 @@ def main() -> int:
             "pcie_inclusive": pcie,
             "same_input": same,
             "system": system,
+            "single_stream": single,
             "gpu_event_ms_per_step": round(ev_ms / args.steps, 3),
             "build_flags": backend.build_flags() if hasattr(backend, "build_flags") else None,
             "per_rank": {"frames_per_s": [round(r, 1) for r in rates], "min": round(min(rates), 1), "max": round(max(rates), 1),

@@ -323,7 +323,11 @@ E264_DEV void dbkp_phase_store(const DbkpLds &L, const FrameCtx &f, int a0, int 
 {
 	const int n_mbs = f.wm * f.hm;
 #pragma unroll
+#ifdef E264_ABL_DBKP_STORE1 // timing ablation: a quarter of every record is written (wrong parameters): what the 256-byte records cost in stores
+	for (int k = 0; k < 1; k++) {
+#else
 	for (int k = 0; k < E264_DBK_BYTES / 64; k++) { // 64 records x 16 pieces of 16 bytes, consecutive threads consecutive pieces
+#endif
 		const int idx = k * DP_NT + tid, i = idx >> 4, part = idx & 15;
 		if (a0 + i < n_mbs)
 			*(gv4u *)(f.dbk + (size_t)(a0 + i) * E264_DBK_BYTES + part * 16) = *(const v4u *)&L.pieces[i][part * 4];

@@ -759,8 +759,29 @@ struct __attribute__((aligned(16))) IntraLds {
 	uint32_t hdrs[NW][64 * 8];           // E264Mb records of the 64 macroblocks being scanned, per wave
 	WaveLds w[NW];
 	int progress[E264_MAX_ROWS];         // macroblocks finished per row
+	int next_row;                        // the next macroblock row nobody has taken yet (rows beyond the first NW are handed out as waves finish theirs)
 	uint32_t i4tab[14 * 16 + 9 * 64];    // c_i4tab, then c_i8tab: read with a per-lane index
 };
+
+// Which row a wave takes after row y.  Round 6: FIRST COME, FIRST SERVED (an LDS counter) instead of y + NW.  On an I picture every row costs the same
+// and nothing changes; on a P / B picture the intra macroblocks are unevenly spread over the rows (bench GOP: 6 +- 2.4 per row), a wave with a static
+// share of 4 - 5 rows is 30 % over the mean often enough that the picture waits for it.  Rows are still STARTED in increasing order (the counter), so
+// the row a wave may have to wait for (y - 1) has always been taken by somebody: no deadlock.
+#ifndef E264_INTRA_DYNROWS
+#define E264_INTRA_DYNROWS 1
+#endif
+#ifndef E264_ROW_TAKE
+#define E264_ROW_TAKE(p) __hip_atomic_fetch_add((p), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#endif
+template <int NW>
+E264_DEV int intra_next_row(int *next_row, int y, int lane)
+{
+	if (!E264_INTRA_DYNROWS || NW == 1)
+		return y + NW;
+	int ny = 0;
+	if (lane == 0) ny = E264_ROW_TAKE(next_row);
+	return E264_FIRST(ny);
+}
 
 // what thread tid of the picture's workgroup does
 template <int NW>
@@ -782,6 +803,7 @@ E264_DEV void intra_kernel_body(IntraLds<NW> &S, const E264Job &job, const int t
 #endif
 	for (int i = tid; i < f.hm; i += NW * 64)
 		progress[i] = 0;
+	if (tid == 0) S.next_row = NW;
 	for (int i = tid; i < 14 * 16 + 9 * 64; i += NW * 64)
 		i4tab[i] = i < 14 * 16 ? c_i4tab[i] : c_i8tab[i - 14 * 16];
 	E264_WG_SYNC();
@@ -796,7 +818,7 @@ E264_DEV void intra_kernel_body(IntraLds<NW> &S, const E264Job &job, const int t
 	const int ntx16 = (f.wm + 15) >> 4;
 	PH_DECL;
 #pragma unroll 1
-	for (int y = wave; y < f.hm; y += NW) {
+	for (int y = wave; y < f.hm; y = intra_next_row<NW>(&S.next_row, y, lane)) {
 		bool row_start = true; // (uniform) the row's first dependent macroblock has not started yet: see E264_INTRA_SLACK
 		// the row is scanned 64 macroblocks at a time (one vector load + ballot) instead of one scalar load per
 		// macroblock: in P/B frames, where few macroblocks are intra, the scan WAS the kernel's run time

@@ -160,7 +160,9 @@ __global__ __launch_bounds__(DP_NT) void e264_dbkparam2_kernel(const E264Job *jo
 	__syncthreads();
 	dbkp_phase_compute(L, f, a0, tid);
 	__syncthreads();
+#ifndef E264_ABL_DBKP_NOPIECES // timing ablation: the pieces are not built (whatever the LDS holds is written)
 	dbkp_phase_pieces(L, tid);
+#endif
 	__syncthreads();
 	dbkp_phase_store(L, f, a0, tid);
 }
@@ -380,6 +382,12 @@ extern "C" const char *e264_kernel_build_flags(void)
 #endif
 #ifdef E264_ABL_INTRA_STOP
 		" E264_ABL_INTRA_STOP"
+#endif
+#ifdef E264_ABL_DBKP_STORE1
+		" E264_ABL_DBKP_STORE1"
+#endif
+#ifdef E264_ABL_DBKP_NOPIECES
+		" E264_ABL_DBKP_NOPIECES"
 #endif
 #ifdef E264_ABL_INTRA_NOFENCE
 		" E264_ABL_INTRA_NOFENCE"

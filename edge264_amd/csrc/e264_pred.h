@@ -63,6 +63,7 @@ struct __attribute__((aligned(16))) PredLds {
 	int rcnt[2];                        // residual items: 4x4 blocks, 8x8 blocks
 	uint32_t staged[PT_MBS / 32];       // macroblocks this kernel writes (inter, PCM)
 	int any_l1;                         // some quadrant of the tile uses list 1
+	int n_inter, n_uni;                 // inter macroblocks of the tile; of which one partition per list (16x16, P_Skip, B_Skip / direct with one vector)
 	generic_u8p dpb[E264_MAX_SLOTS];
 #ifdef E264_PRED_LDS_PAD // measuring aid: what the kernel does at a lower occupancy (bytes of LDS nobody uses)
 	uint8_t pad[E264_PRED_LDS_PAD];
@@ -86,7 +87,7 @@ E264_DEV void pred_phase_setup(PredLds &L, const FrameCtx &f, const PredTile &t,
 	if (tid < 6) L.cnt[tid] = 0;
 	if (tid < 2) L.rcnt[tid] = 0;
 	if (tid < PT_MBS / 32) L.staged[tid] = 0;
-	if (tid == 0) L.any_l1 = 0;
+	if (tid == 0) { L.any_l1 = 0; L.n_inter = 0; L.n_uni = 0; }
 	if (tid < E264_MAX_SLOTS) L.dpb[tid] = f.dpb[tid];
 	const gu32 *mbs_g = (const gu32 *)(f.payload - f.h->payload_off + f.h->mbs_off);
 	for (int i = tid; i < PT_MBS * 8; i += PT_NT) {
@@ -169,6 +170,11 @@ E264_DEV void pred_phase_classify(PredLds &L, const FrameCtx &f, const PredTile 
 	const uint32_t mot_off = L.hdr[mb][5], mot_hdr = L.hdr[mb][6]; // E264Mb.modes of an inter macroblock: its motion directory
 	if (list == 0 && (E264_MOT_UNI(mot_hdr, 1) || E264_MOT_USED(mot_hdr, 4 + q)))
 		L.any_l1 = 1;
+	if (list == 0 && q == 0) { // what the tile is made of: decides how its chroma is fetched (pred_pair_chroma)
+		lds_add(&L.n_inter, 1);
+		const bool u0 = E264_MOT_UNI(mot_hdr, 0), u1 = E264_MOT_UNI(mot_hdr, 1), any0 = (mot_hdr & 15u) != 0, any1 = (mot_hdr >> 4 & 15u) != 0;
+		if ((u0 || !any0) && (u1 || !any1) && (u0 || u1)) lds_add(&L.n_uni, 1);
+	}
 	uint32_t refword, mvq[4];
 	if (!mot_quadrant(f.motion, mot_off, mot_hdr, list, q, refword, mvq))
 		return;
@@ -698,7 +704,14 @@ E264_DEV void pred_weights(cslice_t s, int list, int refIdx, int refIdxX, Wod &w
 }
 
 // One prediction item of list `list`, class `cls`: luma + chroma of the partition -> the tile in LDS
-E264_DEV void pred_item(PredLds &L, const FrameCtx &f, const PredTile &t, int list, int cls, int desc)
+#ifndef E264_PRED_PAIR_TILES
+#define E264_PRED_PAIR_TILES 0 // 0: never pair (the default: measured, profiles/r06_ablations.txt item 6); 1: per tile, where three quarters of its inter macroblocks are one partition per list; 2: always (the -DE264_PRED_HPAIR build of round 4)
+#endif
+E264_DEV bool pred_pair_chroma(const PredLds &L)
+{
+	return E264_PRED_PAIR_TILES == 2 || (E264_PRED_PAIR_TILES == 1 && L.n_uni * 4 >= L.n_inter * 3);
+}
+E264_DEV void pred_item(PredLds &L, const FrameCtx &f, const PredTile &t, int list, int cls, int desc, const bool pair_tile)
 {
 	const int slot = PI_SLOT(desc), sub = PI_SUB(desc), shape = PI_SHAPE(desc);
 	const int mb = slot >> 2, q = slot & 3;
@@ -720,11 +733,12 @@ E264_DEV void pred_item(PredLds &L, const FrameCtx &f, const PredTile &t, int li
 	// other plane's (5 lane-rows of 12 bytes instead of 10 of 8).  Both lanes decide alike (the test is symmetric).  Bit-exact, 18 % fewer
 	// lane-rows on the bench GOP -- and 11 % SLOWER (1.266 -> 1.407 ms): a wave of one class holds paired and unpaired items side by side
 	// and runs both chroma paths; the kernel's time follows its VALU count, not its lane-rows.
-#ifdef E264_PRED_HPAIR
-	const bool hp = shape == 0 && L.refq[slot ^ 1] == rq && L.mvq[0][slot ^ 1] == mv && L.mvq[1][slot ^ 1] == mv && L.mvq[2][slot ^ 1] == mv && L.mvq[3][slot ^ 1] == mv;
-#else
-	const bool hp = false;
-#endif
+	// Round 6 (-DE264_PRED_PAIR_TILES=1, measured, NOT the default: profiles/r06_ablations.txt item 6): a choice PER TILE (pair_tile, uniform over the
+	// workgroup): on, where at least three quarters of the tile's inter macroblocks are one partition per list -- 94 % of the inter macroblocks of
+	// encoder-made content, every wave then runs the paired path alone; off on tiles of mixed partitions (the synthetic bench GOP: 55 %).  22 % fewer
+	// lane-rows on nat1080_ipp30 -- and 5 % SLOWER there (0.899 -> 0.948 ms), 2 % slower on the bench GOP where no tile pairs: the 12-byte rows cost more
+	// VALU instructions than the 8-byte ones, and this kernel's time is its instruction count.
+	const bool hp = pair_tile && shape == 0 && L.refq[slot ^ 1] == rq && L.mvq[0][slot ^ 1] == mv && L.mvq[1][slot ^ 1] == mv && L.mvq[2][slot ^ 1] == mv && L.mvq[3][slot ^ 1] == mv;
 	const int XCp = ((gx & ~15) >> 1) + (mx >> 3); // the partition's first chroma column
 	uint32_t (*cw3)[3] = (uint32_t (*)[3])&cw[0][0][0]; // the same registers as rows of three dwords
 	const gu8 *cplane = ref + f.psY + ((q & 1) ? (f.sC >> 1) : 0);
@@ -852,6 +866,7 @@ E264_DEV void pred_item(PredLds &L, const FrameCtx &f, const PredTile &t, int li
 
 E264_DEV void pred_phase_items(PredLds &L, const FrameCtx &f, const PredTile &t, int list, int tid)
 {
+	const bool pair_tile = pred_pair_chroma(L);
 	// The sorted list is walked from its END (the two-dimensional classes first): when the tile has more items than
 	// threads, the extra pass that only the first waves make -- while the others wait at the barrier -- then holds the
 	// cheapest items (integer and one-dimensional positions) instead of the most expensive ones.
@@ -867,7 +882,7 @@ E264_DEV void pred_phase_items(PredLds &L, const FrameCtx &f, const PredTile &t,
 			idx = p - k5 - k4; cls = 2;
 			if (idx >= c2) { idx -= c2; cls = 3; if (idx >= c3) { idx -= c3; cls = 1; if (idx >= c1) { idx -= c1; cls = 0; } } }
 		}
-		pred_item(L, f, t, list, cls, *pred_list_slot(L, cls, idx));
+		pred_item(L, f, t, list, cls, *pred_list_slot(L, cls, idx), pair_tile);
 	}
 #elif !defined(E264_PRED_CLASS_PACKED)
 	// Every class starts at a wave boundary: a wave runs ONE of the six flows (packed back to back, a wave of a 256-thread tile
@@ -884,7 +899,7 @@ E264_DEV void pred_phase_items(PredLds &L, const FrameCtx &f, const PredTile &t,
 			if (cls == c && idx >= k) { cls = c - 1; idx -= k; }
 		}
 		if (idx < L.cnt[cls])
-			pred_item(L, f, t, list, cls, *pred_list_slot(L, cls, idx));
+			pred_item(L, f, t, list, cls, *pred_list_slot(L, cls, idx), pair_tile);
 	}
 #else // -DE264_PRED_CLASS_PACKED: the lists back to back (round 2)
 	int n = 0;
@@ -897,7 +912,7 @@ E264_DEV void pred_phase_items(PredLds &L, const FrameCtx &f, const PredTile &t,
 			const int k = L.cnt[c];
 			if (cls == c && idx >= k) { cls = c + 1; idx -= k; }
 		}
-		pred_item(L, f, t, list, cls, *pred_list_slot(L, cls, idx));
+		pred_item(L, f, t, list, cls, *pred_list_slot(L, cls, idx), pair_tile);
 	}
 #endif
 }

@@ -90,3 +90,41 @@ def capture_packets(stream: bytes, n_threads: int = 0) -> tuple[list[bytes], int
     pump()
     L.edge264_free(C.byref(dec))
     return packets, frames, spent
+
+
+def decode_timed(stream: bytes, sink: int = 0) -> dict:
+    """ONE decoder through the edge264.h API on the device sink (edge264_decode_NAL / edge264_get_frame, frames downloaded to the host mirror as an
+    application sees them): wall time per output picture.  bench.py's single-stream latency leg -- the figure the reference's own `edge264_test -b`
+    prints for itself (/root/reference/src/edge264_test.c:522-542), per picture."""
+    L = load()
+    L.e264front_set_sink(sink)
+    buf = C.create_string_buffer(stream + b"\0" * 64, len(stream) + 64)
+    base = C.addressof(buf)
+    end = base + len(stream)
+    t_alloc = time.perf_counter()
+    dec = C.c_void_p(L.edge264_alloc(0, None, None, 0, None, None, None))
+    if not dec:
+        raise FrontError("edge264_alloc failed")
+    out = (C.c_uint8 * 512)()  # Edge264Frame
+    stamps = []
+    t0 = time.perf_counter()
+    nal = L.edge264_find_start_code(base, end, 0)
+    nal = (nal or end) + 3 if (nal or end) < end else end
+    while True:
+        nxt = L.edge264_find_start_code(nal, end, 0) if nal < end else end
+        res = L.edge264_decode_NAL(dec, nal, nxt, None, None)
+        f0 = len(stamps)
+        while L.edge264_get_frame(dec, out, 0) == 0:
+            stamps.append(time.perf_counter())
+        if res == errno.ENOBUFS:
+            if len(stamps) == f0:
+                break
+            continue
+        if res == errno.ENODATA or nal >= end:
+            break
+        nal = min(nxt + 3, end)
+    while L.edge264_get_frame(dec, out, 0) == 0:
+        stamps.append(time.perf_counter())
+    t1 = time.perf_counter()
+    L.edge264_free(C.byref(dec))
+    return {"pictures": len(stamps), "seconds": t1 - t0, "alloc_seconds": t0 - t_alloc, "first_picture_seconds": (stamps[0] - t0) if stamps else None}

@@ -65,6 +65,7 @@ static inline unsigned long long emu_ballot(bool p)
 #define E264_FENCE_RELEASE() do { } while (0)
 #define E264_PROGRESS_STORE(p, v) (*(p) = (v))
 #define E264_PROGRESS_LOAD(p) (*(p))
+#define E264_ROW_TAKE(p) ((*(p))++)                 /* (never reached: one wave takes the rows in order, intra_next_row's NW == 1 path) */
 #define PH_DECL
 #define PH(k)
 #define PH_PARAMS

@@ -317,6 +317,30 @@ def test_bench_says_when_the_synthetic_content_is_overridden():
             assert "2 distinct GOPs" in d["config"]["workload"]
 
 
+def test_bench_line_prices_the_kernels_against_valu_issue():
+    """at the configuration the canned SQ counters were taken on (256 streams, IPPPPPPP, 120 x 68) the line carries, per kernel,
+    the VALU wave-instructions per launch, their share of the chip's issue slots at the live kernel time and lane instructions per sample; `bound`
+    says what the numbers say; the HBM figures of the contract stay.  The legs that need a device (`single_stream`, `pcie_inclusive.link_frac`) are
+    keys of the line and null here (stub device)."""
+    import json
+    env = dict(os.environ, E264_BENCH_BACKEND="tests.stub_backend", OMP_NUM_THREADS="1", PYTHONPATH=ROOT)
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--variants", "1", "--no-verify", "--no-other-configs",
+           "--no-cpu-baseline", "--no-same-input", "--no-system", "--no-host-packets"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    r = d["roofline"]
+    assert r["bound"] in ("valu-issue", "hbm") and r["peak"] == 8000.0 and 0 <= r["frac"]
+    vi = r["valu_issue"]
+    assert vi["source"].startswith("profiles/r") and vi["rate_G_wave_instr_per_s_per_simd"] == 0.54 and vi["simds"] == 1024
+    assert set(vi["kernels"]) >= {"e264_pred_kernel", "e264_dbkparam2_kernel", "e264_intra_kernel"}
+    for k, e in vi["kernels"].items():
+        assert e["valu_wave_instr_per_launch"] > 1e6 and e["valu_issue_frac"] > 0 and e["lane_instr_per_sample"] > 0, k
+    assert r["valu_issue_frac"] == vi["kernels"][r["kernel"]]["valu_issue_frac"]
+    assert "single_stream" in d and d["single_stream"] is None
+
+
 def test_numa_helpers():
     from edge264_amd.sharding import bind_rank_to_gpu_socket, parse_cpulist
     assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and parse_cpulist("") == []

@@ -15,11 +15,13 @@ from oracle.pyoracle import Oracle, _dpb_array
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.fixture(scope="module")
-def emu():
+@pytest.fixture(scope="module", params=["product", "paired_tiles"])
+def emu(request):
+    """product: the default build; paired_tiles: the variant build of tests/emu (-DE264_PRED_PAIR_TILES=1: the chroma of a pair of quadrants fetched by
+    plane on tiles of one-partition macroblocks -- measured and not the default, kept in the tree, so it stays tested)"""
     d = os.path.join(HERE, "emu")
     subprocess.run(["make", "-C", d], check=True, stdout=subprocess.DEVNULL)
-    lib = C.CDLL(os.path.join(d, "libe264_pred_emu.so"))
+    lib = C.CDLL(os.path.join(d, "libe264_pred_emu.so" if request.param == "product" else "libe264_pred_emu_gs2.so"))
     lib.e264emu_pred_frame.argtypes = [C.c_char_p, C.c_void_p]
     lib.e264emu_pred_frame.restype = C.c_int
     return lib
@@ -42,6 +44,12 @@ CASES = {
     "t8x8_scaling": dict(gop="IPB", w=9, h=6, kw=dict(t8x8=True, scaling=True, residual_prob=0.9)),
     "stress_far_mvs": dict(gop="IPBP", w=4, h=3, kw=dict(stress=True, mv_range=400, residual_prob=0.8)),
     "pcm_slices": dict(gop="IPB", w=6, h=5, kw=dict(pcm_prob=0.3, intra_in_inter=0.3, slices_per_frame=3)),
+    # tiles made of one-partition macroblocks (P_Skip / 16x16, one vector per list): the chroma of a pair of quadrants fetched by PLANE (pred_pair_chroma:
+    # at least three quarters of a tile's inter macroblocks), with vectors far outside the frame, weights and both lists
+    "uni_tiles_p": dict(gop="IPP", w=20, h=6, kw=dict(p_skip=0.95, num_refs=2, residual_prob=0.2)),
+    "uni_tiles_far": dict(gop="IPBP", w=5, h=4, kw=dict(p_skip=0.95, stress=True, mv_range=400)),
+    "uni_tiles_b_weighted": dict(gop="IPBB", w=18, h=5, kw=dict(p_skip=0.95, weighted=1)),
+    "uni_tiles_b_implicit": dict(gop="IPBB", w=7, h=5, kw=dict(p_skip=0.95, weighted=2)),
     "all_residual": dict(gop="IPP", w=6, h=4, kw=dict(residual_prob=1.0, p_skip=0.0)),
     # QP walks around 36: lanes of one wave on both sides of the 8x8 dequantisation's two forms (residual.c:214-247; one flow since round 4)
     "t8x8_qp_around_36": dict(gop="IPB", w=9, h=6, kw=dict(t8x8=True, scaling=True, residual_prob=1.0, qp_base=37)),

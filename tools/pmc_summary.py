@@ -20,6 +20,7 @@ ap.add_argument("--streams", type=int)
 ap.add_argument("--gop")
 ap.add_argument("--width-mbs", type=int, default=120)
 ap.add_argument("--height-mbs", type=int, default=68)
+ap.add_argument("--sq-json", help="write the per-kernel SQ counters (wave-instructions per launch by kind, waves, wave cycles) as JSON: bench.py derives the VALU issue share from the newest profiles/r*_sq_mix.json")
 ap.add_argument("--bench-json", help="a bench.py line of the SAME build: its live kernel times are recorded in the traffic file (bench.py flags the file as stale when they drift)")
 args = ap.parse_args()
 
@@ -69,3 +70,15 @@ if args.traffic:
     with open(args.traffic, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", args.traffic)
+
+if args.sq_json:
+    out = {"config": {"streams": args.streams, "gop": args.gop, "width_mbs": args.width_mbs, "height_mbs": args.height_mbs},
+           "note": "SQ counters per launch (summed over XCDs / instances, averaged over all launches of the GOP): wave-level instruction counts by kind",
+           "kernels": {k: {n: v for n, v in c.items() if n.startswith("SQ_")} for k, c in kern.items() if any(n.startswith("SQ_") for n in c)}}
+    if args.bench_json:
+        with open(args.bench_json) as f:
+            bj = json.load(f)
+        out["kernel_ms_per_launch"] = {k: v["ms_per_launch"] for k, v in bj["roofline"]["kernels"].items()}
+    with open(args.sq_json, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", args.sq_json)
