@@ -46,7 +46,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 KERNELS = ["e264_dbkparam2_kernel", "e264_pred_kernel", "e264_intra_kernel", "e264_deblock_kernel"]
 SIDE_QUEUE_DEFAULT = 0
-DBK_BYTES = 256  # deblocking parameters per macroblock (edge264_amd/csrc/e264_kernels.h)
+DBK_BYTES = 144  # deblocking parameters per macroblock (edge264_amd/csrc/e264_kernels.h)
 
 
 def parse_args(argv=None):

@@ -222,28 +222,41 @@ struct DkPrm { s16x2 al[4], be[4], tc[4]; s16x2 thr, strong0, strong2; }; // al:
 // Luma lanes: slot e = edge e of the macroblock.  Chroma lanes: slot 0 = Cb macroblock edge, 1 = Cb inner edge, 2 = Cr
 // macroblock edge, 3 = Cr inner edge.
 // Round 6: the parameter kernel delivers them per lane (e264_dbkp.h: one 16-byte piece per plane kind, direction and segment): a lane
-// fetches the two pieces of its segment (V and H direction) straight into registers one step ahead and spreads each byte into a packed
-// pair with one v_perm -- 26 byte permutes and 4 bit-field extracts where rounds 2 - 5 spent ~26 LDS reads, a dependent table look-up and
-// ~160 VALU instructions per step.
-struct DkRaw { v4u v, h; }; // the lane's pieces of one macroblock: vertical edges (direction 0), horizontal edges (direction 1)
+// fetches the two pieces of its segment (V and H direction) and its plane's 8 bytes of beta straight into registers one step ahead and spreads each
+// byte into a packed pair with one v_perm -- ~24 byte permutes and 4 bit-field extracts where rounds 2 - 5 spent ~26 LDS reads, a dependent table
+// look-up and ~150 VALU instructions per step.
+struct DkRaw { v2u v, h; v2u w; }; // the lane's pieces of one macroblock: vertical edges (direction 0), horizontal edges (direction 1); its plane kind's 8 bytes of beta
 E264_DEV s16x2 dk_dupb(uint32_t w, int k) { return as_s2(v_perm(0, w, 0x0c000c00u | (uint32_t)k * 0x00010001u)); } // byte k of w in both halves
+E264_DEV s16x2 dk_dupb2(uint32_t hi, uint32_t lo, int k) { return as_s2(v_perm(hi, lo, 0x0c000c00u | (uint32_t)k * 0x00010001u)); } // byte k of {hi, lo}
 E264_DEV uint32_t dk_bit_mask(uint32_t w, int bit) { return (uint32_t)((int32_t)(w << (31 - bit)) >> 31); } // all ones where the bit is set (v_bfe_i32)
-E264_DEV void dk_params1(const v4u &piece, DkPrm &P)
+// beta of the four slots: luma {macroblock edge of this direction, inner, inner, inner} out of bytes {inner, left, top}; chroma {Cb mb, Cb inner, Cr mb, Cr inner}
+// out of bytes {Cb inner, left, top, Cr inner, left, top}
+template <int K> E264_DEV void dk_params1(const v2u &piece, const v2u &w, int dir, const DkRole &R, DkPrm &P)
 {
+	const uint32_t tcw = piece.y & 0x7f7f7f7fu;
 #pragma unroll
 	for (int e = 0; e < 4; e++) {
 		P.al[e] = dk_dupb(piece.x, e);
-		P.tc[e] = dk_dupb(piece.y, e);
-		P.be[e] = dk_dupb(piece.z, e);
+		P.tc[e] = dk_dupb(tcw, e);
 	}
-	P.thr = dk_dupb(piece.w, 0);
-	P.strong0 = as_s2(dk_bit_mask(piece.w, 8));
-	P.strong2 = as_s2(dk_bit_mask(piece.w, 9));
+	if (K == 0) { // (every lane a luma lane: constants)
+		P.be[0] = dk_dupb(w.x, 1 + dir); P.be[1] = P.be[2] = P.be[3] = dk_dupb(w.x, 0);
+	} else if (K == 1) {
+		P.be[0] = dk_dupb2(w.y, w.x, 1 + dir); P.be[1] = dk_dupb2(w.y, w.x, 0); P.be[2] = dk_dupb2(w.y, w.x, 4 + dir); P.be[3] = dk_dupb2(w.y, w.x, 3);
+	} else { // mixed waves: by the lane's kind
+		const bool c = R.chroma;
+		const uint32_t s0 = 0x0c000c00u | (uint32_t)(1 + dir) * 0x00010001u, s1 = 0x0c000c00u, s2 = 0x0c000c00u | (uint32_t)(c ? 4 + dir : 0) * 0x00010001u, s3 = 0x0c000c00u | (c ? 3u : 0u) * 0x00010001u;
+		P.be[0] = as_s2(v_perm(w.y, w.x, s0)); P.be[1] = as_s2(v_perm(w.y, w.x, s1)); P.be[2] = as_s2(v_perm(w.y, w.x, s2)); P.be[3] = as_s2(v_perm(w.y, w.x, s3));
+	}
+	const s16x2 two = {2, 2}, sh2 = {2, 2};
+	P.thr = (P.al[0] >> sh2) + two; // only looked at where slot 0 has bS 4: alphaE is alpha there
+	P.strong0 = as_s2(dk_bit_mask(piece.y, 7));
+	P.strong2 = as_s2(dk_bit_mask(piece.y, 23));
 }
-E264_DEV void dk_params(const DkRaw &raw, DkPrm P[2])
+template <int K> E264_DEV void dk_params(const DkRaw &raw, const DkRole &R, DkPrm P[2])
 {
-	dk_params1(raw.v, P[0]);
-	dk_params1(raw.h, P[1]);
+	dk_params1<K>(raw.v, raw.w, 0, R, P[0]);
+	dk_params1<K>(raw.h, raw.w, 1, R, P[1]);
 }
 // The four edge slots of a line pair held in v[0..19] (positions -4..15): slot e works on v[4e .. 4e+7]; in chroma lanes
 // only p1 p0 q0 q1 = v[4e+2 .. 4e+5] matter.
@@ -324,12 +337,14 @@ template <int K> E264_DEV void dk_pick(const v4u N[2 * DK_GS], const DkRole &R0,
 		o.x = R.chroma ? ch.x : lu.x; o.y = R.chroma ? ch.y : lu.y; o.z = R.chroma ? ch.z : lu.z; o.w = R.chroma ? ch.w : lu.w;
 	}
 }
-// the lane's two parameter pieces of macroblock (x, y).  LOADS ONLY.
+// the lane's two parameter pieces of macroblock (x, y) and its 8 bytes of beta.  LOADS ONLY.
 template <int K> E264_DEV void dk_fetch_prm(const FrameCtx &f, const DkRole &R, int x, int y, DkRaw &p)
 {
-	const gu8 *rec = f.dbk + (size_t)(y * f.wm + x) * E264_DBK_BYTES + (dk_chroma<K>(R) ? 128 : 0) + R.seg * 16;
-	p.v = *(const gv4u *)rec;
-	p.h = *(const gv4u *)(rec + 64);
+	const gu8 *rec = f.dbk + (size_t)(y * f.wm + x) * E264_DBK_BYTES;
+	const gu8 *pc = rec + (dk_chroma<K>(R) ? 64 : 0) + R.seg * 8;
+	p.v = *(const gv2u *)pc;
+	p.h = *(const gv2u *)(pc + 32);
+	p.w = *(const gv2u *)(rec + 128 + (dk_chroma<K>(R) ? 8 : 0));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

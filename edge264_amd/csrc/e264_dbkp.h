@@ -14,15 +14,18 @@
 // Raw record (DP_RAW = 64 bytes per macroblock, in LDS only since round 6):
 //   [0..31]  bS[dir][edge][segment]      [32..40] alpha[plane*3 + t], t = 0 internal edges, 1 left MB edge, 2 top MB edge
 //   [41..49] beta                        [50..58] indexA (tC0 lookup)                       [59..63] zero
-// What leaves for memory (round 6, E264_DBK_BYTES = 256 per macroblock) is the same information IN THE LAYOUT OF THE DEBLOCKING KERNEL'S
-// LANES: sixteen 16-byte pieces, one per (plane kind, direction, line-pair segment) -- exactly what one lane of e264_dbk.h needs for its
-// four edge slots of one direction, ready to be spread into packed 16-bit pairs with one byte permute per value:
-//   piece (luma: byte offset (dir * 4 + seg) * 16; chroma: 128 + (dir * 4 + line pair) * 16):
+// What leaves for memory (round 6, E264_DBK_BYTES = 144 per macroblock) is the same information IN THE LAYOUT OF THE DEBLOCKING KERNEL'S
+// LANES: sixteen 8-byte pieces, one per (plane kind, direction, line-pair segment) -- exactly what one lane of e264_dbk.h needs for its
+// four edge slots of one direction, ready to be spread into packed 16-bit pairs with one byte permute per value -- and 16 bytes all lanes share:
+//   piece (luma: byte offset (dir * 4 + seg) * 8; chroma: 64 + (dir * 4 + line pair) * 8):
 //     dword 0  alphaE[slot 0..3]   alpha of the slot's edge, or 0 where its bS is 0 (nothing is below 0: the edge is left alone)
-//     dword 1  tC[slot 0..3]       tC0 of (bS, indexA); chroma: + 1 (its tC); 0 for bS 0 and 4
-//     dword 2  beta[slot 0..3]
-//     dword 3  byte 0: (alpha of slot 0 >> 2) + 2 (the bS 4 luma test); byte 1 bit 0: slot 0 has bS 4, bit 1: slot 2 has bS 4
+//     dword 1  tC[slot 0..3]       tC0 of (bS, indexA); chroma: + 1 (its tC); 0 for bS 0 and 4 (at most 26: bit 7 is free);
+//                                  bit 7 of byte 0: slot 0 has bS 4, bit 7 of byte 2: slot 2 has bS 4
 //   (luma slot e = edge e of the macroblock; chroma slot 0 = Cb macroblock edge, 1 = Cb inner edge, 2 / 3 = the same of Cr)
+//   bytes 128..143: beta of the luma plane {inner, left, top} at 128..130, of Cb at 136..138, of Cr at 139..141 (a lane's own are within 8 bytes)
+//   ((alpha >> 2) + 2 of the bS 4 luma test is not stored: where bS is 4, alphaE IS alpha.)
+// (The first version of the round had 16-byte pieces with beta and the threshold in each: 256 bytes per macroblock, whose stores alone cost this kernel
+// 0.044 ms per launch, profiles/r06_ablations.txt item 8.)
 // Until round 5 every lane of the deblocking kernel derived these from the raw record in every step: ~26 LDS reads, a dependent tC0
 // table look-up and ~160 VALU instructions per step and wave, i.e. once per line-pair segment of each of the 8 (15) macroblocks of a step
 // AND per lane pair that shares it; here it is done once per macroblock by four threads.
@@ -253,25 +256,30 @@ E264_DEV void dbkp_phase_compute(DbkpLds &L, const FrameCtx &f, int a0, int tid)
 	}
 }
 
-// One piece of the lanes' layout out of a raw record (see the head of this file; the selection of bS / alpha / beta / indexA per slot is
+// One piece of the lanes' layout out of a raw record (see the head of this file; the selection of bS / alpha / indexA per slot is
 // what e264_dbk.h's dk_params did per lane and step until round 5).  s: luma segment / chroma line pair, 0..3.
 E264_DEV uint32_t dk_bfi_u(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); } // v_bfi_b32
-E264_DEV v4u dbkp_piece(const uint8_t *rec, const uint8_t *tc0tab, bool chroma, int dir, int s)
+E264_DEV v2u dbkp_piece(const uint8_t *rec, const uint8_t *tc0tab, bool chroma, int dir, int s)
 {
-	uint32_t al = 0, tc = 0, be = 0, last = 0;
+	uint32_t al = 0, tc = 0;
 #pragma unroll
 	for (int e = 0; e < 4; e++) {
 		const bool mbe = chroma ? !(e & 1) : e == 0;                              // a macroblock edge: its own alpha / beta / indexA
 		const int bso = (chroma ? (e & 1) * 8 : e * 4) + s;                       // chroma inner edge = luma edge 2
 		const int abi = (chroma ? (1 + (e >> 1)) * 3 : 0) + (mbe ? 1 + dir : 0);  // [plane * 3 + {inner, left, top}]
-		const uint32_t bS = rec[dir * 16 + bso], alpha = rec[32 + abi], beta = rec[41 + abi], ia = rec[50 + abi];
+		const uint32_t bS = rec[dir * 16 + bso], alpha = rec[32 + abi], ia = rec[50 + abi];
 		al |= (bS ? alpha : 0u) << (8 * e);
 		tc |= ((uint32_t)tc0tab[(bS & 3) * 52 + ia] + (chroma ? 1u : 0u)) << (8 * e);
-		be |= beta << (8 * e);
-		if (e == 0) last |= ((alpha >> 2) + 2) | (bS == 4 ? 0x100u : 0u);
-		if (e == 2) last |= bS == 4 ? 0x200u : 0u;
+		if ((e == 0 || e == 2) && bS == 4) tc |= 0x80u << (8 * e);
 	}
-	return (v4u){al, tc, be, last};
+	return (v2u){al, tc};
+}
+// the 16 bytes of a record that belong to the whole macroblock: beta[plane * 3 + {inner, left, top}] (raw bytes 41..49)
+E264_DEV v4u dbkp_mbwide(const uint8_t *rec)
+{
+	const uint32_t y = (uint32_t)rec[41] | (uint32_t)rec[42] << 8 | (uint32_t)rec[43] << 16;
+	const uint32_t c0 = (uint32_t)rec[44] | (uint32_t)rec[45] << 8 | (uint32_t)rec[46] << 16 | (uint32_t)rec[47] << 24, c1 = (uint32_t)rec[48] | (uint32_t)rec[49] << 8;
+	return (v4u){y, 0, c0, c1};
 }
 // after the raw records: thread r of a macroblock builds the four pieces of direction r >> 1, segments / line pairs 2 (r & 1), 2 (r & 1) + 1.
 // dbkp_piece above is the definition (and what the host tests compare with); this is the same on four slots at a time: the bS of a piece's
@@ -284,18 +292,16 @@ E264_DEV void dbkp_phase_pieces(DbkpLds &L, int tid)
 	const v4u B = *(const v4u *)&L.out[i][dir * 4]; // bS of edges 0..3, one segment per byte
 	const v4u w0 = *(const v4u *)&L.out[i][8], w1 = *(const v4u *)&L.out[i][12];
 	const uint32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-	uint32_t alv[3], bev[3], t_mb[3], t_in[3], thr0 = 0;
+	uint32_t alv[3], t_mb[3], t_in[3];
 #pragma unroll
 	for (int pl = 0; pl < 3; pl++) { // [plane * 3 + {inner, left, top}] at bytes 32 (alpha), 41 (beta), 50 (indexA) of the record
 		const uint32_t a_in = dbkp_byte(w, 3 * pl), a_mb = dir ? dbkp_byte(w, 3 * pl + 2) : dbkp_byte(w, 3 * pl + 1);
-		const uint32_t b_in = dbkp_byte(w, 9 + 3 * pl), b_mb = dir ? dbkp_byte(w, 9 + 3 * pl + 2) : dbkp_byte(w, 9 + 3 * pl + 1);
 		const uint32_t i_in = dbkp_byte(w, 18 + 3 * pl), i_mb = dir ? dbkp_byte(w, 18 + 3 * pl + 2) : dbkp_byte(w, 18 + 3 * pl + 1);
-		alv[pl] = a_mb | a_in << 8; bev[pl] = b_mb | b_in << 8; // (macroblock edge, inner edges)
+		alv[pl] = a_mb | a_in << 8; // (macroblock edge, inner edges)
 		t_mb[pl] = L.tc3[i_mb]; t_in[pl] = L.tc3[i_in];
-		if (pl == 0) thr0 = (a_mb >> 2) + 2;
 	}
-	const uint32_t al_l = v_perm(0, alv[0], 0x01010100u), be_l = v_perm(0, bev[0], 0x01010100u);  // luma slots: mb, inner, inner, inner
-	const uint32_t al_c = v_perm(alv[2], alv[1], 0x05040100u), be_c = v_perm(bev[2], bev[1], 0x05040100u); // chroma slots: Cb mb, Cb inner, Cr mb, Cr inner
+	const uint32_t al_l = v_perm(0, alv[0], 0x01010100u);        // luma slots: mb, inner, inner, inner
+	const uint32_t al_c = v_perm(alv[2], alv[1], 0x05040100u);   // chroma slots: Cb mb, Cb inner, Cr mb, Cr inner
 #pragma unroll
 	for (int k = 0; k < 2; k++) {
 		const uint32_t sg = (uint32_t)(s0 + k);
@@ -304,8 +310,7 @@ E264_DEV void dbkp_phase_pieces(DbkpLds &L, int tid)
 			const uint32_t bsv = v_perm(v_perm(B.w, B.z, sel), v_perm(B.y, B.x, sel), 0x05040100u);
 			const uint32_t nz7 = (bsv + 0x7f7f7f7fu) & 0x80808080u, full = (nz7 << 1) - (nz7 >> 7); // 0xff where bS != 0 (bS <= 4: no carry between bytes)
 			const uint32_t tc = v_perm(t_in[0], t_mb[0], (bsv & 0x03030303u) + 0x04040400u);
-			const uint32_t x4 = bsv & 0x00040004u; // bS == 4 <=> bit 2 (bS is 0..4)
-			*(v4u *)&L.pieces[i][(dir * 4 + s0 + k) * 4] = (v4u){al_l & full, tc, be_l, thr0 | (x4 << 6 & 0x100u) | (x4 >> 9 & 0x200u)};
+			*(v2u *)&L.pieces[i][(dir * 4 + s0 + k) * 2] = (v2u){al_l & full, tc | (bsv & 0x00040004u) << 5}; // bS == 4 <=> bit 2 (bS is 0..4) -> bit 7
 		}
 		{ // chroma: slots (Cb edge 0, Cb edge 2, Cr edge 0, Cr edge 2)
 			const uint32_t sel = sg * 0x01010101u + 0x04000400u;
@@ -313,22 +318,24 @@ E264_DEV void dbkp_phase_pieces(DbkpLds &L, int tid)
 			const uint32_t nz7 = (bsv + 0x7f7f7f7fu) & 0x80808080u, full = (nz7 << 1) - (nz7 >> 7);
 			const uint32_t tsel = (bsv & 0x03030303u) + 0x04000400u;
 			const uint32_t tc = dk_bfi_u(0x0000ffffu, v_perm(t_in[1], t_mb[1], tsel), v_perm(t_in[2], t_mb[2], tsel)) + 0x01010101u;
-			const uint32_t x4 = bsv & 0x00040004u;
-			*(v4u *)&L.pieces[i][32 + (dir * 4 + s0 + k) * 4] = (v4u){al_c & full, tc, be_c, ((alv[1] & 255u) >> 2) + 2 | (x4 << 6 & 0x100u) | (x4 >> 9 & 0x200u)};
+			*(v2u *)&L.pieces[i][16 + (dir * 4 + s0 + k) * 2] = (v2u){al_c & full, tc | (bsv & 0x00040004u) << 5};
 		}
 	}
+	if (r == 0) // beta: raw bytes 41..49 = dwords 10..12 of the record
+		*(v4u *)&L.pieces[i][32] = (v4u){dbkp_byte(w, 9) | dbkp_byte(w, 10) << 8 | dbkp_byte(w, 11) << 16, 0u,
+		                                 dbkp_byte(w, 12) | dbkp_byte(w, 13) << 8 | dbkp_byte(w, 14) << 16 | dbkp_byte(w, 15) << 24, dbkp_byte(w, 16) | dbkp_byte(w, 17) << 8};
 }
 
 E264_DEV void dbkp_phase_store(const DbkpLds &L, const FrameCtx &f, int a0, int tid)
 {
 	const int n_mbs = f.wm * f.hm;
-#pragma unroll
-#ifdef E264_ABL_DBKP_STORE1 // timing ablation: a quarter of every record is written (wrong parameters): what the 256-byte records cost in stores
-	for (int k = 0; k < 1; k++) {
+	constexpr int P16 = E264_DBK_BYTES / 16; // 16-byte pieces per record: consecutive threads write consecutive pieces of consecutive records
+#ifdef E264_ABL_DBKP_STORE1 // timing ablation: part of every record is written (wrong parameters): what the records cost in stores
+	for (int idx = tid; idx < DP_MBS * 4; idx += DP_NT) {
 #else
-	for (int k = 0; k < E264_DBK_BYTES / 64; k++) { // 64 records x 16 pieces of 16 bytes, consecutive threads consecutive pieces
+	for (int idx = tid; idx < DP_MBS * P16; idx += DP_NT) {
 #endif
-		const int idx = k * DP_NT + tid, i = idx >> 4, part = idx & 15;
+		const int i = idx / P16, part = idx - i * P16;
 		if (a0 + i < n_mbs)
 			*(gv4u *)(f.dbk + (size_t)(a0 + i) * E264_DBK_BYTES + part * 16) = *(const v4u *)&L.pieces[i][part * 4];
 	}

@@ -11,7 +11,7 @@ struct E264Job {
 	uint8_t *const *dpb;
 	uint8_t *dbk; // per-stream scratch, E264_SCRATCH_BYTES(macroblocks) (NULL: no deblocking, no intra bitmap -- host tests only, the back end always has one)
 };
-#define E264_DBK_BYTES 256 // sixteen 16-byte pieces in the layout of the deblocking kernel's lanes (e264_dbkp.h)
+#define E264_DBK_BYTES 144 // sixteen 8-byte pieces in the layout of the deblocking kernel's lanes + 16 bytes for the whole macroblock (e264_dbkp.h)
 // The scratch of a stream: the parameter records of n_mbs macroblocks, then the INTRA BITMAP of the picture being decoded: one uint16_t per
 // (macroblock row, group of 16 macroblocks) = per row of a prediction tile, bit i = macroblock 16 g + i is Intra4x4 / 8x8 / 16x16 and this
 // packet's to reconstruct.  Written by e264_pred_kernel (which reads every record anyway), read by e264_intra_kernel in the same submission

@@ -193,7 +193,7 @@ static __device__ __forceinline__ void dk_walk_group(DkWaveT<K> &W, const FrameC
 	if (blockIdx.x == 0 && lane == 0 && tl_slot < 64) g_timeline[2 * tl_slot] = __builtin_amdgcn_s_memtime();
 #endif
 	v4u tt = {0, 0, 0, 0};
-	DkRaw p0 = {tt, tt}, p1 = p0; // the lane's parameter pieces: the set this step uses and the set it requests for the next one
+	DkRaw p0 = {{0, 0}, {0, 0}, {0, 0}}, p1 = p0; // the lane's parameter pieces: the set this step uses and the set it requests for the next one
 	v4u N[2 * DK_GS];       // samples of four (two) macroblocks of the lane's two rows (dk_fetch4), requested at steps t = 0 mod 4 (2)
 	v4u K2a = tt, K2b = tt, K3a = tt, K3b = tt; // the last two (groups of 2: K3, the last one) of them, kept while the next group is on its way
 	PH_DECL;
@@ -206,7 +206,7 @@ static __device__ __forceinline__ void dk_walk_group(DkWaveT<K> &W, const FrameC
 		// conditional stores, any use of a loaded register after them is an s_waitcnt vmcnt(0) = a full drain
 		if (p.top_commit >= 0) dk_top_commit<K>(W, f, lane, p.top_commit, y0, tt);
 		v4u ra, rb;
-		asm volatile("" :: "v"(sp.v), "v"(sp.h)); // (the parameters of this step have landed)
+		asm volatile("" :: "v"(sp.v), "v"(sp.h), "v"(sp.w)); // (the parameters of this step have landed)
 		if (DK_GS == 4) {
 			if (k < 2) dk_pick<K>(N, R, k, ra, rb);
 			else { ra = k == 2 ? K2a : K3a; rb = k == 2 ? K2b : K3b; }
@@ -243,7 +243,7 @@ static __device__ __forceinline__ void dk_walk_group(DkWaveT<K> &W, const FrameC
 #endif
 		{
 			if (p.act) {
-				dk_params(sp, P);
+				dk_params<K>(sp, R, P);
 				PH(3);
 				dk_vpass<K>(W, P[0], R, ra, rb, p.x);
 			}

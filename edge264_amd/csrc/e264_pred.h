@@ -415,6 +415,25 @@ E264_DEV void hrow(const uint32_t g[][2], int j, uint32_t h[2])
 	h[0] = packus4(V[0], V[1]); h[1] = packus4(V[2], V[3]);
 }
 
+// Round 6 (-DE264_PRED_HROW_ONCE): the byte columns of a row spread into 16-bit pairs ONCE per input row (4 permutes) instead of once per output row that
+// taps it (hrow: 6 rows x 4 permutes per output row -- 192 against 52 per 8 x 8 block)
+#ifndef E264_PRED_HROW_ONCE
+#define E264_PRED_HROW_ONCE 1
+#endif
+E264_DEV void urow(const uint32_t g[2], s16x2 U[4])
+{
+	U[0] = pair_at<0>(0, g[0]); U[1] = pair_at<2>(0, g[0]); U[2] = pair_at<0>(0, g[1]); U[3] = pair_at<2>(0, g[1]);
+}
+E264_DEV void hrow_u(const s16x2 U[][4], int j, uint32_t h[2])
+{
+	const s16x2 s5 = {5, 5};
+	s16x2 V[4];
+#pragma unroll
+	for (int p = 0; p < 4; p++)
+		V[p] = tap6u16(U[j][p], U[j + 1][p], U[j + 2][p], U[j + 3][p], U[j + 4][p], U[j + 5][p]) >> s5;
+	h[0] = packus4(V[0], V[1]); h[1] = packus4(V[2], V[3]);
+}
+
 // class 0: integer position.  A holds window rows 2..9 only (8 rows), aligned.
 E264_DEV void luma_g(const Row4 A[8], const LumaSink &sink)
 {
@@ -440,14 +459,24 @@ E264_DEV void luma_h(const Row4 A[13], int yF, const LumaSink &sink)
 {
 	const bool dy = yF == 3, q = yF != 2;
 	uint32_t g[13][2];
+#if E264_PRED_HROW_ONCE
+	s16x2 U[13][4];
+#endif
 #pragma unroll
 	for (int r = 0; r < 13; r++) {
 		g[r][0] = v_alignbyte(A[r].a1, A[r].a0, 2); g[r][1] = v_alignbyte(A[r].a2, A[r].a1, 2);
+#if E264_PRED_HROW_ONCE
+		urow(g[r], U[r]);
+#endif
 		if (r < 5)
 			continue;
 		const int j = r - 5;
 		uint32_t h[2];
+#if E264_PRED_HROW_ONCE
+		hrow_u(U, j, h);
+#else
 		hrow(g, j, h);
+#endif
 		const uint32_t G0 = dy ? g[j + 3][0] : g[j + 2][0], G1 = dy ? g[j + 3][1] : g[j + 2][1];
 		sink_row(sink, j, v_lerp_u8(h[0], q ? G0 : h[0], ONES8), v_lerp_u8(h[1], q ? G1 : h[1], ONES8));
 	}
@@ -458,9 +487,15 @@ E264_DEV void luma_d(const Row4 A[13], int xF, int yF, const LumaSink &sink)
 	const uint32_t dx = xF == 3;
 	const bool dy = yF == 3;
 	uint32_t g[13][2];
+#if E264_PRED_HROW_ONCE
+	s16x2 U[13][4];
+#endif
 #pragma unroll
 	for (int r = 0; r < 13; r++) {
 		gcols(A[r], dx, g[r]);
+#if E264_PRED_HROW_ONCE
+		urow(g[r], U[r]);
+#endif
 		if (r < 5)
 			continue;
 		const int j = r - 5;
@@ -469,7 +504,11 @@ E264_DEV void luma_d(const Row4 A[13], int xF, int yF, const LumaSink &sink)
 		s.a2 = dy ? A[j + 3].a2 : A[j + 2].a2; s.a3 = dy ? A[j + 3].a3 : A[j + 2].a3;
 		uint32_t b[2], h[2];
 		brow(s, b);
+#if E264_PRED_HROW_ONCE
+		hrow_u(U, j, h);
+#else
 		hrow(g, j, h);
+#endif
 		sink_row(sink, j, v_lerp_u8(b[0], h[0], ONES8), v_lerp_u8(b[1], h[1], ONES8));
 	}
 }

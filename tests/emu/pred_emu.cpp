@@ -84,18 +84,21 @@ extern "C" __attribute__((visibility("default"))) int e264emu_dbkparam_raw(const
 	free(out);
 	return r;
 }
-// a raw record -> its sixteen pieces (what the kernel's piece phase does)
-extern "C" __attribute__((visibility("default"))) void e264emu_dbk_pieces(const uint8_t *raw, uint8_t *out256)
+// a raw record -> the E264_DBK_BYTES of the lanes' layout (what the kernel's piece phase does), by the slot-by-slot definition
+extern "C" __attribute__((visibility("default"))) void e264emu_dbk_pieces(const uint8_t *raw, uint8_t *out)
 {
 	uint8_t tc0tab[4 * 52];
 	for (int i = 0; i < 4 * 52; i++) tc0tab[i] = i < 52 ? 0 : c_tc0[i / 52 - 1][i % 52];
 	for (int c = 0; c < 2; c++)
 		for (int dir = 0; dir < 2; dir++)
 			for (int sgm = 0; sgm < 4; sgm++) {
-				const v4u p = dbkp_piece(raw, tc0tab, c != 0, dir, sgm);
-				memcpy(out256 + c * 128 + (dir * 4 + sgm) * 16, &p, 16);
+				const v2u p = dbkp_piece(raw, tc0tab, c != 0, dir, sgm);
+				memcpy(out + c * 64 + (dir * 4 + sgm) * 8, &p, 8);
 			}
+	const v4u w = dbkp_mbwide(raw);
+	memcpy(out + 128, &w, 16);
 }
+extern "C" __attribute__((visibility("default"))) int e264emu_dbk_bytes(void) { return E264_DBK_BYTES; }
 
 // e264_deblock_kernel / e264_deblock2_kernel: dbk = the parameter records (e264emu_dbkparam_frame's output); the picture in
 // dpb[dst_slot] is filtered in place.  Groups of rows are run one after the other (a group only ever waits for the group above it
@@ -154,7 +157,7 @@ static void emu_walk_group(const FrameCtx &f, int q)
 		g_filter_steps++;
 		for (int lane = 0; lane < 64; lane++)
 			if (p[lane].act) {
-				dk_params(np[par][lane], P[lane]);
+				dk_params<K>(np[par][lane], R[lane], P[lane]);
 				dk_vpass<K>(W, P[lane][0], R[lane], ra[lane], rb[lane], p[lane].x);
 			}
 		for (int lane = 0; lane < 64; lane++)
@@ -190,10 +193,11 @@ extern "C" __attribute__((visibility("default"))) void e264emu_dk_filter(uint8_t
 	uint8_t pieces[E264_DBK_BYTES];
 	e264emu_dbk_pieces(prm, pieces);
 	DkRaw raw;
-	memcpy(&raw.v, pieces + (R.chroma ? 128 : 0) + R.seg * 16, 16);
-	memcpy(&raw.h, pieces + (R.chroma ? 128 : 0) + 64 + R.seg * 16, 16);
+	memcpy(&raw.v, pieces + (R.chroma ? 64 : 0) + R.seg * 8, 8);
+	memcpy(&raw.h, pieces + (R.chroma ? 64 : 0) + 32 + R.seg * 8, 8);
+	memcpy(&raw.w, pieces + 128 + (R.chroma ? 8 : 0), 8);
 	DkPrm P[2];
-	dk_params(raw, P);
+	dk_params<2>(raw, R, P);
 	dk_filter<2>(v, P[dir], R);
 	for (int k = 0; k < 20; k++) { // (the pack back to bytes, as dk_vpass / dk_hpass do it: p0 / q0 may arrive unclipped, E264_DBK_SATPACK)
 		const uint32_t b = (E264_DBK_SATPACK && dk_is_p0q0(k)) ? v_sat_pk_u8_i16(as_u(v[k])) : v_perm(0, as_u(v[k]), 0x0c0c0200u);

@@ -69,7 +69,7 @@ def test_deblock_emu(emu, name, gop, w, h, kw, split):
         d = int(P.Packet(pkt).hdr["dst_slot"])
         mine = [None if b is None else b.copy() for b in dpb]
         orc.decode_frame(pkt, mine, 1)          # reconstruction only
-        prm = np.zeros((w * h, 256), np.uint8)  # E264_DBK_BYTES per macroblock
+        prm = np.zeros(w * h * 146 + 64, np.uint8)  # E264_SCRATCH_BYTES (edge264_amd/csrc/e264_kernels.h): 144 bytes of parameters per macroblock + the intra bitmap
         assert emu.e264emu_dbkparam_frame(pkt, prm.ctypes.data) == 0
         assert emu.e264emu_deblock_frame2(pkt, _dpb_array(mine), prm.ctypes.data, split) == 0
         orc.decode_frame(pkt, dpb, 3)           # reconstruction + deblocking: the reference for this frame and the next

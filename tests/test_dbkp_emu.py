@@ -81,15 +81,14 @@ def test_dbkparam_emu(emu, name, gop, w, h, kw):
         bs = orc.frame_bs(pkt, n).reshape(n, 32)
         assert np.array_equal(got[:, :32], bs), f"{name} frame {ft}: bS differs at macroblocks {np.nonzero((got[:, :32] != bs).any(1))[0][:8].tolist()}"
         assert np.array_equal(got[:, 32:], expected_ab(pk, w)), f"{name} frame {ft}: alpha / beta / indexA differ"
-        # what leaves for memory: the sixteen 16-byte pieces of the deblocking lanes' layout.  The kernel builds them four slots at a time
+        # what leaves for memory: the sixteen 8-byte pieces of the deblocking lanes' layout + the macroblock's 16 bytes of beta.  The kernel builds them four slots at a time
         # (byte permutes); the definition is dbkp_piece, slot by slot, on the raw record that has just been checked
-        pieces = np.full((n, 256), 0x5A, np.uint8)
+        pieces = np.full((n, 144), 0x5A, np.uint8)  # E264_DBK_BYTES
         raw2 = np.zeros((n, 64), np.uint8)
         assert emu.e264emu_dbkparam_frame2(pkt, pieces.ctypes.data, raw2.ctypes.data) == 0
         assert np.array_equal(raw2, got)
-        exp = np.zeros((n, 256), np.uint8)
+        exp = np.zeros((n, 144), np.uint8)
         for a in range(n):
             emu.e264emu_dbk_pieces(got[a].ctypes.data, exp[a].ctypes.data)
-        # byte 0 of dword 3 of a chroma piece ((alpha >> 2) + 2 of ITS slot 0) is never read by a chroma lane: both forms fill it alike
         assert np.array_equal(pieces, exp), f"{name} frame {ft}: pieces differ at macroblocks {np.nonzero((pieces != exp).any(1))[0][:8].tolist()}"
 

@@ -33,7 +33,7 @@ def emu():
 
 
 def scratch_bytes(n_mbs):
-    return n_mbs * 258 + 64  # edge264_amd/csrc/e264_kernels.h E264_SCRATCH_BYTES
+    return n_mbs * 146 + 64  # edge264_amd/csrc/e264_kernels.h E264_SCRATCH_BYTES
 
 
 CASES = {
@@ -87,11 +87,11 @@ def test_intra_emu_vs_oracle(emu, name, bitmap):
             mine = [None if b is None else b.copy() for b in dpb]
             orc.decode_frame(pkt, dpb, 1)  # reconstruction only: prediction kernel + intra kernel
             if bitmap:
-                scratch[w * h * 256:] = 0x00 if ft == "I" else 0xFF  # stale entries of the picture before, both ways
+                scratch[w * h * 144:] = 0x00 if ft == "I" else 0xFF  # stale entries of the picture before, both ways
                 assert emu.e264emu_pred_frame2(pkt, _dpb_array(mine), scratch.ctypes.data) == 0
                 assert emu.e264emu_intra_frame2(pkt, _dpb_array(mine), scratch.ctypes.data) == 0
                 ntx = (w + 15) // 16
-                bm = scratch[w * h * 256:w * h * 256 + 2 * ntx * h].view("<u2").reshape(h, ntx)
+                bm = scratch[w * h * 144:w * h * 144 + 2 * ntx * h].view("<u2").reshape(h, ntx)
                 kinds = P.Packet(pkt).mbs["kind"].reshape(h, w)
                 want = np.isin(kinds, (P.MB_I4x4, P.MB_I8x8, P.MB_I16x16))
                 got_bits = np.array([[bm[y, x >> 4] >> (x & 15) & 1 for x in range(w)] for y in range(h)], bool)

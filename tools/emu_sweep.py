@@ -73,7 +73,7 @@ def main():
             dst = int(P.Packet(pkt).hdr["dst_slot"])
             mine = [None if x is None else x.copy() for x in dpb]
             orc.decode_frame(pkt, dpb, 3)
-            prm = np.zeros(256 * w * h, np.uint8)  # E264_DBK_BYTES per macroblock
+            prm = np.zeros(146 * w * h + 64, np.uint8)  # E264_SCRATCH_BYTES
             ok = (pe.e264emu_dbkparam_frame(pkt, prm.ctypes.data) == 0 and pe.e264emu_pred_frame(pkt, _dpb_array(mine)) == 0 and
                   ie.e264emu_intra_frame(pkt, _dpb_array(mine)) == 0)
             if ok:

@@ -86,7 +86,7 @@ def main():
             for i in range(32):
                 arr[i] = libc.malloc(need + 64)
                 C.memset(arr[i], 100 + i, need + 64)
-            dpb_cache[(need, n_mbs)] = (arr, libc.malloc(256 * n_mbs))  # E264_DBK_BYTES per macroblock, exactly what ensure_dbk allocates
+            dpb_cache[(need, n_mbs)] = (arr, libc.malloc(146 * n_mbs + 64))  # E264_SCRATCH_BYTES, exactly what ensure_dbk allocates
         return dpb_cache[(need, n_mbs)]
     tally = dict(packets=len(packets), mutations=0, accepted=0, rejected=0, rejected_against_the_slots=0, changed_nothing=0)
     by_section = {}
