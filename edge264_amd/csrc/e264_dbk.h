@@ -341,9 +341,9 @@ template <int K> E264_DEV void dk_pick(const v4u N[2 * DK_GS], const DkRole &R0,
 template <int K> E264_DEV void dk_fetch_prm(const FrameCtx &f, const DkRole &R, int x, int y, DkRaw &p)
 {
 	const gu8 *rec = f.dbk + (size_t)(y * f.wm + x) * E264_DBK_BYTES;
-	const gu8 *pc = rec + (dk_chroma<K>(R) ? 64 : 0) + R.seg * 8;
-	p.v = *(const gv2u *)pc;
-	p.h = *(const gv2u *)(pc + 32);
+	const v4u both = *(const gv4u *)(rec + (dk_chroma<K>(R) ? 64 : 0) + R.seg * 16); // {V piece, H piece}
+	p.v = (v2u){both.x, both.y};
+	p.h = (v2u){both.z, both.w};
 	p.w = *(const gv2u *)(rec + 128 + (dk_chroma<K>(R) ? 8 : 0));
 }
 

@@ -17,7 +17,7 @@
 // What leaves for memory (round 6, E264_DBK_BYTES = 144 per macroblock) is the same information IN THE LAYOUT OF THE DEBLOCKING KERNEL'S
 // LANES: sixteen 8-byte pieces, one per (plane kind, direction, line-pair segment) -- exactly what one lane of e264_dbk.h needs for its
 // four edge slots of one direction, ready to be spread into packed 16-bit pairs with one byte permute per value -- and 16 bytes all lanes share:
-//   piece (luma: byte offset (dir * 4 + seg) * 8; chroma: 64 + (dir * 4 + line pair) * 8):
+//   piece (luma: byte offset seg * 16 + dir * 8; chroma: 64 + line pair * 16 + dir * 8 -- a lane's two directions are ONE 16-byte load):
 //     dword 0  alphaE[slot 0..3]   alpha of the slot's edge, or 0 where its bS is 0 (nothing is below 0: the edge is left alone)
 //     dword 1  tC[slot 0..3]       tC0 of (bS, indexA); chroma: + 1 (its tC); 0 for bS 0 and 4 (at most 26: bit 7 is free);
 //                                  bit 7 of byte 0: slot 0 has bS 4, bit 7 of byte 2: slot 2 has bS 4
@@ -310,7 +310,7 @@ E264_DEV void dbkp_phase_pieces(DbkpLds &L, int tid)
 			const uint32_t bsv = v_perm(v_perm(B.w, B.z, sel), v_perm(B.y, B.x, sel), 0x05040100u);
 			const uint32_t nz7 = (bsv + 0x7f7f7f7fu) & 0x80808080u, full = (nz7 << 1) - (nz7 >> 7); // 0xff where bS != 0 (bS <= 4: no carry between bytes)
 			const uint32_t tc = v_perm(t_in[0], t_mb[0], (bsv & 0x03030303u) + 0x04040400u);
-			*(v2u *)&L.pieces[i][(dir * 4 + s0 + k) * 2] = (v2u){al_l & full, tc | (bsv & 0x00040004u) << 5}; // bS == 4 <=> bit 2 (bS is 0..4) -> bit 7
+			*(v2u *)&L.pieces[i][(s0 + k) * 4 + dir * 2] = (v2u){al_l & full, tc | (bsv & 0x00040004u) << 5}; // bS == 4 <=> bit 2 (bS is 0..4) -> bit 7
 		}
 		{ // chroma: slots (Cb edge 0, Cb edge 2, Cr edge 0, Cr edge 2)
 			const uint32_t sel = sg * 0x01010101u + 0x04000400u;
@@ -318,7 +318,7 @@ E264_DEV void dbkp_phase_pieces(DbkpLds &L, int tid)
 			const uint32_t nz7 = (bsv + 0x7f7f7f7fu) & 0x80808080u, full = (nz7 << 1) - (nz7 >> 7);
 			const uint32_t tsel = (bsv & 0x03030303u) + 0x04000400u;
 			const uint32_t tc = dk_bfi_u(0x0000ffffu, v_perm(t_in[1], t_mb[1], tsel), v_perm(t_in[2], t_mb[2], tsel)) + 0x01010101u;
-			*(v2u *)&L.pieces[i][16 + (dir * 4 + s0 + k) * 2] = (v2u){al_c & full, tc | (bsv & 0x00040004u) << 5};
+			*(v2u *)&L.pieces[i][16 + (s0 + k) * 4 + dir * 2] = (v2u){al_c & full, tc | (bsv & 0x00040004u) << 5};
 		}
 	}
 	if (r == 0) // beta: raw bytes 41..49 = dwords 10..12 of the record

@@ -418,7 +418,7 @@ E264_DEV void hrow(const uint32_t g[][2], int j, uint32_t h[2])
 // Round 6 (-DE264_PRED_HROW_ONCE): the byte columns of a row spread into 16-bit pairs ONCE per input row (4 permutes) instead of once per output row that
 // taps it (hrow: 6 rows x 4 permutes per output row -- 192 against 52 per 8 x 8 block)
 #ifndef E264_PRED_HROW_ONCE
-#define E264_PRED_HROW_ONCE 1
+#define E264_PRED_HROW_ONCE 0 // measured (profiles/r06_ablations.txt item 9): 140 permutes fewer per item of classes 2 / 3, and no change in time
 #endif
 E264_DEV void urow(const uint32_t g[2], s16x2 U[4])
 {

@@ -93,7 +93,7 @@ extern "C" __attribute__((visibility("default"))) void e264emu_dbk_pieces(const 
 		for (int dir = 0; dir < 2; dir++)
 			for (int sgm = 0; sgm < 4; sgm++) {
 				const v2u p = dbkp_piece(raw, tc0tab, c != 0, dir, sgm);
-				memcpy(out + c * 64 + (dir * 4 + sgm) * 8, &p, 8);
+				memcpy(out + c * 64 + sgm * 16 + dir * 8, &p, 8);
 			}
 	const v4u w = dbkp_mbwide(raw);
 	memcpy(out + 128, &w, 16);
@@ -193,8 +193,8 @@ extern "C" __attribute__((visibility("default"))) void e264emu_dk_filter(uint8_t
 	uint8_t pieces[E264_DBK_BYTES];
 	e264emu_dbk_pieces(prm, pieces);
 	DkRaw raw;
-	memcpy(&raw.v, pieces + (R.chroma ? 64 : 0) + R.seg * 8, 8);
-	memcpy(&raw.h, pieces + (R.chroma ? 64 : 0) + 32 + R.seg * 8, 8);
+	memcpy(&raw.v, pieces + (R.chroma ? 64 : 0) + R.seg * 16, 8);
+	memcpy(&raw.h, pieces + (R.chroma ? 64 : 0) + R.seg * 16 + 8, 8);
 	memcpy(&raw.w, pieces + 128 + (R.chroma ? 8 : 0), 8);
 	DkPrm P[2];
 	dk_params<2>(raw, R, P);
