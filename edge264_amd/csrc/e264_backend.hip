@@ -118,6 +118,7 @@ struct E264Packet {
 	int n_mbs, n_tiles;
 	uint64_t frame_bytes;  // plane_size_Y + plane_size_C the kernels will touch in every slot the packet names
 	uint32_t ref_mask;     // DPB slots its motion refers to
+	bool pred_work;        // it holds inter or PCM macroblocks (else e264_pred_kernel has nothing to do for it)
 };
 
 #define E264_JOB_RING 4 // batches in flight per device: one uploading, one in the kernels, one retiring
@@ -614,7 +615,7 @@ static int check_packet(const void *packet, size_t bytes, int *dst, int *n_mbs, 
 // `slot_bytes` (with `slots`): size of every allocated slot -- a packet whose header claims a larger picture than the slot
 // it writes or reads (SPS size change, stale capture, foreign packet) would make the kernels run past the allocation.
 // `ref_mask_out` (may be null): DPB slots the packet's motion refers to.
-static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *slots, const size_t *slot_bytes = nullptr, uint32_t *ref_mask_out = nullptr)
+static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *slots, const size_t *slot_bytes = nullptr, uint32_t *ref_mask_out = nullptr, bool *pred_work_out = nullptr)
 {
 	int dst, n_mbs, r = check_packet(packet, bytes, &dst, &n_mbs);
 	if (r) return r;
@@ -633,12 +634,14 @@ static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *s
 	const uint8_t *mot = h->motion_off ? p + h->motion_off : nullptr; // compact motion records, up to payload_off
 	const uint32_t mot_bytes = h->motion_off ? h->payload_off - h->motion_off : 0;
 	uint32_t ref_mask = 0, n_coded = 0, n_inter = 0;
+	bool pred_work = false; // some macroblock is the prediction kernel's (inter, PCM)
 	for (int a = 0, col = 0; a < n_mbs; a++, col = col + 1 == h->width_mbs ? 0 : col + 1) {
 		const E264Mb &m = mbs[a];
 		if (m.kind > E264_MB_INTER) return fail(EINVAL, "macroblock kind");
 		if (m.slice >= h->n_slices || m.dbk_slice >= h->n_slices) return fail(EINVAL, "macroblock slice index"); // every record: the parameter kernel reads the slice of absent macroblocks too
 		if (m.kind == E264_MB_ABSENT) continue;
 		n_coded++;
+		if (m.kind == E264_MB_INTER || m.kind == E264_MB_PCM) pred_work = true;
 		if ((m.flags & E264_MBF_T8x8) && (m.kind == E264_MB_I16x16 || m.kind == E264_MB_PCM)) return fail(EINVAL, "8x8 transform flag on an Intra16x16 / PCM macroblock");
 		if ((m.payload_off & 7) || (uint64_t)m.payload_off + e264_mb_payload_bytes(&m) > h->payload_bytes) return fail(EINVAL, "macroblock payload");
 		if ((m.flags & E264_MBF_EDGE_LEFT) && col == 0) return fail(EINVAL, "left edge flag on the first column");
@@ -681,6 +684,7 @@ static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *s
 	if (h->n_coded_mbs != n_coded || h->n_inter_mbs != n_inter) return fail(EINVAL, "header macroblock counts differ from the records");
 	if (h->ref_slots != ref_mask) return fail(EINVAL, "header ref_slots differs from the motion records");
 	if (ref_mask_out) *ref_mask_out = ref_mask;
+	if (pred_work_out) *pred_work_out = pred_work;
 	return 0;
 }
 
@@ -853,11 +857,12 @@ API int e264hip_packet_upload(E264Device *dev, const void *packet, size_t bytes,
 	int dst, n_mbs, n_tiles, r = check_packet(packet, bytes, &dst, &n_mbs, &n_tiles);
 	if (r) return r;
 	uint32_t ref_mask = 0;
-	if ((r = check_packet_deep(packet, bytes, nullptr, nullptr, &ref_mask))) return r;
+	bool pred_work = true;
+	if ((r = check_packet_deep(packet, bytes, nullptr, nullptr, &ref_mask, &pred_work))) return r;
 	if (set_device(dev)) return EIO;
 	E264Packet *p = new (std::nothrow) E264Packet();
 	if (!p) return fail(ENOMEM, "packet object");
-	p->dev = dev; p->bytes = bytes; p->dst_slot = dst; p->n_mbs = n_mbs; p->n_tiles = n_tiles; p->ref_mask = ref_mask;
+	p->dev = dev; p->bytes = bytes; p->dst_slot = dst; p->n_mbs = n_mbs; p->n_tiles = n_tiles; p->ref_mask = ref_mask; p->pred_work = pred_work;
 	p->frame_bytes = (uint64_t)((const E264FrameHdr *)packet)->plane_size_Y + ((const E264FrameHdr *)packet)->plane_size_C;
 	if (hipMalloc((void **)&p->d_bytes, bytes) != hipSuccess) { delete p; return fail(ENOMEM, "hipMalloc packet"); }
 	hipError_t e = hipMemcpy(p->d_bytes, packet, bytes, hipMemcpyHostToDevice);
@@ -879,6 +884,7 @@ struct E264Batch {
 	E264Device *dev;
 	E264Job *d_jobs;
 	int n, max_mbs, max_tiles, lane;
+	bool pred_work; // some packet of the batch has inter / PCM macroblocks (all-intra batches skip the prediction kernel's launch)
 	std::vector<std::pair<E264Stream *, int>> writes; // (stream, destination slot) of every job
 };
 
@@ -912,6 +918,8 @@ API int e264hip_batch_create(E264Device *dev, E264Stream *const *streams, E264Pa
 	E264Batch *b = new (std::nothrow) E264Batch();
 	if (!b) return fail(ENOMEM, "batch object");
 	b->dev = dev; b->n = n; b->max_mbs = max_mbs; b->max_tiles = max_tiles; b->lane = streams[0]->lane;
+	b->pred_work = false;
+	for (int i = 0; i < n; i++) b->pred_work = b->pred_work || packets[i]->pred_work;
 	for (int i = 0; i < n; i++) b->writes.emplace_back(streams[i], packets[i]->dst_slot);
 	if (hipMalloc((void **)&b->d_jobs, sizeof(E264Job) * n) != hipSuccess) { delete b; return fail(ENOMEM, "hipMalloc jobs"); }
 	hipError_t e = hipMemcpy(b->d_jobs, jobs.data(), sizeof(E264Job) * n, hipMemcpyHostToDevice);
@@ -927,7 +935,8 @@ API int e264hip_batch_submit(E264Batch *b, int mode)
 	for (auto &w : b->writes)
 		if (w.first->lane != b->lane) return fail(EINVAL, "a stream of the batch was bound to another lane after batch_create");
 	uint64_t serial = 0;
-	int r = launch(b->dev, b->lane, b->d_jobs, b->n, b->max_mbs, b->max_tiles, mode, &serial);
+	// (E264_RUN_NO_PRED: internal to the launcher -- every packet of the batch was vetted at upload time and none holds an inter or PCM macroblock)
+	int r = launch(b->dev, b->lane, b->d_jobs, b->n, b->max_mbs, b->max_tiles, (mode & E264_RUN_ALL) | (b->pred_work ? 0 : E264_RUN_NO_PRED), &serial);
 	if (!r) for (auto &w : b->writes) { raise_serial(w.first->slot_serial[w.second], serial); raise_serial(w.first->last_serial, serial); }
 	return r;
 }
@@ -1073,7 +1082,7 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 		if (e == hipSuccess) e = hipStreamWaitEvent(q, jr.up, 0);
 	}
 	uint64_t serial = 0;
-	int r = e == hipSuccess ? launch(dev, lane, jr.d, n, max_mbs, max_tiles, mode, &serial) : fail(EIO, "packet upload", e);
+	int r = e == hipSuccess ? launch(dev, lane, jr.d, n, max_mbs, max_tiles, mode & E264_RUN_ALL, &serial) : fail(EIO, "packet upload", e);
 	if (r && up != q) hipStreamSynchronize(up); // copies already queued must not outlive the error return unguarded
 	// the job table and the staging slots are busy until the lane has passed this point -- also on an error above: whatever
 	// part of the batch was queued still reads them

@@ -785,7 +785,7 @@ E264_DEV int intra_next_row(int *next_row, int y, int lane)
 
 // what thread tid of the picture's workgroup does
 template <int NW>
-E264_DEV void intra_kernel_body(IntraLds<NW> &S, const E264Job &job, const int tid)
+E264_DEV void intra_kernel_body(IntraLds<NW> &S, const E264Job &job, const int tid, const bool use_bitmap = true)
 {
 	WaveLds *const lds = S.w;
 	uint32_t (*const hdrs)[64 * 8] = S.hdrs;
@@ -814,7 +814,7 @@ E264_DEV void intra_kernel_body(IntraLds<NW> &S, const E264Job &job, const int t
 	if (lane == 0) L.ws_slice = -1;
 	wave_sync();
 	const gu8 *mbs_g = f.payload - f.h->payload_off + f.h->mbs_off; // the E264Mb array through a per-lane (global) pointer
-	const gu16 *bitmap = f.dbk ? (const gu16 *)(f.dbk + E264_BITMAP_OFF(f.wm * f.hm)) : nullptr;
+	const gu16 *bitmap = (f.dbk && use_bitmap) ? (const gu16 *)(f.dbk + E264_BITMAP_OFF(f.wm * f.hm)) : nullptr;
 	const int ntx16 = (f.wm + 15) >> 4;
 	PH_DECL;
 #pragma unroll 1

@@ -269,7 +269,12 @@ int main(int argc, char **argv)
 					// frame buffers, and the same NAL would return ENOBUFS for ever (until round 5 this loop did exactly that).  edge264_flush is
 					// the API's way out (edge264.h:66: drop the delayed frames, clear the decoder state); decoding resumes at the next IDR picture.
 					// A decoder that is still stuck right after a flush is given up.
-					if (s.just_flushed) { s.done = true; stuck_given_up++; break; }
+					if (s.just_flushed) { s.done = true; stuck_given_up++; fprintf(stderr, "e264_multi: a decoder is still stuck right after edge264_flush: the rest of its stream is dropped\n"); break; }
+					// (edge264_flush clears the pictures in progress: the packets this decoder has already queued must have left for the device first)
+					if (!must_submit_before_fetch) {
+						std::lock_guard<std::mutex> lk(mu);
+						if (!s.q.empty()) return BLOCKED;
+					}
 					F.flush(s.dec);
 					s.just_flushed = true;
 					stuck_flushes++;
@@ -472,5 +477,5 @@ int main(int argc, char **argv)
 		S.size(), devices.size(), n_threads, total_frames, packets, rounds, rounds ? (double)packets / rounds : 0.0, sec, sec > 0 ? total_frames / sec : 0.0,
 		ns_decode.load() * 1e-9, ns_drain.load() * 1e-9, ns_idle.load() * 1e-9, ns_submit.load() * 1e-9, packets ? ns_decode.load() * 1e-6 / (double)packets : 0.0,
 		st_after, st_fps, st_ms, stuck_flushes.load(), stuck_given_up.load());
-	return 0;
+	return stuck_given_up.load() > 0 ? 3 : 0; // a stream that was cut short is not a clean run
 }
