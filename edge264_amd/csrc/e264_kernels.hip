@@ -337,10 +337,21 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock2_kernel(const E264Job *j
 		task = __builtin_amdgcn_readfirstlane(task);
 		if (task >= total)
 			break;
-		// luma groups among the first i tasks of the list: (i * nl) / total; task i is a luma group iff that count grows at i + 1
-		const int lb = task * nl / total, la = (task + 1) * nl / total;
-		if (la > lb) dk_walk_group<0>(lds[wave].l, f, progress_l, lb, lane, lb);
-		else dk_walk_group<1>(lds[wave].c, f, progress_c, task - lb, lane, 32 + task - lb);
+#ifndef E264_DBK_ORDER
+#define E264_DBK_ORDER 0 // the task list: 0 = luma and chroma groups interleaved in proportion (round 4), 1 = all luma groups first, 2 = all chroma groups first
+#endif
+		if (E264_DBK_ORDER == 1) {
+			if (task < nl) dk_walk_group<0>(lds[wave].l, f, progress_l, task, lane, task);
+			else dk_walk_group<1>(lds[wave].c, f, progress_c, task - nl, lane, 32 + task - nl);
+		} else if (E264_DBK_ORDER == 2) {
+			if (task < nc) dk_walk_group<1>(lds[wave].c, f, progress_c, task, lane, 32 + task);
+			else dk_walk_group<0>(lds[wave].l, f, progress_l, task - nc, lane, task - nc);
+		} else {
+			// luma groups among the first i tasks of the list: (i * nl) / total; task i is a luma group iff that count grows at i + 1
+			const int lb = task * nl / total, la = (task + 1) * nl / total;
+			if (la > lb) dk_walk_group<0>(lds[wave].l, f, progress_l, lb, lane, lb);
+			else dk_walk_group<1>(lds[wave].c, f, progress_c, task - lb, lane, 32 + task - lb);
+		}
 	}
 }
 
