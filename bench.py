@@ -285,7 +285,7 @@ def same_input_leg(dev, backend, n_streams, cpu):
     from oracle.cpu_baseline import FIXTURES_1080P  # (the list only: the files the CPU baseline decodes)
     files = [n for n in FIXTURES_1080P if os.path.exists(os.path.join(sdir, n))]
     res = {"files": files, "streams": n_streams, "per_file": {}}
-    tot_frames = tot_res = tot_host = tot_parse = tot_pictures = 0.0
+    tot_frames = tot_res = tot_host = tot_pin = tot_parse = tot_pictures = 0.0
     all_ok = True
     for name in files:
         with open(os.path.join(sdir, name), "rb") as f:
@@ -329,6 +329,23 @@ def same_input_leg(dev, backend, n_streams, cpu):
             dev.submit_host_prepared(hb, backend.RUN_ALL)
         dev.sync()
         t_host = time.perf_counter() - t0
+        # the front end's own road: packets that already sit in page-locked memory, validated by their producer (here: backend.packet_check once),
+        # gathered into the batch's staging buffer and copied in ONE transfer -- no per-macroblock walk inside the clock (one buffer per picture,
+        # read by every stream: 256 page-locked copies of a 30-picture file would be 4 GB)
+        for p in packets:
+            assert backend.packet_check(p) == 0
+        pins = [dev.pinned_copy(p) for p in packets]
+        pbs = [dev.prepare_pinned_batch(sts, [pins[f]] * n_streams, [len(packets[f])] * n_streams) for f in range(len(packets))]
+        for pb in pbs[:2]:
+            dev.submit_pinned_prepared(pb, backend.RUN_ALL)
+        dev.sync()
+        t0 = time.perf_counter()
+        for pb in pbs:
+            dev.submit_pinned_prepared(pb, backend.RUN_ALL)
+        dev.sync()
+        t_pin = time.perf_counter() - t0
+        for pp in pins:
+            dev.pinned_free(pp)
         # verification (untimed): one more pass from cleared slots, four streams, every picture
         orc = Oracle()
         dpb = [np.zeros(nb + 64, np.uint8) if used >> i & 1 else None for i in range(32)]
@@ -348,10 +365,11 @@ def same_input_leg(dev, backend, n_streams, cpu):
         n = len(packets) * n_streams
         res["per_file"][name] = {"pictures": len(packets), "packet_MB_per_picture": round(float(np.mean([len(p) for p in packets])) / 1e6, 3),
                                  "gpu_resident_frames_per_s": round(n / t_res, 1), "gpu_pcie_inclusive_frames_per_s": round(n / t_host, 1),
+                                 "gpu_pcie_inclusive_pinned_frames_per_s": round(n / t_pin, 1),
                                  "host_parse_emit_frames_per_s_one_core": round(len(packets) / parse_s, 1),
                                  "kernel_ms_per_launch": {n: round(t / max(l4, 1), 4) for n, t in zip(KERNELS, k4)},
                                  "pictures_compared": len(packets) * len(probe), "mismatching": bad}
-        tot_frames += n; tot_res += t_res; tot_host += t_host; tot_parse += parse_s; tot_pictures += len(packets)
+        tot_frames += n; tot_res += t_res; tot_host += t_host; tot_pin += t_pin; tot_parse += parse_s; tot_pictures += len(packets)
         for b in bs:
             dev.free_batch(b)
         for row in dpk:
@@ -360,9 +378,10 @@ def same_input_leg(dev, backend, n_streams, cpu):
         for st in sts:
             st.close()
     res.update({"gpu_resident_frames_per_s": round(tot_frames / tot_res, 1), "gpu_pcie_inclusive_frames_per_s": round(tot_frames / tot_host, 1),
+                "gpu_pcie_inclusive_pinned_frames_per_s": round(tot_frames / tot_pin, 1),
                 "host_parse_emit_frames_per_s_one_core": round(tot_pictures / tot_parse, 1) if tot_parse else None, "bit_exact": bool(all_ok),
                 "what": "both sides decode the SAME files (two of random syntax, two from the procedural-video encoder tests/golden/nat_encoder.py): GPU = their command packets (reference parser + emitters, parsed in this process) decoded by "
-                        f"{n_streams} concurrent decoders, packets resident in HBM / pageable host packets with validation + H2D inside the timed region; "
+                        f"{n_streams} concurrent decoders, packets resident in HBM / pageable host packets with validation + H2D inside the timed region / page-locked packets vetted by their producer (the front end's own road) with the H2D inside; "
                         "CPU = the unmodified reference decoder on these files (cpu_baseline, same run).  The parser itself is host work on both sides: "
                         "host_parse_emit is what ONE core delivers, the GPU figures are what the device sustains behind enough parsing cores"})
     if cpu and cpu.get("value"):
