@@ -127,9 +127,7 @@ E264_DEV void dbkp_phase_slices(DbkpLds &L, const FrameCtx &f, int tid)
 {
 	if (f.motion)
 		for (int i = tid; i < (2 * DP_MBS + 1) * 2; i += DP_NT) {
-			// tasks ordered by LIST, not by record (round 6): in a P picture the list-1 tasks find nothing to expand -- interleaved with the list-0 tasks every
-			// wave ran the long path (and the first wave twice: 258 tasks on 256 threads); now two and a bit waves do, the others pass through
-			const int l = i >= 2 * DP_MBS + 1 ? 1 : 0, j = i - l * (2 * DP_MBS + 1);
+			const int j = i >> 1, l = i & 1;
 			if ((L.hdr[j][0] & 255) == E264_MB_INTER) {
 				dbkp_expand_list(f.motion, L.hdr[j][5], L.hdr[j][6], l, L.mo[j]);
 				const uint32_t h = L.hdr[j][6];
