@@ -119,6 +119,7 @@ struct E264Packet {
 	uint64_t frame_bytes;  // plane_size_Y + plane_size_C the kernels will touch in every slot the packet names
 	uint32_t ref_mask;     // DPB slots its motion refers to
 	bool pred_work;        // it holds inter or PCM macroblocks (else e264_pred_kernel has nothing to do for it)
+	bool has_l1;           // some macroblock predicts from list 1 (else the parameter kernel's small form will do)
 };
 
 #define E264_JOB_RING 4 // batches in flight per device: one uploading, one in the kernels, one retiring
@@ -615,7 +616,7 @@ static int check_packet(const void *packet, size_t bytes, int *dst, int *n_mbs, 
 // `slot_bytes` (with `slots`): size of every allocated slot -- a packet whose header claims a larger picture than the slot
 // it writes or reads (SPS size change, stale capture, foreign packet) would make the kernels run past the allocation.
 // `ref_mask_out` (may be null): DPB slots the packet's motion refers to.
-static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *slots, const size_t *slot_bytes = nullptr, uint32_t *ref_mask_out = nullptr, bool *pred_work_out = nullptr)
+static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *slots, const size_t *slot_bytes = nullptr, uint32_t *ref_mask_out = nullptr, bool *pred_work_out = nullptr, bool *has_l1_out = nullptr)
 {
 	int dst, n_mbs, r = check_packet(packet, bytes, &dst, &n_mbs);
 	if (r) return r;
@@ -635,6 +636,7 @@ static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *s
 	const uint32_t mot_bytes = h->motion_off ? h->payload_off - h->motion_off : 0;
 	uint32_t ref_mask = 0, n_coded = 0, n_inter = 0;
 	bool pred_work = false; // some macroblock is the prediction kernel's (inter, PCM)
+	bool has_l1 = false;    // some inter macroblock predicts from list 1 (mot_hdr: its uniform bit or one of its quadrant bits)
 	for (int a = 0, col = 0; a < n_mbs; a++, col = col + 1 == h->width_mbs ? 0 : col + 1) {
 		const E264Mb &m = mbs[a];
 		if (m.kind > E264_MB_INTER) return fail(EINVAL, "macroblock kind");
@@ -661,6 +663,7 @@ static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *s
 			if (!mot) return fail(EINVAL, "inter macroblock without motion section");
 			uint32_t d[2];
 			memcpy(d, m.modes, 8); // motion directory: record offset, shape
+			if (E264_MOT_UNI(d[1], 1) || (d[1] >> 4 & 15u)) has_l1 = true;
 			if ((d[0] & 3) || d[1] >> 26 || (uint64_t)d[0] + e264_mot_record_bytes(d[1]) > mot_bytes) return fail(EINVAL, "macroblock motion record");
 			// the record's reference dwords, where they lie (what e264_motion_expand would spread over 8 parts: the uniform form repeats
 			// one dword, an unused quadrant of a partitioned list reads as -1, which is always admissible)
@@ -685,6 +688,7 @@ static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *s
 	if (h->ref_slots != ref_mask) return fail(EINVAL, "header ref_slots differs from the motion records");
 	if (ref_mask_out) *ref_mask_out = ref_mask;
 	if (pred_work_out) *pred_work_out = pred_work;
+	if (has_l1_out) *has_l1_out = has_l1;
 	return 0;
 }
 
@@ -798,7 +802,8 @@ API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
 	int dst, n_mbs, n_tiles, r = check_packet(packet, bytes, &dst, &n_mbs, &n_tiles);
 	if (r) return r;
 	if (!s->h_table[dst]) return fail(EINVAL, "destination slot not allocated");
-	if ((r = check_packet_deep(packet, bytes, s->h_table, s->slot_bytes))) return r;
+	bool has_l1 = true;
+	if ((r = check_packet_deep(packet, bytes, s->h_table, s->slot_bytes, nullptr, nullptr, &has_l1))) return r;
 	if (set_device(s->dev)) return EIO;
 	if ((r = ensure_dbk(s, n_mbs))) return r;
 	E264Stream::Stage *st = &s->stage[s->stage_next];
@@ -816,7 +821,7 @@ API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
 	hipError_t e = hipMemcpyAsync(st->d, st->h, bytes, hipMemcpyHostToDevice, q);
 	if (e == hipSuccess) e = hipMemcpyAsync(st->d_job, job, sizeof(*job), hipMemcpyHostToDevice, q);
 	uint64_t serial = 0;
-	r = e == hipSuccess ? launch(s->dev, s->lane, st->d_job, 1, n_mbs, n_tiles, E264_RUN_ALL, &serial) : fail(EIO, "hipMemcpyAsync packet", e);
+	r = e == hipSuccess ? launch(s->dev, s->lane, st->d_job, 1, n_mbs, n_tiles, E264_RUN_ALL | (has_l1 ? 0 : E264_RUN_NO_L1), &serial) : fail(EIO, "hipMemcpyAsync packet", e);
 	// whatever was queued reads the staging slot: it is busy until the lane has passed this point, error or not
 	hipEventRecord(st->done, q);
 	st->busy = true;
@@ -857,12 +862,12 @@ API int e264hip_packet_upload(E264Device *dev, const void *packet, size_t bytes,
 	int dst, n_mbs, n_tiles, r = check_packet(packet, bytes, &dst, &n_mbs, &n_tiles);
 	if (r) return r;
 	uint32_t ref_mask = 0;
-	bool pred_work = true;
-	if ((r = check_packet_deep(packet, bytes, nullptr, nullptr, &ref_mask, &pred_work))) return r;
+	bool pred_work = true, has_l1 = true;
+	if ((r = check_packet_deep(packet, bytes, nullptr, nullptr, &ref_mask, &pred_work, &has_l1))) return r;
 	if (set_device(dev)) return EIO;
 	E264Packet *p = new (std::nothrow) E264Packet();
 	if (!p) return fail(ENOMEM, "packet object");
-	p->dev = dev; p->bytes = bytes; p->dst_slot = dst; p->n_mbs = n_mbs; p->n_tiles = n_tiles; p->ref_mask = ref_mask; p->pred_work = pred_work;
+	p->dev = dev; p->bytes = bytes; p->dst_slot = dst; p->n_mbs = n_mbs; p->n_tiles = n_tiles; p->ref_mask = ref_mask; p->pred_work = pred_work; p->has_l1 = has_l1;
 	p->frame_bytes = (uint64_t)((const E264FrameHdr *)packet)->plane_size_Y + ((const E264FrameHdr *)packet)->plane_size_C;
 	if (hipMalloc((void **)&p->d_bytes, bytes) != hipSuccess) { delete p; return fail(ENOMEM, "hipMalloc packet"); }
 	hipError_t e = hipMemcpy(p->d_bytes, packet, bytes, hipMemcpyHostToDevice);
@@ -885,6 +890,7 @@ struct E264Batch {
 	E264Job *d_jobs;
 	int n, max_mbs, max_tiles, lane;
 	bool pred_work; // some packet of the batch has inter / PCM macroblocks (all-intra batches skip the prediction kernel's launch)
+	bool has_l1;    // some packet of the batch predicts from list 1
 	std::vector<std::pair<E264Stream *, int>> writes; // (stream, destination slot) of every job
 };
 
@@ -918,8 +924,8 @@ API int e264hip_batch_create(E264Device *dev, E264Stream *const *streams, E264Pa
 	E264Batch *b = new (std::nothrow) E264Batch();
 	if (!b) return fail(ENOMEM, "batch object");
 	b->dev = dev; b->n = n; b->max_mbs = max_mbs; b->max_tiles = max_tiles; b->lane = streams[0]->lane;
-	b->pred_work = false;
-	for (int i = 0; i < n; i++) b->pred_work = b->pred_work || packets[i]->pred_work;
+	b->pred_work = b->has_l1 = false;
+	for (int i = 0; i < n; i++) { b->pred_work = b->pred_work || packets[i]->pred_work; b->has_l1 = b->has_l1 || packets[i]->has_l1; }
 	for (int i = 0; i < n; i++) b->writes.emplace_back(streams[i], packets[i]->dst_slot);
 	if (hipMalloc((void **)&b->d_jobs, sizeof(E264Job) * n) != hipSuccess) { delete b; return fail(ENOMEM, "hipMalloc jobs"); }
 	hipError_t e = hipMemcpy(b->d_jobs, jobs.data(), sizeof(E264Job) * n, hipMemcpyHostToDevice);
@@ -936,7 +942,7 @@ API int e264hip_batch_submit(E264Batch *b, int mode)
 		if (w.first->lane != b->lane) return fail(EINVAL, "a stream of the batch was bound to another lane after batch_create");
 	uint64_t serial = 0;
 	// (E264_RUN_NO_PRED: internal to the launcher -- every packet of the batch was vetted at upload time and none holds an inter or PCM macroblock)
-	int r = launch(b->dev, b->lane, b->d_jobs, b->n, b->max_mbs, b->max_tiles, (mode & E264_RUN_ALL) | (b->pred_work ? 0 : E264_RUN_NO_PRED), &serial);
+	int r = launch(b->dev, b->lane, b->d_jobs, b->n, b->max_mbs, b->max_tiles, (mode & E264_RUN_ALL) | (b->pred_work ? 0 : E264_RUN_NO_PRED) | (b->has_l1 ? 0 : E264_RUN_NO_L1), &serial);
 	if (!r) for (auto &w : b->writes) { raise_serial(w.first->slot_serial[w.second], serial); raise_serial(w.first->last_serial, serial); }
 	return r;
 }
@@ -998,6 +1004,7 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 	if (!dev || !streams || !packets || !bytes || n <= 0) return fail(EINVAL, "submit_batch_host arguments");
 	if (set_device(dev)) return EIO;
 	std::vector<int> mbs_of((size_t)n), tiles_of((size_t)n), rc((size_t)n, 0), dst_of((size_t)n);
+	std::vector<char> l1_of((size_t)n, 1); // (trusted packets are not walked here: assumed to use list 1)
 	std::vector<std::string> why((size_t)n);
 	for (int i = 0; i < n; i++) {
 		if (!streams[i] || streams[i]->dev != dev) return fail(EINVAL, "batch entry");
@@ -1055,7 +1062,9 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 		std::lock_guard<std::mutex> pg(dev->pool_user);
 		dev->pool.parallel_for(n, [&](int i) {
 			E264Stream *s = streams[i];
-			int r = trusted ? check_slots_of(s, (const E264FrameHdr *)packets[i]) : check_packet_deep(packets[i], bytes[i], s->h_table, s->slot_bytes);
+			bool l1 = true;
+			int r = trusted ? check_slots_of(s, (const E264FrameHdr *)packets[i]) : check_packet_deep(packets[i], bytes[i], s->h_table, s->slot_bytes, nullptr, nullptr, &l1);
+			l1_of[i] = l1;
 			if (r) { rc[i] = r; why[i] = g_err; return; } // the message lives in the worker's thread-local buffer
 			if (stage) memcpy(jr.ph + off_of[i], packets[i], bytes[i]);
 		});
@@ -1081,8 +1090,10 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 		e = hipEventRecord(jr.up, up);
 		if (e == hipSuccess) e = hipStreamWaitEvent(q, jr.up, 0);
 	}
+	bool batch_l1 = false;
+	for (int i = 0; i < n; i++) batch_l1 = batch_l1 || l1_of[i];
 	uint64_t serial = 0;
-	int r = e == hipSuccess ? launch(dev, lane, jr.d, n, max_mbs, max_tiles, mode & E264_RUN_ALL, &serial) : fail(EIO, "packet upload", e);
+	int r = e == hipSuccess ? launch(dev, lane, jr.d, n, max_mbs, max_tiles, (mode & E264_RUN_ALL) | (batch_l1 ? 0 : E264_RUN_NO_L1), &serial) : fail(EIO, "packet upload", e);
 	if (r && up != q) hipStreamSynchronize(up); // copies already queued must not outlive the error return unguarded
 	// the job table and the staging slots are busy until the lane has passed this point -- also on an error above: whatever
 	// part of the batch was queued still reads them

@@ -39,10 +39,16 @@ namespace {
 #define DP_MBS 64
 #define DP_NT 256
 #define DP_RAW 64
-struct __attribute__((aligned(16))) DbkpLds {
+// HAS_L1 = false (round 6): the launcher knows that no packet of the batch predicts from list 1 (every P and I picture: found by the validation that vets a
+// packet anyway) -- the expanded motion has no room for list 1 (80 instead of 144 bytes per record): 18.9 KB of LDS instead of 27.2, EIGHT workgroups per CU
+// instead of six.  This kernel is two dependent trips to memory and three barriers: 0.244 -> 0.192 ms per launch (profiles/r06_ablations.txt item 13).
+template <bool HAS_L1_>
+struct __attribute__((aligned(16))) DbkpLdsT {
+	static constexpr bool HAS_L1 = HAS_L1_;
+	static constexpr int MO = HAS_L1_ ? 36 : 20; // dwords of expanded motion per record: references of both lists (2, 2 unused), 16 vectors per list
 	uint32_t hdr[2 * DP_MBS + 1][8];   // E264Mb: [0] left neighbour of the first macroblock, [1..64] own, [65..128] top neighbours
 	union {
-		uint32_t mo[2 * DP_MBS + 1][36];               // motion in expanded (E264Motion) form, same order; filled from the compact records
+		uint32_t mo[2 * DP_MBS + 1][MO];               // motion in expanded (E264Motion) form, same order; filled from the compact records
 		uint32_t pieces[DP_MBS][E264_DBK_BYTES / 4];   // (once the comparisons are done) the records in the lanes' layout, on their way out
 	};
 	uint32_t out[DP_MBS][DP_RAW / 4];  // raw records
@@ -50,8 +56,12 @@ struct __attribute__((aligned(16))) DbkpLds {
 	uint8_t alpha[52], beta[52];
 	uint32_t tc3[52];                  // per indexA: bytes {0, tC0 of bS 1, of bS 2, of bS 3} (bS 0 and 4 have no tC0: entry bS & 3 = 0)
 	uint32_t any_l1;                   // some record of the workgroup (own, left, top) predicts from list 1
+#ifdef E264_DBKP_LDS_PAD // measuring aid: the kernel at a lower occupancy (bytes of LDS nobody uses)
+	uint8_t pad[E264_DBKP_LDS_PAD];
+#endif
 };
-static_assert(sizeof(((DbkpLds *)0)->pieces) <= sizeof(((DbkpLds *)0)->mo), "the pieces reuse the motion area");
+typedef DbkpLdsT<true> DbkpLds;
+static_assert(sizeof(((DbkpLdsT<true> *)0)->pieces) <= sizeof(((DbkpLdsT<true> *)0)->mo) && sizeof(((DbkpLdsT<false> *)0)->pieces) <= sizeof(((DbkpLdsT<false> *)0)->mo), "the pieces reuse the motion area");
 
 #ifndef E264_HOST_INTRINSICS
 E264_DEV void dbkp_note_l1(uint32_t *p) { atomicOr(p, 1u); }
@@ -66,7 +76,7 @@ E264_DEV int dbkp_addr(const FrameCtx &f, int a0, int j)
 	return min(max(a, 0), n - 1); // clamped: a record that is not a real neighbour is never used (the edge flags gate it)
 }
 
-E264_DEV void dbkp_phase_load(DbkpLds &L, const FrameCtx &f, int a0, int tid)
+template <class LDS> E264_DEV void dbkp_phase_load(LDS &L, const FrameCtx &f, int a0, int tid)
 {
 	const gu8 *mbs_g = f.payload - f.h->payload_off + f.h->mbs_off;
 	for (int i = tid; i < (2 * DP_MBS + 1) * 2; i += DP_NT) { // 32-byte records: 2 pieces of 16 bytes
@@ -123,12 +133,14 @@ E264_DEV void dbkp_expand_list(const gu8 *motion, uint32_t mot_off, uint32_t h, 
 }
 
 // after the records have landed: the motion of the inter macroblocks among them (one task per record and list); slice offsets
-E264_DEV void dbkp_phase_slices(DbkpLds &L, const FrameCtx &f, int tid)
+template <class LDS> E264_DEV void dbkp_phase_slices(LDS &L, const FrameCtx &f, int tid)
 {
 	if (f.motion)
 		for (int i = tid; i < (2 * DP_MBS + 1) * 2; i += DP_NT) {
 			const int j = i >> 1, l = i & 1;
 			if ((L.hdr[j][0] & 255) == E264_MB_INTER) {
+				if (!LDS::HAS_L1 && l) // (no room for it and, by the launcher's word, nothing to put there)
+					continue;
 				dbkp_expand_list(f.motion, L.hdr[j][5], L.hdr[j][6], l, L.mo[j]);
 				const uint32_t h = L.hdr[j][6];
 				if (l && (E264_MOT_UNI(h, 1) || (h >> 4 & 15u))) dbkp_note_l1(&L.any_l1); // (E264_MOT_USED(h, 4..7): the quadrants of list 1)
@@ -224,7 +236,7 @@ E264_DEV void dbkp_ab3(const uint32_t *hm, const uint32_t *hL, const uint32_t *h
 
 // four threads per macroblock: thread r computes the bS of two (direction, edge) pairs -- 8 bytes of the record -- and, r < 3,
 // alpha / beta / indexA of plane r; r == 3 clears the tail of the record
-E264_DEV void dbkp_phase_compute(DbkpLds &L, const FrameCtx &f, int a0, int tid)
+template <class LDS> E264_DEV void dbkp_phase_compute(LDS &L, const FrameCtx &f, int a0, int tid)
 {
 	const bool has_motion = f.motion != nullptr;
 	const int n_mbs = f.wm * f.hm;
@@ -234,7 +246,7 @@ E264_DEV void dbkp_phase_compute(DbkpLds &L, const FrameCtx &f, int a0, int tid)
 	const bool on = a0 + i < n_mbs && (h0 >> 8 & E264_MBF_DEBLOCK) && (h0 & 255) != E264_MB_ABSENT;
 	const int dir = r >> 1, e0 = (r & 1) * 2;
 	v2u bs;
-	if (L.any_l1) { // (uniform over the workgroup)
+	if (LDS::HAS_L1 && L.any_l1) { // (uniform over the workgroup)
 		bs.x = dbkp_bs4<true>(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], L.mo[rt], has_motion, on, dir, e0);
 		bs.y = dbkp_bs4<true>(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], L.mo[rt], has_motion, on, dir, e0 + 1);
 	} else {
@@ -286,7 +298,7 @@ E264_DEV v4u dbkp_mbwide(const uint8_t *rec)
 // four slots gathered into one dword, "bS != 0" as a byte mask, and the tC0 of all four out of ONE byte permute whose selector is bS itself
 // (L.tc3[indexA] = {0, tC0 of bS 1, 2, 3}: the macroblock-edge entry in the low source, the inner-edge entry in the high one).
 E264_DEV uint32_t dbkp_byte(const uint32_t *w, int k) { return w[k >> 2] >> (8 * (k & 3)) & 255u; } // byte k of the raw record's dwords 8..15 (k - 32)
-E264_DEV void dbkp_phase_pieces(DbkpLds &L, int tid)
+template <class LDS> E264_DEV void dbkp_phase_pieces(LDS &L, int tid)
 {
 	const int i = tid >> 2, r = tid & 3, dir = r >> 1, s0 = (r & 1) * 2;
 	const v4u B = *(const v4u *)&L.out[i][dir * 4]; // bS of edges 0..3, one segment per byte
@@ -326,7 +338,7 @@ E264_DEV void dbkp_phase_pieces(DbkpLds &L, int tid)
 		                                 dbkp_byte(w, 12) | dbkp_byte(w, 13) << 8 | dbkp_byte(w, 14) << 16 | dbkp_byte(w, 15) << 24, dbkp_byte(w, 16) | dbkp_byte(w, 17) << 8};
 }
 
-E264_DEV void dbkp_phase_store(const DbkpLds &L, const FrameCtx &f, int a0, int tid)
+template <class LDS> E264_DEV void dbkp_phase_store(const LDS &L, const FrameCtx &f, int a0, int tid)
 {
 	const int n_mbs = f.wm * f.hm;
 	constexpr int P16 = E264_DBK_BYTES / 16; // 16-byte pieces per record: consecutive threads write consecutive pieces of consecutive records

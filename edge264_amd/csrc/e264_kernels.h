@@ -20,7 +20,8 @@ struct E264Job {
 #define E264_BITMAP_OFF(n_mbs) ((size_t)(n_mbs) * E264_DBK_BYTES)
 
 #define E264_RUN_NO_PRED 4 // (launcher-internal) no job of the batch has an inter or PCM macroblock: e264_pred_kernel is not launched and the intra kernel scans without its bitmap
-// mode: bit0 reconstruction, bit1 deblocking, bit2 E264_RUN_NO_PRED.  waves: 4, 8 or 16 macroblock rows in flight per frame.
+#define E264_RUN_NO_L1 8   // (launcher-internal) no job of the batch predicts from list 1 (validated packets of I / P pictures): e264_dbkparam2_kernel<false>
+// mode: bit0 reconstruction, bit1 deblocking, bit2 E264_RUN_NO_PRED, bit3 E264_RUN_NO_L1.  waves: 4, 8 or 16 macroblock rows in flight per frame.
 // max_mbs: largest macroblock count among the jobs; max_tiles: largest e264_pred_tiles() among the jobs.  marks: NULL or 5 events (boundaries of the 4 kernels).
 // fork: NULL, or a second queue + events on which the parameter kernel runs beside the macroblock-parallel kernel
 // (amarks: 2 events bracketing it there, recorded when marks != NULL).

@@ -142,9 +142,10 @@ __attribute__((amdgpu_waves_per_eu(E264_PRED_WAVES_PER_EU, E264_PRED_WAVES_PER_E
 
 // Deblocking parameters of every macroblock, 64 consecutive macroblocks per workgroup: records in through LDS with
 // contiguous 16-byte loads, parameters out as contiguous 16-byte stores (e264_dbkp.h; the phases run on the host in tests/emu).
+template <bool HAS_L1>
 __global__ __launch_bounds__(DP_NT) void e264_dbkparam2_kernel(const E264Job *jobs)
 {
-	__shared__ DbkpLds L;
+	__shared__ DbkpLdsT<HAS_L1> L;
 	const int tid = (int)threadIdx.x;
 	FrameCtx f;
 	int bx, by;
@@ -400,6 +401,7 @@ extern "C" const char *e264_kernel_build_flags(void)
 #ifdef E264_ABL_DBKP_NOPIECES
 		" E264_ABL_DBKP_NOPIECES"
 #endif
+
 #ifdef E264_ABL_INTRA_NOFENCE
 		" E264_ABL_INTRA_NOFENCE"
 #endif
@@ -440,6 +442,7 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 	// marks (optional): 5 events recorded before / between / after the four launches
 	if (marks) hipEventRecord(marks[0], stream);
 	const bool dbkp = (mode & 2) != 0;
+	const bool no_l1 = (mode & E264_RUN_NO_L1) != 0; // no packet of the batch predicts from list 1: the parameter kernel's small form (eight workgroups per CU)
 	// fork (optional): the parameter kernel reads nothing but the packet and is needed only by the deblocking kernel, so it
 	// runs on a second queue NEXT TO the macroblock-parallel kernel -- 28 VGPRs per wave, its waves fit beside the two
 	// 215-VGPR waves per SIMD and use issue slots those leave idle.  Ordered after everything enqueued before (the packet
@@ -453,14 +456,17 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 		hipEventRecord(fork->forked, stream);
 		hipStreamWaitEvent(fork->aux, fork->forked, 0);
 		if (marks) hipEventRecord(fork->amarks[0], fork->aux);
-		hipLaunchKernelGGL(e264_dbkparam2_kernel, dim3((max_mbs + DP_MBS - 1) / DP_MBS, n_jobs), dim3(DP_NT), 0, fork->aux, jobs);
+		if (no_l1) hipLaunchKernelGGL(e264_dbkparam2_kernel<false>, dim3((max_mbs + DP_MBS - 1) / DP_MBS, n_jobs), dim3(DP_NT), 0, fork->aux, jobs);
+		else hipLaunchKernelGGL(e264_dbkparam2_kernel<true>, dim3((max_mbs + DP_MBS - 1) / DP_MBS, n_jobs), dim3(DP_NT), 0, fork->aux, jobs);
 		if (marks) hipEventRecord(fork->amarks[1], fork->aux);
 		hipEventRecord(fork->joined, fork->aux);
 	};
 	if (where == 1)
 		launch_side();
-	else if (dbkp && !side)
-		hipLaunchKernelGGL(e264_dbkparam2_kernel, dim3((max_mbs + DP_MBS - 1) / DP_MBS, n_jobs), dim3(DP_NT), 0, stream, jobs);
+	else if (dbkp && !side) {
+		if (no_l1) hipLaunchKernelGGL(e264_dbkparam2_kernel<false>, dim3((max_mbs + DP_MBS - 1) / DP_MBS, n_jobs), dim3(DP_NT), 0, stream, jobs);
+		else hipLaunchKernelGGL(e264_dbkparam2_kernel<true>, dim3((max_mbs + DP_MBS - 1) / DP_MBS, n_jobs), dim3(DP_NT), 0, stream, jobs);
+	}
 	if (marks) hipEventRecord(marks[1], stream);
 	// an all-intra batch (every picture of an I launch: E264_RUN_NO_PRED) has nothing for the prediction kernel: 34 816 workgroups that load their records and
 	// leave cost 0.12 ms per launch of 256 pictures; the intra kernel then scans without the bitmap those workgroups would have written

@@ -41,7 +41,11 @@ extern "C" __attribute__((visibility("default"))) int e264emu_pred_frame(const u
 
 // e264_dbkparam2_kernel: out = E264_DBK_BYTES (256) per macroblock, the pieces of the deblocking lanes' layout; raw (may be NULL) = the 64-byte
 // raw records (bS, alpha, beta, indexA) the pieces are made of, as they stand in LDS between the kernel's phases
-extern "C" __attribute__((visibility("default"))) int e264emu_dbkparam_frame2(const uint8_t *pkt, uint8_t *out, uint8_t *raw)
+template <bool HAS_L1> static int emu_dbkparam(const uint8_t *pkt, uint8_t *out, uint8_t *raw);
+extern "C" __attribute__((visibility("default"))) int e264emu_dbkparam_frame2(const uint8_t *pkt, uint8_t *out, uint8_t *raw) { return emu_dbkparam<true>(pkt, out, raw); }
+// the kernel's small form (no room for list 1 in LDS): for pictures that do not predict from list 1 only -- the launcher's choice on the device
+extern "C" __attribute__((visibility("default"))) int e264emu_dbkparam_frame2_nol1(const uint8_t *pkt, uint8_t *out, uint8_t *raw) { return emu_dbkparam<false>(pkt, out, raw); }
+template <bool HAS_L1> static int emu_dbkparam(const uint8_t *pkt, uint8_t *out, uint8_t *raw)
 {
 	uint8_t dummy = 0;
 	uint8_t *dpb[E264_MAX_SLOTS];
@@ -50,7 +54,7 @@ extern "C" __attribute__((visibility("default"))) int e264emu_dbkparam_frame2(co
 	FrameCtx f;
 	if (!open_frame(f, job))
 		return -1;
-	static DbkpLds L;
+	static DbkpLdsT<HAS_L1> L;
 	const int n = f.wm * f.hm;
 	for (int a0 = 0; a0 < n; a0 += DP_MBS) {
 		memset(&L, 0xA5, sizeof(L));

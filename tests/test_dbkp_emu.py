@@ -25,6 +25,8 @@ def emu():
     lib.e264emu_dbkparam_raw.restype = C.c_int
     lib.e264emu_dbkparam_frame2.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p]
     lib.e264emu_dbkparam_frame2.restype = C.c_int
+    lib.e264emu_dbkparam_frame2_nol1.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p]
+    lib.e264emu_dbkparam_frame2_nol1.restype = C.c_int
     lib.e264emu_dbk_pieces.argtypes = [C.c_void_p, C.c_void_p]
     lib.e264emu_dbk_pieces.restype = None
     return lib
@@ -91,4 +93,11 @@ def test_dbkparam_emu(emu, name, gop, w, h, kw):
         for a in range(n):
             emu.e264emu_dbk_pieces(got[a].ctypes.data, exp[a].ctypes.data)
         assert np.array_equal(pieces, exp), f"{name} frame {ft}: pieces differ at macroblocks {np.nonzero((pieces != exp).any(1))[0][:8].tolist()}"
+        # the kernel's small form (e264_dbkparam2_kernel<false>: no room for list 1 in LDS, eight workgroups per CU): what the launcher picks for batches whose
+        # validated packets do not predict from list 1 -- every I and P picture: the same records
+        if ft != "B":
+            p2 = np.full((n, 144), 0xA5, np.uint8)
+            r2 = np.zeros((n, 64), np.uint8)
+            assert emu.e264emu_dbkparam_frame2_nol1(pkt, p2.ctypes.data, r2.ctypes.data) == 0
+            assert np.array_equal(r2, got) and np.array_equal(p2, exp), f"{name} frame {ft}: the small form differs"
 
