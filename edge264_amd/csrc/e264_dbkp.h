@@ -46,11 +46,16 @@ template <bool HAS_L1_>
 struct __attribute__((aligned(16))) DbkpLdsT {
 	static constexpr bool HAS_L1 = HAS_L1_;
 	static constexpr int MO = HAS_L1_ ? 36 : 20; // dwords of expanded motion per record: references of both lists (2, 2 unused), 16 vectors per list
+	// TOPC (the full form, round 6): a TOP neighbour is only ever compared along its bottom row of 4x4 blocks -- its motion is kept as 9 dwords (the references of its
+	// two lower quadrants of both lists as bytes, four vectors per list) instead of 36: 20.3 KB instead of 27.2, eight workgroups per CU for B pictures too
+	static constexpr bool TOPC = HAS_L1_;
+	static constexpr int NFULL = TOPC ? DP_MBS + 1 : 2 * DP_MBS + 1; // records whose motion is kept in full: [0] the left neighbour, [1..64] own (, [65..128] top)
 	uint32_t hdr[2 * DP_MBS + 1][8];   // E264Mb: [0] left neighbour of the first macroblock, [1..64] own, [65..128] top neighbours
 	union {
-		uint32_t mo[2 * DP_MBS + 1][MO];               // motion in expanded (E264Motion) form, same order; filled from the compact records
+		uint32_t mo[NFULL][MO];                        // motion in expanded (E264Motion) form, same order; filled from the compact records
 		uint32_t pieces[DP_MBS][E264_DBK_BYTES / 4];   // (once the comparisons are done) the records in the lanes' layout, on their way out
 	};
+	uint32_t mot[TOPC ? DP_MBS : 1][9]; // TOPC: top neighbour i: [0] = {l0 ref of quadrant 2, of 3, l1 ref of 2, of 3}, [1..4] l0 vectors of blocks 10 11 14 15, [5..8] l1
 	uint32_t out[DP_MBS][DP_RAW / 4];  // raw records
 	int8_t fo[DP_MBS][2];              // FilterOffsetA / B of each macroblock's slice
 	uint8_t alpha[52], beta[52];
@@ -91,7 +96,7 @@ template <class LDS> E264_DEV void dbkp_phase_load(LDS &L, const FrameCtx &f, in
 // One list of a macroblock's compact motion record (edge264_cmd.h E264_MOT_*) -> the per-4x4 form the comparisons index:
 // mo[l] = the four quadrants' DPB slots as bytes (0xff: unused), mo[4 + l * 16 + k] = vector of 4x4 block k (unused: 0).
 // Every offset follows from the shape word alone, so the loads do not wait for one another.
-E264_DEV void dbkp_expand_list(const gu8 *motion, uint32_t mot_off, uint32_t h, int l, uint32_t *mo)
+E264_DEV void dbkp_expand_list(const gu8 *motion, uint32_t mot_off, uint32_t h, int l, uint32_t *mo, const bool bottom_row_only = false)
 {
 	uint32_t off = mot_off;
 	if (l) { // skip the list-0 part
@@ -105,7 +110,7 @@ E264_DEV void dbkp_expand_list(const gu8 *motion, uint32_t mot_off, uint32_t h, 
 	uint32_t refs = 0xffffffffu;
 	v4u mv[4];
 #ifdef E264_ABL_DBKP_NOMOT // timing ablation: the motion records are not read (wrong bS): 0.225 -> 0.157 ms, profiles/r03_ablations.txt item 17
-	if (off != 0xfffffffcu) { mo[l] = off; for (int q = 0; q < 4; q++) *(v4u *)&mo[4 + l * 16 + q * 4] = (v4u){off, h, off, h}; return; }
+	if (off != 0xfffffffcu && !bottom_row_only) { mo[l] = off; for (int q = 0; q < 4; q++) *(v4u *)&mo[4 + l * 16 + q * 4] = (v4u){off, h, off, h}; return; }
 #endif
 	if (E264_MOT_UNI(h, l)) {
 		const uint32_t r = rec[0], v = rec[1];
@@ -127,6 +132,11 @@ E264_DEV void dbkp_expand_list(const gu8 *motion, uint32_t mot_off, uint32_t h, 
 			rec += 1 + mot_nmv(sub);
 		}
 	}
+	if (bottom_row_only) { // a top neighbour (DbkpLdsT::mot): the two lower quadrants' references, the four vectors of its bottom row
+		((uint16_t *)mo)[l] = (uint16_t)(refs >> 16);
+		mo[1 + l * 4] = mv[2].z; mo[2 + l * 4] = mv[2].w; mo[3 + l * 4] = mv[3].z; mo[4 + l * 4] = mv[3].w;
+		return;
+	}
 	mo[l] = refs;
 #pragma unroll
 	for (int q = 0; q < 4; q++) *(v4u *)&mo[4 + l * 16 + q * 4] = mv[q];
@@ -141,7 +151,8 @@ template <class LDS> E264_DEV void dbkp_phase_slices(LDS &L, const FrameCtx &f, 
 			if ((L.hdr[j][0] & 255) == E264_MB_INTER) {
 				if (!LDS::HAS_L1 && l) // (no room for it and, by the launcher's word, nothing to put there)
 					continue;
-				dbkp_expand_list(f.motion, L.hdr[j][5], L.hdr[j][6], l, L.mo[j]);
+				if (LDS::TOPC && j > DP_MBS) dbkp_expand_list(f.motion, L.hdr[j][5], L.hdr[j][6], l, L.mot[j - DP_MBS - 1], true);
+				else dbkp_expand_list(f.motion, L.hdr[j][5], L.hdr[j][6], l, L.mo[LDS::TOPC && j > DP_MBS ? 0 : j]);
 				const uint32_t h = L.hdr[j][6];
 				if (l && (E264_MOT_UNI(h, 1) || (h >> 4 & 15u))) dbkp_note_l1(&L.any_l1); // (E264_MOT_USED(h, 4..7): the quadrants of list 1)
 			}
@@ -172,7 +183,8 @@ E264_DEV uint32_t dbkp_absdiff2(uint32_t A, uint32_t B)
 // L1 = false (round 5): no record of the workgroup predicts from list 1 (every workgroup of a P picture): the list-1 halves of the comparison are
 // constants -- references 0xff on both sides, vectors 0 -- so "same lists" reduces to the list-0 reference and vector, and "crossed lists" is always a
 // difference (a used list-0 slot against 0xff).  A quarter of the vector arithmetic of the general form.
-template <bool L1>
+// TOPC: the top neighbour's motion (mT) is in the 9-dword form of DbkpLdsT::mot
+template <bool L1, bool TOPC>
 E264_DEV uint32_t dbkp_bs4(const uint32_t *hm, const uint32_t *mm, const uint32_t *hL, const uint32_t *mL, const uint32_t *hT, const uint32_t *mT,
 	bool has_motion, bool on, int dir, int e)
 {
@@ -200,17 +212,22 @@ E264_DEV uint32_t dbkp_bs4(const uint32_t *hm, const uint32_t *mm, const uint32_
 		const int o = (int)(offs >> (4 * sg) & 15u), kq = qb + o, kp = pb + o;
 		uint32_t bs = ((nzp >> kp | nzq >> kq) & 1u) ? 2u : 0u;
 		if (has_motion) { // (uniform) references as bytes (unused list: 0xff), vectors biased for dbkp_absdiff2 (unused list: 0)
-			const int sq = (kq >> 2) * 8, sp = (kp >> 2) * 8;
+			const int sq = (kq >> 2) * 8;
+			// where the p side's references and vectors are: the full form, or (top edge, TOPC) the top neighbour's bottom-row form: kp is 10, 11, 14 or 15 there
+			const bool top = TOPC && e == 0 && dir == 1;
+			const int tq = (kp >> 2) & 1, ci = tq * 2 + (kp & 1);
+			const int sp = top ? 8 * tq : (kp >> 2) * 8, sp1 = top ? 16 + 8 * tq : sp;
+			const int ip0 = top ? 1 + ci : 4 + kp, ip1 = top ? 5 + ci : 20 + kp, ir1 = top ? 0 : 1;
 			if (L1) {
-				const uint32_t q0 = mm[0] >> sq & 255u, q1 = mm[1] >> sq & 255u, p0 = mn[0] >> sp & 255u, p1 = mn[1] >> sp & 255u;
-				const uint32_t vq0 = mm[4 + kq] ^ DBKP_BIAS, vq1 = mm[20 + kq] ^ DBKP_BIAS, vp0 = mn[4 + kp] ^ DBKP_BIAS, vp1 = mn[20 + kp] ^ DBKP_BIAS;
+				const uint32_t q0 = mm[0] >> sq & 255u, q1 = mm[1] >> sq & 255u, p0 = mn[0] >> sp & 255u, p1 = mn[ir1] >> sp1 & 255u;
+				const uint32_t vq0 = mm[4 + kq] ^ DBKP_BIAS, vq1 = mm[20 + kq] ^ DBKP_BIAS, vp0 = mn[ip0] ^ DBKP_BIAS, vp1 = mn[ip1] ^ DBKP_BIAS;
 				// same lists, or crossed (deblock.c:913-925): a difference either way
 				const uint32_t par = (p0 ^ q0) | (p1 ^ q1) | ((dbkp_absdiff2(vp0, vq0) | dbkp_absdiff2(vp1, vq1)) & DBKP_FAR);
 				const uint32_t crs = (p0 ^ q1) | (p1 ^ q0) | ((dbkp_absdiff2(vp0, vq1) | dbkp_absdiff2(vp1, vq0)) & DBKP_FAR);
 				if (bs == 0) bs = (par != 0 && crs != 0) ? 1u : 0u;
 			} else { // list 0 only on both sides (the bias cancels in the difference)
 				const uint32_t q0 = mm[0] >> sq & 255u, p0 = mn[0] >> sp & 255u;
-				const uint32_t par = (p0 ^ q0) | (dbkp_absdiff2(mn[4 + kp] ^ DBKP_BIAS, mm[4 + kq] ^ DBKP_BIAS) & DBKP_FAR);
+				const uint32_t par = (p0 ^ q0) | (dbkp_absdiff2(mn[ip0] ^ DBKP_BIAS, mm[4 + kq] ^ DBKP_BIAS) & DBKP_FAR);
 				if (bs == 0) bs = par != 0 ? 1u : 0u;
 			}
 		}
@@ -246,12 +263,13 @@ template <class LDS> E264_DEV void dbkp_phase_compute(LDS &L, const FrameCtx &f,
 	const bool on = a0 + i < n_mbs && (h0 >> 8 & E264_MBF_DEBLOCK) && (h0 & 255) != E264_MB_ABSENT;
 	const int dir = r >> 1, e0 = (r & 1) * 2;
 	v2u bs;
+	const uint32_t *mtop = LDS::TOPC ? L.mot[LDS::TOPC ? i : 0] : L.mo[LDS::TOPC ? 0 : rt]; // the top neighbour's motion, in the form this LDS keeps it
 	if (LDS::HAS_L1 && L.any_l1) { // (uniform over the workgroup)
-		bs.x = dbkp_bs4<true>(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], L.mo[rt], has_motion, on, dir, e0);
-		bs.y = dbkp_bs4<true>(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], L.mo[rt], has_motion, on, dir, e0 + 1);
+		bs.x = dbkp_bs4<true, LDS::TOPC>(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], mtop, has_motion, on, dir, e0);
+		bs.y = dbkp_bs4<true, LDS::TOPC>(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], mtop, has_motion, on, dir, e0 + 1);
 	} else {
-		bs.x = dbkp_bs4<false>(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], L.mo[rt], has_motion, on, dir, e0);
-		bs.y = dbkp_bs4<false>(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], L.mo[rt], has_motion, on, dir, e0 + 1);
+		bs.x = dbkp_bs4<false, LDS::TOPC>(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], mtop, has_motion, on, dir, e0);
+		bs.y = dbkp_bs4<false, LDS::TOPC>(L.hdr[rm], L.mo[rm], L.hdr[rl], L.mo[rl], L.hdr[rt], mtop, has_motion, on, dir, e0 + 1);
 	}
 	*(v2u *)&L.out[i][2 * r] = bs;
 	uint8_t *o8 = (uint8_t *)&L.out[i][0];

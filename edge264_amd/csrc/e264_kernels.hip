@@ -143,9 +143,8 @@ __attribute__((amdgpu_waves_per_eu(E264_PRED_WAVES_PER_EU, E264_PRED_WAVES_PER_E
 // Deblocking parameters of every macroblock, 64 consecutive macroblocks per workgroup: records in through LDS with
 // contiguous 16-byte loads, parameters out as contiguous 16-byte stores (e264_dbkp.h; the phases run on the host in tests/emu).
 template <bool HAS_L1>
-__global__ __launch_bounds__(DP_NT) void e264_dbkparam2_kernel(const E264Job *jobs)
+static __device__ __forceinline__ void dbkparam2_body(DbkpLdsT<HAS_L1> &L, const E264Job *jobs)
 {
-	__shared__ DbkpLdsT<HAS_L1> L;
 	const int tid = (int)threadIdx.x;
 	FrameCtx f;
 	int bx, by;
@@ -166,6 +165,19 @@ __global__ __launch_bounds__(DP_NT) void e264_dbkparam2_kernel(const E264Job *jo
 #endif
 	__syncthreads();
 	dbkp_phase_store(L, f, a0, tid);
+}
+// Two forms of one kernel (e264_dbkp.h): <false> for batches the launcher knows to be without list-1 motion (18.6 KB of LDS, 52 VGPRs as the compiler likes them: eight
+// workgroups per CU), <true> the general one -- 19.9 KB, and held to 64 VGPRs (two of them spill) so that the register file, too, takes eight workgroups
+template <bool HAS_L1> __global__ void e264_dbkparam2_kernel(const E264Job *jobs);
+template <> __global__ __launch_bounds__(DP_NT) void e264_dbkparam2_kernel<false>(const E264Job *jobs)
+{
+	__shared__ DbkpLdsT<false> L;
+	dbkparam2_body<false>(L, jobs);
+}
+template <> __attribute__((amdgpu_waves_per_eu(8, 8))) __global__ __launch_bounds__(DP_NT) void e264_dbkparam2_kernel<true>(const E264Job *jobs)
+{
+	__shared__ DbkpLdsT<true> L;
+	dbkparam2_body<true>(L, jobs);
 }
 
 template <int NW>

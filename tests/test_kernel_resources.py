@@ -6,7 +6,7 @@ and not as an unexplained slowdown on the next GPU visit:
   e264_pred_kernel          4 workgroups of 256 threads per CU: <= 128 VGPRs, <= 40 KB of LDS (160 KB / 4)
   e264_intra_kernel<16>     16 waves of one workgroup per CU:   <= 128 VGPRs (4 waves per SIMD), one workgroup's LDS <= 160 KB
   e264_deblock2_kernel<8>   8 waves per CU:                     <= 256 VGPRs (2 waves per SIMD), LDS <= 160 KB
-  e264_dbkparam2_kernel     >= 5 workgroups per CU:             <= 96 VGPRs, <= 32 KB of LDS
+  e264_dbkparam2_kernel     8 workgroups per CU (both forms):   <= 64 VGPRs, <= 20 KB of LDS
 """
 import os
 import re
@@ -23,7 +23,7 @@ BUDGET = {  # kernel name fragment -> (max VGPRs, max LDS bytes per workgroup)
     "e264_pred_kernel": (128, 160 * 1024 // 4),
     "e264_intra_kernelILi16E": (128, 160 * 1024),
     "e264_deblock2_kernelILi8E": (256, 160 * 1024),
-    "e264_dbkparam2_kernel": (96, 32 * 1024),
+    "e264_dbkparam2_kernel": (64, 160 * 1024 // 8),
 }
 
 
@@ -46,6 +46,9 @@ def test_kernels_fit_their_occupancy_budgets(tmp_path):
         hits = {k: v for k, v in kernels.items() if frag in k}
         assert hits, f"{frag}: not in the compiler's report ({sorted(kernels)})"
         for name, r in hits.items():
-            assert r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, f"{name}: spills ({r})"
+            if "dbkparam2_kernelILb1E" in name:  # the general form of the parameter kernel is HELD to 64 VGPRs for eight workgroups per CU: two registers spill, by choice
+                assert r["VGPRs Spill"] <= 2 and r["ScratchSize"] <= 16, f"{name}: spills more than the two registers it was measured with ({r})"
+            else:
+                assert r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, f"{name}: spills ({r})"
             assert r["VGPRs"] + r.get("AGPRs", 0) <= max_vgpr, f"{name}: {r['VGPRs']} VGPRs > {max_vgpr}"
             assert r["LDS Size"] <= max_lds, f"{name}: {r['LDS Size']} bytes of LDS > {max_lds}"
