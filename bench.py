@@ -285,7 +285,7 @@ def same_input_leg(dev, backend, n_streams, cpu):
     from oracle.cpu_baseline import FIXTURES_1080P  # (the list only: the files the CPU baseline decodes)
     files = [n for n in FIXTURES_1080P if os.path.exists(os.path.join(sdir, n))]
     res = {"files": files, "streams": n_streams, "per_file": {}}
-    tot_frames = tot_res = tot_host = tot_pin = tot_parse = tot_pictures = 0.0
+    tot_frames = tot_res = tot_host = tot_pin = tot_parse = tot_pictures = tot_wire = tot_bytes = tot_wbytes = 0.0
     all_ok = True
     for name in files:
         with open(os.path.join(sdir, name), "rb") as f:
@@ -346,30 +346,61 @@ def same_input_leg(dev, backend, n_streams, cpu):
         t_pin = time.perf_counter() - t0
         for pp in pins:
             dev.pinned_free(pp)
-        # verification (untimed): one more pass from cleared slots, four streams, every picture
+        # the same road with the front end folding its packets (e264front_set_compact(1): the WIRE form, include/edge264_compact.h -- P_Skip / plain
+        # 16x16 macroblocks without residual in 12 bytes instead of 40, unfolded on the device by e264_expand_kernel in front of the four kernels)
+        wire, _, wire_parse_s = front.capture_packets(data, compact=True)
+        front.capture_packets(b"", compact=False)
+        assert len(wire) == len(packets)
+        for p in wire:
+            assert backend.packet_check(p) == 0
+        wpins = [dev.pinned_copy(p) for p in wire]
+        wbs = [dev.prepare_pinned_batch(sts, [wpins[f]] * n_streams, [len(wire[f])] * n_streams) for f in range(len(wire))]
+        for pb in wbs[:2]:
+            dev.submit_pinned_prepared(pb, backend.RUN_ALL)
+        dev.sync()
+        t0 = time.perf_counter()
+        for pb in wbs:
+            dev.submit_pinned_prepared(pb, backend.RUN_ALL)
+        dev.sync()
+        t_wire = time.perf_counter() - t0
+        # verification (untimed): one more pass from cleared slots, four streams, every picture -- resident version-4 packets, then the wire packets
         orc = Oracle()
         dpb = [np.zeros(nb + 64, np.uint8) if used >> i & 1 else None for i in range(32)]
-        for st in sts:
-            for i in slots:
-                st.fill(i, 0)
         probe = sorted({0, n_streams // 3, 2 * n_streams // 3, n_streams - 1})
         bad = 0
-        for f, p in enumerate(packets):
+        want = []
+        for p in packets:
             orc.decode_frame(p, dpb, 3)
-            dev.submit_prepared(bs[f], backend.RUN_ALL)
-            dev.sync()
-            d = int(parsed[f].hdr["dst_slot"])
-            for k in probe:
-                bad += 0 if np.array_equal(sts[k].download(d), dpb[d][:nb]) else 1
+            want.append(dpb[int(P.Packet(p).hdr["dst_slot"])][:nb].copy())
+        for form in ("resident", "wire"):
+            for st in sts:
+                for i in slots:
+                    st.fill(i, 0)
+            for f in range(len(packets)):
+                if form == "resident":
+                    dev.submit_prepared(bs[f], backend.RUN_ALL)
+                else:
+                    dev.submit_pinned_prepared(wbs[f], backend.RUN_ALL)
+                dev.sync()
+                d = int(parsed[f].hdr["dst_slot"])
+                for k in probe:
+                    bad += 0 if np.array_equal(sts[k].download(d), want[f]) else 1
+        del want
+        for pp in wpins:
+            dev.pinned_free(pp)
         all_ok &= bad == 0
         n = len(packets) * n_streams
         res["per_file"][name] = {"pictures": len(packets), "packet_MB_per_picture": round(float(np.mean([len(p) for p in packets])) / 1e6, 3),
                                  "gpu_resident_frames_per_s": round(n / t_res, 1), "gpu_pcie_inclusive_frames_per_s": round(n / t_host, 1),
                                  "gpu_pcie_inclusive_pinned_frames_per_s": round(n / t_pin, 1),
+                                 "wire_MB_per_picture": round(float(np.mean([len(p) for p in wire])) / 1e6, 3),
+                                 "gpu_pcie_inclusive_pinned_wire_frames_per_s": round(n / t_wire, 1),
+                                 "host_parse_emit_wire_frames_per_s_one_core": round(len(packets) / wire_parse_s, 1),
                                  "host_parse_emit_frames_per_s_one_core": round(len(packets) / parse_s, 1),
                                  "kernel_ms_per_launch": {n: round(t / max(l4, 1), 4) for n, t in zip(KERNELS, k4)},
-                                 "pictures_compared": len(packets) * len(probe), "mismatching": bad}
+                                 "pictures_compared": 2 * len(packets) * len(probe), "mismatching": bad}
         tot_frames += n; tot_res += t_res; tot_host += t_host; tot_pin += t_pin; tot_parse += parse_s; tot_pictures += len(packets)
+        tot_wire += t_wire; tot_bytes += sum(len(p) for p in packets); tot_wbytes += sum(len(p) for p in wire)
         for b in bs:
             dev.free_batch(b)
         for row in dpk:
@@ -379,9 +410,10 @@ def same_input_leg(dev, backend, n_streams, cpu):
             st.close()
     res.update({"gpu_resident_frames_per_s": round(tot_frames / tot_res, 1), "gpu_pcie_inclusive_frames_per_s": round(tot_frames / tot_host, 1),
                 "gpu_pcie_inclusive_pinned_frames_per_s": round(tot_frames / tot_pin, 1),
+                "gpu_pcie_inclusive_pinned_wire_frames_per_s": round(tot_frames / tot_wire, 1), "wire_bytes_over_packet_bytes": round(tot_wbytes / tot_bytes, 3),
                 "host_parse_emit_frames_per_s_one_core": round(tot_pictures / tot_parse, 1) if tot_parse else None, "bit_exact": bool(all_ok),
                 "what": "both sides decode the SAME files (two of random syntax, two from the procedural-video encoder tests/golden/nat_encoder.py): GPU = their command packets (reference parser + emitters, parsed in this process) decoded by "
-                        f"{n_streams} concurrent decoders, packets resident in HBM / pageable host packets with validation + H2D inside the timed region / page-locked packets vetted by their producer (the front end's own road) with the H2D inside; "
+                        f"{n_streams} concurrent decoders, packets resident in HBM / pageable host packets with validation + H2D inside the timed region / page-locked packets vetted by their producer (the front end's own road) with the H2D inside, as version-4 packets and in the wire form (version 5, include/edge264_compact.h: the front end folds P_Skip / plain 16x16 macroblocks, e264_expand_kernel unfolds them on the device); "
                         "CPU = the unmodified reference decoder on these files (cpu_baseline, same run).  The parser itself is host work on both sides: "
                         "host_parse_emit is what ONE core delivers, the GPU figures are what the device sustains behind enough parsing cores"})
     if cpu and cpu.get("value"):

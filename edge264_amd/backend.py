@@ -57,6 +57,9 @@ def load_library():
         "e264hip_packet_free": (None, [vp]),
         "e264hip_submit_batch": (i, [vp, C.POINTER(vp), C.POINTER(vp), i, i]),
         "e264hip_packet_check": (i, [vp, sz]),
+        "e264hip_packet_compact_bound": (sz, [vp, sz]),
+        "e264hip_packet_compact": (sz, [vp, sz, vp, sz]),
+        "e264hip_packet_expand": (sz, [vp, sz, vp, sz]),
         "e264hip_submit_batch_host": (i, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), i, i]),
         "e264hip_submit_batch_pinned": (i, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), i, i, i]),
         "e264hip_host_alloc": (vp, [vp, sz]),
@@ -94,7 +97,7 @@ EXPORTED_SYMBOLS = [
     "e264hip_stream_open", "e264hip_stream_close", "e264hip_stream_bind_lane", "e264hip_stream_flush", "e264hip_frame_alloc",
     "e264hip_frame_free", "e264hip_frame_fill", "e264hip_frame_upload", "e264hip_frame_submit",
     "e264hip_packet_buffer", "e264hip_frame_wait", "e264hip_frame_download", "e264hip_packet_upload",
-    "e264hip_packet_free", "e264hip_packet_check", "e264hip_submit_batch", "e264hip_submit_batch_host", "e264hip_submit_batch_pinned", "e264hip_host_alloc", "e264hip_host_free", "e264hip_batch_create", "e264hip_batch_submit", "e264hip_batch_free", "e264hip_event_record", "e264hip_event_elapsed_ms", "e264hip_event_query",
+    "e264hip_packet_free", "e264hip_packet_check", "e264hip_packet_compact_bound", "e264hip_packet_compact", "e264hip_packet_expand", "e264hip_submit_batch", "e264hip_submit_batch_host", "e264hip_submit_batch_pinned", "e264hip_host_alloc", "e264hip_host_free", "e264hip_batch_create", "e264hip_batch_submit", "e264hip_batch_free", "e264hip_event_record", "e264hip_event_elapsed_ms", "e264hip_event_query",
     "e264hip_kernel_timing", "e264hip_kernel_time_ms", "e264hip_set_option", "e264hip_build_flags", "e264hip_frame_device_ptr",
 ]
 
@@ -110,6 +113,32 @@ def packet_check(pkt: bytes) -> int:
     L = load_library()
     buf = (C.c_char * len(pkt)).from_buffer_copy(pkt)
     return L.e264hip_packet_check(C.cast(buf, C.c_void_p), len(pkt))
+
+
+def packet_compact(pkt: bytes) -> bytes:
+    """A version-4 packet in its WIRE form (version 5, include/edge264_compact.h).  Host only."""
+    L = load_library()
+    src = (C.c_char * len(pkt)).from_buffer_copy(pkt)
+    cap = L.e264hip_packet_compact_bound(C.cast(src, C.c_void_p), len(pkt))
+    out = (C.c_char * max(cap, 1))()
+    n = L.e264hip_packet_compact(C.cast(src, C.c_void_p), len(pkt), C.cast(out, C.c_void_p), cap) if cap else 0
+    if not n:
+        raise BackendError(f"packet_compact: {last_error()}")
+    return bytes(out[:n])
+
+
+def packet_expand(pkt: bytes) -> bytes:
+    """A wire packet as the canonical version-4 packet it stands for.  Host only."""
+    L = load_library()
+    src = (C.c_char * len(pkt)).from_buffer_copy(pkt)
+    cap = L.e264hip_packet_expand(C.cast(src, C.c_void_p), len(pkt), None, 0)
+    if not cap:
+        raise BackendError(f"packet_expand: {last_error()}")
+    out = (C.c_char * cap)()
+    n = L.e264hip_packet_expand(C.cast(src, C.c_void_p), len(pkt), C.cast(out, C.c_void_p), cap)
+    if not n:
+        raise BackendError(f"packet_expand: {last_error()}")
+    return bytes(out[:n])
 
 
 def last_error() -> str:

@@ -30,6 +30,7 @@
 
 #include "../../include/edge264_hip.h"
 #include "e264_kernels.h"
+#include "../../include/edge264_compact.h"
 
 #define API extern "C" __attribute__((visibility("default")))
 
@@ -181,6 +182,8 @@ struct E264Stream {
 	size_t slot_bytes[E264_MAX_SLOTS];
 	uint8_t *d_dbk;                       // per-stream scratch of the kernels: E264_SCRATCH_BYTES(dbk_mbs) (deblocking parameters + the intra bitmap)
 	size_t dbk_mbs;
+	uint8_t *d_expand;                    // where e264_expand_kernel unfolds the stream's wire packets (include/edge264_compact.h), expand_cap bytes; NULL until the first one
+	size_t expand_cap;
 	// the slot table reaches the device from a small pinned ring (asynchronous: a pageable source would make hipMemcpyAsync
 	// wait for the queue)
 	enum { NTAB = 4 };
@@ -505,6 +508,7 @@ API void e264hip_stream_close(E264Stream *s)
 		if (st.done) hipEventDestroy(st.done);
 	}
 	mem_release(dev, s->d_dbk, E264_SCRATCH_BYTES(s->dbk_mbs), false, 0, 0);
+	mem_release(dev, s->d_expand, s->expand_cap, false, 0, 0);
 	if (s->dl_done) hipEventDestroy(s->dl_done);
 	for (int i = 0; i < E264Stream::NTAB; i++)
 		if (s->tab_ev[i]) hipEventDestroy(s->tab_ev[i]);
@@ -592,12 +596,23 @@ API int e264hip_frame_upload(E264Stream *s, int slot, const void *src, size_t by
 }
 
 // tiles: workgroups e264_pred_kernel needs for this frame
-static int check_packet(const void *packet, size_t bytes, int *dst, int *n_mbs, int *tiles = nullptr)
+// area (may be null): 0 for a version-4 packet; for a WIRE packet (version 5, include/edge264_compact.h), whose structure is checked here,
+// the bytes its expansion on the device needs
+static int check_packet(const void *packet, size_t bytes, int *dst, int *n_mbs, int *tiles = nullptr, size_t *area = nullptr)
 {
 	const E264FrameHdr *h = (const E264FrameHdr *)packet;
-	if (!packet || bytes < sizeof(*h) || h->magic != E264_MAGIC || h->version != E264_VERSION || h->total_bytes > bytes)
+	if (!packet || bytes < sizeof(*h) || h->magic != E264_MAGIC || (h->version != E264_VERSION && h->version != E264_VERSION_COMPACT) || h->total_bytes > bytes)
 		return fail(EINVAL, "not a command packet");
 	if (h->dst_slot < 0 || h->dst_slot >= E264_MAX_SLOTS) return fail(EINVAL, "dst_slot");
+	if (area) *area = 0;
+	if (h->version == E264_VERSION_COMPACT) {
+		if (e264_check_compact(packet, h->total_bytes)) return fail(EINVAL, "wire packet structure");
+		if (area) *area = e264_expand_area_bytes(packet);
+		*dst = h->dst_slot;
+		*n_mbs = (int)h->width_mbs * h->height_mbs;
+		if (tiles) *tiles = e264_pred_tiles(h->width_mbs, h->height_mbs);
+		return 0;
+	}
 	size_t n_mb = (size_t)h->width_mbs * h->height_mbs;
 	size_t need = (size_t)h->mbs_off + n_mb * sizeof(E264Mb);
 	if (h->motion_off && (h->motion_off < need || (need = (size_t)h->motion_off) > h->total_bytes)) return fail(EINVAL, "motion section");
@@ -622,6 +637,16 @@ static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *s
 	if (r) return r;
 	const E264FrameHdr *h = (const E264FrameHdr *)packet;
 	const uint8_t *p = (const uint8_t *)packet;
+	if (h->version == E264_VERSION_COMPACT) {
+		// a wire packet means what its expansion means: unfolded here (host, this thread's buffer) and walked as the version-4 packet the kernels
+		// will see -- e264_expand_kernel writes the same records and motion section (tests/test_compact.py)
+		static thread_local std::vector<uint8_t> unfolded;
+		const size_t need = e264_expanded_bytes(packet);
+		if (unfolded.size() < need) unfolded.resize(need + need / 4);
+		const size_t got = e264_expand_packet(packet, h->total_bytes, unfolded.data(), unfolded.size());
+		if (!got) return fail(EINVAL, "wire packet expansion");
+		return check_packet_deep(unfolded.data(), got, slots, slot_bytes, ref_mask_out, pred_work_out, has_l1_out);
+	}
 	if (h->width_mbs == 0 || h->height_mbs == 0 || h->height_mbs > 1056) return fail(EINVAL, "frame size");
 	if (h->n_slices == 0 || (size_t)h->slices_off + (size_t)h->n_slices * sizeof(E264SliceParams) > h->mbs_off) return fail(EINVAL, "slice section");
 	if ((h->slices_off | h->mbs_off | h->motion_off | h->payload_off) & 7) return fail(EINVAL, "section alignment");
@@ -698,6 +723,33 @@ API int e264hip_packet_check(const void *packet, size_t bytes)
 	return check_packet_deep(packet, bytes, nullptr);
 }
 
+// The wire form (include/edge264_compact.h) for callers that do not compile C: the Python tools, a binding in another language.
+API size_t e264hip_packet_compact_bound(const void *packet, size_t bytes)
+{
+	const E264FrameHdr *h = (const E264FrameHdr *)packet;
+	return (packet && bytes >= sizeof(*h) && h->magic == E264_MAGIC && h->version == E264_VERSION) ? e264_compact_bound(packet) : 0;
+}
+// version 4 -> version 5; the input must pass e264hip_packet_check (checked here).  Returns the size written, 0 on error (e264hip_last_error).
+API size_t e264hip_packet_compact(const void *packet, size_t bytes, void *out, size_t cap)
+{
+	const E264FrameHdr *h = (const E264FrameHdr *)packet;
+	if (!packet || !out || bytes < sizeof(*h) || h->version != E264_VERSION || check_packet_deep(packet, bytes, nullptr)) { fail(EINVAL, "packet_compact: not a sound version-4 packet"); return 0; }
+	const size_t r = e264_compact_packet(packet, h->total_bytes, out, cap);
+	if (!r) fail(EINVAL, "packet_compact: output buffer too small");
+	return r;
+}
+// version 5 -> the canonical version-4 packet.  out == NULL: the size needed.  0 on error.
+API size_t e264hip_packet_expand(const void *packet, size_t bytes, void *out, size_t cap)
+{
+	int dst, n_mbs;
+	const E264FrameHdr *h = (const E264FrameHdr *)packet;
+	if (check_packet(packet, bytes, &dst, &n_mbs) || h->version != E264_VERSION_COMPACT) { fail(EINVAL, "packet_expand: not a sound wire packet"); return 0; }
+	if (!out) return e264_expanded_bytes(packet);
+	const size_t r = e264_expand_packet(packet, h->total_bytes, out, cap);
+	if (!r) fail(EINVAL, "packet_expand: output buffer too small");
+	return r;
+}
+
 // A packet that has passed e264hip_packet_check (its header summarises its records) against THIS stream's allocations:
 // the destination and every slot of hdr.ref_slots exist and hold a picture of the packet's size.
 static int check_slots_of(const E264Stream *s, const E264FrameHdr *h)
@@ -720,6 +772,17 @@ static int ensure_dbk(E264Stream *s, int n_mbs)
 	s->d_dbk = (uint8_t *)mem_acquire(s->dev, E264_SCRATCH_BYTES(n_mbs), false);
 	s->dbk_mbs = s->d_dbk ? (size_t)n_mbs : 0;
 	return s->d_dbk ? 0 : fail(ENOMEM, "hipMalloc deblock parameters");
+}
+
+// the stream's expansion buffer (wire packets only)
+static int ensure_expand(E264Stream *s, size_t area)
+{
+	if (!area || s->expand_cap >= area) return 0;
+	mem_release(s->dev, s->d_expand, s->expand_cap, false, mark_lane(s->dev, s->lane), s->lane);
+	const size_t cap = (area + area / 4 + 65535) & ~(size_t)65535; // the motion section varies from picture to picture
+	s->d_expand = (uint8_t *)mem_acquire(s->dev, cap, false);
+	s->expand_cap = s->d_expand ? cap : 0;
+	return s->d_expand ? 0 : fail(ENOMEM, "hipMalloc expansion buffer");
 }
 
 // Launches the kernels over a job table that already lives in HBM, on compute lane `lane`.
@@ -799,13 +862,14 @@ API void *e264hip_packet_buffer(E264Stream *s, size_t max_bytes)
 API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
 {
 	if (!s) return fail(EINVAL, "null stream");
-	int dst, n_mbs, n_tiles, r = check_packet(packet, bytes, &dst, &n_mbs, &n_tiles);
+	size_t area = 0;
+	int dst, n_mbs, n_tiles, r = check_packet(packet, bytes, &dst, &n_mbs, &n_tiles, &area);
 	if (r) return r;
 	if (!s->h_table[dst]) return fail(EINVAL, "destination slot not allocated");
 	bool has_l1 = true;
 	if ((r = check_packet_deep(packet, bytes, s->h_table, s->slot_bytes, nullptr, nullptr, &has_l1))) return r;
 	if (set_device(s->dev)) return EIO;
-	if ((r = ensure_dbk(s, n_mbs))) return r;
+	if ((r = ensure_dbk(s, n_mbs)) || (r = ensure_expand(s, area))) return r;
 	E264Stream::Stage *st = &s->stage[s->stage_next];
 	if (packet == st->h && bytes > st->cap) return fail(EINVAL, "packet larger than the buffer e264hip_packet_buffer returned");
 	if (packet != st->h) { // caller did not use our pinned buffer: stage it
@@ -817,11 +881,11 @@ API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
 	hipStream_t q = lane_of(s);
 	// the job record rides at the tail of the pinned staging buffer: tiny H2D on the same queue
 	E264Job *job = (E264Job *)((uint8_t *)st->h + st->cap); // pinned, lives as long as the staging slot
-	job->packet = st->d; job->dpb = s->d_table; job->dbk = s->d_dbk;
+	job->packet = st->d; job->dpb = s->d_table; job->dbk = s->d_dbk; job->expand = area ? s->d_expand : nullptr;
 	hipError_t e = hipMemcpyAsync(st->d, st->h, bytes, hipMemcpyHostToDevice, q);
 	if (e == hipSuccess) e = hipMemcpyAsync(st->d_job, job, sizeof(*job), hipMemcpyHostToDevice, q);
 	uint64_t serial = 0;
-	r = e == hipSuccess ? launch(s->dev, s->lane, st->d_job, 1, n_mbs, n_tiles, E264_RUN_ALL | (has_l1 ? 0 : E264_RUN_NO_L1), &serial) : fail(EIO, "hipMemcpyAsync packet", e);
+	r = e == hipSuccess ? launch(s->dev, s->lane, st->d_job, 1, n_mbs, n_tiles, E264_RUN_ALL | (has_l1 ? 0 : E264_RUN_NO_L1) | (area ? E264_RUN_EXPAND : 0), &serial) : fail(EIO, "hipMemcpyAsync packet", e);
 	// whatever was queued reads the staging slot: it is busy until the lane has passed this point, error or not
 	hipEventRecord(st->done, q);
 	st->busy = true;
@@ -864,6 +928,12 @@ API int e264hip_packet_upload(E264Device *dev, const void *packet, size_t bytes,
 	uint32_t ref_mask = 0;
 	bool pred_work = true, has_l1 = true;
 	if ((r = check_packet_deep(packet, bytes, nullptr, nullptr, &ref_mask, &pred_work, &has_l1))) return r;
+	std::vector<uint8_t> unfolded; // a packet that stays in HBM is kept as the kernels read it: a wire packet is unfolded once, here
+	if (((const E264FrameHdr *)packet)->version == E264_VERSION_COMPACT) {
+		unfolded.resize(e264_expanded_bytes(packet));
+		bytes = e264_expand_packet(packet, ((const E264FrameHdr *)packet)->total_bytes, unfolded.data(), unfolded.size());
+		packet = unfolded.data();
+	}
 	if (set_device(dev)) return EIO;
 	E264Packet *p = new (std::nothrow) E264Packet();
 	if (!p) return fail(ENOMEM, "packet object");
@@ -918,6 +988,7 @@ API int e264hip_batch_create(E264Device *dev, E264Stream *const *streams, E264Pa
 		jobs[i].packet = packets[i]->d_bytes;
 		jobs[i].dpb = streams[i]->d_table;
 		jobs[i].dbk = streams[i]->d_dbk;
+		jobs[i].expand = nullptr; // (resident packets are version 4: e264hip_packet_upload)
 		if (packets[i]->n_mbs > max_mbs) max_mbs = packets[i]->n_mbs;
 		if (packets[i]->n_tiles > max_tiles) max_tiles = packets[i]->n_tiles;
 	}
@@ -1015,11 +1086,13 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 	const int lane = streams[0]->lane;
 	// headers first (cheap, serial): sizes, destination slots
 	int max_mbs = 0, max_tiles = 0;
-	std::vector<size_t> off_of((size_t)n);
+	std::vector<size_t> off_of((size_t)n), area_of((size_t)n);
 	size_t total = 0;
+	bool any_wire = false;
 	for (int i = 0; i < n; i++) {
-		int r = check_packet(packets[i], bytes[i], &dst_of[i], &mbs_of[i], &tiles_of[i]);
+		int r = check_packet(packets[i], bytes[i], &dst_of[i], &mbs_of[i], &tiles_of[i], &area_of[i]);
 		if (r) return r;
+		any_wire = any_wire || area_of[i];
 		if (!streams[i]->h_table[dst_of[i]]) return fail(EINVAL, "destination slot not allocated");
 		if (tiles_of[i] > max_tiles) max_tiles = tiles_of[i];
 		if (mbs_of[i] > max_mbs) max_mbs = mbs_of[i];
@@ -1054,7 +1127,7 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 	for (int i = 0; i < n; i++) { // per-stream buffers (HIP calls: this thread only); the rings advance only when everything is there
 		E264Stream *s = streams[i];
 		int r = ensure_dbk(s, mbs_of[i]);
-		if (r) return r;
+		if (r || (r = ensure_expand(s, area_of[i]))) return r;
 		if (!stage && !(stage_of[i] = stage_prepare(s, bytes[i]))) return ENOMEM;
 	}
 	{ // every packet on its own, in parallel: the per-macroblock walk, and -- while its lines are still in the core's cache -- the copy
@@ -1079,6 +1152,7 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 	for (int i = 0; i < n; i++) {
 		jr.h[i].packet = stage ? jr.pd + off_of[i] : stage_of[i]->d;
 		jr.h[i].dpb = streams[i]->d_table; jr.h[i].dbk = streams[i]->d_dbk;
+		jr.h[i].expand = area_of[i] ? streams[i]->d_expand : nullptr;
 	}
 	if (!stage)
 		for (int i = 0; i < n && e == hipSuccess; i++)
@@ -1093,7 +1167,7 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 	bool batch_l1 = false;
 	for (int i = 0; i < n; i++) batch_l1 = batch_l1 || l1_of[i];
 	uint64_t serial = 0;
-	int r = e == hipSuccess ? launch(dev, lane, jr.d, n, max_mbs, max_tiles, (mode & E264_RUN_ALL) | (batch_l1 ? 0 : E264_RUN_NO_L1), &serial) : fail(EIO, "packet upload", e);
+	int r = e == hipSuccess ? launch(dev, lane, jr.d, n, max_mbs, max_tiles, (mode & E264_RUN_ALL) | (batch_l1 ? 0 : E264_RUN_NO_L1) | (any_wire ? E264_RUN_EXPAND : 0), &serial) : fail(EIO, "packet upload", e);
 	if (r && up != q) hipStreamSynchronize(up); // copies already queued must not outlive the error return unguarded
 	// the job table and the staging slots are busy until the lane has passed this point -- also on an error above: whatever
 	// part of the batch was queued still reads them

@@ -83,7 +83,7 @@ E264_DEV int dbkp_addr(const FrameCtx &f, int a0, int j)
 
 template <class LDS> E264_DEV void dbkp_phase_load(LDS &L, const FrameCtx &f, int a0, int tid)
 {
-	const gu8 *mbs_g = f.payload - f.h->payload_off + f.h->mbs_off;
+	const gu8 *mbs_g = f.mbs_g;
 	for (int i = tid; i < (2 * DP_MBS + 1) * 2; i += DP_NT) { // 32-byte records: 2 pieces of 16 bytes
 		const int j = i >> 1, part = i & 1;
 		*(v4u *)&L.hdr[j][part * 4] = *(const gv4u *)(mbs_g + (size_t)dbkp_addr(f, a0, j) * 32 + part * 16);

@@ -220,6 +220,7 @@ struct FrameCtx {
 	chdr_t h;
 	cslice_t slices;
 	cmb_t mbs;
+	const gu8 *mbs_g;  // the same array through a per-lane (global) pointer
 	const gu8 *motion; // compact motion records (edge264_cmd.h E264_MOT_*), NULL if the frame has no inter macroblock
 	const gu8 *payload;
 	gdpb_t dpb;
@@ -241,13 +242,23 @@ E264_DEV bool open_frame(FrameCtx &f, const E264Job &job)
 {
 	const uint8_t *pkt = job.packet;
 	chdr_t h = (chdr_t)pkt;
-	if (h->magic != E264_MAGIC || h->version != E264_VERSION)
+	if (h->magic != E264_MAGIC)
 		return false;
 	f.h = h;
 	f.slices = (cslice_t)(pkt + h->slices_off);
-	f.mbs = (cmb_t)(pkt + h->mbs_off);
 	f.payload = (const gu8 *)(pkt + h->payload_off);
-	f.motion = h->motion_off ? (const gu8 *)(pkt + h->motion_off) : nullptr;
+	if (h->version == E264_VERSION) {
+		f.mbs = (cmb_t)(pkt + h->mbs_off);
+		f.mbs_g = (const gu8 *)(pkt + h->mbs_off);
+		f.motion = h->motion_off ? (const gu8 *)(pkt + h->motion_off) : nullptr;
+	} else if (h->version == 5u && job.expand) {
+		// a wire packet (include/edge264_compact.h): records and motion section are where e264_expand_kernel has put them, the rest where it lies
+		f.mbs = (cmb_t)job.expand;
+		f.mbs_g = (const gu8 *)job.expand;
+		const uint32_t n_compact = *(const uint32_t E264_AS_CONST *)(pkt + h->mbs_off); // E264CompactHdr.n_compact
+		f.motion = (h->motion_off || n_compact) ? (const gu8 *)job.expand + 32u * (uint32_t)h->width_mbs * (uint32_t)h->height_mbs : nullptr;
+	} else
+		return false;
 	f.dpb_lds = nullptr;
 	f.dpb = (gdpb_t)job.dpb;
 	f.cur = (gu8 *)job.dpb[h->dst_slot];

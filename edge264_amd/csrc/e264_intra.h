@@ -813,7 +813,7 @@ E264_DEV void intra_kernel_body(IntraLds<NW> &S, const E264Job &job, const int t
 	WaveLds &L = lds[wave];
 	if (lane == 0) L.ws_slice = -1;
 	wave_sync();
-	const gu8 *mbs_g = f.payload - f.h->payload_off + f.h->mbs_off; // the E264Mb array through a per-lane (global) pointer
+	const gu8 *mbs_g = f.mbs_g; // the E264Mb array through a per-lane (global) pointer
 	const gu16 *bitmap = (f.dbk && use_bitmap) ? (const gu16 *)(f.dbk + E264_BITMAP_OFF(f.wm * f.hm)) : nullptr;
 	const int ntx16 = (f.wm + 15) >> 4;
 	PH_DECL;

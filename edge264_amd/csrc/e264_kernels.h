@@ -10,6 +10,7 @@ struct E264Job {
 	const uint8_t *packet;
 	uint8_t *const *dpb;
 	uint8_t *dbk; // per-stream scratch, E264_SCRATCH_BYTES(macroblocks) (NULL: no deblocking, no intra bitmap -- host tests only, the back end always has one)
+	uint8_t *expand; // per-stream expansion buffer of a WIRE packet (version 5, include/edge264_compact.h: e264_expand_area_bytes), NULL for a version-4 packet
 };
 #define E264_DBK_BYTES 144 // sixteen 8-byte pieces in the layout of the deblocking kernel's lanes + 16 bytes for the whole macroblock (e264_dbkp.h)
 // The scratch of a stream: the parameter records of n_mbs macroblocks, then the INTRA BITMAP of the picture being decoded: one uint16_t per
@@ -20,8 +21,9 @@ struct E264Job {
 #define E264_BITMAP_OFF(n_mbs) ((size_t)(n_mbs) * E264_DBK_BYTES)
 
 #define E264_RUN_NO_PRED 4 // (launcher-internal) no job of the batch has an inter or PCM macroblock: e264_pred_kernel is not launched and the intra kernel scans without its bitmap
+#define E264_RUN_EXPAND 16 // (launcher-internal) some job of the batch is a wire packet: e264_expand_kernel runs first
 #define E264_RUN_NO_L1 8   // (launcher-internal) no job of the batch predicts from list 1 (validated packets of I / P pictures): e264_dbkparam2_kernel<false>
-// mode: bit0 reconstruction, bit1 deblocking, bit2 E264_RUN_NO_PRED, bit3 E264_RUN_NO_L1.  waves: 4, 8 or 16 macroblock rows in flight per frame.
+// mode: bit0 reconstruction, bit1 deblocking, bit2 E264_RUN_NO_PRED, bit3 E264_RUN_NO_L1, bit4 E264_RUN_EXPAND.  waves: 4, 8 or 16 macroblock rows in flight per frame.
 // max_mbs: largest macroblock count among the jobs; max_tiles: largest e264_pred_tiles() among the jobs.  marks: NULL or 5 events (boundaries of the 4 kernels).
 // fork: NULL, or a second queue + events on which the parameter kernel runs beside the macroblock-parallel kernel
 // (amarks: 2 events bracketing it there, recorded when marks != NULL).

@@ -34,6 +34,7 @@
 #include "e264_pred.h"
 #include "e264_dbkp.h"
 #include "e264_dbk.h"
+#include "e264_expand.h"
 
 namespace {
 // -DE264_PHASE_TIMING: wall cycles of the mbpar kernel's phases, summed over all waves (tools/visits/gpu_phase.sh reads them back
@@ -441,6 +442,14 @@ extern "C" const char *e264_kernel_build_flags(void)
 		;
 }
 
+// ---------------------------------------------------------------------------------
+// Kernel 0 (only for batches with wire packets): version 5 -> the record array and motion section of version 4 (e264_expand.h)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(XP_NT) void e264_expand_kernel(const E264Job *jobs)
+{
+	expand_thread(jobs[blockIdx.y], blockIdx.x * XP_NT + threadIdx.x, gridDim.x * XP_NT);
+}
+
 extern "C" int e264_pred_tiles(int width_mbs, int height_mbs)
 {
 	return ((width_mbs + PT_W - 1) / PT_W) * ((height_mbs + PT_H - 1) / PT_H);
@@ -451,6 +460,9 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 {
 	if (n_jobs <= 0)
 		return hipSuccess;
+	// wire packets first (before the marks: they bracket the four kernels; the whole-run clocks contain this one)
+	if (mode & E264_RUN_EXPAND)
+		hipLaunchKernelGGL(e264_expand_kernel, dim3((max_mbs + XP_NT - 1) / XP_NT, n_jobs), dim3(XP_NT), 0, stream, jobs);
 	// marks (optional): 5 events recorded before / between / after the four launches
 	if (marks) hipEventRecord(marks[0], stream);
 	const bool dbkp = (mode & 2) != 0;

@@ -89,7 +89,7 @@ E264_DEV void pred_phase_setup(PredLds &L, const FrameCtx &f, const PredTile &t,
 	if (tid < PT_MBS / 32) L.staged[tid] = 0;
 	if (tid == 0) { L.any_l1 = 0; L.n_inter = 0; L.n_uni = 0; }
 	if (tid < E264_MAX_SLOTS) L.dpb[tid] = f.dpb[tid];
-	const gu32 *mbs_g = (const gu32 *)(f.payload - f.h->payload_off + f.h->mbs_off);
+	const gu32 *mbs_g = (const gu32 *)f.mbs_g;
 	for (int i = tid; i < PT_MBS * 8; i += PT_NT) {
 		const int mb = i >> 3, mbx = t.tx0 + (mb & (PT_W - 1)), mby = t.ty0 + mb / PT_W;
 		uint32_t v = 0;

@@ -39,6 +39,7 @@ def load():
     L.edge264_get_frame.restype = C.c_int
     L.edge264_get_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.e264front_set_sink.argtypes = [C.c_int]
+    L.e264front_set_compact.argtypes = [C.c_int]
     L.e264front_take_packet.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.e264front_take_packet.restype = C.c_int
     L.e264front_free_packet.argtypes = [C.c_void_p]
@@ -46,11 +47,13 @@ def load():
     return L
 
 
-def capture_packets(stream: bytes, n_threads: int = 0) -> tuple[list[bytes], int, float]:
+def capture_packets(stream: bytes, n_threads: int = 0, compact: bool = False) -> tuple[list[bytes], int, float]:
     """Parses `stream` (Annex B) with the capture sink.  Returns (command packets in decoding order, output frames the
-    decoder handed out, seconds of host time spent parsing + emitting)."""
+    decoder handed out, seconds of host time spent parsing + emitting).  compact: pictures with inter macroblocks come in the
+    wire form (version 5, include/edge264_compact.h)."""
     L = load()
     L.e264front_set_sink(1)
+    L.e264front_set_compact(1 if compact else 0)
     buf = C.create_string_buffer(stream + b"\0" * 64, len(stream) + 64)
     base = C.addressof(buf)
     end = base + len(stream)
@@ -92,12 +95,13 @@ def capture_packets(stream: bytes, n_threads: int = 0) -> tuple[list[bytes], int
     return packets, frames, spent
 
 
-def decode_timed(stream: bytes, sink: int = 0) -> dict:
+def decode_timed(stream: bytes, sink: int = 0, compact: bool = False) -> dict:
     """ONE decoder through the edge264.h API on the device sink (edge264_decode_NAL / edge264_get_frame, frames downloaded to the host mirror as an
     application sees them): wall time per output picture.  bench.py's single-stream latency leg -- the figure the reference's own `edge264_test -b`
     prints for itself (/root/reference/src/edge264_test.c:522-542), per picture."""
     L = load()
     L.e264front_set_sink(sink)
+    L.e264front_set_compact(1 if compact else 0)
     buf = C.create_string_buffer(stream + b"\0" * 64, len(stream) + 64)
     base = C.addressof(buf)
     end = base + len(stream)

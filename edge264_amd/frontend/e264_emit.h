@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "edge264_cmd.h"
+#include "edge264_compact.h"
 
 typedef struct {
 	uint8_t *samples;  /* host mirror handed to the reference as samples_buffers[slot] */
@@ -101,6 +102,9 @@ typedef struct E264Emitter {
 	int (*flush_partial)(struct E264Emitter *, int slot); /* sends the picture-so-far as a packet (edge264_hip_frontend.c) */
 	/* sink */
 	int sink_kind;      /* 0 HIP back end, 1 capture, 2 HIP frames + queued packets (external batcher) */
+	int compact;        /* pictures with inter macroblocks leave in the wire form (include/edge264_compact.h) */
+	uint8_t *fold_buf;  /* where such a picture's version-4 packet is assembled before it is folded */
+	size_t fold_cap;
 	void *hip_dev, *hip_stream;
 	/* the caller's allocators (edge264.h:42-43), NULL: ours */
 	Edge264AllocCb user_alloc;
@@ -242,7 +246,11 @@ static void e264_fill_slice(E264Emitter *e, E264FrameBuilder *b, int idx, const 
 	if (b->slice_filled[idx])
 		return;
 	e264_fill_slice_task(e, b, idx, &ctx->t);
-	memcpy(b->slices[idx].implicit_weights, ctx->implicit_weights, sizeof(b->slices[idx].implicit_weights));
+	/* the entries initialize_context has written (src/edge264_headers.c:231-252: B slices, active references) and decode_inter reads (implicit
+	 * weighting only, src/edge264_inter.c:1149); the rest of the worker's table is whatever its stack held and stays zero here */
+	if (ctx->t.slice_type == 1 && ctx->t.pps.weighted_bipred_idc == 2)
+		for (int i = 0; i < ctx->t.pps.num_ref_idx_active[0] && i < 32; i++)
+			memcpy(b->slices[idx].implicit_weights[i], ctx->implicit_weights[i], ctx->t.pps.num_ref_idx_active[1] < 32 ? (size_t)ctx->t.pps.num_ref_idx_active[1] : 32);
 }
 
 static void e264_payload_append(E264FrameBuilder *b, const void *src, size_t n)

@@ -11,6 +11,7 @@ import numpy as np
 
 E264_MAGIC = 0x34363245
 E264_VERSION = 4
+E264_VERSION_COMPACT = 5  # the wire form, include/edge264_compact.h
 MAX_SLOTS = 32
 
 MB_ABSENT, MB_I4x4, MB_I8x8, MB_I16x16, MB_PCM, MB_INTER = range(6)
@@ -257,6 +258,10 @@ class Packet:
     """Read-only parsed view of a packet."""
 
     def __init__(self, data: bytes):
+        if len(data) >= 8 and int.from_bytes(bytes(data[0:4]), "little") == E264_MAGIC and int.from_bytes(bytes(data[4:8]), "little") == E264_VERSION_COMPACT:
+            # a wire packet (include/edge264_compact.h) is read as the version-4 packet it stands for: one definition of the expansion, the C one
+            from . import backend
+            data = backend.packet_expand(bytes(data))
         self.data = data
         self.hdr = np.frombuffer(data, FRAME_HDR, 1)[0]
         if self.hdr["magic"] != E264_MAGIC or self.hdr["version"] != E264_VERSION:

@@ -104,6 +104,17 @@ int  e264hip_submit_batch(E264Device *dev, E264Stream *const *streams, E264Packe
  * all correct decoders, src/edge264.c:161-216). */
 const char *e264hip_build_flags(void);
 int  e264hip_packet_check(const void *packet, size_t bytes);
+/* The WIRE form of a packet (version 5, include/edge264_compact.h: fewer bytes over PCIe for pictures full of skipped / plain 16x16 macroblocks -- what the
+ * stream itself spends a run length on, src/edge264_slice.c:1651-1849).  Every host-packet entry point (e264hip_frame_submit, e264hip_submit_batch_host /
+ * _pinned, e264hip_packet_upload, e264hip_packet_check) takes either form; a wire packet is unfolded on the device by one more kernel in front of the four
+ * (into a buffer of the stream's) and means exactly what its expansion means.  C callers use the inline functions of edge264_compact.h (the front end does);
+ * these three are the same functions for callers that do not compile C:
+ *   e264hip_packet_compact_bound   capacity e264hip_packet_compact needs for this version-4 packet (0: not one)
+ *   e264hip_packet_compact         version 4 (must pass e264hip_packet_check) -> version 5; returns the bytes written, 0 on error
+ *   e264hip_packet_expand          version 5 -> the canonical version-4 packet; out == NULL: the size needed; 0 on error */
+size_t e264hip_packet_compact_bound(const void *packet, size_t bytes);
+size_t e264hip_packet_compact(const void *packet, size_t bytes, void *out, size_t cap);
+size_t e264hip_packet_expand(const void *packet, size_t bytes, void *out, size_t cap);
 /* Same for packets that still live in HOST memory (the finished frames of many decoders, src/edge264_headers.c:532-568,
  * one per stream): staged through each stream's pinned ring, copied and launched on the device queue without any
  * synchronisation; the host buffers may be reused on return.  This is what a multi-stream front end calls once per

@@ -81,6 +81,8 @@ static inline int relane(int lane) { return lane; }
 
 namespace {
 IntraLds<1> g_lds;
+static uint8_t *g_expand; // expansion buffer of a wire packet (include/edge264_compact.h), filled by the caller (pred_emu's e264emu_expand); NULL for version 4
+extern "C" __attribute__((visibility("default"))) void e264emu_set_expand(uint8_t *area) { g_expand = area; }
 const E264Job *g_job;
 void fibre_main(int lane)
 {
@@ -106,7 +108,7 @@ extern "C" __attribute__((visibility("default"))) int e264emu_intra_frame(const 
 }
 extern "C" __attribute__((visibility("default"))) int e264emu_intra_frame2(const uint8_t *pkt, uint8_t *const *dpb, uint8_t *scratch)
 {
-	const E264Job job = {pkt, dpb, scratch};
+	const E264Job job = {pkt, dpb, scratch, g_expand};
 	FrameCtx f;
 	if (!open_frame(f, job))
 		return -1;

@@ -6,11 +6,22 @@
 #include "emu_shims.h"
 #include "../../edge264_amd/csrc/e264_pred.h"
 #include "../../edge264_amd/csrc/e264_dbkp.h"
+#include "../../edge264_amd/csrc/e264_expand.h"
+
+// e264_expand_kernel over one wire packet (include/edge264_compact.h) with a grid of nt threads: area = e264_expand_area_bytes(wire)
+extern "C" __attribute__((visibility("default"))) int e264emu_expand(const uint8_t *wire, uint8_t *area, int nt)
+{
+	E264Job job = {wire, nullptr, nullptr, area};
+	for (int t = 0; t < nt; t++) expand_thread(job, (uint32_t)t, (uint32_t)nt);
+	return 0;
+}
+static uint8_t *g_expand; // the expansion buffer the frame entry points below hand to the kernels (NULL: version-4 packets)
+extern "C" __attribute__((visibility("default"))) void e264emu_set_expand(uint8_t *area) { g_expand = area; }
 
 // dbk: NULL, or the stream's scratch (E264_SCRATCH_BYTES(macroblocks)): the kernel then also writes the intra bitmap of its tiles
 extern "C" __attribute__((visibility("default"))) int e264emu_pred_frame2(const uint8_t *pkt, uint8_t *const *dpb, uint8_t *dbk)
 {
-	E264Job job = {pkt, dpb, dbk};
+	E264Job job = {pkt, dpb, dbk, g_expand};
 	FrameCtx f;
 	if (!open_frame(f, job))
 		return -1;
@@ -50,7 +61,7 @@ template <bool HAS_L1> static int emu_dbkparam(const uint8_t *pkt, uint8_t *out,
 	uint8_t dummy = 0;
 	uint8_t *dpb[E264_MAX_SLOTS];
 	for (int i = 0; i < E264_MAX_SLOTS; i++) dpb[i] = &dummy;
-	E264Job job = {pkt, dpb, out};
+	E264Job job = {pkt, dpb, out, g_expand};
 	FrameCtx f;
 	if (!open_frame(f, job))
 		return -1;
@@ -80,7 +91,7 @@ extern "C" __attribute__((visibility("default"))) int e264emu_dbkparam_raw(const
 	uint8_t dummy = 0;
 	uint8_t *dpb[E264_MAX_SLOTS];
 	for (int i = 0; i < E264_MAX_SLOTS; i++) dpb[i] = &dummy;
-	E264Job job = {pkt, dpb, &dummy};
+	E264Job job = {pkt, dpb, &dummy, g_expand};
 	if (!open_frame(f, job))
 		return -1;
 	uint8_t *out = (uint8_t *)malloc((size_t)f.wm * f.hm * E264_DBK_BYTES);
@@ -171,7 +182,7 @@ static void emu_walk_group(const FrameCtx &f, int q)
 // split: 0 = mixed waves (e264_deblock_kernel), 1 = luma waves + chroma waves (e264_deblock2_kernel)
 extern "C" __attribute__((visibility("default"))) int e264emu_deblock_frame2(const uint8_t *pkt, uint8_t *const *dpb, uint8_t *dbk, int split)
 {
-	E264Job job = {pkt, dpb, dbk};
+	E264Job job = {pkt, dpb, dbk, g_expand};
 	FrameCtx f;
 	if (!open_frame(f, job) || !f.dbk)
 		return -1;

@@ -1,0 +1,143 @@
+"""Wire packets (version 5, include/edge264_compact.h) through every host-packet entry point of the C-ABI on the MI355X: e264_expand_kernel in
+front of the four kernels.  Expectation: the pictures the version-4 packets give through the same entry point (whose parity with the oracle and the
+reference is the business of the other -m gpu tests) and, for the front end with e264front_set_compact(1), the unmodified reference's md5s."""
+import ctypes as C
+import glob
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from edge264_amd import backend, front, packet as P, synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+STREAMS = os.path.join(HERE, "golden", "streams")
+FRONT = os.path.join(os.path.dirname(HERE), "edge264_amd", "libedge264_hipfront.so")
+NAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(STREAMS, "*.264")))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def device():
+    dev = backend.Device(0)
+    yield dev
+    dev.close()
+
+
+def _gop(g, gop):
+    return [bytes(g.next_frame(ft)) for ft in gop]
+
+
+def synth_streams(n, w, h, gop, **kw):
+    return [_gop(synth.StreamSynth(w, h, seed=100 + i, **kw), gop) for i in range(n)]
+
+
+def run(device, per_stream, how):
+    """per_stream: packet lists (one per stream, same length).  Picture i of every stream in one submission through entry point `how`.
+    Returns [stream][picture] md5 of the destination slot."""
+    n = len(per_stream)
+    h0 = P.Packet(per_stream[0][0]).hdr
+    sts = [backend.Stream(device, int(h0["width_mbs"]), int(h0["height_mbs"])) for _ in range(n)]
+    allocated = [set() for _ in range(n)]
+    out = [[] for _ in range(n)]
+    pinned = []
+    try:
+        for i in range(len(per_stream[0])):
+            pkts = [ps[i] for ps in per_stream]
+            for st, al, pkt in zip(sts, allocated, pkts):
+                h = P.Packet(pkt).hdr
+                st.frame_bytes = int(h["plane_size_Y"]) + int(h["plane_size_C"])
+                for s in range(P.MAX_SLOTS):
+                    if (s == int(h["dst_slot"]) or int(h["ref_slots"]) >> s & 1) and s not in al:
+                        st.alloc(s)
+                        st.fill(s, 0)
+                        al.add(s)
+            if how == "single":
+                for st, pkt in zip(sts, pkts):
+                    st.submit(pkt)
+            elif how == "host":
+                device.submit_batch_host(sts, pkts)
+            elif how in ("pinned", "pinned_untrusted"):
+                ptrs = [device.pinned_copy(p) for p in pkts]
+                pinned += ptrs
+                device.submit_pinned_prepared(device.prepare_pinned_batch(sts, ptrs, [len(p) for p in pkts]), trusted=how == "pinned")
+            elif how == "resident":
+                dps = [device.upload_packet(p) for p in pkts]
+                device.submit_batch(sts, dps)
+                for dp in dps:
+                    dp.free()
+            for k, (st, pkt) in enumerate(zip(sts, pkts)):
+                out[k].append(hashlib.md5(st.download(int(P.Packet(pkt).hdr["dst_slot"])).tobytes()).hexdigest())
+    finally:
+        device.sync()
+        for p in pinned:
+            device.pinned_free(p)
+        for st in sts:
+            st.close()
+    return out
+
+
+@pytest.mark.parametrize("how", ["single", "host", "pinned", "pinned_untrusted", "resident"])
+def test_wire_packets_give_the_same_pictures(device, how):
+    cases = [synth_streams(3, 20, 6, "IPPBP", p_skip=0.9, num_refs=2, residual_prob=0.3),
+             synth_streams(40 if how != "single" else 2, 7, 5, "IPBP", p_skip=0.6, intra_in_inter=0.2),  # >= 32 pinned packets: the gathered transfer
+             synth_streams(2, 65, 3, "IPP", p_skip=1.0, residual_prob=0.0)]
+    folded = 0
+    for per_stream in cases:
+        wire = [[backend.packet_compact(p) for p in ps] for ps in per_stream]
+        folded += sum(w[4] == 5 for ws in wire for w in ws)
+        assert run(device, wire, how) == run(device, per_stream, how)
+    assert folded > 20
+
+
+def test_mixed_batches_and_growing_motion_sections(device):
+    """one submission with version-4 and wire packets side by side; a stream whose later pictures need a larger expansion buffer"""
+    a = synth_streams(4, 20, 6, "IPPPP", p_skip=0.9)
+    mixed = [[backend.packet_compact(p) if (k + i) & 1 else p for i, p in enumerate(ps)] for k, ps in enumerate(a)]
+    assert run(device, mixed, "host") == run(device, a, "host")
+    g = synth.StreamSynth(20, 6, seed=9, p_skip=0.95)
+    first = _gop(g, "IPP")
+    g.p_skip = 0.3  # many partitioned macroblocks: longer motion records
+    later = _gop(g, "PBPB")
+    grow = [first + later]
+    wire = [[backend.packet_compact(p) for p in grow[0]]]
+    assert run(device, wire, "single") == run(device, grow, "single")
+
+
+@pytest.fixture(scope="module")
+def hipfront():
+    if not os.path.exists(FRONT):
+        pytest.fail(f"{FRONT} missing: it is built in the container by `make -C oracle ref` and travels with the snapshot")
+    from oracle.pyoracle import HipFront
+    h = HipFront()
+    h.lib.e264front_set_sink(0)
+    h.lib.e264front_set_compact.argtypes = [C.c_int]
+    h.lib.e264front_set_compact(1)
+    yield h
+    h.lib.e264front_set_compact(0)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_front_end_in_wire_form_matches_reference(name, hipfront):
+    """every committed stream through edge264.h on the device sink with the front end folding its packets: the unmodified reference's frames and codes"""
+    with open(os.path.join(STREAMS, "reference_md5.json")) as f:
+        sums = json.load(f)
+    data = open(os.path.join(STREAMS, name + ".264"), "rb").read()
+    frames, codes = hipfront.decode(data)
+    assert codes == sums[name]["nal_codes"]
+    assert [hashlib.md5(b"".join(p.tobytes() for p in fr)).hexdigest() for fr in frames] == sums[name]["md5"]
+
+
+def test_captured_streams_as_wire_batches(device):
+    """real streams' packets (front end, capture sink, folded by the front end itself), several streams per submission, against their version-4 form"""
+    names = ["ipb_spatial", "cabac_ipb_temporal_implicit", "weighted_explicit", "nat_small_ipp8", "cabac_nat_small_ibbp10"]
+    for nm in names:
+        data = open(os.path.join(STREAMS, nm + ".264"), "rb").read()
+        plain = [bytes(p) for p in front.capture_packets(data)[0]]
+        wire = [bytes(p) for p in front.capture_packets(data, compact=True)[0]]
+        front.capture_packets(b"", compact=False)
+        assert any(w[4] == 5 for w in wire), nm
+        assert run(device, [wire, wire], "host") == run(device, [plain, plain], "host"), nm
