@@ -652,6 +652,7 @@ def main() -> int:
 
     # ---- bit-exactness at full size (untimed): EVERY stream, EVERY frame of one more GOP against the CPU oracle ----
     verify, bit_exact = None, None
+    expect = None  # [variant][frame]: the oracle's picture (kept for the wire-form check of the PCIe-inclusive leg)
     if rank == 0 and not args.no_verify and not stub:
         from oracle.pyoracle import Oracle
         nb = frame_nb
@@ -667,6 +668,10 @@ def main() -> int:
             submit_frame(batches[f], backend.RUN_ALL)
             dev.sync()
             d = int(parsed[f].hdr["dst_slot"])
+            if world == 1 and not args.no_host_packets:
+                expect = expect or [[] for _ in range(V)]
+                for v in range(V):
+                    expect[v].append(dpbs[v][d][:nb].copy())
             for k, st in enumerate(streams):
                 bad += 0 if np.array_equal(st.download(d), dpbs[k % V][d][:nb]) else 1
         verify = {"streams": len(streams), "frames_per_stream": len(packets), "frames_compared": len(streams) * len(packets), "distinct_pictures": V * len(packets),
@@ -824,10 +829,44 @@ def main() -> int:
                                            "their producer -> gathered into the batch's staging buffer -> one H2D per batch -> 4 kernels"}
         for pp in pins:
             dev.pinned_free(pp)
+        # ... and folded as e264front_set_compact(1) makes the front end fold them (the wire form, include/edge264_compact.h; the synthetic GOP gives residual to
+        # nearly every macroblock and folds little -- an encoder's pictures fold to 0.7, see same_input)
+        wpk = [[backend.packet_compact(p) for p in pk] for pk in vpk]
+        spins = [[dev.pinned_copy(p) for p in wpk[k % V]] for k in range(len(streams))]
+        pins = [pp for row in spins for pp in row]
+        pbs = [dev.prepare_pinned_batch([streams[k] for k in idx], [spins[k][f] for k in idx], [len(wpk[k % V][f]) for k in idx]) for f in range(len(packets)) for idx in groups]
+        for pb in pbs:
+            dev.submit_pinned_prepared(pb, backend.RUN_ALL)
+        dev.sync()
+        t2 = time.perf_counter()
+        for _ in range(2):
+            for pb in pbs:
+                dev.submit_pinned_prepared(pb, backend.RUN_ALL)
+        dev.sync()
+        dt2 = time.perf_counter() - t2
+        pcie["pinned_wire"] = {"value": round(2 * len(packets) * len(streams) / dt2, 1), "unit": "frames/s",
+                               "packet_MB_per_frame": round(float(np.mean([len(p) for pk in wpk for p in pk])) / 1e6, 3),
+                               "what": "pinned_in_place with the packets in their wire form (version 5): one more kernel (e264_expand_kernel) per submission, fewer bytes over the link"}
+        if expect is not None:  # untimed: one more GOP from refilled slots through the wire packets, every frame of a sample of streams against the oracle's pictures
+            for st in streams:
+                for i in range(n_slots):
+                    st.fill(i, fill_value)
+            probe = sorted({0, len(streams) // 3, 2 * len(streams) // 3, len(streams) - 1})
+            wbad = 0
+            for f in range(len(packets)):
+                for g in range(len(groups)):
+                    dev.submit_pinned_prepared(pbs[f * len(groups) + g], backend.RUN_ALL)
+                dev.sync()
+                d = int(parsed[f].hdr["dst_slot"])
+                for k in probe:
+                    wbad += 0 if np.array_equal(streams[k].download(d), expect[k % V][f]) else 1
+            pcie["pinned_wire"].update({"bit_exact": wbad == 0, "frames_compared": len(probe) * len(packets)})
+        for pp in pins:
+            dev.pinned_free(pp)
         link = link_rate_gbs()
         pcie["link_h2d_GBps_measured"] = link
         if link:
-            for e in (pcie, pcie["pinned_in_place"]):
+            for e in (pcie, pcie["pinned_in_place"], pcie["pinned_wire"]):
                 gbs = e["value"] * pcie["packet_MB_per_frame"] * 1e6 / 1e9
                 e["packet_GBps"] = round(gbs, 2)
                 e["link_frac"] = round(gbs / link, 3)

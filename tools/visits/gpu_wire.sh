@@ -7,12 +7,14 @@ timeout 1200 python -m pytest tests/test_hip_wire.py -x -q > $OUT/pytest_wire.lo
 if [ -n "$2" ]; then
   timeout 1200 python -m pytest tests -m gpu -x -q --deselect tests/test_hip_wire.py > $OUT/pytest_gpu.log 2>&1; echo "pytest gpu rc=$?"; tail -3 $OUT/pytest_gpu.log
 fi
-timeout 600 python bench.py --no-cpu-baseline --no-host-packets --no-other-configs --no-system --no-single-stream > $OUT/bench.json 2> $OUT/bench.err
+timeout 900 python bench.py --no-cpu-baseline --no-other-configs --no-system --no-single-stream > $OUT/bench.json 2> $OUT/bench.err
 python - <<PY
 import json
 try:
     d = json.load(open('$OUT/bench.json'))
     print('headline', d['value'], d['bit_exact'])
+    pc = d['pcie_inclusive']
+    print('pcie_inclusive', pc['value'], pc.get('link_frac'), 'pinned', pc['pinned_in_place']['value'], pc['pinned_in_place'].get('link_frac'), 'wire', pc['pinned_wire'])
     s = d['same_input']
     print('same_input bit_exact', s['bit_exact'], {k: v for k, v in s.items() if k.startswith('gpu_') or k.startswith('wire')})
     for f, r in s['per_file'].items():
