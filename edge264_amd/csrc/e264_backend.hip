@@ -151,6 +151,9 @@ struct E264Device {
 		// pageable batches: the packets of the WHOLE batch back to back in one page-locked buffer and one device buffer, so that a
 		// batch crosses PCIe as ONE transfer (256 copies of 1 MB each reached 35 GB/s, and cost the submitting thread 257 driver calls)
 		uint8_t *ph = nullptr, *pd = nullptr; size_t pcap = 0;
+		// wire packets of the batch (include/edge264_compact.h) are unfolded HERE, by e264_expand_kernel on the upload queue right behind the batch's copy --
+		// beside the kernels of the batch before, whose streams read THEIR ring slot's buffer: nothing to order but what the ring already orders
+		uint8_t *xd = nullptr; size_t xcap = 0;
 	} jring[E264_JOB_RING];
 	int jring_next = 0;
 	// Which submission wrote a slot last, and when it has retired: edge264_get_frame of ONE decoder must not wait for the
@@ -182,7 +185,7 @@ struct E264Stream {
 	size_t slot_bytes[E264_MAX_SLOTS];
 	uint8_t *d_dbk;                       // per-stream scratch of the kernels: E264_SCRATCH_BYTES(dbk_mbs) (deblocking parameters + the intra bitmap)
 	size_t dbk_mbs;
-	uint8_t *d_expand;                    // where e264_expand_kernel unfolds the stream's wire packets (include/edge264_compact.h), expand_cap bytes; NULL until the first one
+	uint8_t *d_expand;                    // where e264_expand_kernel unfolds the wire packets (include/edge264_compact.h) of e264hip_frame_submit, expand_cap bytes; NULL until the first one (batches: the ring slot's buffer)
 	size_t expand_cap;
 	// the slot table reaches the device from a small pinned ring (asynchronous: a pageable source would make hipMemcpyAsync
 	// wait for the queue)
@@ -404,6 +407,7 @@ API void e264hip_device_close(E264Device *dev)
 		if (jr.d) hipFree(jr.d);
 		if (jr.ph) hipHostFree(jr.ph);
 		if (jr.pd) hipFree(jr.pd);
+		if (jr.xd) hipFree(jr.xd);
 		if (jr.done) hipEventDestroy(jr.done);
 		if (jr.up) hipEventDestroy(jr.up);
 	}
@@ -631,22 +635,63 @@ static int check_packet(const void *packet, size_t bytes, int *dst, int *n_mbs, 
 // `slot_bytes` (with `slots`): size of every allocated slot -- a packet whose header claims a larger picture than the slot
 // it writes or reads (SPS size change, stale capture, foreign packet) would make the kernels run past the allocation.
 // `ref_mask_out` (may be null): DPB slots the packet's motion refers to.
+struct DeepAcc { uint32_t ref_mask = 0, n_coded = 0, n_inter = 0; bool pred_work = false, has_l1 = false; };
+// one macroblock record against its packet: m (the version-4 record), a / col (its address and column), mot / mot_bytes (the motion section its mot_off counts in)
+static int check_mb(const E264FrameHdr *h, const E264Mb &m, int a, int col, const uint8_t *mot, uint32_t mot_bytes, uint8_t *const *slots, const size_t *slot_bytes, uint64_t frame_need, DeepAcc &acc)
+{
+	if (m.kind > E264_MB_INTER) return fail(EINVAL, "macroblock kind");
+	if (m.slice >= h->n_slices || m.dbk_slice >= h->n_slices) return fail(EINVAL, "macroblock slice index"); // every record: the parameter kernel reads the slice of absent macroblocks too
+	if (m.kind == E264_MB_ABSENT) return 0;
+	acc.n_coded++;
+	if (m.kind == E264_MB_INTER || m.kind == E264_MB_PCM) acc.pred_work = true; // some macroblock is the prediction kernel's
+	if ((m.flags & E264_MBF_T8x8) && (m.kind == E264_MB_I16x16 || m.kind == E264_MB_PCM)) return fail(EINVAL, "8x8 transform flag on an Intra16x16 / PCM macroblock");
+	if ((m.payload_off & 7) || (uint64_t)m.payload_off + e264_mb_payload_bytes(&m) > h->payload_bytes) return fail(EINVAL, "macroblock payload");
+	if ((m.flags & E264_MBF_EDGE_LEFT) && col == 0) return fail(EINVAL, "left edge flag on the first column");
+	if ((m.flags & E264_MBF_EDGE_TOP) && a < h->width_mbs) return fail(EINVAL, "top edge flag on the first row");
+	// internal intra modes (src/edge264_internal.h:564-634): the kernels index tables with them
+	if (m.kind == E264_MB_I4x4) {
+		uint64_t mm;
+		memcpy(&mm, m.modes, 8); // 16 nibbles: above 13 <=> bits 1, 2 and 3 all set
+		if ((mm >> 1) & (mm >> 2) & (mm >> 3) & 0x1111111111111111ull) return fail(EINVAL, "Intra4x4 mode");
+	} else if (m.kind == E264_MB_I8x8) {
+		for (int k = 0; k < 4; k++)
+			if (m.modes[k] > 31) return fail(EINVAL, "Intra8x8 mode");
+	} else if (m.kind == E264_MB_I16x16 && m.i16_mode > 6) return fail(EINVAL, "Intra16x16 mode");
+	if (m.kind >= E264_MB_I4x4 && m.kind <= E264_MB_I16x16 && m.chroma_mode > 6) return fail(EINVAL, "intra chroma mode");
+	if (m.kind == E264_MB_INTER) {
+		acc.n_inter++;
+		if (!mot) return fail(EINVAL, "inter macroblock without motion section");
+		uint32_t d[2];
+		memcpy(d, m.modes, 8); // motion directory: record offset, shape
+		if (E264_MOT_UNI(d[1], 1) || (d[1] >> 4 & 15u)) acc.has_l1 = true; // predicts from list 1 (its uniform bit or one of its quadrant bits)
+		if ((d[0] & 3) || d[1] >> 26 || (uint64_t)d[0] + e264_mot_record_bytes(d[1]) > mot_bytes) return fail(EINVAL, "macroblock motion record");
+		// the record's reference dwords, where they lie (what e264_motion_expand would spread over 8 parts: the uniform form repeats
+		// one dword, an unused quadrant of a partitioned list reads as -1, which is always admissible)
+		const uint8_t *rec = mot + d[0];
+		uint32_t n = 0;
+		for (int l = 0; l < 2; l++) {
+			const bool uni = E264_MOT_UNI(d[1], l);
+			for (int q = 0; q < (uni ? 1 : 4); q++) {
+				if (!uni && !E264_MOT_USED(d[1], l * 4 + q)) continue;
+				const int rp = (int8_t)rec[n], ri = (int8_t)rec[n + 1];
+				if (rp < 0 || rp >= E264_MAX_SLOTS) return fail(EINVAL, "reference slot"); // a part the directory announces predicts from a picture
+				if (slots && !slots[rp]) return fail(EINVAL, "reference slot not allocated");
+				if (slots && slot_bytes && frame_need > slot_bytes[rp]) return fail(EINVAL, "picture larger than a reference slot");
+				acc.ref_mask |= 1u << rp;
+				if (ri < -1 || ri > 31) return fail(EINVAL, "reference index");
+				n += uni ? 8 : 4 + 4 * e264_mot_nmv(E264_MOT_SUB(d[1], l * 4 + q));
+			}
+		}
+	}
+	return 0;
+}
+
 static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *slots, const size_t *slot_bytes = nullptr, uint32_t *ref_mask_out = nullptr, bool *pred_work_out = nullptr, bool *has_l1_out = nullptr)
 {
 	int dst, n_mbs, r = check_packet(packet, bytes, &dst, &n_mbs);
 	if (r) return r;
 	const E264FrameHdr *h = (const E264FrameHdr *)packet;
 	const uint8_t *p = (const uint8_t *)packet;
-	if (h->version == E264_VERSION_COMPACT) {
-		// a wire packet means what its expansion means: unfolded here (host, this thread's buffer) and walked as the version-4 packet the kernels
-		// will see -- e264_expand_kernel writes the same records and motion section (tests/test_compact.py)
-		static thread_local std::vector<uint8_t> unfolded;
-		const size_t need = e264_expanded_bytes(packet);
-		if (unfolded.size() < need) unfolded.resize(need + need / 4);
-		const size_t got = e264_expand_packet(packet, h->total_bytes, unfolded.data(), unfolded.size());
-		if (!got) return fail(EINVAL, "wire packet expansion");
-		return check_packet_deep(unfolded.data(), got, slots, slot_bytes, ref_mask_out, pred_work_out, has_l1_out);
-	}
 	if (h->width_mbs == 0 || h->height_mbs == 0 || h->height_mbs > 1056) return fail(EINVAL, "frame size");
 	if (h->n_slices == 0 || (size_t)h->slices_off + (size_t)h->n_slices * sizeof(E264SliceParams) > h->mbs_off) return fail(EINVAL, "slice section");
 	if ((h->slices_off | h->mbs_off | h->motion_off | h->payload_off) & 7) return fail(EINVAL, "section alignment");
@@ -656,64 +701,51 @@ static int check_packet_deep(const void *packet, size_t bytes, uint8_t *const *s
 		return fail(EINVAL, "plane sizes");
 	const uint64_t frame_need = (uint64_t)h->plane_size_Y + h->plane_size_C;
 	if (slots && slot_bytes && slots[dst] && frame_need > slot_bytes[dst]) return fail(EINVAL, "picture larger than the destination slot");
-	const E264Mb *mbs = (const E264Mb *)(p + h->mbs_off);
 	const uint8_t *mot = h->motion_off ? p + h->motion_off : nullptr; // compact motion records, up to payload_off
 	const uint32_t mot_bytes = h->motion_off ? h->payload_off - h->motion_off : 0;
-	uint32_t ref_mask = 0, n_coded = 0, n_inter = 0;
-	bool pred_work = false; // some macroblock is the prediction kernel's (inter, PCM)
-	bool has_l1 = false;    // some inter macroblock predicts from list 1 (mot_hdr: its uniform bit or one of its quadrant bits)
-	for (int a = 0, col = 0; a < n_mbs; a++, col = col + 1 == h->width_mbs ? 0 : col + 1) {
-		const E264Mb &m = mbs[a];
-		if (m.kind > E264_MB_INTER) return fail(EINVAL, "macroblock kind");
-		if (m.slice >= h->n_slices || m.dbk_slice >= h->n_slices) return fail(EINVAL, "macroblock slice index"); // every record: the parameter kernel reads the slice of absent macroblocks too
-		if (m.kind == E264_MB_ABSENT) continue;
-		n_coded++;
-		if (m.kind == E264_MB_INTER || m.kind == E264_MB_PCM) pred_work = true;
-		if ((m.flags & E264_MBF_T8x8) && (m.kind == E264_MB_I16x16 || m.kind == E264_MB_PCM)) return fail(EINVAL, "8x8 transform flag on an Intra16x16 / PCM macroblock");
-		if ((m.payload_off & 7) || (uint64_t)m.payload_off + e264_mb_payload_bytes(&m) > h->payload_bytes) return fail(EINVAL, "macroblock payload");
-		if ((m.flags & E264_MBF_EDGE_LEFT) && col == 0) return fail(EINVAL, "left edge flag on the first column");
-		if ((m.flags & E264_MBF_EDGE_TOP) && a < h->width_mbs) return fail(EINVAL, "top edge flag on the first row");
-		// internal intra modes (src/edge264_internal.h:564-634): the kernels index tables with them
-		if (m.kind == E264_MB_I4x4) {
-			uint64_t mm;
-			memcpy(&mm, m.modes, 8); // 16 nibbles: above 13 <=> bits 1, 2 and 3 all set
-			if ((mm >> 1) & (mm >> 2) & (mm >> 3) & 0x1111111111111111ull) return fail(EINVAL, "Intra4x4 mode");
-		} else if (m.kind == E264_MB_I8x8) {
-			for (int k = 0; k < 4; k++)
-				if (m.modes[k] > 31) return fail(EINVAL, "Intra8x8 mode");
-		} else if (m.kind == E264_MB_I16x16 && m.i16_mode > 6) return fail(EINVAL, "Intra16x16 mode");
-		if (m.kind >= E264_MB_I4x4 && m.kind <= E264_MB_I16x16 && m.chroma_mode > 6) return fail(EINVAL, "intra chroma mode");
-		if (m.kind == E264_MB_INTER) {
-			n_inter++;
-			if (!mot) return fail(EINVAL, "inter macroblock without motion section");
-			uint32_t d[2];
-			memcpy(d, m.modes, 8); // motion directory: record offset, shape
-			if (E264_MOT_UNI(d[1], 1) || (d[1] >> 4 & 15u)) has_l1 = true;
-			if ((d[0] & 3) || d[1] >> 26 || (uint64_t)d[0] + e264_mot_record_bytes(d[1]) > mot_bytes) return fail(EINVAL, "macroblock motion record");
-			// the record's reference dwords, where they lie (what e264_motion_expand would spread over 8 parts: the uniform form repeats
-			// one dword, an unused quadrant of a partitioned list reads as -1, which is always admissible)
-			const uint8_t *rec = mot + d[0];
-			uint32_t n = 0;
-			for (int l = 0; l < 2; l++) {
-				const bool uni = E264_MOT_UNI(d[1], l);
-				for (int q = 0; q < (uni ? 1 : 4); q++) {
-					if (!uni && !E264_MOT_USED(d[1], l * 4 + q)) continue;
-					const int rp = (int8_t)rec[n], ri = (int8_t)rec[n + 1];
-					if (rp < 0 || rp >= E264_MAX_SLOTS) return fail(EINVAL, "reference slot"); // a part the directory announces predicts from a picture
-					if (slots && !slots[rp]) return fail(EINVAL, "reference slot not allocated");
-					if (slots && slot_bytes && frame_need > slot_bytes[rp]) return fail(EINVAL, "picture larger than a reference slot");
-					ref_mask |= 1u << rp;
-					if (ri < -1 || ri > 31) return fail(EINVAL, "reference index");
-					n += uni ? 8 : 4 + 4 * e264_mot_nmv(E264_MOT_SUB(d[1], l * 4 + q));
+	DeepAcc acc;
+	if (h->version == E264_VERSION_COMPACT) {
+		// A wire packet (include/edge264_compact.h; check_packet has vetted its structure) means what its expansion means: every entry is held
+		// against the same checks as the version-4 record e264_expand_kernel will make of it -- walked in place, entry by entry (the sequential
+		// form of e264_expand_mb: running counts instead of popcounts), without unfolding the packet.
+		const E264CompactHdr *ch = (const E264CompactHdr *)(p + h->mbs_off);
+		const uint32_t wm = h->width_mbs, hm = h->height_mbs, wpr = ch->words_per_row;
+		const uint32_t *cbits = (const uint32_t *)(p + h->mbs_off + 16) + 3 * hm, *bbits = cbits + (size_t)hm * wpr;
+		const uint8_t *e = p + h->mbs_off + e264_compact_table_bytes(wm, hm);
+		for (uint32_t y = 0, a = 0; y < hm; y++)
+			for (uint32_t x = 0; x < wm; x++, a++) {
+				E264Mb m;
+				if (!(cbits[y * wpr + (x >> 5)] >> (x & 31) & 1u)) {
+					memcpy(&m, e, 32);
+					e += 32;
+					if ((r = check_mb(h, m, (int)a, (int)x, mot, mot_bytes, slots, slot_bytes, frame_need, acc))) return r;
+					continue;
 				}
+				const bool both = bbits[y * wpr + (x >> 5)] >> (x & 31) & 1u;
+				E264MbCompact k;
+				memcpy(&k, e, 12);
+				uint8_t rec[16] = {k.ref_slot, k.ref_idx, 0, 0};
+				memcpy(rec + 4, k.mv, 4);
+				if (both) memcpy(rec + 8, e + 12, 8);
+				e += both ? 20 : 12;
+				memset(&m, 0, sizeof(m));
+				m.kind = E264_MB_INTER; m.flags = (uint8_t)(k.flags & ~E264_MBCF_LIST1);
+				m.qp[0] = k.qp[0]; m.qp[1] = k.qp[1]; m.qp[2] = k.qp[2];
+				m.slice = k.slice; m.dbk_slice = k.dbk_slice;
+				const uint32_t d[2] = {0, both ? E264_MOT_HDR_UNI01 : (k.flags & E264_MBCF_LIST1) ? E264_MOT_HDR_UNI1 : E264_MOT_HDR_UNI0};
+				memcpy(m.modes, d, 8);
+				if ((r = check_mb(h, m, (int)a, (int)x, rec, both ? 16 : 8, slots, slot_bytes, frame_need, acc))) return r;
 			}
-		}
+	} else {
+		const E264Mb *mbs = (const E264Mb *)(p + h->mbs_off);
+		for (int a = 0, col = 0; a < n_mbs; a++, col = col + 1 == h->width_mbs ? 0 : col + 1)
+			if ((r = check_mb(h, mbs[a], a, col, mot, mot_bytes, slots, slot_bytes, frame_need, acc))) return r;
 	}
-	if (h->n_coded_mbs != n_coded || h->n_inter_mbs != n_inter) return fail(EINVAL, "header macroblock counts differ from the records");
-	if (h->ref_slots != ref_mask) return fail(EINVAL, "header ref_slots differs from the motion records");
-	if (ref_mask_out) *ref_mask_out = ref_mask;
-	if (pred_work_out) *pred_work_out = pred_work;
-	if (has_l1_out) *has_l1_out = has_l1;
+	if (h->n_coded_mbs != acc.n_coded || h->n_inter_mbs != acc.n_inter) return fail(EINVAL, "header macroblock counts differ from the records");
+	if (h->ref_slots != acc.ref_mask) return fail(EINVAL, "header ref_slots differs from the motion records");
+	if (ref_mask_out) *ref_mask_out = acc.ref_mask;
+	if (pred_work_out) *pred_work_out = acc.pred_work;
+	if (has_l1_out) *has_l1_out = acc.has_l1;
 	return 0;
 }
 
@@ -1086,13 +1118,15 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 	const int lane = streams[0]->lane;
 	// headers first (cheap, serial): sizes, destination slots
 	int max_mbs = 0, max_tiles = 0;
-	std::vector<size_t> off_of((size_t)n), area_of((size_t)n);
-	size_t total = 0;
+	std::vector<size_t> off_of((size_t)n), area_of((size_t)n), xoff_of((size_t)n);
+	size_t total = 0, xtotal = 0;
 	bool any_wire = false;
 	for (int i = 0; i < n; i++) {
 		int r = check_packet(packets[i], bytes[i], &dst_of[i], &mbs_of[i], &tiles_of[i], &area_of[i]);
 		if (r) return r;
 		any_wire = any_wire || area_of[i];
+		xoff_of[i] = xtotal;
+		xtotal += (area_of[i] + 255) & ~(size_t)255;
 		if (!streams[i]->h_table[dst_of[i]]) return fail(EINVAL, "destination slot not allocated");
 		if (tiles_of[i] > max_tiles) max_tiles = tiles_of[i];
 		if (mbs_of[i] > max_mbs) max_mbs = mbs_of[i];
@@ -1121,13 +1155,20 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 		if (!(jr.pd = (uint8_t *)mem_acquire(dev, cap, false))) { mem_release(dev, jr.ph, cap, true, 0, 0); jr.ph = nullptr; return fail(ENOMEM, "device batch staging"); }
 		jr.pcap = cap;
 	}
+	if (jr.xcap < xtotal) {
+		if (jr.xd) mem_release(dev, jr.xd, jr.xcap, false, 0, 0); // not busy: nothing in flight reads it
+		jr.xd = nullptr; jr.xcap = 0;
+		const size_t cap = (xtotal + xtotal / 4 + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+		if (!(jr.xd = (uint8_t *)mem_acquire(dev, cap, false))) return fail(ENOMEM, "device expansion buffer");
+		jr.xcap = cap;
+	}
 	if (!jr.done && hipEventCreateWithFlags(&jr.done, E264_WAIT_EVENT) != hipSuccess) { jr.done = nullptr; return fail(EIO, "hipEventCreate"); }
 	if (!jr.up && hipEventCreateWithFlags(&jr.up, hipEventDisableTiming) != hipSuccess) { jr.up = nullptr; return fail(EIO, "hipEventCreate"); }
 	std::vector<E264Stream::Stage *> stage_of((size_t)n, nullptr);
 	for (int i = 0; i < n; i++) { // per-stream buffers (HIP calls: this thread only); the rings advance only when everything is there
 		E264Stream *s = streams[i];
 		int r = ensure_dbk(s, mbs_of[i]);
-		if (r || (r = ensure_expand(s, area_of[i]))) return r;
+		if (r) return r;
 		if (!stage && !(stage_of[i] = stage_prepare(s, bytes[i]))) return ENOMEM;
 	}
 	{ // every packet on its own, in parallel: the per-macroblock walk, and -- while its lines are still in the core's cache -- the copy
@@ -1152,7 +1193,7 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 	for (int i = 0; i < n; i++) {
 		jr.h[i].packet = stage ? jr.pd + off_of[i] : stage_of[i]->d;
 		jr.h[i].dpb = streams[i]->d_table; jr.h[i].dbk = streams[i]->d_dbk;
-		jr.h[i].expand = area_of[i] ? streams[i]->d_expand : nullptr;
+		jr.h[i].expand = area_of[i] ? jr.xd + xoff_of[i] : nullptr;
 	}
 	if (!stage)
 		for (int i = 0; i < n && e == hipSuccess; i++)
@@ -1160,6 +1201,7 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 	else
 		e = hipMemcpyAsync(jr.pd, jr.ph, total, hipMemcpyHostToDevice, up);
 	if (e == hipSuccess) e = hipMemcpyAsync(jr.d, jr.h, sizeof(E264Job) * n, hipMemcpyHostToDevice, up);
+	if (e == hipSuccess && any_wire) e = e264_launch_expand(jr.d, n, max_mbs, up);
 	if (e == hipSuccess && up != q) {
 		e = hipEventRecord(jr.up, up);
 		if (e == hipSuccess) e = hipStreamWaitEvent(q, jr.up, 0);
@@ -1167,7 +1209,7 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 	bool batch_l1 = false;
 	for (int i = 0; i < n; i++) batch_l1 = batch_l1 || l1_of[i];
 	uint64_t serial = 0;
-	int r = e == hipSuccess ? launch(dev, lane, jr.d, n, max_mbs, max_tiles, (mode & E264_RUN_ALL) | (batch_l1 ? 0 : E264_RUN_NO_L1) | (any_wire ? E264_RUN_EXPAND : 0), &serial) : fail(EIO, "packet upload", e);
+	int r = e == hipSuccess ? launch(dev, lane, jr.d, n, max_mbs, max_tiles, (mode & E264_RUN_ALL) | (batch_l1 ? 0 : E264_RUN_NO_L1), &serial) : fail(EIO, "packet upload", e);
 	if (r && up != q) hipStreamSynchronize(up); // copies already queued must not outlive the error return unguarded
 	// the job table and the staging slots are busy until the lane has passed this point -- also on an error above: whatever
 	// part of the batch was queued still reads them

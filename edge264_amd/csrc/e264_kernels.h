@@ -21,7 +21,7 @@ struct E264Job {
 #define E264_BITMAP_OFF(n_mbs) ((size_t)(n_mbs) * E264_DBK_BYTES)
 
 #define E264_RUN_NO_PRED 4 // (launcher-internal) no job of the batch has an inter or PCM macroblock: e264_pred_kernel is not launched and the intra kernel scans without its bitmap
-#define E264_RUN_EXPAND 16 // (launcher-internal) some job of the batch is a wire packet: e264_expand_kernel runs first
+#define E264_RUN_EXPAND 16 // (launcher-internal) some job is a wire packet that has not been unfolded yet: e264_expand_kernel runs first, on the same queue
 #define E264_RUN_NO_L1 8   // (launcher-internal) no job of the batch predicts from list 1 (validated packets of I / P pictures): e264_dbkparam2_kernel<false>
 // mode: bit0 reconstruction, bit1 deblocking, bit2 E264_RUN_NO_PRED, bit3 E264_RUN_NO_L1, bit4 E264_RUN_EXPAND.  waves: 4, 8 or 16 macroblock rows in flight per frame.
 // max_mbs: largest macroblock count among the jobs; max_tiles: largest e264_pred_tiles() among the jobs.  marks: NULL or 5 events (boundaries of the 4 kernels).
@@ -34,5 +34,8 @@ extern "C" int e264_pred_tiles(int width_mbs, int height_mbs);
 extern "C" const char *e264_kernel_build_flags(void);
 extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int max_mbs, int max_tiles, int mode, int waves, hipStream_t stream, hipEvent_t *marks,
 	const E264Fork *fork);
+
+// e264_expand_kernel alone (a batch's wire packets, on the queue of its upload); E264_RUN_EXPAND in e264_launch_frames' mode runs it in front of the four instead
+extern "C" hipError_t e264_launch_expand(const E264Job *jobs, int n_jobs, int max_mbs, hipStream_t stream);
 
 #endif

@@ -455,6 +455,13 @@ extern "C" int e264_pred_tiles(int width_mbs, int height_mbs)
 	return ((width_mbs + PT_W - 1) / PT_W) * ((height_mbs + PT_H - 1) / PT_H);
 }
 
+extern "C" hipError_t e264_launch_expand(const E264Job *jobs, int n_jobs, int max_mbs, hipStream_t stream)
+{
+	if (n_jobs > 0)
+		hipLaunchKernelGGL(e264_expand_kernel, dim3((max_mbs + XP_NT - 1) / XP_NT, n_jobs), dim3(XP_NT), 0, stream, jobs);
+	return hipGetLastError();
+}
+
 extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int max_mbs, int max_tiles, int mode, int waves, hipStream_t stream, hipEvent_t *marks,
 	const E264Fork *fork)
 {
@@ -462,7 +469,7 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 		return hipSuccess;
 	// wire packets first (before the marks: they bracket the four kernels; the whole-run clocks contain this one)
 	if (mode & E264_RUN_EXPAND)
-		hipLaunchKernelGGL(e264_expand_kernel, dim3((max_mbs + XP_NT - 1) / XP_NT, n_jobs), dim3(XP_NT), 0, stream, jobs);
+		e264_launch_expand(jobs, n_jobs, max_mbs, stream);
 	// marks (optional): 5 events recorded before / between / after the four launches
 	if (marks) hipEventRecord(marks[0], stream);
 	const bool dbkp = (mode & 2) != 0;

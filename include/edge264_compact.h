@@ -28,6 +28,7 @@
  * Plain C99, no dependencies: the front end (C), the back end (C++) and, through the back end's exports, the Python tools share this one definition. */
 #ifndef EDGE264_COMPACT_H
 #define EDGE264_COMPACT_H
+#include <stddef.h>
 #include <string.h>
 #include "edge264_cmd.h"
 #ifdef __cplusplus
@@ -74,22 +75,105 @@ static inline uint32_t e264_compact_table_bytes(uint32_t width_mbs, uint32_t hei
 /* how can this version-4 record go?  0: as it is, 1: one-list entry, 2: two-list entry.  rec: its motion record (NULL when the packet has no motion section) */
 static inline int e264_mb_compact_class(const E264Mb *m, const uint8_t *rec)
 {
-	uint32_t d[2];
+	uint32_t d[2], r0, r1;
 	if (m->kind != E264_MB_INTER || (m->flags & ~(E264_MBF_EDGE_LEFT | E264_MBF_EDGE_TOP | E264_MBF_DEBLOCK)) || m->coded || m->nz_mask || m->slice > 255 || m->dbk_slice > 255 || !rec)
 		return 0;
 	memcpy(d, m->modes, 8);
-	if (rec[0] >= 32 || rec[1] >= 32 || rec[2] || rec[3])
+	memcpy(&r0, rec, 4);
+	if (r0 & 0xffffe0e0u) /* slot and index below 32, the two spare bytes zero */
 		return 0;
 	if (d[1] == E264_MOT_HDR_UNI0 || d[1] == E264_MOT_HDR_UNI1)
 		return 1;
-	return (d[1] == E264_MOT_HDR_UNI01 && rec[8] < 32 && rec[9] < 32 && !rec[10] && !rec[11]) ? 2 : 0;
+	if (d[1] != E264_MOT_HDR_UNI01)
+		return 0;
+	memcpy(&r1, rec + 8, 4);
+	return (r1 & 0xffffe0e0u) ? 0 : 2;
 }
 
-/* upper bound of what e264_compact_packet writes for this version-4 packet */
+/* upper bound of what e264_compact_packet / e264_compact_sections write for a picture whose version-4 packet has this header */
 static inline size_t e264_compact_bound(const void *v4)
 {
 	const E264FrameHdr *h = (const E264FrameHdr *)v4;
 	return (size_t)h->total_bytes + e264_compact_table_bytes(h->width_mbs, h->height_mbs) + 64;
+}
+
+/* The fold, from the SECTIONS of a version-4 packet wherever they lie (a front end folds straight out of its builder's arrays; e264_compact_packet below
+ * folds a packet).  h: the version-4 header (magic, sizes, slices_off, mbs_off, n_slices, payload_bytes and the summary fields are taken as they are;
+ * motion_off, payload_off, total_bytes, version are written anew).  mot: NULL when no macroblock is inter.  payload_len <= h->payload_bytes bytes are
+ * copied, the rest is zeros.  The sections must be what e264hip_packet_check would accept.  Returns the wire size, 0 when `cap` is too small. */
+static inline size_t e264_compact_sections(const E264FrameHdr *h, const void *slices, const E264Mb *mbs, const uint8_t *mot, const uint8_t *payload, size_t payload_len,
+	void *out, size_t cap)
+{
+	const uint32_t wm = h->width_mbs, hm = h->height_mbs, wpr = (wm + 31u) >> 5;
+	const uint32_t tb = e264_compact_table_bytes(wm, hm);
+	if (cap < (size_t)h->total_bytes + tb + 64)
+		return 0;
+	uint8_t *o = (uint8_t *)out;
+	memcpy(o, h, sizeof(*h));
+	memset(o + sizeof(*h), 0, h->slices_off - sizeof(*h));
+	memcpy(o + h->slices_off, slices, sizeof(E264SliceParams) * (size_t)h->n_slices);
+	const uint32_t send = h->slices_off + (uint32_t)sizeof(E264SliceParams) * h->n_slices;
+	memset(o + send, 0, h->mbs_off - send + tb);
+	E264FrameHdr *oh = (E264FrameHdr *)o;
+	E264CompactHdr *ch = (E264CompactHdr *)(o + h->mbs_off);
+	uint32_t *row_off = (uint32_t *)(o + h->mbs_off + 16), *row_cbase = row_off + hm, *row_bbase = row_cbase + hm, *cbits = row_bbase + hm, *bbits = cbits + hm * wpr;
+	uint8_t *ent = o + h->mbs_off + tb;
+	uint32_t eoff = 0, nc = 0, nb = 0, moff = 0;
+	const E264Mb *m = mbs;
+	for (uint32_t y = 0; y < hm; y++) {
+		row_off[y] = eoff; row_cbase[y] = nc; row_bbase[y] = nb;
+		for (uint32_t x = 0; x < wm; x++, m++) {
+			if (m->kind != E264_MB_INTER) { memcpy(ent + eoff, m, 32); eoff += 32; continue; }
+			uint32_t d[2];
+			memcpy(d, m->modes, 8);
+			const uint8_t *rec = mot ? mot + d[0] : NULL;
+			const int cls = e264_mb_compact_class(m, rec);
+			if (!cls) {
+				memcpy(ent + eoff, m, 32);
+				memcpy(ent + eoff + offsetof(E264Mb, modes), &moff, 4); /* mot_off in this packet's motion section */
+				moff += e264_mot_record_bytes(d[1]);
+				eoff += 32;
+				continue;
+			}
+			uint8_t *c = ent + eoff; /* E264MbCompact */
+			c[0] = (uint8_t)(m->flags | (d[1] == E264_MOT_HDR_UNI1 ? E264_MBCF_LIST1 : 0)); c[1] = rec[0]; c[2] = rec[1]; c[3] = (uint8_t)m->slice;
+			c[4] = m->qp[0]; c[5] = m->qp[1]; c[6] = m->qp[2]; c[7] = (uint8_t)m->dbk_slice;
+			memcpy(c + 8, rec + 4, 4);
+			eoff += 12; nc++;
+			cbits[y * wpr + (x >> 5)] |= 1u << (x & 31);
+			if (cls == 2) {
+				memcpy(c + 12, rec + 8, 8);
+				eoff += 8; nb++;
+				bbits[y * wpr + (x >> 5)] |= 1u << (x & 31);
+			}
+		}
+	}
+	ch->n_compact = nc; ch->n_both = nb; ch->entries_bytes = eoff; ch->words_per_row = wpr;
+	/* motion section: the records of the full inter macroblocks, in macroblock order (the bitmap says which are not) */
+	uint32_t pos = (h->mbs_off + tb + eoff + 7u) & ~7u;
+	memset(ent + eoff, 0, pos - (h->mbs_off + tb + eoff));
+	oh->motion_off = moff ? pos : 0;
+	if (moff) {
+		m = mbs;
+		for (uint32_t y = 0; y < hm; y++)
+			for (uint32_t x = 0; x < wm; x++, m++) {
+				if (m->kind != E264_MB_INTER || (cbits[y * wpr + (x >> 5)] >> (x & 31) & 1u)) continue;
+				uint32_t d[2];
+				memcpy(d, m->modes, 8);
+				const uint32_t rb = e264_mot_record_bytes(d[1]);
+				memcpy(o + pos, mot + d[0], rb);
+				pos += rb;
+			}
+	}
+	const uint32_t pad = ((pos + 7u) & ~7u) - pos;
+	memset(o + pos, 0, pad);
+	pos += pad;
+	if (payload_len) memcpy(o + pos, payload, payload_len);
+	memset(o + pos + payload_len, 0, h->payload_bytes - payload_len);
+	oh->version = E264_VERSION_COMPACT;
+	oh->payload_off = pos;
+	oh->total_bytes = pos + h->payload_bytes;
+	return oh->total_bytes;
 }
 
 /* version 4 (already vetted: e264hip_packet_check, or the front end's own product) -> version 5.  Returns the wire size, 0 when `cap` is too small or the
@@ -98,73 +182,9 @@ static inline size_t e264_compact_packet(const void *v4, size_t bytes, void *out
 {
 	const uint8_t *p = (const uint8_t *)v4;
 	const E264FrameHdr *h = (const E264FrameHdr *)v4;
-	if (bytes < sizeof(*h) || h->magic != E264_MAGIC || h->version != E264_VERSION || cap < e264_compact_bound(v4))
+	if (bytes < sizeof(*h) || h->magic != E264_MAGIC || h->version != E264_VERSION)
 		return 0;
-	const uint32_t wm = h->width_mbs, hm = h->height_mbs, n = wm * hm, wpr = (wm + 31u) >> 5;
-	const E264Mb *mbs = (const E264Mb *)(p + h->mbs_off);
-	const uint8_t *mot = h->motion_off ? p + h->motion_off : NULL;
-	uint8_t *o = (uint8_t *)out;
-	memcpy(o, p, h->mbs_off); /* header + slice table */
-	E264FrameHdr *oh = (E264FrameHdr *)o;
-	const uint32_t tb = e264_compact_table_bytes(wm, hm);
-	E264CompactHdr *ch = (E264CompactHdr *)(o + h->mbs_off);
-	uint32_t *row_off = (uint32_t *)(o + h->mbs_off + 16), *row_cbase = row_off + hm, *row_bbase = row_cbase + hm, *cbits = row_bbase + hm, *bbits = cbits + hm * wpr;
-	memset(o + h->mbs_off, 0, tb);
-	uint8_t *ent = o + h->mbs_off + tb;
-	uint32_t eoff = 0, nc = 0, nb = 0, moff = 0;
-	for (uint32_t y = 0; y < hm; y++) {
-		row_off[y] = eoff; row_cbase[y] = nc; row_bbase[y] = nb;
-		for (uint32_t x = 0; x < wm; x++) {
-			const E264Mb *m = &mbs[y * wm + x];
-			uint32_t d[2];
-			memcpy(d, m->modes, 8);
-			const uint8_t *rec = (m->kind == E264_MB_INTER && mot) ? mot + d[0] : NULL;
-			const int cls = e264_mb_compact_class(m, rec);
-			if (cls) {
-				E264MbCompact c;
-				c.flags = (uint8_t)(m->flags | (d[1] == E264_MOT_HDR_UNI1 ? E264_MBCF_LIST1 : 0)); c.ref_slot = rec[0]; c.ref_idx = rec[1]; c.slice = (uint8_t)m->slice;
-				c.qp[0] = m->qp[0]; c.qp[1] = m->qp[1]; c.qp[2] = m->qp[2]; c.dbk_slice = (uint8_t)m->dbk_slice;
-				memcpy(c.mv, rec + 4, 4);
-				memcpy(ent + eoff, &c, 12);
-				eoff += 12; nc++;
-				cbits[y * wpr + (x >> 5)] |= 1u << (x & 31);
-				if (cls == 2) {
-					memcpy(ent + eoff, rec + 8, 8);
-					eoff += 8; nb++;
-					bbits[y * wpr + (x >> 5)] |= 1u << (x & 31);
-				}
-			} else {
-				E264Mb f = *m;
-				if (m->kind == E264_MB_INTER) { d[0] = moff; memcpy(f.modes, d, 8); moff += e264_mot_record_bytes(d[1]); }
-				memcpy(ent + eoff, &f, 32);
-				eoff += 32;
-			}
-		}
-	}
-	ch->n_compact = nc; ch->n_both = nb; ch->entries_bytes = eoff; ch->words_per_row = wpr;
-	/* motion section: the records of the full inter macroblocks, in macroblock order */
-	uint32_t pos = (h->mbs_off + tb + eoff + 7u) & ~7u;
-	memset(ent + eoff, 0, pos - (h->mbs_off + tb + eoff));
-	oh->motion_off = moff ? pos : 0;
-	if (moff)
-		for (uint32_t a = 0; a < n; a++) {
-			const E264Mb *m = &mbs[a];
-			if (m->kind != E264_MB_INTER) continue;
-			uint32_t d[2];
-			memcpy(d, m->modes, 8);
-			if (e264_mb_compact_class(m, mot + d[0])) continue;
-			const uint32_t rb = e264_mot_record_bytes(d[1]);
-			memcpy(o + pos, mot + d[0], rb);
-			pos += rb;
-		}
-	const uint32_t pad = ((pos + 7u) & ~7u) - pos;
-	memset(o + pos, 0, pad);
-	pos += pad;
-	memcpy(o + pos, p + h->payload_off, h->payload_bytes);
-	oh->version = E264_VERSION_COMPACT;
-	oh->payload_off = pos;
-	oh->total_bytes = pos + h->payload_bytes;
-	return oh->total_bytes;
+	return e264_compact_sections(h, p + h->slices_off, (const E264Mb *)(p + h->mbs_off), h->motion_off ? p + h->motion_off : NULL, p + h->payload_off, h->payload_bytes, out, cap);
 }
 
 /* Structure of a version-5 packet: everything an expansion (host or device) reads lies inside the packet and says what the bitmaps say.  0 = sound.

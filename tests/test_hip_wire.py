@@ -141,3 +141,28 @@ def test_captured_streams_as_wire_batches(device):
         front.capture_packets(b"", compact=False)
         assert any(w[4] == 5 for w in wire), nm
         assert run(device, [wire, wire], "host") == run(device, [plain, plain], "host"), nm
+
+
+def test_multi_stream_driver_in_wire_form(tmp_path):
+    """e264_multi (many decoders, parser threads, packets in page-locked memory submitted in place and trusted) with E264_FRONT_COMPACT=1: the reference's frames"""
+    import subprocess
+    root = os.path.dirname(HERE)
+    exe, hip = os.path.join(root, "edge264_amd", "e264_multi"), os.path.join(root, "edge264_amd", "libedge264_hip.so")
+    for p in (exe, FRONT, hip):
+        assert os.path.exists(p), f"{p} missing (built by __graft_entry__.build())"
+    with open(os.path.join(STREAMS, "reference_md5.json")) as f:
+        sums = json.load(f)
+    names = ["ipb_spatial", "cabac_ipb_temporal_implicit", "nat_small_ipp8", "cabac_nat_small_ibbp10", "weighted_explicit", "mvc_ipb", "cabac_nat_small_aq_slices_ibbp10"]
+    files = [os.path.join(STREAMS, n + ".264") for n in names]
+    out = subprocess.run([exe, "--front", FRONT, "--hip", hip, "--repeat", "3", "--threads", "3", "--out", str(tmp_path)] + files,
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, E264_FRONT_COMPACT="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    stats = json.loads(out.stdout.strip().splitlines()[-1])
+    assert stats["frames"] == 3 * sum(len(sums[n]["md5"]) for n in names)
+    k = 0
+    for _ in range(3):
+        for n in names:
+            nby = sums[n]["width_mbs"] * 16 * sums[n]["height_mbs"] * 16 * 3 // 2 * sums[n]["views"]
+            data = open(tmp_path / f"s{k}.yuv", "rb").read()
+            assert [hashlib.md5(data[i:i + nby]).hexdigest() for i in range(0, len(data), nby)] == sums[n]["md5"], f"stream {k} ({n})"
+            k += 1
