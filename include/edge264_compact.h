@@ -3,7 +3,7 @@
  * Why.  A packet crosses PCIe once and is then read by four kernels; with the copy inside the clock the back end runs at 0.9 of the link
  * (bench.py pcie_inclusive.link_frac), and most macroblocks of an encoder-made stream say "one vector per list, no residual" -- P_Skip, B_Skip / Direct with one
  * motion for the whole macroblock, plain 16x16 -- in 40 or 48 bytes: a 32-byte record of which 7 bytes carry information and an 8-byte motion record per list
- * (6 400 of the 8 160 macroblocks of a P picture of tests/golden/streams/nat1080_ipp30.264, 5 700 of a B picture of cabac_hd1080_ibbp30.264).  The stream itself
+ * (5 200 of the 8 160 macroblocks of an average picture of tests/golden/streams/nat1080_ipp30.264, 5 700 of cabac_hd1080_ibbp30.264).  The stream itself
  * spends a run length on them (mb_skip_run, /root/reference/src/edge264_slice.c:1651-1849).
  *
  * What.  Version 5 keeps header, slice table, motion records and payload of version 4 and replaces the array of E264Mb by a table in which such a macroblock
