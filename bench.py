@@ -71,6 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--variants", type=int, default=int(os.environ.get("E264_VARIANTS", 4)), help="distinct synthetic GOPs (seeds 1234, 1235, ...): stream k decodes GOP k mod V, "
                     "so that the timed pictures and the verification are not copies of one GOP")
     ap.add_argument("--no-system", action="store_true", help="skip the system leg (e264_multi: parser + emitters + GPU on the container's cores, N=1)")
+    ap.add_argument("--no-staggered", action="store_true", help="skip the leg with the streams' GOPs out of phase (N=1)")
     ap.add_argument("--no-single-stream", action="store_true", help="skip the single-stream latency leg (N=1)")
     ap.add_argument("--no-same-input", action="store_true", help="skip the same-input leg (the 1080p bitstream fixtures on the GPU next to the CPU reference, N=1)")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("E264_LANES", 1)), help="compute lanes (HIP queues): the streams are split into this many "
@@ -271,6 +272,74 @@ def single_stream_leg(dev, backend, gop_packets, W, H, n_slots, frame_nb, fill_v
     except Exception as e:  # noqa: BLE001
         out["api"] = {"unavailable": f"{type(e).__name__}: {e}"}
     return out
+
+
+def staggered_leg(dev, backend, streams, dpk, vpk, groups, n_slots, fill_value, nb, verify):
+    """GOPs OUT OF PHASE (round 6).  The headline decodes picture f of every stream in submission f: all I pictures share one submission, in which the intra kernel
+    (one workgroup per picture) keeps every CU busy.  Independent streams have their I pictures anywhere: here stream k runs k mod G pictures ahead, so every
+    submission holds I and P pictures in the GOP's proportion (a stream that starts inside its GOP predicts from the filled slots: deterministic, verified against
+    the oracle decoding the same order).  `lockstep`: the four kernels over the whole submission, the I pictures' 2.7-ms intra pass with 7/8 of the CUs idle;
+    `value`: the launcher's default -- that pass starts on a second queue at the beginning of the submission, beside the parameter and prediction kernels of the
+    other pictures (E264Fork.n_nopred, edge264_amd/csrc/e264_kernels.h)."""
+    from edge264_amd import packet as P
+    G, V, lanes = len(dpk[0]), len(vpk), len(groups)
+
+    def phase(k):
+        return (k // lanes) % G
+    bs = [[dev.make_batch([streams[k] for k in idx], [dpk[k][(f + phase(k)) % G] for k in idx]) for idx in groups] for f in range(G)]
+
+    def one_pass():
+        for row in bs:
+            for b in row:
+                dev.submit_prepared(b, backend.RUN_ALL)
+
+    def refill():
+        for st in streams:
+            for i in range(n_slots):
+                st.fill(i, fill_value)
+    res = {"streams": len(streams), "gop_phase_of_stream_k": "k mod %d" % G}
+    for label, split in (("lockstep", 0), ("split", 1)):
+        dev.set_option("split_intra", split)
+        refill()
+        one_pass()
+        dev.sync()
+        dev.kernel_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            one_pass()
+        dev.sync()
+        dt = time.perf_counter() - t0
+        k4, l4 = dev.kernel_time_ms()
+        dev.kernel_timing(False)
+        res[label] = {"value": round(3 * G * len(streams) / dt, 1), "unit": "frames/s", "ms_per_submission": round(1e3 * dt / (3 * G), 3),
+                      "kernel_ms_per_launch": {n: round(t / max(l4, 1), 4) for n, t in zip(KERNELS, k4)}}
+    res["value"] = res["split"]["value"]
+    res["unit"] = "frames/s"
+    res["note"] = ("kernel_ms_per_launch.e264_intra_kernel of `split` is the lane's wait for the I pictures' intra pass on the second queue after its own kernels, "
+                   "not that pass's duration")
+    if verify:
+        from oracle.pyoracle import Oracle
+        refill()
+        probe = list(range(min(G, len(streams))))  # one stream of every phase
+        dpbs = {k: [np.full(nb + 64, fill_value, np.uint8) for _ in range(n_slots)] + [None] * (32 - n_slots) for k in probe}
+        orcs = {k: Oracle() for k in probe}
+        bad = 0
+        for f in range(G):
+            for b in bs[f]:
+                dev.submit_prepared(b, backend.RUN_ALL)
+            dev.sync()
+            for k in probe:
+                pkt = vpk[k % V][(f + phase(k)) % G]
+                orcs[k].decode_frame(pkt, dpbs[k], 3)
+                d = int(P.Packet(pkt).hdr["dst_slot"])
+                bad += 0 if np.array_equal(streams[k].download(d), dpbs[k][d][:nb]) else 1
+        res["bit_exact"] = bad == 0
+        res["frames_compared"] = G * len(probe)
+    for row in bs:
+        for b in row:
+            dev.free_batch(b)
+    refill()
+    return res
 
 
 def same_input_leg(dev, backend, n_streams, cpu):
@@ -705,6 +774,11 @@ def main() -> int:
         except (OSError, FileNotFoundError):
             pass
 
+    # ---- the same GOPs out of phase (N=1 only): what a fleet of independent streams looks like to the launcher ----
+    staggered = None
+    if rank == 0 and world == 1 and not args.no_staggered and not stub and not args.capture and len(packets) > 1:
+        staggered = staggered_leg(dev, backend, streams, dpk, vpk, groups, n_slots, fill_value, frame_nb, not args.no_verify)
+
     # ---- the other single-GPU configurations of BASELINE.json, short runs on the same streams (N=1 only) -----
     other = None
     if rank == 0 and world == 1 and not args.no_other_configs and not stub:
@@ -931,6 +1005,7 @@ def main() -> int:
             "cpu_baseline": cpu,
             "bit_exact": bit_exact, "verify": verify,
             "other_configs": other,
+            "staggered_gops": staggered,
             "pcie_inclusive": pcie,
             "same_input": same,
             "system": system,

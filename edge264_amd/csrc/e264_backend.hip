@@ -132,10 +132,12 @@ struct E264Device {
 	hipStream_t qc = nullptr;  // download queue
 	int waves;                 // waves per frame workgroup of the deblocking kernel (5 macroblock rows each): 2, 4, 7 or 8
 	int intra_waves;           // waves per frame workgroup of the intra kernel (1 macroblock row each)
+	std::atomic<int> max_lane{0}; // highest lane a stream was ever bound to
+	int split_intra;           // option "split_intra" (default 1): in a submission that mixes I pictures with others, their intra pass runs on q2 from the start (E264Fork.n_nopred)
 	int side_queue;            // option "side_queue": parameter kernel on a second queue beside the macroblock-parallel kernel
 	int upload_queue;          // option "upload_queue" (default 1): the H2D copies of host batches go through qup
-	hipStream_t q2;
-	hipEvent_t forked, joined;
+	hipStream_t q2[NQ];        // one second queue per compute lane (+ its fork / join events): lanes must not share one (their split submissions would queue behind each other)
+	hipEvent_t forked[NQ], joined[NQ];
 	hipEvent_t lane_ev[NQ];    // e264hip_event_record: joins the other lanes into lane 0
 	std::mutex lock;           // kernel launches + their timing marks + the submission event ring
 	std::mutex batch_lock;     // host batches: job ring, staging
@@ -368,11 +370,20 @@ API int e264hip_device_open(int ordinal, E264Device **out)
 		}
 	for (int i = 0; i < 16; i++)
 		hipEventCreate(&d->ev[i]);
-	d->side_queue = 0; d->q2 = nullptr; d->forked = d->joined = nullptr; // measured: no gain (profiles/r01k_ablation_breakdown.txt), off by default
-	if (hipStreamCreateWithFlags(&d->q2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&d->forked, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&d->joined, hipEventDisableTiming) != hipSuccess) {
-		d->q2 = nullptr; // not fatal: the option then stays off
-	}
+	d->split_intra = 1;
+	d->side_queue = 0; // measured: no gain (profiles/r01k_ablation_breakdown.txt), off by default
+	for (int i = 0; i < E264Device::NQ; i++) { d->q2[i] = nullptr; d->forked[i] = d->joined[i] = nullptr; }
+	bool q2_ok = true;
+	for (int i = 0; i < E264Device::NQ && q2_ok; i++)
+		q2_ok = hipStreamCreateWithFlags(&d->q2[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&d->forked[i], hipEventDisableTiming) == hipSuccess &&
+			hipEventCreateWithFlags(&d->joined[i], hipEventDisableTiming) == hipSuccess;
+	if (!q2_ok) // not fatal: the options that need a second queue then stay off
+		for (int i = 0; i < E264Device::NQ; i++) {
+			if (d->q2[i]) hipStreamDestroy(d->q2[i]);
+			if (d->forked[i]) hipEventDestroy(d->forked[i]);
+			if (d->joined[i]) hipEventDestroy(d->joined[i]);
+			d->q2[i] = nullptr; d->forked[i] = d->joined[i] = nullptr;
+		}
 	if (hipStreamCreateWithFlags(&d->qc, hipStreamNonBlocking) != hipSuccess) d->qc = nullptr; // downloads then share the lane
 	if (hipStreamCreateWithFlags(&d->qup, hipStreamNonBlocking) != hipSuccess) d->qup = nullptr; // uploads then share the lane
 	for (int i = 0; i < E264Device::NEV; i++)
@@ -388,7 +399,8 @@ API int e264hip_device_sync(E264Device *dev)
 	if (dev->qup) HIPCHK(hipStreamSynchronize(dev->qup), EIO);
 	for (int i = 0; i < E264Device::NQ; i++)
 		HIPCHK(hipStreamSynchronize(dev->q[i]), EIO);
-	if (dev->q2) HIPCHK(hipStreamSynchronize(dev->q2), EIO);
+	for (int i = 0; i < E264Device::NQ; i++)
+		if (dev->q2[i]) HIPCHK(hipStreamSynchronize(dev->q2[i]), EIO);
 	return 0;
 }
 
@@ -399,9 +411,11 @@ API void e264hip_device_close(E264Device *dev)
 	e264hip_device_sync(dev);
 	for (int i = 0; i < 16; i++) hipEventDestroy(dev->ev[i]);
 	for (auto &p : dev->kev) { for (int i = 0; i < 5; i++) hipEventDestroy(p.e[i]); for (int i = 0; i < 2; i++) hipEventDestroy(p.a[i]); }
-	if (dev->q2) hipStreamDestroy(dev->q2);
-	if (dev->forked) hipEventDestroy(dev->forked);
-	if (dev->joined) hipEventDestroy(dev->joined);
+	for (int i = 0; i < E264Device::NQ; i++) {
+		if (dev->q2[i]) hipStreamDestroy(dev->q2[i]);
+		if (dev->forked[i]) hipEventDestroy(dev->forked[i]);
+		if (dev->joined[i]) hipEventDestroy(dev->joined[i]);
+	}
 	for (auto &jr : dev->jring) {
 		if (jr.h) hipHostFree(jr.h);
 		if (jr.d) hipFree(jr.d);
@@ -423,9 +437,14 @@ API void e264hip_device_close(E264Device *dev)
 API int e264hip_set_option(E264Device *dev, const char *name, int value)
 {
 	if (!dev || !name) return -1;
+	if (!strcmp(name, "split_intra")) {
+		int prev = dev->split_intra;
+		dev->split_intra = value == 2 ? 2 : value != 0; // 2: also with more than two lanes in use (for runs with GPU_MAX_HW_QUEUES raised)
+		return prev;
+	}
 	if (!strcmp(name, "side_queue")) {
 		int prev = dev->side_queue;
-		dev->side_queue = dev->q2 ? (value == 1 || value == 2 ? value : 0) : 0; // 1: beside the prediction kernel, 2: beside the intra kernel
+		dev->side_queue = dev->q2[0] ? (value == 1 || value == 2 ? value : 0) : 0; // 1: beside the prediction kernel, 2: beside the intra kernel
 		return prev;
 	}
 	if (!strcmp(name, "upload_queue")) {
@@ -479,6 +498,8 @@ API int e264hip_stream_bind_lane(E264Stream *s, int lane)
 	// what the old lane still has queued for this stream (table updates, fills, submissions) must be over before the new one starts
 	HIPCHK(hipStreamSynchronize(lane_of(s)), EIO);
 	s->lane = lane;
+	int seen = s->dev->max_lane.load(std::memory_order_relaxed);
+	while (seen < lane && !s->dev->max_lane.compare_exchange_weak(seen, lane, std::memory_order_relaxed)) {}
 	return 0;
 }
 
@@ -818,11 +839,15 @@ static int ensure_expand(E264Stream *s, size_t area)
 }
 
 // Launches the kernels over a job table that already lives in HBM, on compute lane `lane`.
-static int launch(E264Device *dev, int lane, const E264Job *d_jobs, int n, int max_mbs, int max_tiles, int mode, uint64_t *serial_out = nullptr)
+// n_nopred: the table's LAST n_nopred jobs hold no inter / PCM macroblock (0: unknown or none)
+static int launch(E264Device *dev, int lane, const E264Job *d_jobs, int n, int max_mbs, int max_tiles, int mode, uint64_t *serial_out = nullptr, int n_nopred = 0)
 {
 	std::lock_guard<std::mutex> g(dev->lock);
 	hipEvent_t *marks = nullptr;
-	E264Fork fork = {dev->side_queue ? dev->q2 : nullptr, dev->forked, dev->joined, nullptr, dev->side_queue};
+	// (not with more than two lanes in use: lanes and second queues then share the runtime's hardware queues -- four by default, GPU_MAX_HW_QUEUES -- and a lane's
+	// kernels wait behind another lane's 2.7-ms intra pass: 38.7 k against 52.0 k frames/s without the split, tools/stagger_probe.py, profiles/r06_ablations.txt item 16)
+	const bool split = (dev->split_intra == 2 || (dev->split_intra && dev->max_lane.load(std::memory_order_relaxed) < 2)) && dev->q2[lane] && n_nopred > 0 && n_nopred < n;
+	E264Fork fork = {dev->side_queue || split ? dev->q2[lane] : nullptr, dev->forked[lane], dev->joined[lane], nullptr, dev->side_queue, split ? n_nopred : 0};
 	if (dev->ktiming) {
 		if (dev->kev_used == dev->kev.size()) {
 			E264Device::Marks m;
@@ -831,7 +856,7 @@ static int launch(E264Device *dev, int lane, const E264Job *d_jobs, int n, int m
 			dev->kev.push_back(m);
 		}
 		E264Device::Marks &m = dev->kev[dev->kev_used++];
-		m.side = fork.aux != nullptr && (mode & 2);
+		m.side = !split && dev->side_queue && fork.aux != nullptr && (mode & 2); // (the parameter kernel's own marks; in a split submission it stays on the lane and the intra phase [2..3] holds the join)
 		marks = m.e; fork.amarks = m.a;
 	}
 	HIPCHK(e264_launch_frames(d_jobs, n, max_mbs, max_tiles, mode, dev->waves | dev->intra_waves << 8, dev->q[lane], marks, &fork), EIO);
@@ -991,6 +1016,7 @@ struct E264Batch {
 	E264Device *dev;
 	E264Job *d_jobs;
 	int n, max_mbs, max_tiles, lane;
+	int n_nopred;   // the table's last n_nopred jobs are pictures without inter / PCM macroblocks
 	bool pred_work; // some packet of the batch has inter / PCM macroblocks (all-intra batches skip the prediction kernel's launch)
 	bool has_l1;    // some packet of the batch predicts from list 1
 	std::vector<std::pair<E264Stream *, int>> writes; // (stream, destination slot) of every job
@@ -1002,6 +1028,7 @@ API int e264hip_batch_create(E264Device *dev, E264Stream *const *streams, E264Pa
 	if (set_device(dev)) return EIO;
 	std::vector<E264Job> jobs((size_t)n);
 	int max_mbs = 0, max_tiles = 0;
+	size_t n_front = 0, n_back = 0;
 	for (int i = 0; i < n; i++) {
 		if (!streams[i] || !packets[i] || streams[i]->dev != dev || packets[i]->dev != dev) return fail(EINVAL, "batch entry");
 		if (streams[i]->lane != streams[0]->lane) return fail(EINVAL, "the streams of a batch must be bound to one compute lane");
@@ -1017,16 +1044,19 @@ API int e264hip_batch_create(E264Device *dev, E264Stream *const *streams, E264Pa
 			if (streams[j] == streams[i]) return fail(EINVAL, "a stream may contribute one frame per batch");
 		int r = ensure_dbk(streams[i], packets[i]->n_mbs);
 		if (r) return r;
-		jobs[i].packet = packets[i]->d_bytes;
-		jobs[i].dpb = streams[i]->d_table;
-		jobs[i].dbk = streams[i]->d_dbk;
-		jobs[i].expand = nullptr; // (resident packets are version 4: e264hip_packet_upload)
+		// the table's order is the launcher's to choose: pictures without prediction work (I pictures) LAST, so that a mixed batch can start their intra pass
+		// beside the others' parameter and prediction kernels (E264Fork.n_nopred)
+		E264Job &jb = jobs[packets[i]->pred_work ? n_front++ : (size_t)n - 1 - n_back++];
+		jb.packet = packets[i]->d_bytes;
+		jb.dpb = streams[i]->d_table;
+		jb.dbk = streams[i]->d_dbk;
+		jb.expand = nullptr; // (resident packets are version 4: e264hip_packet_upload)
 		if (packets[i]->n_mbs > max_mbs) max_mbs = packets[i]->n_mbs;
 		if (packets[i]->n_tiles > max_tiles) max_tiles = packets[i]->n_tiles;
 	}
 	E264Batch *b = new (std::nothrow) E264Batch();
 	if (!b) return fail(ENOMEM, "batch object");
-	b->dev = dev; b->n = n; b->max_mbs = max_mbs; b->max_tiles = max_tiles; b->lane = streams[0]->lane;
+	b->dev = dev; b->n = n; b->max_mbs = max_mbs; b->max_tiles = max_tiles; b->lane = streams[0]->lane; b->n_nopred = (int)n_back;
 	b->pred_work = b->has_l1 = false;
 	for (int i = 0; i < n; i++) { b->pred_work = b->pred_work || packets[i]->pred_work; b->has_l1 = b->has_l1 || packets[i]->has_l1; }
 	for (int i = 0; i < n; i++) b->writes.emplace_back(streams[i], packets[i]->dst_slot);
@@ -1045,7 +1075,7 @@ API int e264hip_batch_submit(E264Batch *b, int mode)
 		if (w.first->lane != b->lane) return fail(EINVAL, "a stream of the batch was bound to another lane after batch_create");
 	uint64_t serial = 0;
 	// (E264_RUN_NO_PRED: internal to the launcher -- every packet of the batch was vetted at upload time and none holds an inter or PCM macroblock)
-	int r = launch(b->dev, b->lane, b->d_jobs, b->n, b->max_mbs, b->max_tiles, (mode & E264_RUN_ALL) | (b->pred_work ? 0 : E264_RUN_NO_PRED) | (b->has_l1 ? 0 : E264_RUN_NO_L1), &serial);
+	int r = launch(b->dev, b->lane, b->d_jobs, b->n, b->max_mbs, b->max_tiles, (mode & E264_RUN_ALL) | (b->pred_work ? 0 : E264_RUN_NO_PRED) | (b->has_l1 ? 0 : E264_RUN_NO_L1), &serial, b->n_nopred);
 	if (!r) for (auto &w : b->writes) { raise_serial(w.first->slot_serial[w.second], serial); raise_serial(w.first->last_serial, serial); }
 	return r;
 }
@@ -1107,7 +1137,7 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 	if (!dev || !streams || !packets || !bytes || n <= 0) return fail(EINVAL, "submit_batch_host arguments");
 	if (set_device(dev)) return EIO;
 	std::vector<int> mbs_of((size_t)n), tiles_of((size_t)n), rc((size_t)n, 0), dst_of((size_t)n);
-	std::vector<char> l1_of((size_t)n, 1); // (trusted packets are not walked here: assumed to use list 1)
+	std::vector<char> l1_of((size_t)n, 1), pw_of((size_t)n, 1); // (trusted packets are not walked here: assumed to use list 1 and to hold prediction work)
 	std::vector<std::string> why((size_t)n);
 	for (int i = 0; i < n; i++) {
 		if (!streams[i] || streams[i]->dev != dev) return fail(EINVAL, "batch entry");
@@ -1176,9 +1206,9 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 		std::lock_guard<std::mutex> pg(dev->pool_user);
 		dev->pool.parallel_for(n, [&](int i) {
 			E264Stream *s = streams[i];
-			bool l1 = true;
-			int r = trusted ? check_slots_of(s, (const E264FrameHdr *)packets[i]) : check_packet_deep(packets[i], bytes[i], s->h_table, s->slot_bytes, nullptr, nullptr, &l1);
-			l1_of[i] = l1;
+			bool l1 = true, pw = true;
+			int r = trusted ? check_slots_of(s, (const E264FrameHdr *)packets[i]) : check_packet_deep(packets[i], bytes[i], s->h_table, s->slot_bytes, nullptr, &pw, &l1);
+			l1_of[i] = l1; pw_of[i] = pw;
 			if (r) { rc[i] = r; why[i] = g_err; return; } // the message lives in the worker's thread-local buffer
 			if (stage) memcpy(jr.ph + off_of[i], packets[i], bytes[i]);
 		});
@@ -1190,10 +1220,12 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 	// ---- copies on the upload queue, kernels on the lane behind the batch's upload event ----
 	hipStream_t q = dev->q[lane], up = dev->upload_queue && dev->qup ? dev->qup : q;
 	hipError_t e = hipSuccess;
+	int n_front = 0, n_back = 0; // pictures without prediction work last in the table (as in e264hip_batch_create)
 	for (int i = 0; i < n; i++) {
-		jr.h[i].packet = stage ? jr.pd + off_of[i] : stage_of[i]->d;
-		jr.h[i].dpb = streams[i]->d_table; jr.h[i].dbk = streams[i]->d_dbk;
-		jr.h[i].expand = area_of[i] ? jr.xd + xoff_of[i] : nullptr;
+		E264Job &jb = jr.h[pw_of[i] ? n_front++ : n - 1 - n_back++];
+		jb.packet = stage ? jr.pd + off_of[i] : stage_of[i]->d;
+		jb.dpb = streams[i]->d_table; jb.dbk = streams[i]->d_dbk;
+		jb.expand = area_of[i] ? jr.xd + xoff_of[i] : nullptr;
 	}
 	if (!stage)
 		for (int i = 0; i < n && e == hipSuccess; i++)
@@ -1209,7 +1241,7 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 	bool batch_l1 = false;
 	for (int i = 0; i < n; i++) batch_l1 = batch_l1 || l1_of[i];
 	uint64_t serial = 0;
-	int r = e == hipSuccess ? launch(dev, lane, jr.d, n, max_mbs, max_tiles, (mode & E264_RUN_ALL) | (batch_l1 ? 0 : E264_RUN_NO_L1), &serial) : fail(EIO, "packet upload", e);
+	int r = e == hipSuccess ? launch(dev, lane, jr.d, n, max_mbs, max_tiles, (mode & E264_RUN_ALL) | (batch_l1 ? 0 : E264_RUN_NO_L1), &serial, n_back) : fail(EIO, "packet upload", e);
 	if (r && up != q) hipStreamSynchronize(up); // copies already queued must not outlive the error return unguarded
 	// the job table and the staging slots are busy until the lane has passed this point -- also on an error above: whatever
 	// part of the batch was queued still reads them

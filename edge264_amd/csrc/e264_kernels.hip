@@ -474,14 +474,29 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 	if (marks) hipEventRecord(marks[0], stream);
 	const bool dbkp = (mode & 2) != 0;
 	const bool no_l1 = (mode & E264_RUN_NO_L1) != 0; // no packet of the batch predicts from list 1: the parameter kernel's small form (eight workgroups per CU)
-	// fork (optional): the parameter kernel reads nothing but the packet and is needed only by the deblocking kernel, so it
-	// runs on a second queue NEXT TO the macroblock-parallel kernel -- 28 VGPRs per wave, its waves fit beside the two
-	// 215-VGPR waves per SIMD and use issue slots those leave idle.  Ordered after everything enqueued before (the packet
-	// copies, the previous batch's deblocking that still reads the parameter buffer) by `forked`, before deblocking by `joined`.
-	// fork->where: 1 = beside the macroblock-parallel kernel (rounds 1 - 4: no gain, that kernel fills every CU), 2 = beside the intra
-	// kernel (round 6): one 125-KB workgroup per CU leaves 38 KB of LDS and, on P / B pictures, most issue slots -- the 27-KB / 40-VGPR
-	// parameter workgroups fit beside it, and deblocking (the only consumer) starts when both are done.
-	const bool side = dbkp && fork && fork->aux;
+	const int intra_waves_ = waves >> 8 ? waves >> 8 : waves & 255;
+	auto launch_intra = [&](const E264Job *j, int n, hipStream_t q, int use_bitmap) {
+		switch (intra_waves_) {
+		case 4: hipLaunchKernelGGL(e264_intra_kernel<4>, dim3(n), dim3(256), 0, q, j, use_bitmap); break;
+		case 16: hipLaunchKernelGGL(e264_intra_kernel<16>, dim3(n), dim3(1024), 0, q, j, use_bitmap); break;
+		default: hipLaunchKernelGGL(e264_intra_kernel<8>, dim3(n), dim3(512), 0, q, j, use_bitmap); break;
+		}
+	};
+	// a submission that mixes pictures without prediction work (the table's last n_nopred jobs: I pictures) with others: their intra pass starts NOW on the
+	// second queue (E264Fork.n_nopred, e264_kernels.h); the rest of this function then sees the other jobs only, up to deblocking
+	const int n_split = (fork && fork->aux && (mode & 1) && !(mode & E264_RUN_NO_PRED) && fork->n_nopred > 0 && fork->n_nopred < n_jobs) ? fork->n_nopred : 0;
+	const int n_front = n_jobs - n_split;
+	if (n_split) {
+		hipEventRecord(fork->forked, stream);
+		hipStreamWaitEvent(fork->aux, fork->forked, 0);
+		if (marks) hipEventRecord(fork->amarks[0], fork->aux);
+		launch_intra(jobs + n_front, n_split, fork->aux, 0);
+		if (marks) hipEventRecord(fork->amarks[1], fork->aux);
+		hipEventRecord(fork->joined, fork->aux);
+	}
+	// fork->where (optional): the parameter kernel reads nothing but the packet and is needed only by the deblocking kernel, so it can run on the second queue beside
+	// the prediction kernel (1; rounds 1 - 4: no gain, that kernel fills every CU) or beside the intra kernel (2; round 6: no gain either, profiles/r06_ablations.txt item 1)
+	const bool side = dbkp && fork && fork->aux && fork->where && !n_split; // (not when the second queue is taken)
 	const int where = side ? (fork->where == 2 ? 2 : 1) : 0;
 	auto launch_side = [&]() {
 		hipEventRecord(fork->forked, stream);
@@ -503,19 +518,14 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 	// leave cost 0.12 ms per launch of 256 pictures; the intra kernel then scans without the bitmap those workgroups would have written
 	const bool no_pred = (mode & E264_RUN_NO_PRED) != 0;
 	if ((mode & 1) && !no_pred)
-		hipLaunchKernelGGL(e264_pred_kernel, dim3(max_tiles, n_jobs), dim3(PT_NT), 0, stream, jobs, mode);
+		hipLaunchKernelGGL(e264_pred_kernel, dim3(max_tiles, n_front), dim3(PT_NT), 0, stream, jobs, mode);
 	if (marks) hipEventRecord(marks[2], stream);
 	if (where == 2)
 		launch_side();
-	const int intra_waves = waves >> 8 ? waves >> 8 : waves & 255;
 	waves &= 255;
-	if (mode & 1) {
-		switch (intra_waves) {
-		case 4: hipLaunchKernelGGL(e264_intra_kernel<4>, dim3(n_jobs), dim3(256), 0, stream, jobs, no_pred ? 0 : 1); break;
-		case 16: hipLaunchKernelGGL(e264_intra_kernel<16>, dim3(n_jobs), dim3(1024), 0, stream, jobs, no_pred ? 0 : 1); break;
-		default: hipLaunchKernelGGL(e264_intra_kernel<8>, dim3(n_jobs), dim3(512), 0, stream, jobs, no_pred ? 0 : 1); break;
-		}
-	}
+	if (mode & 1)
+		launch_intra(jobs, n_front, stream, no_pred ? 0 : 1);
+	if (n_split) hipStreamWaitEvent(stream, fork->joined, 0);
 	if (side) hipStreamWaitEvent(stream, fork->joined, 0); // (before the mark: with the parameter kernel beside it, "intra" is the phase both share)
 	if (marks) hipEventRecord(marks[3], stream);
 	if (mode & 2) {

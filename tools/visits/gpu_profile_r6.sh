@@ -7,14 +7,14 @@ REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/pytest_gpu.log
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-B="python $REPO/bench.py --no-cpu-baseline --no-verify --no-other-configs --no-host-packets --no-same-input --no-system --no-single-stream"
+B="python $REPO/bench.py --no-cpu-baseline --no-verify --no-other-configs --no-host-packets --no-same-input --no-system --no-single-stream --no-staggered"
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_kt -- $B > $OUT/bench_kt.json 2> $OUT/bench_kt.err; echo "kt rc=$?"
 timeout 400 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B -d $OUT/pmc_rd -- $B --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_rd.err; echo "rd rc=$?"
 timeout 400 rocprofv3 --pmc TCC_EA0_WRREQ TCC_EA0_WRREQ_64B -d $OUT/pmc_wr -- $B --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_wr.err; echo "wr rc=$?"
 timeout 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM -d $OUT/pmc_sq -- $B --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_sq.err; echo "sq rc=$?"
 # the host-packet legs alone (page-locked packets, version 4 and wire form): e264_expand_kernel's duration beside the four
-timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_wire -- python $REPO/bench.py --no-cpu-baseline --no-verify --no-other-configs --no-same-input --no-system --no-single-stream > $OUT/bench_wire_kt.json 2> $OUT/bench_wire_kt.err; echo "wire kt rc=$?"
+timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_wire -- python $REPO/bench.py --no-cpu-baseline --no-verify --no-other-configs --no-same-input --no-system --no-single-stream --no-staggered > $OUT/bench_wire_kt.json 2> $OUT/bench_wire_kt.err; echo "wire kt rc=$?"
 cd $REPO
 python tools/rocprof_summary.py $(find $OUT/prof_kt -name '*.db' | head -1) > $OUT/kernel_stats.txt 2>&1; cat $OUT/kernel_stats.txt
 python tools/rocprof_summary.py $(find $OUT/prof_wire -name '*.db' | head -1) > $OUT/kernel_stats_host_packets.txt 2>&1; cat $OUT/kernel_stats_host_packets.txt
@@ -35,6 +35,7 @@ print(d['value'], d['bit_exact'], r['bound'], r['kernel'], r['frac'], r['valu_is
 print({k.split('_')[1]: (v['valu_issue_frac'], v['lane_instr_per_sample']) for k,v in r['valu_issue']['kernels'].items()})
 print(d['cpu_baseline']['value'], d['cpu_baseline'].get('per_core'))
 p=d['pcie_inclusive']; print(p['value'], p.get('link_frac'), p['pinned_in_place']['value'], p['pinned_in_place'].get('link_frac'), p.get('link_h2d_GBps_measured'), p.get('pinned_wire'))
+print(json.dumps(d['staggered_gops']))
 print(json.dumps(d['single_stream']))
 print(json.dumps(d['same_input'])[:1800]); print({k[:10]: v['value'] for k,v in d['other_configs'].items()}); print(json.dumps(d['system'])[:1200])"
 python -c "

@@ -15,7 +15,7 @@ for spec in $2; do   # spec = variant[@ENV=VAL[,ENV=VAL...]]
   lib=$REPO/edge264_amd/variants/libedge264_hip_$v.so
   [ $v = main ] && lib=$REPO/edge264_amd/libedge264_hip.so
   v=$(echo "$spec" | tr '@=,' '___')
-  env $envs E264_ALLOW_ABLATION=1 E264_HIP_LIB=$lib timeout 500 python bench.py --no-cpu-baseline --no-host-packets --no-other-configs --no-system $BENCH_ARGS > $OUT/bench_$v.json 2> $OUT/bench_$v.err
+  env $envs E264_ALLOW_ABLATION=1 E264_HIP_LIB=$lib timeout 500 python bench.py --no-cpu-baseline --no-host-packets --no-other-configs --no-system --no-staggered $BENCH_ARGS > $OUT/bench_$v.json 2> $OUT/bench_$v.err
   python - <<PY
 import json
 try:

@@ -7,7 +7,7 @@ timeout 1200 python -m pytest tests/test_hip_wire.py -x -q > $OUT/pytest_wire.lo
 if [ -n "$2" ]; then
   timeout 1200 python -m pytest tests -m gpu -x -q --deselect tests/test_hip_wire.py > $OUT/pytest_gpu.log 2>&1; echo "pytest gpu rc=$?"; tail -3 $OUT/pytest_gpu.log
 fi
-timeout 900 python bench.py --no-cpu-baseline --no-other-configs --no-system --no-single-stream > $OUT/bench.json 2> $OUT/bench.err
+timeout 900 python bench.py --no-cpu-baseline --no-other-configs --no-system --no-single-stream --no-staggered > $OUT/bench.json 2> $OUT/bench.err
 python - <<PY
 import json
 try:
