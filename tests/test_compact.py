@@ -238,3 +238,29 @@ def test_damaged_wire_packets_are_refused_or_sound():
         backend.packet_compact(wire)  # already folded
     with pytest.raises(backend.BackendError):
         backend.packet_expand(synth_packets()[0][1])  # not a wire packet
+
+
+@needs_front
+def test_front_end_folds_pictures_that_leave_in_several_packets():
+    """damaged streams (a slice cut short and sent again: the picture goes out in several packets whose records are edited in the packet -- E264_MBF_DONE, flags --
+    before they are folded): packet by packet the fold of what the front end sends with the option off"""
+    from tests import damage
+    n5 = multi = 0
+    cases = [damage.truncated_then_resent(*c) for c in damage.RESENT[:10]] + [damage.two_truncated_then_resent(*c) for c in damage.RESENT2[:4]]
+    for data in cases:
+        plain = [bytes(p) for p in front.capture_packets(data)[0]]
+        wire = [bytes(p) for p in front.capture_packets(data, compact=True)[0]]
+        assert len(plain) == len(wire)
+        seen = {}
+        for a, b in zip(plain, wire):
+            assert backend.packet_check(b) == 0
+            fid = int(P.Packet(a).hdr["frame_id"])
+            seen[fid] = seen.get(fid, 0) + 1
+            if b[4] == 5:
+                assert b == backend.packet_compact(a)
+                n5 += 1
+            else:
+                assert a == b
+        multi += sum(1 for v in seen.values() if v > 1)
+    front.capture_packets(b"", compact=False)
+    assert n5 > 20 and multi > 5

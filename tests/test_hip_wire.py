@@ -166,3 +166,26 @@ def test_multi_stream_driver_in_wire_form(tmp_path):
             data = open(tmp_path / f"s{k}.yuv", "rb").read()
             assert [hashlib.md5(data[i:i + nby]).hexdigest() for i in range(0, len(data), nby)] == sums[n]["md5"], f"stream {k} ({n})"
             k += 1
+
+
+def test_concealment_in_wire_form(hipfront):
+    """tests/test_frontend_hip.py::test_concealment_on_the_gpu with the front end folding: pictures that leave in several packets (their records edited in the
+    packet before the fold) through the device expansion -- the unmodified reference's frames"""
+    from tests import damage
+    with open(os.path.join(STREAMS, "damage_md5.json")) as f:
+        sums = json.load(f)
+
+    def md5s(frames):
+        return [hashlib.md5(b"".join(p.tobytes() for p in fr)).hexdigest() for fr in frames]
+    for name, which, keep in damage.RESENT:
+        frames, codes = hipfront.decode(damage.truncated_then_resent(name, which, keep))
+        want = sums[f"{name}-{which}-{keep}"]
+        assert codes == want["nal_codes"] and md5s(frames) == want["md5"], (name, which, keep)
+    for name, which, ka, kb in damage.RESENT2:
+        frames, codes = hipfront.decode(damage.two_truncated_then_resent(name, which, ka, kb))
+        want = sums[f"{name}-{which}+{which + 1}-{ka}-{kb}"]
+        assert codes == want["nal_codes"] and md5s(frames) == want["md5"], (name, which, ka, kb)
+    for name in damage.DAMAGED_FILES:
+        frames, codes = hipfront.decode(open(os.path.join(damage.DAMAGED_DIR, name + ".264"), "rb").read())
+        want = sums[f"file-{name}"]
+        assert codes == want["nal_codes"] and md5s(frames) == want["md5"], name
