@@ -584,7 +584,10 @@ API void e264hip_frame_free(E264Stream *s, int slot)
 {
 	if (!s || slot < 0 || slot >= E264_MAX_SLOTS || !s->h_table[slot]) return;
 	set_device(s->dev);
-	// kernels and fills already queued may still read or write the slot: it is parked until the stream's latest work has retired
+	// A host batch naming this stream may be under assembly on another thread (e264_multi's submitter: it has read the stream's slot pointers for the
+	// validation and not launched yet): the free waits for that batch to be launched or refused ...
+	std::lock_guard<std::mutex> bg(s->dev->batch_lock);
+	// ... and kernels and fills already queued may still read or write the slot: it is parked until the stream's latest work has retired
 	// behind the lane's CURRENT tail (a marker of its own), not s->last_serial: a batch the submitter thread has just launched may not have
 	// published its serial to the stream yet (the block could be recycled while that batch still used it)
 	mem_release(s->dev, s->h_table[slot], s->slot_bytes[slot] + 64, false, mark_lane(s->dev, s->lane), s->lane);
