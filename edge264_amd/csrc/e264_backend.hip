@@ -373,10 +373,17 @@ API int e264hip_device_open(int ordinal, E264Device **out)
 	d->split_intra = 1;
 	d->side_queue = 0; // measured: no gain (profiles/r01k_ablation_breakdown.txt), off by default
 	for (int i = 0; i < E264Device::NQ; i++) { d->q2[i] = nullptr; d->forked[i] = d->joined[i] = nullptr; }
-	bool q2_ok = true;
-	for (int i = 0; i < E264Device::NQ && q2_ok; i++)
-		q2_ok = hipStreamCreateWithFlags(&d->q2[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&d->forked[i], hipEventDisableTiming) == hipSuccess &&
+	// The runtime deals its hardware queues (four by default, GPU_MAX_HW_QUEUES) to HIP streams in the order they are made: lane 0's second queue, the download
+	// queue and the upload queue come right after the lanes, as in every round so far; the other lanes' second queues LAST (made in front of qc / qup they pushed the
+	// download queue onto lane 0's hardware queue: one stream through edge264.h 1.03 -> 1.62 ms per picture, gpurun_out/r06f)
+	auto make_q2 = [&](int i) {
+		return hipStreamCreateWithFlags(&d->q2[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&d->forked[i], hipEventDisableTiming) == hipSuccess &&
 			hipEventCreateWithFlags(&d->joined[i], hipEventDisableTiming) == hipSuccess;
+	};
+	bool q2_ok = make_q2(0);
+	if (hipStreamCreateWithFlags(&d->qc, hipStreamNonBlocking) != hipSuccess) d->qc = nullptr; // downloads then share the lane
+	if (hipStreamCreateWithFlags(&d->qup, hipStreamNonBlocking) != hipSuccess) d->qup = nullptr; // uploads then share the lane
+	for (int i = 1; i < E264Device::NQ && q2_ok; i++) q2_ok = make_q2(i);
 	if (!q2_ok) // not fatal: the options that need a second queue then stay off
 		for (int i = 0; i < E264Device::NQ; i++) {
 			if (d->q2[i]) hipStreamDestroy(d->q2[i]);
@@ -384,8 +391,6 @@ API int e264hip_device_open(int ordinal, E264Device **out)
 			if (d->joined[i]) hipEventDestroy(d->joined[i]);
 			d->q2[i] = nullptr; d->forked[i] = d->joined[i] = nullptr;
 		}
-	if (hipStreamCreateWithFlags(&d->qc, hipStreamNonBlocking) != hipSuccess) d->qc = nullptr; // downloads then share the lane
-	if (hipStreamCreateWithFlags(&d->qup, hipStreamNonBlocking) != hipSuccess) d->qup = nullptr; // uploads then share the lane
 	for (int i = 0; i < E264Device::NEV; i++)
 		if (hipEventCreateWithFlags(&d->sub_ev[i], E264_WAIT_EVENT) != hipSuccess) d->sub_ev[i] = nullptr;
 	*out = d;

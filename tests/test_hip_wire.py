@@ -108,16 +108,22 @@ def test_mixed_batches_and_growing_motion_sections(device):
 
 
 @pytest.fixture(scope="module")
-def hipfront():
+def _hipfront_lib():
     if not os.path.exists(FRONT):
         pytest.fail(f"{FRONT} missing: it is built in the container by `make -C oracle ref` and travels with the snapshot")
     from oracle.pyoracle import HipFront
     h = HipFront()
-    h.lib.e264front_set_sink(0)
     h.lib.e264front_set_compact.argtypes = [C.c_int]
-    h.lib.e264front_set_compact(1)
-    yield h
-    h.lib.e264front_set_compact(0)
+    return h
+
+
+@pytest.fixture
+def hipfront(_hipfront_lib):
+    """the front library on the device sink, folding (both switches are global to the library and other tests of this file move them: set per test)"""
+    _hipfront_lib.lib.e264front_set_sink(0)
+    _hipfront_lib.lib.e264front_set_compact(1)
+    yield _hipfront_lib
+    _hipfront_lib.lib.e264front_set_compact(0)
 
 
 @pytest.mark.parametrize("name", NAMES)
