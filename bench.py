@@ -390,7 +390,7 @@ def same_input_leg(dev, backend, n_streams, cpu):
         k4, l4 = dev.kernel_time_ms()
         dev.kernel_timing(False)
         hbs = [dev.prepare_host_batch(sts, [packets[f]] * n_streams) for f in range(len(packets))]
-        for hb in hbs[:2]:
+        for hb in hbs + hbs[:4]:  # a whole pass and four more (untimed): every slot of the back end's batch ring has seen the largest batch -- its staging buffers have grown -- before the clock starts
             dev.submit_host_prepared(hb, backend.RUN_ALL)
         dev.sync()
         t0 = time.perf_counter()
@@ -405,7 +405,7 @@ def same_input_leg(dev, backend, n_streams, cpu):
             assert backend.packet_check(p) == 0
         pins = [dev.pinned_copy(p) for p in packets]
         pbs = [dev.prepare_pinned_batch(sts, [pins[f]] * n_streams, [len(packets[f])] * n_streams) for f in range(len(packets))]
-        for pb in pbs[:2]:
+        for pb in pbs + pbs[:4]:
             dev.submit_pinned_prepared(pb, backend.RUN_ALL)
         dev.sync()
         t0 = time.perf_counter()
@@ -424,7 +424,7 @@ def same_input_leg(dev, backend, n_streams, cpu):
             assert backend.packet_check(p) == 0
         wpins = [dev.pinned_copy(p) for p in wire]
         wbs = [dev.prepare_pinned_batch(sts, [wpins[f]] * n_streams, [len(wire[f])] * n_streams) for f in range(len(wire))]
-        for pb in wbs[:2]:
+        for pb in wbs + wbs[:4]:  # (the ring slots' expansion buffers are made here)
             dev.submit_pinned_prepared(pb, backend.RUN_ALL)
         dev.sync()
         t0 = time.perf_counter()

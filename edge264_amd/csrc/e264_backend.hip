@@ -1145,7 +1145,7 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 	if (!dev || !streams || !packets || !bytes || n <= 0) return fail(EINVAL, "submit_batch_host arguments");
 	if (set_device(dev)) return EIO;
 	std::vector<int> mbs_of((size_t)n), tiles_of((size_t)n), rc((size_t)n, 0), dst_of((size_t)n);
-	std::vector<char> l1_of((size_t)n, 1), pw_of((size_t)n, 1); // (trusted packets are not walked here: assumed to use list 1 and to hold prediction work)
+	std::vector<char> l1_of((size_t)n, 1), pw_of((size_t)n, 1); // (trusted packets are not walked here: assumed to use list 1; prediction work: see below)
 	std::vector<std::string> why((size_t)n);
 	for (int i = 0; i < n; i++) {
 		if (!streams[i] || streams[i]->dev != dev) return fail(EINVAL, "batch entry");
@@ -1216,6 +1216,16 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 			E264Stream *s = streams[i];
 			bool l1 = true, pw = true;
 			int r = trusted ? check_slots_of(s, (const E264FrameHdr *)packets[i]) : check_packet_deep(packets[i], bytes[i], s->h_table, s->slot_bytes, nullptr, &pw, &l1);
+			if (trusted && !r) {
+				// the producer has vetted the packet (its header summarises its records): a picture without inter macroblocks has prediction work only if one
+				// of its macroblocks is I_PCM -- one byte per record of a version-4 packet (a picture without inter macroblocks is never folded)
+				const E264FrameHdr *h = (const E264FrameHdr *)packets[i];
+				if (h->n_inter_mbs == 0 && h->version == E264_VERSION) {
+					const uint8_t *k = (const uint8_t *)packets[i] + h->mbs_off;
+					pw = false;
+					for (int a = 0; a < mbs_of[i] && !pw; a++) pw = k[(size_t)a * sizeof(E264Mb)] == E264_MB_PCM;
+				}
+			}
 			l1_of[i] = l1; pw_of[i] = pw;
 			if (r) { rc[i] = r; why[i] = g_err; return; } // the message lives in the worker's thread-local buffer
 			if (stage) memcpy(jr.ph + off_of[i], packets[i], bytes[i]);

@@ -27,7 +27,7 @@ def streams(n, w, h, **kw):
     return [_gop(synth.StreamSynth(w, h, seed=300 + i, **kw), GOPS[i % len(GOPS)]) for i in range(n)]
 
 
-@pytest.mark.parametrize("how", ["resident", "host", "pinned_untrusted"])
+@pytest.mark.parametrize("how", ["resident", "host", "pinned", "pinned_untrusted"])
 def test_mixed_submissions(device, how, oracle):
     per_stream = streams(11, 20, 6, num_refs=2, intra_in_inter=0.2, t8x8=True)
     device.set_option("split_intra", 1)
@@ -43,6 +43,18 @@ def test_mixed_submissions(device, how, oracle):
         for i, pkt in enumerate(per_stream[k]):
             oracle.decode_frame(pkt, dpb, 3)
             assert hashlib.md5(dpb[int(P.Packet(pkt).hdr["dst_slot"])][:nb].tobytes()).hexdigest() == got[k][i], (k, i)
+
+
+@pytest.mark.parametrize("how", ["resident", "pinned"])
+def test_mixed_submissions_with_pcm(device, how):
+    """I pictures WITH I_PCM macroblocks have work for the prediction kernel and stay with the others; those without are split off -- both kinds in one batch"""
+    per_stream = [_gop(synth.StreamSynth(9, 5, seed=500 + i, pcm_prob=0.3 if i & 1 else 0.0, intra_in_inter=0.2), GOPS[i % len(GOPS)]) for i in range(9)]
+    device.set_option("split_intra", 1)
+    got = run(device, per_stream, how)
+    device.set_option("split_intra", 0)
+    assert got == run(device, per_stream, how)
+    device.set_option("split_intra", 1)
+    assert got == [run(device, [ps], "single")[0] for ps in per_stream]
 
 
 def test_mixed_submissions_on_two_lanes(device):
