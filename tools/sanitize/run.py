@@ -63,7 +63,10 @@ def main():
     ap.add_argument("--flips", type=int, default=3, help="corrupted variants per fixture")
     ap.add_argument("--out", default=None)
     ap.add_argument("--no-tsan", action="store_true", help="skip the ThreadSanitizer leg (e264_multi --parse-only)")
+    ap.add_argument("--compact", action="store_true", help="the front end folds its packets (E264_FRONT_COMPACT=1: the wire form, include/edge264_compact.h)")
     args = ap.parse_args()
+    if args.compact:
+        os.environ["E264_FRONT_COMPACT"] = "1"
     subprocess.run(["make", "-C", HERE], check=True, stdout=subprocess.DEVNULL)
     exe, lib = os.path.join(HERE, "hostprof_san"), os.path.join(HERE, "libedge264_hipfront_san.so")
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:halt_on_error=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=0")
