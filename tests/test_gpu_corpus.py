@@ -34,10 +34,22 @@ def test_corpus_sample_is_well_formed():
 
 
 @pytest.mark.gpu
-def test_corpus_sample_on_the_hip_sink():
+@pytest.mark.parametrize("wire", [0, 1], ids=["version4", "wire"])
+def test_corpus_sample_on_the_hip_sink(wire):
+    """wire = 1 (round 6): the front end folds its packets (include/edge264_compact.h) and the device unfolds them -- the same answers"""
+    import ctypes as C
     from oracle.pyoracle import HipFront  # (test infrastructure: the ctypes binding of the edge264.h API; no oracle code runs here)
     h = HipFront()
     h.lib.e264front_set_sink(0)
+    h.lib.e264front_set_compact.argtypes = [C.c_int]
+    h.lib.e264front_set_compact(wire)
+    try:
+        _run_corpus(h)
+    finally:
+        h.lib.e264front_set_compact(0)
+
+
+def _run_corpus(h):
     z, index = load()
     bad, pics = [], 0
     for c in index:
