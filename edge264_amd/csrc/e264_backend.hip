@@ -67,11 +67,11 @@ struct HostPool {
 	std::condition_variable cv, done_cv;
 	const std::function<void(int)> *fn = nullptr;
 	std::atomic<int> next{0};
-	int n = 0, active = 0;
+	int n = 0, active = 0, limit = 0;
 	uint64_t gen = 0;
 	bool stop = false, started = false;
 	void run() { for (int i; (i = next.fetch_add(1)) < n;) (*fn)(i); }
-	void worker()
+	void worker(int id)
 	{
 		uint64_t seen = 0;
 		std::unique_lock<std::mutex> lk(m);
@@ -79,23 +79,28 @@ struct HostPool {
 			cv.wait(lk, [&] { return stop || gen != seen; });
 			if (stop) return;
 			seen = gen;
+			const bool mine = id < limit; // (a job may ask for fewer workers than the pool has)
 			lk.unlock();
-			run();
+			if (mine) run();
 			lk.lock();
 			if (--active == 0) done_cv.notify_one();
 		}
 	}
-	void parallel_for(int count, const std::function<void(int)> &f)
+	// max_workers: pool threads that take part beside the caller (0: all).  Items that only copy (a trusted batch's gather into the staging buffer) are bound by
+	// memory, not by cores: with all fifteen workers such batches ran at 82 - 96 k frames/s and unevenly, with eight at 109 - 111 k (four: too few when every
+	// stream's buffer is cold; tools/pin_probe.py, profiles/r06_ablations.txt item 17)
+	void parallel_for(int count, const std::function<void(int)> &f, int max_workers = 0)
 	{
 		std::unique_lock<std::mutex> lk(m);
 		if (!started) {
 			started = true;
 			const char *e = getenv("E264_HOST_THREADS");
 			int want = e ? atoi(e) : (int)std::min(15u, std::thread::hardware_concurrency() / 2);
-			for (int i = 0; i < want; i++) th.emplace_back([this] { worker(); });
+			for (int i = 0; i < want; i++) th.emplace_back([this, i] { worker(i); });
 		}
 		if (th.empty() || count < 4) { lk.unlock(); for (int i = 0; i < count; i++) f(i); return; }
 		fn = &f; n = count; next = 0; active = (int)th.size(); gen++;
+		limit = max_workers > 0 ? max_workers : (int)th.size();
 		lk.unlock();
 		cv.notify_all();
 		run(); // the caller works too
@@ -123,6 +128,7 @@ struct E264Packet {
 	bool has_l1;           // some macroblock predicts from list 1 (else the parameter kernel's small form will do)
 };
 
+#define E264_GATHER_WORKERS 8 // pool threads that gather a trusted batch into its staging buffer (copy only: see HostPool::parallel_for; E264_GATHER_THREADS overrides)
 #define E264_JOB_RING 4 // batches in flight per device: one uploading, one in the kernels, one retiring
 struct E264Device {
 	int ordinal;
@@ -1136,6 +1142,11 @@ API void e264hip_host_free(E264Device *dev, void *p)
 {
 	if (dev && p && !set_device(dev)) hipHostFree(p);
 }
+static int gather_workers()
+{
+	static const int v = [] { const char *e = getenv("E264_GATHER_THREADS"); return e ? atoi(e) : E264_GATHER_WORKERS; }();
+	return v;
+}
 static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const void *const *packets, const size_t *bytes, int n, int mode, int flags)
 {
 	const bool pinned = flags & 1, trusted = flags & 2;
@@ -1229,7 +1240,7 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 			l1_of[i] = l1; pw_of[i] = pw;
 			if (r) { rc[i] = r; why[i] = g_err; return; } // the message lives in the worker's thread-local buffer
 			if (stage) memcpy(jr.ph + off_of[i], packets[i], bytes[i]);
-		});
+		}, trusted ? gather_workers() : 0);
 	}
 	for (int i = 0; i < n; i++)
 		if (rc[i]) return fail(rc[i], why[i].c_str());
