@@ -87,8 +87,8 @@ struct HostPool {
 		}
 	}
 	// max_workers: pool threads that take part beside the caller (0: all).  Items that only copy (a trusted batch's gather into the staging buffer) are bound by
-	// memory, not by cores: with all fifteen workers such batches ran at 82 - 96 k frames/s and unevenly, with eight at 109 - 111 k (four: too few when every
-	// stream's buffer is cold; tools/pin_probe.py, profiles/r06_ablations.txt item 17)
+	// memory, not by cores: one buffer per stream (what a front end leaves) 106 / 109 / 108 k frames/s with 8 / 12 / 15 workers, four too few (66.7 k on one box);
+	// tools/pin_probe.py, profiles/r06_ablations.txt item 17
 	void parallel_for(int count, const std::function<void(int)> &f, int max_workers = 0)
 	{
 		std::unique_lock<std::mutex> lk(m);
@@ -128,7 +128,7 @@ struct E264Packet {
 	bool has_l1;           // some macroblock predicts from list 1 (else the parameter kernel's small form will do)
 };
 
-#define E264_GATHER_WORKERS 8 // pool threads that gather a trusted batch into its staging buffer (copy only: see HostPool::parallel_for; E264_GATHER_THREADS overrides)
+#define E264_GATHER_WORKERS 12 // pool threads that gather a trusted batch into its staging buffer (copy only: see HostPool::parallel_for; E264_GATHER_THREADS overrides)
 #define E264_JOB_RING 4 // batches in flight per device: one uploading, one in the kernels, one retiring
 struct E264Device {
 	int ordinal;
@@ -1142,6 +1142,48 @@ API void e264hip_host_free(E264Device *dev, void *p)
 {
 	if (dev && p && !set_device(dev)) hipHostFree(p);
 }
+// What the launcher wants to know about a packet its producer has vetted (E264_SUBMIT_TRUSTED: the header summarises the records, the records are sound) without the
+// per-macroblock walk: does any macroblock have work for the prediction kernel (inter, I_PCM), does any predict from list 1 (else the parameter kernel's small form
+// will do)?  One byte / one dword per record: ~10 us per 1080p packet, on the thread that gathers it.
+static void scan_trusted(const void *packet, int n_mbs, bool *pred_work, bool *has_l1)
+{
+	const E264FrameHdr *h = (const E264FrameHdr *)packet;
+	const uint8_t *p = (const uint8_t *)packet;
+	*pred_work = true; *has_l1 = true;
+	if (h->version == E264_VERSION) {
+		const uint8_t *rec = p + h->mbs_off;
+		bool pw = h->n_inter_mbs != 0, l1 = false;
+		for (int a = 0; a < n_mbs && !(pw && l1); a++, rec += sizeof(E264Mb)) {
+			if (rec[0] == E264_MB_PCM) pw = true;
+			else if (rec[0] == E264_MB_INTER) {
+				uint32_t mh;
+				memcpy(&mh, rec + offsetof(E264Mb, modes) + 4, 4);
+				if (E264_MOT_UNI(mh, 1) || (mh >> 4 & 15u)) l1 = true;
+			}
+			if (!h->n_inter_mbs && pw) break; // (no inter macroblock: nothing more to learn)
+		}
+		*pred_work = pw; *has_l1 = l1;
+	} else if (h->version == E264_VERSION_COMPACT) { // (folded: it has inter macroblocks; its structure was checked by check_packet)
+		const E264CompactHdr *ch = (const E264CompactHdr *)(p + h->mbs_off);
+		if (ch->n_both) return;
+		const uint32_t wm = h->width_mbs, hm = h->height_mbs, wpr = ch->words_per_row;
+		const uint32_t *cbits = (const uint32_t *)(p + h->mbs_off + 16) + 3 * hm;
+		const uint8_t *e = p + h->mbs_off + e264_compact_table_bytes(wm, hm);
+		bool l1 = false;
+		for (uint32_t y = 0; y < hm && !l1; y++)
+			for (uint32_t x = 0; x < wm && !l1; x++) {
+				if (cbits[y * wpr + (x >> 5)] >> (x & 31) & 1u) { l1 = e[0] & E264_MBCF_LIST1; e += 12; continue; } // (no two-list entry: n_both == 0)
+				if (e[0] == E264_MB_INTER) {
+					uint32_t mh;
+					memcpy(&mh, e + offsetof(E264Mb, modes) + 4, 4);
+					l1 = E264_MOT_UNI(mh, 1) || (mh >> 4 & 15u);
+				}
+				e += 32;
+			}
+		*has_l1 = l1;
+	}
+}
+
 static int gather_workers()
 {
 	static const int v = [] { const char *e = getenv("E264_GATHER_THREADS"); return e ? atoi(e) : E264_GATHER_WORKERS; }();
@@ -1156,7 +1198,7 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 	if (!dev || !streams || !packets || !bytes || n <= 0) return fail(EINVAL, "submit_batch_host arguments");
 	if (set_device(dev)) return EIO;
 	std::vector<int> mbs_of((size_t)n), tiles_of((size_t)n), rc((size_t)n, 0), dst_of((size_t)n);
-	std::vector<char> l1_of((size_t)n, 1), pw_of((size_t)n, 1); // (trusted packets are not walked here: assumed to use list 1; prediction work: see below)
+	std::vector<char> l1_of((size_t)n, 1), pw_of((size_t)n, 1); // (trusted packets are not walked here: scan_trusted)
 	std::vector<std::string> why((size_t)n);
 	for (int i = 0; i < n; i++) {
 		if (!streams[i] || streams[i]->dev != dev) return fail(EINVAL, "batch entry");
@@ -1227,16 +1269,7 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 			E264Stream *s = streams[i];
 			bool l1 = true, pw = true;
 			int r = trusted ? check_slots_of(s, (const E264FrameHdr *)packets[i]) : check_packet_deep(packets[i], bytes[i], s->h_table, s->slot_bytes, nullptr, &pw, &l1);
-			if (trusted && !r) {
-				// the producer has vetted the packet (its header summarises its records): a picture without inter macroblocks has prediction work only if one
-				// of its macroblocks is I_PCM -- one byte per record of a version-4 packet (a picture without inter macroblocks is never folded)
-				const E264FrameHdr *h = (const E264FrameHdr *)packets[i];
-				if (h->n_inter_mbs == 0 && h->version == E264_VERSION) {
-					const uint8_t *k = (const uint8_t *)packets[i] + h->mbs_off;
-					pw = false;
-					for (int a = 0; a < mbs_of[i] && !pw; a++) pw = k[(size_t)a * sizeof(E264Mb)] == E264_MB_PCM;
-				}
-			}
+			if (trusted && !r) scan_trusted(packets[i], mbs_of[i], &pw, &l1);
 			l1_of[i] = l1; pw_of[i] = pw;
 			if (r) { rc[i] = r; why[i] = g_err; return; } // the message lives in the worker's thread-local buffer
 			if (stage) memcpy(jr.ph + off_of[i], packets[i], bytes[i]);
