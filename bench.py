@@ -401,12 +401,14 @@ def same_input_leg(dev, backend, n_streams, cpu):
         dev.sync()
         t_host = (time.perf_counter() - t0) / REP
         # the front end's own road: packets that already sit in page-locked memory, validated by their producer (here: backend.packet_check once),
-        # gathered into the batch's staging buffer and copied in ONE transfer -- no per-macroblock walk inside the clock (one buffer per picture,
-        # read by every stream: 256 page-locked copies of a 30-picture file would be 4 GB)
+        # gathered into the batch's staging buffer and copied in ONE transfer -- no per-macroblock walk inside the clock.  One buffer per stream and
+        # picture, as 256 decoders leave them (3.6 GB per file; until round 6 one buffer per picture was read by every stream: sixteen threads gathering the
+        # same lines 256 times read 82 - 111 k from box to box, profiles/r06_ablations.txt item 17)
         for p in packets:
             assert backend.packet_check(p) == 0
-        pins = [dev.pinned_copy(p) for p in packets]
-        pbs = [dev.prepare_pinned_batch(sts, [pins[f]] * n_streams, [len(packets[f])] * n_streams) for f in range(len(packets))]
+        spins = [[dev.pinned_copy(p) for p in packets] for _ in range(n_streams)]
+        pins = [pp for row in spins for pp in row]
+        pbs = [dev.prepare_pinned_batch(sts, [spins[k][f] for k in range(n_streams)], [len(packets[f])] * n_streams) for f in range(len(packets))]
         for pb in pbs + pbs[:4]:
             dev.submit_pinned_prepared(pb, backend.RUN_ALL)
         dev.sync()
@@ -425,8 +427,9 @@ def same_input_leg(dev, backend, n_streams, cpu):
         assert len(wire) == len(packets)
         for p in wire:
             assert backend.packet_check(p) == 0
-        wpins = [dev.pinned_copy(p) for p in wire]
-        wbs = [dev.prepare_pinned_batch(sts, [wpins[f]] * n_streams, [len(wire[f])] * n_streams) for f in range(len(wire))]
+        wspins = [[dev.pinned_copy(p) for p in wire] for _ in range(n_streams)]
+        wpins = [pp for row in wspins for pp in row]
+        wbs = [dev.prepare_pinned_batch(sts, [wspins[k][f] for k in range(n_streams)], [len(wire[f])] * n_streams) for f in range(len(wire))]
         for pb in wbs + wbs[:4]:  # (the ring slots' expansion buffers are made here)
             dev.submit_pinned_prepared(pb, backend.RUN_ALL)
         dev.sync()
