@@ -1303,7 +1303,7 @@ static int submit_host_impl(E264Device *dev, E264Stream *const *streams, const v
 	bool batch_l1 = false;
 	for (int i = 0; i < n; i++) batch_l1 = batch_l1 || l1_of[i];
 	uint64_t serial = 0;
-	int r = e == hipSuccess ? launch(dev, lane, jr.d, n, max_mbs, max_tiles, (mode & E264_RUN_ALL) | (batch_l1 ? 0 : E264_RUN_NO_L1), &serial, n_back) : fail(EIO, "packet upload", e);
+	int r = e == hipSuccess ? launch(dev, lane, jr.d, n, max_mbs, max_tiles, (mode & E264_RUN_ALL) | (batch_l1 ? 0 : E264_RUN_NO_L1) | (n_back == n ? E264_RUN_NO_PRED : 0), &serial, n_back) : fail(EIO, "packet upload", e);
 	if (r && up != q) hipStreamSynchronize(up); // copies already queued must not outlive the error return unguarded
 	// the job table and the staging slots are busy until the lane has passed this point -- also on an error above: whatever
 	// part of the batch was queued still reads them
