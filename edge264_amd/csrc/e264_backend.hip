@@ -937,8 +937,8 @@ API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
 	int dst, n_mbs, n_tiles, r = check_packet(packet, bytes, &dst, &n_mbs, &n_tiles, &area);
 	if (r) return r;
 	if (!s->h_table[dst]) return fail(EINVAL, "destination slot not allocated");
-	bool has_l1 = true;
-	if ((r = check_packet_deep(packet, bytes, s->h_table, s->slot_bytes, nullptr, nullptr, &has_l1))) return r;
+	bool has_l1 = true, pred_work = true;
+	if ((r = check_packet_deep(packet, bytes, s->h_table, s->slot_bytes, nullptr, &pred_work, &has_l1))) return r;
 	if (set_device(s->dev)) return EIO;
 	if ((r = ensure_dbk(s, n_mbs)) || (r = ensure_expand(s, area))) return r;
 	E264Stream::Stage *st = &s->stage[s->stage_next];
@@ -956,7 +956,7 @@ API int e264hip_frame_submit(E264Stream *s, const void *packet, size_t bytes)
 	hipError_t e = hipMemcpyAsync(st->d, st->h, bytes, hipMemcpyHostToDevice, q);
 	if (e == hipSuccess) e = hipMemcpyAsync(st->d_job, job, sizeof(*job), hipMemcpyHostToDevice, q);
 	uint64_t serial = 0;
-	r = e == hipSuccess ? launch(s->dev, s->lane, st->d_job, 1, n_mbs, n_tiles, E264_RUN_ALL | (has_l1 ? 0 : E264_RUN_NO_L1) | (area ? E264_RUN_EXPAND : 0), &serial) : fail(EIO, "hipMemcpyAsync packet", e);
+	r = e == hipSuccess ? launch(s->dev, s->lane, st->d_job, 1, n_mbs, n_tiles, E264_RUN_ALL | (has_l1 ? 0 : E264_RUN_NO_L1) | (pred_work ? 0 : E264_RUN_NO_PRED) | (area ? E264_RUN_EXPAND : 0), &serial) : fail(EIO, "hipMemcpyAsync packet", e);
 	// whatever was queued reads the staging slot: it is busy until the lane has passed this point, error or not
 	hipEventRecord(st->done, q);
 	st->busy = true;
