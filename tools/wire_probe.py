@@ -62,13 +62,25 @@ def main():
     dpk = [[dev.upload_packet(p) for p in plain] for _ in sts]
     bs = [dev.make_batch(sts, [dpk[k][f] for k in range(n)]) for f in range(len(plain))]
     timed("resident", lambda f: dev.submit_prepared(bs[f], backend.RUN_ALL), len(plain))
+    # one page-locked buffer per stream and picture (what n decoders leave), both forms resident in host memory at once; the legs ALTERNATE so that a drift of the
+    # box shows as a drift of both
+    legs = {}
     for label, pk in (("pinned_v4", plain), ("pinned_wire", wire)):
-        pins = [dev.pinned_copy(p) for p in pk]
-        pbs = [dev.prepare_pinned_batch(sts, [pins[f]] * n, [len(pk[f])] * n) for f in range(len(pk))]
-        timed(label, lambda f: dev.submit_pinned_prepared(pbs[f], backend.RUN_ALL), len(pk))
-        out[label]["MB_per_batch"] = round(sum(len(p) for p in pk) * n / len(pk) / 1e6, 1)
-        for pp in pins:
-            dev.pinned_free(pp)
+        pins = [[dev.pinned_copy(p) for p in pk] for _ in range(n)]
+        legs[label] = (pins, [dev.prepare_pinned_batch(sts, [pins[k][f] for k in range(n)], [len(pk[f])] * n) for f in range(len(pk))], pk)
+    rounds = int(os.environ.get("E264_PROBE_ROUNDS", 3))
+    for r in range(rounds):
+        for label in ("pinned_v4", "pinned_wire"):
+            pins, pbs, pk = legs[label]
+            timed(f"{label}#{r}", lambda f: dev.submit_pinned_prepared(pbs[f], backend.RUN_ALL), len(pk))
+            out[f"{label}#{r}"]["MB_per_batch"] = round(sum(len(p) for p in pk) * n / len(pk) / 1e6, 1)
+    for label in legs:
+        v = [out[f"{label}#{r}"]["frames_per_s"] for r in range(rounds)]
+        out[label] = {"frames_per_s_rounds": v, "mean": round(sum(v) / len(v), 1), "min": min(v), "max": max(v)}
+    for pins, _, _ in legs.values():
+        for row in pins:
+            for pp in row:
+                dev.pinned_free(pp)
     print(json.dumps(out, indent=1))
 
 
