@@ -264,3 +264,30 @@ def test_front_end_folds_pictures_that_leave_in_several_packets():
         multi += sum(1 for v in seen.values() if v > 1)
     front.capture_packets(b"", compact=False)
     assert n5 > 20 and multi > 5
+
+
+@needs_front
+def test_expand_kernel_source_on_large_pictures(emu):
+    """1080p packets of an encoder-shaped stream (P and B pictures, 120 x 68 macroblocks: four bitmap words per row) and a synthetic 4096-wide picture (eight words per
+    row): the kernel's source against the host expansion, and the fold's own round trip"""
+    pe, _ = emu
+    cases = []
+    for name in ("nat1080_ipp30.264", "cabac_nat1080_ibbp30.264"):
+        pk = front.capture_packets(open(os.path.join(STREAMS, name), "rb").read())[0]
+        cases += [(name, backend.packet_compact(bytes(p))) for p in pk[1:8:3]]
+    g = synth.StreamSynth(256, 3, seed=77, p_skip=0.8, num_refs=2)
+    cases += [("wide", backend.packet_compact(bytes(g.next_frame(ft)))) for ft in "IPB"]
+    n = 0
+    for name, wire in cases:
+        if wire[4] != 5:
+            continue
+        back = backend.packet_expand(wire)
+        assert backend.packet_check(wire) == 0 and backend.packet_check(back) == 0 and backend.packet_compact(back) == wire, name
+        h = np.frombuffer(back, P.FRAME_HDR, 1)[0]
+        want = back[int(h["mbs_off"]):int(h["payload_off"])]
+        area = (C.c_uint8 * (len(want) + 64))()
+        C.memset(area, 0xA5, len(want) + 64)
+        pe.e264emu_expand(wire, area, 256 * 3)
+        assert bytes(area[:len(want)]) == want and bytes(area[len(want):]) == b"\xa5" * 64, name
+        n += 1
+    assert n >= 7
