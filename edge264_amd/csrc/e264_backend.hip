@@ -139,6 +139,8 @@ struct E264Device {
 	int waves;                 // waves per frame workgroup of the deblocking kernel (5 macroblock rows each): 2, 4, 7 or 8
 	int intra_waves;           // waves per frame workgroup of the intra kernel (1 macroblock row each)
 	std::atomic<int> max_lane{0}; // highest lane a stream was ever bound to
+	int n_cus;                 // compute units of the device
+	int split_planes;          // option "split_planes" (default 1): the split-off pictures' intra pass with luma and chroma on two workgroups (e264_intra_planes_kernel)
 	int split_intra;           // option "split_intra" (default 1): in a submission that mixes I pictures with others, their intra pass runs on q2 from the start (E264Fork.n_nopred)
 	int side_queue;            // option "side_queue": parameter kernel on a second queue beside the macroblock-parallel kernel
 	int upload_queue;          // option "upload_queue" (default 1): the H2D copies of host batches go through qup
@@ -360,6 +362,7 @@ API int e264hip_device_open(int ordinal, E264Device **out)
 	E264Device *d = new (std::nothrow) E264Device();
 	if (!d) return fail(ENOMEM, "device object");
 	d->ordinal = ordinal;
+	d->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	d->waves = 108; // round 4: e264_deblock2_kernel, 8 waves that take luma groups (8 rows) and chroma groups (15 rows) from one list: 0.99 - 1.02 ms against
 	// 1.02 - 1.03 for the mixed waves below (profiles/r04_ablations.txt item 7).  Before (waves = 8, e264_deblock_kernel): 40 macroblock rows in flight (all the LDS takes: 154 KB); since the samples are fetched four macroblocks at a time 8 waves beat
 	              // 7 (1.081 -> 1.051 ms per 256 x 1080p; round 2, one macroblock per fetch: 7 was the optimum)
@@ -376,7 +379,7 @@ API int e264hip_device_open(int ordinal, E264Device **out)
 		}
 	for (int i = 0; i < 16; i++)
 		hipEventCreate(&d->ev[i]);
-	d->split_intra = 1;
+	d->split_intra = 1; d->split_planes = 1;
 	d->side_queue = 0; // measured: no gain (profiles/r01k_ablation_breakdown.txt), off by default
 	for (int i = 0; i < E264Device::NQ; i++) { d->q2[i] = nullptr; d->forked[i] = d->joined[i] = nullptr; }
 	// The runtime deals its hardware queues (four by default, GPU_MAX_HW_QUEUES) to HIP streams in the order they are made: lane 0's second queue, the download
@@ -448,6 +451,11 @@ API void e264hip_device_close(E264Device *dev)
 API int e264hip_set_option(E264Device *dev, const char *name, int value)
 {
 	if (!dev || !name) return -1;
+	if (!strcmp(name, "split_planes")) {
+		int prev = dev->split_planes;
+		dev->split_planes = value != 0;
+		return prev;
+	}
 	if (!strcmp(name, "split_intra")) {
 		int prev = dev->split_intra;
 		dev->split_intra = value == 2 ? 2 : value != 0; // 2: also with more than two lanes in use (for runs with GPU_MAX_HW_QUEUES raised)
@@ -861,7 +869,14 @@ static int launch(E264Device *dev, int lane, const E264Job *d_jobs, int n, int m
 	// (not with more than two lanes in use: lanes and second queues then share the runtime's hardware queues -- four by default, GPU_MAX_HW_QUEUES -- and a lane's
 	// kernels wait behind another lane's 2.7-ms intra pass: 38.7 k against 52.0 k frames/s without the split, tools/stagger_probe.py, profiles/r06_ablations.txt item 16)
 	const bool split = (dev->split_intra == 2 || (dev->split_intra && dev->max_lane.load(std::memory_order_relaxed) < 2)) && dev->q2[lane] && n_nopred > 0 && n_nopred < n;
-	E264Fork fork = {dev->side_queue || split ? dev->q2[lane] : nullptr, dev->forked[lane], dev->joined[lane], nullptr, dev->side_queue, split ? n_nopred : 0};
+	// Two workgroups per picture (luma, chroma: e264_intra_planes_kernel) for the pictures whose intra pass stands alone -- while they are few: each takes a whole CU
+	// (125 KB of LDS) from the prediction kernel of the others, and with more than ~320 other pictures in the submission their kernels outlast a one-workgroup pass
+	// anyway (tools/stagger_probe.py: 256 pictures out of phase 72.4 -> 84.9 k frames/s; 512: 88.7 -> 86.9 k without this rule; profiles/r06_ablations.txt item 18)
+	const int cu_budget = dev->n_cus * 3 / 8;
+	int planes = 0;
+	if (dev->split_planes && split && 2 * n_nopred <= cu_budget && n - n_nopred <= 320) planes |= 1;
+	if (dev->split_planes && (mode & E264_RUN_NO_PRED) && 2 * n <= cu_budget) planes |= 2;
+	E264Fork fork = {dev->side_queue || split || planes ? dev->q2[lane] : nullptr, dev->forked[lane], dev->joined[lane], nullptr, dev->side_queue, split ? n_nopred : 0, planes};
 	if (dev->ktiming) {
 		if (dev->kev_used == dev->kev.size()) {
 			E264Device::Marks m;

@@ -288,6 +288,8 @@ E264_DEV void slice_cache(WaveLds &L, const FrameCtx &f, int slice, int lane)
 
 // coefs holds the macroblock's payload (coef_dma + coef_dma_wait), the slice cache is valid (slice_cache)
 // inter: the macroblock is an inter one (its own scaling lists); the intra kernel never sees one and passes a constant
+// PLANES: 1 = luma only, 2 = chroma only, 3 = both (e264_intra_planes_kernel: an I picture's luma and chroma on two workgroups)
+template <int PLANES = 3>
 E264_DEV void compute_residual(WaveLds &L, const int16_t *coefs, const FrameCtx &f, const MbInfo &m, bool inter, int lane)
 {
 	// zero the residual tile (384 int16 = 192 dwords)
@@ -307,7 +309,7 @@ E264_DEV void compute_residual(WaveLds &L, const int16_t *coefs, const FrameCtx 
 	if (!coded) return;
 
 	// DC transforms (residual.c:352-399 and :456-480): one output per lane
-	if (ldc && lane < 16) {
+	if ((PLANES & 1) && ldc && lane < 16) {
 		int r = lane >> 2, l = lane & 3, acc = 0;
 		// f[r][l] = sum_m sum_i A[r][m] A[l][i] c[4i+m], A = rows {++++, ++--, +--+, +-+-}
 #pragma unroll
@@ -323,7 +325,7 @@ E264_DEV void compute_residual(WaveLds &L, const int16_t *coefs, const FrameCtx 
 		int k = (r >> 1) * 8 + (l >> 1) * 4 + (r & 1) * 2 + (l & 1);
 		L.dc[k] = (int)((uint32_t)acc * (uint32_t)LS + 32u) >> 6;
 	}
-	if (cdc && lane >= 16 && lane < 24) {
+	if ((PLANES & 2) && cdc && lane >= 16 && lane < 24) {
 		int n = lane & 3, pc = (lane >> 2) & 1; // pc: 0 Cb, 1 Cr
 		int c0 = cdc[pc], c4 = cdc[4 + pc], c2 = cdc[2 + pc], c6 = cdc[6 + pc];
 		int v = n == 0 ? c0 + c4 + c2 + c6 : n == 1 ? c0 - c4 + c2 - c6 : n == 2 ? c0 + c4 - c2 - c6 : c0 - c4 - c2 + c6;
@@ -335,20 +337,20 @@ E264_DEV void compute_residual(WaveLds &L, const int16_t *coefs, const FrameCtx 
 
 	// luma
 	if (m.kind == E264_MB_I16x16) {
-		if (coded & (0xffff | E264_CODED_LUMA_DC))
+		if ((PLANES & 1) && (coded & (0xffff | E264_CODED_LUMA_DC)))
 			idct4x4_blocks(L, 16, coded & 0xffff, true, ldc != nullptr, co, l8, ws4, m.qp[0], 0, 0, 16, lane);
 		co += __builtin_popcount(coded & 0xffff) * 16 * lsz;
 	} else if (m.flags & E264_MBF_T8x8) {
-		if (coded & 0x1111)
+		if ((PLANES & 1) && (coded & 0x1111))
 			idct8x8_blocks(L, coded, co, l8, ws8 + (inter ? 64 : 0), m.qp[0], lane);
 		co += __builtin_popcount(coded & 0x1111) * 64 * lsz;
 	} else {
-		if (coded & 0xffff)
+		if ((PLANES & 1) && (coded & 0xffff))
 			idct4x4_blocks(L, 16, coded & 0xffff, false, false, co, l8, ws4 + (inter ? 3 : 0) * 16, m.qp[0], 0, 0, 16, lane);
 		co += __builtin_popcount(coded & 0xffff) * 16 * lsz;
 	}
 	// chroma: 8 blocks, Cb 0..3 then Cr 4..7; different QP / scaling list per plane
-	if (coded & (0xff0000 | E264_CODED_CHROMA_DC)) {
+	if ((PLANES & 2) && (coded & (0xff0000 | E264_CODED_CHROMA_DC))) {
 		int k = lane >> 2;
 		int pc = (k >> 2) & 1;
 		idct4x4_blocks(L, 8, coded >> 16 & 0xff, true, cdc != nullptr, co, l8, ws4 + (1 + pc + (inter ? 3 : 0)) * 16, pc ? m.qp[2] : m.qp[1], 16, 256, 8, lane);
@@ -621,7 +623,7 @@ E264_DEV int intra_chroma_px(const WaveLds &L, int p, int mode, int x, int y)
 #ifndef E264_INTRA_LAUNDER
 #define E264_INTRA_LAUNDER 5
 #endif
-template <int WHICH>
+template <int WHICH, int PLANES = 3>
 E264_DEV void recon_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, int mbx, int mby, int lane, const uint32_t *i4tab, const int16_t *coefs,
 	int16_t *coefs_next, const uint32_t *next_rec, MbInfo &mn PH_PARAMS)
 {
@@ -656,7 +658,7 @@ E264_DEV void recon_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, int mbx, 
 	}
 	slice_cache(L, f, m.slice, lane);
 	PH(3);
-	compute_residual(L, coefs, f, m, WHICH == 2 ? false : m.kind == E264_MB_INTER, (E264_INTRA_LAUNDER & 4) ? relane(lane) : lane);
+	compute_residual<PLANES>(L, coefs, f, m, WHICH == 2 ? false : m.kind == E264_MB_INTER, (E264_INTRA_LAUNDER & 4) ? relane(lane) : lane);
 	PH(4);
 
 	int pY[4], pC[2];
@@ -664,7 +666,9 @@ E264_DEV void recon_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, int mbx, 
 	if (WHICH != 1 && m.kind != E264_MB_INTER) {
 		commit_intra_neighbours(L, nbv, (E264_INTRA_LAUNDER & 8) ? relane(lane) : lane);
 		PH(5);
-		if (m.kind == E264_MB_I16x16) {
+		if (!(PLANES & 1)) {
+			// (chroma only: the luma samples are another workgroup's)
+		} else if (m.kind == E264_MB_I16x16) {
 			intra16x16_pred(L, m.i16_mode, X, Yr, pY);
 		} else if (m.kind == E264_MB_I4x4) { // edge264_slice.c:615-635: predict, add residual, next block
 			tile_luma = true;
@@ -716,22 +720,28 @@ E264_DEV void recon_mb(WaveLds &L, const FrameCtx &f, const MbInfo &m, int mbx, 
 			}
 		}
 		PH(6);
-		pC[0] = intra_chroma_px(L, cpl, m.chroma_mode, cx, cy);
-		pC[1] = intra_chroma_px(L, cpl, m.chroma_mode, cx + 1, cy);
+		if (PLANES & 2) {
+			pC[0] = intra_chroma_px(L, cpl, m.chroma_mode, cx, cy);
+			pC[1] = intra_chroma_px(L, cpl, m.chroma_mode, cx + 1, cy);
+		}
 	}
 	// add residual, clip, store (int16 wrap add then packus: residual.c:160-171)
-	uint32_t outw;
-	if (tile_luma) {
-		outw = *(const uint32_t *)&L.YT(Yr, X);
-	} else {
-		const int16_t *rr = L.res + Yr * 16 + X;
-		outw = (uint32_t)clip255(w16(pY[0] + rr[0])) | (uint32_t)clip255(w16(pY[1] + rr[1])) << 8 |
-			(uint32_t)clip255(w16(pY[2] + rr[2])) << 16 | (uint32_t)clip255(w16(pY[3] + rr[3])) << 24;
+	if (PLANES & 1) {
+		uint32_t outw;
+		if (tile_luma) {
+			outw = *(const uint32_t *)&L.YT(Yr, X);
+		} else {
+			const int16_t *rr = L.res + Yr * 16 + X;
+			outw = (uint32_t)clip255(w16(pY[0] + rr[0])) | (uint32_t)clip255(w16(pY[1] + rr[1])) << 8 |
+				(uint32_t)clip255(w16(pY[2] + rr[2])) << 16 | (uint32_t)clip255(w16(pY[3] + rr[3])) << 24;
+		}
+		PH(7);
+		*(gu32 *)dY = outw;
 	}
-	PH(7);
-	*(gu32 *)dY = outw;
-	const int16_t *rc = L.res + 256 + cpl * 64 + cy * 8 + cx;
-	*(gu16 *)dC = (uint16_t)(clip255(w16(pC[0] + rc[0])) | clip255(w16(pC[1] + rc[1])) << 8);
+	if (PLANES & 2) {
+		const int16_t *rc = L.res + 256 + cpl * 64 + cy * 8 + cx;
+		*(gu16 *)dC = (uint16_t)(clip255(w16(pC[0] + rc[0])) | clip255(w16(pC[1] + rc[1])) << 8);
+	}
 }
 
 // ---------------------------------------------------------------------------------
@@ -784,7 +794,7 @@ E264_DEV int intra_next_row(int *next_row, int y, int lane)
 }
 
 // what thread tid of the picture's workgroup does
-template <int NW>
+template <int NW, int PLANES = 3>
 E264_DEV void intra_kernel_body(IntraLds<NW> &S, const E264Job &job, const int tid, const bool use_bitmap = true)
 {
 	WaveLds *const lds = S.w;
@@ -893,7 +903,7 @@ E264_DEV void intra_kernel_body(IntraLds<NW> &S, const E264Job &job, const int t
 				}
 				PH(1);
 				coef_dma_wait();
-				recon_mb<2>(L, f, mi, x, y, lane, i4tab, S.coef[wave][buf], S.coef[wave][buf ^ 1], next_rec, mn PH_ARGS);
+				recon_mb<2, PLANES>(L, f, mi, x, y, lane, i4tab, S.coef[wave][buf], S.coef[wave][buf ^ 1], next_rec, mn PH_ARGS);
 				PH(8);
 #ifndef E264_ABL_INTRA_NOFENCE // timing ablation: progress published without waiting for the stores
 				E264_FENCE_RELEASE();

@@ -187,6 +187,15 @@ __global__ __launch_bounds__(NW * 64) void e264_intra_kernel(const E264Job *jobs
 	__shared__ IntraLds<NW> S;
 	intra_kernel_body<NW>(S, jobs[blockIdx.x], (int)threadIdx.x, use_bitmap != 0);
 }
+// The same pass with a picture's LUMA and CHROMA on two workgroups (blockIdx.y): intra prediction and residual of the two never meet (a chroma block predicts from
+// chroma samples only), so an I picture whose intra pass stands alone on the critical path -- a submission that mixes it with P / B pictures (E264Fork.n_nopred), one
+// stream by itself -- gets two CUs instead of one.  Sixteen waves each; no bitmap (pictures without prediction work).
+__global__ __launch_bounds__(1024) void e264_intra_planes_kernel(const E264Job *jobs)
+{
+	__shared__ IntraLds<16> S;
+	if (blockIdx.y == 0) intra_kernel_body<16, 1>(S, jobs[blockIdx.x], (int)threadIdx.x, false);
+	else intra_kernel_body<16, 2>(S, jobs[blockIdx.x], (int)threadIdx.x, false);
+}
 
 
 // In-loop deblocking: one workgroup per picture (e264_dbk.h; the phases run on the host in tests/emu).  A wave walks a GROUP of
@@ -490,7 +499,8 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 		hipEventRecord(fork->forked, stream);
 		hipStreamWaitEvent(fork->aux, fork->forked, 0);
 		if (marks) hipEventRecord(fork->amarks[0], fork->aux);
-		launch_intra(jobs + n_front, n_split, fork->aux, 0);
+		if ((fork->planes & 1) && intra_waves_ == 16) hipLaunchKernelGGL(e264_intra_planes_kernel, dim3(n_split, 2), dim3(1024), 0, fork->aux, jobs + n_front);
+		else launch_intra(jobs + n_front, n_split, fork->aux, 0);
 		if (marks) hipEventRecord(fork->amarks[1], fork->aux);
 		hipEventRecord(fork->joined, fork->aux);
 	}
@@ -523,7 +533,9 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 	if (where == 2)
 		launch_side();
 	waves &= 255;
-	if (mode & 1)
+	if ((mode & 1) && no_pred && fork && (fork->planes & 2) && intra_waves_ == 16) // a FEW pictures, all without prediction work (one stream's I picture): two CUs each
+		hipLaunchKernelGGL(e264_intra_planes_kernel, dim3(n_jobs, 2), dim3(1024), 0, stream, jobs);
+	else if (mode & 1)
 		launch_intra(jobs, n_front, stream, no_pred ? 0 : 1);
 	if (n_split) hipStreamWaitEvent(stream, fork->joined, 0);
 	if (side) hipStreamWaitEvent(stream, fork->joined, 0); // (before the mark: with the parameter kernel beside it, "intra" is the phase both share)

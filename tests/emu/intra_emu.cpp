@@ -84,9 +84,12 @@ IntraLds<1> g_lds;
 static uint8_t *g_expand; // expansion buffer of a wire packet (include/edge264_compact.h), filled by the caller (pred_emu's e264emu_expand); NULL for version 4
 extern "C" __attribute__((visibility("default"))) void e264emu_set_expand(uint8_t *area) { g_expand = area; }
 const E264Job *g_job;
+int g_planes = 3; // 3: e264_intra_kernel; 1 / 2: one workgroup of e264_intra_planes_kernel (luma / chroma)
 void fibre_main(int lane)
 {
-	intra_kernel_body<1>(g_lds, *g_job, lane);
+	if (g_planes == 1) intra_kernel_body<1, 1>(g_lds, *g_job, lane);
+	else if (g_planes == 2) intra_kernel_body<1, 2>(g_lds, *g_job, lane);
+	else intra_kernel_body<1>(g_lds, *g_job, lane);
 	g_done[lane] = true;
 	g_alive--;
 	if (g_alive > 0 && g_arrived == g_alive) { g_arrived = 0; g_gen++; } // (never the case: the lanes of a wave leave the kernel together)
@@ -128,4 +131,15 @@ extern "C" __attribute__((visibility("default"))) int e264emu_intra_frame2(const
 	g_cur = 0;
 	swapcontext(&g_main, &g_ctx[0]);
 	return 0;
+}
+
+// e264_intra_planes_kernel on one picture: its two workgroups one after the other -- chroma FIRST, so that a chroma sample that needed a luma one (none may) would find it missing
+extern "C" __attribute__((visibility("default"))) int e264emu_intra_frame_planes(const uint8_t *pkt, uint8_t *const *dpb)
+{
+	g_planes = 2;
+	int r = e264emu_intra_frame2(pkt, dpb, nullptr);
+	g_planes = 1;
+	if (!r) r = e264emu_intra_frame2(pkt, dpb, nullptr);
+	g_planes = 3;
+	return r;
 }

@@ -32,6 +32,9 @@ def test_mixed_submissions(device, how, oracle):
     per_stream = streams(11, 20, 6, num_refs=2, intra_in_inter=0.2, t8x8=True)
     device.set_option("split_intra", 1)
     got = run(device, per_stream, how)
+    device.set_option("split_planes", 0)  # the split-off pictures' intra pass on one workgroup instead of two (luma, chroma)
+    assert got == run(device, per_stream, how)
+    device.set_option("split_planes", 1)
     device.set_option("split_intra", 0)
     assert got == run(device, per_stream, how)
     device.set_option("split_intra", 1)

@@ -23,7 +23,8 @@ def emu():
     ilib = C.CDLL(os.path.join(d, "libe264_intra_emu.so"))
     lib.e264emu_intra_frame = ilib.e264emu_intra_frame
     lib.e264emu_intra_frame2 = ilib.e264emu_intra_frame2
-    for fn in (lib.e264emu_pred_frame, lib.e264emu_intra_frame):
+    lib.e264emu_intra_frame_planes = ilib.e264emu_intra_frame_planes
+    for fn in (lib.e264emu_pred_frame, lib.e264emu_intra_frame, lib.e264emu_intra_frame_planes):
         fn.argtypes = [C.c_char_p, C.c_void_p]
         fn.restype = C.c_int
     for fn in (lib.e264emu_pred_frame2, lib.e264emu_intra_frame2):
@@ -67,11 +68,14 @@ def _synth(w, h, seed, kw):
     return g
 
 
-@pytest.mark.parametrize("bitmap", [False, True], ids=["scan", "bitmap"])
+@pytest.mark.parametrize("bitmap", [False, True, "planes"], ids=["scan", "bitmap", "planes"])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_intra_emu_vs_oracle(emu, name, bitmap):
     """bitmap: the prediction kernel leaves the intra bitmap in the stream's scratch and the intra kernel skips by it (what a submission does on
-    the device); scan: no scratch, every chunk of every row is scanned (the fallback)"""
+    the device); scan: no scratch, every chunk of every row is scanned (the fallback); planes: e264_intra_planes_kernel -- the picture's chroma by one
+    workgroup, then its luma by another (the launcher's form for I pictures split off a mixed submission)"""
+    planes = bitmap == "planes"
+    bitmap = bitmap is True
     c = CASES[name]
     w, h = c["w"], c["h"]
     scratch = np.full(scratch_bytes(w * h), 0xFF if bitmap else 0, np.uint8)  # (stale ones: the kernel must overwrite every entry it reads)
@@ -98,7 +102,7 @@ def test_intra_emu_vs_oracle(emu, name, bitmap):
                 assert np.array_equal(got_bits, want), f"{name} frame {ft}: intra bitmap differs"
             else:
                 assert emu.e264emu_pred_frame(pkt, _dpb_array(mine)) == 0
-                assert emu.e264emu_intra_frame(pkt, _dpb_array(mine)) == 0
+                assert (emu.e264emu_intra_frame_planes if planes else emu.e264emu_intra_frame)(pkt, _dpb_array(mine)) == 0
             sY = w * 16
             got_y = mine[d][:sY * h * 16].reshape(h * 16, sY)
             exp_y = dpb[d][:sY * h * 16].reshape(h * 16, sY)

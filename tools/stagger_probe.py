@@ -44,9 +44,13 @@ def main():
         dpk.append([dev.upload_packet(p) for p in vpk[k % V]])
     groups = [list(range(g, n, lanes)) for g in range(lanes)]
     out = {"streams": n, "lanes": lanes, "gop": gop}
-    for label, phase, split in (("in_phase", lambda k: 0, 1), ("staggered_lockstep", lambda k: (k // lanes) % G, 0), ("staggered", lambda k: (k // lanes) % G, 1),
-                                ("two_phases_lockstep", lambda k: ((k // lanes) % 2) * (G // 2), 0), ("two_phases", lambda k: ((k // lanes) % 2) * (G // 2), 1)):
-        dev.set_option("split_intra", split)  # 1 (the default): the I pictures' intra pass on the second queue from the start of a mixed submission
+    for label, phase, split, planes in (("in_phase", lambda k: 0, 1, 1), ("staggered_lockstep", lambda k: (k // lanes) % G, 0, 0),
+                                        ("staggered_one_workgroup", lambda k: (k // lanes) % G, 1, 0), ("staggered", lambda k: (k // lanes) % G, 1, 1),
+                                        ("two_phases_lockstep", lambda k: ((k // lanes) % 2) * (G // 2), 0, 0), ("two_phases", lambda k: ((k // lanes) % 2) * (G // 2), 1, 1)):
+        # split_intra 1 (the default): the I pictures' intra pass on the second queue from the start of a mixed submission; split_planes 1 (the default): their luma
+        # and chroma on two workgroups (e264_intra_planes_kernel)
+        dev.set_option("split_intra", split)
+        dev.set_option("split_planes", planes)
         bs = [[dev.make_batch([sts[k] for k in idx], [dpk[k][(f + phase(k)) % G] for k in idx]) for idx in groups] for f in range(G)]
         for f in range(G):
             for b in bs[f]:
