@@ -27,7 +27,7 @@ struct E264Job {
 // max_mbs: largest macroblock count among the jobs; max_tiles: largest e264_pred_tiles() among the jobs.  marks: NULL or 5 events (boundaries of the 4 kernels).
 // fork: NULL, or a second queue + events on which the parameter kernel runs beside the macroblock-parallel kernel
 // (amarks: 2 events bracketing it there, recorded when marks != NULL).
-struct E264Fork { hipStream_t aux; hipEvent_t forked, joined; hipEvent_t *amarks; int where; int n_nopred; int planes; }; // planes: bit 0 = e264_intra_planes_kernel for the split-off pictures, bit 1 = for an all-intra batch (E264_RUN_NO_PRED): the back end's call (few enough pictures for two CUs each) // where: 1 = beside the prediction kernel, 2 = beside the intra kernel
+struct E264Fork { hipStream_t aux; hipEvent_t forked, joined; hipEvent_t *amarks; int where; int n_nopred; int planes; }; // planes: bit 0 = e264_intra_planes_kernel for the split-off pictures, bit 1 = for an all-intra batch (E264_RUN_NO_PRED), bit 2 = e264_deblock2_planes_kernel for the whole batch: the back end's calls (few enough pictures for two CUs each) // where: 1 = beside the prediction kernel, 2 = beside the intra kernel
 // n_nopred (round 6): the LAST n_nopred jobs of the table hold no inter / PCM macroblock (I pictures: known from their validation).  In a submission that
 // mixes them with P / B pictures -- streams whose GOPs are not in phase -- their intra pass (one workgroup per picture, 2.7 ms for a 1080p I picture) runs on
 // `aux` from the start of the submission, beside the parameter and prediction kernels of the others, and deblocking waits for both:

@@ -378,6 +378,37 @@ __global__ __launch_bounds__(NW * 64) void e264_deblock2_kernel(const E264Job *j
 	}
 }
 
+// The same walk with a picture's luma groups on one workgroup and its chroma groups on another (blockIdx.y): the two chains never meet (separate samples, the same
+// read-only parameters), so a picture that has the device to itself -- one stream, a small batch -- gets two CUs for the kernel that is most of its latency
+// (one workgroup per picture: 0.9 ms of a P picture's 0.9).  The back end's call (E264Fork.planes bit 2: few pictures).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void e264_deblock2_planes_kernel(const E264Job *jobs)
+{
+	__shared__ DkWaveAny lds[NW];
+	__shared__ int progress[(E264_MAX_ROWS + DK_ROWS_OF(0) - 1) / DK_ROWS_OF(0)]; // (the longer of the two chains: luma groups are the shorter ones)
+	__shared__ int next_task;
+	const int lane = lane_id();
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	FrameCtx f;
+	if (!open_frame(f, jobs[blockIdx.x]) || !f.dbk)
+		return;
+	const bool chroma = blockIdx.y != 0;
+	const int n = chroma ? (f.hm + DK_ROWS_OF(1) - 1) / DK_ROWS_OF(1) : (f.hm + DK_ROWS_OF(0) - 1) / DK_ROWS_OF(0);
+	for (int i = threadIdx.x; i < n; i += NW * 64) progress[i] = 0;
+	if (threadIdx.x == 0) next_task = 0;
+	__syncthreads();
+#pragma unroll 1
+	for (;;) {
+		int task = 0;
+		if (lane == 0) task = atomicAdd(&next_task, 1);
+		task = __builtin_amdgcn_readfirstlane(task);
+		if (task >= n)
+			break;
+		if (chroma) dk_walk_group<1>(lds[wave].c, f, progress, task, lane, 32 + task);
+		else dk_walk_group<0>(lds[wave].l, f, progress, task, lane, task);
+	}
+}
+
 // Build-time switches this code object was compiled with, as a space-separated list ("" = the product build).  The timing
 // ablations (E264_ABL_*, E264_PHASE_*) produce WRONG SAMPLES on purpose: a library that reports one is refused by every loader
 // (e264hip_device_open, edge264_amd/backend.py, the front end) unless E264_ALLOW_ABLATION=1 is set -- the A/B tooling sets it.
@@ -540,7 +571,9 @@ extern "C" hipError_t e264_launch_frames(const E264Job *jobs, int n_jobs, int ma
 	if (n_split) hipStreamWaitEvent(stream, fork->joined, 0);
 	if (side) hipStreamWaitEvent(stream, fork->joined, 0); // (before the mark: with the parameter kernel beside it, "intra" is the phase both share)
 	if (marks) hipEventRecord(marks[3], stream);
-	if (mode & 2) {
+	if ((mode & 2) && waves == 108 && fork && (fork->planes & 4)) // few pictures: two workgroups each (luma groups, chroma groups)
+		hipLaunchKernelGGL(e264_deblock2_planes_kernel<8>, dim3(n_jobs, 2), dim3(512), 0, stream, jobs);
+	else if (mode & 2) {
 		switch (waves) { // waves per picture (default 8, set by the back end); 100 + n: luma / chroma waves (e264_deblock2_kernel)
 #if E264_DBK_GS == 2 // strips of four macroblocks: 12.6 KB of LDS per wave, twelve waves (three per SIMD) fit the CU
 		case 112: hipLaunchKernelGGL(e264_deblock2_kernel<12>, dim3(n_jobs), dim3(768), 0, stream, jobs); break;
