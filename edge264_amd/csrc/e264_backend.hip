@@ -878,7 +878,7 @@ static int launch(E264Device *dev, int lane, const E264Job *d_jobs, int n, int m
 	// ... a kernel that has the lane to itself (an all-intra batch's intra pass, every batch's deblocking) may take every CU: 64 streams 38.2 -> 42.8 k frames/s,
 	// 128 streams 61.6 -> 69.8 k (gpurun_out/pa1; E264_PLANES_ALONE overrides for A/B)
 	static const int alone_env = getenv("E264_PLANES_ALONE") ? atoi(getenv("E264_PLANES_ALONE")) : 0;
-	const int cu_alone = alone_env > 0 ? alone_env : dev->n_cus;
+	const int cu_alone = alone_env > 0 ? alone_env : dev->n_cus / (dev->max_lane.load(std::memory_order_relaxed) + 1); // (the lanes in use run beside each other: a lane's share)
 	if (dev->split_planes && (mode & E264_RUN_NO_PRED) && 2 * n <= cu_alone) planes |= 2;
 	if (dev->split_planes && 2 * n <= cu_alone) planes |= 4; // ... and the deblocking kernel's luma and chroma groups (one stream: a P picture 0.89 ms, of which that kernel is most)
 	E264Fork fork = {dev->side_queue || split || planes ? dev->q2[lane] : nullptr, dev->forked[lane], dev->joined[lane], nullptr, dev->side_queue, split ? n_nopred : 0, planes};
